@@ -1,0 +1,360 @@
+// oracle/ref_harness.cpp -- TEST INFRASTRUCTURE, not product code.
+//
+// A small driver (our code) that links the REFERENCE's own translation units
+// (compiled in place from /root/reference by oracle/Makefile.ref into
+// oracle/_ref/) and runs the prefilter+align hot path through the
+// reference's classes exactly as its own drivers do:
+//   * prefilter loop  = lib/mmseqs/src/prefiltering/Prefiltering.cpp:60-72,
+//     192-218,514-553 (matrices, k-mer threshold, index build) and :790-887
+//     (per-query QueryMatcher::matchQuery + hit formatting);
+//   * align loop      = lib/mmseqs/src/alignment/Alignment.cpp:152-154,263,
+//     279-514 (Matcher::initQuery / getSWResult / checkCriteria / compareHits
+//     / resultToBuffer).
+// The reference's Parameters singleton, workflows and DB writers are NOT
+// built (they need cmake-generated headers); the loops above are restated
+// here with the reference's defaults for `metaeuk predictexons`
+// (SURVEY.md section 3.2 argv).  Everything arithmetic is the reference's
+// compiled code.
+//
+// Modes:
+//   ref_harness pipeline <matdir> <targets.txt> <queries.txt> <outdir> [-s 5.7] [--threads N] [--dump]
+//   ref_harness sw       <matdir> <targets.txt> <queries.txt> <pairs.txt> <out.txt> [--dbres N]
+//   ref_harness submat   <matfile.out> <bitFactor> <bias>
+// Sequence files: one amino-acid sequence per line; key = 0-based line number.
+#include "SubstitutionMatrix.h"
+#include "ExtendedSubstitutionMatrix.h"
+#include "IndexTable.h"
+#include "IndexBuilder.h"
+#include "QueryMatcher.h"
+#include "Matcher.h"
+#include "EvalueComputation.h"
+#include "Sequence.h"
+#include "DBReader.h"
+#include "Parameters.h"
+#include "Util.h"
+#include "FastSort.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cfloat>
+#include <string>
+#include <vector>
+#include <fstream>
+#include <chrono>
+#include <omp.h>
+#include <sys/stat.h>
+
+// Debug.h declares this global; the reference defines it in Application.cpp
+// (which pulls the whole CLI).  It is only the program name for messages.
+const char *binary_name = "ref_harness";
+
+static std::vector<std::string> readLines(const char *path) {
+    std::vector<std::string> v;
+    std::ifstream in(path);
+    if (!in) { fprintf(stderr, "cannot open %s\n", path); exit(2); }
+    std::string line;
+    while (std::getline(in, line)) {
+        while (!line.empty() && (line.back() == '\r' || line.back() == ' ')) line.pop_back();
+        v.push_back(line);
+    }
+    return v;
+}
+
+// Write a sequence DB in the MMseqs2 on-disk format
+// (DBWriter.cpp:401-428 index lines, :193-213 dbtype; entries are "SEQ\n\0").
+static void writeSeqDb(const std::string &base, const std::vector<std::string> &seqs) {
+    FILE *d = fopen(base.c_str(), "wb");
+    FILE *i = fopen((base + ".index").c_str(), "wb");
+    size_t off = 0;
+    for (size_t k = 0; k < seqs.size(); k++) {
+        fwrite(seqs[k].data(), 1, seqs[k].size(), d);
+        fputc('\n', d); fputc('\0', d);
+        fprintf(i, "%zu\t%zu\t%zu\n", k, off, seqs[k].size() + 2);
+        off += seqs[k].size() + 2;
+    }
+    fclose(d); fclose(i);
+    FILE *t = fopen((base + ".dbtype").c_str(), "wb");
+    int dbtype = Parameters::DBTYPE_AMINO_ACIDS;
+    fwrite(&dbtype, 4, 1, t);
+    fclose(t);
+}
+
+static double now() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static int kmerThreshold(float sensitivity, int kmerSize) {
+    // Prefiltering.cpp:1048-1060 (sequence-sequence branch)
+    float kmerThrBest = FLT_MAX;
+    if (kmerSize == 5) { float base = 160.75; kmerThrBest = base - (sensitivity * 12.75); }
+    else if (kmerSize == 6) { float base = 163.2; kmerThrBest = base - (sensitivity * 8.917); }
+    else if (kmerSize == 7) { float base = 186.15; kmerThrBest = base - (sensitivity * 11.22); }
+    return static_cast<int>(kmerThrBest);
+}
+
+static int cmdSubmat(int argc, char **argv) {
+    SubstitutionMatrix m(argv[2], atof(argv[3]), atof(argv[4]));
+    for (int i = 0; i < m.alphabetSize; i++) {
+        for (int j = 0; j < m.alphabetSize; j++) printf("%d%c", m.subMatrix[i][j], j + 1 == m.alphabetSize ? '\n' : ' ');
+    }
+    for (int i = 0; i < m.alphabetSize; i++) printf("%.17g%c", m.pBack[i], i + 1 == m.alphabetSize ? '\n' : ' ');
+    for (int i = 0; i < m.alphabetSize; i++) {
+        for (int j = 0; j < m.alphabetSize; j++) printf("%.17g%c", m.probMatrix[i][j], j + 1 == m.alphabetSize ? '\n' : ' ');
+    }
+    return 0;
+}
+
+static int cmdPipeline(int argc, char **argv) {
+    if (argc < 6) return 2;
+    std::string matdir = argv[2];
+    std::vector<std::string> targets = readLines(argv[3]);
+    std::vector<std::string> queries = readLines(argv[4]);
+    std::string outdir = argv[5];
+    float sensitivity = 5.7f;
+    int threads = 1;
+    bool dump = false;
+    bool doAlign = true;
+    size_t maxResListLen = 300;
+    for (int a = 6; a < argc; a++) {
+        std::string s = argv[a];
+        if (s == "-s") sensitivity = atof(argv[++a]);
+        else if (s == "--threads") threads = atoi(argv[++a]);
+        else if (s == "--dump") dump = true;
+        else if (s == "--no-align") doAlign = false;
+        else if (s == "--max-seqs") maxResListLen = atol(argv[++a]);
+    }
+    mkdir(outdir.c_str(), 0755);
+    omp_set_num_threads(threads);
+    std::string tdb = outdir + "/_tdb", qdb = outdir + "/_qdb";
+    writeSeqDb(tdb, targets);
+    writeSeqDb(qdb, queries);
+
+    DBReader<unsigned int> tdbr(tdb.c_str(), (tdb + ".index").c_str(), threads, DBReader<unsigned int>::USE_INDEX | DBReader<unsigned int>::USE_DATA);
+    tdbr.open(DBReader<unsigned int>::LINEAR_ACCCESS);
+    DBReader<unsigned int> qdbr(qdb.c_str(), (qdb + ".index").c_str(), threads, DBReader<unsigned int>::USE_INDEX | DBReader<unsigned int>::USE_DATA);
+    qdbr.open(DBReader<unsigned int>::LINEAR_ACCCESS);
+
+    const int querySeqType = Parameters::DBTYPE_AMINO_ACIDS, targetSeqType = Parameters::DBTYPE_AMINO_ACIDS;
+    const size_t maxSeqLen = 65535;
+    // Prefiltering.cpp:68-70
+    std::string blosum = matdir + "/blosum62.out", vtml = matdir + "/VTML80.out";
+    BaseMatrix *kmerSubMat = new SubstitutionMatrix(vtml.c_str(), 8.0, -0.2f);
+    BaseMatrix *ungappedSubMat = new SubstitutionMatrix(blosum.c_str(), 2.0, -0.2f);
+    const int alphabetSize = kmerSubMat->alphabetSize;
+    int kmerSize = IndexTable::computeKmerSize(tdbr.getAminoAcidDBSize());
+    const int kmerThr = kmerThreshold(sensitivity, kmerSize);
+    maxResListLen = std::min(tdbr.getSize(), maxResListLen);
+    double t0 = now();
+    // Prefiltering.cpp:208-213
+    kmerSubMat->alphabetSize = kmerSubMat->alphabetSize - 1;
+    ScoreMatrix _2mer = ExtendedSubstitutionMatrix::calcScoreMatrix(*kmerSubMat, 2);
+    ScoreMatrix _3mer = ExtendedSubstitutionMatrix::calcScoreMatrix(*kmerSubMat, 3);
+    kmerSubMat->alphabetSize = alphabetSize;
+    double tExt = now() - t0;
+    // Prefiltering.cpp:514-553
+    t0 = now();
+    SequenceLookup *sequenceLookup = NULL;
+    Sequence tseq(maxSeqLen, targetSeqType, kmerSubMat, kmerSize, true, true, true, "");
+    IndexTable *indexTable = new IndexTable(alphabetSize - 1, kmerSize, false);
+    IndexBuilder::fillDatabase(indexTable, &sequenceLookup, *kmerSubMat, _3mer, _2mer, &tseq, &tdbr, 0, tdbr.getSize(),
+                               kmerThr, true /*mask*/, false /*maskLowerCase*/, 0.9f /*maskProb*/, 0 /*maskNrepeats*/, 0 /*targetSearchMode*/);
+    double tIndex = now() - t0;
+
+    if (dump) {
+        FILE *f = fopen((outdir + "/masked_targets.txt").c_str(), "w");
+        for (size_t id = 0; id < tdbr.getSize(); id++) {
+            std::pair<const unsigned char *, const unsigned int> s = sequenceLookup->getSequence(id);
+            for (unsigned int p = 0; p < s.second; p++) fputc(kmerSubMat->num2aa[s.first[p]], f);
+            fputc('\n', f);
+        }
+        fclose(f);
+        f = fopen((outdir + "/index.txt").c_str(), "w");
+        for (size_t k = 0; k < indexTable->getTableSize(); k++) {
+            size_t n;
+            IndexEntryLocal *e = indexTable->getDBSeqList(k, &n);
+            if (n == 0) continue;
+            fprintf(f, "%zu", k);
+            for (size_t j = 0; j < n; j++) fprintf(f, " %u:%u", e[j].seqId, (unsigned) e[j].position_j);
+            fputc('\n', f);
+        }
+        fclose(f);
+    }
+
+    const size_t nq = qdbr.getSize();
+    std::vector<std::string> prefOut(nq), alnOut(nq);
+    std::vector<std::string> statOut(nq);
+    size_t totalHits = 0;
+    double kmersPerPos = 0; size_t dbMatches = 0;
+    t0 = now();
+#pragma omp parallel num_threads(threads)
+    {
+        unsigned int thread_idx = (unsigned int) omp_get_thread_num();
+        Sequence seq(qdbr.getMaxSeqLen(), querySeqType, kmerSubMat, kmerSize, true, true, true, "");
+        QueryMatcher matcher(indexTable, sequenceLookup, kmerSubMat, ungappedSubMat, kmerThr, kmerSize, tdbr.getSize(),
+                             std::max(tdbr.getMaxSeqLen(), qdbr.getMaxSeqLen()), maxResListLen, true, 1.0f,
+                             true, 15, false, false);
+        matcher.setSubstitutionMatrix(&_3mer, &_2mer);
+        char buffer[128];
+#pragma omp for schedule(dynamic, 1) reduction(+: totalHits, kmersPerPos, dbMatches)
+        for (size_t id = 0; id < nq; id++) {
+            char *seqData = qdbr.getData(id, thread_idx);
+            unsigned int qKey = qdbr.getDbKey(id);
+            seq.mapSequence(id, qKey, seqData, qdbr.getSeqLen(id));
+            std::pair<hit_t *, size_t> res = matcher.matchQuery(&seq, UINT_MAX, false);
+            std::string &out = prefOut[id];
+            for (size_t i = 0; i < res.second; i++) {
+                hit_t *h = res.first + i;
+                h->seqId = tdbr.getDbKey(h->seqId);
+                int len = QueryMatcher::prefilterHitToBuffer(buffer, *h);
+                out.append(buffer, len);
+            }
+            totalHits += res.second;
+            kmersPerPos += matcher.getStatistics()->kmersPerPos;
+            dbMatches += matcher.getStatistics()->dbMatches;
+            if (dump) {
+                char tmp[128];
+                snprintf(tmp, sizeof(tmp), "%.17g\t%zu\n", matcher.getStatistics()->kmersPerPos * seq.L, matcher.getStatistics()->dbMatches);
+                statOut[id] = tmp;
+            }
+        }
+    }
+    double tPref = now() - t0;
+
+    // ---------------- align (Alignment.cpp) ----------------
+    size_t alignmentsNum = 0, totalPassed = 0;
+    double cellsFwd = 0;
+    double tAln = 0;
+    if (doAlign) {
+        BaseMatrix *m = new SubstitutionMatrix(blosum.c_str(), 2.0, 0.0);
+        const int gapOpen = 11, gapExtend = 1;
+        EvalueComputation evaluer(tdbr.getAminoAcidDBSize(), m, gapOpen, gapExtend);
+        const double evalThr = 100.0;
+        const float covThr = 0.0f; const int covMode = 0; const int seqIdMode = 0;
+        const int alnLenThr = 11; const double seqIdThr = 0.0;
+        const unsigned int swMode = Matcher::SCORE_COV;
+        t0 = now();
+#pragma omp parallel num_threads(threads)
+        {
+            unsigned int thread_idx = (unsigned int) omp_get_thread_num();
+            char buffer[1024 + 32768 * 4];
+            Sequence qSeq(maxSeqLen, querySeqType, m, 0, false, true);
+            Sequence dbSeq(maxSeqLen, targetSeqType, m, 0, false, true);
+            Matcher matcher(querySeqType, targetSeqType, std::max(tdbr.getMaxSeqLen(), qdbr.getMaxSeqLen()), m, &evaluer, true, 1.0f, gapOpen, gapExtend, 0.0f, 40);
+            std::vector<Matcher::result_t> swResults;
+#pragma omp for schedule(dynamic, 5) reduction(+: alignmentsNum, totalPassed, cellsFwd)
+            for (size_t id = 0; id < nq; id++) {
+                std::string &pref = prefOut[id];
+                char *data = (char *) pref.c_str();
+                unsigned int queryDbKey = qdbr.getDbKey(id);
+                if (*data != '\0') {
+                    size_t qId = qdbr.getId(queryDbKey);
+                    qSeq.mapSequence(qId, queryDbKey, qdbr.getData(qId, thread_idx), qdbr.getSeqLen(qId));
+                    matcher.initQuery(&qSeq);
+                }
+                while (*data != '\0') {
+                    hit_t hit = QueryMatcher::parsePrefilterHit(data);
+                    const unsigned int dbKey = hit.seqId;
+                    short diagonal = static_cast<short>(hit.diagonal);
+                    data = Util::skipLine(data);
+                    size_t dbId = tdbr.getId(dbKey);
+                    dbSeq.mapSequence(dbId, dbKey, tdbr.getData(dbId, thread_idx), tdbr.getSeqLen(dbId));
+                    Matcher::result_t res = matcher.getSWResult(&dbSeq, static_cast<int>(diagonal), false, covMode, covThr, evalThr, swMode, seqIdMode, false, false);
+                    alignmentsNum++;
+                    cellsFwd += (double) qSeq.L * (double) dbSeq.L;
+                    const bool evalOk = (res.eval <= evalThr);
+                    const bool seqIdOK = (res.seqId >= seqIdThr);
+                    const bool covOK = Util::hasCoverage(covThr, covMode, res.qcov, res.dbcov);
+                    const bool alnLenOK = Util::hasAlignmentLength(alnLenThr, res.alnLength);
+                    if (evalOk && seqIdOK && covOK && alnLenOK) {
+                        swResults.emplace_back(res);
+                        totalPassed++;
+                    }
+                }
+                if (swResults.size() > 1) {
+                    SORT_SERIAL(swResults.begin(), swResults.end(), Matcher::compareHits);
+                }
+                std::string &out = alnOut[id];
+                for (size_t r = 0; r < swResults.size(); r++) {
+                    size_t len = Matcher::resultToBuffer(buffer, swResults[r], false);
+                    out.append(buffer, len);
+                }
+                swResults.clear();
+            }
+        }
+        tAln = now() - t0;
+    }
+
+    {
+        FILE *f = fopen((outdir + "/pref.txt").c_str(), "w");
+        for (size_t id = 0; id < nq; id++) { fprintf(f, ">%u\n", qdbr.getDbKey(id)); fputs(prefOut[id].c_str(), f); }
+        fclose(f);
+        if (doAlign) {
+            f = fopen((outdir + "/aln.txt").c_str(), "w");
+            for (size_t id = 0; id < nq; id++) { fprintf(f, ">%u\n", qdbr.getDbKey(id)); fputs(alnOut[id].c_str(), f); }
+            fclose(f);
+        }
+        if (dump) {
+            f = fopen((outdir + "/stats.txt").c_str(), "w");
+            for (size_t id = 0; id < nq; id++) fputs(statOut[id].c_str(), f);
+            fclose(f);
+        }
+    }
+    size_t qres = 0; for (size_t i = 0; i < queries.size(); i++) qres += queries[i].size();
+    printf("{\"queries\": %zu, \"targets\": %zu, \"query_residues\": %zu, \"target_residues\": %zu, \"k\": %d, \"kmer_thr\": %d, "
+           "\"threads\": %d, \"t_extmat\": %.4f, \"t_index\": %.4f, \"t_prefilter\": %.4f, \"t_align\": %.4f, "
+           "\"pref_hits\": %zu, \"kmers_per_pos\": %.4f, \"db_matches\": %zu, \"alignments\": %zu, \"passed\": %zu, \"cells_fwd\": %.0f}\n",
+           queries.size(), targets.size(), qres, (size_t) tdbr.getAminoAcidDBSize(), kmerSize, kmerThr, threads, tExt, tIndex, tPref, tAln,
+           totalHits, kmersPerPos / (double) nq, dbMatches, alignmentsNum, totalPassed, cellsFwd);
+    return 0;
+}
+
+// Function-level SW goldens: every listed pair goes through
+// Matcher::getSWResult (SCORE_COV mode) with an e-value threshold that never
+// rejects, so the reverse pass always runs.
+static int cmdSw(int argc, char **argv) {
+    if (argc < 7) return 2;
+    std::string matdir = argv[2];
+    std::vector<std::string> targets = readLines(argv[3]);
+    std::vector<std::string> queries = readLines(argv[4]);
+    std::vector<std::string> pairs = readLines(argv[5]);
+    size_t dbRes = 0;
+    for (size_t i = 0; i < targets.size(); i++) dbRes += targets[i].size();
+    for (int a = 7; a < argc; a++) if (std::string(argv[a]) == "--dbres") dbRes = atol(argv[++a]);
+    std::string blosum = matdir + "/blosum62.out";
+    BaseMatrix *m = new SubstitutionMatrix(blosum.c_str(), 2.0, 0.0);
+    EvalueComputation evaluer(dbRes, m, 11, 1);
+    size_t maxLen = 1;
+    for (size_t i = 0; i < targets.size(); i++) maxLen = std::max(maxLen, targets[i].size());
+    for (size_t i = 0; i < queries.size(); i++) maxLen = std::max(maxLen, queries[i].size());
+    Sequence qSeq(maxLen + 1, Parameters::DBTYPE_AMINO_ACIDS, m, 0, false, true);
+    Sequence dbSeq(maxLen + 1, Parameters::DBTYPE_AMINO_ACIDS, m, 0, false, true);
+    Matcher matcher(Parameters::DBTYPE_AMINO_ACIDS, Parameters::DBTYPE_AMINO_ACIDS, maxLen + 1, m, &evaluer, true, 1.0f, 11, 1, 0.0f, 40);
+    FILE *f = fopen(argv[6], "w");
+    char buffer[4096];
+    int lastQ = -1;
+    for (size_t p = 0; p < pairs.size(); p++) {
+        int q, t;
+        if (sscanf(pairs[p].c_str(), "%d %d", &q, &t) != 2) continue;
+        if (q != lastQ) {
+            qSeq.mapSequence(q, q, queries[q].c_str(), queries[q].size());
+            matcher.initQuery(&qSeq);
+            lastQ = q;
+        }
+        dbSeq.mapSequence(t, t, targets[t].c_str(), targets[t].size());
+        Matcher::result_t res = matcher.getSWResult(&dbSeq, 0, false, 0, 0.0f, DBL_MAX, Matcher::SCORE_COV, 0, false, false);
+        size_t len = Matcher::resultToBuffer(buffer, res, false);
+        fprintf(f, "%d\t%d\t", q, t);
+        fwrite(buffer, 1, len, f);
+    }
+    fclose(f);
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) { fprintf(stderr, "usage: ref_harness pipeline|sw|submat ...\n"); return 2; }
+    std::string cmd = argv[1];
+    if (cmd == "submat") return cmdSubmat(argc, argv);
+    if (cmd == "pipeline") return cmdPipeline(argc, argv);
+    if (cmd == "sw") return cmdSw(argc, argv);
+    return 2;
+}
