@@ -1,0 +1,292 @@
+/* oracle/mko_prefilter.c -- TEST INFRASTRUCTURE (parity oracle).  See mko.h.
+ * One query through QueryMatcher::matchQuery (M/src/prefiltering/QueryMatcher.cpp:85-211). */
+#include "mko.h"
+#include <stdlib.h>
+#include <string.h>
+
+static const int SPACED6[6] = {0, 1, 3, 5, 8, 9};
+
+/* QueryMatcher::initDiagonalMatcher (QueryMatcher.cpp:422-450): BINSIZE from the host L2 size */
+int mko_bin_count_for(uint64_t db_size, uint64_t l2) {
+    for (int x = 2; x <= 1024; x *= 2) if (db_size / (uint64_t) x < l2) return x;
+    return 2048;
+}
+
+/* UngappedAlignment::createProfile (UngappedAlignment.cpp:385-414): profile[pos][aa] (row of 21) */
+void mko_ungapped_profile(const mko_submat *um, const uint8_t *q, int L, const float *bias, int8_t *profile) {
+    for (int pos = 0; pos < L; pos++) {
+        float aaCorrBias = bias[pos];
+        /* float/4 is float; -+0.5 promotes to double; result stored back into a float, then char */
+        aaCorrBias = (float) ((aaCorrBias < 0.0) ? (double) (aaCorrBias / 4) - 0.5 : (double) (aaCorrBias / 4) + 0.5);
+        signed char corr = (signed char) aaCorrBias;
+        for (int a = 0; a < MKO_ALPH; a++) profile[pos * 21 + a] = (int8_t) (um->sub[q[pos]][a] + corr);
+    }
+}
+
+/* UngappedAlignment::scalarDiagonalScoring (:30-43) */
+static int scalar_diag(const int8_t *profile, unsigned int len, const uint8_t *db) {
+    int max = 0, score = 0;
+    for (unsigned int pos = 0; pos < len; pos++) {
+        int curr = profile[pos * 21 + db[pos]];
+        score = curr + score;
+        score = (score < 0) ? 0 : score;
+        max = (score > max) ? score : max;
+    }
+    return max;
+}
+
+/* UngappedAlignment::computeSingelSequenceScores (:416-431) */
+static int single_scores(const int8_t *profile, unsigned int qlen, const uint8_t *t, unsigned int tlen, int diagonal, unsigned int minDist) {
+    int max = 0;
+    if (diagonal >= 0 && minDist < qlen) {
+        unsigned int n = tlen < (qlen - minDist) ? tlen : (qlen - minDist);
+        int s = scalar_diag(profile + (size_t) minDist * 21, n, t);
+        max = s > max ? s : max;
+    } else if (diagonal < 0 && minDist < tlen) {
+        unsigned int n = (tlen - minDist) < qlen ? (tlen - minDist) : qlen;
+        int s = scalar_diag(profile, n, t + minDist);
+        max = s > max ? s : max;
+    }
+    return max;
+}
+
+/* UngappedAlignment::scoreSingleSequence (:441-451) incl. computeLongScore (:312-329); returns the
+ * exact (unclamped) score of `diagonal` (u16 as stored in CounterResult). */
+int mko_ungapped_score(const int8_t *profile, int qlen, const uint8_t *t, int tlen, uint16_t diagonal) {
+    if (qlen >= 32768 || tlen >= 32768) {
+        int totalMax = 0;
+        for (unsigned int d = 1; d <= 1 + (unsigned int) tlen / 32768; d++) {
+            int realDiagonal = (int) (-d * 65536 + diagonal);   /* unsigned wrap then int, as in the reference */
+            int minDist = abs(realDiagonal);
+            int m = single_scores(profile, qlen, t, tlen, realDiagonal, (unsigned int) minDist);
+            totalMax = totalMax > m ? totalMax : m;
+        }
+        for (unsigned int d = 0; d <= (unsigned int) qlen / 65536; d++) {
+            int realDiagonal = (int) (d * 65536 + diagonal);
+            int minDist = abs(realDiagonal);
+            int m = single_scores(profile, qlen, t, tlen, realDiagonal, (unsigned int) minDist);
+            totalMax = totalMax > m ? totalMax : m;
+        }
+        return totalMax;
+    }
+    /* distanceFromDiagonal (:364-369) */
+    unsigned short d1 = (unsigned short) (0 - diagonal), d2 = diagonal;
+    unsigned short minDist = d1 < d2 ? d1 : d2;
+    return single_scores(profile, qlen, t, tlen, (int) (short) diagonal, minDist);
+}
+
+typedef struct { uint32_t id; uint16_t diagonal; uint8_t count; } cres_t;   /* CounterResult */
+
+/* stable partition by id & (B-1): CacheFriendlyOperations::hashIndexEntry / hashElements */
+static void bin_partition(const cres_t *in, size_t n, int B, cres_t *out, size_t *bin_start /* B+1 */) {
+    size_t *cnt = (size_t *) calloc((size_t) B + 1, sizeof(size_t));
+    for (size_t i = 0; i < n; i++) cnt[(in[i].id & (uint32_t) (B - 1)) + 1]++;
+    for (int b = 0; b < B; b++) cnt[b + 1] += cnt[b];
+    memcpy(bin_start, cnt, ((size_t) B + 1) * sizeof(size_t));
+    for (size_t i = 0; i < n; i++) out[cnt[in[i].id & (uint32_t) (B - 1)]++] = in[i];
+    free(cnt);
+}
+
+static int hit_cmp(const void *a, const void *b) {   /* hit_t::compareHitsByScoreAndId (QueryMatcher.h:38-48) */
+    const mko_hit *x = (const mko_hit *) a, *y = (const mko_hit *) b;
+    int ax = abs(x->score), ay = abs(y->score);
+    if (ax != ay) return ax > ay ? -1 : 1;
+    if (x->seq_id != y->seq_id) return x->seq_id < y->seq_id ? -1 : 1;
+    return 0;
+}
+
+int mko_prefilter_query(const mko_prefilter_ctx *ctx, const uint8_t *q, int L, mko_hit *out, mko_prefilter_stats *st) {
+    const mko_index *ix = ctx->index;
+    const int B = ctx->bin_count;
+    int shift = 0;
+    while ((1 << shift) < B) shift++;
+    const size_t dbSize = ix->n_seq;
+    const size_t maxDbMatches = (dbSize > 1000000 ? dbSize : 1000000) * 2;
+    const size_t foundDiagonalsSize = dbSize > 1000000 ? dbSize : 1000000;
+    int maxHits = ctx->max_hits < (int) dbSize ? ctx->max_hits : (int) dbSize;
+    float *bias = (float *) malloc((size_t) (L > 0 ? L : 1) * sizeof(float));
+    int8_t *profile = (int8_t *) malloc((size_t) (L > 0 ? L : 1) * 21);
+    mko_comp_bias(ctx->kmer_mat, q, L, ctx->bias_scale, bias);               /* QueryMatcher.cpp:91-99 */
+    mko_ungapped_profile(ctx->ungapped_mat, q, L, bias, profile);            /* :100-102 */
+
+    /* ---- match() (:213-346): gather index entries in (i, k-mer list, index list) order ---- */
+    size_t cap = 1 << 16, n = 0;
+    cres_t *hits = (cres_t *) malloc(cap * sizeof(cres_t));
+    size_t kcap = 1 << 20;
+    uint64_t *klist = (uint64_t *) malloc(kcap * sizeof(uint64_t));
+    uint64_t kmerListLen = 0;
+    int rc = 0;
+    for (int i = 0; i + 10 <= L; i++) {
+        uint8_t kmer[6];
+        int hasX = 0;
+        float biasCorrection = 0;
+        for (int p = 0; p < 6; p++) {
+            kmer[p] = q[i + SPACED6[p]];
+            hasX |= (kmer[p] == MKO_X);
+            biasCorrection += bias[i + SPACED6[p]];
+        }
+        if (hasX) continue;
+        short b = (short) ((biasCorrection < 0.0) ? (double) biasCorrection - 0.5 : (double) biasCorrection + 0.5);
+        int kms = ctx->kmer_thr - b;
+        short kmerMatchScore = (short) (kms > 0 ? kms : 0);
+        size_t nk = mko_kmer_list6(ctx->three, kmer, kmerMatchScore, klist, kcap);
+        if (nk > kcap) {
+            kcap = nk;
+            klist = (uint64_t *) realloc(klist, kcap * sizeof(uint64_t));
+            nk = mko_kmer_list6(ctx->three, kmer, kmerMatchScore, klist, kcap);
+        }
+        kmerListLen += nk;
+        for (size_t k = 0; k < nk; k++) {
+            const uint64_t o0 = ix->offsets[klist[k]], o1 = ix->offsets[klist[k] + 1];
+            const size_t sz = (size_t) (o1 - o0);
+            if (n + sz >= maxDbMatches) { rc = -1; goto done; }   /* overflow path (:281-316) not restated */
+            if (n + sz > cap) { while (n + sz > cap) cap *= 2; hits = (cres_t *) realloc(hits, cap * sizeof(cres_t)); }
+            for (size_t e = 0; e < sz; e++) {
+                hits[n].id = ix->seq_id[o0 + e];
+                hits[n].diagonal = (uint16_t) (i - (int) ix->pos[o0 + e]);   /* hashIndexEntry :337-347 */
+                hits[n].count = 0;
+                n++;
+            }
+        }
+    }
+    if (st) { st->kmer_list_len = kmerListLen; st->db_matches = n; st->diagonals = 0; }
+    {
+        /* ---- findDuplicates (CacheFriendlyOperations.cpp:38-49,185-274), computeTotalScore == false ---- */
+        cres_t *binned = (cres_t *) malloc((n + 1) * sizeof(cres_t));
+        size_t *bs = (size_t *) malloc(((size_t) B + 1) * sizeof(size_t));
+        bin_partition(hits, n, B, binned, bs);
+        uint8_t *dup = (uint8_t *) calloc((dbSize >> shift) + 2, 1);
+        cres_t *cand = (cres_t *) malloc((n + 1) * sizeof(cres_t));
+        cres_t *tmp = (cres_t *) malloc((n + 1) * sizeof(cres_t));
+        size_t nc = 0;
+        for (int bin = 0; bin < B; bin++) {
+            const cres_t *bp = binned + bs[bin];
+            const size_t cur = bs[bin + 1] - bs[bin];
+            size_t ec = 0;
+            for (size_t k = 0; k < cur; k++) {
+                const uint32_t h = bp[k].id >> shift;
+                const uint8_t currDiagonal = (uint8_t) bp[k].diagonal;
+                const uint8_t prevDiagonal = dup[h];
+                tmp[ec] = bp[k];
+                ec += (currDiagonal == prevDiagonal) ? 1 : 0;
+                dup[h] = currDiagonal;
+            }
+            if (nc + (ec < cur / 2 ? ec : cur / 2) >= foundDiagonalsSize) break;   /* :214-216 */
+            for (size_t k = ec; k-- > 0;) dup[tmp[k].id >> shift] = (uint8_t) ((uint8_t) tmp[k].diagonal + 1);
+            for (size_t k = 0; k < ec; k++) {
+                const uint32_t h = tmp[k].id >> shift;
+                cand[nc].id = tmp[k].id;
+                cand[nc].count = 0;
+                cand[nc].diagonal = tmp[k].diagonal;
+                nc += (dup[h] != (uint8_t) tmp[k].diagonal) ? 1 : 0;
+                dup[h] = (uint8_t) tmp[k].diagonal;
+            }
+            for (size_t k = 0; k < cur; k++) dup[bp[k].id >> shift] = 0;
+        }
+        if (st) st->diagonals = nc;
+        if (nc >= foundDiagonalsSize / 2) { rc = -1; free(binned); free(bs); free(dup); free(cand); free(tmp); goto done; }
+
+        /* ---- UngappedAlignment::align / computeScores (:331-362): count = min(255, score) ---- */
+        for (size_t k = 0; k < nc; k++) {
+            const uint32_t id = cand[k].id;
+            int s = mko_ungapped_score(profile, L, ix->masked + ix->seq_off[id], (int) (ix->seq_off[id + 1] - ix->seq_off[id]), cand[k].diagonal);
+            cand[k].count = (uint8_t) (s < 255 ? s : 255);
+        }
+        /* ---- keepMaxScoreElementOnly (CacheFriendlyOperations.cpp:70-78,350-380) ---- */
+        bin_partition(cand, nc, B, binned, bs);
+        size_t nr = 0;
+        for (int bin = 0; bin < B; bin++) {
+            const cres_t *bp = binned + bs[bin];
+            const size_t cur = bs[bin + 1] - bs[bin];
+            for (size_t k = 0; k < cur; k++) {
+                const uint32_t h = bp[k].id >> shift;
+                if (bp[k].count > dup[h]) dup[h] = bp[k].count;
+            }
+            for (size_t k = 0; k < cur; k++) {
+                const uint32_t h = bp[k].id >> shift;
+                cand[nr] = bp[k];
+                int found = (dup[h] == bp[k].count) ? 1 : 0;
+                nr += (size_t) found;
+                dup[h] = (uint8_t) (dup[h] * (1 - found));
+            }
+        }
+        /* ---- score histogram, threshold (QueryMatcher.h:206-216, .cpp:152-155) ---- */
+        unsigned int scoreSizes[256];
+        memset(scoreSizes, 0, sizeof(scoreSizes));
+        for (size_t k = 0; k < nr; k++) scoreSizes[cand[k].count]++;
+        unsigned int thr;
+        {
+            size_t found = 0;
+            size_t t;
+            for (t = 255; t > 0; t--) { found += scoreSizes[t]; if (found >= (size_t) maxHits) break; }
+            thr = (unsigned int) t;
+        }
+        unsigned int diagonalThr = thr > (unsigned int) ctx->min_diag_score ? thr : (unsigned int) ctx->min_diag_score;
+        /* ---- radixSortByScoreSize (:498-523): descending score, stable ---- */
+        cres_t *sorted = binned;   /* reuse */
+        size_t above = 0;
+        {
+            size_t ptr[256];
+            size_t prev = nr;
+            for (int s = 0; s < 256; s++) { ptr[s] = prev - scoreSizes[s]; prev = ptr[s]; }
+            for (size_t k = 0; k < nr; k++) {
+                if (cand[k].count >= diagonalThr) { above++; sorted[ptr[cand[k].count]++] = cand[k]; }
+            }
+        }
+        int nout = 0;
+        if (diagonalThr >= 255) {
+            /* saturated threshold: rescoreHits (:525-544) then radix sort again, getResult with rescale */
+            memset(scoreSizes, 0, sizeof(scoreSizes));
+            int maxSelfScore = mko_ungapped_score(profile, L, q, L, 0);
+            maxSelfScore = maxSelfScore - 255;
+            maxSelfScore = maxSelfScore > 1 ? maxSelfScore : 1;
+            maxSelfScore = maxSelfScore < 65535 ? maxSelfScore : 65535;
+            float fltMax = (float) maxSelfScore;
+            size_t elements = 0;
+            for (size_t k = 0; k < above && sorted[k].count >= 255; k++) {
+                const uint32_t id = sorted[k].id;
+                unsigned int newScore = (unsigned int) mko_ungapped_score(profile, L, ix->masked + ix->seq_off[id], (int) (ix->seq_off[id + 1] - ix->seq_off[id]), sorted[k].diagonal);
+                newScore -= 255;
+                float score = (float) (newScore < 65535u ? newScore : 65535u);
+                sorted[k].count = (uint8_t) ((double) ((score / fltMax) * (float) 255) + 0.5);
+                scoreSizes[sorted[k].count] += 1;
+                elements++;
+            }
+            size_t ptr[256];
+            size_t prev = elements;
+            for (int s = 0; s < 256; s++) { ptr[s] = prev - scoreSizes[s]; prev = ptr[s]; }
+            for (size_t k = 0; k < elements; k++) cand[ptr[sorted[k].count]++] = sorted[k];
+            for (size_t k = 0; k < elements && nout < maxHits; k++) {
+                out[nout].seq_id = cand[k].id;
+                out[nout].diagonal = cand[k].diagonal;
+                unsigned int newScore = 255u + ((unsigned int) cand[k].count * (unsigned int) maxSelfScore / 255u);
+                out[nout].score = (int32_t) newScore;
+                nout++;
+            }
+        } else {
+            /* getResult<UNGAPPED_DIAGONAL_SCORE> (:363-420) */
+            for (size_t k = 0; k < above && nout < maxHits; k++) {
+                out[nout].seq_id = sorted[k].id;
+                out[nout].diagonal = sorted[k].diagonal;
+                out[nout].score = sorted[k].count;
+                if (sorted[k].count >= 255) {
+                    const uint32_t id = sorted[k].id;
+                    out[nout].score = mko_ungapped_score(profile, L, ix->masked + ix->seq_off[id], (int) (ix->seq_off[id + 1] - ix->seq_off[id]), sorted[k].diagonal);
+                }
+                nout++;
+            }
+        }
+        if (nout > 1) qsort(out, (size_t) nout, sizeof(mko_hit), hit_cmp);   /* :203-209 */
+        rc = nout;
+        free(binned); free(bs); free(dup); free(cand); free(tmp);
+    }
+done:
+    free(hits); free(klist); free(bias); free(profile);
+    return rc;
+}
+
+/* QueryMatcher::prefilterHitToBuffer (QueryMatcher.h:118-130) */
+#include <stdio.h>
+size_t mko_format_hit(char *buf, const mko_hit *h) {
+    return (size_t) sprintf(buf, "%u\t%d\t%d\n", h->seq_id, h->score, (int) (short) h->diagonal);
+}

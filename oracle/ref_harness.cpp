@@ -37,6 +37,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cfloat>
+#include <cmath>
 #include <string>
 #include <vector>
 #include <fstream>
@@ -213,7 +214,7 @@ static int cmdPipeline(int argc, char **argv) {
             dbMatches += matcher.getStatistics()->dbMatches;
             if (dump) {
                 char tmp[128];
-                snprintf(tmp, sizeof(tmp), "%.17g\t%zu\n", matcher.getStatistics()->kmersPerPos * seq.L, matcher.getStatistics()->dbMatches);
+                snprintf(tmp, sizeof(tmp), "%lld\t%zu\n", llround(matcher.getStatistics()->kmersPerPos * seq.L), matcher.getStatistics()->dbMatches);
                 statOut[id] = tmp;
             }
         }
