@@ -1,0 +1,140 @@
+/* include/metaeuk_amd.h -- C ABI of the MI355X-native prefilter+align hot path.
+ *
+ * Plain C, opaque handles, caller-owned buffers, int return codes (0 = ok,
+ * negative = error; mk_last_error() gives the message).  No C++/torch types
+ * cross this boundary.  Every entry point names the reference interface it
+ * replaces (paths relative to the reference tree, M/ = lib/mmseqs/).
+ *
+ * Drop-in seam: the reference's in-process seam for this path is
+ *   QueryMatcher::matchQuery(Sequence*, unsigned, bool)   M/src/prefiltering/QueryMatcher.h:64
+ *   Matcher::initQuery / Matcher::getSWResult(...)        M/src/alignment/Matcher.h:153-154,206
+ * called once per query from Prefiltering::runSplit (Prefiltering.cpp:817-886)
+ * and Alignment::run (Alignment.cpp:312-514).  A GPU wants batches, so the ABI
+ * is the batch form of those two calls plus the one-time target set-up that
+ * Prefiltering::getIndexTable (Prefiltering.cpp:514-553) performs.
+ * INTEGRATION.md shows the `prefilter` / `align` command bodies a maintainer
+ * would register in src/metaeuk.cpp:21-96 on top of this ABI.
+ */
+#ifndef METAEUK_AMD_H
+#define METAEUK_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MK_OK 0
+#define MK_ERR_ARG (-1)
+#define MK_ERR_DEVICE (-2)       /* HIP error / no GPU: the product never falls back to the CPU */
+#define MK_ERR_UNSUPPORTED (-3)  /* a reference corner this build does not restate (message says which) */
+#define MK_ERR_SW_MISMATCH (-4)  /* forward/backward SW scores differ: the reference EXITs here too
+                                    (StripedSmithWaterman.cpp:466-473) */
+
+typedef struct mk_targetdb mk_targetdb;
+typedef struct mk_queries mk_queries;
+
+/* hit_t (M/src/prefiltering/QueryMatcher.h:33-49) */
+typedef struct { uint32_t seq_id; int32_t pref_score; uint16_t diagonal; uint16_t pad_; } mk_hit;
+
+/* Matcher::result_t fields that reach the 10-column output (M/src/alignment/Matcher.h:30-91) */
+typedef struct {
+    uint32_t db_key;
+    int32_t bit_score;
+    float seq_id;
+    float qcov, dbcov;
+    double evalue;
+    int32_t q_start, q_end, q_len;
+    int32_t db_start, db_end, db_len;
+    int32_t aln_len;
+    int32_t raw_score;
+} mk_alignment;
+
+/* Search parameters = the subset of the reference's `prefilter` / `align` flag lists
+ * (M/src/commons/Parameters.cpp:387-455) that the predictexons path honours. */
+typedef struct {
+    float sensitivity;        /* -s                (5.7 for the BASELINE configs) */
+    int kmer_score;           /* --k-score; INT32_MAX = derive from -s (Prefiltering.cpp:1005-1065) */
+    int max_seqs;             /* --max-seqs 300 */
+    int min_ungapped_score;   /* --min-ungapped-score 15 */
+    int comp_bias_corr;       /* --comp-bias-corr 1 */
+    float comp_bias_scale;    /* --comp-bias-corr-scale 1.0 */
+    int mask;                 /* --mask 1 (tantan on targets) */
+    float mask_prob;          /* --mask-prob 0.9 */
+    int gap_open, gap_extend; /* --gap-open 11 --gap-extend 1 */
+    double evalue_thr;        /* -e 100 (predictexons default, src/workflow/PredictExons.cpp:8-16) */
+    int min_aln_len;          /* --min-aln-len = --min-exon-aa 11 */
+    /* properties of the reference BUILD/HOST that leak into its results (SURVEY.md 8a-10,12): */
+    int simd_lanes_byte;      /* 32 = AVX2, 16 = SSE4.1  (striped SW stripe length) */
+    int simd_lanes_word;      /* 16 = AVX2,  8 = SSE4.1 */
+    int simd_lanes_double;    /*  4 = AVX2,  2 = SSE4.1  (tantan partial sums) */
+    uint64_t host_l2_bytes;   /* Util::getL2CacheSize() of the host being reproduced (tie order at --max-seqs) */
+} mk_params;
+
+/* ---- process-wide ---- */
+int mk_init(int device_ordinal);            /* binds the calling process to one GPU (one process per GPU) */
+const char *mk_last_error(void);
+void mk_default_params(mk_params *p);       /* defaults of `metaeuk predictexons` (SURVEY.md 3.2 argv) */
+int mk_device_name(char *buf, size_t cap);
+
+/* ---- encoding: Sequence::mapSequence + SubstitutionMatrix::aa2num (Sequence.cpp:307-324) ---- */
+void mk_encode(const char *ascii, size_t len, uint8_t *codes);
+
+/* ---- target side: replaces Prefiltering::getIndexTable -> IndexBuilder::fillDatabase
+ * (M/src/prefiltering/IndexBuilder.cpp:55-239): tantan masking, SequenceLookup, k-mer index;
+ * plus ExtendedSubstitutionMatrix::calcScoreMatrix (ExtendedSubstitutionMatrix.cpp:20-69).
+ * residues: encoded 0..20, concatenated; offsets[n+1].  Everything ends up resident in HBM. */
+int mk_targetdb_create(const uint8_t *residues, const uint64_t *offsets, uint32_t n_targets,
+                       const mk_params *params, mk_targetdb **out);
+void mk_targetdb_destroy(mk_targetdb *db);
+uint64_t mk_targetdb_residues(const mk_targetdb *db);
+uint64_t mk_targetdb_index_entries(const mk_targetdb *db);
+/* copies of host-built artefacts, for tests */
+int mk_targetdb_masked(const mk_targetdb *db, uint8_t *out /* residues */);
+
+/* ---- query batch: Sequence::mapSequence + calcLocalAaBiasCorrection + createProfile/ssw_init inputs.
+ * Uploads the batch; derived per-residue arrays are computed on the device. */
+int mk_queries_create(const uint8_t *residues, const uint64_t *offsets, uint32_t n_queries,
+                      const mk_params *params, mk_queries **out);
+void mk_queries_destroy(mk_queries *q);
+
+/* ---- prefilter: batch form of QueryMatcher::matchQuery (QueryMatcher.cpp:85-211).
+ * out_hits must hold n_queries*max_seqs entries; query i's hits are out_hits[i*max_seqs ..][0..counts[i]),
+ * sorted like the reference (|score| desc, seq_id asc). */
+int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *params,
+                 mk_hit *out_hits, uint32_t *out_counts);
+
+/* ---- align: batch form of Matcher::initQuery + getSWResult + Alignment::checkCriteria + sort
+ * (Matcher.cpp:49-142, Alignment.cpp:346-405).  hits/counts as produced by mk_prefilter
+ * (seq_id = target index).  out must hold sum(counts) entries; query i's accepted alignments are
+ * written contiguously from out[prefix(counts)[i]], out_counts[i] of them, in output order. */
+int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *params,
+             const mk_hit *hits, const uint32_t *counts, uint32_t hits_stride,
+             mk_alignment *out, uint32_t *out_counts);
+
+/* ---- kernel-level entry points (used by the parity tests and bench.py) ---- */
+/* Smith-Waterman on explicit pairs: for pair p, query q_idx[p] vs target t_idx[p].
+ * out5[p*5..] = score, q_end, t_end, q_start, t_start (starts = -1 unless with_start). */
+int mk_sw_pairs(mk_targetdb *db, mk_queries *q, const mk_params *params,
+                const uint32_t *q_idx, const uint32_t *t_idx, uint64_t n_pairs, int with_start,
+                int32_t *out5);
+/* ungapped diagonal scores (exact, unclamped) for (q_idx, t_idx, diagonal) triples:
+ * UngappedAlignment::scoreSingelSequenceByCounterResult (UngappedAlignment.cpp:434-451) */
+int mk_ungapped(mk_targetdb *db, mk_queries *q, const uint32_t *q_idx, const uint32_t *t_idx,
+                const uint16_t *diagonal, uint64_t n, int32_t *out_scores);
+
+/* timing of the last mk_prefilter / mk_align / mk_sw_pairs call, from HIP events on the
+ * library's stream: names[i] -> ms and launches; used for the roofline line of bench.py */
+typedef struct { const char *name; double ms; uint64_t launches; double alg_bytes; double cells; } mk_kernel_stat;
+int mk_kernel_stats(mk_kernel_stat *out, int cap);
+void mk_kernel_stats_reset(void);
+
+/* ---- formatting: QueryMatcher::prefilterHitToBuffer (QueryMatcher.h:118-130),
+ * Matcher::resultToBuffer (Matcher.cpp:280-327) ---- */
+size_t mk_format_hit(char *buf, uint32_t db_key, int32_t score, uint16_t diagonal);
+size_t mk_format_alignment(char *buf, const mk_alignment *a);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

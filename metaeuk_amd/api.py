@@ -1,0 +1,213 @@
+"""ctypes binding of the C ABI in include/metaeuk_amd.h (tests / bench plumbing only).
+
+The product is the shared library; nothing in this file computes anything.  If the library is
+missing it is built; if it cannot be loaded the import fails loudly (no fallback).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_LIB = None
+
+
+class Params(C.Structure):
+    _fields_ = [("sensitivity", C.c_float), ("kmer_score", C.c_int), ("max_seqs", C.c_int),
+                ("min_ungapped_score", C.c_int), ("comp_bias_corr", C.c_int), ("comp_bias_scale", C.c_float),
+                ("mask", C.c_int), ("mask_prob", C.c_float), ("gap_open", C.c_int), ("gap_extend", C.c_int),
+                ("evalue_thr", C.c_double), ("min_aln_len", C.c_int), ("simd_lanes_byte", C.c_int),
+                ("simd_lanes_word", C.c_int), ("simd_lanes_double", C.c_int), ("host_l2_bytes", C.c_uint64)]
+
+
+class Hit(C.Structure):
+    _fields_ = [("seq_id", C.c_uint32), ("pref_score", C.c_int32), ("diagonal", C.c_uint16), ("pad_", C.c_uint16)]
+
+
+class Alignment(C.Structure):
+    _fields_ = [("db_key", C.c_uint32), ("bit_score", C.c_int32), ("seq_id", C.c_float), ("qcov", C.c_float),
+                ("dbcov", C.c_float), ("evalue", C.c_double), ("q_start", C.c_int32), ("q_end", C.c_int32),
+                ("q_len", C.c_int32), ("db_start", C.c_int32), ("db_end", C.c_int32), ("db_len", C.c_int32),
+                ("aln_len", C.c_int32), ("raw_score", C.c_int32)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("ms", C.c_double), ("launches", C.c_uint64), ("alg_bytes", C.c_double),
+                ("cells", C.c_double)]
+
+
+HIT_DTYPE = np.dtype([("seq_id", "<u4"), ("pref_score", "<i4"), ("diagonal", "<u2"), ("pad_", "<u2")])
+
+EXPORTS = ["mk_init", "mk_last_error", "mk_default_params", "mk_device_name", "mk_encode", "mk_targetdb_create",
+           "mk_targetdb_destroy", "mk_targetdb_residues", "mk_targetdb_index_entries", "mk_targetdb_masked",
+           "mk_queries_create", "mk_queries_destroy", "mk_prefilter", "mk_align", "mk_sw_pairs", "mk_ungapped",
+           "mk_kernel_stats", "mk_kernel_stats_reset", "mk_format_hit", "mk_format_alignment"]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = _build.LIB
+        if not os.path.exists(path):
+            _build.build()
+        L = C.CDLL(path)
+        L.mk_last_error.restype = C.c_char_p
+        L.mk_targetdb_residues.restype = C.c_uint64
+        L.mk_targetdb_index_entries.restype = C.c_uint64
+        L.mk_format_hit.restype = C.c_size_t
+        L.mk_format_alignment.restype = C.c_size_t
+        _LIB = L
+    return _LIB
+
+
+class MkError(RuntimeError):
+    pass
+
+
+def _chk(rc):
+    if rc != 0:
+        raise MkError("metaeuk_amd error %d: %s" % (rc, lib().mk_last_error().decode()))
+
+
+def init(device=0):
+    _chk(lib().mk_init(int(device)))
+
+
+def default_params():
+    p = Params()
+    lib().mk_default_params(C.byref(p))
+    return p
+
+
+def device_name():
+    buf = C.create_string_buffer(256)
+    _chk(lib().mk_device_name(buf, 256))
+    return buf.value.decode()
+
+
+def encode(seqs):
+    """list of str -> (uint8 residues, uint64 offsets[n+1])"""
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+    joined = "".join(seqs).encode()
+    out = np.zeros(max(1, len(joined)), dtype=np.uint8)
+    lib().mk_encode(joined, C.c_size_t(len(joined)), out.ctypes.data_as(C.c_void_p))
+    return out, off
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class TargetDB:
+    def __init__(self, seqs, params=None):
+        self.params = params or default_params()
+        self.res, self.off = encode(seqs)
+        self.n = len(seqs)
+        self.h = C.c_void_p()
+        _chk(lib().mk_targetdb_create(_p(self.res), _p(self.off), C.c_uint32(self.n), C.byref(self.params), C.byref(self.h)))
+
+    def masked(self):
+        out = np.zeros(max(1, int(self.off[-1])), dtype=np.uint8)
+        _chk(lib().mk_targetdb_masked(self.h, _p(out)))
+        return out
+
+    def index_entries(self):
+        return int(lib().mk_targetdb_index_entries(self.h))
+
+    def close(self):
+        if self.h:
+            lib().mk_targetdb_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Queries:
+    def __init__(self, seqs, params=None):
+        self.params = params or default_params()
+        self.res, self.off = encode(seqs)
+        self.n = len(seqs)
+        self.h = C.c_void_p()
+        _chk(lib().mk_queries_create(_p(self.res), _p(self.off), C.c_uint32(self.n), C.byref(self.params), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().mk_queries_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def prefilter(db, q, params=None):
+    p = params or db.params
+    hits = np.zeros(q.n * p.max_seqs, dtype=HIT_DTYPE)
+    counts = np.zeros(q.n, dtype=np.uint32)
+    _chk(lib().mk_prefilter(db.h, q.h, C.byref(p), _p(hits), _p(counts)))
+    return hits.reshape(q.n, p.max_seqs), counts
+
+
+def align(db, q, hits, counts, params=None):
+    p = params or db.params
+    total = int(counts.sum())
+    out = (Alignment * max(1, total))()
+    out_counts = np.zeros(q.n, dtype=np.uint32)
+    hits = np.ascontiguousarray(hits)
+    _chk(lib().mk_align(db.h, q.h, C.byref(p), _p(hits), _p(counts), C.c_uint32(hits.shape[1]), out, _p(out_counts)))
+    return out, out_counts
+
+
+def sw_pairs(db, q, q_idx, t_idx, with_start=True, params=None):
+    p = params or db.params
+    q_idx = np.ascontiguousarray(q_idx, dtype=np.uint32)
+    t_idx = np.ascontiguousarray(t_idx, dtype=np.uint32)
+    out = np.zeros((len(q_idx), 5), dtype=np.int32)
+    _chk(lib().mk_sw_pairs(db.h, q.h, C.byref(p), _p(q_idx), _p(t_idx), C.c_uint64(len(q_idx)), C.c_int(1 if with_start else 0), _p(out)))
+    return out
+
+
+def ungapped(db, q, q_idx, t_idx, diag):
+    q_idx = np.ascontiguousarray(q_idx, dtype=np.uint32)
+    t_idx = np.ascontiguousarray(t_idx, dtype=np.uint32)
+    diag = np.ascontiguousarray(diag, dtype=np.uint16)
+    out = np.zeros(len(q_idx), dtype=np.int32)
+    _chk(lib().mk_ungapped(db.h, q.h, _p(q_idx), _p(t_idx), _p(diag), C.c_uint64(len(q_idx)), _p(out)))
+    return out
+
+
+def kernel_stats(reset=False):
+    arr = (KernelStat * 64)()
+    n = lib().mk_kernel_stats(arr, 64)
+    res = {arr[i].name.decode(): dict(ms=arr[i].ms, launches=int(arr[i].launches), alg_bytes=arr[i].alg_bytes, cells=arr[i].cells)
+           for i in range(n)}
+    if reset:
+        lib().mk_kernel_stats_reset()
+    return res
+
+
+def format_hits(hits_row, count, key_of=None):
+    buf = C.create_string_buffer(64)
+    out = []
+    for h in hits_row[:count]:
+        key = int(h["seq_id"]) if key_of is None else key_of(int(h["seq_id"]))
+        n = lib().mk_format_hit(buf, C.c_uint32(key), C.c_int32(int(h["pref_score"])), C.c_uint16(int(h["diagonal"])))
+        out.append(buf.raw[:n].decode())
+    return "".join(out)
+
+
+def format_alignments(alns, start, count):
+    buf = C.create_string_buffer(256)
+    out = []
+    for i in range(start, start + count):
+        n = lib().mk_format_alignment(buf, C.byref(alns[i]))
+        out.append(buf.raw[:n].decode())
+    return "".join(out)

@@ -1,0 +1,48 @@
+"""Builds metaeuk_amd/lib/libmetaeuk_amd.so (HIP kernels + C ABI) for gfx950 with hipcc.
+
+The extension is built IN-TREE so that it travels with the repository snapshot to the GPU box.
+hipcc cross-compiles for gfx950 without a GPU being present.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = [os.path.join(HERE, "csrc", f) for f in ("mk_host.cpp", "mk_abi.cpp", "mk_sw.hip", "mk_prefilter.hip", "mk_cli.cpp")]
+HDR = [os.path.join(HERE, "csrc", f) for f in ("mk_host.hpp", "mk_kernels.hpp", "mk_prefilter.hpp", "mk_dbio.hpp")] + [
+    os.path.join(HERE, "..", "include", "metaeuk_amd.h"), os.path.join(HERE, "data", "matrices.inc")]
+LIB = os.path.join(HERE, "lib", "libmetaeuk_amd.so")
+BIN = os.path.join(HERE, "lib", "metaeuk-amd")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fopenmp", "-ffp-contract=off",
+         "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    srcs = [s for s in SRC if os.path.exists(s)]
+    lib_srcs = [s for s in srcs if not s.endswith("mk_cli.cpp")]
+    if force or _stale(LIB, lib_srcs + HDR):
+        cmd = [hipcc] + FLAGS + ["-shared"] + lib_srcs + ["-o", LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    cli = os.path.join(HERE, "csrc", "mk_cli.cpp")
+    if os.path.exists(cli) and (force or _stale(BIN, [cli, LIB] + HDR)):
+        cmd = [hipcc] + FLAGS + [cli, "-o", BIN, "-L" + os.path.dirname(LIB), "-lmetaeuk_amd", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    print(LIB)

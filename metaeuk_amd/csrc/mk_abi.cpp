@@ -1,0 +1,517 @@
+// metaeuk_amd/csrc/mk_abi.cpp -- C ABI (include/metaeuk_amd.h) over the HIP kernels.
+// One process drives one GPU (mk_init); all device work goes through one HIP stream owned by the
+// library.  There is NO CPU fallback for the kernels: without a usable HIP device every compute
+// entry point fails with MK_ERR_DEVICE.
+#include "../../include/metaeuk_amd.h"
+#include "mk_host.hpp"
+#include "mk_kernels.hpp"
+#include "mk_prefilter.hpp"
+
+#include <algorithm>
+#include <climits>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(MK_ERR_DEVICE, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+bool g_ready = false;
+int g_device = -1;
+hipStream_t g_stream = nullptr;
+
+struct StatAcc { double ms = 0; uint64_t launches = 0; double bytes = 0; double cells = 0; };
+std::map<std::string, StatAcc> g_stats;
+std::vector<std::string> g_statNames;   // stable storage for names handed out
+
+struct Timed {
+    hipEvent_t a{}, b{};
+    std::string name; double bytes; double cells;
+};
+std::vector<Timed> g_pending;
+
+int timed_begin(const char *name, double bytes, double cells) {
+    Timed t; t.name = name; t.bytes = bytes; t.cells = cells;
+    if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return -1;
+    hipEventRecord(t.a, g_stream);
+    g_pending.push_back(t);
+    return (int) g_pending.size() - 1;
+}
+void timed_end(int h) { if (h >= 0) hipEventRecord(g_pending[h].b, g_stream); }
+void timed_flush() {
+    for (Timed &t : g_pending) {
+        float ms = 0;
+        hipEventSynchronize(t.b);
+        hipEventElapsedTime(&ms, t.a, t.b);
+        StatAcc &s = g_stats[t.name];
+        s.ms += ms; s.launches += 1; s.bytes += t.bytes; s.cells += t.cells;
+        hipEventDestroy(t.a); hipEventDestroy(t.b);
+    }
+    g_pending.clear();
+}
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr; size_t n = 0;
+    ~DevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t count) {
+        if (p) { hipFree(p); p = nullptr; }
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+    }
+    hipError_t upload(const T *h, size_t count) {
+        hipError_t e = alloc(count);
+        if (e != hipSuccess || count == 0) return e;
+        return hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, g_stream);
+    }
+};
+
+}  // namespace
+
+struct mk_targetdb {
+    uint32_t n = 0;
+    std::vector<uint64_t> off;
+    std::vector<uint8_t> maskedHost;
+    mk::SubMat kmerMat, ungMat, alnMat;
+    mk::Evaluer evaluer;
+    int kmerThr = 0;
+    uint64_t nEntries = 0;
+    DevBuf<uint8_t> dRes, dMasked;
+    DevBuf<uint64_t> dOff;
+    DevBuf<uint32_t> dKmerOff;       // 20^6 + 1 (entries < 2^32)
+    DevBuf<uint64_t> dEntries;       // seqId | pos << 32
+    DevBuf<int16_t> dScore3;
+    DevBuf<uint16_t> dIndex3;
+    DevBuf<int8_t> dMatAln, dMatUng;
+};
+
+struct mk_queries {
+    uint32_t n = 0;
+    std::vector<uint64_t> off;
+    std::vector<uint8_t> res;
+    mk::QueryDerived der;
+    DevBuf<uint8_t> dRes;
+    DevBuf<uint64_t> dOff;
+    DevBuf<int16_t> dKmerThr;
+    DevBuf<int8_t> dCorr, dBias8;
+};
+
+namespace {
+
+int ensure_ready() {
+    if (!g_ready) return fail(MK_ERR_DEVICE, "mk_init() was not called or no HIP device is usable");
+    return MK_OK;
+}
+
+// ---- Smith-Waterman batches ---------------------------------------------------------------------
+struct PairRes { int score, qEnd, tEnd, qStart, tStart; bool word; };
+
+int bucket_of(uint32_t qLen) { return qLen <= 32 ? 0 : qLen <= 64 ? 1 : qLen <= 128 ? 2 : qLen <= 256 ? 3 : 4; }
+const int BUCKET_G[5] = {16, 16, 16, 16, 64};
+const int BUCKET_R[5] = {2, 4, 8, 16, 16};
+
+// run `jobs` (any order) through the right kernel variants; out[i] corresponds to jobs[i]
+int run_sw_jobs(const mk_targetdb *db, const mk_queries *q, const mk_params *P, std::vector<mk::SwJob> &jobs,
+                std::vector<mk::SwOut> &out, const char *statName) {
+    const size_t n = jobs.size();
+    out.assign(n, mk::SwOut{0, -1, -1, 0});
+    if (n == 0) return MK_OK;
+    // counting sort by (bucket, target length class) so that the DPs sharing a wave have similar lengths
+    const int CLS = 512;
+    std::vector<uint32_t> hist(5 * CLS + 1, 0);
+    auto keyOf = [&](const mk::SwJob &j) { return (uint32_t) (bucket_of(j.q_len) * CLS + (CLS - 1 - std::min<uint32_t>(j.t_len / 64, CLS - 1))); };
+    for (const mk::SwJob &j : jobs) hist[keyOf(j) + 1]++;
+    for (size_t k = 0; k < hist.size() - 1; k++) hist[k + 1] += hist[k];
+    std::vector<uint32_t> bucketStart(6);
+    for (int b = 0; b <= 5; b++) bucketStart[b] = hist[std::min<size_t>((size_t) b * CLS, hist.size() - 1)];
+    std::vector<uint32_t> order(n);
+    std::vector<mk::SwJob> sorted(n);
+    {
+        std::vector<uint32_t> cur(hist.begin(), hist.end() - 1);
+        for (size_t i = 0; i < n; i++) { const uint32_t p = cur[keyOf(jobs[i])]++; order[p] = (uint32_t) i; sorted[p] = jobs[i]; }
+    }
+    DevBuf<mk::SwJob> dJobs;
+    DevBuf<mk::SwOut> dOut;
+    HIPCHK(dJobs.upload(sorted.data(), n));
+    HIPCHK(dOut.alloc(n));
+    DevBuf<uint2> dBorder;
+    for (int b = 0; b < 5; b++) {
+        const uint32_t lo = bucketStart[b], hi = bucketStart[b + 1];
+        if (hi == lo) continue;
+        mk::SwLaunch L;
+        L.q_res = q->dRes.p; L.q_bias8 = q->dBias8.p; L.t_res = db->dRes.p; L.mat = db->dMatAln.p;
+        L.jobs = dJobs.p + lo; L.out = dOut.p + lo; L.n_jobs = hi - lo;
+        L.boundary = nullptr; L.boundary_stride = 0;
+        L.gap_open = P->gap_open; L.gap_extend = P->gap_extend;
+        double cells = 0, bytes = 0;
+        uint32_t maxT = 0; bool multi = false;
+        for (uint32_t i = lo; i < hi; i++) {
+            cells += (double) sorted[i].q_len * (double) sorted[i].t_len;
+            bytes += (double) sorted[i].t_len + 2.0 * sorted[i].q_len + sizeof(mk::SwJob) + sizeof(mk::SwOut);
+            maxT = std::max(maxT, sorted[i].t_len);
+            if (sorted[i].q_len > (uint32_t) (BUCKET_G[b] * BUCKET_R[b])) multi = true;
+        }
+        if (multi) {
+            HIPCHK(dBorder.alloc((size_t) (hi - lo) * maxT));
+            L.boundary = dBorder.p; L.boundary_stride = maxT;
+        }
+        char nm[64];
+        snprintf(nm, sizeof(nm), "%s_g%dr%d", statName, BUCKET_G[b], BUCKET_R[b]);
+        const int th = timed_begin(nm, bytes, cells);
+        HIPCHK(mk::launch_sw(L, BUCKET_G[b], BUCKET_R[b], g_stream));
+        timed_end(th);
+    }
+    std::vector<mk::SwOut> tmp(n);
+    HIPCHK(hipMemcpyAsync(tmp.data(), dOut.p, n * sizeof(mk::SwOut), hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    timed_flush();
+    for (size_t p = 0; p < n; p++) out[order[p]] = tmp[p];
+    return MK_OK;
+}
+
+// forward (byte semantics, then word semantics where the byte pass would have saturated) and, for the
+// pairs flagged in needStart, the reverse pass.  ssw_align_private<SEQ_SEQ> (StripedSmithWaterman.cpp:309-545)
+int sw_pairs(const mk_targetdb *db, const mk_queries *q, const mk_params *P, const uint32_t *qIdx, const uint32_t *tIdx,
+             size_t n, const std::vector<uint8_t> *needStartIn, std::vector<PairRes> &res,
+             std::vector<uint8_t> *needStartOut = nullptr, bool (*decide)(void *, size_t, const PairRes &) = nullptr, void *ctx = nullptr) {
+    res.assign(n, PairRes{0, -1, -1, -1, -1, false});
+    const int LB = P->simd_lanes_byte, LW = P->simd_lanes_word;
+    std::vector<mk::SwJob> jobs(n);
+    for (size_t p = 0; p < n; p++) {
+        if (qIdx[p] >= q->n || tIdx[p] >= db->n) return fail(MK_ERR_ARG, "pair %zu out of range", p);
+        mk::SwJob &j = jobs[p];
+        j.q_start = (uint32_t) q->off[qIdx[p]]; j.q_len = (uint32_t) (q->off[qIdx[p] + 1] - q->off[qIdx[p]]);
+        j.t_start = db->off[tIdx[p]]; j.t_len = (uint32_t) (db->off[tIdx[p] + 1] - db->off[tIdx[p]]);
+        j.q_step = 1; j.t_step = 1;
+        j.seg_len = (j.q_len + LB - 1) / LB;
+    }
+    std::vector<mk::SwOut> out;
+    int rc = run_sw_jobs(db, q, P, jobs, out, "sw_fwd");
+    if (rc != MK_OK) return rc;
+    std::vector<size_t> redo;
+    for (size_t p = 0; p < n; p++) {
+        res[p].score = out[p].score; res[p].tEnd = out[p].end_col; res[p].qEnd = out[p].end_row;
+        if (out[p].score + q->der.swBias[qIdx[p]] >= 255) redo.push_back(p);    // sw_sse2_byte overflow (:879-883)
+    }
+    if (!redo.empty()) {
+        std::vector<mk::SwJob> j2(redo.size());
+        for (size_t k = 0; k < redo.size(); k++) { j2[k] = jobs[redo[k]]; j2[k].seg_len = (j2[k].q_len + LW - 1) / LW; }
+        std::vector<mk::SwOut> o2;
+        rc = run_sw_jobs(db, q, P, j2, o2, "sw_fwd_word");
+        if (rc != MK_OK) return rc;
+        for (size_t k = 0; k < redo.size(); k++) {
+            PairRes &r = res[redo[k]];
+            r.score = o2[k].score; r.tEnd = o2[k].end_col; r.qEnd = o2[k].end_row; r.word = true;
+        }
+    }
+    // which pairs need start positions
+    std::vector<size_t> rev;
+    for (size_t p = 0; p < n; p++) {
+        bool need = needStartIn ? (*needStartIn)[p] != 0 : (decide ? decide(ctx, p, res[p]) : false);
+        if (needStartOut) (*needStartOut)[p] = need;
+        if (need && res[p].score > 0) rev.push_back(p);
+    }
+    if (!rev.empty()) {
+        std::vector<mk::SwJob> j3(rev.size());
+        for (size_t k = 0; k < rev.size(); k++) {
+            const size_t p = rev[k];
+            const PairRes &r = res[p];
+            mk::SwJob &j = j3[k];
+            j.q_len = (uint32_t) r.qEnd + 1; j.t_len = (uint32_t) r.tEnd + 1;
+            j.q_start = jobs[p].q_start + (uint32_t) r.qEnd; j.q_step = -1;
+            j.t_start = jobs[p].t_start + (uint64_t) r.tEnd; j.t_step = -1;
+            const int lanes = r.word ? LW : LB;
+            j.seg_len = (j.q_len + lanes - 1) / lanes;
+        }
+        std::vector<mk::SwOut> o3;
+        rc = run_sw_jobs(db, q, P, j3, o3, "sw_rev");
+        if (rc != MK_OK) return rc;
+        for (size_t k = 0; k < rev.size(); k++) {
+            PairRes &r = res[rev[k]];
+            if (o3[k].score != r.score)
+                return fail(MK_ERR_SW_MISMATCH, "Score of forward/backward SW differ: %d %d (pair %zu)", r.score, o3[k].score, rev[k]);
+            r.tStart = r.tEnd - o3[k].end_col;
+            r.qStart = r.qEnd - o3[k].end_row;
+        }
+    }
+    return MK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mk_last_error(void) { return g_err.c_str(); }
+
+int mk_init(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return fail(MK_ERR_DEVICE, "no HIP device visible (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(MK_ERR_ARG, "device ordinal %d out of range (%d devices)", device, count);
+    HIPCHK(hipSetDevice(device));
+    if (!g_stream) HIPCHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_device = device;
+    g_ready = true;
+    return MK_OK;
+}
+
+int mk_device_name(char *buf, size_t cap) {
+    int rc = ensure_ready();
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, g_device));
+    snprintf(buf, cap, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return MK_OK;
+}
+
+void mk_default_params(mk_params *p) {
+    p->sensitivity = 5.7f; p->kmer_score = INT_MAX; p->max_seqs = 300; p->min_ungapped_score = 15;
+    p->comp_bias_corr = 1; p->comp_bias_scale = 1.0f; p->mask = 1; p->mask_prob = 0.9f;
+    p->gap_open = 11; p->gap_extend = 1; p->evalue_thr = 100.0; p->min_aln_len = 11;
+    p->simd_lanes_byte = 32; p->simd_lanes_word = 16; p->simd_lanes_double = 4;
+    p->host_l2_bytes = 1048576;
+}
+
+void mk_encode(const char *ascii, size_t len, uint8_t *codes) { mk::encode(ascii, len, codes); }
+
+int mk_targetdb_create(const uint8_t *residues, const uint64_t *offsets, uint32_t n, const mk_params *P, mk_targetdb **out) {
+    int rc = ensure_ready();
+    if (rc) return rc;
+    if (!residues || !offsets || !P || !out) return fail(MK_ERR_ARG, "null argument");
+    mk_targetdb *db = new mk_targetdb();
+    db->n = n;
+    db->off.assign(offsets, offsets + n + 1);
+    for (uint32_t i = 0; i < n; i++)
+        if (offsets[i + 1] - offsets[i] >= 32768) { delete db; return fail(MK_ERR_UNSUPPORTED, "target %u is >= 32768 residues: the reference's wrapped-diagonal path (UngappedAlignment.cpp:312-329) is not restated", i); }
+    mk::build_submat(db->kmerMat, mk::MAT_VTML80, 8.0f, -0.2f);     // Prefiltering.cpp:68
+    mk::build_submat(db->ungMat, mk::MAT_BLOSUM62, 2.0f, -0.2f);    // Prefiltering.cpp:69
+    mk::build_submat(db->alnMat, mk::MAT_BLOSUM62, 2.0f, 0.0f);     // Alignment.cpp:152
+    db->kmerThr = mk::kmer_threshold(P->sensitivity, P->kmer_score);
+    db->evaluer.init(offsets[n]);
+    mk::TargetIndex ix;
+    mk::build_index(db->kmerMat, residues, offsets, n, db->kmerThr, P->mask != 0, P->mask_prob, P->simd_lanes_double, ix);
+    if (ix.entries.size() >= 0xFFFFFFFFull) { delete db; return fail(MK_ERR_UNSUPPORTED, "index has >= 2^32 entries"); }
+    db->nEntries = ix.entries.size();
+    db->maskedHost = ix.masked;
+    std::vector<uint32_t> off32(ix.offsets.size());
+    for (size_t k = 0; k < ix.offsets.size(); k++) off32[k] = (uint32_t) ix.offsets[k];
+    mk::ScoreMat3 sm;
+    mk::build_scoremat3(db->kmerMat, sm);
+    int8_t matAln[441], matUng[441];
+    for (int i = 0; i < 21; i++)
+        for (int j = 0; j < 21; j++) { matAln[i * 21 + j] = (int8_t) db->alnMat.sub[i][j]; matUng[i * 21 + j] = (int8_t) db->ungMat.sub[i][j]; }
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; };
+    ok(db->dRes.upload(residues, offsets[n]));
+    ok(db->dMasked.upload(ix.masked.data(), ix.masked.size()));
+    ok(db->dOff.upload(offsets, n + 1));
+    ok(db->dKmerOff.upload(off32.data(), off32.size()));
+    ok(db->dEntries.upload(ix.entries.data(), ix.entries.size()));
+    ok(db->dScore3.upload(sm.score.data(), sm.score.size()));
+    ok(db->dIndex3.upload(sm.index.data(), sm.index.size()));
+    ok(db->dMatAln.upload(matAln, 441));
+    ok(db->dMatUng.upload(matUng, 441));
+    ok(hipStreamSynchronize(g_stream));
+    if (e != hipSuccess) { delete db; return fail(MK_ERR_DEVICE, "target upload failed: %s", hipGetErrorString(e)); }
+    *out = db;
+    return MK_OK;
+}
+
+void mk_targetdb_destroy(mk_targetdb *db) { delete db; }
+uint64_t mk_targetdb_residues(const mk_targetdb *db) { return db ? db->off[db->n] : 0; }
+uint64_t mk_targetdb_index_entries(const mk_targetdb *db) { return db ? db->nEntries : 0; }
+int mk_targetdb_masked(const mk_targetdb *db, uint8_t *out) {
+    if (!db || !out) return fail(MK_ERR_ARG, "null argument");
+    std::memcpy(out, db->maskedHost.data(), db->maskedHost.size());
+    return MK_OK;
+}
+
+int mk_queries_create(const uint8_t *residues, const uint64_t *offsets, uint32_t n, const mk_params *P, mk_queries **out) {
+    int rc = ensure_ready();
+    if (rc) return rc;
+    if (!residues || !offsets || !P || !out) return fail(MK_ERR_ARG, "null argument");
+    if (offsets[n] >= 0xFFFFFFFFull) return fail(MK_ERR_ARG, "query batch too large (>= 2^32 residues): split it");
+    mk_queries *q = new mk_queries();
+    q->n = n;
+    q->off.assign(offsets, offsets + n + 1);
+    q->res.assign(residues, residues + offsets[n]);
+    for (uint32_t i = 0; i < n; i++)
+        if (offsets[i + 1] - offsets[i] >= 32768) { delete q; return fail(MK_ERR_UNSUPPORTED, "query %u is >= 32768 residues", i); }
+    mk::SubMat kmerMat, alnMat;
+    mk::build_submat(kmerMat, mk::MAT_VTML80, 8.0f, -0.2f);
+    mk::build_submat(alnMat, mk::MAT_BLOSUM62, 2.0f, 0.0f);
+    mk::derive_queries(kmerMat, alnMat, residues, offsets, n, mk::kmer_threshold(P->sensitivity, P->kmer_score),
+                       P->comp_bias_corr != 0, P->comp_bias_scale, q->der);
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; };
+    ok(q->dRes.upload(residues, offsets[n]));
+    ok(q->dOff.upload(offsets, n + 1));
+    ok(q->dKmerThr.upload(q->der.kmerThr.data(), q->der.kmerThr.size()));
+    ok(q->dCorr.upload(q->der.diagCorr.data(), q->der.diagCorr.size()));
+    ok(q->dBias8.upload(q->der.swBias8.data(), q->der.swBias8.size()));
+    ok(hipStreamSynchronize(g_stream));
+    if (e != hipSuccess) { delete q; return fail(MK_ERR_DEVICE, "query upload failed: %s", hipGetErrorString(e)); }
+    *out = q;
+    return MK_OK;
+}
+
+void mk_queries_destroy(mk_queries *q) { delete q; }
+
+int mk_sw_pairs(mk_targetdb *db, mk_queries *q, const mk_params *P, const uint32_t *qIdx, const uint32_t *tIdx,
+                uint64_t n, int withStart, int32_t *out5) {
+    int rc = ensure_ready();
+    if (rc) return rc;
+    if (!db || !q || !P || !out5) return fail(MK_ERR_ARG, "null argument");
+    std::vector<PairRes> res;
+    std::vector<uint8_t> need(n, withStart ? 1 : 0);
+    rc = sw_pairs(db, q, P, qIdx, tIdx, n, &need, res);
+    if (rc) return rc;
+    for (uint64_t p = 0; p < n; p++) {
+        out5[p * 5 + 0] = res[p].score; out5[p * 5 + 1] = res[p].qEnd; out5[p * 5 + 2] = res[p].tEnd;
+        out5[p * 5 + 3] = res[p].qStart; out5[p * 5 + 4] = res[p].tStart;
+    }
+    return MK_OK;
+}
+
+int mk_ungapped(mk_targetdb *db, mk_queries *q, const uint32_t *qIdx, const uint32_t *tIdx, const uint16_t *diag, uint64_t n, int32_t *outScores) {
+    int rc = ensure_ready();
+    if (rc) return rc;
+    if (!db || !q || !outScores) return fail(MK_ERR_ARG, "null argument");
+    std::vector<mk::UngappedJob> jobs(n);
+    double bytes = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (qIdx[i] >= q->n || tIdx[i] >= db->n) return fail(MK_ERR_ARG, "candidate %llu out of range", (unsigned long long) i);
+        mk::UngappedJob &j = jobs[i];
+        j.q_start = (uint32_t) q->off[qIdx[i]]; j.q_len = (uint32_t) (q->off[qIdx[i] + 1] - q->off[qIdx[i]]);
+        j.t_start = db->off[tIdx[i]]; j.t_len = (uint32_t) (db->off[tIdx[i] + 1] - db->off[tIdx[i]]);
+        j.diagonal = diag[i];
+        bytes += sizeof(mk::UngappedJob) + 4 + std::min(j.q_len, j.t_len);
+    }
+    DevBuf<mk::UngappedJob> dJobs;
+    DevBuf<int32_t> dOut;
+    HIPCHK(dJobs.upload(jobs.data(), n));
+    HIPCHK(dOut.alloc(n));
+    mk::UngappedLaunch L;
+    L.q_res = q->dRes.p; L.q_corr = q->dCorr.p; L.t_masked = db->dMasked.p; L.mat = db->dMatUng.p;
+    L.jobs = dJobs.p; L.out = dOut.p; L.n_jobs = n;
+    const int th = timed_begin("ungapped", bytes, 0);
+    HIPCHK(mk::launch_ungapped(L, g_stream));
+    timed_end(th);
+    HIPCHK(hipMemcpyAsync(outScores, dOut.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    timed_flush();
+    return MK_OK;
+}
+
+int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *P, mk_hit *outHits, uint32_t *outCounts) {
+    int rc = ensure_ready();
+    if (rc) return rc;
+    if (!db || !q || !P || !outHits || !outCounts) return fail(MK_ERR_ARG, "null argument");
+    mk::PrefilterDeviceView V;
+    V.q_res = q->dRes.p; V.q_off = q->dOff.p; V.q_kmer_thr = q->dKmerThr.p; V.q_corr = q->dCorr.p; V.n_queries = q->n;
+    V.t_masked = db->dMasked.p; V.t_off = db->dOff.p; V.n_targets = db->n;
+    V.kmer_off = db->dKmerOff.p; V.entries = db->dEntries.p; V.score3 = db->dScore3.p; V.index3 = db->dIndex3.p;
+    V.mat_ung = db->dMatUng.p;
+    std::string err;
+    const int binCount = mk::bin_count_for(db->n, P->host_l2_bytes);
+    rc = mk::run_prefilter(V, q->off, q->res, q->der.diagCorr.data(), db->off, *P, binCount, g_stream, outHits, outCounts, err,
+                           [](const char *name, double bytes, double cells) { return timed_begin(name, bytes, cells); },
+                           [](int h) { timed_end(h); });
+    timed_flush();
+    if (rc != MK_OK) return fail(rc, "%s", err.c_str());
+    return MK_OK;
+}
+
+int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *P, const mk_hit *hits, const uint32_t *counts, uint32_t stride,
+             mk_alignment *out, uint32_t *outCounts) {
+    int rc = ensure_ready();
+    if (rc) return rc;
+    if (!db || !q || !P || !hits || !counts || !out || !outCounts) return fail(MK_ERR_ARG, "null argument");
+    std::vector<uint32_t> qIdx, tIdx;
+    std::vector<uint64_t> first(q->n + 1, 0);
+    for (uint32_t i = 0; i < q->n; i++) {
+        first[i] = qIdx.size();
+        for (uint32_t h = 0; h < counts[i]; h++) { qIdx.push_back(i); tIdx.push_back(hits[(size_t) i * stride + h].seq_id); }
+    }
+    first[q->n] = qIdx.size();
+    const size_t n = qIdx.size();
+    struct Ctx { const mk_targetdb *db; const mk_queries *q; const mk_params *P; const uint32_t *qIdx; std::vector<double> ev; } ctx{db, q, P, qIdx.data(), std::vector<double>(n, 0.0)};
+    std::vector<PairRes> res;
+    std::vector<uint8_t> need(n, 0);
+    // reverse pass only where the e-value gate passes (ssw_align_private :390-398, covThr = 0)
+    rc = sw_pairs(db, q, P, qIdx.data(), tIdx.data(), n, nullptr, res, &need,
+                  [](void *c, size_t p, const PairRes &r) -> bool {
+                      Ctx *x = static_cast<Ctx *>(c);
+                      if (r.score <= 0) return false;
+                      const uint32_t qi = x->qIdx[p];
+                      const double qLen = (double) (x->q->off[qi + 1] - x->q->off[qi]);
+                      x->ev[p] = x->db->evaluer.evalue((double) r.score, qLen);
+                      return !(x->ev[p] > x->P->evalue_thr);
+                  }, &ctx);
+    if (rc) return rc;
+    // Matcher::getSWResult (Matcher.cpp:60-142) + Alignment::checkCriteria (Alignment.cpp:548-567) + sort (:403-405)
+    size_t w = 0;
+    for (uint32_t i = 0; i < q->n; i++) {
+        const size_t begin = w;
+        const int qLen = (int) (q->off[i + 1] - q->off[i]);
+        for (uint64_t p = first[i]; p < first[i + 1]; p++) {
+            const PairRes &r = res[p];
+            if (r.score <= 0 || !need[p]) continue;       // e-value above threshold: rejected by checkCriteria
+            const uint32_t t = tIdx[p];
+            const int tLen = (int) (db->off[t + 1] - db->off[t]);
+            mk_alignment a;
+            a.db_key = t; a.q_len = qLen; a.db_len = tLen; a.raw_score = r.score;
+            a.evalue = ctx.ev[p];
+            a.qcov = mk::compute_cov((unsigned) r.qStart, (unsigned) r.qEnd, (unsigned) qLen);
+            a.dbcov = mk::compute_cov((unsigned) r.tStart, (unsigned) r.tEnd, (unsigned) tLen);
+            a.q_start = r.qStart; a.q_end = r.qEnd; a.db_start = r.tStart; a.db_end = r.tEnd;
+            a.aln_len = std::max(std::abs(r.qEnd - r.qStart), std::abs(r.tEnd - r.tStart)) + 1;
+            const unsigned int qAln = std::max((unsigned) r.qEnd - (unsigned) r.qStart, 1u);
+            const unsigned int dbAln = std::max((unsigned) r.tEnd - (unsigned) r.tStart, 1u);
+            const uint16_t s16 = (uint16_t) r.score;
+            float sid = (s16 / static_cast<float>(std::max(qAln, dbAln))) * 0.1656 + 0.1141;   // Matcher.cpp:160-164
+            sid = std::min(sid, 1.0f);
+            a.seq_id = std::max(0.0f, sid);
+            a.bit_score = static_cast<int>(db->evaluer.bitScore((double) r.score) + 0.5);
+            if (a.evalue <= P->evalue_thr && a.aln_len >= P->min_aln_len) out[w++] = a;
+        }
+        if (w - begin > 1) std::sort(out + begin, out + w, mk::alignment_less);
+        outCounts[i] = (uint32_t) (w - begin);
+    }
+    return MK_OK;
+}
+
+int mk_kernel_stats(mk_kernel_stat *out, int cap) {
+    int k = 0;
+    g_statNames.clear();
+    for (auto &kv : g_stats) g_statNames.push_back(kv.first);
+    for (auto &kv : g_stats) {
+        if (k >= cap) break;
+        out[k].name = g_statNames[k].c_str();
+        out[k].ms = kv.second.ms; out[k].launches = kv.second.launches; out[k].alg_bytes = kv.second.bytes; out[k].cells = kv.second.cells;
+        k++;
+    }
+    return k;
+}
+void mk_kernel_stats_reset(void) { g_stats.clear(); }
+
+size_t mk_format_hit(char *buf, uint32_t key, int32_t score, uint16_t diag) { return mk::format_hit(buf, key, score, diag); }
+size_t mk_format_alignment(char *buf, const mk_alignment *a) { return mk::format_alignment(buf, *a); }
+
+}  // extern "C"

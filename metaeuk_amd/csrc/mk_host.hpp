@@ -1,0 +1,82 @@
+// metaeuk_amd/csrc/mk_host.hpp -- host-side (CPU) pieces of the prefilter+align path that are
+// not kernels: substitution matrices, sequence encoding, composition bias, the similar-3-mer
+// table, tantan masking + k-mer index construction, ALP e-values, per-query hit selection and
+// result formatting.  Each function mirrors one reference routine (cited in mk_host.cpp); all
+// floating-point expressions keep the reference's float/double mix because their rounded
+// results feed integer decisions that must be bit-exact.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "../../include/metaeuk_amd.h"
+
+namespace mk {
+
+constexpr int ALPH = 21;       // 20 amino acids + X
+constexpr int XCODE = 20;
+constexpr int KMER = 6;
+constexpr int SPAN = 10;       // spaced seed 1101010011
+extern const int SPACED6[6];
+
+struct SubMat {
+    short sub[ALPH][ALPH];
+    double prob[ALPH][ALPH];
+    double pback[ALPH];
+    double lambda;
+    std::string name;
+};
+enum { MAT_BLOSUM62 = 0, MAT_VTML80 = 1 };
+void build_submat(SubMat &m, int which, float bitFactor, float scoreBias);
+void encode(const char *s, size_t n, uint8_t *codes);
+void comp_bias(const SubMat &m, const uint8_t *seq, int L, float scale, float *bias);
+int kmer_threshold(float sensitivity, int kmerScoreOverride);
+int bin_count_for(uint64_t dbSize, uint64_t l2Bytes);
+
+// similar-3-mer table: row r (= 3-mer index) lists all 8000 3-mers by descending score
+struct ScoreMat3 {
+    std::vector<int16_t> score;   // [8000][8000]
+    std::vector<uint16_t> index;  // [8000][8000]
+};
+void build_scoremat3(const SubMat &kmerMat, ScoreMat3 &out);
+
+int tantan_mask(const SubMat &kmerMat, uint8_t *seq, int L, double minMaskProb, int lanes);
+
+struct TargetIndex {
+    std::vector<uint64_t> offsets;   // 20^6 + 1
+    std::vector<uint64_t> entries;   // packed: seqId | pos << 32
+    std::vector<uint8_t> masked;     // masked residues (SequenceLookup)
+    uint64_t maskedResidues = 0;
+};
+void build_index(const SubMat &kmerMat, const uint8_t *residues, const uint64_t *seqOff, uint32_t nSeq,
+                 int kmerThr, bool mask, float maskProb, int tantanLanes, TargetIndex &out);
+
+// per-residue query-side arrays consumed by the kernels
+struct QueryDerived {
+    std::vector<int16_t> kmerThr;   // per k-mer start: threshold for the generator, -1 = skip (X / too short)
+    std::vector<int8_t> diagCorr;   // UngappedAlignment aaCorrectionScore
+    std::vector<int8_t> swBias8;    // SmithWaterman composition_bias
+    std::vector<int32_t> swBias;    // per query: byte-mode bias
+};
+void derive_queries(const SubMat &kmerMat, const SubMat &alnMat, const uint8_t *res, const uint64_t *off, uint32_t n,
+                    int kmerThr, bool compBias, float scale, QueryDerived &out);
+
+struct Evaluer {
+    double lambda, K, logK, a_I, b_I, a_J, b_J, alpha_I, beta_I, alpha_J, beta_J, sigma, tau, vi_y_thr, vj_y_thr, c_y_thr, dbRes;
+    void init(uint64_t dbResidues);
+    double evalue(double score, double qLen) const;
+    double bitScore(double score) const;
+};
+
+// candidate diagonal after double-hit detection + scoring
+struct Cand { uint32_t id; uint16_t diag; int32_t score; uint32_t ordinal; };
+// QueryMatcher::matchQuery tail: best diagonal per target, threshold, top-N, sort.  `cands` in canonical
+// hit order (ascending ordinal).  selfScore = exact ungapped self score (only used when saturated).
+int select_hits(std::vector<Cand> &cands, int binCount, int maxHits, int minDiagScore, int selfScore, mk_hit *out);
+
+float compute_cov(unsigned int startPos, unsigned int endPos, unsigned int len);
+size_t format_hit(char *buf, uint32_t key, int32_t score, uint16_t diag);
+size_t format_alignment(char *buf, const mk_alignment &a);
+bool alignment_less(const mk_alignment &a, const mk_alignment &b);
+
+}  // namespace mk

@@ -1,0 +1,31 @@
+// metaeuk_amd/csrc/mk_prefilter.hpp -- device pipeline for the k-mer prefilter
+// (QueryMatcher::match + findDuplicates + UngappedAlignment::align on the GPU).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "../../include/metaeuk_amd.h"
+
+namespace mk {
+
+struct PrefilterDeviceView {
+    // query batch
+    const uint8_t *q_res; const uint64_t *q_off; const int16_t *q_kmer_thr; const int8_t *q_corr; uint32_t n_queries;
+    // target side
+    const uint8_t *t_masked; const uint64_t *t_off; uint32_t n_targets;
+    const uint32_t *kmer_off; const uint64_t *entries;
+    const int16_t *score3; const uint16_t *index3;
+    const int8_t *mat_ung;
+};
+
+typedef int (*timed_begin_fn)(const char *name, double bytes, double cells);
+typedef void (*timed_end_fn)(int handle);
+
+// Runs the whole prefilter for the batch.  q_off_host / t_off_host mirror the device offset arrays.
+int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &q_off_host, const std::vector<uint8_t> &q_res_host,
+                  const int8_t *q_corr_host,
+                  const std::vector<uint64_t> &t_off_host, const mk_params &P, int binCount, hipStream_t stream,
+                  mk_hit *outHits, uint32_t *outCounts, std::string &err, timed_begin_fn tb, timed_end_fn te);
+
+}  // namespace mk

@@ -1,0 +1,228 @@
+// metaeuk_amd/csrc/mk_sw.hip -- gapped Smith-Waterman and ungapped diagonal scoring kernels for
+// gfx950 (wave64).  Replaces SmithWaterman::sw_sse2_byte / sw_sse2_word
+// (M/src/alignment/StripedSmithWaterman.cpp:638-940, 942-1214) and
+// UngappedAlignment::computeSingelSequenceScores (M/src/prefiltering/UngappedAlignment.cpp:416-431).
+//
+// SW design (MI355X-first, not a port of the striped-SIMD layout):
+//   * one DP per G-lane group (G = 16 = one DPP row, or 64 = a whole wave); every lane owns R
+//     consecutive query rows in registers (H, E, best-key per row);
+//   * the group sweeps the target as an anti-diagonal wavefront: at step s lane l is on column s-l;
+//     the three values that cross the lane boundary (H of the last row, the running F, the
+//     "within-stripe" F) and the target residue itself travel lane-to-lane with ONE pair of DPP
+//     row_shr / wave_shr moves per step -- no LDS, no bpermute; lane 0 injects residues/tile borders;
+//   * substitution scores come from an LDS query profile prof[residue][row] (+int8 composition
+//     bias), one ds_read of R bytes per lane per column;
+//   * the running maximum is a packed key (score << 17 | ~column) per row, so the reference's
+//     "first column where the maximum is reached, smallest row in it" needs one v_max_u32 per cell;
+//   * queries longer than G*R rows are processed in row tiles; the bottom row of a tile is parked in
+//     HBM (8 B per column) and re-read by lane 0 of the next tile.
+// Recurrence = the reference's as-implemented semantics (DESIGN.md "SW recurrence"): E is opened from
+// H' (before the lazy-F correction) and the in-column F restarts at every stripe head of the SIMD
+// layout being reproduced (seg_len), so results match the SSE/AVX2 builds bit for bit.
+#include "mk_kernels.hpp"
+
+namespace mk {
+
+template <int G>
+__device__ __forceinline__ uint32_t shift_up(uint32_t top, uint32_t x) {
+    // value held by lane-1 of the same group; lane 0 of the group keeps `top`
+    if constexpr (G == 16) {
+        return (uint32_t) __builtin_amdgcn_update_dpp((int) top, (int) x, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    } else {
+        return (uint32_t) __builtin_amdgcn_update_dpp((int) top, (int) x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    }
+}
+
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+
+template <int R>
+__device__ __forceinline__ void load_scores(const int8_t *p, int (&sc)[R]) {
+    if constexpr (R == 2) {
+        const uint32_t w = *reinterpret_cast<const uint16_t *>(p);
+        sc[0] = (int) (int8_t) (w & 0xFF);
+        sc[1] = (int) (int8_t) (w >> 8);
+    } else {
+        const uint32_t *pw = reinterpret_cast<const uint32_t *>(p);
+#pragma unroll
+        for (int k = 0; k < R / 4; k++) {
+            const uint32_t w = pw[k];
+            sc[4 * k + 0] = (int) (int8_t) (w & 0xFF);
+            sc[4 * k + 1] = (int) (int8_t) ((w >> 8) & 0xFF);
+            sc[4 * k + 2] = (int) (int8_t) ((w >> 16) & 0xFF);
+            sc[4 * k + 3] = (int) (int8_t) (w >> 24);
+        }
+    }
+}
+
+template <int G, int R, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void sw_kernel(SwLaunch L) {
+    constexpr int GPB = BLOCK / G;
+    constexpr int ROWS = G * R;
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    const int lane = threadIdx.x % G;
+    const int grp = threadIdx.x / G;
+    const uint64_t jobId = (uint64_t) blockIdx.x * GPB + grp;
+    const bool have = jobId < L.n_jobs;
+    SwJob job;
+    if (have) job = L.jobs[jobId];
+    else { job.t_start = 0; job.q_start = 0; job.q_len = 0; job.t_len = 0; job.q_step = 1; job.t_step = 1; job.seg_len = 1; }
+    int8_t *prof = smem + (size_t) grp * 22 * ROWS;
+    const int go = L.gap_open, ge = L.gap_extend;
+    const int qLen = (int) job.q_len, tLen = (int) job.t_len;
+    const int segLen = job.seg_len > 0 ? (int) job.seg_len : 1;
+    const int nTiles = (qLen + ROWS - 1) / ROWS;
+    uint2 *border = L.boundary ? L.boundary + jobId * (uint64_t) L.boundary_stride : nullptr;
+
+    uint32_t bestKey = 0;
+    int bestRow = 0;
+    for (int tile = 0; tile < nTiles; tile++) {
+        const int row0 = tile * ROWS;
+        // ---- LDS query profile for this row tile: prof[t][row] = mat[t][q_row] + bias8[q_row] ----
+        for (int idx = lane; idx < 22 * ROWS; idx += G) {
+            const int t = idx / ROWS, row = idx - t * ROWS;
+            const int q = row0 + row;
+            int v = 0;
+            if (t < 21 && q < qLen) {
+                const int64_t qi = (int64_t) job.q_start + (int64_t) q * job.q_step;
+                v = (int) L.mat[t * 21 + L.q_res[qi]] + (int) L.q_bias8[qi];
+            }
+            prof[idx] = (int8_t) v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        int H[R], E[R];
+        uint32_t key[R], keep[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            H[r] = 0; E[r] = 0; key[r] = 0;
+            keep[r] = ((row0 + lane * R + r) % segLen == 0) ? 0u : 0xFFFFFFFFu;   // in-column F restarts at stripe heads
+        }
+        uint32_t out0 = 0, out1 = 21u << 16;   // what this lane hands to lane+1: (H_last | F << 16), (Fm | residue << 16)
+        int hupPrev = 0;
+        const int steps = tLen > 0 ? tLen + G - 1 : 0;
+        const bool readTop = (tile > 0);
+        const bool writeBottom = (tile + 1 < nTiles);
+        for (int s = 0; s < steps; s++) {
+            uint32_t top0 = 0, top1 = 21u << 16;
+            if (lane == 0 && s < tLen) {
+                const uint32_t res = L.t_res[(int64_t) job.t_start + (int64_t) s * job.t_step];
+                uint32_t fm = 0;
+                if (readTop) { const uint2 b = border[s]; top0 = b.x; fm = b.y & 0xFFFFu; }
+                top1 = fm | (res << 16);
+            }
+            const uint32_t in0 = shift_up<G>(top0, out0);
+            const uint32_t in1 = shift_up<G>(top1, out1);
+            const int hup = (int) (in0 & 0xFFFFu);
+            int F = (int) (in0 >> 16);
+            int Fm = (int) (in1 & 0xFFFFu);
+            const uint32_t tres = in1 >> 16;
+            const int c = s - lane;
+            const uint32_t cinv = 0x1FFFFu - (uint32_t) max(c, 0);
+            int sc[R];
+            load_scores<R>(prof + tres * ROWS + lane * R, sc);
+            int dsave = hupPrev;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                int d = min(dsave + sc[r], 32767);             // int16 saturating add of the word pass
+                dsave = H[r];
+                const int fmr = (int) ((uint32_t) Fm & keep[r]);
+                const int hp = max3i(d, E[r], fmr);            // H' (E >= 0 keeps it non-negative)
+                const int h = max(hp, F);                      // H after the lazy-F correction
+                key[r] = max(key[r], ((uint32_t) h << 17) | cinv);
+                const int ho = hp - go;
+                E[r] = max3i(E[r] - ge, ho, 0);
+                F = max3i(F - ge, ho, 0);
+                Fm = max3i(fmr - ge, ho, 0);
+                H[r] = h;
+            }
+            hupPrev = hup;
+            out0 = (uint32_t) H[R - 1] | ((uint32_t) F << 16);
+            out1 = (uint32_t) Fm | (tres << 16);
+            if (writeBottom && lane == G - 1 && c >= 0 && c < tLen) border[c] = make_uint2(out0, (uint32_t) Fm);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (key[r] > bestKey) { bestKey = key[r]; bestRow = row0 + lane * R + r; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- group reduction: largest key, then smallest row ----
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) {
+        const uint32_t ok = (uint32_t) __shfl_xor((int) bestKey, m, G);
+        const int orow = __shfl_xor(bestRow, m, G);
+        if (ok > bestKey || (ok == bestKey && orow < bestRow)) { bestKey = ok; bestRow = orow; }
+    }
+    if (have && lane == 0) {
+        SwOut o;
+        o.score = (int32_t) (bestKey >> 17);
+        o.end_col = o.score > 0 ? (int32_t) (0x1FFFFu - (bestKey & 0x1FFFFu)) : -1;
+        o.end_row = o.score > 0 ? bestRow : -1;
+        o.pad = 0;
+        L.out[jobId] = o;
+    }
+}
+
+template <int G, int R, int BLOCK>
+static hipError_t launch_one(const SwLaunch &L, hipStream_t stream) {
+    constexpr int GPB = BLOCK / G;
+    const size_t lds = (size_t) GPB * 22 * G * R;
+    const uint64_t blocks = (L.n_jobs + GPB - 1) / GPB;
+    if (blocks == 0) return hipSuccess;
+    static bool attr = false;
+    if (!attr && lds > 48 * 1024) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_kernel<G, R, BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((sw_kernel<G, R, BLOCK>), dim3((unsigned) blocks), dim3(BLOCK), lds, stream, L);
+    return hipGetLastError();
+}
+
+hipError_t launch_sw(const SwLaunch &L, int G, int R, hipStream_t stream) {
+    if (G == 16 && R == 2) return launch_one<16, 2, 256>(L, stream);
+    if (G == 16 && R == 4) return launch_one<16, 4, 256>(L, stream);
+    if (G == 16 && R == 8) return launch_one<16, 8, 256>(L, stream);
+    if (G == 16 && R == 16) return launch_one<16, 16, 128>(L, stream);
+    if (G == 64 && R == 16) return launch_one<64, 16, 128>(L, stream);
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ungapped diagonal scoring: one lane per (query, target, diagonal) candidate; exact (unclamped)
+// maximum of the prefix-reset running sum along the diagonal.  The 21x21 matrix sits in LDS; the
+// per-position int8 correction is UngappedAlignment::createProfile's aaCorrectionScore.
+__global__ __launch_bounds__(256) void ungapped_kernel(UngappedLaunch L) {
+    __shared__ int8_t smat[21 * 21 + 3];
+    for (int i = threadIdx.x; i < 21 * 21; i += blockDim.x) smat[i] = L.mat[i];
+    __syncthreads();
+    const uint64_t id = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= L.n_jobs) return;
+    const UngappedJob j = L.jobs[id];
+    const int diag = (int) (short) (uint16_t) j.diagonal;
+    const uint32_t d16 = j.diagonal & 0xFFFFu;
+    const uint32_t dist = min((0x10000u - d16) & 0xFFFFu, d16);   // UngappedAlignment::distanceFromDiagonal
+    uint32_t n = 0, q0 = 0, t0 = 0;
+    if (diag >= 0 && dist < j.q_len) { n = min(j.t_len, j.q_len - dist); q0 = dist; }
+    else if (diag < 0 && dist < j.t_len) { n = min(j.t_len - dist, j.q_len); t0 = dist; }
+    const uint8_t *q = L.q_res + j.q_start + q0;
+    const int8_t *corr = L.q_corr + j.q_start + q0;
+    const uint8_t *t = L.t_masked + j.t_start + t0;
+    int score = 0, best = 0;
+    for (uint32_t k = 0; k < n; k++) {
+        const int curr = (int) (int8_t) (smat[q[k] * 21 + t[k]] + corr[k]);
+        score = max(score + curr, 0);
+        best = max(best, score);
+    }
+    L.out[id] = best;
+}
+
+hipError_t launch_ungapped(const UngappedLaunch &L, hipStream_t stream) {
+    if (L.n_jobs == 0) return hipSuccess;
+    const uint64_t blocks = (L.n_jobs + 255) / 256;
+    hipLaunchKernelGGL(ungapped_kernel, dim3((unsigned) blocks), dim3(256), 0, stream, L);
+    return hipGetLastError();
+}
+
+}  // namespace mk

@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def small_workload():
+    from metaeuk_amd import synth
+    return synth.make_workload(12, 200, seed=7)
+
+
+@pytest.fixture(scope="session")
+def gpu_api():
+    from metaeuk_amd import api
+    api.init(0)
+    return api

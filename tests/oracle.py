@@ -1,0 +1,116 @@
+"""Test-side access to the parity oracle (oracle/): builds it on demand and wraps a few C entry
+points with ctypes.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ODIR, "_build", "liboracle.so")
+CLI = os.path.join(ODIR, "_build", "mko_cli")
+REF = os.path.join(ODIR, "_ref", "ref_harness")
+REF_MATDIR = "/root/reference/lib/mmseqs/data"
+
+
+def build():
+    srcs = [os.path.join(ODIR, f) for f in os.listdir(ODIR) if f.endswith((".c", ".h"))]
+    newest = max(os.path.getmtime(s) for s in srcs)
+    if not (os.path.exists(LIB) and os.path.exists(CLI) and os.path.getmtime(LIB) >= newest and os.path.getmtime(CLI) >= newest):
+        subprocess.check_call(["make", "-C", ODIR, "_build/liboracle.so", "_build/mko_cli"], stdout=subprocess.DEVNULL)
+    return LIB
+
+
+class SubMat(C.Structure):
+    _fields_ = [("sub", (C.c_short * 21) * 21), ("prob", (C.c_double * 21) * 21), ("pback", C.c_double * 21),
+                ("lambda_", C.c_double), ("name", C.c_char_p)]
+
+
+class SwResult(C.Structure):
+    _fields_ = [("score", C.c_int), ("q_end", C.c_int), ("t_end", C.c_int), ("q_start", C.c_int), ("t_start", C.c_int),
+                ("word", C.c_int), ("rev_mismatch", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB)
+    return _lib
+
+
+def submat(which, bit_factor, bias):
+    m = SubMat()
+    lib().mko_submat_init(C.byref(m), C.c_int(which), C.c_float(bit_factor), C.c_float(bias))
+    return m
+
+
+def encode(s):
+    out = np.zeros(max(1, len(s)), dtype=np.uint8)
+    lib().mko_map_sequence(s.encode(), C.c_int(len(s)), out.ctypes.data_as(C.c_void_p))
+    return out[:len(s)]
+
+
+_ALN = None
+
+
+def sw(q, t, lanes_byte=32, lanes_word=16, gap_open=11, gap_extend=1, with_start=True):
+    """oracle SW for two amino-acid strings -> (score, q_end, t_end, q_start, t_start)"""
+    global _ALN
+    if _ALN is None:
+        _ALN = submat(0, 2.0, 0.0)
+    qc, tc = encode(q), encode(t)
+    cb = np.zeros(max(1, len(q)), dtype=np.int8)
+    bias = C.c_int()
+    L = lib()
+    L.mko_sw_query_init(C.byref(_ALN), qc.ctypes.data_as(C.c_void_p), C.c_int(len(q)), C.c_float(1.0), cb.ctypes.data_as(C.c_void_p), C.byref(bias))
+    r = SwResult()
+    L.mko_sw_forward(C.byref(_ALN), qc.ctypes.data_as(C.c_void_p), cb.ctypes.data_as(C.c_void_p), bias, C.c_int(len(q)),
+                     tc.ctypes.data_as(C.c_void_p), C.c_int(len(t)), C.c_int(gap_open), C.c_int(gap_extend), C.c_int(lanes_byte), C.c_int(lanes_word), C.byref(r))
+    if with_start and r.score > 0:
+        L.mko_sw_reverse(C.byref(_ALN), qc.ctypes.data_as(C.c_void_p), cb.ctypes.data_as(C.c_void_p), bias, C.c_int(len(q)),
+                         tc.ctypes.data_as(C.c_void_p), C.c_int(len(t)), C.c_int(gap_open), C.c_int(gap_extend), C.c_int(lanes_byte), C.c_int(lanes_word), C.byref(r))
+    return (r.score, r.q_end, r.t_end, r.q_start, r.t_start, r.rev_mismatch)
+
+
+def run_pipeline(targets, queries, outdir, extra=()):
+    """oracle CLI over sequence lists -> (pref dict, aln dict) keyed by query index"""
+    build()
+    os.makedirs(outdir, exist_ok=True)
+    tf, qf = os.path.join(outdir, "targets.txt"), os.path.join(outdir, "queries.txt")
+    open(tf, "w").write("\n".join(targets) + "\n")
+    open(qf, "w").write("\n".join(queries) + "\n")
+    subprocess.check_call([CLI, "pipeline", tf, qf, os.path.join(outdir, "oracle")] + list(extra), stdout=subprocess.DEVNULL)
+    return read_blocks(os.path.join(outdir, "oracle", "pref.txt")), read_blocks(os.path.join(outdir, "oracle", "aln.txt"))
+
+
+def run_ref_pipeline(targets, queries, outdir, extra=()):
+    os.makedirs(outdir, exist_ok=True)
+    tf, qf = os.path.join(outdir, "targets.txt"), os.path.join(outdir, "queries.txt")
+    open(tf, "w").write("\n".join(targets) + "\n")
+    open(qf, "w").write("\n".join(queries) + "\n")
+    subprocess.check_call([REF, "pipeline", REF_MATDIR, tf, qf, os.path.join(outdir, "ref")] + list(extra),
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return read_blocks(os.path.join(outdir, "ref", "pref.txt")), read_blocks(os.path.join(outdir, "ref", "aln.txt"))
+
+
+def read_blocks(path):
+    """'>key' separated blocks -> list of strings indexed by key order"""
+    import gzip
+    op = gzip.open if path.endswith(".gz") else open
+    blocks, cur = [], None
+    with op(path, "rt") as f:
+        for line in f:
+            if line.startswith(">"):
+                if cur is not None:
+                    blocks.append("".join(cur))
+                cur = []
+            else:
+                cur.append(line)
+    if cur is not None:
+        blocks.append("".join(cur))
+    return blocks
