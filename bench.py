@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- prefilter+align throughput of the MI355X hot path on the BASELINE workload.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one full pass of the hot path (query-side derivation, k-mer prefilter, ungapped diagonal
+scoring, hit selection, gapped SW forward/reverse, e-values) over one batch of synthetic ORF
+fragments against the HBM-resident target DB + index.  The workload is BASELINE.json configs[1]
+(10k synthetic 5-kb contigs x 100k proteins, -s 5.7) unless --contigs/--targets shrink it.
+Multi-GPU = query sharding (weak scaling: every rank searches its own 10k contigs against a full
+replica of the target index; no collective on the data path, only the timing barrier/max).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_inputs(n_contigs, n_targets, seed, rank):
+    from metaeuk_amd import synth
+    targets, founders = synth.make_targets(n_targets, seed)
+    queries = synth.make_queries(n_contigs, founders, seed + 7919 * rank)
+    return targets, queries
+
+
+def pack(codes_list):
+    off = np.zeros(len(codes_list) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(c) for c in codes_list], dtype=np.uint64)
+    res = np.concatenate(codes_list).astype(np.uint8) if codes_list else np.zeros(1, np.uint8)
+    return np.ascontiguousarray(res), off
+
+
+def cpu_baseline(targets, queries, budget_queries, threads):
+    """Reference AVX2 code (oracle/_ref/ref_harness, built from the reference's own sources) timed on the
+    host cores of this box on a bounded sample of the same workload; falls back to the C oracle port."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from metaeuk_amd import synth
+    sample = queries[:budget_queries]
+    with tempfile.TemporaryDirectory() as tmp:
+        tf, qf = os.path.join(tmp, "t.txt"), os.path.join(tmp, "q.txt")
+        with open(tf, "w") as f:
+            f.write("\n".join(synth.codes_to_str(t) for t in targets) + "\n")
+        with open(qf, "w") as f:
+            f.write("\n".join(synth.codes_to_str(q) for q in sample) + "\n")
+        if os.path.exists(oracle.REF):
+            matdir = os.path.join(tmp, "mat")
+            oracle.write_matrix_files(matdir)
+            out = subprocess.check_output([oracle.REF, "pipeline", matdir, tf, qf, os.path.join(tmp, "o"), "--threads", str(threads)],
+                                          stderr=subprocess.DEVNULL).decode().strip().splitlines()[-1]
+            st = json.loads(out)
+            t = st["t_prefilter"] + st["t_align"]
+            kind = "reference"
+        else:
+            oracle.build()
+            env = dict(os.environ, OMP_NUM_THREADS=str(threads))
+            out = subprocess.check_output([oracle.CLI, "pipeline", tf, qf, os.path.join(tmp, "o")], env=env).decode().strip().splitlines()[-1]
+            st = json.loads(out)
+            t = st["t_prefilter_align"]
+            kind = "port"
+    return {"value": len(sample) / t, "unit": "fragments/s", "cores": threads, "kind": kind,
+            "sample": "first %d ORF fragments of the same workload vs the full target DB; prefilter %.2fs + align %.2fs (index build excluded)" % (
+                len(sample), st.get("t_prefilter", t), st.get("t_align", 0.0)),
+            "gcups_align": st["cells_fwd"] / max(st.get("t_align", t), 1e-9) / 1e9}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--contigs", type=int, default=10000)
+    ap.add_argument("--targets", type=int, default=100000)
+    ap.add_argument("--seed", type=int, default=11)
+    ap.add_argument("--cpu-sample", type=int, default=400000, help="queries in the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist_.init_process_group(backend="nccl")
+        dist = dist_
+
+    from metaeuk_amd import api
+    api.init(local_rank)
+    params = api.default_params()
+
+    t0 = time.time()
+    targets, queries = make_inputs(args.contigs, args.targets, args.seed, rank)
+    t_res, t_off = pack(targets)
+    q_res, q_off = pack(queries)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    db = api.TargetDB.from_codes(t_res, t_off, params)
+    t_index = time.time() - t0
+
+    def barrier():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step():
+        q = api.Queries.from_codes(q_res, q_off, params)
+        hits, hoff = api.prefilter(db, q)
+        alns, aoff = api.align(db, q)
+        res = (int(hoff[-1]), int(aoff[-1]))
+        q.close()
+        return res
+
+    for _ in range(args.warmup):
+        step()
+    api.kernel_stats(reset=True)
+    barrier()
+    t0 = time.time()
+    nhits = npass = 0
+    for _ in range(args.steps):
+        nhits, npass = step()
+    barrier()
+    elapsed = time.time() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    stats = api.kernel_stats()
+    nq = len(queries)
+    ms_per_step = elapsed / max(args.steps, 1) * 1e3
+    frag_per_s = world * nq * args.steps / elapsed
+    cells_sw = sum(v["cells"] for k, v in stats.items() if k.startswith("sw_"))
+    gcups_total = world * cells_sw / elapsed / 1e9
+    sw_ms = sum(v["ms"] for k, v in stats.items() if k.startswith("sw_"))
+    kstats = {k: v for k, v in stats.items() if not k.startswith("host_")}
+    dom_name, dom = max(kstats.items(), key=lambda kv: kv[1]["ms"]) if kstats else ("none", dict(ms=0, launches=1, alg_bytes=0, cells=0))
+    per_launch_ms = dom["ms"] / max(dom["launches"], 1)
+    achieved = (dom["alg_bytes"] / max(dom["launches"], 1)) / max(per_launch_ms * 1e-3, 1e-12) / 1e9
+    line = {
+        "metric": "prefilter+align ORF-fragments/sec (bit-exact hits)",
+        "value": frag_per_s, "unit": "fragments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "i32 DP on u8 residues / i8 scores", "data": "synthetic",
+        "config": {"workload": "predictexons hot path: %d synthetic 5-kb contigs (%d ORF fragments/rank, %d aa) x %d-protein DB (%d aa), -s 5.7" % (
+            args.contigs, nq, int(q_off[-1]), args.targets, int(t_off[-1])), "parallelism": "query-shard x%d" % world,
+            "seed": args.seed},
+        "gcups_sw": gcups_total,
+        "gcups_sw_kernel_only": (cells_sw / max(sw_ms * 1e-3, 1e-12) / 1e9) if sw_ms else None,
+        "prefilter_hits": nhits, "alignments_passed": npass,
+        "setup_s": {"generate": round(t_gen, 2), "target_index_build_upload": round(t_index, 2)},
+        "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(stats.items())},
+        "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "avg_launch_ms": per_launch_ms, "launches": dom["launches"]},
+    }
+    if rank == 0:
+        if world == 1 and args.cpu_sample > 0:
+            try:
+                line["cpu_baseline"] = cpu_baseline(targets, queries, min(args.cpu_sample, nq), int(api.lib().mk_host_threads()))
+            except Exception as e:  # the baseline is reported, never required
+                line["cpu_baseline"] = {"value": None, "unit": "fragments/s", "cores": os.cpu_count(), "kind": "reference", "sample": "failed: %r" % (e,)}
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -76,6 +76,7 @@ int mk_init(int device_ordinal);            /* binds the calling process to one 
 const char *mk_last_error(void);
 void mk_default_params(mk_params *p);       /* defaults of `metaeuk predictexons` (SURVEY.md 3.2 argv) */
 int mk_device_name(char *buf, size_t cap);
+int mk_host_threads(void);                  /* CPUs usable by this process (affinity and cgroup quota) */
 
 /* ---- encoding: Sequence::mapSequence + SubstitutionMatrix::aa2num (Sequence.cpp:307-324) ---- */
 void mk_encode(const char *ascii, size_t len, uint8_t *codes);
@@ -92,25 +93,27 @@ uint64_t mk_targetdb_index_entries(const mk_targetdb *db);
 /* copies of host-built artefacts, for tests */
 int mk_targetdb_masked(const mk_targetdb *db, uint8_t *out /* residues */);
 
-/* ---- query batch: Sequence::mapSequence + calcLocalAaBiasCorrection + createProfile/ssw_init inputs.
- * Uploads the batch; derived per-residue arrays are computed on the device. */
+/* ---- query batch: Sequence::mapSequence + the per-residue inputs of calcLocalAaBiasCorrection /
+ * createProfile / ssw_init.  Uploads the batch to HBM.  The batch handle also carries the results
+ * of the two stages, the way the reference passes them through the pref_0 / search_res DBs. */
 int mk_queries_create(const uint8_t *residues, const uint64_t *offsets, uint32_t n_queries,
                       const mk_params *params, mk_queries **out);
 void mk_queries_destroy(mk_queries *q);
 
 /* ---- prefilter: batch form of QueryMatcher::matchQuery (QueryMatcher.cpp:85-211).
- * out_hits must hold n_queries*max_seqs entries; query i's hits are out_hits[i*max_seqs ..][0..counts[i]),
- * sorted like the reference (|score| desc, seq_id asc). */
-int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *params,
-                 mk_hit *out_hits, uint32_t *out_counts);
+ * Query i's hits are hits[offsets[i] .. offsets[i+1]), sorted like the reference (|score| desc,
+ * seq_id asc); seq_id = target index.  The arrays are owned by the batch handle. */
+int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *params);
+int mk_prefilter_result(const mk_queries *q, const mk_hit **hits, const uint64_t **offsets /* n+1 */);
+/* install a prefilter result produced elsewhere (the `align` command reading a pref_0 DB,
+ * Alignment.cpp:312-358) */
+int mk_prefilter_result_set(mk_queries *q, const mk_hit *hits, const uint64_t *offsets);
 
 /* ---- align: batch form of Matcher::initQuery + getSWResult + Alignment::checkCriteria + sort
- * (Matcher.cpp:49-142, Alignment.cpp:346-405).  hits/counts as produced by mk_prefilter
- * (seq_id = target index).  out must hold sum(counts) entries; query i's accepted alignments are
- * written contiguously from out[prefix(counts)[i]], out_counts[i] of them, in output order. */
-int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *params,
-             const mk_hit *hits, const uint32_t *counts, uint32_t hits_stride,
-             mk_alignment *out, uint32_t *out_counts);
+ * (Matcher.cpp:49-142, Alignment.cpp:346-405) over the batch's prefilter result.  Query i's accepted
+ * alignments, in output order, are alns[offsets[i] .. offsets[i+1]). */
+int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *params);
+int mk_align_result(const mk_queries *q, const mk_alignment **alns, const uint64_t **offsets /* n+1 */);
 
 /* ---- kernel-level entry points (used by the parity tests and bench.py) ---- */
 /* Smith-Waterman on explicit pairs: for pair p, query q_idx[p] vs target t_idx[p].

@@ -41,7 +41,8 @@ HIT_DTYPE = np.dtype([("seq_id", "<u4"), ("pref_score", "<i4"), ("diagonal", "<u
 
 EXPORTS = ["mk_init", "mk_last_error", "mk_default_params", "mk_device_name", "mk_encode", "mk_targetdb_create",
            "mk_targetdb_destroy", "mk_targetdb_residues", "mk_targetdb_index_entries", "mk_targetdb_masked",
-           "mk_queries_create", "mk_queries_destroy", "mk_prefilter", "mk_align", "mk_sw_pairs", "mk_ungapped",
+           "mk_queries_create", "mk_queries_destroy", "mk_prefilter", "mk_prefilter_result", "mk_prefilter_result_set",
+           "mk_align", "mk_align_result", "mk_sw_pairs", "mk_ungapped",
            "mk_kernel_stats", "mk_kernel_stats_reset", "mk_format_hit", "mk_format_alignment"]
 
 
@@ -101,12 +102,17 @@ def _p(a):
 
 
 class TargetDB:
-    def __init__(self, seqs, params=None):
+    def __init__(self, seqs, params=None, _codes=None):
         self.params = params or default_params()
-        self.res, self.off = encode(seqs)
-        self.n = len(seqs)
+        self.res, self.off = _codes if _codes is not None else encode(seqs)
+        self.n = len(self.off) - 1
         self.h = C.c_void_p()
         _chk(lib().mk_targetdb_create(_p(self.res), _p(self.off), C.c_uint32(self.n), C.byref(self.params), C.byref(self.h)))
+
+    @classmethod
+    def from_codes(cls, res, off, params=None):
+        """res: uint8 codes 0..20 in matrix alphabet order (ACDEFGHIKLMNPQRSTVWYX), off: uint64[n+1]"""
+        return cls(None, params, _codes=(np.ascontiguousarray(res, dtype=np.uint8), np.ascontiguousarray(off, dtype=np.uint64)))
 
     def masked(self):
         out = np.zeros(max(1, int(self.off[-1])), dtype=np.uint8)
@@ -129,12 +135,16 @@ class TargetDB:
 
 
 class Queries:
-    def __init__(self, seqs, params=None):
+    def __init__(self, seqs, params=None, _codes=None):
         self.params = params or default_params()
-        self.res, self.off = encode(seqs)
-        self.n = len(seqs)
+        self.res, self.off = _codes if _codes is not None else encode(seqs)
+        self.n = len(self.off) - 1
         self.h = C.c_void_p()
         _chk(lib().mk_queries_create(_p(self.res), _p(self.off), C.c_uint32(self.n), C.byref(self.params), C.byref(self.h)))
+
+    @classmethod
+    def from_codes(cls, res, off, params=None):
+        return cls(None, params, _codes=(np.ascontiguousarray(res, dtype=np.uint8), np.ascontiguousarray(off, dtype=np.uint64)))
 
     def close(self):
         if self.h:
@@ -149,21 +159,33 @@ class Queries:
 
 
 def prefilter(db, q, params=None):
+    """-> (hits structured array [total], offsets uint64[n+1]); views into memory owned by the batch handle"""
     p = params or db.params
-    hits = np.zeros(q.n * p.max_seqs, dtype=HIT_DTYPE)
-    counts = np.zeros(q.n, dtype=np.uint32)
-    _chk(lib().mk_prefilter(db.h, q.h, C.byref(p), _p(hits), _p(counts)))
-    return hits.reshape(q.n, p.max_seqs), counts
+    _chk(lib().mk_prefilter(db.h, q.h, C.byref(p)))
+    return prefilter_result(q)
 
 
-def align(db, q, hits, counts, params=None):
+def prefilter_result(q):
+    hp, op = C.c_void_p(), C.c_void_p()
+    _chk(lib().mk_prefilter_result(q.h, C.byref(hp), C.byref(op)))
+    off = np.ctypeslib.as_array(C.cast(op, C.POINTER(C.c_uint64)), shape=(q.n + 1,))
+    total = int(off[-1])
+    if total == 0:
+        return np.zeros(0, dtype=HIT_DTYPE), off
+    raw = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_uint8)), shape=(total * HIT_DTYPE.itemsize,))
+    return raw.view(HIT_DTYPE), off
+
+
+def align(db, q, params=None):
+    """-> (ctypes array of Alignment [total], offsets uint64[n+1])"""
     p = params or db.params
-    total = int(counts.sum())
-    out = (Alignment * max(1, total))()
-    out_counts = np.zeros(q.n, dtype=np.uint32)
-    hits = np.ascontiguousarray(hits)
-    _chk(lib().mk_align(db.h, q.h, C.byref(p), _p(hits), _p(counts), C.c_uint32(hits.shape[1]), out, _p(out_counts)))
-    return out, out_counts
+    _chk(lib().mk_align(db.h, q.h, C.byref(p)))
+    ap, op = C.c_void_p(), C.c_void_p()
+    _chk(lib().mk_align_result(q.h, C.byref(ap), C.byref(op)))
+    off = np.ctypeslib.as_array(C.cast(op, C.POINTER(C.c_uint64)), shape=(q.n + 1,))
+    total = int(off[-1])
+    alns = C.cast(ap, C.POINTER(Alignment * max(total, 1))).contents
+    return alns, off
 
 
 def sw_pairs(db, q, q_idx, t_idx, with_start=True, params=None):
@@ -194,20 +216,20 @@ def kernel_stats(reset=False):
     return res
 
 
-def format_hits(hits_row, count, key_of=None):
+def format_hits(hits, lo, hi, key_of=None):
     buf = C.create_string_buffer(64)
     out = []
-    for h in hits_row[:count]:
+    for h in hits[lo:hi]:
         key = int(h["seq_id"]) if key_of is None else key_of(int(h["seq_id"]))
         n = lib().mk_format_hit(buf, C.c_uint32(key), C.c_int32(int(h["pref_score"])), C.c_uint16(int(h["diagonal"])))
         out.append(buf.raw[:n].decode())
     return "".join(out)
 
 
-def format_alignments(alns, start, count):
+def format_alignments(alns, lo, hi):
     buf = C.create_string_buffer(256)
     out = []
-    for i in range(start, start + count):
+    for i in range(lo, hi):
         n = lib().mk_format_alignment(buf, C.byref(alns[i]))
         out.append(buf.raw[:n].decode())
     return "".join(out)

@@ -8,11 +8,13 @@
 #include "mk_prefilter.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <omp.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -65,6 +67,16 @@ void timed_flush() {
     g_pending.clear();
 }
 
+// wall-clock of host-side phases, reported next to the kernel times (launches = 0)
+struct HostTimer {
+    std::string name; std::chrono::steady_clock::time_point t0;
+    explicit HostTimer(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {}
+    ~HostTimer() {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        g_stats[name].ms += ms;
+    }
+};
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr; size_t n = 0;
@@ -110,6 +122,9 @@ struct mk_queries {
     DevBuf<uint64_t> dOff;
     DevBuf<int16_t> dKmerThr;
     DevBuf<int8_t> dCorr, dBias8;
+    // stage results (the reference hands these over through the pref_0 / search_res DBs)
+    std::vector<mk_hit> hits; std::vector<uint64_t> hitOff; bool havePref = false;
+    std::vector<mk_alignment> alns; std::vector<uint64_t> alnOff; bool haveAln = false;
 };
 
 namespace {
@@ -132,6 +147,7 @@ int run_sw_jobs(const mk_targetdb *db, const mk_queries *q, const mk_params *P, 
     const size_t n = jobs.size();
     out.assign(n, mk::SwOut{0, -1, -1, 0});
     if (n == 0) return MK_OK;
+    HostTimer *htPrep = new HostTimer("host_sw_prepare");
     // counting sort by (bucket, target length class) so that the DPs sharing a wave have similar lengths
     const int CLS = 512;
     std::vector<uint32_t> hist(5 * CLS + 1, 0);
@@ -146,6 +162,7 @@ int run_sw_jobs(const mk_targetdb *db, const mk_queries *q, const mk_params *P, 
         std::vector<uint32_t> cur(hist.begin(), hist.end() - 1);
         for (size_t i = 0; i < n; i++) { const uint32_t p = cur[keyOf(jobs[i])]++; order[p] = (uint32_t) i; sorted[p] = jobs[i]; }
     }
+    delete htPrep;
     DevBuf<mk::SwJob> dJobs;
     DevBuf<mk::SwOut> dOut;
     HIPCHK(dJobs.upload(sorted.data(), n));
@@ -222,10 +239,16 @@ int sw_pairs(const mk_targetdb *db, const mk_queries *q, const mk_params *P, con
     }
     // which pairs need start positions
     std::vector<size_t> rev;
-    for (size_t p = 0; p < n; p++) {
-        bool need = needStartIn ? (*needStartIn)[p] != 0 : (decide ? decide(ctx, p, res[p]) : false);
-        if (needStartOut) (*needStartOut)[p] = need;
-        if (need && res[p].score > 0) rev.push_back(p);
+    {
+        HostTimer ht("host_evalue_gate");
+        std::vector<uint8_t> needV(n, 0);
+#pragma omp parallel for schedule(static)
+        for (size_t p = 0; p < n; p++)
+            needV[p] = needStartIn ? ((*needStartIn)[p] != 0) : (decide ? decide(ctx, p, res[p]) : false);
+        for (size_t p = 0; p < n; p++) {
+            if (needStartOut) (*needStartOut)[p] = needV[p];
+            if (needV[p] && res[p].score > 0) rev.push_back(p);
+        }
     }
     if (!rev.empty()) {
         std::vector<mk::SwJob> j3(rev.size());
@@ -259,7 +282,27 @@ extern "C" {
 
 const char *mk_last_error(void) { return g_err.c_str(); }
 
+// CPUs this process may actually use: min(affinity mask, cgroup-v2 cpu.max quota).  The GPU boxes expose
+// 256 hardware threads behind a 16-CPU quota; an OpenMP team sized from nproc would be throttled.
+static int effective_cpus() {
+    int n = omp_get_num_procs();
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        char a[64];
+        long period = 0;
+        if (fscanf(f, "%63s %ld", a, &period) == 2 && strcmp(a, "max") != 0 && period > 0) {
+            const long quota = atol(a);
+            if (quota > 0) n = std::min<long>(n, std::max<long>(1, (quota + period - 1) / period));
+        }
+        fclose(f);
+    }
+    return std::max(n, 1);
+}
+
+int mk_host_threads(void) { return effective_cpus(); }
+
 int mk_init(int device) {
+    if (!getenv("OMP_NUM_THREADS")) omp_set_num_threads(effective_cpus());
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) return fail(MK_ERR_DEVICE, "no HIP device visible (%s)", hipGetErrorString(e));
@@ -356,8 +399,11 @@ int mk_queries_create(const uint8_t *residues, const uint64_t *offsets, uint32_t
     mk::SubMat kmerMat, alnMat;
     mk::build_submat(kmerMat, mk::MAT_VTML80, 8.0f, -0.2f);
     mk::build_submat(alnMat, mk::MAT_BLOSUM62, 2.0f, 0.0f);
-    mk::derive_queries(kmerMat, alnMat, residues, offsets, n, mk::kmer_threshold(P->sensitivity, P->kmer_score),
-                       P->comp_bias_corr != 0, P->comp_bias_scale, q->der);
+    {
+        HostTimer ht("host_query_derive");
+        mk::derive_queries(kmerMat, alnMat, residues, offsets, n, mk::kmer_threshold(P->sensitivity, P->kmer_score),
+                           P->comp_bias_corr != 0, P->comp_bias_scale, q->der);
+    }
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; };
     ok(q->dRes.upload(residues, offsets[n]));
@@ -419,10 +465,10 @@ int mk_ungapped(mk_targetdb *db, mk_queries *q, const uint32_t *qIdx, const uint
     return MK_OK;
 }
 
-int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *P, mk_hit *outHits, uint32_t *outCounts) {
+int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     int rc = ensure_ready();
     if (rc) return rc;
-    if (!db || !q || !P || !outHits || !outCounts) return fail(MK_ERR_ARG, "null argument");
+    if (!db || !q || !P) return fail(MK_ERR_ARG, "null argument");
     mk::PrefilterDeviceView V;
     V.q_res = q->dRes.p; V.q_off = q->dOff.p; V.q_kmer_thr = q->dKmerThr.p; V.q_corr = q->dCorr.p; V.n_queries = q->n;
     V.t_masked = db->dMasked.p; V.t_off = db->dOff.p; V.n_targets = db->n;
@@ -430,27 +476,43 @@ int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *P, mk_hit *out
     V.mat_ung = db->dMatUng.p;
     std::string err;
     const int binCount = mk::bin_count_for(db->n, P->host_l2_bytes);
-    rc = mk::run_prefilter(V, q->off, q->res, q->der.diagCorr.data(), db->off, *P, binCount, g_stream, outHits, outCounts, err,
+    HostTimer ht("host_prefilter_total");
+    rc = mk::run_prefilter(V, q->off, q->res, q->der.diagCorr.data(), db->off, *P, binCount, g_stream, q->hits, q->hitOff, err,
                            [](const char *name, double bytes, double cells) { return timed_begin(name, bytes, cells); },
-                           [](int h) { timed_end(h); });
+                           [](int h) { timed_end(h); },
+                           [](int h, double bytes, double cells) { if (h >= 0) { g_pending[h].bytes = bytes; g_pending[h].cells = cells; } });
     timed_flush();
     if (rc != MK_OK) return fail(rc, "%s", err.c_str());
+    q->havePref = true;
     return MK_OK;
 }
 
-int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *P, const mk_hit *hits, const uint32_t *counts, uint32_t stride,
-             mk_alignment *out, uint32_t *outCounts) {
+int mk_prefilter_result(const mk_queries *q, const mk_hit **hits, const uint64_t **offsets) {
+    if (!q || !hits || !offsets) return fail(MK_ERR_ARG, "null argument");
+    if (!q->havePref) return fail(MK_ERR_ARG, "no prefilter result in this batch");
+    *hits = q->hits.data(); *offsets = q->hitOff.data();
+    return MK_OK;
+}
+
+int mk_prefilter_result_set(mk_queries *q, const mk_hit *hits, const uint64_t *offsets) {
+    if (!q || !offsets || (!hits && offsets[q->n] > 0)) return fail(MK_ERR_ARG, "null argument");
+    q->hitOff.assign(offsets, offsets + q->n + 1);
+    q->hits.assign(hits, hits + offsets[q->n]);
+    q->havePref = true;
+    return MK_OK;
+}
+
+int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     int rc = ensure_ready();
     if (rc) return rc;
-    if (!db || !q || !P || !hits || !counts || !out || !outCounts) return fail(MK_ERR_ARG, "null argument");
-    std::vector<uint32_t> qIdx, tIdx;
-    std::vector<uint64_t> first(q->n + 1, 0);
-    for (uint32_t i = 0; i < q->n; i++) {
-        first[i] = qIdx.size();
-        for (uint32_t h = 0; h < counts[i]; h++) { qIdx.push_back(i); tIdx.push_back(hits[(size_t) i * stride + h].seq_id); }
-    }
-    first[q->n] = qIdx.size();
-    const size_t n = qIdx.size();
+    if (!db || !q || !P) return fail(MK_ERR_ARG, "null argument");
+    if (!q->havePref) return fail(MK_ERR_ARG, "mk_align: the batch has no prefilter result");
+    HostTimer htAll("host_align_total");
+    const size_t n = q->hits.size();
+    std::vector<uint32_t> qIdx(n), tIdx(n);
+#pragma omp parallel for schedule(static)
+    for (uint32_t i = 0; i < q->n; i++)
+        for (uint64_t h = q->hitOff[i]; h < q->hitOff[i + 1]; h++) { qIdx[h] = i; tIdx[h] = q->hits[h].seq_id; }
     struct Ctx { const mk_targetdb *db; const mk_queries *q; const mk_params *P; const uint32_t *qIdx; std::vector<double> ev; } ctx{db, q, P, qIdx.data(), std::vector<double>(n, 0.0)};
     std::vector<PairRes> res;
     std::vector<uint8_t> need(n, 0);
@@ -466,11 +528,15 @@ int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *P, const mk_hit *h
                   }, &ctx);
     if (rc) return rc;
     // Matcher::getSWResult (Matcher.cpp:60-142) + Alignment::checkCriteria (Alignment.cpp:548-567) + sort (:403-405)
-    size_t w = 0;
+    HostTimer ht("host_align_assemble");
+    std::vector<mk_alignment> tmp(n);
+    std::vector<uint32_t> cnt(q->n, 0);
+#pragma omp parallel for schedule(dynamic, 256)
     for (uint32_t i = 0; i < q->n; i++) {
-        const size_t begin = w;
         const int qLen = (int) (q->off[i + 1] - q->off[i]);
-        for (uint64_t p = first[i]; p < first[i + 1]; p++) {
+        const uint64_t begin = q->hitOff[i];
+        uint64_t w = begin;
+        for (uint64_t p = q->hitOff[i]; p < q->hitOff[i + 1]; p++) {
             const PairRes &r = res[p];
             if (r.score <= 0 || !need[p]) continue;       // e-value above threshold: rejected by checkCriteria
             const uint32_t t = tIdx[p];
@@ -489,11 +555,25 @@ int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *P, const mk_hit *h
             sid = std::min(sid, 1.0f);
             a.seq_id = std::max(0.0f, sid);
             a.bit_score = static_cast<int>(db->evaluer.bitScore((double) r.score) + 0.5);
-            if (a.evalue <= P->evalue_thr && a.aln_len >= P->min_aln_len) out[w++] = a;
+            if (a.evalue <= P->evalue_thr && a.aln_len >= P->min_aln_len) tmp[w++] = a;
         }
-        if (w - begin > 1) std::sort(out + begin, out + w, mk::alignment_less);
-        outCounts[i] = (uint32_t) (w - begin);
+        if (w - begin > 1) std::sort(tmp.begin() + begin, tmp.begin() + w, mk::alignment_less);
+        cnt[i] = (uint32_t) (w - begin);
     }
+    q->alnOff.assign((size_t) q->n + 1, 0);
+    for (uint32_t i = 0; i < q->n; i++) q->alnOff[i + 1] = q->alnOff[i] + cnt[i];
+    q->alns.resize(q->alnOff[q->n]);
+#pragma omp parallel for schedule(static)
+    for (uint32_t i = 0; i < q->n; i++)
+        std::copy(tmp.begin() + q->hitOff[i], tmp.begin() + q->hitOff[i] + cnt[i], q->alns.begin() + q->alnOff[i]);
+    q->haveAln = true;
+    return MK_OK;
+}
+
+int mk_align_result(const mk_queries *q, const mk_alignment **alns, const uint64_t **offsets) {
+    if (!q || !alns || !offsets) return fail(MK_ERR_ARG, "null argument");
+    if (!q->haveAln) return fail(MK_ERR_ARG, "no alignment result in this batch");
+    *alns = q->alns.data(); *offsets = q->alnOff.data();
     return MK_OK;
 }
 

@@ -263,8 +263,10 @@ int self_score(const SubMat &ung, const uint8_t *q, const int8_t *corr, int L) {
 int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOff, const std::vector<uint8_t> &qRes,
                   const int8_t *qCorrHost,
                   const std::vector<uint64_t> &tOff, const mk_params &P, int binCount, hipStream_t stream,
-                  mk_hit *outHits, uint32_t *outCounts, std::string &err, timed_begin_fn tb, timed_end_fn te) {
+                  std::vector<mk_hit> &outHits, std::vector<uint64_t> &outOff, std::string &err, timed_begin_fn tb, timed_end_fn te, timed_set_fn ts) {
     const uint32_t nq = V.n_queries;
+    outHits.clear();
+    outOff.assign((size_t) nq + 1, 0);
     const int maxHits = std::min<int>(P.max_seqs, (int) V.n_targets);
     const uint64_t dbSize = V.n_targets;
     const uint64_t maxDbMatches = std::max<uint64_t>(1000000, dbSize) * 2;   // QueryMatcher.cpp:43
@@ -278,7 +280,8 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     Dev<DCand> dCand;
     Dev<int32_t> dScore;
     uint32_t q0 = 0;
-    std::vector<uint32_t> hHit;
+    std::vector<uint32_t> hHit, hKmer;
+    uint64_t totalKmers = 0;
     std::vector<DCand> hCand;
     std::vector<int32_t> hScore;
     std::vector<Cand> perQuery;
@@ -304,9 +307,14 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             hipLaunchKernelGGL(probe_kernel<false>, dim3(blocks), dim3(256), 0, stream, A);
             te(th);
             PCHK(hipGetLastError());
-            hHit.resize(nPos);
+            hHit.resize(nPos); hKmer.resize(nPos);
             PCHK(hipMemcpyAsync(hHit.data(), dHit.p, nPos * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            PCHK(hipMemcpyAsync(hKmer.data(), dKmer.p, nPos * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             PCHK(hipStreamSynchronize(stream));
+            totalKmers = 0;
+            for (uint64_t k = 0; k < nPos; k++) totalKmers += hKmer[k];
+            // algorithmic bytes of the count pass: one offset pair per similar k-mer + the two 3-mer score rows' heads
+            ts(th, 8.0 * (double) totalKmers + 2.0 * 2.0 * ROWCACHE * (double) nPos, (double) totalKmers);
             totalHits = 0;
             uint64_t perQ = 0;
             uint32_t qi = q0;
@@ -319,7 +327,8 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             }
             if (totalHits > HIT_CAP && q1 - q0 > 1) { q1 = q0 + (q1 - q0) / 2; shrunk = true; }
         } while (shrunk);
-        for (uint32_t q = q0; q < q1; q++) outCounts[q] = 0;
+        std::vector<uint32_t> chunkCnt(q1 - q0, 0), slot(q1 - q0 + 1, 0);
+        std::vector<mk_hit> chunkHits;
         if (nPos > 0 && totalHits > 0) {
             if (totalHits >= 0xFFFFFFFFull) { err = "a single query produces >= 2^32 index hits"; return MK_ERR_UNSUPPORTED; }
             // 2. exclusive scan of per-position hit counts (in place)
@@ -336,7 +345,8 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             A.V = V; A.pos_begin = qOff[q0]; A.pos_end = qOff[q1]; A.q_first = q0;
             A.hit_count = dHit.p; A.kmer_count = dKmer.p; A.keys = dKeys.p; A.vals = dVals.p;
             const unsigned blocks = (unsigned) ((nPos + 3) / 4);
-            th = tb("kmer_probe_gather", 0, 0);
+            // gather pass: offset pairs again + 8 B per index entry read + 16 B (key,value) written per entry
+            th = tb("kmer_probe_gather", 8.0 * (double) totalKmers + 24.0 * (double) totalHits + 4.0 * ROWCACHE * (double) nPos, (double) totalKmers);
             hipLaunchKernelGGL(probe_kernel<true>, dim3(blocks), dim3(256), 0, stream, A);
             te(th);
             PCHK(hipGetLastError());
@@ -365,7 +375,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             if (nCand > 0) {
                 // 6. exact ungapped scores
                 PCHK(dScore.reserve(nCand));
-                th = tb("diag_score", 0, 0);
+                th = tb("diag_score", 24.0 * nCand, 0);
                 hipLaunchKernelGGL(diag_score_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, V, q0, dCand.p, nCand, dScore.p);
                 te(th);
                 PCHK(hipGetLastError());
@@ -382,6 +392,8 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                     std::vector<uint32_t> cur(start.begin(), start.end() - 1);
                     for (uint32_t k = 0; k < nCand; k++) orderIdx[cur[hCand[k].q]++] = k;
                 }
+                for (uint32_t ql = 0; ql < q1 - q0; ql++) slot[ql + 1] = slot[ql] + std::min<uint32_t>(start[ql + 1] - start[ql], (uint32_t) maxHits);
+                chunkHits.resize(slot[q1 - q0]);
 #pragma omp parallel for schedule(dynamic, 64) private(perQuery)
                 for (uint32_t ql = 0; ql < q1 - q0; ql++) {
                     if (start[ql + 1] == start[ql]) continue;
@@ -401,9 +413,13 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                             self = self_score(ungMat, qRes.data() + qOff[q], qCorrHost + qOff[q], L);
                         }
                     }
-                    outCounts[q] = (uint32_t) select_hits(perQuery, binCount, maxHits, P.min_ungapped_score, self, outHits + (size_t) q * P.max_seqs);
+                    chunkCnt[ql] = (uint32_t) select_hits(perQuery, binCount, maxHits, P.min_ungapped_score, self, chunkHits.data() + slot[ql]);
                 }
             }
+        }
+        for (uint32_t ql = 0; ql < q1 - q0; ql++) {
+            outOff[(size_t) q0 + ql + 1] = outOff[(size_t) q0 + ql] + chunkCnt[ql];
+            if (chunkCnt[ql]) outHits.insert(outHits.end(), chunkHits.begin() + slot[ql], chunkHits.begin() + slot[ql] + chunkCnt[ql]);
         }
         q0 = q1;
     }

@@ -21,11 +21,12 @@ struct PrefilterDeviceView {
 
 typedef int (*timed_begin_fn)(const char *name, double bytes, double cells);
 typedef void (*timed_end_fn)(int handle);
+typedef void (*timed_set_fn)(int handle, double bytes, double cells);
 
 // Runs the whole prefilter for the batch.  q_off_host / t_off_host mirror the device offset arrays.
 int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &q_off_host, const std::vector<uint8_t> &q_res_host,
                   const int8_t *q_corr_host,
                   const std::vector<uint64_t> &t_off_host, const mk_params &P, int binCount, hipStream_t stream,
-                  mk_hit *outHits, uint32_t *outCounts, std::string &err, timed_begin_fn tb, timed_end_fn te);
+                  std::vector<mk_hit> &outHits, std::vector<uint64_t> &outOff, std::string &err, timed_begin_fn tb, timed_end_fn te, timed_set_fn ts);
 
 }  // namespace mk

@@ -114,3 +114,25 @@ def read_blocks(path):
     if cur is not None:
         blocks.append("".join(cur))
     return blocks
+
+
+def write_matrix_files(outdir):
+    """Materialise blosum62.out / VTML80.out (MMseqs2 text format) from the repository's matrix DATA
+    table so that the reference harness can run where /root/reference does not exist."""
+    import re
+    os.makedirs(outdir, exist_ok=True)
+    inc = open(os.path.join(ROOT, "metaeuk_amd", "data", "matrices.inc")).read()
+    for name, fname in (("BLOSUM62", "blosum62.out"), ("VTML80", "VTML80.out")):
+        alpha = re.search(r'MK_%s_ALPHABET\[\] = "(\w+)"' % name, inc).group(1)
+        lam = re.search(r"MK_%s_LAMBDA = ([^;]+);" % name, inc).group(1)
+        bg = re.search(r"MK_%s_BACKGROUND\[\d+\] = \{([^}]*)\}" % name, inc).group(1).replace(",", " ").split()
+        body = re.search(r"MK_%s_SCORES\[\d+\]\[\d+\] = \{(.*?)\n\};" % name, inc, re.S).group(1)
+        rows = [r.replace(",", " ").split() for r in re.findall(r"\{([^}]*)\}", body)]
+        with open(os.path.join(outdir, fname), "w") as f:
+            f.write("# %s\n" % name)
+            f.write("# Background (precomputed optional): %s\n" % " ".join(bg))
+            f.write("# Lambda     (precomputed optional): %s\n" % lam)
+            f.write("   " + " ".join(alpha) + "\n")
+            for a, r in zip(alpha, rows):
+                f.write(a + " " + " ".join(r) + "\n")
+    return outdir
