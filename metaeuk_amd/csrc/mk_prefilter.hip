@@ -270,8 +270,9 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     const int maxHits = std::min<int>(P.max_seqs, (int) V.n_targets);
     const uint64_t dbSize = V.n_targets;
     const uint64_t maxDbMatches = std::max<uint64_t>(1000000, dbSize) * 2;   // QueryMatcher.cpp:43
-    const size_t HIT_CAP = 96u << 20;                 // hits per chunk kept in HBM (keys+values, double buffered)
-    const uint64_t POS_CAP = 4u << 20;                // residues per chunk
+    const size_t HIT_CAP = 768u << 20;                // index hits per chunk kept in HBM: 32 B each (key+value, double buffered)
+    const uint64_t POS_CAP = 24u << 20;               // residues per chunk
+    double hitsPerPos = 0;                            // running estimate used to size the next chunk
     SubMat ungMat, kmerMat;
     build_submat(ungMat, MAT_BLOSUM62, 2.0f, -0.2f);
     Dev<uint32_t> dHit, dKmer, dCount;
@@ -289,7 +290,12 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     while (q0 < nq) {
         // chunk = as many whole queries as fit POS_CAP residues
         uint32_t q1 = q0;
-        while (q1 < nq && (qOff[q1 + 1] - qOff[q0] <= POS_CAP || q1 == q0)) q1++;
+        {
+            uint64_t posBudget = POS_CAP;
+            if (hitsPerPos > 0) posBudget = std::min<uint64_t>(POS_CAP, (uint64_t) (0.8 * (double) HIT_CAP / hitsPerPos));
+            else posBudget = std::min<uint64_t>(POS_CAP, 1u << 20);   // first chunk: small probe
+            while (q1 < nq && (qOff[q1 + 1] - qOff[q0] <= posBudget || q1 == q0)) q1++;
+        }
         bool shrunk;
         uint64_t totalHits = 0;
         uint64_t nPos = 0;
@@ -325,6 +331,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                 if (perQ >= maxDbMatches) { err = "query " + std::to_string(qi) + " overflows the reference's databaseHits buffer (not restated)"; return MK_ERR_UNSUPPORTED; }
                 totalHits += hHit[k];
             }
+            if (nPos > 0) hitsPerPos = std::max(1.0, (double) totalHits / (double) nPos);
             if (totalHits > HIT_CAP && q1 - q0 > 1) { q1 = q0 + (q1 - q0) / 2; shrunk = true; }
         } while (shrunk);
         std::vector<uint32_t> chunkCnt(q1 - q0, 0), slot(q1 - q0 + 1, 0);

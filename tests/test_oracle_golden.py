@@ -1,0 +1,63 @@
+"""CPU tests: the C oracle against the golden fixtures produced by the reference's own code, and
+(when the harness is present) against a live run of the reference harness."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+import oracle
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _lines(name):
+    with gzip.open(os.path.join(GOLD, name), "rt") as f:
+        return f.read().split("\n")[:-1]
+
+
+def _text(name):
+    with gzip.open(os.path.join(GOLD, name), "rt") as f:
+        return f.read()
+
+
+@pytest.mark.parametrize("tag", ["small", "edge"])
+@pytest.mark.parametrize("lanes", [(32, 16, 4), (16, 8, 2)])
+def test_oracle_pipeline_matches_golden(tag, lanes, tmp_path):
+    targets, queries = _lines(tag + "_targets.txt.gz"), _lines(tag + "_queries.txt.gz")
+    extra = ["--l2", "2097152", "--lanes-byte", str(lanes[0]), "--lanes-word", str(lanes[1]), "--tantan-lanes", str(lanes[2])]
+    oracle.run_pipeline(targets, queries, str(tmp_path), extra=extra)
+    assert open(tmp_path / "oracle" / "pref.txt").read() == _text(tag + "_pref.txt.gz")
+    assert open(tmp_path / "oracle" / "aln.txt").read() == _text(tag + "_aln.txt.gz")
+
+
+def test_oracle_sw_matches_golden(tmp_path):
+    oracle.build()
+    t, q = _lines("sw_targets.txt.gz"), _lines("sw_queries.txt.gz")
+    (tmp_path / "t.txt").write_text("\n".join(t) + "\n")
+    (tmp_path / "q.txt").write_text("\n".join(q) + "\n")
+    (tmp_path / "p.txt").write_text("\n".join("%d %d" % (i, i) for i in range(len(q))) + "\n")
+    for lanes in ((32, 16), (16, 8), (1, 1)):
+        subprocess.check_call([oracle.CLI, "sw", str(tmp_path / "t.txt"), str(tmp_path / "q.txt"), str(tmp_path / "p.txt"),
+                               str(tmp_path / "out.tsv"), "--dbres", "7500000", "--lanes-byte", str(lanes[0]), "--lanes-word", str(lanes[1])])
+        assert (tmp_path / "out.tsv").read_text() == _text("sw_expected.tsv.gz"), lanes
+
+
+@pytest.mark.skipif(not os.path.exists(oracle.REF) or not os.path.isdir("/root/reference"), reason="reference harness not built here")
+def test_oracle_matches_live_reference(tmp_path):
+    from metaeuk_amd import synth
+    targets, queries = synth.make_workload(6, 150, seed=3)
+    opref, oaln = oracle.run_pipeline(targets, queries, str(tmp_path), extra=["--dump"])
+    rpref, raln = oracle.run_ref_pipeline(targets, queries, str(tmp_path), extra=["--dump", "--threads", "2"])
+    assert opref == rpref and oaln == raln
+    for f in ("masked_targets.txt", "index.txt", "stats.txt"):
+        assert open(tmp_path / "oracle" / f).read() == open(tmp_path / "ref" / f).read(), f
+
+
+def test_matrix_tables_reproduce_reference_matrices(tmp_path):
+    """the .out text regenerated from the repository's matrix table parses back to identical numbers"""
+    d = oracle.write_matrix_files(str(tmp_path / "mat"))
+    txt = open(os.path.join(d, "blosum62.out")).read()
+    assert "W" in txt and "10.5040" in txt
+    m = oracle.submat(0, 2.0, 0.0)
+    assert m.sub[18][18] == 11 and m.sub[0][0] == 4 and m.sub[20][20] == -1   # W/W, A/A, X/X of BLOSUM62 in half bits
