@@ -3,6 +3,7 @@
 // library.  There is NO CPU fallback for the kernels: without a usable HIP device every compute
 // entry point fails with MK_ERR_DEVICE.
 #include "../../include/metaeuk_amd.h"
+#include "mk_align.hpp"
 #include "mk_host.hpp"
 #include "mk_kernels.hpp"
 #include "mk_prefilter.hpp"
@@ -15,7 +16,6 @@
 #include <cstring>
 #include <map>
 #include <omp.h>
-#include <mutex>
 #include <string>
 #include <vector>
 
@@ -37,52 +37,47 @@ bool g_ready = false;
 int g_device = -1;
 hipStream_t g_stream = nullptr;
 
+// ---- per-kernel timing (HIP events on the library's stream) and host-phase wall clock -------------
 struct StatAcc { double ms = 0; uint64_t launches = 0; double bytes = 0; double cells = 0; };
 std::map<std::string, StatAcc> g_stats;
-std::vector<std::string> g_statNames;   // stable storage for names handed out
+std::vector<std::string> g_statNames;
 
-struct Timed {
-    hipEvent_t a{}, b{};
-    std::string name; double bytes; double cells;
-};
+struct Timed { hipEvent_t a{}, b{}; std::string name; double bytes; double cells; };
 std::vector<Timed> g_pending;
 
 int timed_begin(const char *name, double bytes, double cells) {
     Timed t; t.name = name; t.bytes = bytes; t.cells = cells;
     if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return -1;
-    hipEventRecord(t.a, g_stream);
+    (void) hipEventRecord(t.a, g_stream);
     g_pending.push_back(t);
     return (int) g_pending.size() - 1;
 }
-void timed_end(int h) { if (h >= 0) hipEventRecord(g_pending[h].b, g_stream); }
+void timed_end(int h) { if (h >= 0) (void) hipEventRecord(g_pending[h].b, g_stream); }
+void timed_set(int h, double bytes, double cells) { if (h >= 0 && h < (int) g_pending.size()) { g_pending[h].bytes = bytes; g_pending[h].cells = cells; } }
 void timed_flush() {
     for (Timed &t : g_pending) {
         float ms = 0;
-        hipEventSynchronize(t.b);
-        hipEventElapsedTime(&ms, t.a, t.b);
+        (void) hipEventSynchronize(t.b);
+        (void) hipEventElapsedTime(&ms, t.a, t.b);
         StatAcc &s = g_stats[t.name];
         s.ms += ms; s.launches += 1; s.bytes += t.bytes; s.cells += t.cells;
-        hipEventDestroy(t.a); hipEventDestroy(t.b);
+        (void) hipEventDestroy(t.a); (void) hipEventDestroy(t.b);
     }
     g_pending.clear();
 }
 
-// wall-clock of host-side phases, reported next to the kernel times (launches = 0)
 struct HostTimer {
     std::string name; std::chrono::steady_clock::time_point t0;
     explicit HostTimer(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {}
-    ~HostTimer() {
-        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        g_stats[name].ms += ms;
-    }
+    ~HostTimer() { g_stats[name].ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
 template <typename T>
 struct DevBuf {
     T *p = nullptr; size_t n = 0;
-    ~DevBuf() { if (p) hipFree(p); }
+    ~DevBuf() { if (p) (void) hipFree(p); }
     hipError_t alloc(size_t count) {
-        if (p) { hipFree(p); p = nullptr; }
+        if (p) { (void) hipFree(p); p = nullptr; }
         n = count;
         if (count == 0) return hipSuccess;
         return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
@@ -94,6 +89,23 @@ struct DevBuf {
     }
 };
 
+// CPUs this process may actually use: min(affinity mask, cgroup-v2 cpu.max quota).  The GPU boxes expose
+// 256 hardware threads behind a 16-CPU quota; an OpenMP team sized from nproc would be throttled.
+int effective_cpus() {
+    int n = omp_get_num_procs();
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        char a[64];
+        long period = 0;
+        if (fscanf(f, "%63s %ld", a, &period) == 2 && strcmp(a, "max") != 0 && period > 0) {
+            const long quota = atol(a);
+            if (quota > 0) n = (int) std::min<long>(n, std::max<long>(1, (quota + period - 1) / period));
+        }
+        fclose(f);
+    }
+    return std::max(n, 1);
+}
+
 }  // namespace
 
 struct mk_targetdb {
@@ -104,6 +116,7 @@ struct mk_targetdb {
     mk::Evaluer evaluer;
     int kmerThr = 0;
     uint64_t nEntries = 0;
+    uint32_t maxLen = 0;
     DevBuf<uint8_t> dRes, dMasked;
     DevBuf<uint64_t> dOff;
     DevBuf<uint32_t> dKmerOff;       // 20^6 + 1 (entries < 2^32)
@@ -115,6 +128,7 @@ struct mk_targetdb {
 
 struct mk_queries {
     uint32_t n = 0;
+    uint32_t maxLen = 0;
     std::vector<uint64_t> off;
     std::vector<uint8_t> res;
     mk::QueryDerived der;
@@ -134,46 +148,40 @@ int ensure_ready() {
     return MK_OK;
 }
 
-// ---- Smith-Waterman batches ---------------------------------------------------------------------
-struct PairRes { int score, qEnd, tEnd, qStart, tStart; bool word; };
+mk::AlignView align_view(const mk_targetdb *db, const mk_queries *q) {
+    mk::AlignView V;
+    V.q_res = q->dRes.p; V.q_bias8 = q->dBias8.p; V.q_off = q->dOff.p; V.n_queries = q->n;
+    V.t_res = db->dRes.p; V.t_off = db->dOff.p; V.n_targets = db->n; V.mat_aln = db->dMatAln.p;
+    V.max_q_len = q->maxLen; V.max_t_len = db->maxLen;
+    return V;
+}
 
-int bucket_of(uint32_t qLen) { return qLen <= 32 ? 0 : qLen <= 64 ? 1 : qLen <= 128 ? 2 : qLen <= 256 ? 3 : 4; }
-const int BUCKET_G[5] = {16, 16, 16, 16, 64};
-const int BUCKET_R[5] = {2, 4, 8, 16, 16};
-
-// run `jobs` (any order) through the right kernel variants; out[i] corresponds to jobs[i]
+// Test-path SW: explicit jobs built on the host, grouped by tile configuration.
 int run_sw_jobs(const mk_targetdb *db, const mk_queries *q, const mk_params *P, std::vector<mk::SwJob> &jobs,
                 std::vector<mk::SwOut> &out, const char *statName) {
     const size_t n = jobs.size();
     out.assign(n, mk::SwOut{0, -1, -1, 0});
     if (n == 0) return MK_OK;
-    HostTimer *htPrep = new HostTimer("host_sw_prepare");
-    // counting sort by (bucket, target length class) so that the DPs sharing a wave have similar lengths
-    const int CLS = 512;
-    std::vector<uint32_t> hist(5 * CLS + 1, 0);
-    auto keyOf = [&](const mk::SwJob &j) { return (uint32_t) (bucket_of(j.q_len) * CLS + (CLS - 1 - std::min<uint32_t>(j.t_len / 64, CLS - 1))); };
-    for (const mk::SwJob &j : jobs) hist[keyOf(j) + 1]++;
-    for (size_t k = 0; k < hist.size() - 1; k++) hist[k + 1] += hist[k];
-    std::vector<uint32_t> bucketStart(6);
-    for (int b = 0; b <= 5; b++) bucketStart[b] = hist[std::min<size_t>((size_t) b * CLS, hist.size() - 1)];
-    std::vector<uint32_t> order(n);
-    std::vector<mk::SwJob> sorted(n);
-    {
-        std::vector<uint32_t> cur(hist.begin(), hist.end() - 1);
-        for (size_t i = 0; i < n; i++) { const uint32_t p = cur[keyOf(jobs[i])]++; order[p] = (uint32_t) i; sorted[p] = jobs[i]; }
+    std::vector<mk::SwJob> sorted;
+    sorted.reserve(n);
+    uint32_t bounds[mk::SW_NCFG + 1];
+    for (int c = 0; c < mk::SW_NCFG; c++) {
+        bounds[c] = (uint32_t) sorted.size();
+        for (size_t i = 0; i < n; i++)
+            if (mk::sw_cfg_of(jobs[i].q_len) == c) { mk::SwJob j = jobs[i]; j.slot = (uint32_t) i; sorted.push_back(j); }
     }
-    delete htPrep;
+    bounds[mk::SW_NCFG] = (uint32_t) sorted.size();
     DevBuf<mk::SwJob> dJobs;
     DevBuf<mk::SwOut> dOut;
+    DevBuf<uint32_t> dBorder;
     HIPCHK(dJobs.upload(sorted.data(), n));
     HIPCHK(dOut.alloc(n));
-    DevBuf<uint2> dBorder;
-    for (int b = 0; b < 5; b++) {
-        const uint32_t lo = bucketStart[b], hi = bucketStart[b + 1];
+    for (int c = 0; c < mk::SW_NCFG; c++) {
+        const uint32_t lo = bounds[c], hi = bounds[c + 1];
         if (hi == lo) continue;
         mk::SwLaunch L;
         L.q_res = q->dRes.p; L.q_bias8 = q->dBias8.p; L.t_res = db->dRes.p; L.mat = db->dMatAln.p;
-        L.jobs = dJobs.p + lo; L.out = dOut.p + lo; L.n_jobs = hi - lo;
+        L.jobs = dJobs.p + lo; L.out = dOut.p; L.n_jobs = hi - lo; L.order = nullptr;
         L.boundary = nullptr; L.boundary_stride = 0;
         L.gap_open = P->gap_open; L.gap_extend = P->gap_extend;
         double cells = 0, bytes = 0;
@@ -182,97 +190,21 @@ int run_sw_jobs(const mk_targetdb *db, const mk_queries *q, const mk_params *P, 
             cells += (double) sorted[i].q_len * (double) sorted[i].t_len;
             bytes += (double) sorted[i].t_len + 2.0 * sorted[i].q_len + sizeof(mk::SwJob) + sizeof(mk::SwOut);
             maxT = std::max(maxT, sorted[i].t_len);
-            if (sorted[i].q_len > (uint32_t) (BUCKET_G[b] * BUCKET_R[b])) multi = true;
+            if (sorted[i].q_len > (uint32_t) mk::sw_cfg_rows(c)) multi = true;
         }
         if (multi) {
             HIPCHK(dBorder.alloc((size_t) (hi - lo) * maxT));
             L.boundary = dBorder.p; L.boundary_stride = maxT;
         }
         char nm[64];
-        snprintf(nm, sizeof(nm), "%s_g%dr%d", statName, BUCKET_G[b], BUCKET_R[b]);
+        snprintf(nm, sizeof(nm), "%s_rows%d", statName, mk::sw_cfg_rows(c));
         const int th = timed_begin(nm, bytes, cells);
-        HIPCHK(mk::launch_sw(L, BUCKET_G[b], BUCKET_R[b], g_stream));
+        HIPCHK(mk::launch_sw(L, c, g_stream));
         timed_end(th);
     }
-    std::vector<mk::SwOut> tmp(n);
-    HIPCHK(hipMemcpyAsync(tmp.data(), dOut.p, n * sizeof(mk::SwOut), hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipMemcpyAsync(out.data(), dOut.p, n * sizeof(mk::SwOut), hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
     timed_flush();
-    for (size_t p = 0; p < n; p++) out[order[p]] = tmp[p];
-    return MK_OK;
-}
-
-// forward (byte semantics, then word semantics where the byte pass would have saturated) and, for the
-// pairs flagged in needStart, the reverse pass.  ssw_align_private<SEQ_SEQ> (StripedSmithWaterman.cpp:309-545)
-int sw_pairs(const mk_targetdb *db, const mk_queries *q, const mk_params *P, const uint32_t *qIdx, const uint32_t *tIdx,
-             size_t n, const std::vector<uint8_t> *needStartIn, std::vector<PairRes> &res,
-             std::vector<uint8_t> *needStartOut = nullptr, bool (*decide)(void *, size_t, const PairRes &) = nullptr, void *ctx = nullptr) {
-    res.assign(n, PairRes{0, -1, -1, -1, -1, false});
-    const int LB = P->simd_lanes_byte, LW = P->simd_lanes_word;
-    std::vector<mk::SwJob> jobs(n);
-    for (size_t p = 0; p < n; p++) {
-        if (qIdx[p] >= q->n || tIdx[p] >= db->n) return fail(MK_ERR_ARG, "pair %zu out of range", p);
-        mk::SwJob &j = jobs[p];
-        j.q_start = (uint32_t) q->off[qIdx[p]]; j.q_len = (uint32_t) (q->off[qIdx[p] + 1] - q->off[qIdx[p]]);
-        j.t_start = db->off[tIdx[p]]; j.t_len = (uint32_t) (db->off[tIdx[p] + 1] - db->off[tIdx[p]]);
-        j.q_step = 1; j.t_step = 1;
-        j.seg_len = (j.q_len + LB - 1) / LB;
-    }
-    std::vector<mk::SwOut> out;
-    int rc = run_sw_jobs(db, q, P, jobs, out, "sw_fwd");
-    if (rc != MK_OK) return rc;
-    std::vector<size_t> redo;
-    for (size_t p = 0; p < n; p++) {
-        res[p].score = out[p].score; res[p].tEnd = out[p].end_col; res[p].qEnd = out[p].end_row;
-        if (out[p].score + q->der.swBias[qIdx[p]] >= 255) redo.push_back(p);    // sw_sse2_byte overflow (:879-883)
-    }
-    if (!redo.empty()) {
-        std::vector<mk::SwJob> j2(redo.size());
-        for (size_t k = 0; k < redo.size(); k++) { j2[k] = jobs[redo[k]]; j2[k].seg_len = (j2[k].q_len + LW - 1) / LW; }
-        std::vector<mk::SwOut> o2;
-        rc = run_sw_jobs(db, q, P, j2, o2, "sw_fwd_word");
-        if (rc != MK_OK) return rc;
-        for (size_t k = 0; k < redo.size(); k++) {
-            PairRes &r = res[redo[k]];
-            r.score = o2[k].score; r.tEnd = o2[k].end_col; r.qEnd = o2[k].end_row; r.word = true;
-        }
-    }
-    // which pairs need start positions
-    std::vector<size_t> rev;
-    {
-        HostTimer ht("host_evalue_gate");
-        std::vector<uint8_t> needV(n, 0);
-#pragma omp parallel for schedule(static)
-        for (size_t p = 0; p < n; p++)
-            needV[p] = needStartIn ? ((*needStartIn)[p] != 0) : (decide ? decide(ctx, p, res[p]) : false);
-        for (size_t p = 0; p < n; p++) {
-            if (needStartOut) (*needStartOut)[p] = needV[p];
-            if (needV[p] && res[p].score > 0) rev.push_back(p);
-        }
-    }
-    if (!rev.empty()) {
-        std::vector<mk::SwJob> j3(rev.size());
-        for (size_t k = 0; k < rev.size(); k++) {
-            const size_t p = rev[k];
-            const PairRes &r = res[p];
-            mk::SwJob &j = j3[k];
-            j.q_len = (uint32_t) r.qEnd + 1; j.t_len = (uint32_t) r.tEnd + 1;
-            j.q_start = jobs[p].q_start + (uint32_t) r.qEnd; j.q_step = -1;
-            j.t_start = jobs[p].t_start + (uint64_t) r.tEnd; j.t_step = -1;
-            const int lanes = r.word ? LW : LB;
-            j.seg_len = (j.q_len + lanes - 1) / lanes;
-        }
-        std::vector<mk::SwOut> o3;
-        rc = run_sw_jobs(db, q, P, j3, o3, "sw_rev");
-        if (rc != MK_OK) return rc;
-        for (size_t k = 0; k < rev.size(); k++) {
-            PairRes &r = res[rev[k]];
-            if (o3[k].score != r.score)
-                return fail(MK_ERR_SW_MISMATCH, "Score of forward/backward SW differ: %d %d (pair %zu)", r.score, o3[k].score, rev[k]);
-            r.tStart = r.tEnd - o3[k].end_col;
-            r.qStart = r.qEnd - o3[k].end_row;
-        }
-    }
     return MK_OK;
 }
 
@@ -281,24 +213,6 @@ int sw_pairs(const mk_targetdb *db, const mk_queries *q, const mk_params *P, con
 extern "C" {
 
 const char *mk_last_error(void) { return g_err.c_str(); }
-
-// CPUs this process may actually use: min(affinity mask, cgroup-v2 cpu.max quota).  The GPU boxes expose
-// 256 hardware threads behind a 16-CPU quota; an OpenMP team sized from nproc would be throttled.
-static int effective_cpus() {
-    int n = omp_get_num_procs();
-    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
-    if (f) {
-        char a[64];
-        long period = 0;
-        if (fscanf(f, "%63s %ld", a, &period) == 2 && strcmp(a, "max") != 0 && period > 0) {
-            const long quota = atol(a);
-            if (quota > 0) n = std::min<long>(n, std::max<long>(1, (quota + period - 1) / period));
-        }
-        fclose(f);
-    }
-    return std::max(n, 1);
-}
-
 int mk_host_threads(void) { return effective_cpus(); }
 
 int mk_init(int device) {
@@ -340,8 +254,11 @@ int mk_targetdb_create(const uint8_t *residues, const uint64_t *offsets, uint32_
     mk_targetdb *db = new mk_targetdb();
     db->n = n;
     db->off.assign(offsets, offsets + n + 1);
-    for (uint32_t i = 0; i < n; i++)
-        if (offsets[i + 1] - offsets[i] >= 32768) { delete db; return fail(MK_ERR_UNSUPPORTED, "target %u is >= 32768 residues: the reference's wrapped-diagonal path (UngappedAlignment.cpp:312-329) is not restated", i); }
+    for (uint32_t i = 0; i < n; i++) {
+        const uint64_t L = offsets[i + 1] - offsets[i];
+        if (L >= 32768) { delete db; return fail(MK_ERR_UNSUPPORTED, "target %u is >= 32768 residues: the reference's wrapped-diagonal path (UngappedAlignment.cpp:312-329) is not restated", i); }
+        db->maxLen = std::max<uint32_t>(db->maxLen, (uint32_t) L);
+    }
     mk::build_submat(db->kmerMat, mk::MAT_VTML80, 8.0f, -0.2f);     // Prefiltering.cpp:68
     mk::build_submat(db->ungMat, mk::MAT_BLOSUM62, 2.0f, -0.2f);    // Prefiltering.cpp:69
     mk::build_submat(db->alnMat, mk::MAT_BLOSUM62, 2.0f, 0.0f);     // Alignment.cpp:152
@@ -394,8 +311,11 @@ int mk_queries_create(const uint8_t *residues, const uint64_t *offsets, uint32_t
     q->n = n;
     q->off.assign(offsets, offsets + n + 1);
     q->res.assign(residues, residues + offsets[n]);
-    for (uint32_t i = 0; i < n; i++)
-        if (offsets[i + 1] - offsets[i] >= 32768) { delete q; return fail(MK_ERR_UNSUPPORTED, "query %u is >= 32768 residues", i); }
+    for (uint32_t i = 0; i < n; i++) {
+        const uint64_t L = offsets[i + 1] - offsets[i];
+        if (L >= 32768) { delete q; return fail(MK_ERR_UNSUPPORTED, "query %u is >= 32768 residues", i); }
+        q->maxLen = std::max<uint32_t>(q->maxLen, (uint32_t) L);
+    }
     mk::SubMat kmerMat, alnMat;
     mk::build_submat(kmerMat, mk::MAT_VTML80, 8.0f, -0.2f);
     mk::build_submat(alnMat, mk::MAT_BLOSUM62, 2.0f, 0.0f);
@@ -419,18 +339,44 @@ int mk_queries_create(const uint8_t *residues, const uint64_t *offsets, uint32_t
 
 void mk_queries_destroy(mk_queries *q) { delete q; }
 
+// forward + (optionally) reverse pass on explicit pairs: ssw_align_private<SEQ_SEQ> (StripedSmithWaterman.cpp:309-545)
 int mk_sw_pairs(mk_targetdb *db, mk_queries *q, const mk_params *P, const uint32_t *qIdx, const uint32_t *tIdx,
                 uint64_t n, int withStart, int32_t *out5) {
     int rc = ensure_ready();
     if (rc) return rc;
     if (!db || !q || !P || !out5) return fail(MK_ERR_ARG, "null argument");
-    std::vector<PairRes> res;
-    std::vector<uint8_t> need(n, withStart ? 1 : 0);
-    rc = sw_pairs(db, q, P, qIdx, tIdx, n, &need, res);
-    if (rc) return rc;
+    std::vector<mk::SwJob> jobs(n);
     for (uint64_t p = 0; p < n; p++) {
-        out5[p * 5 + 0] = res[p].score; out5[p * 5 + 1] = res[p].qEnd; out5[p * 5 + 2] = res[p].tEnd;
-        out5[p * 5 + 3] = res[p].qStart; out5[p * 5 + 4] = res[p].tStart;
+        if (qIdx[p] >= q->n || tIdx[p] >= db->n) return fail(MK_ERR_ARG, "pair %llu out of range", (unsigned long long) p);
+        mk::SwJob &j = jobs[p];
+        j.q_start = (uint32_t) q->off[qIdx[p]]; j.q_len = (uint32_t) (q->off[qIdx[p] + 1] - q->off[qIdx[p]]);
+        j.t_start = db->off[tIdx[p]]; j.t_len = (uint32_t) (db->off[tIdx[p] + 1] - db->off[tIdx[p]]);
+        j.q_step = 1; j.t_step = 1; j.slot = (uint32_t) p;
+    }
+    std::vector<mk::SwOut> fwd, rev;
+    rc = run_sw_jobs(db, q, P, jobs, fwd, "sw_fwd");
+    if (rc) return rc;
+    std::vector<mk::SwJob> rj;
+    std::vector<uint64_t> rp;
+    for (uint64_t p = 0; p < n; p++) {
+        out5[p * 5 + 0] = fwd[p].score; out5[p * 5 + 1] = fwd[p].end_row; out5[p * 5 + 2] = fwd[p].end_col;
+        out5[p * 5 + 3] = -1; out5[p * 5 + 4] = -1;
+        if (withStart && fwd[p].score > 0) {
+            mk::SwJob j;
+            j.q_len = (uint32_t) fwd[p].end_row + 1; j.t_len = (uint32_t) fwd[p].end_col + 1;
+            j.q_start = jobs[p].q_start + (uint32_t) fwd[p].end_row; j.q_step = -1;
+            j.t_start = jobs[p].t_start + (uint64_t) fwd[p].end_col; j.t_step = -1; j.slot = 0;
+            rj.push_back(j); rp.push_back(p);
+        }
+    }
+    rc = run_sw_jobs(db, q, P, rj, rev, "sw_rev");
+    if (rc) return rc;
+    for (size_t k = 0; k < rp.size(); k++) {
+        const uint64_t p = rp[k];
+        if (rev[k].score != fwd[p].score)
+            return fail(MK_ERR_SW_MISMATCH, "Score of forward/backward SW differ: %d %d (pair %llu)", fwd[p].score, rev[k].score, (unsigned long long) p);
+        out5[p * 5 + 3] = fwd[p].end_row - rev[k].end_row;
+        out5[p * 5 + 4] = fwd[p].end_col - rev[k].end_col;
     }
     return MK_OK;
 }
@@ -476,11 +422,11 @@ int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     V.mat_ung = db->dMatUng.p;
     std::string err;
     const int binCount = mk::bin_count_for(db->n, P->host_l2_bytes);
-    HostTimer ht("host_prefilter_total");
-    rc = mk::run_prefilter(V, q->off, q->res, q->der.diagCorr.data(), db->off, *P, binCount, g_stream, q->hits, q->hitOff, err,
-                           [](const char *name, double bytes, double cells) { return timed_begin(name, bytes, cells); },
-                           [](int h) { timed_end(h); },
-                           [](int h, double bytes, double cells) { if (h >= 0) { g_pending[h].bytes = bytes; g_pending[h].cells = cells; } });
+    {
+        HostTimer ht("host_prefilter_total");
+        rc = mk::run_prefilter(V, q->off, q->res, q->der.diagCorr.data(), db->off, *P, binCount, g_stream, q->hits, q->hitOff, err,
+                               timed_begin, timed_end, timed_set);
+    }
     timed_flush();
     if (rc != MK_OK) return fail(rc, "%s", err.c_str());
     q->havePref = true;
@@ -502,6 +448,8 @@ int mk_prefilter_result_set(mk_queries *q, const mk_hit *hits, const uint64_t *o
     return MK_OK;
 }
 
+// Alignment::run over the batch (Alignment.cpp:312-514): SW on the device, then Matcher::getSWResult's
+// float/double tail (Matcher.cpp:60-142), Alignment::checkCriteria (:548-567) and the per-query sort (:403-405)
 int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     int rc = ensure_ready();
     if (rc) return rc;
@@ -509,47 +457,77 @@ int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     if (!q->havePref) return fail(MK_ERR_ARG, "mk_align: the batch has no prefilter result");
     HostTimer htAll("host_align_total");
     const size_t n = q->hits.size();
-    std::vector<uint32_t> qIdx(n), tIdx(n);
-#pragma omp parallel for schedule(static)
-    for (uint32_t i = 0; i < q->n; i++)
-        for (uint64_t h = q->hitOff[i]; h < q->hitOff[i + 1]; h++) { qIdx[h] = i; tIdx[h] = q->hits[h].seq_id; }
-    struct Ctx { const mk_targetdb *db; const mk_queries *q; const mk_params *P; const uint32_t *qIdx; std::vector<double> ev; } ctx{db, q, P, qIdx.data(), std::vector<double>(n, 0.0)};
-    std::vector<PairRes> res;
-    std::vector<uint8_t> need(n, 0);
-    // reverse pass only where the e-value gate passes (ssw_align_private :390-398, covThr = 0)
-    rc = sw_pairs(db, q, P, qIdx.data(), tIdx.data(), n, nullptr, res, &need,
-                  [](void *c, size_t p, const PairRes &r) -> bool {
-                      Ctx *x = static_cast<Ctx *>(c);
-                      if (r.score <= 0) return false;
-                      const uint32_t qi = x->qIdx[p];
-                      const double qLen = (double) (x->q->off[qi + 1] - x->q->off[qi]);
-                      x->ev[p] = x->db->evaluer.evalue((double) r.score, qLen);
-                      return !(x->ev[p] > x->P->evalue_thr);
-                  }, &ctx);
-    if (rc) return rc;
-    // Matcher::getSWResult (Matcher.cpp:60-142) + Alignment::checkCriteria (Alignment.cpp:548-567) + sort (:403-405)
+    std::vector<uint32_t> tIdx(n);
+    double work[2 * mk::SW_NCFG];
+    for (int c = 0; c < 2 * mk::SW_NCFG; c++) work[c] = 0;
+    {
+        HostTimer ht("host_align_prepare");
+#pragma omp parallel
+        {
+            double w[2 * mk::SW_NCFG];
+            for (int c = 0; c < 2 * mk::SW_NCFG; c++) w[c] = 0;
+#pragma omp for schedule(static)
+            for (uint32_t i = 0; i < q->n; i++) {
+                const uint32_t qLen = (uint32_t) (q->off[i + 1] - q->off[i]);
+                const int c = mk::sw_cfg_of(qLen);
+                for (uint64_t h = q->hitOff[i]; h < q->hitOff[i + 1]; h++) {
+                    const uint32_t t = q->hits[h].seq_id;
+                    tIdx[h] = t;
+                    const uint32_t tLen = t < db->n ? (uint32_t) (db->off[t + 1] - db->off[t]) : 0;
+                    w[2 * c] += (double) tLen + 2.0 * qLen + sizeof(mk::SwJob) + sizeof(mk::SwOut);
+                    w[2 * c + 1] += (double) qLen * (double) tLen;
+                }
+            }
+#pragma omp critical
+            for (int c = 0; c < 2 * mk::SW_NCFG; c++) work[c] += w[c];
+        }
+    }
+    for (size_t h = 0; h < n; h++) if (tIdx[h] >= db->n) return fail(MK_ERR_ARG, "prefilter hit %zu names target %u (DB has %u)", h, tIdx[h], db->n);
+    std::vector<mk::GateEntry> gate;
+    {
+        HostTimer ht("host_gate_table");
+        mk::build_gate_table(db->evaluer, P->evalue_thr, q->off, gate);
+    }
+    std::vector<mk::AlnRaw> raw;
+    std::string err;
+    rc = mk::run_align_device(align_view(db, q), q->hitOff.data(), tIdx.data(), n, gate, *P, g_stream, work, raw, err,
+                              timed_begin, timed_end, timed_set);
+    timed_flush();
+    if (rc != MK_OK) return fail(rc, "%s", err.c_str());
     HostTimer ht("host_align_assemble");
-    std::vector<mk_alignment> tmp(n);
+    // raw is ordered by pair index == by query; slice it per query
+    const size_t m = raw.size();
+    std::vector<uint64_t> first(q->n + 1, 0);
+    {
+        size_t k = 0;
+        for (uint32_t i = 0; i < q->n; i++) {
+            while (k < m && raw[k].pair < q->hitOff[i]) k++;
+            first[i] = k;
+        }
+        first[q->n] = m;
+    }
+    std::vector<mk_alignment> tmp(m);
     std::vector<uint32_t> cnt(q->n, 0);
-#pragma omp parallel for schedule(dynamic, 256)
+    int mismatch = 0;
+#pragma omp parallel for schedule(dynamic, 512) reduction(+ : mismatch)
     for (uint32_t i = 0; i < q->n; i++) {
         const int qLen = (int) (q->off[i + 1] - q->off[i]);
-        const uint64_t begin = q->hitOff[i];
+        const uint64_t begin = first[i];
         uint64_t w = begin;
-        for (uint64_t p = q->hitOff[i]; p < q->hitOff[i + 1]; p++) {
-            const PairRes &r = res[p];
-            if (r.score <= 0 || !need[p]) continue;       // e-value above threshold: rejected by checkCriteria
-            const uint32_t t = tIdx[p];
+        for (uint64_t k = first[i]; k < first[i + 1]; k++) {
+            const mk::AlnRaw &r = raw[k];
+            if (r.q_start == -2) { mismatch++; continue; }
+            const uint32_t t = tIdx[r.pair];
             const int tLen = (int) (db->off[t + 1] - db->off[t]);
             mk_alignment a;
             a.db_key = t; a.q_len = qLen; a.db_len = tLen; a.raw_score = r.score;
-            a.evalue = ctx.ev[p];
-            a.qcov = mk::compute_cov((unsigned) r.qStart, (unsigned) r.qEnd, (unsigned) qLen);
-            a.dbcov = mk::compute_cov((unsigned) r.tStart, (unsigned) r.tEnd, (unsigned) tLen);
-            a.q_start = r.qStart; a.q_end = r.qEnd; a.db_start = r.tStart; a.db_end = r.tEnd;
-            a.aln_len = std::max(std::abs(r.qEnd - r.qStart), std::abs(r.tEnd - r.tStart)) + 1;
-            const unsigned int qAln = std::max((unsigned) r.qEnd - (unsigned) r.qStart, 1u);
-            const unsigned int dbAln = std::max((unsigned) r.tEnd - (unsigned) r.tStart, 1u);
+            a.evalue = db->evaluer.evalue((double) r.score, (double) qLen);
+            a.qcov = mk::compute_cov((unsigned) r.q_start, (unsigned) r.q_end, (unsigned) qLen);
+            a.dbcov = mk::compute_cov((unsigned) r.t_start, (unsigned) r.t_end, (unsigned) tLen);
+            a.q_start = r.q_start; a.q_end = r.q_end; a.db_start = r.t_start; a.db_end = r.t_end;
+            a.aln_len = std::max(std::abs(r.q_end - r.q_start), std::abs(r.t_end - r.t_start)) + 1;
+            const unsigned int qAln = std::max((unsigned) r.q_end - (unsigned) r.q_start, 1u);
+            const unsigned int dbAln = std::max((unsigned) r.t_end - (unsigned) r.t_start, 1u);
             const uint16_t s16 = (uint16_t) r.score;
             float sid = (s16 / static_cast<float>(std::max(qAln, dbAln))) * 0.1656 + 0.1141;   // Matcher.cpp:160-164
             sid = std::min(sid, 1.0f);
@@ -560,12 +538,13 @@ int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *P) {
         if (w - begin > 1) std::sort(tmp.begin() + begin, tmp.begin() + w, mk::alignment_less);
         cnt[i] = (uint32_t) (w - begin);
     }
+    if (mismatch) return fail(MK_ERR_SW_MISMATCH, "Score of forward/backward SW differ for %d pairs", mismatch);
     q->alnOff.assign((size_t) q->n + 1, 0);
     for (uint32_t i = 0; i < q->n; i++) q->alnOff[i + 1] = q->alnOff[i] + cnt[i];
     q->alns.resize(q->alnOff[q->n]);
 #pragma omp parallel for schedule(static)
     for (uint32_t i = 0; i < q->n; i++)
-        std::copy(tmp.begin() + q->hitOff[i], tmp.begin() + q->hitOff[i] + cnt[i], q->alns.begin() + q->alnOff[i]);
+        std::copy(tmp.begin() + first[i], tmp.begin() + first[i] + cnt[i], q->alns.begin() + q->alnOff[i]);
     q->haveAln = true;
     return MK_OK;
 }

@@ -1,0 +1,302 @@
+// metaeuk_amd/csrc/mk_align.hip -- the alignment stage as a device-resident pipeline.
+// Per batch: the (query,target) pairs of the prefilter result go up once (4 B per pair); jobs are built,
+// ordered by (tile configuration, target length), run forward, gated by the e-value table, run backward
+// for the survivors, and only the accepted pairs' integers come back (24 B each).
+//   expand_pairs_kernel  pair -> query (binary search in the per-query offsets), forward SwJob + sort key
+//   hipcub radix sort    jobs ordered so that the DPs sharing a wave have the same tile shape / similar length
+//   sw_kernel<G,R>       forward pass (mk_sw.hip), results scattered to pair order
+//   gate_kernel          e-value gate (table per query length) + reverse SwJob for the survivors
+//   sw_kernel<G,R>       reverse pass on the reversed prefixes -> start positions
+//   collect_kernel       AlnRaw records in pair order
+#include "mk_align.hpp"
+#include "mk_kernels.hpp"
+#include <hipcub/hipcub.hpp>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <omp.h>
+
+namespace mk {
+
+namespace {
+
+constexpr uint32_t KEY_CLS = 4096;
+
+__device__ __forceinline__ uint32_t sort_key(uint32_t qLen, uint32_t tLen) {
+    return (uint32_t) sw_cfg_of(qLen) * KEY_CLS + (KEY_CLS - 1 - min(tLen >> 4, KEY_CLS - 1));
+}
+
+__global__ __launch_bounds__(256) void expand_pairs_kernel(AlignView V, const uint64_t *hitOff, const uint32_t *tIdx, uint64_t n,
+                                                           SwJob *jobs, uint32_t *keys, uint32_t *idx, uint32_t *qOfPair) {
+    const uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    uint32_t lo = 0, hi = V.n_queries;              // largest q with hitOff[q] <= p
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (hitOff[mid] <= p) lo = mid; else hi = mid; }
+    const uint32_t q = lo, t = tIdx[p];
+    SwJob j;
+    j.q_start = (uint32_t) V.q_off[q]; j.q_len = (uint32_t) (V.q_off[q + 1] - V.q_off[q]);
+    j.t_start = V.t_off[t]; j.t_len = (uint32_t) (V.t_off[t + 1] - V.t_off[t]);
+    j.q_step = 1; j.t_step = 1; j.slot = (uint32_t) p;
+    jobs[p] = j;
+    keys[p] = sort_key(j.q_len, j.t_len);
+    idx[p] = (uint32_t) p;
+    qOfPair[p] = q;
+}
+
+// first index whose key >= c*KEY_CLS, for c = 0..SW_NCFG; plus the key at that index
+__global__ void bounds_kernel(const uint32_t *sortedKeys, uint32_t n, uint32_t *bounds /* SW_NCFG+1 */, uint32_t *firstKey /* SW_NCFG */) {
+    const uint32_t c = threadIdx.x;
+    if (c > SW_NCFG) return;
+    const uint32_t want = c * KEY_CLS;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sortedKeys[mid] < want) lo = mid + 1; else hi = mid; }
+    bounds[c] = lo;
+    if (c < SW_NCFG) firstKey[c] = lo < n ? sortedKeys[lo] : 0;
+}
+
+__global__ __launch_bounds__(256) void gate_kernel(AlignView V, const SwJob *fwdJobs, const SwOut *fwdOut, uint64_t n, const GateEntry *gate,
+                                                   uint32_t *revCount, uint32_t *revPair, SwJob *revJobs, uint32_t *revKeys, uint32_t *revIdx) {
+    const uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const SwOut o = fwdOut[p];
+    if (o.score <= 0) return;
+    const SwJob f = fwdJobs[p];
+    const GateEntry g = gate[f.q_len];
+    bool pass = o.score >= g.s0;
+    if (!pass && o.score < 256) pass = (g.mask[o.score >> 5] >> (o.score & 31)) & 1u;
+    if (!pass) return;
+    const uint32_t r = atomicAdd(revCount, 1u);
+    revPair[r] = (uint32_t) p;
+    SwJob j;
+    j.q_len = (uint32_t) o.end_row + 1; j.t_len = (uint32_t) o.end_col + 1;
+    j.q_start = f.q_start + (uint32_t) o.end_row; j.q_step = -1;
+    j.t_start = f.t_start + (uint64_t) o.end_col; j.t_step = -1;
+    j.slot = r;
+    revJobs[r] = j;
+    revKeys[r] = sort_key(j.q_len, j.t_len);
+    revIdx[r] = r;
+}
+
+__global__ void iota_kernel(uint32_t *p, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
+__global__ __launch_bounds__(256) void collect_kernel(const uint32_t *sortedPair, const uint32_t *sortedRev, uint32_t n,
+                                                      const SwOut *fwdOut, const SwOut *revOut, AlnRaw *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = sortedPair[i], r = sortedRev[i];
+    const SwOut f = fwdOut[p], b = revOut[r];
+    AlnRaw a;
+    a.pair = p; a.score = f.score; a.q_end = f.end_row; a.t_end = f.end_col;
+    // reverse score kept in q_start when it disagrees (the reference EXITs on that, :466-473)
+    if (b.score != f.score) { a.q_start = -2; a.t_start = b.score; }
+    else { a.q_start = f.end_row - b.end_row; a.t_start = f.end_col - b.end_col; }
+    out[i] = a;
+}
+
+}  // namespace
+
+// pass(score) table per query length present in the batch
+void build_gate_table(const Evaluer &ev, double evalThr, const std::vector<uint64_t> &qOff, std::vector<GateEntry> &table) {
+    uint32_t maxLen = 0;
+    const size_t n = qOff.size() - 1;
+    for (size_t i = 0; i < n; i++) maxLen = std::max<uint32_t>(maxLen, (uint32_t) (qOff[i + 1] - qOff[i]));
+    std::vector<uint8_t> present(maxLen + 1, 0);
+    for (size_t i = 0; i < n; i++) present[qOff[i + 1] - qOff[i]] = 1;
+    table.assign(maxLen + 1, GateEntry{1 << 30, {0, 0, 0, 0, 0, 0, 0, 0}});
+#pragma omp parallel for schedule(dynamic, 16)
+    for (uint32_t L = 1; L <= maxLen; L++) {
+        if (!present[L]) continue;
+        GateEntry g;
+        std::memset(&g, 0, sizeof(g));
+        // e-values fall monotonically with the score beyond the finite-size regime; scan high -> low for the last failure
+        const int SCAN = 4096;
+        int lastFail = 0;
+        for (int s = SCAN; s >= 1; s--) {
+            const bool pass = !(ev.evalue((double) s, (double) L) > evalThr);
+            if (!pass) { lastFail = s; break; }
+        }
+        g.s0 = lastFail >= SCAN ? (1 << 30) : lastFail + 1;
+        for (int s = 1; s < 256 && s < g.s0; s++)
+            if (!(ev.evalue((double) s, (double) L) > evalThr)) g.mask[s >> 5] |= 1u << (s & 31);
+        table[L] = g;
+    }
+}
+
+#define ACHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); return MK_ERR_DEVICE; } } while (0)
+#define ANULL(p) do { if (!(p)) { err = "device scratch allocation failed (" #p ")"; return MK_ERR_DEVICE; } } while (0)
+
+static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jobs, SwOut *out, uint32_t *keys, uint32_t *idx,
+                         uint32_t *keys2, uint32_t *idx2, uint32_t n, const char *tag, hipStream_t stream, std::string &err,
+                         timed_begin_fn tb, timed_end_fn te, int *handles /* SW_NCFG, may be null */) {
+    if (handles) for (int c = 0; c < SW_NCFG; c++) handles[c] = -1;
+    if (n == 0) return MK_OK;
+    hipcub::DoubleBuffer<uint32_t> kb(keys, keys2), vb(idx, idx2);
+    size_t tempBytes = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, kb, vb, (int) n, 0, 15, stream);
+    void *temp = dev_scratch("align_sort_temp", tempBytes);
+    ANULL(temp);
+    int th = tb("align_sort", 16.0 * n, 0);
+    ACHK(hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, kb, vb, (int) n, 0, 15, stream));
+    te(th);
+    uint32_t *dBounds = (uint32_t *) dev_scratch("align_bounds", 64 * sizeof(uint32_t));
+    ANULL(dBounds);
+    hipLaunchKernelGGL(bounds_kernel, dim3(1), dim3(64), 0, stream, kb.Current(), n, dBounds, dBounds + 32);
+    ACHK(hipGetLastError());
+    uint32_t hb[64];
+    ACHK(hipMemcpyAsync(hb, dBounds, sizeof(hb), hipMemcpyDeviceToHost, stream));
+    ACHK(hipStreamSynchronize(stream));
+    for (int c = 0; c < SW_NCFG; c++) {
+        const uint32_t lo = hb[c], hi = hb[c + 1];
+        if (hi <= lo) continue;
+        SwLaunch L;
+        L.q_res = V.q_res; L.q_bias8 = V.q_bias8; L.t_res = V.t_res; L.mat = V.mat_aln;
+        L.jobs = jobs; L.out = out; L.n_jobs = hi - lo; L.order = vb.Current() + lo;
+        L.boundary = nullptr; L.boundary_stride = 0;
+        L.gap_open = P.gap_open; L.gap_extend = P.gap_extend;
+        if (c == SW_NCFG - 1 && V.max_q_len > (uint32_t) sw_cfg_rows(c)) {
+            const uint32_t cls = KEY_CLS - 1 - (hb[32 + c] % KEY_CLS);          // largest target-length class in this bucket
+            const uint32_t stride = std::min<uint32_t>(V.max_t_len, (cls + 1) * 16);
+            L.boundary = (uint32_t *) dev_scratch("align_border", (size_t) (hi - lo) * stride * sizeof(uint32_t));
+            ANULL(L.boundary);
+            L.boundary_stride = stride;
+        }
+        char nm[64];
+        snprintf(nm, sizeof(nm), "%s_rows%d", tag, sw_cfg_rows(c));
+        th = tb(nm, 0, 0);
+        if (handles) handles[c] = th;
+        ACHK(launch_sw(L, c, stream));
+        te(th);
+    }
+    return MK_OK;
+}
+
+int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const uint32_t *tIdxHost, uint64_t nPairs,
+                     const std::vector<GateEntry> &gate, const mk_params &P, hipStream_t stream,
+                     const double *fwdWork /* per cfg: bytes, cells; may be null */,
+                     std::vector<AlnRaw> &out, std::string &err, timed_begin_fn tb, timed_end_fn te, timed_set_fn ts) {
+    out.clear();
+    if (nPairs == 0) return MK_OK;
+    if (nPairs >= 0x7FFFFFFFull) { err = "more than 2^31 pairs in one batch: split the batch"; return MK_ERR_UNSUPPORTED; }
+    const uint32_t n = (uint32_t) nPairs;
+    uint64_t *dHitOff = (uint64_t *) dev_scratch("align_hitoff", ((size_t) V.n_queries + 1) * sizeof(uint64_t));
+    uint32_t *dT = (uint32_t *) dev_scratch("align_tidx", (size_t) n * 4);
+    uint32_t *dQ = (uint32_t *) dev_scratch("align_qidx", (size_t) n * 4);
+    SwJob *dJobs = (SwJob *) dev_scratch("align_jobs", (size_t) n * sizeof(SwJob));
+    SwOut *dOut = (SwOut *) dev_scratch("align_out", (size_t) n * sizeof(SwOut));
+    uint32_t *dKeys = (uint32_t *) dev_scratch("align_keys", (size_t) n * 4), *dKeys2 = (uint32_t *) dev_scratch("align_keys2", (size_t) n * 4);
+    uint32_t *dIdx = (uint32_t *) dev_scratch("align_idx", (size_t) n * 4), *dIdx2 = (uint32_t *) dev_scratch("align_idx2", (size_t) n * 4);
+    GateEntry *dGate = (GateEntry *) dev_scratch("align_gate", gate.size() * sizeof(GateEntry));
+    uint32_t *dCount = (uint32_t *) dev_scratch("align_count", 16);
+    ANULL(dHitOff); ANULL(dT); ANULL(dQ); ANULL(dJobs); ANULL(dOut); ANULL(dKeys); ANULL(dKeys2); ANULL(dIdx); ANULL(dIdx2); ANULL(dGate); ANULL(dCount);
+    ACHK(hipMemcpyAsync(dHitOff, hitOffHost, ((size_t) V.n_queries + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    ACHK(hipMemcpyAsync(dT, tIdxHost, (size_t) n * 4, hipMemcpyHostToDevice, stream));
+    ACHK(hipMemcpyAsync(dGate, gate.data(), gate.size() * sizeof(GateEntry), hipMemcpyHostToDevice, stream));
+    ACHK(hipMemsetAsync(dOut, 0, (size_t) n * sizeof(SwOut), stream));
+    ACHK(hipMemsetAsync(dCount, 0, 16, stream));
+    int th = tb("align_expand", 48.0 * n, 0);
+    hipLaunchKernelGGL(expand_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, V, dHitOff, dT, (uint64_t) n, dJobs, dKeys, dIdx, dQ);
+    te(th);
+    ACHK(hipGetLastError());
+    int hFwd[SW_NCFG], hRev[SW_NCFG];
+    int rc = run_sorted_sw(V, P, dJobs, dOut, dKeys, dIdx, dKeys2, dIdx2, n, "sw_fwd", stream, err, tb, te, hFwd);
+    for (int c = 0; c < SW_NCFG; c++) if (hFwd[c] >= 0 && fwdWork) ts(hFwd[c], fwdWork[2 * c], fwdWork[2 * c + 1]);
+    if (rc != MK_OK) return rc;
+    // gate + reverse jobs (reuse the key/index buffers; at most n survivors)
+    uint32_t *dRevPair = (uint32_t *) dev_scratch("align_revpair", (size_t) n * 4);
+    SwJob *dRevJobs = (SwJob *) dev_scratch("align_revjobs", (size_t) n * sizeof(SwJob));
+    ANULL(dRevPair); ANULL(dRevJobs);
+    th = tb("align_gate", 48.0 * n, 0);
+    hipLaunchKernelGGL(gate_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, V, dJobs, dOut, (uint64_t) n, dGate, dCount, dRevPair, dRevJobs, dKeys, dIdx);
+    te(th);
+    ACHK(hipGetLastError());
+    uint32_t nRev = 0;
+    ACHK(hipMemcpyAsync(&nRev, dCount, 4, hipMemcpyDeviceToHost, stream));
+    ACHK(hipStreamSynchronize(stream));
+    if (nRev == 0) return MK_OK;
+    SwOut *dRevOut = (SwOut *) dev_scratch("align_revout", (size_t) nRev * sizeof(SwOut));
+    ANULL(dRevOut);
+    ACHK(hipMemsetAsync(dRevOut, 0, (size_t) nRev * sizeof(SwOut), stream));
+    rc = run_sorted_sw(V, P, dRevJobs, dRevOut, dKeys, dIdx, dKeys2, dIdx2, nRev, "sw_rev", stream, err, tb, te, hRev);
+    if (rc != MK_OK) return rc;
+    // order the survivors by pair index and collect
+    uint32_t *dSeq = (uint32_t *) dev_scratch("align_seq", (size_t) nRev * 4), *dSeq2 = (uint32_t *) dev_scratch("align_seq2", (size_t) nRev * 4);
+    uint32_t *dPair2 = (uint32_t *) dev_scratch("align_revpair2", (size_t) nRev * 4);
+    AlnRaw *dRaw = (AlnRaw *) dev_scratch("align_raw", (size_t) nRev * sizeof(AlnRaw));
+    ANULL(dSeq); ANULL(dSeq2); ANULL(dPair2); ANULL(dRaw);
+    hipLaunchKernelGGL(iota_kernel, dim3((nRev + 255) / 256), dim3(256), 0, stream, dSeq, nRev);
+    ACHK(hipGetLastError());
+    hipcub::DoubleBuffer<uint32_t> pb(dRevPair, dPair2), sb(dSeq, dSeq2);
+    size_t tempBytes = 0;
+    int bits = 1; while ((1ull << bits) < nPairs) bits++;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, pb, sb, (int) nRev, 0, bits, stream);
+    void *temp = dev_scratch("align_sort_temp", tempBytes);
+    ANULL(temp);
+    th = tb("align_sort", 16.0 * nRev, 0);
+    ACHK(hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, pb, sb, (int) nRev, 0, bits, stream));
+    te(th);
+    th = tb("align_collect", 64.0 * nRev, 0);
+    hipLaunchKernelGGL(collect_kernel, dim3((nRev + 255) / 256), dim3(256), 0, stream, pb.Current(), sb.Current(), nRev, dOut, dRevOut, dRaw);
+    te(th);
+    ACHK(hipGetLastError());
+    AlnRaw *hRaw = (AlnRaw *) pinned_scratch("align_raw_host", (size_t) nRev * sizeof(AlnRaw));
+    ANULL(hRaw);
+    ACHK(hipMemcpyAsync(hRaw, dRaw, (size_t) nRev * sizeof(AlnRaw), hipMemcpyDeviceToHost, stream));
+    ACHK(hipStreamSynchronize(stream));
+    out.assign(hRaw, hRaw + nRev);
+    // reverse-pass work per tile configuration, from the results
+    {
+        double w[2 * SW_NCFG];
+        for (int c = 0; c < 2 * SW_NCFG; c++) w[c] = 0;
+        for (uint32_t i = 0; i < nRev; i++) {
+            const uint32_t ql = (uint32_t) out[i].q_end + 1, tl = (uint32_t) out[i].t_end + 1;
+            const int c = sw_cfg_of(ql);
+            w[2 * c] += (double) tl + 2.0 * ql + sizeof(SwJob) + sizeof(SwOut);
+            w[2 * c + 1] += (double) ql * (double) tl;
+        }
+        for (int c = 0; c < SW_NCFG; c++) if (hRev[c] >= 0) ts(hRev[c], w[2 * c], w[2 * c + 1]);
+    }
+    (void) dQ;
+    return MK_OK;
+}
+
+// ---- persistent scratch buffers ------------------------------------------------------------------
+namespace {
+struct Scratch { void *p = nullptr; size_t cap = 0; bool pinned = false; };
+std::map<std::string, Scratch> &scratch_map() { static std::map<std::string, Scratch> m; return m; }
+}
+
+void *dev_scratch(const char *name, size_t bytes) {
+    Scratch &s = scratch_map()[std::string("d:") + name];
+    if (bytes <= s.cap && s.p) return s.p;
+    if (s.p) (void) hipFree(s.p);
+    s.p = nullptr; s.cap = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 8, 256);
+    if (hipMalloc(&s.p, want) != hipSuccess) { s.p = nullptr; return nullptr; }
+    s.cap = want;
+    return s.p;
+}
+
+void *pinned_scratch(const char *name, size_t bytes) {
+    Scratch &s = scratch_map()[std::string("h:") + name];
+    if (bytes <= s.cap && s.p) return s.p;
+    if (s.p) (void) hipHostFree(s.p);
+    s.p = nullptr; s.cap = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 8, 256);
+    if (hipHostMalloc(&s.p, want, hipHostMallocDefault) != hipSuccess) { s.p = nullptr; return nullptr; }
+    s.cap = want; s.pinned = true;
+    return s.p;
+}
+
+void scratch_release_all() {
+    for (auto &kv : scratch_map()) {
+        if (!kv.second.p) continue;
+        if (kv.first[0] == 'h') (void) hipHostFree(kv.second.p); else (void) hipFree(kv.second.p);
+        kv.second = Scratch();
+    }
+}
+
+}  // namespace mk

@@ -1,5 +1,5 @@
 // metaeuk_amd/csrc/mk_kernels.hpp -- device-side data structures and launch wrappers shared by the
-// HIP kernels (mk_sw.hip, mk_prefilter.hip) and the C-ABI glue (mk_abi.cpp).
+// HIP kernels (mk_sw.hip, mk_align.hip, mk_prefilter.hip) and the C-ABI glue (mk_abi.cpp).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -8,7 +8,7 @@ namespace mk {
 
 // One Smith-Waterman DP: rows = query residues q_res[q_start + k*q_step], k < q_len (with their int8
 // composition bias), columns = target residues t_res[t_start + c*t_step], c < t_len.
-// seg_len = stripe length ceil(q_len / simd lanes) of the reference build being reproduced.
+// `slot` = where the result goes (results are scattered back to the caller's pair order).
 struct SwJob {
     uint64_t t_start;
     uint32_t q_start;
@@ -16,7 +16,7 @@ struct SwJob {
     uint32_t t_len;
     int32_t q_step;      // +1 forward, -1 reverse pass
     int32_t t_step;
-    uint32_t seg_len;
+    uint32_t slot;
 };
 // result: score, first column (in pass order) where the maximum is reached, smallest row with the maximum there
 struct SwOut { int32_t score; int32_t end_col; int32_t end_row; int32_t pad; };
@@ -26,12 +26,25 @@ struct SwLaunch {
     const uint8_t *t_res;
     const int8_t *mat;          // 21x21 int8 substitution scores, mat[t*21+q]
     const SwJob *jobs; SwOut *out; uint64_t n_jobs;
-    uint2 *boundary;            // multi-tile scratch: per job max_tlen entries (may be null when single tile)
-    uint32_t boundary_stride;   // entries per job
+    const uint32_t *order;      // optional indirection: the kernel's i-th DP is jobs[order[i]]
+    uint32_t *boundary;         // multi-tile scratch: per job boundary_stride entries (null when every job is single tile)
+    uint32_t boundary_stride;
     int gap_open, gap_extend;
 };
-// G lanes per DP (16 or 64), R rows per lane (2,4,8,16)
-hipError_t launch_sw(const SwLaunch &L, int G, int R, hipStream_t stream);
+
+// tile configurations: G lanes per DP x R rows per lane; a job uses the smallest one whose G*R >= q_len
+// (the last one also handles longer queries in row tiles)
+constexpr int SW_NCFG = 8;
+__host__ __device__ inline int sw_cfg_rows(int c) {
+    const int rows[SW_NCFG] = {32, 64, 128, 256, 384, 512, 768, 1024};
+    return rows[c];
+}
+__host__ __device__ inline int sw_cfg_of(uint32_t qLen) {
+    int c = 0;
+    while (c < SW_NCFG - 1 && (uint32_t) sw_cfg_rows(c) < qLen) c++;
+    return c;
+}
+hipError_t launch_sw(const SwLaunch &L, int cfg, hipStream_t stream);
 
 struct UngappedJob { uint64_t t_start; uint32_t q_start; uint32_t q_len; uint32_t t_len; uint32_t diagonal; };
 struct UngappedLaunch {
@@ -41,5 +54,10 @@ struct UngappedLaunch {
     const UngappedJob *jobs; int32_t *out; uint64_t n_jobs;
 };
 hipError_t launch_ungapped(const UngappedLaunch &L, hipStream_t stream);
+
+// persistent, growable device / pinned-host buffers (one set per process; no hipMalloc on the hot path)
+void *dev_scratch(const char *name, size_t bytes);          // nullptr on allocation failure
+void *pinned_scratch(const char *name, size_t bytes);
+void scratch_release_all();
 
 }  // namespace mk

@@ -4,32 +4,38 @@
 // UngappedAlignment::computeSingelSequenceScores (M/src/prefiltering/UngappedAlignment.cpp:416-431).
 //
 // SW design (MI355X-first, not a port of the striped-SIMD layout):
-//   * one DP per G-lane group (G = 16 = one DPP row, or 64 = a whole wave); every lane owns R
-//     consecutive query rows in registers (H, E, best-key per row);
+//   * one DP per G-lane group (G = 16 = one DPP row, 32, or 64 = a whole wave); every lane owns R
+//     consecutive query rows in registers (H, E and a packed best-key per row);
 //   * the group sweeps the target as an anti-diagonal wavefront: at step s lane l is on column s-l;
-//     the three values that cross the lane boundary (H of the last row, the running F, the
-//     "within-stripe" F) and the target residue itself travel lane-to-lane with ONE pair of DPP
-//     row_shr / wave_shr moves per step -- no LDS, no bpermute; lane 0 injects residues/tile borders;
+//     what crosses the lane boundary -- H of the lane's last row, the running F, and the target
+//     residue itself -- travels lane-to-lane with two DPP row_shr / wave_shr moves per step:
+//     no LDS traffic, no bpermute; lane 0 injects residues (and tile borders);
 //   * substitution scores come from an LDS query profile prof[residue][row] (+int8 composition
 //     bias), one ds_read of R bytes per lane per column;
 //   * the running maximum is a packed key (score << 17 | ~column) per row, so the reference's
-//     "first column where the maximum is reached, smallest row in it" needs one v_max_u32 per cell;
+//     "first column where the maximum is reached, smallest row in it" costs one v_max_u32 per cell;
 //   * queries longer than G*R rows are processed in row tiles; the bottom row of a tile is parked in
-//     HBM (8 B per column) and re-read by lane 0 of the next tile.
-// Recurrence = the reference's as-implemented semantics (DESIGN.md "SW recurrence"): E is opened from
-// H' (before the lazy-F correction) and the in-column F restarts at every stripe head of the SIMD
-// layout being reproduced (seg_len), so results match the SSE/AVX2 builds bit for bit.
+//     HBM (4 B per column) and re-read by lane 0 of the next tile.
+// Recurrence: affine-gap local alignment, H = max(0, diag+s, E, F), E/F opened from H with gap_open and
+// extended with gap_extend.  The reference's striped kernels never open E out of a lazy-F-corrected
+// cell and restart the in-register F at stripe heads; both only forbid an F-gap directly followed by an
+// E-gap, and every such path has an equal-scoring twin with the two gaps swapped (E then F), which is
+// allowed.  H is therefore identical cell by cell to plain Gotoh for every SIMD width (DESIGN.md,
+// "SW recurrence"); the oracle keeps the literal striped semantics and the tests compare against it.
 #include "mk_kernels.hpp"
 
 namespace mk {
 
 template <int G>
-__device__ __forceinline__ uint32_t shift_up(uint32_t top, uint32_t x) {
-    // value held by lane-1 of the same group; lane 0 of the group keeps `top`
+__device__ __forceinline__ uint32_t shift_up(uint32_t top, uint32_t x, int laneInGroup) {
+    // value held by lane-1 of the same group; lane 0 of the group receives `top`
     if constexpr (G == 16) {
         return (uint32_t) __builtin_amdgcn_update_dpp((int) top, (int) x, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
-    } else {
+    } else if constexpr (G == 64) {
         return (uint32_t) __builtin_amdgcn_update_dpp((int) top, (int) x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    } else {
+        const uint32_t v = (uint32_t) __builtin_amdgcn_update_dpp((int) top, (int) x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        return laneInGroup == 0 ? top : v;
     }
 }
 
@@ -64,20 +70,19 @@ __global__ __launch_bounds__(BLOCK) void sw_kernel(SwLaunch L) {
     const uint64_t jobId = (uint64_t) blockIdx.x * GPB + grp;
     const bool have = jobId < L.n_jobs;
     SwJob job;
-    if (have) job = L.jobs[jobId];
-    else { job.t_start = 0; job.q_start = 0; job.q_len = 0; job.t_len = 0; job.q_step = 1; job.t_step = 1; job.seg_len = 1; }
+    if (have) job = L.jobs[L.order ? (uint64_t) L.order[jobId] : jobId];
+    else { job.t_start = 0; job.q_start = 0; job.q_len = 0; job.t_len = 0; job.q_step = 1; job.t_step = 1; job.slot = 0; }
     int8_t *prof = smem + (size_t) grp * 22 * ROWS;
     const int go = L.gap_open, ge = L.gap_extend;
     const int qLen = (int) job.q_len, tLen = (int) job.t_len;
-    const int segLen = job.seg_len > 0 ? (int) job.seg_len : 1;
     const int nTiles = (qLen + ROWS - 1) / ROWS;
-    uint2 *border = L.boundary ? L.boundary + jobId * (uint64_t) L.boundary_stride : nullptr;
+    uint32_t *border = L.boundary ? L.boundary + jobId * (uint64_t) L.boundary_stride : nullptr;
 
     uint32_t bestKey = 0;
     int bestRow = 0;
     for (int tile = 0; tile < nTiles; tile++) {
         const int row0 = tile * ROWS;
-        // ---- LDS query profile for this row tile: prof[t][row] = mat[t][q_row] + bias8[q_row] ----
+        // ---- LDS query profile for this row tile: prof[t][row] = mat[t][q_row] + bias8[q_row]; row 21 = zeros ----
         for (int idx = lane; idx < 22 * ROWS; idx += G) {
             const int t = idx / ROWS, row = idx - t * ROWS;
             const int q = row0 + row;
@@ -92,31 +97,24 @@ __global__ __launch_bounds__(BLOCK) void sw_kernel(SwLaunch L) {
         __builtin_amdgcn_wave_barrier();
 
         int H[R], E[R];
-        uint32_t key[R], keep[R];
+        uint32_t key[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            H[r] = 0; E[r] = 0; key[r] = 0;
-            keep[r] = ((row0 + lane * R + r) % segLen == 0) ? 0u : 0xFFFFFFFFu;   // in-column F restarts at stripe heads
-        }
-        uint32_t out0 = 0, out1 = 21u << 16;   // what this lane hands to lane+1: (H_last | F << 16), (Fm | residue << 16)
+        for (int r = 0; r < R; r++) { H[r] = 0; E[r] = 0; key[r] = 0; }
+        uint32_t out0 = 0, out1 = 21u;          // what this lane hands to lane+1: (H_last | F << 16), residue
         int hupPrev = 0;
         const int steps = tLen > 0 ? tLen + G - 1 : 0;
         const bool readTop = (tile > 0);
         const bool writeBottom = (tile + 1 < nTiles);
         for (int s = 0; s < steps; s++) {
-            uint32_t top0 = 0, top1 = 21u << 16;
+            uint32_t top0 = 0, top1 = 21u;      // residue code 21 = "no column": an all-zero profile row
             if (lane == 0 && s < tLen) {
-                const uint32_t res = L.t_res[(int64_t) job.t_start + (int64_t) s * job.t_step];
-                uint32_t fm = 0;
-                if (readTop) { const uint2 b = border[s]; top0 = b.x; fm = b.y & 0xFFFFu; }
-                top1 = fm | (res << 16);
+                top1 = L.t_res[(int64_t) job.t_start + (int64_t) s * job.t_step];
+                if (readTop) top0 = border[s];
             }
-            const uint32_t in0 = shift_up<G>(top0, out0);
-            const uint32_t in1 = shift_up<G>(top1, out1);
+            const uint32_t in0 = shift_up<G>(top0, out0, lane);
+            const uint32_t tres = shift_up<G>(top1, out1, lane);
             const int hup = (int) (in0 & 0xFFFFu);
             int F = (int) (in0 >> 16);
-            int Fm = (int) (in1 & 0xFFFFu);
-            const uint32_t tres = in1 >> 16;
             const int c = s - lane;
             const uint32_t cinv = 0x1FFFFu - (uint32_t) max(c, 0);
             int sc[R];
@@ -124,22 +122,19 @@ __global__ __launch_bounds__(BLOCK) void sw_kernel(SwLaunch L) {
             int dsave = hupPrev;
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                int d = min(dsave + sc[r], 32767);             // int16 saturating add of the word pass
+                const int d = min(dsave + sc[r], 32767);       // int16 saturating add of the reference's word pass
                 dsave = H[r];
-                const int fmr = (int) ((uint32_t) Fm & keep[r]);
-                const int hp = max3i(d, E[r], fmr);            // H' (E >= 0 keeps it non-negative)
-                const int h = max(hp, F);                      // H after the lazy-F correction
+                const int h = max3i(d, E[r], F);               // E >= 0 keeps H non-negative
                 key[r] = max(key[r], ((uint32_t) h << 17) | cinv);
-                const int ho = hp - go;
+                const int ho = h - go;
                 E[r] = max3i(E[r] - ge, ho, 0);
                 F = max3i(F - ge, ho, 0);
-                Fm = max3i(fmr - ge, ho, 0);
                 H[r] = h;
             }
             hupPrev = hup;
             out0 = (uint32_t) H[R - 1] | ((uint32_t) F << 16);
-            out1 = (uint32_t) Fm | (tres << 16);
-            if (writeBottom && lane == G - 1 && c >= 0 && c < tLen) border[c] = make_uint2(out0, (uint32_t) Fm);
+            out1 = tres;
+            if (writeBottom && lane == G - 1 && c >= 0 && c < tLen) border[c] = out0;
         }
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -161,7 +156,7 @@ __global__ __launch_bounds__(BLOCK) void sw_kernel(SwLaunch L) {
         o.end_col = o.score > 0 ? (int32_t) (0x1FFFFu - (bestKey & 0x1FFFFu)) : -1;
         o.end_row = o.score > 0 ? bestRow : -1;
         o.pad = 0;
-        L.out[jobId] = o;
+        L.out[job.slot] = o;
     }
 }
 
@@ -173,20 +168,26 @@ static hipError_t launch_one(const SwLaunch &L, hipStream_t stream) {
     if (blocks == 0) return hipSuccess;
     static bool attr = false;
     if (!attr && lds > 48 * 1024) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_kernel<G, R, BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_kernel<G, R, BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        if (e != hipSuccess) return e;
         attr = true;
     }
     hipLaunchKernelGGL((sw_kernel<G, R, BLOCK>), dim3((unsigned) blocks), dim3(BLOCK), lds, stream, L);
     return hipGetLastError();
 }
 
-hipError_t launch_sw(const SwLaunch &L, int G, int R, hipStream_t stream) {
-    if (G == 16 && R == 2) return launch_one<16, 2, 256>(L, stream);
-    if (G == 16 && R == 4) return launch_one<16, 4, 256>(L, stream);
-    if (G == 16 && R == 8) return launch_one<16, 8, 256>(L, stream);
-    if (G == 16 && R == 16) return launch_one<16, 16, 128>(L, stream);
-    if (G == 64 && R == 16) return launch_one<64, 16, 128>(L, stream);
-    return hipErrorInvalidValue;
+hipError_t launch_sw(const SwLaunch &L, int cfg, hipStream_t stream) {
+    switch (cfg) {
+        case 0: return launch_one<16, 2, 256>(L, stream);
+        case 1: return launch_one<16, 4, 256>(L, stream);
+        case 2: return launch_one<16, 8, 256>(L, stream);
+        case 3: return launch_one<16, 16, 128>(L, stream);
+        case 4: return launch_one<32, 12, 128>(L, stream);
+        case 5: return launch_one<32, 16, 128>(L, stream);
+        case 6: return launch_one<64, 12, 128>(L, stream);
+        case 7: return launch_one<64, 16, 128>(L, stream);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
