@@ -131,3 +131,73 @@ def test_pipeline_vs_oracle(gpu_api, small_workload, tmp_path):
             bad.append(("aln", i))
     assert not bad, bad[:10]
     assert int(hoff[-1]) > 100 and int(aoff[-1]) > 50
+
+
+# ---- golden fixtures (produced by the reference's own compiled code, tests/golden/make_golden.py) ----
+import gzip
+import os
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _lines(name):
+    with gzip.open(os.path.join(GOLD, name), "rt") as f:
+        return f.read().split("\n")[:-1]
+
+
+def _blocks(name):
+    return oracle.read_blocks(os.path.join(GOLD, name))
+
+
+@pytest.mark.parametrize("tag", ["small", "edge"])
+def test_pipeline_vs_golden(gpu_api, tag):
+    api = gpu_api
+    targets, queries = _lines(tag + "_targets.txt.gz"), _lines(tag + "_queries.txt.gz")
+    params = api.default_params()
+    params.host_l2_bytes = 2097152            # tests/golden/PROVENANCE.txt
+    db = api.TargetDB(targets, params)
+    q = api.Queries(queries, params)
+    hits, hoff = api.prefilter(db, q)
+    alns, aoff = api.align(db, q)
+    gpref, galn = _blocks(tag + "_pref.txt.gz"), _blocks(tag + "_aln.txt.gz")
+    assert len(gpref) == len(queries)
+    for i in range(len(queries)):
+        assert api.format_hits(hits, int(hoff[i]), int(hoff[i + 1])) == gpref[i], ("pref", i)
+        assert api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1])) == galn[i], ("aln", i)
+
+
+def test_sw_vs_golden(gpu_api):
+    """400 adversarial pairs (gap next to gap, poly-residue inserts, long related pairs): coordinates and bit
+    scores printed by the reference (AVX2 == SSE4.1) vs the kernel's integers"""
+    api = gpu_api
+    t, q = _lines("sw_targets.txt.gz"), _lines("sw_queries.txt.gz")
+    with gzip.open(os.path.join(GOLD, "sw_expected.tsv.gz"), "rt") as f:
+        exp = [l.rstrip("\n").split("\t") for l in f]
+    params = api.default_params()
+    db = api.TargetDB(t, params)
+    qq = api.Queries(q, params)
+    idx = np.arange(len(q), dtype=np.uint32)
+    got = api.sw_pairs(db, qq, idx, idx, with_start=True)
+    for k, e in enumerate(exp):
+        # columns: q t key bits seqid evalue qStart qEnd qLen tStart tEnd tLen
+        assert (int(got[k][3]), int(got[k][1]), int(got[k][4]), int(got[k][2])) == (int(e[6]), int(e[7]), int(e[9]), int(e[10])), (k, got[k], e)
+        assert int(got[k][0]) == oracle.sw(q[k], t[k])[0]
+
+
+def test_max_seqs_truncation_order(gpu_api, small_workload, tmp_path):
+    """--max-seqs smaller than the number of qualifying targets: the cut follows the reference's bin order"""
+    targets, queries = small_workload
+    api = gpu_api
+    params = api.default_params()
+    params.max_seqs = 3
+    db = api.TargetDB(targets, params)
+    q = api.Queries(queries, params)
+    hits, hoff = api.prefilter(db, q, params)
+    alns, aoff = api.align(db, q, params)
+    opref, oaln = oracle.run_pipeline(targets, queries, str(tmp_path), extra=["--l2", str(params.host_l2_bytes), "--max-seqs", "3"])
+    ntrunc = 0
+    for i in range(len(queries)):
+        assert api.format_hits(hits, int(hoff[i]), int(hoff[i + 1])) == opref[i], ("pref", i)
+        assert api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1])) == oaln[i], ("aln", i)
+        ntrunc += int(hoff[i + 1] - hoff[i]) == 3
+    assert ntrunc > 5
