@@ -1,0 +1,277 @@
+// metaeuk_amd/csrc/mk_cli.cpp -- `metaeuk-amd prefilter|align`: the two hot modules of
+// `metaeuk predictexons` with the reference's process-level signature, flag names and on-disk DB format,
+// on top of the C ABI (include/metaeuk_amd.h).
+//
+//   prefilter <i:queryDB> <i:targetDB> <o:prefilterDB> [flags]          M/src/MMseqsBase.cpp:591-598
+//   align     <i:queryDB> <i:targetDB> <i:prefilterDB> <o:alignmentDB>  M/src/MMseqsBase.cpp:641-649
+//
+// blastp.sh:70,85 invokes exactly these two with the flag strings built by
+// Parameters::createParameterString (Parameters.cpp:2811-2881), i.e. every flag of the module's list is
+// passed explicitly.  All of them are accepted here; the ones the predictexons path actually varies are
+// honoured, and a value that would change results in a way this build does not restate is a hard error
+// (the reference parser also fails hard on anything it does not know).  On failure nothing named
+// <out>.dbtype is left behind, because the workflows use that file as their "step done" marker
+// (blastp.sh:59,77).  Exit status non-zero on any error, as `EXIT(EXIT_FAILURE)` does (Util.h:14).
+#include "../../include/metaeuk_amd.h"
+#include "mk_dbio.hpp"
+
+#include <chrono>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include <unistd.h>
+
+namespace {
+
+struct Flag { const char *name; const char *def; bool honoured; };
+// union of the `prefilter` and `align` parameter lists (Parameters.cpp:387-455) + common ones
+const Flag FLAGS[] = {
+    {"--sub-mat", "aa:blosum62.out,nucl:nucleotide.out", false}, {"--seed-sub-mat", "aa:VTML80.out,nucl:nucleotide.out", false},
+    {"-s", "4", true}, {"-k", "0", false}, {"--k-score", "seq:2147483647,prof:2147483647", true},
+    {"--target-search-mode", "0", false}, {"--alph-size", "aa:21,nucl:5", false}, {"--max-seq-len", "65535", false},
+    {"--max-seqs", "300", true}, {"--split", "0", false}, {"--split-mode", "2", false}, {"--split-memory-limit", "0", false},
+    {"-c", "0", false}, {"--cov-mode", "0", false}, {"--comp-bias-corr", "1", true}, {"--comp-bias-corr-scale", "1", true},
+    {"--diag-score", "1", false}, {"--exact-kmer-matching", "0", false}, {"--mask", "1", true}, {"--mask-prob", "0.9", true},
+    {"--mask-lower-case", "0", false}, {"--mask-n-repeat", "0", false}, {"--min-ungapped-score", "15", true},
+    {"--add-self-matches", "0", false}, {"--spaced-kmer-mode", "1", false}, {"--spaced-kmer-pattern", "", false},
+    {"--local-tmp", "", false}, {"--db-load-mode", "0", false}, {"--pca", "", false}, {"--pcb", "", false},
+    {"--taxon-list", "", false}, {"--threads", "", true}, {"--compressed", "0", false}, {"-v", "3", true},
+    {"-a", "0", false}, {"--alignment-mode", "2", false}, {"--alignment-output-mode", "0", false}, {"--wrapped-scoring", "0", false},
+    {"-e", "100", true}, {"--min-seq-id", "0", false}, {"--min-aln-len", "0", true}, {"--seq-id-mode", "0", false},
+    {"--alt-ali", "0", false}, {"--max-rejected", "2147483647", false}, {"--max-accept", "2147483647", false},
+    {"--score-bias", "0", false}, {"--realign", "0", false}, {"--realign-score-bias", "-0.2", false}, {"--realign-max-seqs", "2147483647", false},
+    {"--corr-score-weight", "0", false}, {"--gap-open", "aa:11,nucl:5", true}, {"--gap-extend", "aa:1,nucl:2", true}, {"--zdrop", "40", false},
+    // properties of the reference build/host being reproduced (see mk_params in the ABI header)
+    {"--ref-simd", "avx2", true}, {"--ref-l2-bytes", "", true}, {"--gpu", "0", true},
+};
+
+int die(const char *fmt, const std::string &a = "") {
+    fprintf(stderr, fmt, a.c_str());
+    fprintf(stderr, "\n");
+    return EXIT_FAILURE;
+}
+
+bool sameValue(const std::string &v, const char *def) {
+    if (v == def) return true;
+    // numeric equality ("0.000" vs "0") and the aa: part of MultiParams ("aa:21,nucl:5")
+    char *e1, *e2;
+    const double a = strtod(v.c_str(), &e1), b = strtod(def, &e2);
+    if (*e1 == 0 && *e2 == 0 && e1 != v.c_str()) return a == b;
+    return false;
+}
+
+std::string aaPart(const std::string &v) {          // "aa:11,nucl:5" -> "11"; "11" -> "11"
+    const size_t p = v.find("aa:");
+    if (p == std::string::npos) return v;
+    const size_t c = v.find(',', p);
+    return v.substr(p + 3, c == std::string::npos ? std::string::npos : c - p - 3);
+}
+
+struct Args {
+    std::vector<std::string> pos;
+    std::map<std::string, std::string> opt;
+};
+
+int parse(int argc, char **argv, Args &a) {
+    for (int i = 2; i < argc; i++) {
+        const std::string s = argv[i];
+        if (s.size() >= 2 && s[0] == '-' && !(s[1] >= '0' && s[1] <= '9')) {
+            const Flag *f = nullptr;
+            for (const Flag &k : FLAGS) if (s == k.name) f = &k;
+            if (!f) return die("Unrecognized parameter \"%s\"", s);
+            if (i + 1 >= argc) return die("Missing argument %s", s);
+            a.opt[s] = argv[++i];
+        } else {
+            a.pos.push_back(s);
+        }
+    }
+    for (const Flag &k : FLAGS) {
+        auto it = a.opt.find(k.name);
+        if (it == a.opt.end() || k.honoured) continue;
+        std::string v = it->second, d = k.def;
+        if (std::string(k.name) == "--alph-size" || std::string(k.name) == "--sub-mat" || std::string(k.name) == "--seed-sub-mat") { v = aaPart(v); d = aaPart(d); }
+        if (std::string(k.name) == "--max-seq-len" || std::string(k.name) == "--split-memory-limit" || std::string(k.name) == "--local-tmp" ||
+            std::string(k.name) == "--db-load-mode" || std::string(k.name) == "--split" || std::string(k.name) == "--split-mode" ||
+            std::string(k.name) == "--pca" || std::string(k.name) == "--pcb" || std::string(k.name) == "--zdrop" || std::string(k.name) == "--realign-score-bias" ||
+            std::string(k.name) == "--realign-max-seqs" || std::string(k.name) == "--seq-id-mode" || std::string(k.name) == "--mask-lower-case" ||
+            std::string(k.name) == "--threads") continue;     // no effect on this path
+        if (std::string(k.name) == "-k") {                    // 0 = automatic = 6 below 3.35e9 target residues (IndexTable.h:439-449)
+            if (v != "0" && v != "6") { fprintf(stderr, "-k %s: only k = 6 (or 0 = auto) is implemented\n", v.c_str()); return EXIT_FAILURE; }
+            continue;
+        }
+        if (!sameValue(v, d.c_str())) {
+            fprintf(stderr, "%s %s: only the default (%s) is implemented by the MI355X path\n", k.name, it->second.c_str(), k.def);
+            return EXIT_FAILURE;
+        }
+    }
+    return 0;
+}
+
+int fillParams(const Args &a, mk_params &P, int &gpu) {
+    mk_default_params(&P);
+    P.sensitivity = 4.0f;                                    // Parameters.cpp:2360 (search overrides with -s explicitly)
+    P.min_aln_len = 0;                                       // module default; predictexons passes --min-aln-len 11
+    auto get = [&](const char *k) -> const std::string * { auto it = a.opt.find(k); return it == a.opt.end() ? nullptr : &it->second; };
+    if (auto v = get("-s")) P.sensitivity = (float) atof(v->c_str());
+    if (auto v = get("--k-score")) {
+        std::string s = *v;
+        const size_t p = s.find("seq:");
+        if (p != std::string::npos) s = s.substr(p + 4);
+        P.kmer_score = atoi(s.c_str());
+    }
+    if (auto v = get("--max-seqs")) P.max_seqs = atoi(v->c_str());
+    if (auto v = get("--min-ungapped-score")) P.min_ungapped_score = atoi(v->c_str());
+    if (auto v = get("--comp-bias-corr")) P.comp_bias_corr = atoi(v->c_str());
+    if (auto v = get("--comp-bias-corr-scale")) P.comp_bias_scale = (float) atof(v->c_str());
+    if (auto v = get("--mask")) P.mask = atoi(v->c_str());
+    if (auto v = get("--mask-prob")) P.mask_prob = (float) atof(v->c_str());
+    if (auto v = get("-e")) P.evalue_thr = atof(v->c_str());
+    if (auto v = get("--min-aln-len")) P.min_aln_len = atoi(v->c_str());
+    if (auto v = get("--gap-open")) P.gap_open = atoi(aaPart(*v).c_str());
+    if (auto v = get("--gap-extend")) P.gap_extend = atoi(aaPart(*v).c_str());
+    if (auto v = get("--threads")) setenv("OMP_NUM_THREADS", v->c_str(), 0);
+    if (auto v = get("--ref-simd")) {
+        if (*v == "sse41") { P.simd_lanes_byte = 16; P.simd_lanes_word = 8; P.simd_lanes_double = 2; }
+        else if (*v != "avx2") return die("--ref-simd must be avx2 or sse41 (got %s)", *v);
+    }
+    long l2 = sysconf(_SC_LEVEL2_CACHE_SIZE);                // Util::getL2CacheSize (Util.cpp:317-332) of THIS host
+    P.host_l2_bytes = l2 > 0 ? (uint64_t) l2 : 262144;
+    if (auto v = get("--ref-l2-bytes")) if (!v->empty()) P.host_l2_bytes = strtoull(v->c_str(), nullptr, 10);
+    gpu = 0;
+    if (auto v = get("--gpu")) gpu = atoi(v->c_str());
+    if (const char *lr = getenv("LOCAL_RANK")) if (!get("--gpu")) gpu = atoi(lr);
+    if (P.gap_open != 11 || P.gap_extend != 1) return die("only --gap-open 11 --gap-extend 1 has a hard-coded Gumbel parameter set in the reference (EvalueComputation.h:64-69); other values are not implemented%s");
+    return 0;
+}
+
+// sequence DB -> encoded residues + offsets, in LINEAR_ACCCESS (data offset) order
+void encodeDb(const mk::Database &db, std::vector<uint8_t> &res, std::vector<uint64_t> &off) {
+    off.assign(db.entries.size() + 1, 0);
+    for (size_t i = 0; i < db.entries.size(); i++) off[i + 1] = off[i] + db.seqLen(i);
+    res.assign(off.back() + 1, 0);
+    for (size_t i = 0; i < db.entries.size(); i++) mk_encode(db.entry(i), db.seqLen(i), res.data() + off[i]);
+}
+
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int cmdPrefilterOrAlign(bool isAlign, int argc, char **argv) {
+    Args a;
+    if (int rc = parse(argc, argv, a)) return rc;
+    const size_t need = isAlign ? 4 : 3;
+    if (a.pos.size() != need) {
+        fprintf(stderr, "usage: metaeuk-amd %s <i:queryDB> <i:targetDB> %s[options]\n", isAlign ? "align" : "prefilter",
+                isAlign ? "<i:resultDB> <o:alignmentDB> " : "<o:prefilterDB> ");
+        return EXIT_FAILURE;
+    }
+    mk_params P;
+    int gpu = 0;
+    if (int rc = fillParams(a, P, gpu)) return rc;
+    const double t0 = now();
+    mk::Database qdb, tdb;
+    std::string e = qdb.open(a.pos[0]);
+    if (!e.empty()) return die("%s", e);
+    e = tdb.open(a.pos[1]);
+    if (!e.empty()) return die("%s", e);
+    if ((qdb.dbtype & 0xFFFF) != mk::DBTYPE_AMINO_ACIDS || (tdb.dbtype & 0xFFFF) != mk::DBTYPE_AMINO_ACIDS)
+        return die("only amino-acid query and target databases are implemented (profile targets: SURVEY 8f-4)%s");
+    if (mk_init(gpu) != MK_OK) return die("%s", mk_last_error());
+    std::vector<uint8_t> qres, tres;
+    std::vector<uint64_t> qoff, toff;
+    encodeDb(qdb, qres, qoff);
+    encodeDb(tdb, tres, toff);
+    mk_targetdb *T = nullptr;
+    mk_queries *Q = nullptr;
+    if (mk_targetdb_create(tres.data(), toff.data(), (uint32_t) tdb.entries.size(), &P, &T) != MK_OK) return die("%s", mk_last_error());
+    if (mk_queries_create(qres.data(), qoff.data(), (uint32_t) qdb.entries.size(), &P, &Q) != MK_OK) return die("%s", mk_last_error());
+    const size_t nq = qdb.entries.size();
+    char line[512];
+    std::string buf;
+    if (!isAlign) {
+        if (mk_prefilter(T, Q, &P) != MK_OK) return die("%s", mk_last_error());
+        const mk_hit *hits; const uint64_t *hoff;
+        mk_prefilter_result(Q, &hits, &hoff);
+        mk::DatabaseWriter w(a.pos[2], mk::DBTYPE_PREFILTER_RES);
+        e = w.open();
+        if (!e.empty()) return die("%s", e);
+        for (size_t i = 0; i < nq; i++) {
+            buf.clear();
+            for (uint64_t h = hoff[i]; h < hoff[i + 1]; h++)    // seqId -> dbKey (Prefiltering.cpp:845-852)
+                buf.append(line, mk_format_hit(line, tdb.entries[hits[h].seq_id].key, hits[h].pref_score, hits[h].diagonal));
+            w.write(qdb.entries[i].key, buf.data(), buf.size());
+        }
+        e = w.close();
+        if (!e.empty()) return die("%s", e);
+        fprintf(stderr, "prefilter: %zu queries x %zu targets, %llu hits, %.2f s\n", nq, tdb.entries.size(), (unsigned long long) hoff[nq], now() - t0);
+    } else {
+        // read the prefilter DB: key \t score \t diagonal lines (QueryMatcher::parsePrefilterHit, QueryMatcher.h:87-102)
+        mk::Database pdb;
+        e = pdb.open(a.pos[2]);
+        if (!e.empty()) return die("%s", e);
+        std::map<uint32_t, uint32_t> qKeyToIdx, tKeyToIdx;
+        for (size_t i = 0; i < nq; i++) qKeyToIdx[qdb.entries[i].key] = (uint32_t) i;
+        for (size_t i = 0; i < tdb.entries.size(); i++) tKeyToIdx[tdb.entries[i].key] = (uint32_t) i;
+        std::vector<std::vector<mk_hit>> perQ(nq);
+        for (size_t i = 0; i < pdb.entries.size(); i++) {
+            auto qi = qKeyToIdx.find(pdb.entries[i].key);
+            if (qi == qKeyToIdx.end()) return die("Query sequence %s is required in the prefiltering, but is not contained in the query sequence database", std::to_string(pdb.entries[i].key));
+            const char *p = pdb.entry(i);
+            while (*p != '\0') {
+                char *q;
+                mk_hit h;
+                const uint32_t key = (uint32_t) strtoul(p, &q, 10);
+                h.pref_score = (int32_t) strtol(q, &q, 10);
+                h.diagonal = (uint16_t) (short) strtol(q, &q, 10);
+                h.pad_ = 0;
+                auto ti = tKeyToIdx.find(key);
+                if (ti == tKeyToIdx.end()) return die("Sequence %s is required in the prefiltering, but is not contained in the target sequence database", std::to_string(key));
+                h.seq_id = ti->second;
+                perQ[qi->second].push_back(h);
+                while (*q != '\n' && *q != '\0') q++;
+                p = (*q == '\n') ? q + 1 : q;
+            }
+        }
+        std::vector<uint64_t> hoff(nq + 1, 0);
+        std::vector<mk_hit> hits;
+        for (size_t i = 0; i < nq; i++) { hits.insert(hits.end(), perQ[i].begin(), perQ[i].end()); hoff[i + 1] = hits.size(); }
+        if (mk_prefilter_result_set(Q, hits.data(), hoff.data()) != MK_OK) return die("%s", mk_last_error());
+        if (mk_align(T, Q, &P) != MK_OK) return die("%s", mk_last_error());
+        const mk_alignment *alns; const uint64_t *aoff;
+        mk_align_result(Q, &alns, &aoff);
+        mk::DatabaseWriter w(a.pos[3], mk::DBTYPE_ALIGNMENT_RES);
+        e = w.open();
+        if (!e.empty()) return die("%s", e);
+        for (size_t i = 0; i < nq; i++) {
+            buf.clear();
+            for (uint64_t k = aoff[i]; k < aoff[i + 1]; k++) {
+                mk_alignment al = alns[k];
+                al.db_key = tdb.entries[al.db_key].key;
+                buf.append(line, mk_format_alignment(line, &al));
+            }
+            w.write(qdb.entries[i].key, buf.data(), buf.size());
+        }
+        e = w.close();
+        if (!e.empty()) return die("%s", e);
+        fprintf(stderr, "align: %llu alignments calculated, %llu passed, %.2f s\n", (unsigned long long) hits.size(), (unsigned long long) aoff[nq], now() - t0);
+    }
+    mk_queries_destroy(Q);
+    mk_targetdb_destroy(T);
+    return EXIT_SUCCESS;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    if (argc < 2) {
+        fprintf(stderr, "metaeuk-amd: MI355X prefilter+align modules of `metaeuk predictexons`\n  metaeuk-amd prefilter <queryDB> <targetDB> <prefilterDB> [flags]\n  metaeuk-amd align <queryDB> <targetDB> <prefilterDB> <alignmentDB> [flags]\n");
+        return EXIT_FAILURE;
+    }
+    const std::string cmd = argv[1];
+    if (cmd == "prefilter") return cmdPrefilterOrAlign(false, argc, argv);
+    if (cmd == "align") return cmdPrefilterOrAlign(true, argc, argv);
+    fprintf(stderr, "Invalid Command: %s\n", cmd.c_str());
+    return EXIT_FAILURE;
+}

@@ -201,3 +201,58 @@ def test_max_seqs_truncation_order(gpu_api, small_workload, tmp_path):
         assert api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1])) == oaln[i], ("aln", i)
         ntrunc += int(hoff[i + 1] - hoff[i]) == 3
     assert ntrunc > 5
+
+
+def _write_seq_db(base, seqs, keys=None):
+    """MMseqs2 sequence DB: data 'SEQ\\n\\0', index 'key\\toffset\\tlength', dbtype 0 (amino acids)"""
+    keys = keys if keys is not None else list(range(len(seqs)))
+    off = 0
+    with open(base, "wb") as d, open(base + ".index", "w") as i:
+        for k, s in zip(keys, seqs):
+            d.write(s.encode() + b"\n\0")
+            i.write("%d\t%d\t%d\n" % (k, off, len(s) + 2))
+            off += len(s) + 2
+    with open(base + ".dbtype", "wb") as t:
+        t.write((0).to_bytes(4, "little"))
+
+
+def _read_result_db(base):
+    data = open(base, "rb").read()
+    out = {}
+    for line in open(base + ".index"):
+        k, o, l = line.split("\t")
+        out[int(k)] = data[int(o):int(o) + int(l) - 1].decode()
+    return out
+
+
+def test_cli_prefilter_align_db_roundtrip(gpu_api, tmp_path):
+    """the `prefilter` / `align` commands over MMseqs2-format DBs, with the predictexons argv"""
+    import subprocess
+    from metaeuk_amd import build
+    targets, queries = _lines("small_targets.txt.gz"), _lines("small_queries.txt.gz")[:600]
+    qkeys = [3 * i + 1 for i in range(len(queries))]          # non-contiguous keys
+    _write_seq_db(str(tmp_path / "q"), queries, qkeys)
+    _write_seq_db(str(tmp_path / "t"), targets)
+    pre = [build.BIN, "prefilter", str(tmp_path / "q"), str(tmp_path / "t"), str(tmp_path / "pref_0"),
+           "--sub-mat", "aa:blosum62.out,nucl:nucleotide.out", "--seed-sub-mat", "aa:VTML80.out,nucl:nucleotide.out", "-k", "0",
+           "--k-score", "seq:2147483647,prof:2147483647", "--alph-size", "aa:21,nucl:5", "--max-seq-len", "65535", "--max-seqs", "300",
+           "--split", "0", "--split-mode", "2", "-c", "0", "--comp-bias-corr", "1", "--diag-score", "1", "--exact-kmer-matching", "0",
+           "--mask", "1", "--mask-prob", "0.9", "--min-ungapped-score", "15", "--spaced-kmer-mode", "1", "-s", "5.7", "--threads", "4",
+           "--ref-l2-bytes", "2097152"]
+    subprocess.check_call(pre)
+    aln = [build.BIN, "align", str(tmp_path / "q"), str(tmp_path / "t"), str(tmp_path / "pref_0"), str(tmp_path / "res"),
+           "--alignment-mode", "2", "-e", "100", "--min-aln-len", "11", "--min-seq-id", "0", "-c", "0", "--max-rejected", "2147483647",
+           "--max-accept", "2147483647", "--alt-ali", "0", "--realign", "0", "--gap-open", "aa:11,nucl:5", "--gap-extend", "aa:1,nucl:2",
+           "--comp-bias-corr", "1", "-a", "0", "--threads", "4"]
+    subprocess.check_call(aln)
+    assert open(tmp_path / "pref_0.dbtype", "rb").read() == (7).to_bytes(4, "little")
+    assert open(tmp_path / "res.dbtype", "rb").read() == (5).to_bytes(4, "little")
+    pref, res = _read_result_db(str(tmp_path / "pref_0")), _read_result_db(str(tmp_path / "res"))
+    gpref, galn = _blocks("small_pref.txt.gz"), _blocks("small_aln.txt.gz")
+    assert sorted(pref) == qkeys and sorted(res) == qkeys
+    for i, k in enumerate(qkeys):
+        assert pref[k] == gpref[i], ("pref", i)
+        assert res[k] == galn[i], ("aln", i)
+    # unknown flags are a hard error and leave no "done" marker behind
+    bad = subprocess.run([build.BIN, "prefilter", str(tmp_path / "q"), str(tmp_path / "t"), str(tmp_path / "x"), "--no-such-flag", "1"], capture_output=True)
+    assert bad.returncode != 0 and not (tmp_path / "x.dbtype").exists()
