@@ -99,6 +99,10 @@ int mk_targetdb_masked(const mk_targetdb *db, uint8_t *out /* residues */);
 int mk_queries_create(const uint8_t *residues, const uint64_t *offsets, uint32_t n_queries,
                       const mk_params *params, mk_queries **out);
 void mk_queries_destroy(mk_queries *q);
+/* test hook: the per-residue arrays derived on the device for this batch -- k-mer threshold per k-mer start
+ * (QueryMatcher.cpp:225-244; -1 = no k-mer / contains X), int8 diagonal correction (UngappedAlignment.cpp:391-396),
+ * int8 SW composition bias (StripedSmithWaterman.cpp:1228-1235).  Each array has offsets[n_queries] entries. */
+int mk_queries_derived(const mk_queries *q, int16_t *kmer_thr, int8_t *diag_corr, int8_t *sw_bias8);
 
 /* ---- prefilter: batch form of QueryMatcher::matchQuery (QueryMatcher.cpp:85-211).
  * Query i's hits are hits[offsets[i] .. offsets[i+1]), sorted like the reference (|score| desc,

@@ -41,7 +41,7 @@ HIT_DTYPE = np.dtype([("seq_id", "<u4"), ("pref_score", "<i4"), ("diagonal", "<u
 
 EXPORTS = ["mk_init", "mk_last_error", "mk_default_params", "mk_device_name", "mk_encode", "mk_targetdb_create",
            "mk_targetdb_destroy", "mk_targetdb_residues", "mk_targetdb_index_entries", "mk_targetdb_masked",
-           "mk_queries_create", "mk_queries_destroy", "mk_prefilter", "mk_prefilter_result", "mk_prefilter_result_set",
+           "mk_queries_create", "mk_queries_destroy", "mk_queries_derived", "mk_prefilter", "mk_prefilter_result", "mk_prefilter_result_set",
            "mk_align", "mk_align_result", "mk_sw_pairs", "mk_ungapped",
            "mk_kernel_stats", "mk_kernel_stats_reset", "mk_format_hit", "mk_format_alignment"]
 
@@ -145,6 +145,13 @@ class Queries:
     @classmethod
     def from_codes(cls, res, off, params=None):
         return cls(None, params, _codes=(np.ascontiguousarray(res, dtype=np.uint8), np.ascontiguousarray(off, dtype=np.uint64)))
+
+    def derived(self):
+        """(kmer_thr i16, diag_corr i8, sw_bias8 i8) as derived on the device -- test hook."""
+        total = int(self.off[-1])
+        kt = np.zeros(total, dtype=np.int16); dc = np.zeros(total, dtype=np.int8); sb = np.zeros(total, dtype=np.int8)
+        _chk(lib().mk_queries_derived(self.h, _p(kt), _p(dc), _p(sb)))
+        return kt, dc, sb
 
     def close(self):
         if self.h:

@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, "csrc", f) for f in ("mk_host.cpp", "mk_abi.cpp", "mk_sw.hip", "mk_align.hip", "mk_prefilter.hip", "mk_cli.cpp")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("mk_host.cpp", "mk_abi.cpp", "mk_sw.hip", "mk_align.hip", "mk_prefilter.hip", "mk_derive.hip", "mk_cli.cpp")]
 HDR = [os.path.join(HERE, "csrc", f) for f in ("mk_host.hpp", "mk_kernels.hpp", "mk_prefilter.hpp", "mk_align.hpp", "mk_dbio.hpp")] + [
     os.path.join(HERE, "..", "include", "metaeuk_amd.h"), os.path.join(HERE, "data", "matrices.inc")]
 LIB = os.path.join(HERE, "lib", "libmetaeuk_amd.so")
@@ -29,8 +29,22 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = [s for s in SRC if os.path.exists(s)]
     lib_srcs = [s for s in srcs if not s.endswith("mk_cli.cpp")]
-    if force or _stale(LIB, lib_srcs + HDR):
-        cmd = [hipcc] + FLAGS + ["-shared"] + lib_srcs + ["-o", LIB]
+    objdir = os.path.join(os.path.dirname(LIB), "obj")
+    os.makedirs(objdir, exist_ok=True)
+    objs, procs = [], []
+    for src in lib_srcs:                      # one object per translation unit, compiled in parallel, rebuilt only when stale
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + HDR):
+            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    if force or procs or _stale(LIB, objs):
+        cmd = [hipcc] + FLAGS + ["-shared"] + objs + ["-o", LIB]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -89,6 +89,15 @@ struct DevBuf {
     }
 };
 
+}  // namespace
+
+namespace mk {
+void host_stat(const char *name, double ms) { g_stats[name].ms += ms; }
+double ScopedHost::now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace mk
+
+namespace {
+
 // CPUs this process may actually use: min(affinity mask, cgroup-v2 cpu.max quota).  The GPU boxes expose
 // 256 hardware threads behind a 16-CPU quota; an OpenMP team sized from nproc would be throttled.
 int effective_cpus() {
@@ -131,7 +140,6 @@ struct mk_queries {
     uint32_t maxLen = 0;
     std::vector<uint64_t> off;
     std::vector<uint8_t> res;
-    mk::QueryDerived der;
     DevBuf<uint8_t> dRes;
     DevBuf<uint64_t> dOff;
     DevBuf<int16_t> dKmerThr;
@@ -319,25 +327,42 @@ int mk_queries_create(const uint8_t *residues, const uint64_t *offsets, uint32_t
     mk::SubMat kmerMat, alnMat;
     mk::build_submat(kmerMat, mk::MAT_VTML80, 8.0f, -0.2f);
     mk::build_submat(alnMat, mk::MAT_BLOSUM62, 2.0f, 0.0f);
-    {
-        HostTimer ht("host_query_derive");
-        mk::derive_queries(kmerMat, alnMat, residues, offsets, n, mk::kmer_threshold(P->sensitivity, P->kmer_score),
-                           P->comp_bias_corr != 0, P->comp_bias_scale, q->der);
-    }
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; };
-    ok(q->dRes.upload(residues, offsets[n]));
+    const uint64_t total = offsets[n];
+    ok(q->dRes.upload(residues, total));
     ok(q->dOff.upload(offsets, n + 1));
-    ok(q->dKmerThr.upload(q->der.kmerThr.data(), q->der.kmerThr.size()));
-    ok(q->dCorr.upload(q->der.diagCorr.data(), q->der.diagCorr.size()));
-    ok(q->dBias8.upload(q->der.swBias8.data(), q->der.swBias8.size()));
+    ok(q->dKmerThr.alloc(total));
+    ok(q->dCorr.alloc(total));
+    ok(q->dBias8.alloc(total));
+    if (e == hipSuccess) {
+        const int th = timed_begin("query_derive", (double) total * 9.0, 0);
+        ok(mk::launch_derive(q->dRes.p, q->dOff.p, n, total, kmerMat, alnMat, mk::kmer_threshold(P->sensitivity, P->kmer_score),
+                             P->comp_bias_corr != 0, P->comp_bias_scale, q->dKmerThr.p, q->dCorr.p, q->dBias8.p, g_stream));
+        timed_end(th);
+    }
     ok(hipStreamSynchronize(g_stream));
+    timed_flush();
     if (e != hipSuccess) { delete q; return fail(MK_ERR_DEVICE, "query upload failed: %s", hipGetErrorString(e)); }
     *out = q;
     return MK_OK;
 }
 
 void mk_queries_destroy(mk_queries *q) { delete q; }
+
+// test hook: the per-residue arrays the device derived for this batch (kmer threshold per k-mer start,
+// int8 diagonal correction, int8 SW composition bias)
+int mk_queries_derived(const mk_queries *q, int16_t *kmer_thr, int8_t *diag_corr, int8_t *sw_bias8) {
+    int rc = ensure_ready();
+    if (rc) return rc;
+    if (!q || !kmer_thr || !diag_corr || !sw_bias8) return fail(MK_ERR_ARG, "null argument");
+    const size_t total = q->off[q->n];
+    if (total == 0) return MK_OK;
+    HIPCHK(hipMemcpy(kmer_thr, q->dKmerThr.p, total * sizeof(int16_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(diag_corr, q->dCorr.p, total, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(sw_bias8, q->dBias8.p, total, hipMemcpyDeviceToHost));
+    return MK_OK;
+}
 
 // forward + (optionally) reverse pass on explicit pairs: ssw_align_private<SEQ_SEQ> (StripedSmithWaterman.cpp:309-545)
 int mk_sw_pairs(mk_targetdb *db, mk_queries *q, const mk_params *P, const uint32_t *qIdx, const uint32_t *tIdx,
@@ -424,7 +449,7 @@ int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     const int binCount = mk::bin_count_for(db->n, P->host_l2_bytes);
     {
         HostTimer ht("host_prefilter_total");
-        rc = mk::run_prefilter(V, q->off, q->res, q->der.diagCorr.data(), db->off, *P, binCount, g_stream, q->hits, q->hitOff, err,
+        rc = mk::run_prefilter(V, q->off, q->res, nullptr, db->off, *P, binCount, g_stream, q->hits, q->hitOff, err,
                                timed_begin, timed_end, timed_set);
     }
     timed_flush();

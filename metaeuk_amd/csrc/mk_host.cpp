@@ -283,59 +283,6 @@ void build_index(const SubMat &km, const uint8_t *residues, const uint64_t *seqO
         for (uint64_t v : perSeq[s]) out.entries[cursor[v >> 16]++] = static_cast<uint64_t>(s) | ((v & 0xFFFF) << 32);
 }
 
-// query-side derived arrays:
-//  * kmerThr per k-mer start   : QueryMatcher::match (QueryMatcher.cpp:225-244)
-//  * diagCorr                  : UngappedAlignment::createProfile (UngappedAlignment.cpp:391-396)
-//  * swBias8 / swBias          : SmithWaterman::ssw_init (StripedSmithWaterman.cpp:1228-1284)
-void derive_queries(const SubMat &kmerMat, const SubMat &alnMat, const uint8_t *res, const uint64_t *off, uint32_t n,
-                    int kmerThr, bool compBias, float scale, QueryDerived &out) {
-    const uint64_t total = off[n];
-    out.kmerThr.assign(total, -1);
-    out.diagCorr.assign(total, 0);
-    out.swBias8.assign(total, 0);
-    out.swBias.assign(n, 0);
-    int matMin = 0;
-    for (int i = 0; i < ALPH; i++)
-        for (int j = 0; j < ALPH; j++) matMin = std::min<int>(matMin, static_cast<int8_t>(alnMat.sub[i][j]));
-#pragma omp parallel
-    {
-        std::vector<float> b1, b2;
-#pragma omp for schedule(dynamic, 256)
-        for (uint32_t qi = 0; qi < n; qi++) {
-            const uint8_t *q = res + off[qi];
-            const int L = static_cast<int>(off[qi + 1] - off[qi]);
-            b1.assign(L, 0.0f); b2.assign(L, 0.0f);
-            if (compBias) {
-                comp_bias(kmerMat, q, L, scale, b1.data());
-                comp_bias(alnMat, q, L, scale, b2.data());
-            }
-            int8_t *corr = out.diagCorr.data() + off[qi];
-            int8_t *sw8 = out.swBias8.data() + off[qi];
-            int16_t *kt = out.kmerThr.data() + off[qi];
-            int minBias = 0;
-            for (int i = 0; i < L; i++) {
-                float c = b1[i];
-                c = (c < 0.0) ? c / 4 - 0.5 : c / 4 + 0.5;
-                corr[i] = static_cast<int8_t>(static_cast<char>(c));
-                sw8[i] = static_cast<int8_t>((b2[i] < 0.0) ? b2[i] - 0.5 : b2[i] + 0.5);
-                minBias = std::min<int>(minBias, sw8[i]);
-            }
-            out.swBias[qi] = std::abs(matMin) + std::abs(minBias);
-            for (int i = 0; i + SPAN <= L; i++) {
-                float acc = 0;
-                bool hasX = false;
-                for (int p = 0; p < KMER; p++) {
-                    acc += b1[i + SPACED6[p]];
-                    hasX |= (q[i + SPACED6[p]] == XCODE);
-                }
-                if (hasX) continue;
-                const short r = static_cast<short>((acc < 0.0) ? acc - 0.5 : acc + 0.5);
-                kt[i] = static_cast<int16_t>(std::max(kmerThr - r, 0));
-            }
-        }
-    }
-}
-
 // EvalueComputation (M/src/alignment/EvalueComputation.h:18-40,64-69) over Sls::AlignmentEvaluer
 // (M/lib/alp/sls_alignment_evaluer.cpp:657-835,989-1029; sls_pvalues.cpp:342-520; sls_basic.hpp:195-198)
 void Evaluer::init(uint64_t dbResidues) {

@@ -51,16 +51,6 @@ struct TargetIndex {
 void build_index(const SubMat &kmerMat, const uint8_t *residues, const uint64_t *seqOff, uint32_t nSeq,
                  int kmerThr, bool mask, float maskProb, int tantanLanes, TargetIndex &out);
 
-// per-residue query-side arrays consumed by the kernels
-struct QueryDerived {
-    std::vector<int16_t> kmerThr;   // per k-mer start: threshold for the generator, -1 = skip (X / too short)
-    std::vector<int8_t> diagCorr;   // UngappedAlignment aaCorrectionScore
-    std::vector<int8_t> swBias8;    // SmithWaterman composition_bias
-    std::vector<int32_t> swBias;    // per query: byte-mode bias
-};
-void derive_queries(const SubMat &kmerMat, const SubMat &alnMat, const uint8_t *res, const uint64_t *off, uint32_t n,
-                    int kmerThr, bool compBias, float scale, QueryDerived &out);
-
 struct Evaluer {
     double lambda, K, logK, a_I, b_I, a_J, b_J, alpha_I, beta_I, alpha_J, beta_J, sigma, tau, vi_y_thr, vj_y_thr, c_y_thr, dbRes;
     void init(uint64_t dbResidues);

@@ -55,6 +55,20 @@ struct UngappedLaunch {
 };
 hipError_t launch_ungapped(const UngappedLaunch &L, hipStream_t stream);
 
+// per-residue query-side inputs (k-mer thresholds, int8 diagonal correction, int8 SW composition bias), mk_derive.hip
+struct SubMat;
+hipError_t launch_derive(const uint8_t *dRes, const uint64_t *dOff, uint32_t nq, uint64_t total, const SubMat &kmerMat, const SubMat &alnMat,
+                         int kmerThr, bool compBias, float scale, int16_t *dKthr, int8_t *dCorr, int8_t *dSw8, hipStream_t stream);
+
+// wall-clock accounting of host-side phases (shows up in mk_kernel_stats with launches == 0)
+void host_stat(const char *name, double ms);
+struct ScopedHost {
+    const char *name; double t0;
+    static double now_ms();
+    explicit ScopedHost(const char *n) : name(n), t0(now_ms()) {}
+    ~ScopedHost() { host_stat(name, now_ms() - t0); }
+};
+
 // persistent, growable device / pinned-host buffers (one set per process; no hipMalloc on the hot path)
 void *dev_scratch(const char *name, size_t bytes);          // nullptr on allocation failure
 void *pinned_scratch(const char *name, size_t bytes);

@@ -412,7 +412,8 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
         }
         const uint32_t nqc = q1 - q0;
         std::vector<uint32_t> chunkCnt(nqc, 0);
-        std::vector<mk_hit> chunkHits;                 // device-final hits of the chunk (compact, query order)
+        const mk_hit *devHits = nullptr;               // device-final hits of the chunk (compact, query order; pinned staging)
+        size_t nDevHits = 0;
         std::vector<std::vector<mk_hit>> hostHits;     // per flagged query
         std::vector<uint32_t> hostQ;
         if (nPos > 0 && totalHits > 0) {
@@ -516,7 +517,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                     PCHK(hipGetLastError());
                     PCHK(hipMemcpyAsync(hHitsOut, dHitsOut, (size_t) nValid * sizeof(mk_hit), hipMemcpyDeviceToHost, stream));
                     PCHK(hipStreamSynchronize(stream));
-                    chunkHits.assign(hHitsOut, hHitsOut + nValid);
+                    devHits = hHitsOut; nDevHits = nValid;
                 }
                 for (uint32_t ql = 0; ql < nqc; ql++) chunkCnt[ql] = hPerQ[ql] >= (uint32_t) maxHits ? 0 : hPerQ[ql];
                 if (nFlagged > 0) {
@@ -538,7 +539,13 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                         int n255 = 0;
                         for (const Cand &c : perQuery) n255 += c.score >= 255;
                         int self = 0;
-                        if (n255 >= maxHits) self = self_score(ungMat, qRes.data() + qOff[q], qCorrHost + qOff[q], (int) (qOff[q + 1] - qOff[q]));
+                        if (n255 >= maxHits) {
+                            const int L = (int) (qOff[q + 1] - qOff[q]);
+                            std::vector<int8_t> corr((size_t) L);
+                            if (qCorrHost) std::memcpy(corr.data(), qCorrHost + qOff[q], (size_t) L);
+                            else PCHK(hipMemcpy(corr.data(), V.q_corr + qOff[q], (size_t) L, hipMemcpyDeviceToHost));
+                            self = self_score(ungMat, qRes.data() + qOff[q], corr.data(), L);
+                        }
                         std::vector<mk_hit> hh((size_t) maxHits);
                         const int cnt = select_hits(perQuery, binCount, maxHits, P.min_ungapped_score, self, hh.data());
                         hh.resize((size_t) cnt);
@@ -550,18 +557,30 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
         }
         // append the chunk: device-final hits are compact in query order; flagged queries come from the host lists
         {
-            size_t dev = 0, hk = 0;
-            for (uint32_t ql = 0; ql < nqc; ql++) {
-                const size_t qg = (size_t) q0 + ql;
-                if (hk < hostQ.size() && hostQ[hk] == ql) {
-                    outHits.insert(outHits.end(), hostHits[hk].begin(), hostHits[hk].end());
-                    outOff[qg + 1] = outOff[qg] + hostHits[hk].size();
-                    hk++;
-                } else {
-                    const uint32_t c = chunkCnt[ql];
-                    if (c) outHits.insert(outHits.end(), chunkHits.begin() + dev, chunkHits.begin() + dev + c);
-                    dev += c;
-                    outOff[qg + 1] = outOff[qg] + c;
+            ScopedHost sh("host_prefilter_append");
+            if (outHits.capacity() < outHits.size() + nDevHits + 4096) {
+                // grow geometrically, sized from the progress so far
+                const double frac = std::max(0.02, (double) q1 / (double) nq);
+                const size_t want = (size_t) ((double) (outHits.size() + nDevHits) / frac * 1.1) + 4096;
+                outHits.reserve(std::max(want, outHits.size() + nDevHits + 4096));
+            }
+            if (hostQ.empty()) {
+                outHits.insert(outHits.end(), devHits, devHits + nDevHits);
+                for (uint32_t ql = 0; ql < nqc; ql++) outOff[(size_t) q0 + ql + 1] = outOff[(size_t) q0 + ql] + chunkCnt[ql];
+            } else {
+                size_t dev = 0, hk = 0;
+                for (uint32_t ql = 0; ql < nqc; ql++) {
+                    const size_t qg = (size_t) q0 + ql;
+                    if (hk < hostQ.size() && hostQ[hk] == ql) {
+                        outHits.insert(outHits.end(), hostHits[hk].begin(), hostHits[hk].end());
+                        outOff[qg + 1] = outOff[qg] + hostHits[hk].size();
+                        hk++;
+                    } else {
+                        const uint32_t c = chunkCnt[ql];
+                        if (c) outHits.insert(outHits.end(), devHits + dev, devHits + dev + c);
+                        dev += c;
+                        outOff[qg + 1] = outOff[qg] + c;
+                    }
                 }
             }
         }

@@ -256,3 +256,44 @@ def test_cli_prefilter_align_db_roundtrip(gpu_api, tmp_path):
     # unknown flags are a hard error and leave no "done" marker behind
     bad = subprocess.run([build.BIN, "prefilter", str(tmp_path / "q"), str(tmp_path / "t"), str(tmp_path / "x"), "--no-such-flag", "1"], capture_output=True)
     assert bad.returncode != 0 and not (tmp_path / "x.dbtype").exists()
+
+
+def test_device_derive_matches_oracle(gpu_api, small_workload):
+    """k-mer thresholds, int8 diagonal correction and int8 SW bias derived by the device kernels (mk_derive.hip)
+    against the oracle's comp-bias functions: float/double expression types must match bit for bit."""
+    import ctypes as C
+    targets, queries = small_workload
+    rng = random.Random(5)
+    queries = list(queries[:400]) + ["A" * 60, "ACDEFGHIKLX" * 7, "WWWWWWWWWWWWKKKKKKKKKKKK", "MK", "ACDEFGHIKL",
+                                      _rand_seq(rng, 700), "X" * 30, "".join(rng.choice("DEKR") for _ in range(90))]
+    q = gpu_api.Queries(queries)
+    kt, dc, sb = q.derived()
+    L = oracle.lib()
+    kmer_mat, aln_mat = oracle.submat(1, 8.0, -0.2), oracle.submat(0, 2.0, 0.0)
+    p = gpu_api.default_params()
+    thr = int(np.float32(163.2) - np.float32(p.sensitivity) * 8.917)
+    sp = (0, 1, 3, 5, 8, 9)
+    for i, s in enumerate(queries):
+        lo, hi = int(q.off[i]), int(q.off[i + 1])
+        n = hi - lo
+        codes = oracle.encode(s)
+        b1 = np.zeros(max(1, n), dtype=np.float32)
+        L.mko_comp_bias(C.byref(kmer_mat), codes.ctypes.data_as(C.c_void_p), C.c_int(n), C.c_float(1.0), b1.ctypes.data_as(C.c_void_p))
+        cb = np.zeros(max(1, n), dtype=np.int8)
+        bias = C.c_int()
+        L.mko_sw_query_init(C.byref(aln_mat), codes.ctypes.data_as(C.c_void_p), C.c_int(n), C.c_float(1.0), cb.ctypes.data_as(C.c_void_p), C.byref(bias))
+        assert np.array_equal(sb[lo:hi], cb[:n]), "SW bias, query %d" % i
+        exp_corr = np.zeros(n, dtype=np.int8)
+        exp_kt = np.full(n, -1, dtype=np.int16)
+        for k in range(n):
+            c = b1[k]
+            c = np.float32(np.float64(c / np.float32(4)) - 0.5) if c < 0 else np.float32(np.float64(c / np.float32(4)) + 0.5)
+            exp_corr[k] = int(c)                      # C float -> char truncates toward zero
+            if k + 10 <= n and not any(codes[k + d] == 20 for d in sp):
+                acc = np.float32(0)
+                for d in sp:
+                    acc = np.float32(acc + b1[k + d])
+                r = int(np.float64(acc) - 0.5) if acc < 0 else int(np.float64(acc) + 0.5)
+                exp_kt[k] = max(thr - r, 0)
+        assert np.array_equal(dc[lo:hi], exp_corr), "diagonal correction, query %d" % i
+        assert np.array_equal(kt[lo:hi], exp_kt), "k-mer threshold, query %d" % i
