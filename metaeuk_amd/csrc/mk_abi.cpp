@@ -93,6 +93,12 @@ struct DevBuf {
 
 namespace mk {
 void host_stat(const char *name, double ms) { g_stats[name].ms += ms; }
+hipError_t sync_wait(hipStream_t stream, const char *statName) {
+    const double t0 = ScopedHost::now_ms();
+    const hipError_t e = hipStreamSynchronize(stream);
+    host_stat(statName, ScopedHost::now_ms() - t0);
+    return e;
+}
 double ScopedHost::now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }  // namespace mk
 
@@ -145,8 +151,8 @@ struct mk_queries {
     DevBuf<int16_t> dKmerThr;
     DevBuf<int8_t> dCorr, dBias8;
     // stage results (the reference hands these over through the pref_0 / search_res DBs)
-    std::vector<mk_hit> hits; std::vector<uint64_t> hitOff; bool havePref = false;
-    std::vector<mk_alignment> alns; std::vector<uint64_t> alnOff; bool haveAln = false;
+    mk::HostBlock hits; size_t nHits = 0; std::vector<uint64_t> hitOff; bool havePref = false;
+    mk::HostBlock alns; std::vector<uint64_t> alnOff; bool haveAln = false;
 };
 
 namespace {
@@ -449,7 +455,7 @@ int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     const int binCount = mk::bin_count_for(db->n, P->host_l2_bytes);
     {
         HostTimer ht("host_prefilter_total");
-        rc = mk::run_prefilter(V, q->off, q->res, nullptr, db->off, *P, binCount, g_stream, q->hits, q->hitOff, err,
+        rc = mk::run_prefilter(V, q->off, q->res, nullptr, db->off, *P, binCount, g_stream, q->hits, q->nHits, q->hitOff, err,
                                timed_begin, timed_end, timed_set);
     }
     timed_flush();
@@ -461,14 +467,18 @@ int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *P) {
 int mk_prefilter_result(const mk_queries *q, const mk_hit **hits, const uint64_t **offsets) {
     if (!q || !hits || !offsets) return fail(MK_ERR_ARG, "null argument");
     if (!q->havePref) return fail(MK_ERR_ARG, "no prefilter result in this batch");
-    *hits = q->hits.data(); *offsets = q->hitOff.data();
+    *hits = (const mk_hit *) q->hits.p; *offsets = q->hitOff.data();
     return MK_OK;
 }
 
 int mk_prefilter_result_set(mk_queries *q, const mk_hit *hits, const uint64_t *offsets) {
     if (!q || !offsets || (!hits && offsets[q->n] > 0)) return fail(MK_ERR_ARG, "null argument");
+    for (uint32_t i = 0; i < q->n; i++) if (offsets[i + 1] < offsets[i]) return fail(MK_ERR_ARG, "offsets are not ascending at query %u", i);
+    if (offsets[0] != 0) return fail(MK_ERR_ARG, "offsets[0] must be 0");
     q->hitOff.assign(offsets, offsets + q->n + 1);
-    q->hits.assign(hits, hits + offsets[q->n]);
+    q->nHits = offsets[q->n];
+    if (!q->hits.reserve(std::max<size_t>(q->nHits, 1) * sizeof(mk_hit), 0)) return fail(MK_ERR_DEVICE, "pinned host allocation failed");
+    if (q->nHits) std::memcpy(q->hits.p, hits, q->nHits * sizeof(mk_hit));
     q->havePref = true;
     return MK_OK;
 }
@@ -481,60 +491,60 @@ int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     if (!db || !q || !P) return fail(MK_ERR_ARG, "null argument");
     if (!q->havePref) return fail(MK_ERR_ARG, "mk_align: the batch has no prefilter result");
     HostTimer htAll("host_align_total");
-    const size_t n = q->hits.size();
-    std::vector<uint32_t> tIdx(n);
+    const size_t n = q->nHits;
+    const mk_hit *hits = (const mk_hit *) q->hits.p;
     double work[2 * mk::SW_NCFG];
     for (int c = 0; c < 2 * mk::SW_NCFG; c++) work[c] = 0;
     {
-        HostTimer ht("host_align_prepare");
+        HostTimer ht("host_align_prepare");           // forward-pass work per tile configuration (statistics only)
 #pragma omp parallel
         {
             double w[2 * mk::SW_NCFG];
             for (int c = 0; c < 2 * mk::SW_NCFG; c++) w[c] = 0;
-#pragma omp for schedule(static)
+#pragma omp for schedule(static) nowait
             for (uint32_t i = 0; i < q->n; i++) {
                 const uint32_t qLen = (uint32_t) (q->off[i + 1] - q->off[i]);
                 const int c = mk::sw_cfg_of(qLen);
                 for (uint64_t h = q->hitOff[i]; h < q->hitOff[i + 1]; h++) {
-                    const uint32_t t = q->hits[h].seq_id;
-                    tIdx[h] = t;
+                    const uint32_t t = hits[h].seq_id;
                     const uint32_t tLen = t < db->n ? (uint32_t) (db->off[t + 1] - db->off[t]) : 0;
                     w[2 * c] += (double) tLen + 2.0 * qLen + sizeof(mk::SwJob) + sizeof(mk::SwOut);
                     w[2 * c + 1] += (double) qLen * (double) tLen;
                 }
             }
-#pragma omp critical
+#pragma omp critical(mk_align_fwdwork)
             for (int c = 0; c < 2 * mk::SW_NCFG; c++) work[c] += w[c];
         }
     }
-    for (size_t h = 0; h < n; h++) if (tIdx[h] >= db->n) return fail(MK_ERR_ARG, "prefilter hit %zu names target %u (DB has %u)", h, tIdx[h], db->n);
     std::vector<mk::GateEntry> gate;
     {
         HostTimer ht("host_gate_table");
         mk::build_gate_table(db->evaluer, P->evalue_thr, q->off, gate);
     }
-    std::vector<mk::AlnRaw> raw;
+    const mk::AlnRaw *raw = nullptr;
+    size_t m = 0;
     std::string err;
-    rc = mk::run_align_device(align_view(db, q), q->hitOff.data(), tIdx.data(), n, gate, *P, g_stream, work, raw, err,
+    rc = mk::run_align_device(align_view(db, q), q->hitOff.data(), hits, n, gate, *P, g_stream, work, &raw, &m, err,
                               timed_begin, timed_end, timed_set);
     timed_flush();
     if (rc != MK_OK) return fail(rc, "%s", err.c_str());
     HostTimer ht("host_align_assemble");
-    // raw is ordered by pair index == by query; slice it per query
-    const size_t m = raw.size();
-    std::vector<uint64_t> first(q->n + 1, 0);
-    {
-        size_t k = 0;
-        for (uint32_t i = 0; i < q->n; i++) {
-            while (k < m && raw[k].pair < q->hitOff[i]) k++;
-            first[i] = k;
-        }
-        first[q->n] = m;
+    // raw is ordered by pair index == by query: query i owns raw[first[i] .. first[i+1])
+    std::vector<uint64_t> first((size_t) q->n + 1);
+#pragma omp parallel for schedule(static)
+    for (uint32_t i = 0; i <= q->n; i++) {
+        const uint64_t want = i < q->n ? q->hitOff[i] : (uint64_t) n;
+        size_t lo = 0, hi = m;                         // first record with pair >= want
+        while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (raw[mid].pair < want) lo = mid + 1; else hi = mid; }
+        first[i] = lo;
     }
-    std::vector<mk_alignment> tmp(m);
-    std::vector<uint32_t> cnt(q->n, 0);
+    // records are written at their upper-bound position; rejected ones (rare) leave holes that are closed afterwards
+    if (!q->alns.reserve(std::max<size_t>(m, 1) * sizeof(mk_alignment), 0)) return fail(MK_ERR_DEVICE, "pinned host allocation failed");
+    mk_alignment *alns = (mk_alignment *) q->alns.p;
+    std::vector<uint32_t> cnt(q->n);
     int mismatch = 0;
-#pragma omp parallel for schedule(dynamic, 512) reduction(+ : mismatch)
+    uint64_t holes = 0;
+#pragma omp parallel for schedule(dynamic, 512) reduction(+ : mismatch, holes)
     for (uint32_t i = 0; i < q->n; i++) {
         const int qLen = (int) (q->off[i + 1] - q->off[i]);
         const uint64_t begin = first[i];
@@ -542,7 +552,7 @@ int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *P) {
         for (uint64_t k = first[i]; k < first[i + 1]; k++) {
             const mk::AlnRaw &r = raw[k];
             if (r.q_start == -2) { mismatch++; continue; }
-            const uint32_t t = tIdx[r.pair];
+            const uint32_t t = hits[r.pair].seq_id;
             const int tLen = (int) (db->off[t + 1] - db->off[t]);
             mk_alignment a;
             a.db_key = t; a.q_len = qLen; a.db_len = tLen; a.raw_score = r.score;
@@ -558,18 +568,19 @@ int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *P) {
             sid = std::min(sid, 1.0f);
             a.seq_id = std::max(0.0f, sid);
             a.bit_score = static_cast<int>(db->evaluer.bitScore((double) r.score) + 0.5);
-            if (a.evalue <= P->evalue_thr && a.aln_len >= P->min_aln_len) tmp[w++] = a;
+            if (a.evalue <= P->evalue_thr && a.aln_len >= P->min_aln_len) alns[w++] = a;
         }
-        if (w - begin > 1) std::sort(tmp.begin() + begin, tmp.begin() + w, mk::alignment_less);
+        if (w - begin > 1) std::sort(alns + begin, alns + w, mk::alignment_less);
         cnt[i] = (uint32_t) (w - begin);
+        holes += first[i + 1] - w;
     }
     if (mismatch) return fail(MK_ERR_SW_MISMATCH, "Score of forward/backward SW differ for %d pairs", mismatch);
-    q->alnOff.assign((size_t) q->n + 1, 0);
+    q->alnOff.resize((size_t) q->n + 1);
+    q->alnOff[0] = 0;
     for (uint32_t i = 0; i < q->n; i++) q->alnOff[i + 1] = q->alnOff[i] + cnt[i];
-    q->alns.resize(q->alnOff[q->n]);
-#pragma omp parallel for schedule(static)
-    for (uint32_t i = 0; i < q->n; i++)
-        std::copy(tmp.begin() + first[i], tmp.begin() + first[i] + cnt[i], q->alns.begin() + q->alnOff[i]);
+    if (holes)
+        for (uint32_t i = 0; i < q->n; i++)            // blocks only move towards the front: in-order memmove is safe
+            if (cnt[i] && q->alnOff[i] != first[i]) std::memmove(alns + q->alnOff[i], alns + first[i], (size_t) cnt[i] * sizeof(mk_alignment));
     q->haveAln = true;
     return MK_OK;
 }
@@ -577,7 +588,7 @@ int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *P) {
 int mk_align_result(const mk_queries *q, const mk_alignment **alns, const uint64_t **offsets) {
     if (!q || !alns || !offsets) return fail(MK_ERR_ARG, "null argument");
     if (!q->haveAln) return fail(MK_ERR_ARG, "no alignment result in this batch");
-    *alns = q->alns.data(); *offsets = q->alnOff.data();
+    *alns = (const mk_alignment *) q->alns.p; *offsets = q->alnOff.data();
     return MK_OK;
 }
 

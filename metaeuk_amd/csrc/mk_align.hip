@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <omp.h>
 
 namespace mk {
@@ -27,21 +28,21 @@ __device__ __forceinline__ uint32_t sort_key(uint32_t qLen, uint32_t tLen) {
     return (uint32_t) sw_cfg_of(qLen) * KEY_CLS + (KEY_CLS - 1 - min(tLen >> 4, KEY_CLS - 1));
 }
 
-__global__ __launch_bounds__(256) void expand_pairs_kernel(AlignView V, const uint64_t *hitOff, const uint32_t *tIdx, uint64_t n,
-                                                           SwJob *jobs, uint32_t *keys, uint32_t *idx, uint32_t *qOfPair) {
+__global__ __launch_bounds__(256) void expand_pairs_kernel(AlignView V, const uint64_t *hitOff, const mk_hit *hits, uint64_t n,
+                                                           SwJob *jobs, uint32_t *keys, uint32_t *idx, uint32_t *badTarget) {
     const uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     uint32_t lo = 0, hi = V.n_queries;              // largest q with hitOff[q] <= p
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (hitOff[mid] <= p) lo = mid; else hi = mid; }
-    const uint32_t q = lo, t = tIdx[p];
+    const uint32_t q = lo, t = hits[p].seq_id;
     SwJob j;
     j.q_start = (uint32_t) V.q_off[q]; j.q_len = (uint32_t) (V.q_off[q + 1] - V.q_off[q]);
-    j.t_start = V.t_off[t]; j.t_len = (uint32_t) (V.t_off[t + 1] - V.t_off[t]);
+    if (t < V.n_targets) { j.t_start = V.t_off[t]; j.t_len = (uint32_t) (V.t_off[t + 1] - V.t_off[t]); }
+    else { j.t_start = 0; j.t_len = 0; atomicMax(badTarget, (uint32_t) p + 1u); }     // reported to the caller, nothing is aligned
     j.q_step = 1; j.t_step = 1; j.slot = (uint32_t) p;
     jobs[p] = j;
     keys[p] = sort_key(j.q_len, j.t_len);
     idx[p] = (uint32_t) p;
-    qOfPair[p] = q;
 }
 
 // first index whose key >= c*KEY_CLS, for c = 0..SW_NCFG; plus the key at that index
@@ -146,9 +147,10 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
     ANULL(dBounds);
     hipLaunchKernelGGL(bounds_kernel, dim3(1), dim3(64), 0, stream, kb.Current(), n, dBounds, dBounds + 32);
     ACHK(hipGetLastError());
-    uint32_t hb[64];
-    ACHK(hipMemcpyAsync(hb, dBounds, sizeof(hb), hipMemcpyDeviceToHost, stream));
-    ACHK(hipStreamSynchronize(stream));
+    uint32_t *hb = (uint32_t *) pinned_scratch("align_bounds_h", 64 * sizeof(uint32_t));
+    ANULL(hb);
+    ACHK(hipMemcpyAsync(hb, dBounds, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    ACHK(sync_wait(stream, "wait_align"));
     for (int c = 0; c < SW_NCFG; c++) {
         const uint32_t lo = hb[c], hi = hb[c + 1];
         if (hi <= lo) continue;
@@ -174,31 +176,30 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
     return MK_OK;
 }
 
-int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const uint32_t *tIdxHost, uint64_t nPairs,
+int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hit *hitsHost, uint64_t nPairs,
                      const std::vector<GateEntry> &gate, const mk_params &P, hipStream_t stream,
                      const double *fwdWork /* per cfg: bytes, cells; may be null */,
-                     std::vector<AlnRaw> &out, std::string &err, timed_begin_fn tb, timed_end_fn te, timed_set_fn ts) {
-    out.clear();
+                     const AlnRaw **out, size_t *nOut, std::string &err, timed_begin_fn tb, timed_end_fn te, timed_set_fn ts) {
+    *out = nullptr; *nOut = 0;
     if (nPairs == 0) return MK_OK;
     if (nPairs >= 0x7FFFFFFFull) { err = "more than 2^31 pairs in one batch: split the batch"; return MK_ERR_UNSUPPORTED; }
     const uint32_t n = (uint32_t) nPairs;
     uint64_t *dHitOff = (uint64_t *) dev_scratch("align_hitoff", ((size_t) V.n_queries + 1) * sizeof(uint64_t));
-    uint32_t *dT = (uint32_t *) dev_scratch("align_tidx", (size_t) n * 4);
-    uint32_t *dQ = (uint32_t *) dev_scratch("align_qidx", (size_t) n * 4);
+    mk_hit *dHits = (mk_hit *) dev_scratch("align_hits", (size_t) n * sizeof(mk_hit));
     SwJob *dJobs = (SwJob *) dev_scratch("align_jobs", (size_t) n * sizeof(SwJob));
     SwOut *dOut = (SwOut *) dev_scratch("align_out", (size_t) n * sizeof(SwOut));
     uint32_t *dKeys = (uint32_t *) dev_scratch("align_keys", (size_t) n * 4), *dKeys2 = (uint32_t *) dev_scratch("align_keys2", (size_t) n * 4);
     uint32_t *dIdx = (uint32_t *) dev_scratch("align_idx", (size_t) n * 4), *dIdx2 = (uint32_t *) dev_scratch("align_idx2", (size_t) n * 4);
     GateEntry *dGate = (GateEntry *) dev_scratch("align_gate", gate.size() * sizeof(GateEntry));
     uint32_t *dCount = (uint32_t *) dev_scratch("align_count", 16);
-    ANULL(dHitOff); ANULL(dT); ANULL(dQ); ANULL(dJobs); ANULL(dOut); ANULL(dKeys); ANULL(dKeys2); ANULL(dIdx); ANULL(dIdx2); ANULL(dGate); ANULL(dCount);
+    ANULL(dHitOff); ANULL(dHits); ANULL(dJobs); ANULL(dOut); ANULL(dKeys); ANULL(dKeys2); ANULL(dIdx); ANULL(dIdx2); ANULL(dGate); ANULL(dCount);
     ACHK(hipMemcpyAsync(dHitOff, hitOffHost, ((size_t) V.n_queries + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
-    ACHK(hipMemcpyAsync(dT, tIdxHost, (size_t) n * 4, hipMemcpyHostToDevice, stream));
+    ACHK(hipMemcpyAsync(dHits, hitsHost, (size_t) n * sizeof(mk_hit), hipMemcpyHostToDevice, stream));
     ACHK(hipMemcpyAsync(dGate, gate.data(), gate.size() * sizeof(GateEntry), hipMemcpyHostToDevice, stream));
     ACHK(hipMemsetAsync(dOut, 0, (size_t) n * sizeof(SwOut), stream));
     ACHK(hipMemsetAsync(dCount, 0, 16, stream));
     int th = tb("align_expand", 48.0 * n, 0);
-    hipLaunchKernelGGL(expand_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, V, dHitOff, dT, (uint64_t) n, dJobs, dKeys, dIdx, dQ);
+    hipLaunchKernelGGL(expand_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, V, dHitOff, dHits, (uint64_t) n, dJobs, dKeys, dIdx, dCount + 1);
     te(th);
     ACHK(hipGetLastError());
     int hFwd[SW_NCFG], hRev[SW_NCFG];
@@ -213,9 +214,12 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const uint3
     hipLaunchKernelGGL(gate_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, V, dJobs, dOut, (uint64_t) n, dGate, dCount, dRevPair, dRevJobs, dKeys, dIdx);
     te(th);
     ACHK(hipGetLastError());
-    uint32_t nRev = 0;
-    ACHK(hipMemcpyAsync(&nRev, dCount, 4, hipMemcpyDeviceToHost, stream));
-    ACHK(hipStreamSynchronize(stream));
+    uint32_t *hCount = (uint32_t *) pinned_scratch("align_count_h", 16);
+    ANULL(hCount);
+    ACHK(hipMemcpyAsync(hCount, dCount, 8, hipMemcpyDeviceToHost, stream));
+    ACHK(sync_wait(stream, "wait_align"));
+    if (hCount[1] != 0) { err = "prefilter hit " + std::to_string(hCount[1] - 1) + " names a target outside the DB"; return MK_ERR_ARG; }
+    const uint32_t nRev = hCount[0];
     if (nRev == 0) return MK_OK;
     SwOut *dRevOut = (SwOut *) dev_scratch("align_revout", (size_t) nRev * sizeof(SwOut));
     ANULL(dRevOut);
@@ -245,21 +249,28 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const uint3
     AlnRaw *hRaw = (AlnRaw *) pinned_scratch("align_raw_host", (size_t) nRev * sizeof(AlnRaw));
     ANULL(hRaw);
     ACHK(hipMemcpyAsync(hRaw, dRaw, (size_t) nRev * sizeof(AlnRaw), hipMemcpyDeviceToHost, stream));
-    ACHK(hipStreamSynchronize(stream));
-    out.assign(hRaw, hRaw + nRev);
+    ACHK(sync_wait(stream, "wait_align"));
+    *out = hRaw; *nOut = nRev;
     // reverse-pass work per tile configuration, from the results
     {
         double w[2 * SW_NCFG];
         for (int c = 0; c < 2 * SW_NCFG; c++) w[c] = 0;
-        for (uint32_t i = 0; i < nRev; i++) {
-            const uint32_t ql = (uint32_t) out[i].q_end + 1, tl = (uint32_t) out[i].t_end + 1;
-            const int c = sw_cfg_of(ql);
-            w[2 * c] += (double) tl + 2.0 * ql + sizeof(SwJob) + sizeof(SwOut);
-            w[2 * c + 1] += (double) ql * (double) tl;
+#pragma omp parallel
+        {
+            double wl[2 * SW_NCFG];
+            for (int c = 0; c < 2 * SW_NCFG; c++) wl[c] = 0;
+#pragma omp for schedule(static) nowait
+            for (uint32_t i = 0; i < nRev; i++) {
+                const uint32_t ql = (uint32_t) hRaw[i].q_end + 1, tl = (uint32_t) hRaw[i].t_end + 1;
+                const int c = sw_cfg_of(ql);
+                wl[2 * c] += (double) tl + 2.0 * ql + sizeof(SwJob) + sizeof(SwOut);
+                wl[2 * c + 1] += (double) ql * (double) tl;
+            }
+#pragma omp critical(mk_align_revwork)
+            for (int c = 0; c < 2 * SW_NCFG; c++) w[c] += wl[c];
         }
         for (int c = 0; c < SW_NCFG; c++) if (hRev[c] >= 0) ts(hRev[c], w[2 * c], w[2 * c + 1]);
     }
-    (void) dQ;
     return MK_OK;
 }
 
@@ -291,12 +302,61 @@ void *pinned_scratch(const char *name, size_t bytes) {
     return s.p;
 }
 
+namespace {
+struct FreeBlock { void *p; size_t cap; };
+std::vector<FreeBlock> &block_pool() { static std::vector<FreeBlock> v; return v; }
+std::mutex &block_mutex() { static std::mutex m; return m; }
+constexpr size_t BLOCK_POOL_MAX = 6;
+}
+
+bool HostBlock::reserve(size_t bytes, size_t keepBytes) {
+    if (bytes <= cap && p) return true;
+    void *np = nullptr; size_t ncap = 0;
+    {
+        std::lock_guard<std::mutex> g(block_mutex());
+        auto &pool = block_pool();
+        int best = -1;                               // smallest pooled block that is large enough
+        for (int i = 0; i < (int) pool.size(); i++)
+            if (pool[i].cap >= bytes && (best < 0 || pool[i].cap < pool[best].cap)) best = i;
+        if (best >= 0) { np = pool[best].p; ncap = pool[best].cap; pool.erase(pool.begin() + best); }
+    }
+    if (!np) {
+        ncap = std::max<size_t>(bytes + bytes / 8, 4096);
+        if (hipHostMalloc(&np, ncap, hipHostMallocDefault) != hipSuccess) return false;
+    }
+    if (p && keepBytes) std::memcpy(np, p, std::min(keepBytes, cap));
+    release();
+    p = np; cap = ncap;
+    return true;
+}
+
+void HostBlock::release() {
+    if (!p) return;
+    void *drop = nullptr;
+    {
+        std::lock_guard<std::mutex> g(block_mutex());
+        auto &pool = block_pool();
+        pool.push_back(FreeBlock{p, cap});
+        if (pool.size() > BLOCK_POOL_MAX) {          // keep the largest blocks
+            int small = 0;
+            for (int i = 1; i < (int) pool.size(); i++) if (pool[i].cap < pool[small].cap) small = i;
+            drop = pool[small].p;
+            pool.erase(pool.begin() + small);
+        }
+    }
+    if (drop) (void) hipHostFree(drop);
+    p = nullptr; cap = 0;
+}
+
 void scratch_release_all() {
     for (auto &kv : scratch_map()) {
         if (!kv.second.p) continue;
         if (kv.first[0] == 'h') (void) hipHostFree(kv.second.p); else (void) hipFree(kv.second.p);
         kv.second = Scratch();
     }
+    std::lock_guard<std::mutex> g(block_mutex());
+    for (FreeBlock &b : block_pool()) (void) hipHostFree(b.p);
+    block_pool().clear();
 }
 
 }  // namespace mk

@@ -26,11 +26,12 @@ struct AlnRaw { uint32_t pair; int32_t score, q_end, t_end, q_start, t_start; };
 struct GateEntry { int32_t s0; uint32_t mask[8]; };
 void build_gate_table(const Evaluer &ev, double evalThr, const std::vector<uint64_t> &qOff, std::vector<GateEntry> &table);
 
-// pairs = (query of pair p is the one whose hitOff range contains p, target tIdx[p]); tIdx on the host.
-// out: accepted pairs (those passing the e-value gate) with start positions, ordered by pair index.
-int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const uint32_t *tIdxHost, uint64_t nPairs,
+// pairs = (query of pair p is the one whose hitOff range contains p, target hits[p].seq_id); hits on the host.
+// out: accepted pairs (those passing the e-value gate) with start positions, ordered by pair index; the array is
+// pinned scratch owned by the library and valid until the next call.
+int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hit *hitsHost, uint64_t nPairs,
                      const std::vector<GateEntry> &gate, const mk_params &P, hipStream_t stream,
                      const double *fwdWork /* per tile configuration: algorithmic bytes, cells (2*SW_NCFG) or null */,
-                     std::vector<AlnRaw> &out, std::string &err, timed_begin_fn tb, timed_end_fn te, timed_set_fn ts);
+                     const AlnRaw **out, size_t *nOut, std::string &err, timed_begin_fn tb, timed_end_fn te, timed_set_fn ts);
 
 }  // namespace mk

@@ -62,6 +62,7 @@ hipError_t launch_derive(const uint8_t *dRes, const uint64_t *dOff, uint32_t nq,
 
 // wall-clock accounting of host-side phases (shows up in mk_kernel_stats with launches == 0)
 void host_stat(const char *name, double ms);
+hipError_t sync_wait(hipStream_t stream, const char *statName);   // hipStreamSynchronize, blocked time booked under statName
 struct ScopedHost {
     const char *name; double t0;
     static double now_ms();
@@ -73,5 +74,18 @@ struct ScopedHost {
 void *dev_scratch(const char *name, size_t bytes);          // nullptr on allocation failure
 void *pinned_scratch(const char *name, size_t bytes);
 void scratch_release_all();
+
+// Pinned host block holding a batch's results (prefilter hits / alignments).  Blocks come from a small pool and
+// go back to it when the batch handle dies: the next batch writes into already-mapped, already-pinned pages
+// (device DMA lands the results at their final place, no first-touch faults, no host-side append copy).
+struct HostBlock {
+    void *p = nullptr; size_t cap = 0;
+    HostBlock() = default;
+    HostBlock(const HostBlock &) = delete;
+    HostBlock &operator=(const HostBlock &) = delete;
+    ~HostBlock() { release(); }
+    bool reserve(size_t bytes, size_t keepBytes);   // grow to >= bytes keeping [0, keepBytes); false when the allocation fails
+    void release();
+};
 
 }  // namespace mk

@@ -333,10 +333,18 @@ int self_score(const SubMat &ung, const uint8_t *q, const int8_t *corr, int L) {
 int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOff, const std::vector<uint8_t> &qRes,
                   const int8_t *qCorrHost,
                   const std::vector<uint64_t> &tOff, const mk_params &P, int binCount, hipStream_t stream,
-                  std::vector<mk_hit> &outHits, std::vector<uint64_t> &outOff, std::string &err, timed_begin_fn tb, timed_end_fn te, timed_set_fn ts) {
+                  HostBlock &outBlk, size_t &nOut, std::vector<uint64_t> &outOff, std::string &err, timed_begin_fn tb, timed_end_fn te, timed_set_fn ts) {
     const uint32_t nq = V.n_queries;
-    outHits.clear();
+    nOut = 0;
     outOff.assign((size_t) nq + 1, 0);
+    // room for n more hits in the result block; the estimate of the final size follows the progress through the batch
+    auto reserve_out = [&](size_t n, uint32_t qDone) -> bool {
+        if ((nOut + n) * sizeof(mk_hit) <= outBlk.cap && outBlk.p) return true;
+        if (hipStreamSynchronize(stream) != hipSuccess) return false;      // DMA into the old block must have landed
+        const double frac = std::max(0.02, (double) qDone / (double) nq);
+        const size_t want = (size_t) ((double) (nOut + n) / frac * 1.1) + 4096;
+        return outBlk.reserve(std::max(want, nOut + n + 4096) * sizeof(mk_hit), nOut * sizeof(mk_hit));
+    };
     const int maxHits = std::min<int>(P.max_seqs, (int) V.n_targets);
     const uint64_t dbSize = V.n_targets;
     const uint64_t maxDbMatches = std::max<uint64_t>(1000000, dbSize) * 2;   // QueryMatcher.cpp:43
@@ -351,7 +359,6 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     unsigned long long *dTotals = (unsigned long long *) dev_scratch("pf_totals", 64);
     unsigned long long *hTotals = (unsigned long long *) pinned_scratch("pf_totals_h", 64);
     PNULL(dTotals); PNULL(hTotals);
-    std::vector<Cand> perQuery;
     uint32_t q0 = 0;
     while (q0 < nq) {
         uint32_t q1 = q0;
@@ -402,7 +409,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                                dHit, dLast, maxDbMatches, dTotals);
             PCHK(hipGetLastError());
             PCHK(hipMemcpyAsync(hTotals, dTotals, 24, hipMemcpyDeviceToHost, stream));
-            PCHK(hipStreamSynchronize(stream));
+            PCHK(sync_wait(stream, "wait_prefilter"));
             totalHits = hTotals[0];
             if (hTotals[1] != 0) { err = "query " + std::to_string(hTotals[1] - 1) + " overflows the reference's databaseHits buffer (QueryMatcher.cpp:281-316 is not restated)"; return MK_ERR_UNSUPPORTED; }
             ts(thCount, 8.0 * (double) hTotals[2] + 2.0 * 2.0 * ROWCACHE * (double) nPos, (double) hTotals[2]);
@@ -412,8 +419,9 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
         }
         const uint32_t nqc = q1 - q0;
         std::vector<uint32_t> chunkCnt(nqc, 0);
-        const mk_hit *devHits = nullptr;               // device-final hits of the chunk (compact, query order; pinned staging)
+        const mk_hit *devHits = nullptr;               // device-final hits of the chunk, staged (chunks with --max-seqs queries)
         size_t nDevHits = 0;
+        bool devDirect = false;                        // ... or already on their way to the result block
         std::vector<std::vector<mk_hit>> hostHits;     // per flagged query
         std::vector<uint32_t> hostQ;
         if (nPos > 0 && totalHits > 0) {
@@ -464,7 +472,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             uint32_t *hNum = (uint32_t *) pinned_scratch("pf_num_h", 64);
             PNULL(hNum);
             PCHK(hipMemcpyAsync(hNum, dNum, 4, hipMemcpyDeviceToHost, stream));
-            PCHK(hipStreamSynchronize(stream));
+            PCHK(sync_wait(stream, "wait_prefilter"));
             const uint32_t nCand = hNum[0];
             if (nCand > 0) {
                 CandArrays C;
@@ -507,20 +515,32 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                 uint32_t *hPerQ = (uint32_t *) pinned_scratch("pf_perq_h", (size_t) nqc * 4);
                 PNULL(hPerQ);
                 PCHK(hipMemcpyAsync(hPerQ, dPerQ, (size_t) nqc * 4, hipMemcpyDeviceToHost, stream));
-                PCHK(hipStreamSynchronize(stream));
+                PCHK(sync_wait(stream, "wait_prefilter"));
                 const uint32_t nValid = hNum[1], nFlagged = hNum[2];
+                mk_hit *dHitsOut = nullptr;
                 if (nValid > 0) {
-                    mk_hit *dHitsOut = (mk_hit *) dev_scratch("pf_hits_out", (size_t) nValid * sizeof(mk_hit));
-                    mk_hit *hHitsOut = (mk_hit *) pinned_scratch("pf_hits_out_h", (size_t) nValid * sizeof(mk_hit));
-                    PNULL(dHitsOut); PNULL(hHitsOut);
+                    dHitsOut = (mk_hit *) dev_scratch("pf_hits_out", (size_t) nValid * sizeof(mk_hit));
+                    PNULL(dHitsOut);
                     hipLaunchKernelGGL(emit_kernel, dim3((nValid + 255) / 256), dim3(256), 0, stream, C, ib.Current(), nValid, dHitsOut);
                     PCHK(hipGetLastError());
-                    PCHK(hipMemcpyAsync(hHitsOut, dHitsOut, (size_t) nValid * sizeof(mk_hit), hipMemcpyDeviceToHost, stream));
-                    PCHK(hipStreamSynchronize(stream));
-                    devHits = hHitsOut; nDevHits = nValid;
                 }
-                for (uint32_t ql = 0; ql < nqc; ql++) chunkCnt[ql] = hPerQ[ql] >= (uint32_t) maxHits ? 0 : hPerQ[ql];
-                if (nFlagged > 0) {
+                if (nFlagged == 0) {
+                    // every query of the chunk is final on the device: DMA the compact hit array to its final place
+                    if (nValid > 0) {
+                        if (!reserve_out(nValid, q1)) { err = "pinned host allocation for the prefilter result failed"; return MK_ERR_DEVICE; }
+                        PCHK(hipMemcpyAsync((mk_hit *) outBlk.p + nOut, dHitsOut, (size_t) nValid * sizeof(mk_hit), hipMemcpyDeviceToHost, stream));
+                    }
+                    for (uint32_t ql = 0; ql < nqc; ql++) chunkCnt[ql] = hPerQ[ql];
+                    devDirect = true;
+                    nDevHits = nValid;
+                } else {
+                    if (nValid > 0) {
+                        mk_hit *hHitsOut = (mk_hit *) pinned_scratch("pf_hits_out_h", (size_t) nValid * sizeof(mk_hit));
+                        PNULL(hHitsOut);
+                        PCHK(hipMemcpyAsync(hHitsOut, dHitsOut, (size_t) nValid * sizeof(mk_hit), hipMemcpyDeviceToHost, stream));
+                        devHits = hHitsOut; nDevHits = nValid;
+                    }
+                    for (uint32_t ql = 0; ql < nqc; ql++) chunkCnt[ql] = hPerQ[ql] >= (uint32_t) maxHits ? 0 : hPerQ[ql];
                     // exact reference logic for the queries that reached --max-seqs (tie order depends on BINSIZE)
                     HostCand *dHC = (HostCand *) dev_scratch("pf_hostcand", (size_t) nFlagged * sizeof(HostCand));
                     HostCand *hHC = (HostCand *) pinned_scratch("pf_hostcand_h", (size_t) nFlagged * sizeof(HostCand));
@@ -528,65 +548,84 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                     hipLaunchKernelGGL(export_flagged_kernel, dim3((nFlagged + 255) / 256), dim3(256), 0, stream, C, dFlagSel, nFlagged, dHC);
                     PCHK(hipGetLastError());
                     PCHK(hipMemcpyAsync(hHC, dHC, (size_t) nFlagged * sizeof(HostCand), hipMemcpyDeviceToHost, stream));
-                    PCHK(hipStreamSynchronize(stream));
-                    uint32_t k = 0;
-                    while (k < nFlagged) {
-                        const uint32_t ql = hHC[k].q;
-                        perQuery.clear();
-                        while (k < nFlagged && hHC[k].q == ql) { perQuery.push_back(Cand{hHC[k].id, hHC[k].diag, hHC[k].score, hHC[k].ordinal}); k++; }
-                        std::sort(perQuery.begin(), perQuery.end(), [](const Cand &a, const Cand &b) { return a.ordinal < b.ordinal; });
-                        const uint32_t q = q0 + ql;
-                        int n255 = 0;
-                        for (const Cand &c : perQuery) n255 += c.score >= 255;
-                        int self = 0;
-                        if (n255 >= maxHits) {
-                            const int L = (int) (qOff[q + 1] - qOff[q]);
-                            std::vector<int8_t> corr((size_t) L);
-                            if (qCorrHost) std::memcpy(corr.data(), qCorrHost + qOff[q], (size_t) L);
-                            else PCHK(hipMemcpy(corr.data(), V.q_corr + qOff[q], (size_t) L, hipMemcpyDeviceToHost));
-                            self = self_score(ungMat, qRes.data() + qOff[q], corr.data(), L);
+                    PCHK(sync_wait(stream, "wait_prefilter"));
+                    ScopedHost sh("host_prefilter_maxseqs");
+                    std::vector<uint32_t> runStart;                    // candidate runs, one per flagged query (ascending query)
+                    for (uint32_t k = 0; k < nFlagged; k++) if (k == 0 || hHC[k].q != hHC[k - 1].q) runStart.push_back(k);
+                    runStart.push_back(nFlagged);
+                    const size_t nRuns = runStart.size() - 1;
+                    hostQ.resize(nRuns);
+                    hostHits.resize(nRuns);
+                    int failed = 0;
+#pragma omp parallel
+                    {
+                        std::vector<Cand> perQuery;
+#pragma omp for schedule(dynamic, 4)
+                        for (size_t r = 0; r < nRuns; r++) {
+                            const uint32_t k0 = runStart[r], k1 = runStart[r + 1];
+                            const uint32_t ql = hHC[k0].q;
+                            perQuery.clear();
+                            for (uint32_t k = k0; k < k1; k++) perQuery.push_back(Cand{hHC[k].id, hHC[k].diag, hHC[k].score, hHC[k].ordinal});
+                            std::sort(perQuery.begin(), perQuery.end(), [](const Cand &a, const Cand &b) { return a.ordinal < b.ordinal; });
+                            const uint32_t q = q0 + ql;
+                            int n255 = 0;
+                            for (const Cand &c : perQuery) n255 += c.score >= 255;
+                            int self = 0;
+                            if (n255 >= maxHits) {                     // threshold saturates: QueryMatcher.cpp:525-531 needs the exact self score
+                                const int L = (int) (qOff[q + 1] - qOff[q]);
+                                std::vector<int8_t> corr((size_t) L);
+                                if (qCorrHost) std::memcpy(corr.data(), qCorrHost + qOff[q], (size_t) L);
+                                else {
+#pragma omp critical(mk_pf_corr)
+                                    if (hipMemcpy(corr.data(), V.q_corr + qOff[q], (size_t) L, hipMemcpyDeviceToHost) != hipSuccess) failed = 1;
+                                }
+                                self = self_score(ungMat, qRes.data() + qOff[q], corr.data(), L);
+                            }
+                            std::vector<mk_hit> hh((size_t) maxHits);
+                            const int cnt = select_hits(perQuery, binCount, maxHits, P.min_ungapped_score, self, hh.data());
+                            hh.resize((size_t) cnt);
+                            hostQ[r] = ql;
+                            hostHits[r] = std::move(hh);
                         }
-                        std::vector<mk_hit> hh((size_t) maxHits);
-                        const int cnt = select_hits(perQuery, binCount, maxHits, P.min_ungapped_score, self, hh.data());
-                        hh.resize((size_t) cnt);
-                        hostQ.push_back(ql);
-                        hostHits.push_back(std::move(hh));
                     }
+                    if (failed) { err = "hipMemcpy of the diagonal correction failed"; return MK_ERR_DEVICE; }
                 }
             }
         }
         // append the chunk: device-final hits are compact in query order; flagged queries come from the host lists
-        {
-            ScopedHost sh("host_prefilter_append");
-            if (outHits.capacity() < outHits.size() + nDevHits + 4096) {
-                // grow geometrically, sized from the progress so far
-                const double frac = std::max(0.02, (double) q1 / (double) nq);
-                const size_t want = (size_t) ((double) (outHits.size() + nDevHits) / frac * 1.1) + 4096;
-                outHits.reserve(std::max(want, outHits.size() + nDevHits + 4096));
+        if (devDirect || hostQ.empty()) {
+            if (!devDirect && nDevHits) {                              // (not reached today: the staged copy implies flagged queries)
+                if (!reserve_out(nDevHits, q1)) { err = "pinned host allocation for the prefilter result failed"; return MK_ERR_DEVICE; }
+                std::memcpy((mk_hit *) outBlk.p + nOut, devHits, nDevHits * sizeof(mk_hit));
             }
-            if (hostQ.empty()) {
-                outHits.insert(outHits.end(), devHits, devHits + nDevHits);
-                for (uint32_t ql = 0; ql < nqc; ql++) outOff[(size_t) q0 + ql + 1] = outOff[(size_t) q0 + ql] + chunkCnt[ql];
-            } else {
-                size_t dev = 0, hk = 0;
-                for (uint32_t ql = 0; ql < nqc; ql++) {
-                    const size_t qg = (size_t) q0 + ql;
-                    if (hk < hostQ.size() && hostQ[hk] == ql) {
-                        outHits.insert(outHits.end(), hostHits[hk].begin(), hostHits[hk].end());
-                        outOff[qg + 1] = outOff[qg] + hostHits[hk].size();
-                        hk++;
-                    } else {
-                        const uint32_t c = chunkCnt[ql];
-                        if (c) outHits.insert(outHits.end(), devHits + dev, devHits + dev + c);
-                        dev += c;
-                        outOff[qg + 1] = outOff[qg] + c;
-                    }
+            uint64_t o = outOff[q0];
+            for (uint32_t ql = 0; ql < nqc; ql++) { o += chunkCnt[ql]; outOff[(size_t) q0 + ql + 1] = o; }
+            nOut += nDevHits;
+        } else {
+            ScopedHost sh("host_prefilter_append");
+            size_t extra = 0;
+            for (const auto &hh : hostHits) extra += hh.size();
+            if (!reserve_out(nDevHits + extra, q1)) { err = "pinned host allocation for the prefilter result failed"; return MK_ERR_DEVICE; }
+            mk_hit *dst = (mk_hit *) outBlk.p;
+            size_t dev = 0, hk = 0;
+            for (uint32_t ql = 0; ql < nqc; ql++) {
+                const size_t qg = (size_t) q0 + ql;
+                if (hk < hostQ.size() && hostQ[hk] == ql) {
+                    if (!hostHits[hk].empty()) std::memcpy(dst + nOut, hostHits[hk].data(), hostHits[hk].size() * sizeof(mk_hit));
+                    nOut += hostHits[hk].size();
+                    hk++;
+                } else {
+                    const uint32_t c = chunkCnt[ql];
+                    if (c) std::memcpy(dst + nOut, devHits + dev, (size_t) c * sizeof(mk_hit));
+                    dev += c; nOut += c;
                 }
+                outOff[qg + 1] = nOut;
             }
         }
         q0 = q1;
     }
     (void) tOff;
+    PCHK(sync_wait(stream, "wait_prefilter"));         // the last DMA into the result block
     return MK_OK;
 }
 

@@ -27,6 +27,6 @@ typedef void (*timed_set_fn)(int handle, double bytes, double cells);
 int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &q_off_host, const std::vector<uint8_t> &q_res_host,
                   const int8_t *q_corr_host,
                   const std::vector<uint64_t> &t_off_host, const mk_params &P, int binCount, hipStream_t stream,
-                  std::vector<mk_hit> &outHits, std::vector<uint64_t> &outOff, std::string &err, timed_begin_fn tb, timed_end_fn te, timed_set_fn ts);
+                  struct HostBlock &outHits, size_t &nOutHits, std::vector<uint64_t> &outOff, std::string &err, timed_begin_fn tb, timed_end_fn te, timed_set_fn ts);
 
 }  // namespace mk
