@@ -151,7 +151,12 @@ def main():
     cells_sw = sum(v["cells"] for k, v in stats.items() if k.startswith("sw_"))
     gcups_total = world * cells_sw / elapsed / 1e9
     sw_ms = sum(v["ms"] for k, v in stats.items() if k.startswith("sw_"))
-    kstats = {k: v for k, v in stats.items() if not k.startswith("host_")}
+    kstats = {k: v for k, v in stats.items() if not k.startswith(("host_", "wait_"))}
+    if rank == 0:
+        for k, v in sorted(stats.items()):
+            print("# %-24s ms/step %10.2f launches/step %8.1f bytes/step %.4g cells/step %.4g" % (
+                k, v["ms"] / max(args.steps, 1), v["launches"] / max(args.steps, 1), v["alg_bytes"] / max(args.steps, 1),
+                v["cells"] / max(args.steps, 1)), file=sys.stderr)
     dom_name, dom = max(kstats.items(), key=lambda kv: kv[1]["ms"]) if kstats else ("none", dict(ms=0, launches=1, alg_bytes=0, cells=0))
     per_launch_ms = dom["ms"] / max(dom["launches"], 1)
     achieved = (dom["alg_bytes"] / max(dom["launches"], 1)) / max(per_launch_ms * 1e-3, 1e-12) / 1e9

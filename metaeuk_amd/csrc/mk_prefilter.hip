@@ -5,25 +5,36 @@
 //   CacheFriendlyOperations::findDuplicates (double hits)     M/src/prefiltering/CacheFriendlyOperations.cpp:185-274
 //   UngappedAlignment::computeScores                          M/src/prefiltering/UngappedAlignment.cpp:331-362
 //   keepMaxScoreElementOnly / threshold / getResult / sort    M/src/prefiltering/QueryMatcher.cpp:149-209
-// Pipeline per chunk of queries -- everything stays in HBM, the host sees only the final hit lists:
-//   1. probe_kernel<COUNT>   one wave per k-mer start: enumerate the similar k-mers (two sorted 3-mer rows,
-//                            product order of the reference), read the index offset pair of each, sum list sizes
-//   2. exclusive scan        (hipcub) -> canonical position of every index entry ("ordinal")
-//   3. probe_kernel<GATHER>  same enumeration, copies the index lists: key = (query, target), value = (ordinal, diagonal)
-//   4. stable radix sort     (hipcub) by key: per (query,target) the hits are now in the reference's arrival order
-//   5. double_hit_flag       the sequential 8-bit-diagonal rule of findDuplicates as a neighbour test + short backward
-//                            walk; survivors are compacted IN ORDER (hipcub select), i.e. sorted by (query,target,arrival)
-//   6. cand_score_kernel     exact ungapped score of every surviving (query, target, diagonal)
-//   7. keep_kernel           best diagonal per target (first maximum in arrival order), >= --min-ungapped-score,
-//                            per-query counts; queries that reach --max-seqs are flagged for the exact host
-//                            tie-order logic (mk::select_hits), everything else is final
-//   8. radix sort + emit     hits ordered by (query, score desc, target asc) -> compact mk_hit array + counts
+//
+// Two front ends produce the CANDIDATES of a chunk of queries (the (query, target, diagonal) triples that survive
+// the double-diagonal rule, per query contiguous and ordered by (target, arrival)):
+//
+//  A. fused_kernel  (queries whose index hits fit in the LDS of one workgroup -- the metagenomic fragment case)
+//     one workgroup per query: the waves enumerate the similar k-mers of their positions (two sorted 3-mer rows,
+//     product order of the reference), read the index lists and drop (target, diagonal) straight into LDS in
+//     arrival order; an in-LDS bitonic sort on (target, arrival) groups the hits per target; the sequential
+//     8-bit-diagonal rule of findDuplicates becomes a neighbour test + short backward walk; only the survivors
+//     leave the CU.  HBM traffic = the index probes, nothing else.
+//
+//  B. global path   (everything else: long queries, queries that overflow their LDS tier, big databases)
+//     probe_kernel<COUNT> -> exclusive scan -> probe_kernel<GATHER> (key = (query,target), value = (arrival,diagonal))
+//     -> stable radix sort (hipcub) -> double_hit_flag_kernel -> ordered compaction (hipcub select).
+//
+// Common back end per chunk, everything in HBM, the host sees only the final hit lists:
+//     diag_score_kernel   exact ungapped score of every candidate
+//     keep_kernel         best diagonal per target (first maximum in arrival order), >= --min-ungapped-score,
+//                         per-query counts; queries that reach --max-seqs are flagged for the exact host
+//                         tie-order logic (mk::select_hits), everything else is final
+//     radix sort + emit   hits ordered by (query, score desc, target asc) -> compact mk_hit array, DMA'd to its
+//                         final place in the batch's pinned result block
 #include "mk_prefilter.hpp"
 #include "mk_host.hpp"
 #include "mk_kernels.hpp"
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <numeric>
 
 namespace mk {
 
@@ -50,6 +61,11 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // number of leading entries of a descending int16 row that are >= cutoff
 __device__ __forceinline__ int count_ge(const int16_t *lds, int nLds, const int16_t *row, int cutoff) {
     if (nLds > 0 && (int) lds[nLds - 1] < cutoff) {
@@ -69,11 +85,17 @@ __device__ __forceinline__ uint32_t find_query(const uint64_t *qOff, uint32_t nq
     return lo;
 }
 
+// candidates of a chunk (structure of arrays; q = chunk-local query index)
+struct CandArrays { uint32_t *q; uint32_t *id; uint32_t *ordinal; uint16_t *diag; int32_t *score; };
+
+// =====================================================================================================
+//  B. global path
+// =====================================================================================================
 struct ProbeArgs {
     PrefilterDeviceView V;
-    uint64_t pos_begin, pos_end;      // global residue range of this chunk
-    uint32_t q_first;                 // first query of the chunk
-    uint32_t seq_bits;                // key = qLocal << seq_bits | target
+    uint64_t pos_begin, pos_end;      // residue range (of the view) handled by this launch
+    uint32_t q_first;                 // first view query of the range
+    uint32_t seq_bits;                // key = (q - q_first) << seq_bits | target
     uint32_t *hit_count;              // [pos] (COUNT: written; GATHER: exclusive prefix, read)
     uint32_t *kmer_count;             // [pos] statistics
     uint64_t *keys; uint64_t *vals;   // GATHER outputs
@@ -102,8 +124,7 @@ __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
     const int16_t *s1 = A.V.score3 + (size_t) idx1 * N3;
     const uint16_t *i1 = A.V.index3 + (size_t) idx1 * N3;
     for (int k = lane; k < ROWCACHE; k += WAVE) { sRow1[w][k] = s1[k]; if (GATHER) sIdx1[w][k] = i1[k]; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    wave_sync_lds();
     const int cutoff1 = (int) (short) (thr - (int) sRow1[w][0]);   // threshold - best score of the second half
 
     uint32_t qLocal = 0, iPos = 0, qFirstHit = 0;
@@ -127,8 +148,7 @@ __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
         sPref[w][lane] = excl;
         if (lane == 0) sPref[w][WAVE] = groupTotal;
         sIdx0[w][lane] = valid ? i0[a] : (uint16_t) 0;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        wave_sync_lds();
         kmers += groupTotal;
         // enumerate the (a,b) products of this group 64 at a time, in product order
         for (uint32_t base = 0; base < groupTotal; base += WAVE) {
@@ -160,8 +180,7 @@ __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
                 hits += tot;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        wave_sync_lds();
         if (__any(!valid)) break;
     }
     if (!GATHER) {
@@ -170,7 +189,7 @@ __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
     }
 }
 
-// totals of a chunk after the scan + the reference's per-query databaseHits capacity check
+// totals of a range after the scan + the reference's per-query databaseHits capacity check
 // (QueryMatcher.cpp:43,281-316: a query gathering >= 2*max(1e6,dbSize) entries takes the overflow path)
 __global__ __launch_bounds__(256) void chunk_totals_kernel(const uint64_t *qOff, uint32_t qFirst, uint32_t nq, uint64_t posBegin, uint64_t nPos,
                                                           const uint32_t *scan, const uint32_t *lastCount, uint64_t maxDbMatches,
@@ -213,21 +232,297 @@ __global__ __launch_bounds__(256) void double_hit_flag_kernel(const uint64_t *ke
     flag[t] = emit;
 }
 
-// exact ungapped diagonal score of candidate c (sorted hit index sel[c])
-struct CandArrays { uint32_t *q; uint32_t *id; uint32_t *ordinal; uint16_t *diag; int32_t *score; };
+// selected sorted hits -> candidate arrays (appended at `base`); qMap translates the range-local query index
+// into the chunk-local one (null: qLocal + qAdd)
+__global__ __launch_bounds__(256) void cand_from_sorted_kernel(const uint64_t *keys, const uint64_t *vals, const uint32_t *sel, uint32_t n, uint32_t seqBits,
+                                                               const uint32_t *qMap, uint32_t qAdd, CandArrays C, uint32_t base) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const uint32_t t = sel[c];
+    const uint64_t key = keys[t], val = vals[t];
+    const uint32_t ql = (uint32_t) (key >> seqBits);
+    C.q[base + c] = qMap ? qMap[ql] : ql + qAdd;
+    C.id[base + c] = (uint32_t) (key & ((1ull << seqBits) - 1));
+    C.ordinal[base + c] = (uint32_t) (val >> 16);
+    C.diag[base + c] = (uint16_t) (val & 0xFFFFu);
+}
 
-__global__ __launch_bounds__(256) void cand_score_kernel(PrefilterDeviceView V, uint32_t qFirst, uint32_t seqBits, const uint64_t *keys, const uint64_t *vals,
-                                                         const uint32_t *sel, uint32_t n, CandArrays C) {
+// compact copy of selected queries (the ones the fused kernel could not take) into a small batch for the global path
+__global__ __launch_bounds__(256) void gather_queries_kernel(PrefilterDeviceView V, const uint32_t *srcQuery, const uint64_t *miniOff, uint32_t nMini, uint64_t total,
+                                                             uint8_t *res, int16_t *kthr, int8_t *corr) {
+    const uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= total) return;
+    const uint32_t i = find_query(miniOff, nMini, r);
+    const uint64_t src = V.q_off[srcQuery[i]] + (r - miniOff[i]);
+    res[r] = V.q_res[src]; kthr[r] = V.q_kmer_thr[src]; corr[r] = V.q_corr[src];
+}
+
+// =====================================================================================================
+//  A. fused per-query path
+// =====================================================================================================
+constexpr uint32_t ARR_BITS = 14;                 // arrival index field of the LDS sort key (<= 16384 slots)
+constexpr uint32_t ARR_MASK = (1u << ARR_BITS) - 1u;
+constexpr uint32_t KEY_SENTINEL = 0xFFFFFFFFu;
+
+struct FusedArgs {
+    PrefilterDeviceView V;
+    const uint32_t *queries;          // (global) query ids of this launch, one workgroup each
+    uint32_t n_launch;
+    uint32_t q_first;                 // first query of the chunk: candidates carry q - q_first
+    CandArrays C; uint32_t cand_cap;
+    uint32_t *counters;               // [0] candidates appended [1] overflowed queries
+    uint32_t *overflow_list;          // chunk-local ids of the queries that did not fit their tier
+    unsigned long long *totals;       // [0] k-mers [1] index hits [2] k-mer start positions (statistics / tier sizing)
+};
+
+template <int CAP, int NW>
+__global__ __launch_bounds__(NW * 64) void fused_kernel(FusedArgs A) {
+    constexpr int NCH = CAP / WAVE;               // 64-slot chunks of the hit store
+    constexpr int BLOCK = NW * WAVE;
+    __shared__ uint32_t sKey[CAP];                // phase 1: target id; afterwards target << ARR_BITS | arrival
+    __shared__ uint16_t sDiag[CAP];
+    __shared__ int16_t sRow1[NW][ROWCACHE];
+    __shared__ uint16_t sIdx1[NW][ROWCACHE];
+    __shared__ uint32_t sPref[NW][WAVE + 1];
+    __shared__ uint16_t sIdx0[NW][WAVE];
+    __shared__ uint16_t sChunkOf[NW][NCH];        // wave-local chunk number -> physical chunk
+    __shared__ uint16_t sRankToChunk[NCH];        // arrival rank of a chunk -> physical chunk
+    __shared__ uint16_t sChunkRank[NCH];          // physical chunk -> arrival rank
+    __shared__ uint8_t sOwner[NCH];
+    __shared__ uint32_t sWaveHits[NW], sWaveChunks[NW], sWaveKmers[NW], sWavePos[NW], sWavePrefix[NW + 1];
+    __shared__ uint32_t sFlagBits[CAP / 32];
+    __shared__ uint32_t sWordPrefix[CAP / 32];
+    __shared__ uint32_t sBump, sOverflow, sEmitBase;
+
+    const int tid = threadIdx.x, w = tid / WAVE, lane = tid & (WAVE - 1);
+    const uint32_t q = A.queries[blockIdx.x];
+    const uint64_t qs = A.V.q_off[q];
+    const int L = (int) (A.V.q_off[q + 1] - qs);
+    if (tid == 0) { sBump = 0; sOverflow = 0; }
+    __syncthreads();
+
+    // ---- phase 1: enumerate + gather into LDS.  Wave w owns a contiguous range of k-mer starts, so arrival order is
+    //      (wave, wave-local slot); slots come in 64-entry chunks from a workgroup-wide bump allocator.
+    const int nStart = L >= 10 ? L - 9 : 0;
+    const int per = (nStart + NW - 1) / NW;
+    const int iBeg = min(nStart, w * per), iEnd = min(nStart, iBeg + per);
+    uint32_t wcount = 0, nCh = 0, kmers = 0, npos = 0;
+    bool dead = false;
+    for (int i = iBeg; i < iEnd && !dead; i++) {
+        const uint64_t p = qs + (uint64_t) i;
+        const int thr = (int) A.V.q_kmer_thr[p];
+        if (thr < 0) continue;
+        if (*(volatile uint32_t *) &sOverflow) { dead = true; break; }
+        npos++;
+        const uint8_t *r = A.V.q_res + p;
+        const uint32_t idx0 = r[0] + 20u * r[1] + 400u * r[3];
+        const uint32_t idx1 = r[5] + 20u * r[8] + 400u * r[9];
+        const int16_t *s0 = A.V.score3 + (size_t) idx0 * N3;
+        const uint16_t *i0 = A.V.index3 + (size_t) idx0 * N3;
+        const int16_t *s1 = A.V.score3 + (size_t) idx1 * N3;
+        const uint16_t *i1 = A.V.index3 + (size_t) idx1 * N3;
+        for (int k = lane; k < ROWCACHE; k += WAVE) { sRow1[w][k] = s1[k]; sIdx1[w][k] = i1[k]; }
+        wave_sync_lds();
+        const int cutoff1 = (int) (short) (thr - (int) sRow1[w][0]);
+        for (int a0 = 0; a0 < N3 && !dead; a0 += WAVE) {
+            const int a = a0 + lane;
+            const int sa = (a < N3) ? (int) s0[a] : -32768;
+            const bool valid = sa >= cutoff1;
+            uint32_t nb = 0;
+            if (valid) nb = (uint32_t) count_ge(sRow1[w], ROWCACHE, s1, (int) (short) (thr - sa));
+            uint32_t groupTotal;
+            const uint32_t excl = wave_excl_scan(nb, groupTotal);
+            sPref[w][lane] = excl;
+            if (lane == 0) sPref[w][WAVE] = groupTotal;
+            sIdx0[w][lane] = valid ? i0[a] : (uint16_t) 0;
+            wave_sync_lds();
+            kmers += groupTotal;
+            for (uint32_t base = 0; base < groupTotal && !dead; base += WAVE) {
+                const uint32_t pr = base + lane;
+                uint32_t size = 0, o0 = 0;
+                if (pr < groupTotal) {
+                    int lo = 0, hi = WAVE;
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sPref[w][mid] <= pr) lo = mid; else hi = mid; }
+                    const uint32_t b = pr - sPref[w][lo];
+                    const uint32_t ib = (b < ROWCACHE) ? (uint32_t) sIdx1[w][b] : (uint32_t) i1[b];
+                    const uint32_t kmer = (uint32_t) sIdx0[w][lo] + N3 * ib;
+                    o0 = A.V.kmer_off[kmer];
+                    size = A.V.kmer_off[kmer + 1] - o0;
+                }
+                uint32_t tot;
+                const uint32_t ex = wave_excl_scan(size, tot);
+                if (tot == 0) continue;
+                while (nCh * WAVE < wcount + tot) {                     // wave-uniform: more slots for this group
+                    uint32_t c = 0;
+                    if (lane == 0) c = atomicAdd(&sBump, 1u);
+                    c = (uint32_t) __builtin_amdgcn_readfirstlane((int) c);
+                    if (c >= (uint32_t) NCH) { dead = true; break; }
+                    if (lane == 0) { sChunkOf[w][nCh] = (uint16_t) c; sOwner[c] = (uint8_t) w; }
+                    nCh++;
+                }
+                if (dead) { if (lane == 0) sOverflow = 1; break; }
+                wave_sync_lds();
+                const uint32_t v0 = wcount + ex;
+                for (uint32_t e = 0; e < size; e++) {
+                    const uint64_t ent = A.V.entries[o0 + e];
+                    const uint32_t v = v0 + e;
+                    const uint32_t phys = (uint32_t) sChunkOf[w][v >> 6] * WAVE + (v & 63u);
+                    sKey[phys] = (uint32_t) ent;
+                    sDiag[phys] = (uint16_t) (((uint32_t) i - ((uint32_t) (ent >> 32) & 0xFFFFu)) & 0xFFFFu);
+                }
+                wcount += tot;
+            }
+            wave_sync_lds();
+            if (__any(!valid)) break;
+        }
+    }
+    if (lane == 0) { sWaveHits[w] = wcount; sWaveChunks[w] = nCh; sWaveKmers[w] = kmers; sWavePos[w] = npos; }
+    __syncthreads();
+    if (sOverflow) {                                   // does not fit this tier: the global path takes the query
+        if (tid == 0) A.overflow_list[atomicAdd(&A.counters[1], 1u)] = q - A.q_first;
+        return;
+    }
+    if (tid == 0) {
+        uint32_t acc = 0, hits = 0, km = 0, np = 0;
+        for (int k = 0; k < NW; k++) { sWavePrefix[k] = acc; acc += sWaveChunks[k]; hits += sWaveHits[k]; km += sWaveKmers[k]; np += sWavePos[k]; }
+        sWavePrefix[NW] = acc;
+        atomicAdd(&A.totals[0], (unsigned long long) km);
+        atomicAdd(&A.totals[1], (unsigned long long) hits);
+        atomicAdd(&A.totals[2], (unsigned long long) np);
+    }
+    __syncthreads();
+    const uint32_t nChunks = sWavePrefix[NW];
+    if (nChunks == 0) return;
+    const uint32_t used = nChunks * WAVE;
+    uint32_t P = WAVE;
+    while (P < used) P <<= 1;
+    // chunk ranks (arrival order of the chunks), then the sort keys target << ARR_BITS | arrival
+    for (uint32_t k = (uint32_t) tid; k < (uint32_t) NW * NCH; k += BLOCK) {
+        const uint32_t ww = k / NCH, kk = k % NCH;
+        if (kk < sWaveChunks[ww]) {
+            const uint32_t c = sChunkOf[ww][kk], rank = sWavePrefix[ww] + kk;
+            sRankToChunk[rank] = (uint16_t) c;
+            sChunkRank[c] = (uint16_t) rank;
+        }
+    }
+    __syncthreads();
+    for (uint32_t s = (uint32_t) tid; s < P; s += BLOCK) {
+        uint32_t key = KEY_SENTINEL;
+        if (s < used) {
+            const uint32_t c = s >> 6, rank = sChunkRank[c], ww = sOwner[c];
+            const uint32_t v = (rank - sWavePrefix[ww]) * WAVE + (s & 63u);   // wave-local slot number
+            if (v < sWaveHits[ww]) key = (sKey[s] << ARR_BITS) | (rank * WAVE + (s & 63u));
+        }
+        sKey[s] = key;
+    }
+    __syncthreads();
+
+    // ---- phase 2: bitonic sort of the keys (all distinct: the arrival index makes the order total)
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = (uint32_t) tid; i < (P >> 1); i += BLOCK) {
+                const uint32_t l = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
+                const uint32_t r2 = l | j;
+                const uint32_t x = sKey[l], y = sKey[r2];
+                const bool up = (l & k) == 0;
+                if ((x > y) == up) { sKey[l] = y; sKey[r2] = x; }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- phase 3: the double-diagonal rule on the target runs -> flag bits
+    auto lo_of = [&](uint32_t key) -> uint32_t {
+        const uint32_t arr = key & ARR_MASK;
+        return (uint32_t) sDiag[(uint32_t) sRankToChunk[arr >> 6] * WAVE + (arr & 63u)] & 0xFFu;
+    };
+    for (uint32_t t0 = 0; t0 < P; t0 += BLOCK) {
+        const uint32_t t = t0 + (uint32_t) tid;
+        bool emit = false;
+        if (t < P) {
+            const uint32_t key = sKey[t];
+            if (key != KEY_SENTINEL) {
+                const uint32_t target = key >> ARR_BITS, lo = lo_of(key);
+                const bool samePrev = t > 0 && (sKey[t - 1] >> ARR_BITS) == target;
+                const uint32_t prevLo = samePrev ? lo_of(sKey[t - 1]) : 0u;
+                if (lo == prevLo) {
+                    emit = true;
+                    if (samePrev) {
+                        uint32_t u = t - 1;
+                        while (true) {
+                            const uint32_t ulo = lo_of(sKey[u]);
+                            const bool uSame = u > 0 && (sKey[u - 1] >> ARR_BITS) == target;
+                            const uint32_t uprev = uSame ? lo_of(sKey[u - 1]) : 0u;
+                            if (ulo == uprev) { emit = (ulo != lo); break; }
+                            if (!uSame) break;
+                            u--;
+                        }
+                    }
+                }
+            }
+        }
+        const unsigned long long m = __ballot(emit);
+        if (lane == 0 && t < P) { sFlagBits[t >> 5] = (uint32_t) m; sFlagBits[(t >> 5) + 1] = (uint32_t) (m >> 32); }
+    }
+    __syncthreads();
+    // exclusive prefix of the per-word popcounts (one wave; <= 512 words)
+    const uint32_t nWords = P >> 5;
+    if (w == 0) {
+        const uint32_t perLane = (nWords + WAVE - 1) / WAVE;
+        const uint32_t b = min(nWords, (uint32_t) lane * perLane), e = min(nWords, b + perLane);
+        uint32_t sum = 0;
+        for (uint32_t k = b; k < e; k++) sum += (uint32_t) __popc(sFlagBits[k]);
+        uint32_t total;
+        uint32_t run = wave_excl_scan(sum, total);
+        for (uint32_t k = b; k < e; k++) { sWordPrefix[k] = run; run += (uint32_t) __popc(sFlagBits[k]); }
+        if (lane == 0) { sEmitBase = total ? atomicAdd(&A.counters[0], total) : 0u; sBump = total; }
+    }
+    __syncthreads();
+    const uint32_t nEmit = sBump, base = sEmitBase;
+    if (nEmit == 0 || (unsigned long long) base + nEmit > (unsigned long long) A.cand_cap) return;   // host sees counters[0] > cap and retries
+    for (uint32_t t = (uint32_t) tid; t < P; t += BLOCK) {
+        const uint32_t word = sFlagBits[t >> 5];
+        if (!((word >> (t & 31u)) & 1u)) continue;
+        const uint32_t dst = base + sWordPrefix[t >> 5] + (uint32_t) __popc(word & ((1u << (t & 31u)) - 1u));
+        const uint32_t key = sKey[t], arr = key & ARR_MASK;
+        A.C.q[dst] = q - A.q_first;
+        A.C.id[dst] = key >> ARR_BITS;
+        A.C.ordinal[dst] = arr;
+        A.C.diag[dst] = sDiag[(uint32_t) sRankToChunk[arr >> 6] * WAVE + (arr & 63u)];
+    }
+}
+
+struct FusedTier { int cap; int waves; };
+constexpr int N_TIERS = 4;
+// production tiers, then a miniature set (MK_PREFILTER_TIERS=tiny) with which small test inputs exercise every
+// workgroup shape, the overflow hand-over and the global path
+const FusedTier TIERS[2 * N_TIERS] = {{2048, 4}, {4096, 4}, {8192, 8}, {16384, 16}, {256, 4}, {512, 4}, {1024, 8}, {2048, 16}};
+
+void launch_fused(int tier, const FusedArgs &A, hipStream_t stream) {
+    switch (tier) {
+        case 0: hipLaunchKernelGGL((fused_kernel<2048, 4>), dim3(A.n_launch), dim3(256), 0, stream, A); break;
+        case 1: hipLaunchKernelGGL((fused_kernel<4096, 4>), dim3(A.n_launch), dim3(256), 0, stream, A); break;
+        case 2: hipLaunchKernelGGL((fused_kernel<8192, 8>), dim3(A.n_launch), dim3(512), 0, stream, A); break;
+        case 3: hipLaunchKernelGGL((fused_kernel<16384, 16>), dim3(A.n_launch), dim3(1024), 0, stream, A); break;
+        case 4: hipLaunchKernelGGL((fused_kernel<256, 4>), dim3(A.n_launch), dim3(256), 0, stream, A); break;
+        case 5: hipLaunchKernelGGL((fused_kernel<512, 4>), dim3(A.n_launch), dim3(256), 0, stream, A); break;
+        case 6: hipLaunchKernelGGL((fused_kernel<1024, 8>), dim3(A.n_launch), dim3(512), 0, stream, A); break;
+        default: hipLaunchKernelGGL((fused_kernel<2048, 16>), dim3(A.n_launch), dim3(1024), 0, stream, A); break;
+    }
+}
+
+// =====================================================================================================
+//  common back end
+// =====================================================================================================
+// exact ungapped diagonal score of every candidate
+__global__ __launch_bounds__(256) void diag_score_kernel(PrefilterDeviceView V, uint32_t qFirst, uint32_t n, CandArrays C) {
     __shared__ int8_t smat[21 * 21 + 3];
     for (int i = threadIdx.x; i < 21 * 21; i += blockDim.x) smat[i] = V.mat_ung[i];
     __syncthreads();
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
-    const uint32_t t = sel[c];
-    const uint64_t key = keys[t], val = vals[t];
-    const uint32_t ql = (uint32_t) (key >> seqBits), id = (uint32_t) (key & ((1ull << seqBits) - 1));
-    const uint32_t d16 = (uint32_t) val & 0xFFFFu;
-    const uint32_t q = qFirst + ql;
+    const uint32_t q = qFirst + C.q[c], id = C.id[c];
+    const uint32_t d16 = (uint32_t) C.diag[c];
     const uint64_t qs = V.q_off[q], ts = V.t_off[id];
     const uint32_t qLen = (uint32_t) (V.q_off[q + 1] - qs), tLen = (uint32_t) (V.t_off[id + 1] - ts);
     const int diag = (int) (short) (uint16_t) d16;
@@ -244,11 +539,11 @@ __global__ __launch_bounds__(256) void cand_score_kernel(PrefilterDeviceView V, 
         score = max(score + curr, 0);
         best = max(best, score);
     }
-    C.q[c] = ql; C.id[c] = id; C.ordinal[c] = (uint32_t) (val >> 16); C.diag[c] = (uint16_t) d16; C.score[c] = best;
+    C.score[c] = best;
 }
 
-// keepMaxScoreElementOnly on the (query,target,arrival)-sorted candidates: a candidate survives when its clamped
-// score is the maximum of its (query,target) run and no earlier candidate of the run has the same clamped score.
+// keepMaxScoreElementOnly on the candidates (per (query,target) contiguous, in arrival order): a candidate survives
+// when its clamped score is the maximum of its run and no earlier candidate of the run has the same clamped score.
 // Survivors below --min-ungapped-score can never be reported (diagonalThr >= minDiagScoreThr) and are dropped here.
 __global__ __launch_bounds__(256) void keep_kernel(CandArrays C, uint32_t n, int minDiag, uint8_t *kept, uint32_t *perQuery) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -325,10 +620,151 @@ int self_score(const SubMat &ung, const uint8_t *q, const int8_t *corr, int L) {
     return best;
 }
 
+// sizing state carried from one batch to the next (same database): index hits per k-mer start, candidates per query
+struct SizingMemo { const void *entries = nullptr; uint32_t nTargets = 0; double hitsPerPos = 0, candPerQuery = 0; };
+SizingMemo g_memo;
+
 }  // namespace
 
 #define PCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); return MK_ERR_DEVICE; } } while (0)
 #define PNULL(p) do { if (!(p)) { err = "device scratch allocation failed (" #p ")"; return MK_ERR_DEVICE; } } while (0)
+
+namespace {
+
+constexpr int RC_CAND_OVERFLOW = 1000;            // internal: the chunk produced more candidates than the buffers hold
+
+struct Ctx {
+    hipStream_t stream; std::string *err; timed_begin_fn tb; timed_end_fn te; timed_set_fn ts;
+    uint32_t seqBits; uint64_t maxDbMatches;
+    CandArrays C; uint32_t candCap;
+    unsigned long long *dTotals, *hTotals;
+};
+
+// B. global path over the view queries [a, b): appends their candidates at C[nCand...]; qMap/qAdd translate the view's
+// query index into the chunk-local one.  Splits the range so that the index hits of one piece fit HIT_CAP.
+int global_candidates(Ctx &X, const PrefilterDeviceView &V, const uint64_t *hOff /* host offsets of the view */, uint32_t a, uint32_t b,
+                      const uint32_t *qMap, uint32_t qAddBase, uint32_t &nCand, double &hitsPerPos) {
+    std::string &err = *X.err;
+    hipStream_t stream = X.stream;
+    const size_t HIT_CAP = 768u << 20;                // index hits per piece kept in HBM: 32 B each (key+value, double buffered)
+    const uint64_t POS_CAP = 24u << 20;               // residues per piece
+    const uint32_t QCAP = 1u << 20;
+    uint32_t q0 = a;
+    while (q0 < b) {
+        uint32_t q1 = q0;
+        {
+            uint64_t posBudget = hitsPerPos > 0 ? std::min<uint64_t>(POS_CAP, (uint64_t) (0.8 * (double) HIT_CAP / hitsPerPos))
+                                                : std::min<uint64_t>(POS_CAP, 1u << 20);   // first piece: small probe
+            while (q1 < b && q1 - q0 < QCAP && (hOff[q1 + 1] - hOff[q0] <= posBudget || q1 == q0)) q1++;
+        }
+        uint64_t totalHits = 0, nPos = 0;
+        uint32_t *dHit = nullptr, *dKmer = nullptr;
+        for (;;) {
+            nPos = hOff[q1] - hOff[q0];
+            if (nPos == 0) break;
+            dHit = (uint32_t *) dev_scratch("pf_hit", (nPos + 1) * 4);
+            dKmer = (uint32_t *) dev_scratch("pf_kmer", (nPos + 1) * 4);
+            uint32_t *dLast = (uint32_t *) dev_scratch("pf_last", 16);
+            PNULL(dHit); PNULL(dKmer); PNULL(dLast);
+            ProbeArgs A;
+            A.V = V; A.pos_begin = hOff[q0]; A.pos_end = hOff[q1]; A.q_first = q0; A.seq_bits = X.seqBits;
+            A.hit_count = dHit; A.kmer_count = dKmer; A.keys = nullptr; A.vals = nullptr;
+            const unsigned blocks = (unsigned) ((nPos + 3) / 4);
+            const int thCount = X.tb("kmer_probe_count", 0, 0);
+            hipLaunchKernelGGL(probe_kernel<false>, dim3(blocks), dim3(256), 0, stream, A);
+            X.te(thCount);
+            PCHK(hipGetLastError());
+            // totals: k-mers (reduce), hits (scan); the count of the last position is saved before the in-place scan
+            PCHK(hipMemcpyAsync(dLast, dHit + (nPos - 1), 4, hipMemcpyDeviceToDevice, stream));
+            size_t tb2 = 0, t3 = 0;
+            hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, dHit, dHit, (int) nPos, stream);
+            // kmer_count is u32 per position; the sum can exceed 2^32 -> accumulate in 64 bit via a transform iterator
+            hipcub::TransformInputIterator<unsigned long long, hipcub::CastOp<unsigned long long>, uint32_t *> it(dKmer, hipcub::CastOp<unsigned long long>());
+            hipcub::DeviceReduce::Sum(nullptr, t3, it, X.dTotals + 2, (int) nPos, stream);
+            void *temp = dev_scratch("pf_temp", std::max(tb2, t3));
+            PNULL(temp);
+            PCHK(hipcub::DeviceReduce::Sum(temp, t3, it, X.dTotals + 2, (int) nPos, stream));
+            int th = X.tb("scan", 8.0 * nPos, 0);
+            PCHK(hipcub::DeviceScan::ExclusiveSum(temp, tb2, dHit, dHit, (int) nPos, stream));
+            X.te(th);
+            PCHK(hipMemsetAsync(X.dTotals, 0, 16, stream));
+            hipLaunchKernelGGL(chunk_totals_kernel, dim3((q1 - q0 + 255) / 256), dim3(256), 0, stream, V.q_off, q0, q1 - q0, hOff[q0], nPos,
+                               dHit, dLast, X.maxDbMatches, X.dTotals);
+            PCHK(hipGetLastError());
+            PCHK(hipMemcpyAsync(X.hTotals, X.dTotals, 24, hipMemcpyDeviceToHost, stream));
+            PCHK(sync_wait(stream, "wait_prefilter"));
+            totalHits = X.hTotals[0];
+            if (X.hTotals[1] != 0) { err = "a query overflows the reference's databaseHits buffer (QueryMatcher.cpp:281-316 is not restated)"; return MK_ERR_UNSUPPORTED; }
+            X.ts(thCount, 8.0 * (double) X.hTotals[2] + 2.0 * 2.0 * ROWCACHE * (double) nPos, (double) X.hTotals[2]);
+            hitsPerPos = std::max(1.0, (double) totalHits / (double) nPos);
+            if (totalHits > HIT_CAP && q1 - q0 > 1) { q1 = q0 + (q1 - q0) / 2; continue; }
+            break;
+        }
+        if (nPos > 0 && totalHits > 0) {
+            if (totalHits >= 0x7FFFFFFFull) { err = "a single query produces >= 2^31 index hits"; return MK_ERR_UNSUPPORTED; }
+            const uint32_t nHits = (uint32_t) totalHits;
+            uint64_t *dKeys = (uint64_t *) dev_scratch("pf_keys", (size_t) nHits * 8), *dKeys2 = (uint64_t *) dev_scratch("pf_keys2", (size_t) nHits * 8);
+            uint64_t *dVals = (uint64_t *) dev_scratch("pf_vals", (size_t) nHits * 8), *dVals2 = (uint64_t *) dev_scratch("pf_vals2", (size_t) nHits * 8);
+            PNULL(dKeys); PNULL(dKeys2); PNULL(dVals); PNULL(dVals2);
+            ProbeArgs A;
+            A.V = V; A.pos_begin = hOff[q0]; A.pos_end = hOff[q1]; A.q_first = q0; A.seq_bits = X.seqBits;
+            A.hit_count = dHit; A.kmer_count = dKmer; A.keys = dKeys; A.vals = dVals;
+            const unsigned blocks = (unsigned) ((nPos + 3) / 4);
+            // gather pass: offset pairs again + 8 B per index entry read + 16 B (key,value) written per entry
+            int th = X.tb("kmer_probe_gather", 8.0 * (double) X.hTotals[2] + 24.0 * (double) totalHits + 4.0 * ROWCACHE * (double) nPos, (double) X.hTotals[2]);
+            hipLaunchKernelGGL(probe_kernel<true>, dim3(blocks), dim3(256), 0, stream, A);
+            X.te(th);
+            PCHK(hipGetLastError());
+            // stable sort by (query, target)
+            const uint32_t nqc = q1 - q0;
+            int qBits = 1; while ((1u << qBits) < nqc) qBits++;
+            hipcub::DoubleBuffer<uint64_t> kb(dKeys, dKeys2), vb(dVals, dVals2);
+            size_t tempBytes = 0;
+            hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, kb, vb, (int) nHits, 0, (int) X.seqBits + qBits, stream);
+            void *temp = dev_scratch("pf_temp", tempBytes);
+            PNULL(temp);
+            const int passes = ((int) X.seqBits + qBits + 7) / 8;
+            th = X.tb("sort_hits", 32.0 * passes * (double) nHits, 0);
+            PCHK(hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, kb, vb, (int) nHits, 0, (int) X.seqBits + qBits, stream));
+            X.te(th);
+            // double-hit rule -> flags -> ordered compaction
+            uint8_t *dFlag = (uint8_t *) dev_scratch("pf_flag", nHits);
+            uint32_t *dSel = (uint32_t *) dev_scratch("pf_sel", (size_t) nHits * 4);
+            uint32_t *dNum = (uint32_t *) dev_scratch("pf_num", 64);
+            PNULL(dFlag); PNULL(dSel); PNULL(dNum);
+            th = X.tb("double_hit", 17.0 * nHits, 0);
+            hipLaunchKernelGGL(double_hit_flag_kernel, dim3((nHits + 255) / 256), dim3(256), 0, stream, kb.Current(), vb.Current(), nHits, dFlag);
+            X.te(th);
+            PCHK(hipGetLastError());
+            {
+                hipcub::CountingInputIterator<uint32_t> iota(0);
+                size_t t2 = 0;
+                hipcub::DeviceSelect::Flagged(nullptr, t2, iota, dFlag, dSel, dNum, (int) nHits, stream);
+                temp = dev_scratch("pf_temp", t2);
+                PNULL(temp);
+                th = X.tb("select_candidates", 5.0 * nHits, 0);
+                PCHK(hipcub::DeviceSelect::Flagged(temp, t2, iota, dFlag, dSel, dNum, (int) nHits, stream));
+                X.te(th);
+            }
+            uint32_t *hNum = (uint32_t *) pinned_scratch("pf_num_h", 64);
+            PNULL(hNum);
+            PCHK(hipMemcpyAsync(hNum, dNum, 4, hipMemcpyDeviceToHost, stream));
+            PCHK(sync_wait(stream, "wait_prefilter"));
+            const uint32_t nSel = hNum[0];
+            if ((uint64_t) nCand + nSel > X.candCap) return RC_CAND_OVERFLOW;
+            if (nSel > 0) {
+                hipLaunchKernelGGL(cand_from_sorted_kernel, dim3((nSel + 255) / 256), dim3(256), 0, stream, kb.Current(), vb.Current(), dSel, nSel, X.seqBits,
+                                   qMap ? qMap + q0 : nullptr, qAddBase + q0, X.C, nCand);
+                PCHK(hipGetLastError());
+                nCand += nSel;
+            }
+        }
+        q0 = q1;
+    }
+    return MK_OK;
+}
+
+}  // namespace
 
 int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOff, const std::vector<uint8_t> &qRes,
                   const int8_t *qCorrHost,
@@ -347,249 +783,291 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     };
     const int maxHits = std::min<int>(P.max_seqs, (int) V.n_targets);
     const uint64_t dbSize = V.n_targets;
-    const uint64_t maxDbMatches = std::max<uint64_t>(1000000, dbSize) * 2;   // QueryMatcher.cpp:43
-    const size_t HIT_CAP = 768u << 20;                // index hits per chunk kept in HBM: 32 B each (key+value, double buffered)
-    const uint64_t POS_CAP = 24u << 20;               // residues per chunk
     const uint32_t QCAP = 1u << 20;                   // queries per chunk (20-bit field of the output sort key)
+    const uint32_t CAND_CAP = 96u << 20;              // candidates per chunk held in HBM (~44 B each)
     if (dbSize >= (1ull << 27)) { err = "more than 2^27 targets"; return MK_ERR_UNSUPPORTED; }
     uint32_t seqBits = 1; while ((1ull << seqBits) < dbSize) seqBits++;
-    double hitsPerPos = 0;                            // running estimate used to size the next chunk
+    // front end: "fused" needs the target id to fit beside the 14-bit arrival index in a 32-bit LDS key
+    bool useFused = seqBits + ARR_BITS <= 32;
+    if (const char *e = getenv("MK_PREFILTER_PATH")) {
+        if (!strcmp(e, "global")) useFused = false;
+        else if (strcmp(e, "fused") && strcmp(e, "auto")) { err = "MK_PREFILTER_PATH must be auto, fused or global"; return MK_ERR_ARG; }
+    }
+    int tierBase = 0;
+    if (const char *e = getenv("MK_PREFILTER_TIERS")) {
+        if (!strcmp(e, "tiny")) tierBase = N_TIERS;
+        else if (strcmp(e, "default")) { err = "MK_PREFILTER_TIERS must be default or tiny"; return MK_ERR_ARG; }
+    }
+    const FusedTier *tiers = TIERS + tierBase;
+    if (g_memo.entries != (const void *) V.entries || g_memo.nTargets != V.n_targets) { g_memo = SizingMemo(); g_memo.entries = V.entries; g_memo.nTargets = V.n_targets; }
+    double hitsPerPos = g_memo.hitsPerPos, candPerQuery = g_memo.candPerQuery, globalHitsPerPos = 0;
     SubMat ungMat;
     build_submat(ungMat, MAT_BLOSUM62, 2.0f, -0.2f);
-    unsigned long long *dTotals = (unsigned long long *) dev_scratch("pf_totals", 64);
-    unsigned long long *hTotals = (unsigned long long *) pinned_scratch("pf_totals_h", 64);
-    PNULL(dTotals); PNULL(hTotals);
+
+    Ctx X;
+    X.stream = stream; X.err = &err; X.tb = tb; X.te = te; X.ts = ts; X.seqBits = seqBits;
+    X.maxDbMatches = std::max<uint64_t>(1000000, dbSize) * 2;   // QueryMatcher.cpp:43
+    X.candCap = CAND_CAP;
+    X.dTotals = (unsigned long long *) dev_scratch("pf_totals", 64);
+    X.hTotals = (unsigned long long *) pinned_scratch("pf_totals_h", 64);
+    PNULL(X.dTotals); PNULL(X.hTotals);
+    CandArrays &C = X.C;
+    C.q = (uint32_t *) dev_scratch("pf_cq", (size_t) CAND_CAP * 4); C.id = (uint32_t *) dev_scratch("pf_cid", (size_t) CAND_CAP * 4);
+    C.ordinal = (uint32_t *) dev_scratch("pf_cord", (size_t) CAND_CAP * 4); C.diag = (uint16_t *) dev_scratch("pf_cdiag", (size_t) CAND_CAP * 2);
+    C.score = (int32_t *) dev_scratch("pf_cscore", (size_t) CAND_CAP * 4);
+    PNULL(C.q); PNULL(C.id); PNULL(C.ordinal); PNULL(C.diag); PNULL(C.score);
+    uint32_t *dCounters = (uint32_t *) dev_scratch("pf_fcounters", 64);
+    unsigned long long *dFTotals = (unsigned long long *) dev_scratch("pf_ftotals", 64);
+    uint32_t *hCounters = (uint32_t *) pinned_scratch("pf_fcounters_h", 64);
+    unsigned long long *hFTotals = (unsigned long long *) pinned_scratch("pf_ftotals_h", 64);
+    PNULL(dCounters); PNULL(dFTotals); PNULL(hCounters); PNULL(hFTotals);
+
     uint32_t q0 = 0;
+    uint32_t chunkLimit = QCAP;
     while (q0 < nq) {
-        uint32_t q1 = q0;
-        {
-            uint64_t posBudget = hitsPerPos > 0 ? std::min<uint64_t>(POS_CAP, (uint64_t) (0.8 * (double) HIT_CAP / hitsPerPos))
-                                                : std::min<uint64_t>(POS_CAP, 1u << 20);   // first chunk: small probe
-            while (q1 < nq && q1 - q0 < QCAP && (qOff[q1 + 1] - qOff[q0] <= posBudget || q1 == q0)) q1++;
-        }
-        uint64_t totalHits = 0, nPos = 0;
-        uint32_t *dHit = nullptr, *dKmer = nullptr;
-        int thCount = -1;
-        for (;;) {
-            nPos = qOff[q1] - qOff[q0];
-            if (nPos == 0) break;
-            dHit = (uint32_t *) dev_scratch("pf_hit", (nPos + 1) * 4);
-            dKmer = (uint32_t *) dev_scratch("pf_kmer", (nPos + 1) * 4);
-            uint32_t *dLast = (uint32_t *) dev_scratch("pf_last", 16);
-            PNULL(dHit); PNULL(dKmer); PNULL(dLast);
-            ProbeArgs A;
-            A.V = V; A.pos_begin = qOff[q0]; A.pos_end = qOff[q1]; A.q_first = q0; A.seq_bits = seqBits;
-            A.hit_count = dHit; A.kmer_count = dKmer; A.keys = nullptr; A.vals = nullptr;
-            const unsigned blocks = (unsigned) ((nPos + 3) / 4);
-            thCount = tb("kmer_probe_count", 0, 0);
-            hipLaunchKernelGGL(probe_kernel<false>, dim3(blocks), dim3(256), 0, stream, A);
-            te(thCount);
-            PCHK(hipGetLastError());
-            // totals: k-mers (reduce), hits (scan); the count of the last position is saved before the in-place scan
-            PCHK(hipMemcpyAsync(dLast, dHit + (nPos - 1), 4, hipMemcpyDeviceToDevice, stream));
-            size_t tempBytes = 0, tb2 = 0;
-            hipcub::DeviceReduce::Sum(nullptr, tempBytes, dKmer, dTotals + 2, (int) nPos, stream);
-            hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, dHit, dHit, (int) nPos, stream);
-            void *temp = dev_scratch("pf_temp", std::max(tempBytes, tb2));
-            PNULL(temp);
-            // kmer_count is u32 per position; the sum can exceed 2^32 -> accumulate in 64 bit via a transform iterator
-            {
-                hipcub::TransformInputIterator<unsigned long long, hipcub::CastOp<unsigned long long>, uint32_t *> it(dKmer, hipcub::CastOp<unsigned long long>());
-                size_t t3 = 0;
-                hipcub::DeviceReduce::Sum(nullptr, t3, it, dTotals + 2, (int) nPos, stream);
-                temp = dev_scratch("pf_temp", std::max(std::max(tempBytes, tb2), t3));
-                PNULL(temp);
-                PCHK(hipcub::DeviceReduce::Sum(temp, t3, it, dTotals + 2, (int) nPos, stream));
-            }
-            int th = tb("scan", 8.0 * nPos, 0);
-            PCHK(hipcub::DeviceScan::ExclusiveSum(temp, tb2, dHit, dHit, (int) nPos, stream));
-            te(th);
-            PCHK(hipMemsetAsync(dTotals, 0, 16, stream));
-            hipLaunchKernelGGL(chunk_totals_kernel, dim3((q1 - q0 + 255) / 256), dim3(256), 0, stream, V.q_off, q0, q1 - q0, qOff[q0], nPos,
-                               dHit, dLast, maxDbMatches, dTotals);
-            PCHK(hipGetLastError());
-            PCHK(hipMemcpyAsync(hTotals, dTotals, 24, hipMemcpyDeviceToHost, stream));
-            PCHK(sync_wait(stream, "wait_prefilter"));
-            totalHits = hTotals[0];
-            if (hTotals[1] != 0) { err = "query " + std::to_string(hTotals[1] - 1) + " overflows the reference's databaseHits buffer (QueryMatcher.cpp:281-316 is not restated)"; return MK_ERR_UNSUPPORTED; }
-            ts(thCount, 8.0 * (double) hTotals[2] + 2.0 * 2.0 * ROWCACHE * (double) nPos, (double) hTotals[2]);
-            hitsPerPos = std::max(1.0, (double) totalHits / (double) nPos);
-            if (totalHits > HIT_CAP && q1 - q0 > 1) { q1 = q0 + (q1 - q0) / 2; continue; }
-            break;
-        }
+        // ---- chunk size: bounded by the query field of the sort key and by the candidate buffers
+        uint32_t want = chunkLimit;
+        if (candPerQuery > 0) want = (uint32_t) std::min<double>(want, std::max(1.0, 0.6 * (double) CAND_CAP / candPerQuery));
+        else want = std::min<uint32_t>(want, 1u << 16);                    // nothing known yet: a small probe chunk
+        const uint32_t q1 = (uint32_t) std::min<uint64_t>(nq, (uint64_t) q0 + std::max<uint32_t>(want, 1));
         const uint32_t nqc = q1 - q0;
+        uint32_t nCand = 0;
+        std::vector<uint32_t> fallback;                                     // chunk-local ids for the global path
+        int rc = MK_OK;
+        if (useFused) {
+            // ---- A. fused kernels, one launch per LDS tier; the tier follows the expected number of index hits
+            std::vector<uint32_t> lists[N_TIERS];
+            size_t nListed = 0;
+            uint32_t *hList = nullptr, *dList = nullptr, *dOvf = nullptr;
+            {
+                ScopedHost sh("host_prefilter_tiers");
+                const double hpp = hitsPerPos > 0 ? hitsPerPos : 96.0;
+                for (uint32_t ql = 0; ql < nqc; ql++) {
+                    const uint64_t L = qOff[(size_t) q0 + ql + 1] - qOff[(size_t) q0 + ql];
+                    if (L < 10) continue;                                   // no k-mer: no hits
+                    const double est = hpp * (double) (L - 9) * 1.3;   // + half a 64-slot chunk lost per wave
+                    int t = 0;
+                    while (t < N_TIERS && est + 32.0 * tiers[t].waves > (double) tiers[t].cap) t++;
+                    if (t == N_TIERS) fallback.push_back(ql); else lists[t].push_back(q0 + ql);
+                }
+                for (int t = 0; t < N_TIERS; t++) nListed += lists[t].size();
+                hList = (uint32_t *) pinned_scratch("pf_flist_h", std::max<size_t>(nListed, 1) * 4);
+                dList = (uint32_t *) dev_scratch("pf_flist", std::max<size_t>(nListed, 1) * 4);
+                dOvf = (uint32_t *) dev_scratch("pf_fovf", (size_t) nqc * 4);
+                PNULL(hList); PNULL(dList); PNULL(dOvf);
+                size_t at = 0;
+                for (int t = 0; t < N_TIERS; t++) { if (!lists[t].empty()) std::memcpy(hList + at, lists[t].data(), lists[t].size() * 4); at += lists[t].size(); }
+            }
+            PCHK(hipMemcpyAsync(dList, hList, nListed * 4, hipMemcpyHostToDevice, stream));
+            PCHK(hipMemsetAsync(dCounters, 0, 16, stream));
+            PCHK(hipMemsetAsync(dFTotals, 0, 32, stream));
+            int thFused[N_TIERS];
+            size_t at = 0;
+            for (int t = 0; t < N_TIERS; t++) {
+                thFused[t] = -1;
+                if (lists[t].empty()) continue;
+                FusedArgs A;
+                A.V = V; A.queries = dList + at; A.n_launch = (uint32_t) lists[t].size(); A.q_first = q0;
+                A.C = C; A.cand_cap = CAND_CAP; A.counters = dCounters; A.overflow_list = dOvf; A.totals = dFTotals;
+                char nm[48];
+                snprintf(nm, sizeof(nm), "prefilter_fused_lds%d", tiers[t].cap);
+                thFused[t] = tb(nm, 0, 0);
+                launch_fused(tierBase + t, A, stream);
+                te(thFused[t]);
+                PCHK(hipGetLastError());
+                at += lists[t].size();
+            }
+            PCHK(hipMemcpyAsync(hCounters, dCounters, 16, hipMemcpyDeviceToHost, stream));
+            PCHK(hipMemcpyAsync(hFTotals, dFTotals, 32, hipMemcpyDeviceToHost, stream));
+            PCHK(sync_wait(stream, "wait_prefilter"));
+            const uint32_t nOvf = hCounters[1];
+            if (hCounters[0] > CAND_CAP) rc = RC_CAND_OVERFLOW;
+            else {
+                nCand = hCounters[0];
+                // algorithmic bytes of the fused launches: 8 B per k-mer (offset pair) + 8 B per index entry + the cached row heads,
+                // split over the tiers by their share of the queries (statistics only)
+                for (int t = 0; t < N_TIERS; t++)
+                    if (thFused[t] >= 0) {
+                        const double share = (double) lists[t].size() / (double) std::max<size_t>(nListed, 1);
+                        ts(thFused[t], share * (8.0 * (double) hFTotals[0] + 8.0 * (double) hFTotals[1] + 4.0 * ROWCACHE * (double) hFTotals[2]), share * (double) hFTotals[0]);
+                    }
+                if (hFTotals[2] > 0) hitsPerPos = std::max(1.0, (double) hFTotals[1] / (double) hFTotals[2]);
+                if (nOvf > 0) {
+                    uint32_t *hOvf = (uint32_t *) pinned_scratch("pf_fovf_h", (size_t) nOvf * 4);
+                    PNULL(hOvf);
+                    PCHK(hipMemcpyAsync(hOvf, dOvf, (size_t) nOvf * 4, hipMemcpyDeviceToHost, stream));
+                    PCHK(sync_wait(stream, "wait_prefilter"));
+                    fallback.insert(fallback.end(), hOvf, hOvf + nOvf);
+                    std::sort(fallback.begin(), fallback.end());
+                }
+            }
+        }
+        if (rc == MK_OK && !useFused) {
+            // ---- B. the whole chunk through the global path
+            rc = global_candidates(X, V, qOff.data(), q0, q1, nullptr, (uint32_t) 0 - q0, nCand, globalHitsPerPos);
+        } else if (rc == MK_OK && !fallback.empty()) {
+            // ---- B. the queries the fused kernels could not take, as a compact mini batch
+            const uint32_t nMini = (uint32_t) fallback.size();
+            uint64_t *hMiniOff = (uint64_t *) pinned_scratch("pf_minioff_h", ((size_t) nMini + 1) * 8);
+            uint32_t *hSrc = (uint32_t *) pinned_scratch("pf_minisrc_h", (size_t) nMini * 8);
+            PNULL(hMiniOff); PNULL(hSrc);
+            uint32_t *hMap = hSrc + nMini;
+            hMiniOff[0] = 0;
+            for (uint32_t i = 0; i < nMini; i++) {
+                const size_t qg = (size_t) q0 + fallback[i];
+                hSrc[i] = (uint32_t) qg; hMap[i] = fallback[i];
+                hMiniOff[i + 1] = hMiniOff[i] + (qOff[qg + 1] - qOff[qg]);
+            }
+            const uint64_t total = hMiniOff[nMini];
+            uint64_t *dMiniOff = (uint64_t *) dev_scratch("pf_minioff", ((size_t) nMini + 1) * 8);
+            uint32_t *dSrc = (uint32_t *) dev_scratch("pf_minisrc", (size_t) nMini * 8);
+            uint8_t *dMRes = (uint8_t *) dev_scratch("pf_minires", total + 16);
+            int16_t *dMThr = (int16_t *) dev_scratch("pf_minithr", (total + 16) * 2);
+            int8_t *dMCorr = (int8_t *) dev_scratch("pf_minicorr", total + 16);
+            PNULL(dMiniOff); PNULL(dSrc); PNULL(dMRes); PNULL(dMThr); PNULL(dMCorr);
+            PCHK(hipMemcpyAsync(dMiniOff, hMiniOff, ((size_t) nMini + 1) * 8, hipMemcpyHostToDevice, stream));
+            PCHK(hipMemcpyAsync(dSrc, hSrc, (size_t) nMini * 8, hipMemcpyHostToDevice, stream));
+            if (total > 0) {
+                hipLaunchKernelGGL(gather_queries_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, stream, V, dSrc, dMiniOff, nMini, total, dMRes, dMThr, dMCorr);
+                PCHK(hipGetLastError());
+            }
+            PrefilterDeviceView M = V;
+            M.q_res = dMRes; M.q_off = dMiniOff; M.q_kmer_thr = dMThr; M.q_corr = dMCorr; M.n_queries = nMini;
+            std::vector<uint64_t> miniOff(hMiniOff, hMiniOff + nMini + 1);     // the pinned copy may be overwritten by the next chunk
+            rc = global_candidates(X, M, miniOff.data(), 0, nMini, dSrc + nMini, 0, nCand, globalHitsPerPos);
+        }
+        if (rc == RC_CAND_OVERFLOW) {
+            if (nqc == 1) { err = "one query yields more double-diagonal candidates than the device buffers hold"; return MK_ERR_UNSUPPORTED; }
+            chunkLimit = std::max<uint32_t>(1, nqc / 2);
+            candPerQuery = std::max(candPerQuery, 1.0) * 2.0;
+            continue;                                                      // same q0, smaller chunk
+        }
+        if (rc != MK_OK) return rc;
+        chunkLimit = QCAP;
+        candPerQuery = std::max(1.0, (double) nCand / (double) nqc);
+
+        // ---- common back end
         std::vector<uint32_t> chunkCnt(nqc, 0);
         const mk_hit *devHits = nullptr;               // device-final hits of the chunk, staged (chunks with --max-seqs queries)
         size_t nDevHits = 0;
         bool devDirect = false;                        // ... or already on their way to the result block
         std::vector<std::vector<mk_hit>> hostHits;     // per flagged query
         std::vector<uint32_t> hostQ;
-        if (nPos > 0 && totalHits > 0) {
-            if (totalHits >= 0x7FFFFFFFull) { err = "a single query produces >= 2^31 index hits"; return MK_ERR_UNSUPPORTED; }
-            const uint32_t nHits = (uint32_t) totalHits;
-            uint64_t *dKeys = (uint64_t *) dev_scratch("pf_keys", (size_t) nHits * 8), *dKeys2 = (uint64_t *) dev_scratch("pf_keys2", (size_t) nHits * 8);
-            uint64_t *dVals = (uint64_t *) dev_scratch("pf_vals", (size_t) nHits * 8), *dVals2 = (uint64_t *) dev_scratch("pf_vals2", (size_t) nHits * 8);
-            PNULL(dKeys); PNULL(dKeys2); PNULL(dVals); PNULL(dVals2);
-            ProbeArgs A;
-            A.V = V; A.pos_begin = qOff[q0]; A.pos_end = qOff[q1]; A.q_first = q0; A.seq_bits = seqBits;
-            A.hit_count = dHit; A.kmer_count = dKmer; A.keys = dKeys; A.vals = dVals;
-            const unsigned blocks = (unsigned) ((nPos + 3) / 4);
-            // gather pass: offset pairs again + 8 B per index entry read + 16 B (key,value) written per entry
-            int th = tb("kmer_probe_gather", 8.0 * (double) hTotals[2] + 24.0 * (double) totalHits + 4.0 * ROWCACHE * (double) nPos, (double) hTotals[2]);
-            hipLaunchKernelGGL(probe_kernel<true>, dim3(blocks), dim3(256), 0, stream, A);
-            te(th);
-            PCHK(hipGetLastError());
-            // 4. stable sort by (query, target)
-            int qBits = 1; while ((1u << qBits) < nqc) qBits++;
-            hipcub::DoubleBuffer<uint64_t> kb(dKeys, dKeys2), vb(dVals, dVals2);
-            size_t tempBytes = 0;
-            hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, kb, vb, (int) nHits, 0, (int) seqBits + qBits, stream);
-            void *temp = dev_scratch("pf_temp", tempBytes);
-            PNULL(temp);
-            const int passes = ((int) seqBits + qBits + 7) / 8;
-            th = tb("sort_hits", 32.0 * passes * (double) nHits, 0);
-            PCHK(hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, kb, vb, (int) nHits, 0, (int) seqBits + qBits, stream));
-            te(th);
-            // 5. double-hit rule -> flags -> ordered compaction
-            uint8_t *dFlag = (uint8_t *) dev_scratch("pf_flag", nHits);
-            uint32_t *dSel = (uint32_t *) dev_scratch("pf_sel", (size_t) nHits * 4);
+        if (nCand > 0) {
+            uint8_t *dKept = (uint8_t *) dev_scratch("pf_kept", nCand), *dHostFlag = (uint8_t *) dev_scratch("pf_hostflag", nCand);
+            uint32_t *dPerQ = (uint32_t *) dev_scratch("pf_perq", (size_t) nqc * 4);
+            uint64_t *dOutKey = (uint64_t *) dev_scratch("pf_okey", (size_t) nCand * 8), *dOutKey2 = (uint64_t *) dev_scratch("pf_okey2", (size_t) nCand * 8);
+            uint32_t *dOutIdx = (uint32_t *) dev_scratch("pf_oidx", (size_t) nCand * 4), *dOutIdx2 = (uint32_t *) dev_scratch("pf_oidx2", (size_t) nCand * 4);
+            uint32_t *dFlagSel = (uint32_t *) dev_scratch("pf_flagsel", (size_t) nCand * 4);
             uint32_t *dNum = (uint32_t *) dev_scratch("pf_num", 64);
-            PNULL(dFlag); PNULL(dSel); PNULL(dNum);
-            th = tb("double_hit", 17.0 * nHits, 0);
-            hipLaunchKernelGGL(double_hit_flag_kernel, dim3((nHits + 255) / 256), dim3(256), 0, stream, kb.Current(), vb.Current(), nHits, dFlag);
+            uint32_t *hNum = (uint32_t *) pinned_scratch("pf_num_h", 64);
+            PNULL(dKept); PNULL(dHostFlag); PNULL(dPerQ); PNULL(dOutKey); PNULL(dOutKey2); PNULL(dOutIdx); PNULL(dOutIdx2); PNULL(dFlagSel); PNULL(dNum); PNULL(hNum);
+            int th = tb("diag_score", 28.0 * nCand, 0);
+            hipLaunchKernelGGL(diag_score_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, V, q0, nCand, C);
             te(th);
             PCHK(hipGetLastError());
-            {
-                hipcub::CountingInputIterator<uint32_t> iota(0);
-                size_t t2 = 0;
-                hipcub::DeviceSelect::Flagged(nullptr, t2, iota, dFlag, dSel, dNum, (int) nHits, stream);
-                temp = dev_scratch("pf_temp", t2);
-                PNULL(temp);
-                th = tb("select_candidates", 5.0 * nHits, 0);
-                PCHK(hipcub::DeviceSelect::Flagged(temp, t2, iota, dFlag, dSel, dNum, (int) nHits, stream));
-                te(th);
-            }
-            uint32_t *hNum = (uint32_t *) pinned_scratch("pf_num_h", 64);
-            PNULL(hNum);
-            PCHK(hipMemcpyAsync(hNum, dNum, 4, hipMemcpyDeviceToHost, stream));
+            PCHK(hipMemsetAsync(dPerQ, 0, (size_t) nqc * 4, stream));
+            th = tb("select_hits", 20.0 * nCand, 0);
+            hipLaunchKernelGGL(keep_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, C, nCand, P.min_ungapped_score, dKept, dPerQ);
+            hipLaunchKernelGGL(outkey_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, C, nCand, dKept, dPerQ, (uint32_t) maxHits, seqBits, dOutKey, dOutIdx, dHostFlag);
+            PCHK(hipGetLastError());
+            hipcub::DoubleBuffer<uint64_t> ob(dOutKey, dOutKey2);
+            hipcub::DoubleBuffer<uint32_t> ib(dOutIdx, dOutIdx2);
+            size_t t2 = 0;
+            hipcub::DeviceRadixSort::SortPairs(nullptr, t2, ob, ib, (int) nCand, 0, 64, stream);
+            void *temp = dev_scratch("pf_temp", t2);
+            PNULL(temp);
+            PCHK(hipcub::DeviceRadixSort::SortPairs(temp, t2, ob, ib, (int) nCand, 0, 64, stream));
+            hipLaunchKernelGGL(first_invalid_kernel, dim3(1), dim3(1), 0, stream, ob.Current(), nCand, dNum + 1);
+            // candidates of flagged queries, per query contiguous and in (target, arrival) order, for the host
+            hipcub::CountingInputIterator<uint32_t> iota(0);
+            size_t t3 = 0;
+            hipcub::DeviceSelect::Flagged(nullptr, t3, iota, dHostFlag, dFlagSel, dNum + 2, (int) nCand, stream);
+            void *temp2 = dev_scratch("pf_temp2", t3);
+            PNULL(temp2);
+            PCHK(hipcub::DeviceSelect::Flagged(temp2, t3, iota, dHostFlag, dFlagSel, dNum + 2, (int) nCand, stream));
+            te(th);
+            PCHK(hipMemcpyAsync(hNum, dNum, 12, hipMemcpyDeviceToHost, stream));
+            uint32_t *hPerQ = (uint32_t *) pinned_scratch("pf_perq_h", (size_t) nqc * 4);
+            PNULL(hPerQ);
+            PCHK(hipMemcpyAsync(hPerQ, dPerQ, (size_t) nqc * 4, hipMemcpyDeviceToHost, stream));
             PCHK(sync_wait(stream, "wait_prefilter"));
-            const uint32_t nCand = hNum[0];
-            if (nCand > 0) {
-                CandArrays C;
-                C.q = (uint32_t *) dev_scratch("pf_cq", (size_t) nCand * 4); C.id = (uint32_t *) dev_scratch("pf_cid", (size_t) nCand * 4);
-                C.ordinal = (uint32_t *) dev_scratch("pf_cord", (size_t) nCand * 4); C.diag = (uint16_t *) dev_scratch("pf_cdiag", (size_t) nCand * 2);
-                C.score = (int32_t *) dev_scratch("pf_cscore", (size_t) nCand * 4);
-                uint8_t *dKept = (uint8_t *) dev_scratch("pf_kept", nCand), *dHostFlag = (uint8_t *) dev_scratch("pf_hostflag", nCand);
-                uint32_t *dPerQ = (uint32_t *) dev_scratch("pf_perq", (size_t) nqc * 4);
-                uint64_t *dOutKey = (uint64_t *) dev_scratch("pf_okey", (size_t) nCand * 8), *dOutKey2 = (uint64_t *) dev_scratch("pf_okey2", (size_t) nCand * 8);
-                uint32_t *dOutIdx = (uint32_t *) dev_scratch("pf_oidx", (size_t) nCand * 4), *dOutIdx2 = (uint32_t *) dev_scratch("pf_oidx2", (size_t) nCand * 4);
-                PNULL(C.q); PNULL(C.id); PNULL(C.ordinal); PNULL(C.diag); PNULL(C.score); PNULL(dKept); PNULL(dHostFlag); PNULL(dPerQ);
-                PNULL(dOutKey); PNULL(dOutKey2); PNULL(dOutIdx); PNULL(dOutIdx2);
-                th = tb("diag_score", 28.0 * nCand, 0);
-                hipLaunchKernelGGL(cand_score_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, V, q0, seqBits, kb.Current(), vb.Current(), dSel, nCand, C);
-                te(th);
+            const uint32_t nValid = hNum[1], nFlagged = hNum[2];
+            mk_hit *dHitsOut = nullptr;
+            if (nValid > 0) {
+                dHitsOut = (mk_hit *) dev_scratch("pf_hits_out", (size_t) nValid * sizeof(mk_hit));
+                PNULL(dHitsOut);
+                hipLaunchKernelGGL(emit_kernel, dim3((nValid + 255) / 256), dim3(256), 0, stream, C, ib.Current(), nValid, dHitsOut);
                 PCHK(hipGetLastError());
-                PCHK(hipMemsetAsync(dPerQ, 0, (size_t) nqc * 4, stream));
-                th = tb("select_hits", 20.0 * nCand, 0);
-                hipLaunchKernelGGL(keep_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, C, nCand, P.min_ungapped_score, dKept, dPerQ);
-                hipLaunchKernelGGL(outkey_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, C, nCand, dKept, dPerQ, (uint32_t) maxHits, seqBits, dOutKey, dOutIdx, dHostFlag);
-                PCHK(hipGetLastError());
-                hipcub::DoubleBuffer<uint64_t> ob(dOutKey, dOutKey2);
-                hipcub::DoubleBuffer<uint32_t> ib(dOutIdx, dOutIdx2);
-                size_t t2 = 0;
-                hipcub::DeviceRadixSort::SortPairs(nullptr, t2, ob, ib, (int) nCand, 0, 64, stream);
-                temp = dev_scratch("pf_temp", t2);
-                PNULL(temp);
-                PCHK(hipcub::DeviceRadixSort::SortPairs(temp, t2, ob, ib, (int) nCand, 0, 64, stream));
-                hipLaunchKernelGGL(first_invalid_kernel, dim3(1), dim3(1), 0, stream, ob.Current(), nCand, dNum + 1);
-                // candidates of flagged queries, in (query,target,arrival) order, for the host
-                hipcub::CountingInputIterator<uint32_t> iota(0);
-                size_t t3 = 0;
-                uint32_t *dFlagSel = dSel;            // the first selection is consumed; reuse its buffer
-                hipcub::DeviceSelect::Flagged(nullptr, t3, iota, dHostFlag, dFlagSel, dNum + 2, (int) nCand, stream);
-                void *temp2 = dev_scratch("pf_temp2", t3);
-                PNULL(temp2);
-                PCHK(hipcub::DeviceSelect::Flagged(temp2, t3, iota, dHostFlag, dFlagSel, dNum + 2, (int) nCand, stream));
-                te(th);
-                PCHK(hipMemcpyAsync(hNum, dNum, 12, hipMemcpyDeviceToHost, stream));
-                uint32_t *hPerQ = (uint32_t *) pinned_scratch("pf_perq_h", (size_t) nqc * 4);
-                PNULL(hPerQ);
-                PCHK(hipMemcpyAsync(hPerQ, dPerQ, (size_t) nqc * 4, hipMemcpyDeviceToHost, stream));
-                PCHK(sync_wait(stream, "wait_prefilter"));
-                const uint32_t nValid = hNum[1], nFlagged = hNum[2];
-                mk_hit *dHitsOut = nullptr;
+            }
+            if (nFlagged == 0) {
+                // every query of the chunk is final on the device: DMA the compact hit array to its final place
                 if (nValid > 0) {
-                    dHitsOut = (mk_hit *) dev_scratch("pf_hits_out", (size_t) nValid * sizeof(mk_hit));
-                    PNULL(dHitsOut);
-                    hipLaunchKernelGGL(emit_kernel, dim3((nValid + 255) / 256), dim3(256), 0, stream, C, ib.Current(), nValid, dHitsOut);
-                    PCHK(hipGetLastError());
+                    if (!reserve_out(nValid, q1)) { err = "pinned host allocation for the prefilter result failed"; return MK_ERR_DEVICE; }
+                    PCHK(hipMemcpyAsync((mk_hit *) outBlk.p + nOut, dHitsOut, (size_t) nValid * sizeof(mk_hit), hipMemcpyDeviceToHost, stream));
                 }
-                if (nFlagged == 0) {
-                    // every query of the chunk is final on the device: DMA the compact hit array to its final place
-                    if (nValid > 0) {
-                        if (!reserve_out(nValid, q1)) { err = "pinned host allocation for the prefilter result failed"; return MK_ERR_DEVICE; }
-                        PCHK(hipMemcpyAsync((mk_hit *) outBlk.p + nOut, dHitsOut, (size_t) nValid * sizeof(mk_hit), hipMemcpyDeviceToHost, stream));
-                    }
-                    for (uint32_t ql = 0; ql < nqc; ql++) chunkCnt[ql] = hPerQ[ql];
-                    devDirect = true;
-                    nDevHits = nValid;
-                } else {
-                    if (nValid > 0) {
-                        mk_hit *hHitsOut = (mk_hit *) pinned_scratch("pf_hits_out_h", (size_t) nValid * sizeof(mk_hit));
-                        PNULL(hHitsOut);
-                        PCHK(hipMemcpyAsync(hHitsOut, dHitsOut, (size_t) nValid * sizeof(mk_hit), hipMemcpyDeviceToHost, stream));
-                        devHits = hHitsOut; nDevHits = nValid;
-                    }
-                    for (uint32_t ql = 0; ql < nqc; ql++) chunkCnt[ql] = hPerQ[ql] >= (uint32_t) maxHits ? 0 : hPerQ[ql];
-                    // exact reference logic for the queries that reached --max-seqs (tie order depends on BINSIZE)
-                    HostCand *dHC = (HostCand *) dev_scratch("pf_hostcand", (size_t) nFlagged * sizeof(HostCand));
-                    HostCand *hHC = (HostCand *) pinned_scratch("pf_hostcand_h", (size_t) nFlagged * sizeof(HostCand));
-                    PNULL(dHC); PNULL(hHC);
-                    hipLaunchKernelGGL(export_flagged_kernel, dim3((nFlagged + 255) / 256), dim3(256), 0, stream, C, dFlagSel, nFlagged, dHC);
-                    PCHK(hipGetLastError());
-                    PCHK(hipMemcpyAsync(hHC, dHC, (size_t) nFlagged * sizeof(HostCand), hipMemcpyDeviceToHost, stream));
-                    PCHK(sync_wait(stream, "wait_prefilter"));
-                    ScopedHost sh("host_prefilter_maxseqs");
-                    std::vector<uint32_t> runStart;                    // candidate runs, one per flagged query (ascending query)
-                    for (uint32_t k = 0; k < nFlagged; k++) if (k == 0 || hHC[k].q != hHC[k - 1].q) runStart.push_back(k);
-                    runStart.push_back(nFlagged);
-                    const size_t nRuns = runStart.size() - 1;
-                    hostQ.resize(nRuns);
-                    hostHits.resize(nRuns);
-                    int failed = 0;
+                for (uint32_t ql = 0; ql < nqc; ql++) chunkCnt[ql] = hPerQ[ql];
+                devDirect = true;
+                nDevHits = nValid;
+            } else {
+                if (nValid > 0) {
+                    mk_hit *hHitsOut = (mk_hit *) pinned_scratch("pf_hits_out_h", (size_t) nValid * sizeof(mk_hit));
+                    PNULL(hHitsOut);
+                    PCHK(hipMemcpyAsync(hHitsOut, dHitsOut, (size_t) nValid * sizeof(mk_hit), hipMemcpyDeviceToHost, stream));
+                    devHits = hHitsOut; nDevHits = nValid;
+                }
+                for (uint32_t ql = 0; ql < nqc; ql++) chunkCnt[ql] = hPerQ[ql] >= (uint32_t) maxHits ? 0 : hPerQ[ql];
+                // exact reference logic for the queries that reached --max-seqs (tie order depends on BINSIZE)
+                HostCand *dHC = (HostCand *) dev_scratch("pf_hostcand", (size_t) nFlagged * sizeof(HostCand));
+                HostCand *hHC = (HostCand *) pinned_scratch("pf_hostcand_h", (size_t) nFlagged * sizeof(HostCand));
+                PNULL(dHC); PNULL(hHC);
+                hipLaunchKernelGGL(export_flagged_kernel, dim3((nFlagged + 255) / 256), dim3(256), 0, stream, C, dFlagSel, nFlagged, dHC);
+                PCHK(hipGetLastError());
+                PCHK(hipMemcpyAsync(hHC, dHC, (size_t) nFlagged * sizeof(HostCand), hipMemcpyDeviceToHost, stream));
+                PCHK(sync_wait(stream, "wait_prefilter"));
+                ScopedHost sh("host_prefilter_maxseqs");
+                std::vector<uint32_t> runStart;                    // candidate runs, one per flagged query
+                for (uint32_t k = 0; k < nFlagged; k++) if (k == 0 || hHC[k].q != hHC[k - 1].q) runStart.push_back(k);
+                runStart.push_back(nFlagged);
+                const size_t nRuns = runStart.size() - 1;
+                std::vector<uint32_t> runOrder(nRuns);             // the merge below walks the queries in ascending order
+                std::iota(runOrder.begin(), runOrder.end(), 0u);
+                std::sort(runOrder.begin(), runOrder.end(), [&](uint32_t x, uint32_t y) { return hHC[runStart[x]].q < hHC[runStart[y]].q; });
+                hostQ.resize(nRuns);
+                hostHits.resize(nRuns);
+                int failed = 0;
 #pragma omp parallel
-                    {
-                        std::vector<Cand> perQuery;
+                {
+                    std::vector<Cand> perQuery;
 #pragma omp for schedule(dynamic, 4)
-                        for (size_t r = 0; r < nRuns; r++) {
-                            const uint32_t k0 = runStart[r], k1 = runStart[r + 1];
-                            const uint32_t ql = hHC[k0].q;
-                            perQuery.clear();
-                            for (uint32_t k = k0; k < k1; k++) perQuery.push_back(Cand{hHC[k].id, hHC[k].diag, hHC[k].score, hHC[k].ordinal});
-                            std::sort(perQuery.begin(), perQuery.end(), [](const Cand &a, const Cand &b) { return a.ordinal < b.ordinal; });
-                            const uint32_t q = q0 + ql;
-                            int n255 = 0;
-                            for (const Cand &c : perQuery) n255 += c.score >= 255;
-                            int self = 0;
-                            if (n255 >= maxHits) {                     // threshold saturates: QueryMatcher.cpp:525-531 needs the exact self score
-                                const int L = (int) (qOff[q + 1] - qOff[q]);
-                                std::vector<int8_t> corr((size_t) L);
-                                if (qCorrHost) std::memcpy(corr.data(), qCorrHost + qOff[q], (size_t) L);
-                                else {
+                    for (size_t r = 0; r < nRuns; r++) {
+                        const uint32_t k0 = runStart[runOrder[r]], k1 = runStart[runOrder[r] + 1];
+                        const uint32_t ql = hHC[k0].q;
+                        perQuery.clear();
+                        for (uint32_t k = k0; k < k1; k++) perQuery.push_back(Cand{hHC[k].id, hHC[k].diag, hHC[k].score, hHC[k].ordinal});
+                        std::sort(perQuery.begin(), perQuery.end(), [](const Cand &a, const Cand &b) { return a.ordinal < b.ordinal; });
+                        const uint32_t q = q0 + ql;
+                        int n255 = 0;
+                        for (const Cand &c : perQuery) n255 += c.score >= 255;
+                        int self = 0;
+                        if (n255 >= maxHits) {                     // threshold saturates: QueryMatcher.cpp:525-531 needs the exact self score
+                            const int L = (int) (qOff[q + 1] - qOff[q]);
+                            std::vector<int8_t> corr((size_t) L);
+                            if (qCorrHost) std::memcpy(corr.data(), qCorrHost + qOff[q], (size_t) L);
+                            else {
 #pragma omp critical(mk_pf_corr)
-                                    if (hipMemcpy(corr.data(), V.q_corr + qOff[q], (size_t) L, hipMemcpyDeviceToHost) != hipSuccess) failed = 1;
-                                }
-                                self = self_score(ungMat, qRes.data() + qOff[q], corr.data(), L);
+                                if (hipMemcpy(corr.data(), V.q_corr + qOff[q], (size_t) L, hipMemcpyDeviceToHost) != hipSuccess) failed = 1;
                             }
-                            std::vector<mk_hit> hh((size_t) maxHits);
-                            const int cnt = select_hits(perQuery, binCount, maxHits, P.min_ungapped_score, self, hh.data());
-                            hh.resize((size_t) cnt);
-                            hostQ[r] = ql;
-                            hostHits[r] = std::move(hh);
+                            self = self_score(ungMat, qRes.data() + qOff[q], corr.data(), L);
                         }
+                        std::vector<mk_hit> hh((size_t) maxHits);
+                        const int cnt = select_hits(perQuery, binCount, maxHits, P.min_ungapped_score, self, hh.data());
+                        hh.resize((size_t) cnt);
+                        hostQ[r] = ql;
+                        hostHits[r] = std::move(hh);
                     }
-                    if (failed) { err = "hipMemcpy of the diagonal correction failed"; return MK_ERR_DEVICE; }
                 }
+                if (failed) { err = "hipMemcpy of the diagonal correction failed"; return MK_ERR_DEVICE; }
             }
         }
         // append the chunk: device-final hits are compact in query order; flagged queries come from the host lists
@@ -624,6 +1102,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
         }
         q0 = q1;
     }
+    g_memo.hitsPerPos = hitsPerPos; g_memo.candPerQuery = candPerQuery;
     (void) tOff;
     PCHK(sync_wait(stream, "wait_prefilter"));         // the last DMA into the result block
     return MK_OK;

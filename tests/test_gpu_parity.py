@@ -113,7 +113,16 @@ def test_ungapped(gpu_api, small_workload):
         assert int(got[k]) == exp, (k, int(qi[k]), int(ti[k]), int(diag[k]), int(got[k]), exp)
 
 
-def test_pipeline_vs_oracle(gpu_api, small_workload, tmp_path):
+@pytest.fixture(params=["fused", "fused-tiny", "global"])
+def pf_path(request, monkeypatch):
+    """front end of the prefilter: per-query LDS kernels (production tiers / miniature tiers that force the overflow
+    hand-over on small inputs) or the global sort path; the library reads the variables on every call"""
+    monkeypatch.setenv("MK_PREFILTER_PATH", "global" if request.param == "global" else "fused")
+    monkeypatch.setenv("MK_PREFILTER_TIERS", "tiny" if request.param == "fused-tiny" else "default")
+    return request.param
+
+
+def test_pipeline_vs_oracle(gpu_api, small_workload, tmp_path, pf_path):
     targets, queries = small_workload
     api = gpu_api
     params = api.default_params()
@@ -150,7 +159,7 @@ def _blocks(name):
 
 
 @pytest.mark.parametrize("tag", ["small", "edge"])
-def test_pipeline_vs_golden(gpu_api, tag):
+def test_pipeline_vs_golden(gpu_api, tag, pf_path):
     api = gpu_api
     targets, queries = _lines(tag + "_targets.txt.gz"), _lines(tag + "_queries.txt.gz")
     params = api.default_params()
@@ -184,7 +193,7 @@ def test_sw_vs_golden(gpu_api):
         assert int(got[k][0]) == oracle.sw(q[k], t[k])[0]
 
 
-def test_max_seqs_truncation_order(gpu_api, small_workload, tmp_path):
+def test_max_seqs_truncation_order(gpu_api, small_workload, tmp_path, pf_path):
     """--max-seqs smaller than the number of qualifying targets: the cut follows the reference's bin order"""
     targets, queries = small_workload
     api = gpu_api
