@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", f) for f in ("mk_host.cpp", "mk_abi.cpp", "mk_sw.hip", "mk_align.hip", "mk_prefilter.hip", "mk_derive.hip", "mk_cli.cpp")]
-HDR = [os.path.join(HERE, "csrc", f) for f in ("mk_host.hpp", "mk_kernels.hpp", "mk_prefilter.hpp", "mk_align.hpp", "mk_dbio.hpp")] + [
+HDR = [os.path.join(HERE, "csrc", f) for f in ("mk_host.hpp", "mk_kernels.hpp", "mk_prefilter.hpp", "mk_align.hpp", "mk_dbio.hpp", "mk_enum.hpp")] + [
     os.path.join(HERE, "..", "include", "metaeuk_amd.h"), os.path.join(HERE, "data", "matrices.inc")]
 LIB = os.path.join(HERE, "lib", "libmetaeuk_amd.so")
 BIN = os.path.join(HERE, "lib", "metaeuk-amd")

@@ -135,9 +135,11 @@ struct mk_targetdb {
     DevBuf<uint8_t> dRes, dMasked;
     DevBuf<uint64_t> dOff;
     DevBuf<uint32_t> dKmerOff;       // 20^6 + 1 (entries < 2^32)
+    DevBuf<uint32_t> dKmerBits;      // 20^6 bits: list non-empty
     DevBuf<uint64_t> dEntries;       // seqId | pos << 32
     DevBuf<int16_t> dScore3;
-    DevBuf<uint16_t> dIndex3;
+    DevBuf<uint16_t> dIndex3, dHist3, dCum3;
+    int histLo = 0, histRange = 0;
     DevBuf<int8_t> dMatAln, dMatUng;
 };
 
@@ -296,9 +298,21 @@ int mk_targetdb_create(const uint8_t *residues, const uint64_t *offsets, uint32_
     ok(db->dMasked.upload(ix.masked.data(), ix.masked.size()));
     ok(db->dOff.upload(offsets, n + 1));
     ok(db->dKmerOff.upload(off32.data(), off32.size()));
+    std::vector<uint32_t> bits((off32.size() - 1 + 31) / 32, 0u);
+#pragma omp parallel for schedule(static)
+    for (size_t wd = 0; wd < bits.size(); wd++) {
+        uint32_t m = 0;
+        const size_t k0 = wd * 32, k1 = std::min(k0 + 32, off32.size() - 1);
+        for (size_t k = k0; k < k1; k++) if (off32[k + 1] != off32[k]) m |= 1u << (k - k0);
+        bits[wd] = m;
+    }
+    ok(db->dKmerBits.upload(bits.data(), bits.size()));
     ok(db->dEntries.upload(ix.entries.data(), ix.entries.size()));
     ok(db->dScore3.upload(sm.score.data(), sm.score.size()));
     ok(db->dIndex3.upload(sm.index.data(), sm.index.size()));
+    ok(db->dHist3.upload(sm.hist.data(), sm.hist.size()));
+    ok(db->dCum3.upload(sm.cum.data(), sm.cum.size()));
+    db->histLo = sm.histLo; db->histRange = sm.histRange;
     ok(db->dMatAln.upload(matAln, 441));
     ok(db->dMatUng.upload(matUng, 441));
     ok(hipStreamSynchronize(g_stream));
@@ -449,7 +463,8 @@ int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     mk::PrefilterDeviceView V;
     V.q_res = q->dRes.p; V.q_off = q->dOff.p; V.q_kmer_thr = q->dKmerThr.p; V.q_corr = q->dCorr.p; V.n_queries = q->n;
     V.t_masked = db->dMasked.p; V.t_off = db->dOff.p; V.n_targets = db->n;
-    V.kmer_off = db->dKmerOff.p; V.entries = db->dEntries.p; V.score3 = db->dScore3.p; V.index3 = db->dIndex3.p;
+    V.kmer_off = db->dKmerOff.p; V.kmer_bits = db->dKmerBits.p; V.entries = db->dEntries.p; V.score3 = db->dScore3.p; V.index3 = db->dIndex3.p;
+    V.hist3 = db->dHist3.p; V.cum3 = db->dCum3.p; V.hist_lo = db->histLo; V.hist_range = db->histRange; V.n_entries = db->nEntries;
     V.mat_ung = db->dMatUng.p;
     std::string err;
     const int binCount = mk::bin_count_for(db->n, P->host_l2_bytes);

@@ -1,0 +1,135 @@
+// metaeuk_amd/csrc/mk_enum.hpp -- wave-level enumeration of the similar k-mers of one k-mer start (device code).
+// Reference: KmerGenerator::generateKmerList / calculateArrayProduct (M/src/prefiltering/KmerGenerator.cpp:107-216).
+// The reference multiplies two score-sorted 3-mer rows: for the first-half candidates a = 0,1,.. (descending score s0[a])
+// it takes the second-half candidates b = 0 .. nb(a)-1 with s0[a] + s1[b] >= threshold, and stops at the first a whose
+// best partner fails.  The k-mers come out in "product order" (a major, b minor); that order is what the
+// double-diagonal rule later sees, so it is kept exactly:  lane j of a batch holds product number base + j.
+//
+// What is different from a transcription: nothing is searched, and the dependent-load chain of a position is short.
+//   * nb(a) comes from per-row cumulative score histograms (cum3): one table lookup;
+//   * 256 first-half candidates are taken per step (4 per lane), which covers nearly every position in one step;
+//   * the product -> (a, b) map of a 64-product window is a counting trick: owner(x) = #{a : E_a <= x} for the inclusive
+//     prefix E of nb, i.e. a histogram of E over the window (LDS atomics) + a wave prefix sum in DPP;
+//   * prefix sums run in DPP (row_shr / row_bcast), not through the LDS crossbar.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "mk_prefilter.hpp"
+
+namespace mk {
+namespace enumk {
+
+constexpr int WAVE = 64;
+constexpr int N3 = 8000;
+
+// inclusive prefix sum over the 64 lanes of a wave (GFX9 DPP: row_shr within the 16-lane rows, then row broadcasts)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    int x = (int) v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1,3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2,3
+    return (uint32_t) x;
+}
+__device__ __forceinline__ uint32_t wave_last(uint32_t v) { return (uint32_t) __builtin_amdgcn_readlane((int) v, 63); }
+
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+constexpr int AJ = 4;                    // first-half candidates per lane and step
+constexpr int ABLOCK = AJ * WAVE;        // ... per step (one step covers almost every position: the dependent-load chain
+                                         // of a position is rows -> cumulative counts -> second-half indices -> index probes)
+
+// per-wave LDS scratch of the enumerator
+template <int U>
+struct EnumLds {
+    uint32_t start[ABLOCK];      // exclusive prefix of nb over the first-half candidates of the current step
+    uint16_t idx0[ABLOCK];       // their 3-mer indices
+    uint32_t cnt[U * WAVE];      // histogram of the inclusive prefixes over the current product window
+};
+
+// Calls onBatch(kmer[U], has[U]) for consecutive windows of U*64 products of the k-mer start whose residues are r[0..9]
+// (spaced seed 1101010011), in product order; onBatch returns false to stop early.  Returns the number of similar k-mers.
+template <int U, class F>
+__device__ __forceinline__ uint32_t enumerate_position(const PrefilterDeviceView &V, const uint8_t *r, int thr, int lane, EnumLds<U> &S, F &&onBatch) {
+    const uint32_t idx0 = r[0] + 20u * r[1] + 400u * r[3];
+    const uint32_t idx1 = r[5] + 20u * r[8] + 400u * r[9];
+    const int16_t *s0 = V.score3 + (size_t) idx0 * N3;
+    const uint16_t *i0 = V.index3 + (size_t) idx0 * N3;
+    const uint16_t *i1 = V.index3 + (size_t) idx1 * N3;
+    const int R = V.hist_range, lo = V.hist_lo;
+    const uint16_t *cum1 = V.cum3 + (size_t) idx1 * R;
+    const int cutoff1 = thr - (int) V.score3[(size_t) idx1 * N3];   // first halves below this cannot reach the threshold
+    uint32_t kmers = 0;
+    for (uint32_t a0 = 0; a0 < (uint32_t) N3; a0 += ABLOCK) {
+        // candidate a = a0 + j*64 + lane: (j, lane) ascending = a ascending
+        uint32_t nb[AJ], incl[AJ], ia[AJ];
+        int sa[AJ];
+#pragma unroll
+        for (int j = 0; j < AJ; j++) {
+            const uint32_t a = a0 + (uint32_t) (j * WAVE + lane);
+            sa[j] = a < (uint32_t) N3 ? (int) s0[a] : -32768;
+            ia[j] = a < (uint32_t) N3 ? (uint32_t) i0[a] : 0u;
+        }
+        uint32_t total = 0;
+#pragma unroll
+        for (int j = 0; j < AJ; j++) {
+            nb[j] = 0;
+            if (sa[j] >= cutoff1) {
+                const int xb = thr - sa[j] - lo;
+                nb[j] = xb <= 0 ? (uint32_t) N3 : (xb >= R ? 0u : (uint32_t) cum1[xb]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < AJ; j++) {
+            const uint32_t sc = wave_incl_scan(nb[j]);
+            incl[j] = total + sc;
+            total += wave_last(sc);
+            S.start[j * WAVE + lane] = incl[j] - nb[j];
+            S.idx0[j * WAVE + lane] = (uint16_t) ia[j];
+        }
+        const bool more = __builtin_amdgcn_readlane(sa[AJ - 1], WAVE - 1) >= cutoff1;   // the step's last candidate is still valid
+        kmers += total;
+        for (uint32_t base = 0; base < total; base += U * WAVE) {
+            // owner(x) = #{a : incl_a <= x}: histogram of incl over the window, prefix-summed
+#pragma unroll
+            for (int u = 0; u < U; u++) S.cnt[u * WAVE + lane] = 0;
+            wave_sync_lds();
+            uint32_t carry = 0;
+#pragma unroll
+            for (int j = 0; j < AJ; j++) {
+                const uint32_t rel = incl[j] - base;               // wraps for incl < base: not in the window
+                if (incl[j] >= base && rel < (uint32_t) (U * WAVE)) atomicAdd(&S.cnt[rel], 1u);
+                carry += (uint32_t) __popcll(__ballot(incl[j] < base));
+            }
+            wave_sync_lds();
+            uint32_t kmer[U];
+            bool has[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t x = base + (uint32_t) (u * WAVE + lane);
+                const uint32_t sc = wave_incl_scan(S.cnt[u * WAVE + lane]);
+                const uint32_t owner = carry + sc;
+                carry += wave_last(sc);
+                has[u] = x < total;
+                kmer[u] = 0;
+                if (has[u]) {
+                    const uint32_t b = x - S.start[owner];
+                    kmer[u] = (uint32_t) S.idx0[owner] + (uint32_t) N3 * (uint32_t) i1[b];
+                }
+            }
+            if (!onBatch(kmer, has)) return kmers;
+            wave_sync_lds();
+        }
+        wave_sync_lds();
+        if (!more) break;
+    }
+    return kmers;
+}
+
+}  // namespace enumk
+}  // namespace mk

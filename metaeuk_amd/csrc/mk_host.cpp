@@ -135,6 +135,19 @@ void build_scoremat3(const SubMat &km, ScoreMat3 &out) {
             }
         }
     }
+    // score histograms of every row (rows are sorted descending: first/last entry = max/min)
+    int lo = INT_MAX, hi = INT_MIN;
+    for (int r = 0; r < N; r++) { hi = std::max<int>(hi, out.score[static_cast<size_t>(r) * N]); lo = std::min<int>(lo, out.score[static_cast<size_t>(r) * N + N - 1]); }
+    out.histLo = lo; out.histRange = hi - lo + 1;
+    out.hist.assign(static_cast<size_t>(N) * out.histRange, 0);
+    out.cum.assign(static_cast<size_t>(N) * out.histRange, 0);
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < N; r++) {
+        uint16_t *h = out.hist.data() + static_cast<size_t>(r) * out.histRange, *c = out.cum.data() + static_cast<size_t>(r) * out.histRange;
+        for (int f = 0; f < N; f++) h[out.score[static_cast<size_t>(r) * N + f] - lo]++;
+        unsigned acc = 0;
+        for (int k = out.histRange - 1; k >= 0; k--) { acc += h[k]; c[k] = static_cast<uint16_t>(acc); }
+    }
 }
 
 // tantan::maskSequences as driven by Masker::maskSequence (M/src/commons/Masker.cpp:15-32,

@@ -37,6 +37,10 @@ int bin_count_for(uint64_t dbSize, uint64_t l2Bytes);
 struct ScoreMat3 {
     std::vector<int16_t> score;   // [8000][8000]
     std::vector<uint16_t> index;  // [8000][8000]
+    // per row: how many of the 8000 3-mers score exactly s / at least s, s = histLo .. histLo + histRange - 1.
+    // With these the number of similar k-mers of a position is a ~100-term sum (no enumeration): sizing only.
+    int histLo = 0, histRange = 0;
+    std::vector<uint16_t> hist, cum;   // [8000][histRange]
 };
 void build_scoremat3(const SubMat &kmerMat, ScoreMat3 &out);
 

@@ -30,6 +30,7 @@
 #include "mk_prefilter.hpp"
 #include "mk_host.hpp"
 #include "mk_kernels.hpp"
+#include "mk_enum.hpp"
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <cstdlib>
@@ -41,7 +42,6 @@ namespace mk {
 namespace {
 
 constexpr int WAVE = 64;
-constexpr int ROWCACHE = 512;     // leading entries of the second 3-mer row staged in LDS per wave
 constexpr int N3 = 8000;
 
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
@@ -101,12 +101,16 @@ struct ProbeArgs {
     uint64_t *keys; uint64_t *vals;   // GATHER outputs
 };
 
+// index offset pair of a k-mer (adjacent 32-bit entries; one 8-byte load)
+struct __attribute__((packed, aligned(4))) OffPair { uint32_t lo, hi; };
+__device__ __forceinline__ OffPair load_off_pair(const uint32_t *kmerOff, uint32_t kmer) { return *reinterpret_cast<const OffPair *>(kmerOff + kmer); }
+__device__ __forceinline__ bool kmer_present(const uint32_t *bits, uint32_t kmer) { return (bits[kmer >> 5] >> (kmer & 31u)) & 1u; }
+
+constexpr int PROBE_U = 4;        // 64-k-mer groups whose index probes are issued together
+
 template <bool GATHER>
 __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
-    __shared__ int16_t sRow1[4][ROWCACHE];
-    __shared__ uint16_t sIdx1[4][ROWCACHE];
-    __shared__ uint32_t sPref[4][WAVE + 1];
-    __shared__ uint16_t sIdx0[4][WAVE];
+    __shared__ enumk::EnumLds<PROBE_U> sE[4];
     const int w = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
     const uint64_t p = A.pos_begin + (uint64_t) blockIdx.x * 4 + w;
     if (p >= A.pos_end) return;
@@ -116,17 +120,6 @@ __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
         if (!GATHER && lane == 0) { A.hit_count[rel] = 0; A.kmer_count[rel] = 0; }
         return;
     }
-    const uint8_t *r = A.V.q_res + p;
-    const uint32_t idx0 = r[0] + 20u * r[1] + 400u * r[3];      // spaced seed 1101010011 -> offsets 0,1,3,5,8,9
-    const uint32_t idx1 = r[5] + 20u * r[8] + 400u * r[9];
-    const int16_t *s0 = A.V.score3 + (size_t) idx0 * N3;
-    const uint16_t *i0 = A.V.index3 + (size_t) idx0 * N3;
-    const int16_t *s1 = A.V.score3 + (size_t) idx1 * N3;
-    const uint16_t *i1 = A.V.index3 + (size_t) idx1 * N3;
-    for (int k = lane; k < ROWCACHE; k += WAVE) { sRow1[w][k] = s1[k]; if (GATHER) sIdx1[w][k] = i1[k]; }
-    wave_sync_lds();
-    const int cutoff1 = (int) (short) (thr - (int) sRow1[w][0]);   // threshold - best score of the second half
-
     uint32_t qLocal = 0, iPos = 0, qFirstHit = 0;
     uint32_t hitBase = 0;
     if (GATHER) {
@@ -136,53 +129,39 @@ __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
         qFirstHit = A.hit_count[A.V.q_off[q] - A.pos_begin];
         hitBase = A.hit_count[rel];
     }
-    uint32_t hits = 0, kmers = 0;
-    for (int a0 = 0; a0 < N3; a0 += WAVE) {
-        const int a = a0 + lane;
-        const int sa = (a < N3) ? (int) s0[a] : -32768;
-        const bool valid = sa >= cutoff1;
-        uint32_t nb = 0;
-        if (valid) nb = (uint32_t) count_ge(sRow1[w], ROWCACHE, s1, (int) (short) (thr - sa));
-        uint32_t groupTotal;
-        const uint32_t excl = wave_excl_scan(nb, groupTotal);
-        sPref[w][lane] = excl;
-        if (lane == 0) sPref[w][WAVE] = groupTotal;
-        sIdx0[w][lane] = valid ? i0[a] : (uint16_t) 0;
-        wave_sync_lds();
-        kmers += groupTotal;
-        // enumerate the (a,b) products of this group 64 at a time, in product order
-        for (uint32_t base = 0; base < groupTotal; base += WAVE) {
-            const uint32_t pr = base + lane;
-            uint32_t size = 0, o0 = 0;
-            if (pr < groupTotal) {
-                int lo = 0, hi = WAVE;                 // largest al with sPref[al] <= pr (valid lanes have nb >= 1)
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sPref[w][mid] <= pr) lo = mid; else hi = mid; }
-                const uint32_t b = pr - sPref[w][lo];
-                const uint32_t ib = (b < ROWCACHE && GATHER) ? (uint32_t) sIdx1[w][b] : (uint32_t) i1[b];
-                const uint32_t kmer = (uint32_t) sIdx0[w][lo] + N3 * ib;
-                o0 = A.V.kmer_off[kmer];
-                size = A.V.kmer_off[kmer + 1] - o0;
+    uint32_t hits = 0;
+    const uint32_t kmers = enumk::enumerate_position<PROBE_U>(A.V, A.V.q_res + p, thr, lane, sE[w],
+        [&](const uint32_t (&kmer)[PROBE_U], const bool (&has)[PROBE_U]) -> bool {
+            uint32_t size[PROBE_U], o0[PROBE_U];
+#pragma unroll
+            for (int u = 0; u < PROBE_U; u++) {
+                size[u] = 0; o0[u] = 0;
+                if (has[u] && kmer_present(A.V.kmer_bits, kmer[u])) { const OffPair o = load_off_pair(A.V.kmer_off, kmer[u]); o0[u] = o.lo; size[u] = o.hi - o.lo; }
             }
             if (!GATHER) {
-                hits += size;
+#pragma unroll
+                for (int u = 0; u < PROBE_U; u++) hits += size[u];
             } else {
-                uint32_t tot;
-                const uint32_t ex = wave_excl_scan(size, tot);
-                uint64_t dst = (uint64_t) hitBase + hits + ex;
-                for (uint32_t e = 0; e < size; e++) {
-                    const uint64_t ent = A.V.entries[o0 + e];
-                    const uint32_t seq = (uint32_t) ent;
-                    const uint32_t posj = (uint32_t) (ent >> 32) & 0xFFFFu;
-                    const uint32_t diag = (iPos - posj) & 0xFFFFu;
-                    A.keys[dst + e] = ((uint64_t) qLocal << A.seq_bits) | seq;
-                    A.vals[dst + e] = ((uint64_t) (dst + e - qFirstHit) << 16) | diag;
+                uint64_t ent0[PROBE_U];
+#pragma unroll
+                for (int u = 0; u < PROBE_U; u++) ent0[u] = size[u] ? A.V.entries[o0[u]] : 0ull;
+#pragma unroll
+                for (int u = 0; u < PROBE_U; u++) {
+                    const uint32_t incl = enumk::wave_incl_scan(size[u]);
+                    const uint64_t dst = (uint64_t) hitBase + hits + (incl - size[u]);
+                    for (uint32_t e = 0; e < size[u]; e++) {
+                        const uint64_t ent = e == 0 ? ent0[u] : A.V.entries[o0[u] + e];
+                        const uint32_t seq = (uint32_t) ent;
+                        const uint32_t posj = (uint32_t) (ent >> 32) & 0xFFFFu;
+                        const uint32_t diag = (iPos - posj) & 0xFFFFu;
+                        A.keys[dst + e] = ((uint64_t) qLocal << A.seq_bits) | seq;
+                        A.vals[dst + e] = ((uint64_t) (dst + e - qFirstHit) << 16) | diag;
+                    }
+                    hits += enumk::wave_last(incl);
                 }
-                hits += tot;
             }
-        }
-        wave_sync_lds();
-        if (__any(!valid)) break;
-    }
+            return true;
+        });
     if (!GATHER) {
         hits = wave_sum(hits);
         if (lane == 0) { A.hit_count[rel] = hits; A.kmer_count[rel] = kmers; }
@@ -257,6 +236,30 @@ __global__ __launch_bounds__(256) void gather_queries_kernel(PrefilterDeviceView
     res[r] = V.q_res[src]; kthr[r] = V.q_kmer_thr[src]; corr[r] = V.q_corr[src];
 }
 
+// Exact number of similar k-mers of every k-mer start, without enumerating them: with the per-row score histograms the
+// staircase sum over (first half, second half) collapses to sum_s hist0[s] * cum1[thr - s].  Summed per query; the host
+// sizes the LDS tier of each query with it.
+__global__ __launch_bounds__(256) void kmer_count_kernel(PrefilterDeviceView V, uint64_t posBegin, uint64_t posEnd, uint32_t qFirst, uint32_t *perQuery) {
+    const uint64_t p = posBegin + (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= posEnd) return;
+    const int thr = (int) V.q_kmer_thr[p];
+    if (thr < 0) return;
+    const uint8_t *r = V.q_res + p;
+    const uint32_t idx0 = r[0] + 20u * r[1] + 400u * r[3];
+    const uint32_t idx1 = r[5] + 20u * r[8] + 400u * r[9];
+    const int R = V.hist_range, lo = V.hist_lo;
+    const uint16_t *h0 = V.hist3 + (size_t) idx0 * R, *c1 = V.cum3 + (size_t) idx1 * R;
+    uint32_t total = 0;
+    for (int k = R - 1; k >= 0; k--) {
+        const uint32_t h = h0[k];
+        if (!h) continue;
+        const int x = thr - (lo + k) - lo;            // index of the cutoff in the cumulative row
+        if (x >= R) break;                             // the second half cannot reach the cutoff any more (scores only fall)
+        total += h * (x <= 0 ? (uint32_t) N3 : (uint32_t) c1[x]);
+    }
+    if (total) atomicAdd(&perQuery[find_query(V.q_off, V.n_queries, p) - qFirst], total);
+}
+
 // =====================================================================================================
 //  A. fused per-query path
 // =====================================================================================================
@@ -272,19 +275,21 @@ struct FusedArgs {
     CandArrays C; uint32_t cand_cap;
     uint32_t *counters;               // [0] candidates appended [1] overflowed queries
     uint32_t *overflow_list;          // chunk-local ids of the queries that did not fit their tier
-    unsigned long long *totals;       // [0] k-mers [1] index hits [2] k-mer start positions (statistics / tier sizing)
+    unsigned long long *totals;       // [0] k-mers [1] index hits [2] k-mer start positions (statistics / tier sizing) [3..6] workgroup time: gather, sort, rule+emit, overflowed
 };
+
+constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 
 template <int CAP, int NW>
 __global__ __launch_bounds__(NW * 64) void fused_kernel(FusedArgs A) {
     constexpr int NCH = CAP / WAVE;               // 64-slot chunks of the hit store
     constexpr int BLOCK = NW * WAVE;
+    constexpr int MBITS = (CAP >= 16384 ? 2 : 4) * CAP;   // buckets of the multi-hit filter (the largest tier is out of LDS)
+    constexpr int LOG_MBITS = ilog2(MBITS);
     __shared__ uint32_t sKey[CAP];                // phase 1: target id; afterwards target << ARR_BITS | arrival
     __shared__ uint16_t sDiag[CAP];
-    __shared__ int16_t sRow1[NW][ROWCACHE];
-    __shared__ uint16_t sIdx1[NW][ROWCACHE];
-    __shared__ uint32_t sPref[NW][WAVE + 1];
-    __shared__ uint16_t sIdx0[NW][WAVE];
+    __shared__ uint32_t sBm1[MBITS / 32], sBm2[MBITS / 32];   // bucket hit once / more than once
+    __shared__ enumk::EnumLds<PROBE_U> sE[NW];
     __shared__ uint16_t sChunkOf[NW][NCH];        // wave-local chunk number -> physical chunk
     __shared__ uint16_t sRankToChunk[NCH];        // arrival rank of a chunk -> physical chunk
     __shared__ uint16_t sChunkRank[NCH];          // physical chunk -> arrival rank
@@ -293,13 +298,16 @@ __global__ __launch_bounds__(NW * 64) void fused_kernel(FusedArgs A) {
     __shared__ uint32_t sFlagBits[CAP / 32];
     __shared__ uint32_t sWordPrefix[CAP / 32];
     __shared__ uint32_t sBump, sOverflow, sEmitBase;
+    __shared__ uint32_t sWaveCnt[NW];
 
     const int tid = threadIdx.x, w = tid / WAVE, lane = tid & (WAVE - 1);
     const uint32_t q = A.queries[blockIdx.x];
     const uint64_t qs = A.V.q_off[q];
     const int L = (int) (A.V.q_off[q + 1] - qs);
     if (tid == 0) { sBump = 0; sOverflow = 0; }
+    for (int k = tid; k < MBITS / 32; k += BLOCK) { sBm1[k] = 0; sBm2[k] = 0; }
     __syncthreads();
+    const unsigned long long tStart = wall_clock64();
 
     // ---- phase 1: enumerate + gather into LDS.  Wave w owns a contiguous range of k-mer starts, so arrival order is
     //      (wave, wave-local slot); slots come in 64-entry chunks from a workgroup-wide bump allocator.
@@ -314,45 +322,22 @@ __global__ __launch_bounds__(NW * 64) void fused_kernel(FusedArgs A) {
         if (thr < 0) continue;
         if (*(volatile uint32_t *) &sOverflow) { dead = true; break; }
         npos++;
-        const uint8_t *r = A.V.q_res + p;
-        const uint32_t idx0 = r[0] + 20u * r[1] + 400u * r[3];
-        const uint32_t idx1 = r[5] + 20u * r[8] + 400u * r[9];
-        const int16_t *s0 = A.V.score3 + (size_t) idx0 * N3;
-        const uint16_t *i0 = A.V.index3 + (size_t) idx0 * N3;
-        const int16_t *s1 = A.V.score3 + (size_t) idx1 * N3;
-        const uint16_t *i1 = A.V.index3 + (size_t) idx1 * N3;
-        for (int k = lane; k < ROWCACHE; k += WAVE) { sRow1[w][k] = s1[k]; sIdx1[w][k] = i1[k]; }
-        wave_sync_lds();
-        const int cutoff1 = (int) (short) (thr - (int) sRow1[w][0]);
-        for (int a0 = 0; a0 < N3 && !dead; a0 += WAVE) {
-            const int a = a0 + lane;
-            const int sa = (a < N3) ? (int) s0[a] : -32768;
-            const bool valid = sa >= cutoff1;
-            uint32_t nb = 0;
-            if (valid) nb = (uint32_t) count_ge(sRow1[w], ROWCACHE, s1, (int) (short) (thr - sa));
-            uint32_t groupTotal;
-            const uint32_t excl = wave_excl_scan(nb, groupTotal);
-            sPref[w][lane] = excl;
-            if (lane == 0) sPref[w][WAVE] = groupTotal;
-            sIdx0[w][lane] = valid ? i0[a] : (uint16_t) 0;
-            wave_sync_lds();
-            kmers += groupTotal;
-            for (uint32_t base = 0; base < groupTotal && !dead; base += WAVE) {
-                const uint32_t pr = base + lane;
-                uint32_t size = 0, o0 = 0;
-                if (pr < groupTotal) {
-                    int lo = 0, hi = WAVE;
-                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sPref[w][mid] <= pr) lo = mid; else hi = mid; }
-                    const uint32_t b = pr - sPref[w][lo];
-                    const uint32_t ib = (b < ROWCACHE) ? (uint32_t) sIdx1[w][b] : (uint32_t) i1[b];
-                    const uint32_t kmer = (uint32_t) sIdx0[w][lo] + N3 * ib;
-                    o0 = A.V.kmer_off[kmer];
-                    size = A.V.kmer_off[kmer + 1] - o0;
+        kmers += enumk::enumerate_position<PROBE_U>(A.V, A.V.q_res + p, thr, lane, sE[w],
+            [&](const uint32_t (&kmer)[PROBE_U], const bool (&has)[PROBE_U]) -> bool {
+                uint32_t size[PROBE_U], o0[PROBE_U], ex[PROBE_U];
+                uint64_t ent0[PROBE_U];
+#pragma unroll
+                for (int u = 0; u < PROBE_U; u++) {
+                    size[u] = 0; o0[u] = 0;
+                    if (has[u] && kmer_present(A.V.kmer_bits, kmer[u])) { const OffPair o = load_off_pair(A.V.kmer_off, kmer[u]); o0[u] = o.lo; size[u] = o.hi - o.lo; }
                 }
-                uint32_t tot;
-                const uint32_t ex = wave_excl_scan(size, tot);
-                if (tot == 0) continue;
-                while (nCh * WAVE < wcount + tot) {                     // wave-uniform: more slots for this group
+#pragma unroll
+                for (int u = 0; u < PROBE_U; u++) ent0[u] = size[u] ? A.V.entries[o0[u]] : 0ull;   // first entry of every list (most lists have one)
+                uint32_t totAll = 0;
+#pragma unroll
+                for (int u = 0; u < PROBE_U; u++) { const uint32_t incl = enumk::wave_incl_scan(size[u]); ex[u] = incl - size[u] + totAll; totAll += enumk::wave_last(incl); }
+                if (totAll == 0) return true;
+                while (nCh * WAVE < wcount + totAll) {                  // wave-uniform: more slots for these groups
                     uint32_t c = 0;
                     if (lane == 0) c = atomicAdd(&sBump, 1u);
                     c = (uint32_t) __builtin_amdgcn_readfirstlane((int) c);
@@ -360,26 +345,32 @@ __global__ __launch_bounds__(NW * 64) void fused_kernel(FusedArgs A) {
                     if (lane == 0) { sChunkOf[w][nCh] = (uint16_t) c; sOwner[c] = (uint8_t) w; }
                     nCh++;
                 }
-                if (dead) { if (lane == 0) sOverflow = 1; break; }
+                if (dead) { if (lane == 0) sOverflow = 1; return false; }
                 wave_sync_lds();
-                const uint32_t v0 = wcount + ex;
-                for (uint32_t e = 0; e < size; e++) {
-                    const uint64_t ent = A.V.entries[o0 + e];
-                    const uint32_t v = v0 + e;
-                    const uint32_t phys = (uint32_t) sChunkOf[w][v >> 6] * WAVE + (v & 63u);
-                    sKey[phys] = (uint32_t) ent;
-                    sDiag[phys] = (uint16_t) (((uint32_t) i - ((uint32_t) (ent >> 32) & 0xFFFFu)) & 0xFFFFu);
+#pragma unroll
+                for (int u = 0; u < PROBE_U; u++) {
+                    const uint32_t v0 = wcount + ex[u];
+                    for (uint32_t e = 0; e < size[u]; e++) {
+                        const uint64_t ent = e == 0 ? ent0[u] : A.V.entries[o0[u] + e];
+                        const uint32_t v = v0 + e;
+                        const uint32_t phys = (uint32_t) sChunkOf[w][v >> 6] * WAVE + (v & 63u);
+                        sKey[phys] = (uint32_t) ent;
+                        sDiag[phys] = (uint16_t) (((uint32_t) i - ((uint32_t) (ent >> 32) & 0xFFFFu)) & 0xFFFFu);
+                        // multi-hit filter: a bucket seen twice keeps all its hits for the sort (same target => same bucket)
+                        const uint32_t hb = ((uint32_t) ent * 2654435761u) >> (32 - LOG_MBITS);
+                        const uint32_t bit = 1u << (hb & 31u);
+                        if (atomicOr(&sBm1[hb >> 5], bit) & bit) atomicOr(&sBm2[hb >> 5], bit);
+                    }
                 }
-                wcount += tot;
-            }
-            wave_sync_lds();
-            if (__any(!valid)) break;
-        }
+                wcount += totAll;
+                return true;
+            });
     }
-    if (lane == 0) { sWaveHits[w] = wcount; sWaveChunks[w] = nCh; sWaveKmers[w] = kmers; sWavePos[w] = npos; }
+    if (lane == 0) { sWaveHits[w] = wcount; sWaveChunks[w] = nCh; sWaveKmers[w] = kmers; sWavePos[w] = npos; atomicAdd(&A.totals[7], (wall_clock64() - tStart) / NW); }
     __syncthreads();
+    const unsigned long long tGather = wall_clock64();
     if (sOverflow) {                                   // does not fit this tier: the global path takes the query
-        if (tid == 0) A.overflow_list[atomicAdd(&A.counters[1], 1u)] = q - A.q_first;
+        if (tid == 0) { A.overflow_list[atomicAdd(&A.counters[1], 1u)] = q - A.q_first; atomicAdd(&A.totals[6], tGather - tStart); atomicAdd(&A.totals[8], 1ull); }
         return;
     }
     if (tid == 0) {
@@ -394,9 +385,7 @@ __global__ __launch_bounds__(NW * 64) void fused_kernel(FusedArgs A) {
     const uint32_t nChunks = sWavePrefix[NW];
     if (nChunks == 0) return;
     const uint32_t used = nChunks * WAVE;
-    uint32_t P = WAVE;
-    while (P < used) P <<= 1;
-    // chunk ranks (arrival order of the chunks), then the sort keys target << ARR_BITS | arrival
+    // chunk ranks (arrival order of the chunks)
     for (uint32_t k = (uint32_t) tid; k < (uint32_t) NW * NCH; k += BLOCK) {
         const uint32_t ww = k / NCH, kk = k % NCH;
         if (kk < sWaveChunks[ww]) {
@@ -406,15 +395,37 @@ __global__ __launch_bounds__(NW * 64) void fused_kernel(FusedArgs A) {
         }
     }
     __syncthreads();
-    for (uint32_t s = (uint32_t) tid; s < P; s += BLOCK) {
+    // Only targets hit more than once can satisfy the double-diagonal rule, plus single hits whose diagonal low byte is 0
+    // (the first hit of a target is compared with 0).  Survivors get their sort key target << ARR_BITS | arrival and are
+    // compacted in place: a batch is read, then written at or before its own slots.
+    uint32_t nSurv = 0;
+    for (uint32_t s0 = 0; s0 < used; s0 += BLOCK) {
+        const uint32_t s = s0 + (uint32_t) tid;
+        bool surv = false;
         uint32_t key = KEY_SENTINEL;
         if (s < used) {
             const uint32_t c = s >> 6, rank = sChunkRank[c], ww = sOwner[c];
             const uint32_t v = (rank - sWavePrefix[ww]) * WAVE + (s & 63u);   // wave-local slot number
-            if (v < sWaveHits[ww]) key = (sKey[s] << ARR_BITS) | (rank * WAVE + (s & 63u));
+            if (v < sWaveHits[ww]) {
+                const uint32_t tgt = sKey[s];
+                const uint32_t hb = (tgt * 2654435761u) >> (32 - LOG_MBITS);
+                surv = ((sBm2[hb >> 5] >> (hb & 31u)) & 1u) || ((uint32_t) sDiag[s] & 0xFFu) == 0u;
+                key = (tgt << ARR_BITS) | (rank * WAVE + (s & 63u));
+            }
         }
-        sKey[s] = key;
+        const unsigned long long m = __ballot(surv);
+        if (lane == 0) sWaveCnt[w] = (uint32_t) __popcll(m);
+        __syncthreads();
+        uint32_t before = nSurv, all = 0;
+        for (int k = 0; k < NW; k++) { const uint32_t cnt = sWaveCnt[k]; if (k < w) before += cnt; all += cnt; }
+        if (surv) sKey[before + (uint32_t) __popcll(m & ((1ull << lane) - 1ull))] = key;
+        nSurv += all;
+        __syncthreads();
     }
+    if (nSurv == 0) return;
+    uint32_t P = WAVE;
+    while (P < nSurv) P <<= 1;
+    for (uint32_t s = nSurv + (uint32_t) tid; s < P; s += BLOCK) sKey[s] = KEY_SENTINEL;
     __syncthreads();
 
     // ---- phase 2: bitonic sort of the keys (all distinct: the arrival index makes the order total)
@@ -431,6 +442,7 @@ __global__ __launch_bounds__(NW * 64) void fused_kernel(FusedArgs A) {
         }
     }
 
+    const unsigned long long tSort = wall_clock64();
     // ---- phase 3: the double-diagonal rule on the target runs -> flag bits
     auto lo_of = [&](uint32_t key) -> uint32_t {
         const uint32_t arr = key & ARR_MASK;
@@ -479,6 +491,9 @@ __global__ __launch_bounds__(NW * 64) void fused_kernel(FusedArgs A) {
     }
     __syncthreads();
     const uint32_t nEmit = sBump, base = sEmitBase;
+    if (tid == 0) {                                    // time split of the workgroup (100 MHz ticks), statistics only
+        atomicAdd(&A.totals[3], tGather - tStart); atomicAdd(&A.totals[4], tSort - tGather); atomicAdd(&A.totals[5], wall_clock64() - tSort);
+    }
     if (nEmit == 0 || (unsigned long long) base + nEmit > (unsigned long long) A.cand_cap) return;   // host sees counters[0] > cap and retries
     for (uint32_t t = (uint32_t) tid; t < P; t += BLOCK) {
         const uint32_t word = sFlagBits[t >> 5];
@@ -620,8 +635,8 @@ int self_score(const SubMat &ung, const uint8_t *q, const int8_t *corr, int L) {
     return best;
 }
 
-// sizing state carried from one batch to the next (same database): index hits per k-mer start, candidates per query
-struct SizingMemo { const void *entries = nullptr; uint32_t nTargets = 0; double hitsPerPos = 0, candPerQuery = 0; };
+// sizing state carried from one batch to the next (same database): index hits per similar k-mer, candidates per query
+struct SizingMemo { const void *entries = nullptr; uint32_t nTargets = 0; double hitsPerKmer = 0, candPerQuery = 0; };
 SizingMemo g_memo;
 
 }  // namespace
@@ -695,7 +710,7 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &V, const uint64_t *hOff
             PCHK(sync_wait(stream, "wait_prefilter"));
             totalHits = X.hTotals[0];
             if (X.hTotals[1] != 0) { err = "a query overflows the reference's databaseHits buffer (QueryMatcher.cpp:281-316 is not restated)"; return MK_ERR_UNSUPPORTED; }
-            X.ts(thCount, 8.0 * (double) X.hTotals[2] + 2.0 * 2.0 * ROWCACHE * (double) nPos, (double) X.hTotals[2]);
+            X.ts(thCount, 8.0 * (double) X.hTotals[2] + 64.0 * (double) nPos, (double) X.hTotals[2]);
             hitsPerPos = std::max(1.0, (double) totalHits / (double) nPos);
             if (totalHits > HIT_CAP && q1 - q0 > 1) { q1 = q0 + (q1 - q0) / 2; continue; }
             break;
@@ -711,7 +726,7 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &V, const uint64_t *hOff
             A.hit_count = dHit; A.kmer_count = dKmer; A.keys = dKeys; A.vals = dVals;
             const unsigned blocks = (unsigned) ((nPos + 3) / 4);
             // gather pass: offset pairs again + 8 B per index entry read + 16 B (key,value) written per entry
-            int th = X.tb("kmer_probe_gather", 8.0 * (double) X.hTotals[2] + 24.0 * (double) totalHits + 4.0 * ROWCACHE * (double) nPos, (double) X.hTotals[2]);
+            int th = X.tb("kmer_probe_gather", 8.0 * (double) X.hTotals[2] + 24.0 * (double) totalHits + 64.0 * (double) nPos, (double) X.hTotals[2]);
             hipLaunchKernelGGL(probe_kernel<true>, dim3(blocks), dim3(256), 0, stream, A);
             X.te(th);
             PCHK(hipGetLastError());
@@ -800,7 +815,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     }
     const FusedTier *tiers = TIERS + tierBase;
     if (g_memo.entries != (const void *) V.entries || g_memo.nTargets != V.n_targets) { g_memo = SizingMemo(); g_memo.entries = V.entries; g_memo.nTargets = V.n_targets; }
-    double hitsPerPos = g_memo.hitsPerPos, candPerQuery = g_memo.candPerQuery, globalHitsPerPos = 0;
+    double hitsPerKmer = g_memo.hitsPerKmer, candPerQuery = g_memo.candPerQuery, globalHitsPerPos = 0;
     SubMat ungMat;
     build_submat(ungMat, MAT_BLOSUM62, 2.0f, -0.2f);
 
@@ -817,9 +832,9 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     C.score = (int32_t *) dev_scratch("pf_cscore", (size_t) CAND_CAP * 4);
     PNULL(C.q); PNULL(C.id); PNULL(C.ordinal); PNULL(C.diag); PNULL(C.score);
     uint32_t *dCounters = (uint32_t *) dev_scratch("pf_fcounters", 64);
-    unsigned long long *dFTotals = (unsigned long long *) dev_scratch("pf_ftotals", 64);
+    unsigned long long *dFTotals = (unsigned long long *) dev_scratch("pf_ftotals", 16 * 8 * N_TIERS);
     uint32_t *hCounters = (uint32_t *) pinned_scratch("pf_fcounters_h", 64);
-    unsigned long long *hFTotals = (unsigned long long *) pinned_scratch("pf_ftotals_h", 64);
+    unsigned long long *hFTotals = (unsigned long long *) pinned_scratch("pf_ftotals_h", 16 * 8 * (N_TIERS + 1));
     PNULL(dCounters); PNULL(dFTotals); PNULL(hCounters); PNULL(hFTotals);
 
     uint32_t q0 = 0;
@@ -839,13 +854,28 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             std::vector<uint32_t> lists[N_TIERS];
             size_t nListed = 0;
             uint32_t *hList = nullptr, *dList = nullptr, *dOvf = nullptr;
+            // exact similar-k-mer count per query -> expected index hits -> LDS tier
+            uint32_t *dQK = (uint32_t *) dev_scratch("pf_qkmers", (size_t) nqc * 4);
+            uint32_t *hQK = (uint32_t *) pinned_scratch("pf_qkmers_h", (size_t) nqc * 4);
+            PNULL(dQK); PNULL(hQK);
+            {
+                const uint64_t pb = qOff[q0], pe = qOff[q1];
+                PCHK(hipMemsetAsync(dQK, 0, (size_t) nqc * 4, stream));
+                if (pe > pb) {
+                    const int th = tb("kmer_count", 5.0 * (double) (pe - pb), 0);
+                    hipLaunchKernelGGL(kmer_count_kernel, dim3((unsigned) ((pe - pb + 255) / 256)), dim3(256), 0, stream, V, pb, pe, q0, dQK);
+                    te(th);
+                    PCHK(hipGetLastError());
+                }
+                PCHK(hipMemcpyAsync(hQK, dQK, (size_t) nqc * 4, hipMemcpyDeviceToHost, stream));
+                PCHK(sync_wait(stream, "wait_prefilter"));
+            }
             {
                 ScopedHost sh("host_prefilter_tiers");
-                const double hpp = hitsPerPos > 0 ? hitsPerPos : 96.0;
+                const double hpk = hitsPerKmer > 0 ? hitsPerKmer : std::max(0.05, (double) V.n_entries / 64.0e6);
                 for (uint32_t ql = 0; ql < nqc; ql++) {
-                    const uint64_t L = qOff[(size_t) q0 + ql + 1] - qOff[(size_t) q0 + ql];
-                    if (L < 10) continue;                                   // no k-mer: no hits
-                    const double est = hpp * (double) (L - 9) * 1.3;   // + half a 64-slot chunk lost per wave
+                    if (hQK[ql] == 0) continue;                             // no k-mer: no hits
+                    const double est = hpk * (double) hQK[ql] * 1.12;       // + half a 64-slot chunk lost per wave
                     int t = 0;
                     while (t < N_TIERS && est + 32.0 * tiers[t].waves > (double) tiers[t].cap) t++;
                     if (t == N_TIERS) fallback.push_back(ql); else lists[t].push_back(q0 + ql);
@@ -860,7 +890,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             }
             PCHK(hipMemcpyAsync(dList, hList, nListed * 4, hipMemcpyHostToDevice, stream));
             PCHK(hipMemsetAsync(dCounters, 0, 16, stream));
-            PCHK(hipMemsetAsync(dFTotals, 0, 32, stream));
+            PCHK(hipMemsetAsync(dFTotals, 0, 16 * 8 * N_TIERS, stream));
             int thFused[N_TIERS];
             size_t at = 0;
             for (int t = 0; t < N_TIERS; t++) {
@@ -868,7 +898,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                 if (lists[t].empty()) continue;
                 FusedArgs A;
                 A.V = V; A.queries = dList + at; A.n_launch = (uint32_t) lists[t].size(); A.q_first = q0;
-                A.C = C; A.cand_cap = CAND_CAP; A.counters = dCounters; A.overflow_list = dOvf; A.totals = dFTotals;
+                A.C = C; A.cand_cap = CAND_CAP; A.counters = dCounters; A.overflow_list = dOvf; A.totals = dFTotals + 16 * t;
                 char nm[48];
                 snprintf(nm, sizeof(nm), "prefilter_fused_lds%d", tiers[t].cap);
                 thFused[t] = tb(nm, 0, 0);
@@ -878,8 +908,15 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                 at += lists[t].size();
             }
             PCHK(hipMemcpyAsync(hCounters, dCounters, 16, hipMemcpyDeviceToHost, stream));
-            PCHK(hipMemcpyAsync(hFTotals, dFTotals, 32, hipMemcpyDeviceToHost, stream));
+            PCHK(hipMemcpyAsync(hFTotals + 16, dFTotals, 16 * 8 * N_TIERS, hipMemcpyDeviceToHost, stream));
             PCHK(sync_wait(stream, "wait_prefilter"));
+            for (int k = 0; k < 16; k++) { hFTotals[k] = 0; for (int t = 0; t < N_TIERS; t++) hFTotals[k] += hFTotals[16 * (t + 1) + k]; }
+            if (getenv("MK_PREFILTER_DEBUG"))
+                for (int t = 0; t < N_TIERS; t++) {
+                    const unsigned long long *T = hFTotals + 16 * (t + 1);
+                    fprintf(stderr, "[prefilter]   tier %d (lds %d): queries %zu overflowed %llu | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g sort %.3g emit %.3g overflowed %.3g\n",
+                            t, tiers[t].cap, lists[t].size(), T[8], (double) T[0], (double) T[1], (double) T[2], (double) T[3], (double) T[4], (double) T[5], (double) T[6]);
+                }
             const uint32_t nOvf = hCounters[1];
             if (hCounters[0] > CAND_CAP) rc = RC_CAND_OVERFLOW;
             else {
@@ -889,9 +926,13 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                 for (int t = 0; t < N_TIERS; t++)
                     if (thFused[t] >= 0) {
                         const double share = (double) lists[t].size() / (double) std::max<size_t>(nListed, 1);
-                        ts(thFused[t], share * (8.0 * (double) hFTotals[0] + 8.0 * (double) hFTotals[1] + 4.0 * ROWCACHE * (double) hFTotals[2]), share * (double) hFTotals[0]);
+                        ts(thFused[t], share * (8.0 * (double) hFTotals[0] + 8.0 * (double) hFTotals[1] + 64.0 * (double) hFTotals[2]), share * (double) hFTotals[0]);
                     }
-                if (hFTotals[2] > 0) hitsPerPos = std::max(1.0, (double) hFTotals[1] / (double) hFTotals[2]);
+                if (getenv("MK_PREFILTER_DEBUG"))
+                    fprintf(stderr, "[prefilter] chunk %u..%u: tiers %zu/%zu/%zu/%zu too-long %zu overflow %u | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g (mean wave %.3g) sort %.3g emit %.3g overflowed %.3g | cand %u\n",
+                            q0, q1, lists[0].size(), lists[1].size(), lists[2].size(), lists[3].size(), fallback.size(), nOvf, (double) hFTotals[0], (double) hFTotals[1],
+                            (double) hFTotals[2], (double) hFTotals[3], (double) hFTotals[7], (double) hFTotals[4], (double) hFTotals[5], (double) hFTotals[6], nCand);
+                if (hFTotals[0] > 0) hitsPerKmer = std::max(0.01, (double) hFTotals[1] / (double) hFTotals[0]);
                 if (nOvf > 0) {
                     uint32_t *hOvf = (uint32_t *) pinned_scratch("pf_fovf_h", (size_t) nOvf * 4);
                     PNULL(hOvf);
@@ -1102,7 +1143,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
         }
         q0 = q1;
     }
-    g_memo.hitsPerPos = hitsPerPos; g_memo.candPerQuery = candPerQuery;
+    g_memo.hitsPerKmer = hitsPerKmer; g_memo.candPerQuery = candPerQuery;
     (void) tOff;
     PCHK(sync_wait(stream, "wait_prefilter"));         // the last DMA into the result block
     return MK_OK;

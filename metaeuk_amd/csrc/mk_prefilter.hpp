@@ -15,7 +15,10 @@ struct PrefilterDeviceView {
     // target side
     const uint8_t *t_masked; const uint64_t *t_off; uint32_t n_targets;
     const uint32_t *kmer_off; const uint64_t *entries;
+    const uint32_t *kmer_bits;     // 20^6 bits: k-mer has a non-empty index list (8 MB: stays in L2/MALL, filters the offset probes)
     const int16_t *score3; const uint16_t *index3;
+    const uint16_t *hist3; const uint16_t *cum3; int hist_lo, hist_range;   // per-row score histograms (sizing)
+    uint64_t n_entries;
     const int8_t *mat_ung;
 };
 

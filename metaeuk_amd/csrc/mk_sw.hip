@@ -9,7 +9,8 @@
 //   * the group sweeps the target as an anti-diagonal wavefront: at step s lane l is on column s-l;
 //     what crosses the lane boundary -- H of the lane's last row, the running F, and the target
 //     residue itself -- travels lane-to-lane with two DPP row_shr / wave_shr moves per step:
-//     no LDS traffic, no bpermute; lane 0 injects residues (and tile borders);
+//     no LDS traffic, no bpermute; lane 0 injects residues (and tile borders).  The residues themselves are
+//     fetched 16 columns per DPP row, a block of steps ahead, and rotated into lane 0 (row_ror) -- no load in the step;
 //   * substitution scores come from an LDS query profile prof[residue][row] (+int8 composition
 //     bias), one ds_read of R bytes per lane per column;
 //   * the running maximum is a packed key (score << 17 | ~column) per row, so the reference's
@@ -105,36 +106,47 @@ __global__ __launch_bounds__(BLOCK) void sw_kernel(SwLaunch L) {
         const int steps = tLen > 0 ? tLen + G - 1 : 0;
         const bool readTop = (tile > 0);
         const bool writeBottom = (tile + 1 < nTiles);
-        for (int s = 0; s < steps; s++) {
-            uint32_t top0 = 0, top1 = 21u;      // residue code 21 = "no column": an all-zero profile row
-            if (lane == 0 && s < tLen) {
-                top1 = L.t_res[(int64_t) job.t_start + (int64_t) s * job.t_step];
-                if (readTop) top0 = border[s];
-            }
-            const uint32_t in0 = shift_up<G>(top0, out0, lane);
-            const uint32_t tres = shift_up<G>(top1, out1, lane);
-            const int hup = (int) (in0 & 0xFFFFu);
-            int F = (int) (in0 >> 16);
-            const int c = s - lane;
-            const uint32_t cinv = 0x1FFFFu - (uint32_t) max(c, 0);
-            int sc[R];
-            load_scores<R>(prof + tres * ROWS + lane * R, sc);
-            int dsave = hupPrev;
+        // Target residues are fetched 16 columns at a time, one byte per lane of a DPP row, one block of 16 steps ahead
+        // of their use; a row rotation per step brings the current column's residue to row lane 0 (= lane 0 of the group).
+        const int laneRow = (int) (threadIdx.x & 15u);
+        const int64_t tBase = (int64_t) job.t_start;
+        const int64_t tStep = (int64_t) job.t_step;
+        const int tLast = max(tLen - 1, 0);
+        uint32_t tnext = L.t_res[tBase + (int64_t) min(laneRow, tLast) * tStep];
+        for (int s0 = 0; s0 < steps; s0 += 16) {
+            uint32_t tcur = tnext;
+            tnext = L.t_res[tBase + (int64_t) min(s0 + 16 + laneRow, tLast) * tStep];
+            const int sEnd = min(s0 + 16, steps);
+            for (int s = s0; s < sEnd; s++) {
+                uint32_t top0 = 0;
+                const uint32_t top1 = s < tLen ? tcur : 21u;   // residue code 21 = "no column": an all-zero profile row
+                tcur = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) tcur, 0x12F /* row_ror:15 = one lane towards lane 0 */, 0xf, 0xf, false);
+                if (readTop && lane == 0 && s < tLen) top0 = border[s];
+                const uint32_t in0 = shift_up<G>(top0, out0, lane);
+                const uint32_t tres = shift_up<G>(top1, out1, lane);
+                const int hup = (int) (in0 & 0xFFFFu);
+                int F = (int) (in0 >> 16);
+                const int c = s - lane;
+                const uint32_t cinv = 0x1FFFFu - (uint32_t) max(c, 0);
+                int sc[R];
+                load_scores<R>(prof + tres * ROWS + lane * R, sc);
+                int dsave = hupPrev;
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int d = min(dsave + sc[r], 32767);       // int16 saturating add of the reference's word pass
-                dsave = H[r];
-                const int h = max3i(d, E[r], F);               // E >= 0 keeps H non-negative
-                key[r] = max(key[r], ((uint32_t) h << 17) | cinv);
-                const int ho = h - go;
-                E[r] = max3i(E[r] - ge, ho, 0);
-                F = max3i(F - ge, ho, 0);
-                H[r] = h;
+                for (int r = 0; r < R; r++) {
+                    const int d = min(dsave + sc[r], 32767);       // int16 saturating add of the reference's word pass
+                    dsave = H[r];
+                    const int h = max3i(d, E[r], F);               // E >= 0 keeps H non-negative
+                    key[r] = max(key[r], ((uint32_t) h << 17) | cinv);
+                    const int ho = h - go;
+                    E[r] = max3i(E[r] - ge, ho, 0);
+                    F = max3i(F - ge, ho, 0);
+                    H[r] = h;
+                }
+                hupPrev = hup;
+                out0 = (uint32_t) H[R - 1] | ((uint32_t) F << 16);
+                out1 = tres;
+                if (writeBottom && lane == G - 1 && c >= 0 && c < tLen) border[c] = out0;
             }
-            hupPrev = hup;
-            out0 = (uint32_t) H[R - 1] | ((uint32_t) F << 16);
-            out1 = tres;
-            if (writeBottom && lane == G - 1 && c >= 0 && c < tLen) border[c] = out0;
         }
 #pragma unroll
         for (int r = 0; r < R; r++) {
