@@ -28,8 +28,10 @@ __device__ __forceinline__ uint32_t sort_key(uint32_t qLen, uint32_t tLen) {
     return (uint32_t) sw_cfg_of(qLen) * KEY_CLS + (KEY_CLS - 1 - min(tLen >> 4, KEY_CLS - 1));
 }
 
+// forward jobs are ordered by (tile configuration, query, target length descending): the DPs of a wave share their query
+// (one LDS profile per wave) and have similar numbers of columns
 __global__ __launch_bounds__(256) void expand_pairs_kernel(AlignView V, const uint64_t *hitOff, const mk_hit *hits, uint64_t n,
-                                                           SwJob *jobs, uint32_t *keys, uint32_t *idx, uint32_t *badTarget) {
+                                                           SwJob *jobs, uint64_t *keys, uint32_t *idx, uint32_t *badTarget) {
     const uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     uint32_t lo = 0, hi = V.n_queries;              // largest q with hitOff[q] <= p
@@ -41,8 +43,39 @@ __global__ __launch_bounds__(256) void expand_pairs_kernel(AlignView V, const ui
     else { j.t_start = 0; j.t_len = 0; atomicMax(badTarget, (uint32_t) p + 1u); }     // reported to the caller, nothing is aligned
     j.q_step = 1; j.t_step = 1; j.slot = (uint32_t) p;
     jobs[p] = j;
-    keys[p] = sort_key(j.q_len, j.t_len);
+    keys[p] = ((uint64_t) sw_cfg_of(j.q_len) << 44) | ((uint64_t) q << 12) | (uint64_t) (KEY_CLS - 1 - min(j.t_len >> 4, KEY_CLS - 1));
     idx[p] = (uint32_t) p;
+}
+
+// segment = run of jobs with the same (configuration, query); value = own index at a segment head, 0 elsewhere (max-scan -> head)
+__global__ __launch_bounds__(256) void seg_mark_kernel(const uint64_t *sortedKeys, uint32_t n, uint32_t *head) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    head[i] = (i > 0 && (sortedKeys[i] >> 12) != (sortedKeys[i - 1] >> 12)) ? i : 0u;
+}
+// a wave starts at every (64/G)-th job of a segment
+__global__ __launch_bounds__(256) void wave_flag_kernel(const uint64_t *sortedKeys, const uint32_t *head, uint32_t n, uint8_t *flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int cfg = (int) (sortedKeys[i] >> 44);
+    const uint32_t dpw = cfg < 4 ? 4u : (cfg < 6 ? 2u : 1u);       // 64 / G of launch_sw's configurations
+    flag[i] = ((i - head[i]) % dpw) == 0 ? 1 : 0;
+}
+// job and wave ranges of every configuration; closes the wave list with n
+__global__ void shared_bounds_kernel(const uint64_t *sortedKeys, uint32_t n, uint32_t *waveStart, const uint32_t *nWaves,
+                                     uint32_t *out /* [0..8] job bounds, [16..24] wave bounds, [32..39] first target-length class */) {
+    const uint32_t c = threadIdx.x;
+    const uint32_t nw = nWaves[0];
+    if (c == 0) waveStart[nw] = n;
+    if (c > SW_NCFG) return;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t) (sortedKeys[mid] >> 44) < c) lo = mid + 1; else hi = mid; }
+    out[c] = lo;
+    const uint32_t jb = lo;
+    if (c < SW_NCFG) out[32 + c] = jb < n ? (uint32_t) (sortedKeys[jb] & (KEY_CLS - 1)) : 0u;
+    lo = 0; hi = nw;                                                 // first wave starting at or after the job bound
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (waveStart[mid] < jb) lo = mid + 1; else hi = mid; }
+    out[16 + c] = lo;
 }
 
 // first index whose key >= c*KEY_CLS, for c = 0..SW_NCFG; plus the key at that index
@@ -157,7 +190,8 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
         SwLaunch L;
         L.q_res = V.q_res; L.q_bias8 = V.q_bias8; L.t_res = V.t_res; L.mat = V.mat_aln;
         L.jobs = jobs; L.out = out; L.n_jobs = hi - lo; L.order = vb.Current() + lo;
-        L.boundary = nullptr; L.boundary_stride = 0;
+        L.boundary = nullptr; L.boundary_stride = 0; L.boundary_job0 = 0;
+        L.wave_start = nullptr; L.n_waves = 0;
         L.gap_open = P.gap_open; L.gap_extend = P.gap_extend;
         if (c == SW_NCFG - 1 && V.max_q_len > (uint32_t) sw_cfg_rows(c)) {
             const uint32_t cls = KEY_CLS - 1 - (hb[32 + c] % KEY_CLS);          // largest target-length class in this bucket
@@ -170,6 +204,68 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
         snprintf(nm, sizeof(nm), "%s_rows%d", tag, sw_cfg_rows(c));
         th = tb(nm, 0, 0);
         if (handles) handles[c] = th;
+        ACHK(launch_sw(L, c, stream));
+        te(th);
+    }
+    return MK_OK;
+}
+
+// forward pass: jobs sorted by (configuration, query, target length); one wave per (query, <= 64/G targets)
+static int run_shared_fwd(const AlignView &V, const mk_params &P, const SwJob *jobs, SwOut *out, uint64_t *keys, uint32_t *idx,
+                          uint64_t *keys2, uint32_t *idx2, uint32_t n, hipStream_t stream, std::string &err,
+                          timed_begin_fn tb, timed_end_fn te, int *handles /* SW_NCFG */) {
+    for (int c = 0; c < SW_NCFG; c++) handles[c] = -1;
+    if (n == 0) return MK_OK;
+    hipcub::DoubleBuffer<uint64_t> kb(keys, keys2);
+    hipcub::DoubleBuffer<uint32_t> vb(idx, idx2);
+    uint32_t *dHead = (uint32_t *) dev_scratch("align_seghead", (size_t) n * 4);
+    uint8_t *dFlag = (uint8_t *) dev_scratch("align_waveflag", n);
+    uint32_t *dWave = (uint32_t *) dev_scratch("align_wavestart", ((size_t) n + 1) * 4);
+    uint32_t *dNum = (uint32_t *) dev_scratch("align_nwaves", 16);
+    uint32_t *dBounds = (uint32_t *) dev_scratch("align_bounds", 64 * sizeof(uint32_t));
+    uint32_t *hb = (uint32_t *) pinned_scratch("align_bounds_h", 64 * sizeof(uint32_t));
+    ANULL(dHead); ANULL(dFlag); ANULL(dWave); ANULL(dNum); ANULL(dBounds); ANULL(hb);
+    size_t t1 = 0, t2 = 0, t3 = 0;
+    hipcub::CountingInputIterator<uint32_t> iota(0);
+    hipcub::DeviceRadixSort::SortPairs(nullptr, t1, kb, vb, (int) n, 0, 47, stream);
+    hipcub::DeviceScan::InclusiveScan(nullptr, t2, dHead, dHead, hipcub::Max(), (int) n, stream);
+    hipcub::DeviceSelect::Flagged(nullptr, t3, iota, dFlag, dWave, dNum, (int) n, stream);
+    void *temp = dev_scratch("align_sort_temp", std::max(t1, std::max(t2, t3)));
+    ANULL(temp);
+    int th = tb("align_sort", 6.0 * 24.0 * n, 0);
+    ACHK(hipcub::DeviceRadixSort::SortPairs(temp, t1, kb, vb, (int) n, 0, 47, stream));
+    te(th);
+    th = tb("align_waves", 30.0 * n, 0);
+    hipLaunchKernelGGL(seg_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, kb.Current(), n, dHead);
+    ACHK(hipcub::DeviceScan::InclusiveScan(temp, t2, dHead, dHead, hipcub::Max(), (int) n, stream));
+    hipLaunchKernelGGL(wave_flag_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, kb.Current(), dHead, n, dFlag);
+    ACHK(hipcub::DeviceSelect::Flagged(temp, t3, iota, dFlag, dWave, dNum, (int) n, stream));
+    hipLaunchKernelGGL(shared_bounds_kernel, dim3(1), dim3(64), 0, stream, kb.Current(), n, dWave, dNum, dBounds);
+    te(th);
+    ACHK(hipGetLastError());
+    ACHK(hipMemcpyAsync(hb, dBounds, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    ACHK(sync_wait(stream, "wait_align"));
+    for (int c = 0; c < SW_NCFG; c++) {
+        const uint32_t lo = hb[c], hi = hb[c + 1], wlo = hb[16 + c], whi = hb[16 + c + 1];
+        if (hi <= lo || whi <= wlo) continue;
+        SwLaunch L;
+        L.q_res = V.q_res; L.q_bias8 = V.q_bias8; L.t_res = V.t_res; L.mat = V.mat_aln;
+        L.jobs = jobs; L.out = out; L.n_jobs = hi - lo; L.order = vb.Current();      // wave_start holds absolute sorted positions
+        L.boundary = nullptr; L.boundary_stride = 0; L.boundary_job0 = lo;
+        L.wave_start = dWave + wlo; L.n_waves = whi - wlo;
+        L.gap_open = P.gap_open; L.gap_extend = P.gap_extend;
+        if (c == SW_NCFG - 1 && V.max_q_len > (uint32_t) sw_cfg_rows(c)) {
+            // queries beyond the largest tile run in row tiles with an HBM border per job; the border is as long as the
+            // longest target of the bucket (the first key only bounds its own query)
+            const uint32_t stride = V.max_t_len;
+            L.boundary = (uint32_t *) dev_scratch("align_border", (size_t) (hi - lo) * stride * sizeof(uint32_t));
+            ANULL(L.boundary);
+            L.boundary_stride = stride;
+        }
+        char nm[64];
+        snprintf(nm, sizeof(nm), "sw_fwd_rows%d", sw_cfg_rows(c));
+        th = tb(nm, 0, 0);
+        handles[c] = th;
         ACHK(launch_sw(L, c, stream));
         te(th);
     }
@@ -198,12 +294,14 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hi
     ACHK(hipMemcpyAsync(dGate, gate.data(), gate.size() * sizeof(GateEntry), hipMemcpyHostToDevice, stream));
     ACHK(hipMemsetAsync(dOut, 0, (size_t) n * sizeof(SwOut), stream));
     ACHK(hipMemsetAsync(dCount, 0, 16, stream));
-    int th = tb("align_expand", 48.0 * n, 0);
-    hipLaunchKernelGGL(expand_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, V, dHitOff, dHits, (uint64_t) n, dJobs, dKeys, dIdx, dCount + 1);
+    uint64_t *dKeys64 = (uint64_t *) dev_scratch("align_keys64", (size_t) n * 8), *dKeys64b = (uint64_t *) dev_scratch("align_keys64b", (size_t) n * 8);
+    ANULL(dKeys64); ANULL(dKeys64b);
+    int th = tb("align_expand", 52.0 * n, 0);
+    hipLaunchKernelGGL(expand_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, V, dHitOff, dHits, (uint64_t) n, dJobs, dKeys64, dIdx, dCount + 1);
     te(th);
     ACHK(hipGetLastError());
     int hFwd[SW_NCFG], hRev[SW_NCFG];
-    int rc = run_sorted_sw(V, P, dJobs, dOut, dKeys, dIdx, dKeys2, dIdx2, n, "sw_fwd", stream, err, tb, te, hFwd);
+    int rc = run_shared_fwd(V, P, dJobs, dOut, dKeys64, dIdx, dKeys64b, dIdx2, n, stream, err, tb, te, hFwd);
     for (int c = 0; c < SW_NCFG; c++) if (hFwd[c] >= 0 && fwdWork) ts(hFwd[c], fwdWork[2 * c], fwdWork[2 * c + 1]);
     if (rc != MK_OK) return rc;
     // gate + reverse jobs (reuse the key/index buffers; at most n survivors)

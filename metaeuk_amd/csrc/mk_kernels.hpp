@@ -30,6 +30,11 @@ struct SwLaunch {
     uint32_t *boundary;         // multi-tile scratch: per job boundary_stride entries (null when every job is single tile)
     uint32_t boundary_stride;
     int gap_open, gap_extend;
+    // shared-query mode (forward pass of the pipeline): jobs are ordered by query; wave w runs the jobs
+    // [wave_start[w], wave_start[w+1]) -- all of one query, at most 64/G of them -- on ONE LDS query profile.
+    // null: every job builds its own profile (test path, reverse pass).
+    const uint32_t *wave_start; uint64_t n_waves;
+    uint64_t boundary_job0;     // job index that owns the first boundary_stride entries of `boundary`
 };
 
 // tile configurations: G lanes per DP x R rows per lane; a job uses the smallest one whose G*R >= q_len

@@ -61,35 +61,49 @@ __device__ __forceinline__ void load_scores(const int8_t *p, int (&sc)[R]) {
     }
 }
 
-template <int G, int R, int BLOCK>
+template <int G, int R, int BLOCK, bool SHARED>
 __global__ __launch_bounds__(BLOCK) void sw_kernel(SwLaunch L) {
     constexpr int GPB = BLOCK / G;
     constexpr int ROWS = G * R;
+    static_assert(!SHARED || BLOCK == 64, "shared-query mode runs one wave per workgroup");
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     const int lane = threadIdx.x % G;
     const int grp = threadIdx.x / G;
-    const uint64_t jobId = (uint64_t) blockIdx.x * GPB + grp;
-    const bool have = jobId < L.n_jobs;
+    uint64_t jobId;
+    bool have;
     SwJob job;
-    if (have) job = L.jobs[L.order ? (uint64_t) L.order[jobId] : jobId];
-    else { job.t_start = 0; job.q_start = 0; job.q_len = 0; job.t_len = 0; job.q_step = 1; job.t_step = 1; job.slot = 0; }
-    int8_t *prof = smem + (size_t) grp * 22 * ROWS;
+    uint32_t profQStart = 0; int profQStep = 1;       // query whose profile this lane helps to build
+    if constexpr (SHARED) {
+        const uint32_t w0 = L.wave_start[blockIdx.x], w1 = L.wave_start[blockIdx.x + 1];
+        const uint32_t count = min((uint32_t) GPB, w1 - w0);
+        have = (uint32_t) grp < count;
+        jobId = (uint64_t) w0 + (have ? grp : 0);     // idle groups mirror the first job (same query) with no columns
+        job = L.jobs[L.order ? (uint64_t) L.order[jobId] : jobId];
+        if (!have) job.t_len = 0;
+    } else {
+        jobId = (uint64_t) blockIdx.x * GPB + grp;
+        have = jobId < L.n_jobs;
+        if (have) job = L.jobs[L.order ? (uint64_t) L.order[jobId] : jobId];
+        else { job.t_start = 0; job.q_start = 0; job.q_len = 0; job.t_len = 0; job.q_step = 1; job.t_step = 1; job.slot = 0; }
+    }
+    profQStart = job.q_start; profQStep = job.q_step;
+    int8_t *prof = SHARED ? smem : smem + (size_t) grp * 22 * ROWS;
     const int go = L.gap_open, ge = L.gap_extend;
     const int qLen = (int) job.q_len, tLen = (int) job.t_len;
     const int nTiles = (qLen + ROWS - 1) / ROWS;
-    uint32_t *border = L.boundary ? L.boundary + jobId * (uint64_t) L.boundary_stride : nullptr;
+    uint32_t *border = L.boundary ? L.boundary + (jobId - L.boundary_job0) * (uint64_t) L.boundary_stride : nullptr;
 
     uint32_t bestKey = 0;
     int bestRow = 0;
     for (int tile = 0; tile < nTiles; tile++) {
         const int row0 = tile * ROWS;
         // ---- LDS query profile for this row tile: prof[t][row] = mat[t][q_row] + bias8[q_row]; row 21 = zeros ----
-        for (int idx = lane; idx < 22 * ROWS; idx += G) {
+        for (int idx = SHARED ? (int) threadIdx.x : lane; idx < 22 * ROWS; idx += SHARED ? BLOCK : G) {
             const int t = idx / ROWS, row = idx - t * ROWS;
             const int q = row0 + row;
             int v = 0;
             if (t < 21 && q < qLen) {
-                const int64_t qi = (int64_t) job.q_start + (int64_t) q * job.q_step;
+                const int64_t qi = (int64_t) profQStart + (int64_t) q * profQStep;
                 v = (int) L.mat[t * 21 + L.q_res[qi]] + (int) L.q_bias8[qi];
             }
             prof[idx] = (int8_t) v;
@@ -174,17 +188,23 @@ __global__ __launch_bounds__(BLOCK) void sw_kernel(SwLaunch L) {
 
 template <int G, int R, int BLOCK>
 static hipError_t launch_one(const SwLaunch &L, hipStream_t stream) {
+    if (L.wave_start) {                                     // one wave per workgroup, one profile per wave
+        const size_t lds = (size_t) 22 * G * R;
+        if (L.n_waves == 0) return hipSuccess;
+        hipLaunchKernelGGL((sw_kernel<G, R, 64, true>), dim3((unsigned) L.n_waves), dim3(64), lds, stream, L);
+        return hipGetLastError();
+    }
     constexpr int GPB = BLOCK / G;
     const size_t lds = (size_t) GPB * 22 * G * R;
     const uint64_t blocks = (L.n_jobs + GPB - 1) / GPB;
     if (blocks == 0) return hipSuccess;
     static bool attr = false;
     if (!attr && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_kernel<G, R, BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_kernel<G, R, BLOCK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL((sw_kernel<G, R, BLOCK>), dim3((unsigned) blocks), dim3(BLOCK), lds, stream, L);
+    hipLaunchKernelGGL((sw_kernel<G, R, BLOCK, false>), dim3((unsigned) blocks), dim3(BLOCK), lds, stream, L);
     return hipGetLastError();
 }
 
