@@ -49,7 +49,7 @@ EXPORTS = ["mk_init", "mk_last_error", "mk_default_params", "mk_device_name", "m
 def lib():
     global _LIB
     if _LIB is None:
-        path = _build.LIB
+        path = os.environ.get("METAEUK_AMD_LIB") or _build.LIB   # the override serves kernel-variant experiments
         if not os.path.exists(path):
             _build.build()
         L = C.CDLL(path)

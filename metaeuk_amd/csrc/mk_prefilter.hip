@@ -106,7 +106,14 @@ struct __attribute__((packed, aligned(4))) OffPair { uint32_t lo, hi; };
 __device__ __forceinline__ OffPair load_off_pair(const uint32_t *kmerOff, uint32_t kmer) { return *reinterpret_cast<const OffPair *>(kmerOff + kmer); }
 __device__ __forceinline__ bool kmer_present(const uint32_t *bits, uint32_t kmer) { return (bits[kmer >> 5] >> (kmer & 31u)) & 1u; }
 
-constexpr int PROBE_U = 4;        // 64-k-mer groups whose index probes are issued together
+#ifndef MK_PROBE_U
+#define MK_PROBE_U 4
+#endif
+#ifndef MK_T2_WAVES
+#define MK_T2_WAVES 8
+#endif
+constexpr int PROBE_U = MK_PROBE_U;        // 64-k-mer groups whose index probes are issued together (global path)
+constexpr int FUSED_U = 2;                 // ... in the fused kernels (smaller: the window scratch competes with the hit store for LDS)
 
 template <bool GATHER>
 __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
@@ -269,16 +276,22 @@ constexpr uint32_t KEY_SENTINEL = 0xFFFFFFFFu;
 
 struct FusedArgs {
     PrefilterDeviceView V;
-    const uint32_t *queries;          // (global) query ids of this launch, one workgroup each
+    const uint32_t *queries;          // (global) query ids assigned to this tier, one workgroup each ...
+    uint32_t n_own;
+    const uint32_t *prev_list;        // ... followed by the queries that overflowed the next smaller tier (chunk-local ids,
+    const uint32_t *prev_count;       //     count known on the device only; surplus workgroups exit)
     uint32_t n_launch;
     uint32_t q_first;                 // first query of the chunk: candidates carry q - q_first
     CandArrays C; uint32_t cand_cap;
-    uint32_t *counters;               // [0] candidates appended [1] overflowed queries
-    uint32_t *overflow_list;          // chunk-local ids of the queries that did not fit their tier
+    uint32_t *counters;               // [0] candidates appended
+    uint32_t *overflow_list;          // chunk-local ids of the queries that did not fit this tier
+    uint32_t *overflow_count;
     unsigned long long *totals;       // [0] k-mers [1] index hits [2] k-mer start positions (statistics / tier sizing) [3..6] workgroup time: gather, sort, rule+emit, overflowed
 };
 
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
+// k-mer starts a query may have in the tier with `cap` hit slots (bounds the per-position tables in LDS)
+constexpr int fused_max_positions(int cap) { return cap >= 16384 ? 512 : (cap / 8 < 64 ? 64 : (cap / 8 > 1024 ? 1024 : cap / 8)); }
 
 template <int CAP, int NW>
 __global__ __launch_bounds__(NW * 64) void fused_kernel(FusedArgs A) {
@@ -289,66 +302,80 @@ __global__ __launch_bounds__(NW * 64) void fused_kernel(FusedArgs A) {
     __shared__ uint32_t sKey[CAP];                // phase 1: target id; afterwards target << ARR_BITS | arrival
     __shared__ uint16_t sDiag[CAP];
     __shared__ uint32_t sBm1[MBITS / 32], sBm2[MBITS / 32];   // bucket hit once / more than once
-    __shared__ enumk::EnumLds<PROBE_U> sE[NW];
-    __shared__ uint16_t sChunkOf[NW][NCH];        // wave-local chunk number -> physical chunk
+    __shared__ enumk::EnumLds<FUSED_U> sE[NW];
+    constexpr int MAXPOS = fused_max_positions(CAP);
+    __shared__ uint16_t sChunkOf[NW][NCH];        // chunk number within the wave's current position -> physical chunk
     __shared__ uint16_t sRankToChunk[NCH];        // arrival rank of a chunk -> physical chunk
     __shared__ uint16_t sChunkRank[NCH];          // physical chunk -> arrival rank
-    __shared__ uint8_t sOwner[NCH];
-    __shared__ uint32_t sWaveHits[NW], sWaveChunks[NW], sWaveKmers[NW], sWavePos[NW], sWavePrefix[NW + 1];
+    __shared__ uint16_t sChunkPos[NCH], sChunkSeq[NCH];   // owner position of a chunk, its number within that position
+    __shared__ uint16_t sPosChunks[MAXPOS], sPosHits[MAXPOS], sPosBase[MAXPOS];
+    __shared__ uint32_t sWaveHits[NW], sWaveKmers[NW], sWavePos[NW];
+    __shared__ uint32_t sNextPos;
     __shared__ uint32_t sFlagBits[CAP / 32];
     __shared__ uint32_t sWordPrefix[CAP / 32];
     __shared__ uint32_t sBump, sOverflow, sEmitBase;
     __shared__ uint32_t sWaveCnt[NW];
 
     const int tid = threadIdx.x, w = tid / WAVE, lane = tid & (WAVE - 1);
-    const uint32_t q = A.queries[blockIdx.x];
+    uint32_t q;
+    if (blockIdx.x < A.n_own) q = A.queries[blockIdx.x];
+    else {
+        const uint32_t k = blockIdx.x - A.n_own;
+        if (k >= A.prev_count[0]) return;
+        q = A.q_first + A.prev_list[k];
+    }
     const uint64_t qs = A.V.q_off[q];
     const int L = (int) (A.V.q_off[q + 1] - qs);
-    if (tid == 0) { sBump = 0; sOverflow = 0; }
+    const int nStart = L >= 10 ? L - 9 : 0;       // k-mer starts (<= MAXPOS: the host sends longer queries elsewhere)
+    if (tid == 0) { sBump = 0; sOverflow = nStart > MAXPOS ? 1u : 0u; sNextPos = 0; }
     for (int k = tid; k < MBITS / 32; k += BLOCK) { sBm1[k] = 0; sBm2[k] = 0; }
+    for (int k = tid; k < MAXPOS; k += BLOCK) { sPosChunks[k] = 0; sPosHits[k] = 0; }
     __syncthreads();
     const unsigned long long tStart = wall_clock64();
 
-    // ---- phase 1: enumerate + gather into LDS.  Wave w owns a contiguous range of k-mer starts, so arrival order is
-    //      (wave, wave-local slot); slots come in 64-entry chunks from a workgroup-wide bump allocator.
-    const int nStart = L >= 10 ? L - 9 : 0;
-    const int per = (nStart + NW - 1) / NW;
-    const int iBeg = min(nStart, w * per), iEnd = min(nStart, iBeg + per);
-    uint32_t wcount = 0, nCh = 0, kmers = 0, npos = 0;
+    // ---- phase 1: enumerate + gather into LDS.  The waves take the k-mer starts one at a time from a shared counter; the
+    //      hits of a position go to 64-entry chunks from a workgroup-wide bump allocator, so the arrival order of a slot is
+    //      (position, chunk number within the position, offset) whatever wave produced it.
+    uint32_t whits = 0, kmers = 0, npos = 0;
     bool dead = false;
-    for (int i = iBeg; i < iEnd && !dead; i++) {
+    while (!dead) {
+        uint32_t iu = 0;
+        if (lane == 0) iu = atomicAdd(&sNextPos, 1u);
+        const int i = __builtin_amdgcn_readfirstlane((int) iu);
+        if (i >= nStart) break;
         const uint64_t p = qs + (uint64_t) i;
         const int thr = (int) A.V.q_kmer_thr[p];
         if (thr < 0) continue;
         if (*(volatile uint32_t *) &sOverflow) { dead = true; break; }
         npos++;
-        kmers += enumk::enumerate_position<PROBE_U>(A.V, A.V.q_res + p, thr, lane, sE[w],
-            [&](const uint32_t (&kmer)[PROBE_U], const bool (&has)[PROBE_U]) -> bool {
-                uint32_t size[PROBE_U], o0[PROBE_U], ex[PROBE_U];
-                uint64_t ent0[PROBE_U];
+        uint32_t wcount = 0, nCh = 0;               // hits / chunks of this position
+        kmers += enumk::enumerate_position<FUSED_U>(A.V, A.V.q_res + p, thr, lane, sE[w],
+            [&](const uint32_t (&kmer)[FUSED_U], const bool (&has)[FUSED_U]) -> bool {
+                uint32_t size[FUSED_U], o0[FUSED_U], ex[FUSED_U];
+                uint64_t ent0[FUSED_U];
 #pragma unroll
-                for (int u = 0; u < PROBE_U; u++) {
+                for (int u = 0; u < FUSED_U; u++) {
                     size[u] = 0; o0[u] = 0;
                     if (has[u] && kmer_present(A.V.kmer_bits, kmer[u])) { const OffPair o = load_off_pair(A.V.kmer_off, kmer[u]); o0[u] = o.lo; size[u] = o.hi - o.lo; }
                 }
 #pragma unroll
-                for (int u = 0; u < PROBE_U; u++) ent0[u] = size[u] ? A.V.entries[o0[u]] : 0ull;   // first entry of every list (most lists have one)
+                for (int u = 0; u < FUSED_U; u++) ent0[u] = size[u] ? A.V.entries[o0[u]] : 0ull;   // first entry of every list (most lists have one)
                 uint32_t totAll = 0;
 #pragma unroll
-                for (int u = 0; u < PROBE_U; u++) { const uint32_t incl = enumk::wave_incl_scan(size[u]); ex[u] = incl - size[u] + totAll; totAll += enumk::wave_last(incl); }
+                for (int u = 0; u < FUSED_U; u++) { const uint32_t incl = enumk::wave_incl_scan(size[u]); ex[u] = incl - size[u] + totAll; totAll += enumk::wave_last(incl); }
                 if (totAll == 0) return true;
                 while (nCh * WAVE < wcount + totAll) {                  // wave-uniform: more slots for these groups
                     uint32_t c = 0;
                     if (lane == 0) c = atomicAdd(&sBump, 1u);
                     c = (uint32_t) __builtin_amdgcn_readfirstlane((int) c);
                     if (c >= (uint32_t) NCH) { dead = true; break; }
-                    if (lane == 0) { sChunkOf[w][nCh] = (uint16_t) c; sOwner[c] = (uint8_t) w; }
+                    if (lane == 0) { sChunkOf[w][nCh] = (uint16_t) c; sChunkPos[c] = (uint16_t) i; sChunkSeq[c] = (uint16_t) nCh; }
                     nCh++;
                 }
                 if (dead) { if (lane == 0) sOverflow = 1; return false; }
                 wave_sync_lds();
 #pragma unroll
-                for (int u = 0; u < PROBE_U; u++) {
+                for (int u = 0; u < FUSED_U; u++) {
                     const uint32_t v0 = wcount + ex[u];
                     for (uint32_t e = 0; e < size[u]; e++) {
                         const uint64_t ent = e == 0 ? ent0[u] : A.V.entries[o0[u] + e];
@@ -365,34 +392,40 @@ __global__ __launch_bounds__(NW * 64) void fused_kernel(FusedArgs A) {
                 wcount += totAll;
                 return true;
             });
+        if (lane == 0) { sPosChunks[i] = (uint16_t) nCh; sPosHits[i] = (uint16_t) wcount; }
+        whits += wcount;
     }
-    if (lane == 0) { sWaveHits[w] = wcount; sWaveChunks[w] = nCh; sWaveKmers[w] = kmers; sWavePos[w] = npos; atomicAdd(&A.totals[7], (wall_clock64() - tStart) / NW); }
+    if (lane == 0) { sWaveHits[w] = whits; sWaveKmers[w] = kmers; sWavePos[w] = npos; atomicAdd(&A.totals[7], (wall_clock64() - tStart) / NW); }
     __syncthreads();
     const unsigned long long tGather = wall_clock64();
     if (sOverflow) {                                   // does not fit this tier: the global path takes the query
-        if (tid == 0) { A.overflow_list[atomicAdd(&A.counters[1], 1u)] = q - A.q_first; atomicAdd(&A.totals[6], tGather - tStart); atomicAdd(&A.totals[8], 1ull); }
+        if (tid == 0) { A.overflow_list[atomicAdd(A.overflow_count, 1u)] = q - A.q_first; atomicAdd(&A.totals[6], tGather - tStart); atomicAdd(&A.totals[8], 1ull); }
         return;
     }
     if (tid == 0) {
-        uint32_t acc = 0, hits = 0, km = 0, np = 0;
-        for (int k = 0; k < NW; k++) { sWavePrefix[k] = acc; acc += sWaveChunks[k]; hits += sWaveHits[k]; km += sWaveKmers[k]; np += sWavePos[k]; }
-        sWavePrefix[NW] = acc;
+        uint32_t hits = 0, km = 0, np = 0;
+        for (int k = 0; k < NW; k++) { hits += sWaveHits[k]; km += sWaveKmers[k]; np += sWavePos[k]; }
         atomicAdd(&A.totals[0], (unsigned long long) km);
         atomicAdd(&A.totals[1], (unsigned long long) hits);
         atomicAdd(&A.totals[2], (unsigned long long) np);
     }
-    __syncthreads();
-    const uint32_t nChunks = sWavePrefix[NW];
+    const uint32_t nChunks = sBump;
     if (nChunks == 0) return;
     const uint32_t used = nChunks * WAVE;
-    // chunk ranks (arrival order of the chunks)
-    for (uint32_t k = (uint32_t) tid; k < (uint32_t) NW * NCH; k += BLOCK) {
-        const uint32_t ww = k / NCH, kk = k % NCH;
-        if (kk < sWaveChunks[ww]) {
-            const uint32_t c = sChunkOf[ww][kk], rank = sWavePrefix[ww] + kk;
-            sRankToChunk[rank] = (uint16_t) c;
-            sChunkRank[c] = (uint16_t) rank;
-        }
+    // chunk ranks: exclusive prefix of the chunk counts over the positions (one wave), then rank = base(position) + number
+    if (w == 0) {
+        const uint32_t perLane = ((uint32_t) nStart + WAVE - 1) / WAVE;
+        const uint32_t b = min((uint32_t) nStart, (uint32_t) lane * perLane), e = min((uint32_t) nStart, b + perLane);
+        uint32_t sum = 0;
+        for (uint32_t k = b; k < e; k++) sum += sPosChunks[k];
+        uint32_t run = enumk::wave_incl_scan(sum) - sum;
+        for (uint32_t k = b; k < e; k++) { sPosBase[k] = (uint16_t) run; run += sPosChunks[k]; }
+    }
+    __syncthreads();
+    for (uint32_t c = (uint32_t) tid; c < nChunks; c += BLOCK) {
+        const uint32_t rank = (uint32_t) sPosBase[sChunkPos[c]] + sChunkSeq[c];
+        sRankToChunk[rank] = (uint16_t) c;
+        sChunkRank[c] = (uint16_t) rank;
     }
     __syncthreads();
     // Only targets hit more than once can satisfy the double-diagonal rule, plus single hits whose diagonal low byte is 0
@@ -404,9 +437,9 @@ __global__ __launch_bounds__(NW * 64) void fused_kernel(FusedArgs A) {
         bool surv = false;
         uint32_t key = KEY_SENTINEL;
         if (s < used) {
-            const uint32_t c = s >> 6, rank = sChunkRank[c], ww = sOwner[c];
-            const uint32_t v = (rank - sWavePrefix[ww]) * WAVE + (s & 63u);   // wave-local slot number
-            if (v < sWaveHits[ww]) {
+            const uint32_t c = s >> 6, rank = sChunkRank[c];
+            const uint32_t v = (uint32_t) sChunkSeq[c] * WAVE + (s & 63u);    // slot number within the position
+            if (v < (uint32_t) sPosHits[sChunkPos[c]]) {
                 const uint32_t tgt = sKey[s];
                 const uint32_t hb = (tgt * 2654435761u) >> (32 - LOG_MBITS);
                 surv = ((sBm2[hb >> 5] >> (hb & 31u)) & 1u) || ((uint32_t) sDiag[s] & 0xFFu) == 0u;
@@ -511,13 +544,13 @@ struct FusedTier { int cap; int waves; };
 constexpr int N_TIERS = 4;
 // production tiers, then a miniature set (MK_PREFILTER_TIERS=tiny) with which small test inputs exercise every
 // workgroup shape, the overflow hand-over and the global path
-const FusedTier TIERS[2 * N_TIERS] = {{2048, 4}, {4096, 4}, {8192, 8}, {16384, 16}, {256, 4}, {512, 4}, {1024, 8}, {2048, 16}};
+const FusedTier TIERS[2 * N_TIERS] = {{2048, 4}, {4096, 4}, {8192, MK_T2_WAVES}, {16384, 16}, {256, 4}, {512, 4}, {1024, 8}, {2048, 16}};
 
 void launch_fused(int tier, const FusedArgs &A, hipStream_t stream) {
     switch (tier) {
         case 0: hipLaunchKernelGGL((fused_kernel<2048, 4>), dim3(A.n_launch), dim3(256), 0, stream, A); break;
         case 1: hipLaunchKernelGGL((fused_kernel<4096, 4>), dim3(A.n_launch), dim3(256), 0, stream, A); break;
-        case 2: hipLaunchKernelGGL((fused_kernel<8192, 8>), dim3(A.n_launch), dim3(512), 0, stream, A); break;
+        case 2: hipLaunchKernelGGL((fused_kernel<8192, MK_T2_WAVES>), dim3(A.n_launch), dim3(64 * MK_T2_WAVES), 0, stream, A); break;
         case 3: hipLaunchKernelGGL((fused_kernel<16384, 16>), dim3(A.n_launch), dim3(1024), 0, stream, A); break;
         case 4: hipLaunchKernelGGL((fused_kernel<256, 4>), dim3(A.n_launch), dim3(256), 0, stream, A); break;
         case 5: hipLaunchKernelGGL((fused_kernel<512, 4>), dim3(A.n_launch), dim3(256), 0, stream, A); break;
@@ -636,7 +669,12 @@ int self_score(const SubMat &ung, const uint8_t *q, const int8_t *corr, int L) {
 }
 
 // sizing state carried from one batch to the next (same database): index hits per similar k-mer, candidates per query
-struct SizingMemo { const void *entries = nullptr; uint32_t nTargets = 0; double hitsPerKmer = 0, candPerQuery = 0; };
+struct SizingMemo {
+    const void *entries = nullptr; uint32_t nTargets = 0;
+    double candPerQuery = 0;
+    double hitsPerKmer[4] = {0, 0, 0, 0};     // per LDS tier (short fragments and long ORFs differ in composition)
+    double margin[4] = {1.15, 1.15, 1.15, 1.15};
+};
 SizingMemo g_memo;
 
 }  // namespace
@@ -815,7 +853,8 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     }
     const FusedTier *tiers = TIERS + tierBase;
     if (g_memo.entries != (const void *) V.entries || g_memo.nTargets != V.n_targets) { g_memo = SizingMemo(); g_memo.entries = V.entries; g_memo.nTargets = V.n_targets; }
-    double hitsPerKmer = g_memo.hitsPerKmer, candPerQuery = g_memo.candPerQuery, globalHitsPerPos = 0;
+    double candPerQuery = g_memo.candPerQuery, globalHitsPerPos = 0;
+    static_assert(N_TIERS == 4, "SizingMemo holds four tiers");
     SubMat ungMat;
     build_submat(ungMat, MAT_BLOSUM62, 2.0f, -0.2f);
 
@@ -872,42 +911,51 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             }
             {
                 ScopedHost sh("host_prefilter_tiers");
-                const double hpk = hitsPerKmer > 0 ? hitsPerKmer : std::max(0.05, (double) V.n_entries / 64.0e6);
+                double limit[N_TIERS];                                      // most k-mers a query may have to be tried in tier t
+                for (int t = 0; t < N_TIERS; t++) {
+                    const double hpk = g_memo.hitsPerKmer[t] > 0 ? g_memo.hitsPerKmer[t] : std::max(0.05, (double) V.n_entries / 64.0e6);
+                    limit[t] = ((double) tiers[t].cap - 32.0 * tiers[t].waves) / (hpk * g_memo.margin[t]);   // half a 64-slot chunk lost per wave
+                }
                 for (uint32_t ql = 0; ql < nqc; ql++) {
                     if (hQK[ql] == 0) continue;                             // no k-mer: no hits
-                    const double est = hpk * (double) hQK[ql] * 1.12;       // + half a 64-slot chunk lost per wave
+                    const double km = (double) hQK[ql];
+                    const int npos = (int) (qOff[(size_t) q0 + ql + 1] - qOff[(size_t) q0 + ql]) - 9;
                     int t = 0;
-                    while (t < N_TIERS && est + 32.0 * tiers[t].waves > (double) tiers[t].cap) t++;
+                    while (t < N_TIERS && (km > limit[t] || npos > fused_max_positions(tiers[t].cap))) t++;
                     if (t == N_TIERS) fallback.push_back(ql); else lists[t].push_back(q0 + ql);
                 }
                 for (int t = 0; t < N_TIERS; t++) nListed += lists[t].size();
                 hList = (uint32_t *) pinned_scratch("pf_flist_h", std::max<size_t>(nListed, 1) * 4);
                 dList = (uint32_t *) dev_scratch("pf_flist", std::max<size_t>(nListed, 1) * 4);
-                dOvf = (uint32_t *) dev_scratch("pf_fovf", (size_t) nqc * 4);
+                dOvf = (uint32_t *) dev_scratch("pf_fovf", (size_t) nqc * 4 * N_TIERS);
                 PNULL(hList); PNULL(dList); PNULL(dOvf);
                 size_t at = 0;
                 for (int t = 0; t < N_TIERS; t++) { if (!lists[t].empty()) std::memcpy(hList + at, lists[t].data(), lists[t].size() * 4); at += lists[t].size(); }
             }
             PCHK(hipMemcpyAsync(dList, hList, nListed * 4, hipMemcpyHostToDevice, stream));
-            PCHK(hipMemsetAsync(dCounters, 0, 16, stream));
+            PCHK(hipMemsetAsync(dCounters, 0, 64, stream));
             PCHK(hipMemsetAsync(dFTotals, 0, 16 * 8 * N_TIERS, stream));
             int thFused[N_TIERS];
-            size_t at = 0;
+            size_t at = 0, lower = 0;                                       // lower: queries of the smaller tiers (bound on what can overflow into this one)
             for (int t = 0; t < N_TIERS; t++) {
                 thFused[t] = -1;
-                if (lists[t].empty()) continue;
-                FusedArgs A;
-                A.V = V; A.queries = dList + at; A.n_launch = (uint32_t) lists[t].size(); A.q_first = q0;
-                A.C = C; A.cand_cap = CAND_CAP; A.counters = dCounters; A.overflow_list = dOvf; A.totals = dFTotals + 16 * t;
-                char nm[48];
-                snprintf(nm, sizeof(nm), "prefilter_fused_lds%d", tiers[t].cap);
-                thFused[t] = tb(nm, 0, 0);
-                launch_fused(tierBase + t, A, stream);
-                te(thFused[t]);
-                PCHK(hipGetLastError());
-                at += lists[t].size();
+                const size_t grid = lists[t].size() + lower;
+                if (grid > 0) {
+                    FusedArgs A;
+                    A.V = V; A.queries = dList + at; A.n_own = (uint32_t) lists[t].size(); A.n_launch = (uint32_t) grid; A.q_first = q0;
+                    A.prev_list = t > 0 ? dOvf + (size_t) (t - 1) * nqc : nullptr; A.prev_count = t > 0 ? dCounters + 4 + (t - 1) : dCounters + 15;   // [15] stays 0
+                    A.C = C; A.cand_cap = CAND_CAP; A.counters = dCounters;
+                    A.overflow_list = dOvf + (size_t) t * nqc; A.overflow_count = dCounters + 4 + t; A.totals = dFTotals + 16 * t;
+                    char nm[48];
+                    snprintf(nm, sizeof(nm), "prefilter_fused_lds%d", tiers[t].cap);
+                    thFused[t] = tb(nm, 0, 0);
+                    launch_fused(tierBase + t, A, stream);
+                    te(thFused[t]);
+                    PCHK(hipGetLastError());
+                }
+                at += lists[t].size(); lower += lists[t].size();
             }
-            PCHK(hipMemcpyAsync(hCounters, dCounters, 16, hipMemcpyDeviceToHost, stream));
+            PCHK(hipMemcpyAsync(hCounters, dCounters, 64, hipMemcpyDeviceToHost, stream));
             PCHK(hipMemcpyAsync(hFTotals + 16, dFTotals, 16 * 8 * N_TIERS, hipMemcpyDeviceToHost, stream));
             PCHK(sync_wait(stream, "wait_prefilter"));
             for (int k = 0; k < 16; k++) { hFTotals[k] = 0; for (int t = 0; t < N_TIERS; t++) hFTotals[k] += hFTotals[16 * (t + 1) + k]; }
@@ -917,7 +965,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                     fprintf(stderr, "[prefilter]   tier %d (lds %d): queries %zu overflowed %llu | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g sort %.3g emit %.3g overflowed %.3g\n",
                             t, tiers[t].cap, lists[t].size(), T[8], (double) T[0], (double) T[1], (double) T[2], (double) T[3], (double) T[4], (double) T[5], (double) T[6]);
                 }
-            const uint32_t nOvf = hCounters[1];
+            const uint32_t nOvf = hCounters[4 + N_TIERS - 1];                  // what even the largest tier could not hold
             if (hCounters[0] > CAND_CAP) rc = RC_CAND_OVERFLOW;
             else {
                 nCand = hCounters[0];
@@ -932,11 +980,21 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                     fprintf(stderr, "[prefilter] chunk %u..%u: tiers %zu/%zu/%zu/%zu too-long %zu overflow %u | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g (mean wave %.3g) sort %.3g emit %.3g overflowed %.3g | cand %u\n",
                             q0, q1, lists[0].size(), lists[1].size(), lists[2].size(), lists[3].size(), fallback.size(), nOvf, (double) hFTotals[0], (double) hFTotals[1],
                             (double) hFTotals[2], (double) hFTotals[3], (double) hFTotals[7], (double) hFTotals[4], (double) hFTotals[5], (double) hFTotals[6], nCand);
-                if (hFTotals[0] > 0) hitsPerKmer = std::max(0.01, (double) hFTotals[1] / (double) hFTotals[0]);
+                // per tier: hits per similar k-mer of the queries that fitted, and a safety margin that follows the overflow rate
+                for (int t = 0; t < N_TIERS; t++) {
+                    const unsigned long long *T = hFTotals + 16 * (t + 1);
+                    if (T[0] > 0) g_memo.hitsPerKmer[t] = std::max(0.01, (double) T[1] / (double) T[0]);
+                    const double tried = (double) lists[t].size() + (t > 0 ? (double) hCounters[4 + t - 1] : 0.0);
+                    if (tried >= 256) {
+                        const double frac = (double) hCounters[4 + t] / tried;
+                        if (frac > 0.04) g_memo.margin[t] = std::min(3.0, g_memo.margin[t] * 1.08);
+                        else if (frac < 0.01) g_memo.margin[t] = std::max(1.05, g_memo.margin[t] * 0.98);
+                    }
+                }
                 if (nOvf > 0) {
                     uint32_t *hOvf = (uint32_t *) pinned_scratch("pf_fovf_h", (size_t) nOvf * 4);
                     PNULL(hOvf);
-                    PCHK(hipMemcpyAsync(hOvf, dOvf, (size_t) nOvf * 4, hipMemcpyDeviceToHost, stream));
+                    PCHK(hipMemcpyAsync(hOvf, dOvf + (size_t) (N_TIERS - 1) * nqc, (size_t) nOvf * 4, hipMemcpyDeviceToHost, stream));
                     PCHK(sync_wait(stream, "wait_prefilter"));
                     fallback.insert(fallback.end(), hOvf, hOvf + nOvf);
                     std::sort(fallback.begin(), fallback.end());
@@ -1143,7 +1201,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
         }
         q0 = q1;
     }
-    g_memo.hitsPerKmer = hitsPerKmer; g_memo.candPerQuery = candPerQuery;
+    g_memo.candPerQuery = candPerQuery;
     (void) tOff;
     PCHK(sync_wait(stream, "wait_prefilter"));         // the last DMA into the result block
     return MK_OK;
