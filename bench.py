@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--contigs", type=int, default=10000)
     ap.add_argument("--targets", type=int, default=100000)
     ap.add_argument("--seed", type=int, default=11)
+    ap.add_argument("--two-calls", action="store_true", help="mk_prefilter then mk_align instead of the pipelined mk_search")
     ap.add_argument("--cpu-sample", type=int, default=400000, help="queries in the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -122,8 +123,11 @@ def main():
 
     def step():
         q = api.Queries.from_codes(q_res, q_off, params)
-        hits, hoff = api.prefilter(db, q)
-        alns, aoff = api.align(db, q)
+        if args.two_calls:
+            hits, hoff = api.prefilter(db, q)
+            alns, aoff = api.align(db, q)
+        else:
+            (hits, hoff), (alns, aoff) = api.search(db, q)
         res = (int(hoff[-1]), int(aoff[-1]))
         q.close()
         return res

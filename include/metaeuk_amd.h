@@ -119,6 +119,11 @@ int mk_prefilter_result_set(mk_queries *q, const mk_hit *hits, const uint64_t *o
 int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *params);
 int mk_align_result(const mk_queries *q, const mk_alignment **alns, const uint64_t **offsets /* n+1 */);
 
+/* ---- prefilter + align of the batch in one pipelined pass: the `search` workflow's two module calls
+ * (blastp.sh:70,85 via predictexons.sh:68).  Same results as mk_prefilter followed by mk_align (both result
+ * getters work afterwards); the stages run concurrently on two HIP streams, chunk by chunk. */
+int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *params);
+
 /* ---- kernel-level entry points (used by the parity tests and bench.py) ---- */
 /* Smith-Waterman on explicit pairs: for pair p, query q_idx[p] vs target t_idx[p].
  * out5[p*5..] = score, q_end, t_end, q_start, t_start (starts = -1 unless with_start). */

@@ -42,7 +42,7 @@ HIT_DTYPE = np.dtype([("seq_id", "<u4"), ("pref_score", "<i4"), ("diagonal", "<u
 EXPORTS = ["mk_init", "mk_last_error", "mk_default_params", "mk_device_name", "mk_encode", "mk_targetdb_create",
            "mk_targetdb_destroy", "mk_targetdb_residues", "mk_targetdb_index_entries", "mk_targetdb_masked",
            "mk_queries_create", "mk_queries_destroy", "mk_queries_derived", "mk_prefilter", "mk_prefilter_result", "mk_prefilter_result_set",
-           "mk_align", "mk_align_result", "mk_sw_pairs", "mk_ungapped",
+           "mk_align", "mk_align_result", "mk_search", "mk_sw_pairs", "mk_ungapped",
            "mk_kernel_stats", "mk_kernel_stats_reset", "mk_format_hit", "mk_format_alignment"]
 
 
@@ -183,10 +183,21 @@ def prefilter_result(q):
     return raw.view(HIT_DTYPE), off
 
 
+def search(db, q, params=None):
+    """prefilter + align in one pipelined pass -> ((hits, hit_offsets), (alignments, aln_offsets))"""
+    p = params or db.params
+    _chk(lib().mk_search(db.h, q.h, C.byref(p)))
+    return prefilter_result(q), align_result(q)
+
+
 def align(db, q, params=None):
     """-> (ctypes array of Alignment [total], offsets uint64[n+1])"""
     p = params or db.params
     _chk(lib().mk_align(db.h, q.h, C.byref(p)))
+    return align_result(q)
+
+
+def align_result(q):
     ap, op = C.c_void_p(), C.c_void_p()
     _chk(lib().mk_align_result(q.h, C.byref(ap), C.byref(op)))
     off = np.ctypeslib.as_array(C.cast(op, C.POINTER(C.c_uint64)), shape=(q.n + 1,))

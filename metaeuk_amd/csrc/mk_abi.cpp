@@ -14,8 +14,13 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <omp.h>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -38,29 +43,38 @@ int g_device = -1;
 hipStream_t g_stream = nullptr;
 
 // ---- per-kernel timing (HIP events on the library's stream) and host-phase wall clock -------------
+// The two stages of mk_search run on two host threads with one stream each: pending events are per thread, the
+// accumulators are shared.
 struct StatAcc { double ms = 0; uint64_t launches = 0; double bytes = 0; double cells = 0; };
 std::map<std::string, StatAcc> g_stats;
+std::mutex g_statsMutex;
 std::vector<std::string> g_statNames;
+hipStream_t g_stream2 = nullptr;                         // alignment stage of mk_search
+thread_local hipStream_t t_stream = nullptr;             // stream of the calling thread's stage (null: g_stream)
+hipStream_t cur_stream() { return t_stream ? t_stream : g_stream; }
 
 struct Timed { hipEvent_t a{}, b{}; std::string name; double bytes; double cells; };
-std::vector<Timed> g_pending;
+thread_local std::vector<Timed> g_pending;
 
 int timed_begin(const char *name, double bytes, double cells) {
     Timed t; t.name = name; t.bytes = bytes; t.cells = cells;
     if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return -1;
-    (void) hipEventRecord(t.a, g_stream);
+    (void) hipEventRecord(t.a, cur_stream());
     g_pending.push_back(t);
     return (int) g_pending.size() - 1;
 }
-void timed_end(int h) { if (h >= 0) (void) hipEventRecord(g_pending[h].b, g_stream); }
+void timed_end(int h) { if (h >= 0) (void) hipEventRecord(g_pending[h].b, cur_stream()); }
 void timed_set(int h, double bytes, double cells) { if (h >= 0 && h < (int) g_pending.size()) { g_pending[h].bytes = bytes; g_pending[h].cells = cells; } }
 void timed_flush() {
     for (Timed &t : g_pending) {
         float ms = 0;
         (void) hipEventSynchronize(t.b);
         (void) hipEventElapsedTime(&ms, t.a, t.b);
-        StatAcc &s = g_stats[t.name];
-        s.ms += ms; s.launches += 1; s.bytes += t.bytes; s.cells += t.cells;
+        {
+            std::lock_guard<std::mutex> g(g_statsMutex);
+            StatAcc &s = g_stats[t.name];
+            s.ms += ms; s.launches += 1; s.bytes += t.bytes; s.cells += t.cells;
+        }
         (void) hipEventDestroy(t.a); (void) hipEventDestroy(t.b);
     }
     g_pending.clear();
@@ -69,7 +83,11 @@ void timed_flush() {
 struct HostTimer {
     std::string name; std::chrono::steady_clock::time_point t0;
     explicit HostTimer(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {}
-    ~HostTimer() { g_stats[name].ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+    ~HostTimer() {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        std::lock_guard<std::mutex> g(g_statsMutex);
+        g_stats[name].ms += ms;
+    }
 };
 
 template <typename T>
@@ -92,7 +110,7 @@ struct DevBuf {
 }  // namespace
 
 namespace mk {
-void host_stat(const char *name, double ms) { g_stats[name].ms += ms; }
+void host_stat(const char *name, double ms) { std::lock_guard<std::mutex> g(g_statsMutex); g_stats[name].ms += ms; }
 hipError_t sync_wait(hipStream_t stream, const char *statName) {
     const double t0 = ScopedHost::now_ms();
     const hipError_t e = hipStreamSynchronize(stream);
@@ -199,7 +217,7 @@ int run_sw_jobs(const mk_targetdb *db, const mk_queries *q, const mk_params *P, 
         L.q_res = q->dRes.p; L.q_bias8 = q->dBias8.p; L.t_res = db->dRes.p; L.mat = db->dMatAln.p;
         L.jobs = dJobs.p + lo; L.out = dOut.p; L.n_jobs = hi - lo; L.order = nullptr;
         L.boundary = nullptr; L.boundary_stride = 0; L.boundary_job0 = 0;
-        L.wave_start = nullptr; L.n_waves = 0;
+        L.wave_start = nullptr; L.n_waves = 0; L.work_counter = nullptr; L.persistent_blocks = 0;
         L.gap_open = P->gap_open; L.gap_extend = P->gap_extend;
         double cells = 0, bytes = 0;
         uint32_t maxT = 0; bool multi = false;
@@ -234,12 +252,14 @@ int mk_host_threads(void) { return effective_cpus(); }
 
 int mk_init(int device) {
     if (!getenv("OMP_NUM_THREADS")) omp_set_num_threads(effective_cpus());
+    kmp_set_blocktime(0);                                   // idle team threads sleep: two stages share the host cores in mk_search
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) return fail(MK_ERR_DEVICE, "no HIP device visible (%s)", hipGetErrorString(e));
     if (device < 0 || device >= count) return fail(MK_ERR_ARG, "device ordinal %d out of range (%d devices)", device, count);
     HIPCHK(hipSetDevice(device));
     if (!g_stream) HIPCHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    if (!g_stream2) HIPCHK(hipStreamCreateWithFlags(&g_stream2, hipStreamNonBlocking));
     g_device = device;
     g_ready = true;
     return MK_OK;
@@ -457,22 +477,26 @@ int mk_ungapped(mk_targetdb *db, mk_queries *q, const uint32_t *qIdx, const uint
     return MK_OK;
 }
 
-int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *P) {
-    int rc = ensure_ready();
-    if (rc) return rc;
-    if (!db || !q || !P) return fail(MK_ERR_ARG, "null argument");
+static mk::PrefilterDeviceView prefilter_view(const mk_targetdb *db, const mk_queries *q) {
     mk::PrefilterDeviceView V;
     V.q_res = q->dRes.p; V.q_off = q->dOff.p; V.q_kmer_thr = q->dKmerThr.p; V.q_corr = q->dCorr.p; V.n_queries = q->n;
     V.t_masked = db->dMasked.p; V.t_off = db->dOff.p; V.n_targets = db->n;
     V.kmer_off = db->dKmerOff.p; V.kmer_bits = db->dKmerBits.p; V.entries = db->dEntries.p; V.score3 = db->dScore3.p; V.index3 = db->dIndex3.p;
     V.hist3 = db->dHist3.p; V.cum3 = db->dCum3.p; V.hist_lo = db->histLo; V.hist_range = db->histRange; V.n_entries = db->nEntries;
     V.mat_ung = db->dMatUng.p;
+    return V;
+}
+
+int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *P) {
+    int rc = ensure_ready();
+    if (rc) return rc;
+    if (!db || !q || !P) return fail(MK_ERR_ARG, "null argument");
     std::string err;
     const int binCount = mk::bin_count_for(db->n, P->host_l2_bytes);
     {
         HostTimer ht("host_prefilter_total");
-        rc = mk::run_prefilter(V, q->off, q->res, nullptr, db->off, *P, binCount, g_stream, q->hits, q->nHits, q->hitOff, err,
-                               timed_begin, timed_end, timed_set);
+        rc = mk::run_prefilter(prefilter_view(db, q), q->off, q->res, nullptr, db->off, *P, binCount, g_stream, q->hits, q->nHits, q->hitOff, err,
+                               timed_begin, timed_end, timed_set, mk::PrefilterHooks());
     }
     timed_flush();
     if (rc != MK_OK) return fail(rc, "%s", err.c_str());
@@ -499,16 +523,17 @@ int mk_prefilter_result_set(mk_queries *q, const mk_hit *hits, const uint64_t *o
     return MK_OK;
 }
 
-// Alignment::run over the batch (Alignment.cpp:312-514): SW on the device, then Matcher::getSWResult's
-// float/double tail (Matcher.cpp:60-142), Alignment::checkCriteria (:548-567) and the per-query sort (:403-405)
-int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *P) {
-    int rc = ensure_ready();
-    if (rc) return rc;
-    if (!db || !q || !P) return fail(MK_ERR_ARG, "null argument");
-    if (!q->havePref) return fail(MK_ERR_ARG, "mk_align: the batch has no prefilter result");
-    HostTimer htAll("host_align_total");
-    const size_t n = q->nHits;
-    const mk_hit *hits = (const mk_hit *) q->hits.p;
+// Alignment::run over the queries [q0, q1) (Alignment.cpp:312-514): SW on the device, then Matcher::getSWResult's
+// float/double tail (Matcher.cpp:60-142), Alignment::checkCriteria (:548-567) and the per-query sort (:403-405).
+// Appends the accepted alignments at alns[nAlnOut...] and fills alnOff[q0+1 .. q1].
+static int align_range(mk_targetdb *db, mk_queries *q, const mk_params *P, uint32_t q0, uint32_t q1, const std::vector<mk::GateEntry> &gate,
+                       hipStream_t stream, size_t &nAlnOut) {
+    const uint32_t nqc = q1 - q0;
+    const uint64_t h0 = q->hitOff[q0];
+    const size_t n = (size_t) (q->hitOff[q1] - h0);
+    const mk_hit *hits = (const mk_hit *) q->hits.p + h0;
+    std::vector<uint64_t> hitOff((size_t) nqc + 1);            // pair offsets of the range
+    for (uint32_t i = 0; i <= nqc; i++) hitOff[i] = q->hitOff[(size_t) q0 + i] - h0;
     double work[2 * mk::SW_NCFG];
     for (int c = 0; c < 2 * mk::SW_NCFG; c++) work[c] = 0;
     {
@@ -518,10 +543,10 @@ int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *P) {
             double w[2 * mk::SW_NCFG];
             for (int c = 0; c < 2 * mk::SW_NCFG; c++) w[c] = 0;
 #pragma omp for schedule(static) nowait
-            for (uint32_t i = 0; i < q->n; i++) {
-                const uint32_t qLen = (uint32_t) (q->off[i + 1] - q->off[i]);
+            for (uint32_t i = 0; i < nqc; i++) {
+                const uint32_t qLen = (uint32_t) (q->off[(size_t) q0 + i + 1] - q->off[(size_t) q0 + i]);
                 const int c = mk::sw_cfg_of(qLen);
-                for (uint64_t h = q->hitOff[i]; h < q->hitOff[i + 1]; h++) {
+                for (uint64_t h = hitOff[i]; h < hitOff[i + 1]; h++) {
                     const uint32_t t = hits[h].seq_id;
                     const uint32_t tLen = t < db->n ? (uint32_t) (db->off[t + 1] - db->off[t]) : 0;
                     w[2 * c] += (double) tLen + 2.0 * qLen + sizeof(mk::SwJob) + sizeof(mk::SwOut);
@@ -532,37 +557,33 @@ int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *P) {
             for (int c = 0; c < 2 * mk::SW_NCFG; c++) work[c] += w[c];
         }
     }
-    std::vector<mk::GateEntry> gate;
-    {
-        HostTimer ht("host_gate_table");
-        mk::build_gate_table(db->evaluer, P->evalue_thr, q->off, gate);
-    }
+    mk::AlignView V = align_view(db, q);
+    V.q_off = q->dOff.p + q0; V.n_queries = nqc;
     const mk::AlnRaw *raw = nullptr;
     size_t m = 0;
     std::string err;
-    rc = mk::run_align_device(align_view(db, q), q->hitOff.data(), hits, n, gate, *P, g_stream, work, &raw, &m, err,
-                              timed_begin, timed_end, timed_set);
+    int rc = mk::run_align_device(V, hitOff.data(), hits, n, gate, *P, stream, work, &raw, &m, err, timed_begin, timed_end, timed_set);
     timed_flush();
     if (rc != MK_OK) return fail(rc, "%s", err.c_str());
     HostTimer ht("host_align_assemble");
     // raw is ordered by pair index == by query: query i owns raw[first[i] .. first[i+1])
-    std::vector<uint64_t> first((size_t) q->n + 1);
+    std::vector<uint64_t> first((size_t) nqc + 1);
 #pragma omp parallel for schedule(static)
-    for (uint32_t i = 0; i <= q->n; i++) {
-        const uint64_t want = i < q->n ? q->hitOff[i] : (uint64_t) n;
+    for (uint32_t i = 0; i <= nqc; i++) {
+        const uint64_t want = i < nqc ? hitOff[i] : (uint64_t) n;
         size_t lo = 0, hi = m;                         // first record with pair >= want
         while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (raw[mid].pair < want) lo = mid + 1; else hi = mid; }
         first[i] = lo;
     }
     // records are written at their upper-bound position; rejected ones (rare) leave holes that are closed afterwards
-    if (!q->alns.reserve(std::max<size_t>(m, 1) * sizeof(mk_alignment), 0)) return fail(MK_ERR_DEVICE, "pinned host allocation failed");
-    mk_alignment *alns = (mk_alignment *) q->alns.p;
-    std::vector<uint32_t> cnt(q->n);
+    if (!q->alns.reserve(std::max<size_t>(nAlnOut + m, 1) * sizeof(mk_alignment), nAlnOut * sizeof(mk_alignment))) return fail(MK_ERR_DEVICE, "pinned host allocation failed");
+    mk_alignment *alns = (mk_alignment *) q->alns.p + nAlnOut;
+    std::vector<uint32_t> cnt(nqc);
     int mismatch = 0;
     uint64_t holes = 0;
 #pragma omp parallel for schedule(dynamic, 512) reduction(+ : mismatch, holes)
-    for (uint32_t i = 0; i < q->n; i++) {
-        const int qLen = (int) (q->off[i + 1] - q->off[i]);
+    for (uint32_t i = 0; i < nqc; i++) {
+        const int qLen = (int) (q->off[(size_t) q0 + i + 1] - q->off[(size_t) q0 + i]);
         const uint64_t begin = first[i];
         uint64_t w = begin;
         for (uint64_t k = first[i]; k < first[i + 1]; k++) {
@@ -591,13 +612,114 @@ int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *P) {
         holes += first[i + 1] - w;
     }
     if (mismatch) return fail(MK_ERR_SW_MISMATCH, "Score of forward/backward SW differ for %d pairs", mismatch);
-    q->alnOff.resize((size_t) q->n + 1);
-    q->alnOff[0] = 0;
-    for (uint32_t i = 0; i < q->n; i++) q->alnOff[i + 1] = q->alnOff[i] + cnt[i];
-    if (holes)
-        for (uint32_t i = 0; i < q->n; i++)            // blocks only move towards the front: in-order memmove is safe
-            if (cnt[i] && q->alnOff[i] != first[i]) std::memmove(alns + q->alnOff[i], alns + first[i], (size_t) cnt[i] * sizeof(mk_alignment));
+    uint64_t o = 0;                                    // range-local offsets
+    for (uint32_t i = 0; i < nqc; i++) {
+        if (holes && cnt[i] && o != first[i]) std::memmove(alns + o, alns + first[i], (size_t) cnt[i] * sizeof(mk_alignment));   // blocks only move forward
+        o += cnt[i];
+        q->alnOff[(size_t) q0 + i + 1] = nAlnOut + o;
+    }
+    nAlnOut += o;
+    return MK_OK;
+}
+
+int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *P) {
+    int rc = ensure_ready();
+    if (rc) return rc;
+    if (!db || !q || !P) return fail(MK_ERR_ARG, "null argument");
+    if (!q->havePref) return fail(MK_ERR_ARG, "mk_align: the batch has no prefilter result");
+    HostTimer htAll("host_align_total");
+    std::vector<mk::GateEntry> gate;
+    {
+        HostTimer ht("host_gate_table");
+        mk::build_gate_table(db->evaluer, P->evalue_thr, q->off, gate);
+    }
+    q->alnOff.assign((size_t) q->n + 1, 0);
+    size_t nAln = 0;
+    rc = align_range(db, q, P, 0, q->n, gate, g_stream, nAln);
+    if (rc != MK_OK) return rc;
     q->haveAln = true;
+    return MK_OK;
+}
+
+// prefilter + align of the batch as ONE pipelined pass (the reference's `search` workflow runs the two modules back to back,
+// blastp.sh:70,85): the prefilter works through the queries in chunks on one stream; every finished chunk is aligned on a
+// second stream by a second host thread while the prefilter is already on the next chunk.  The prefilter is bound by memory
+// latency and the Smith-Waterman kernels by the vector ALUs, so the two stages share the GPU well.  Results are identical to
+// mk_prefilter followed by mk_align.
+int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
+    int rc = ensure_ready();
+    if (rc) return rc;
+    if (!db || !q || !P) return fail(MK_ERR_ARG, "null argument");
+    HostTimer htAll("host_search_total");
+    std::vector<mk::GateEntry> gate;
+    {
+        HostTimer ht("host_gate_table");
+        mk::build_gate_table(db->evaluer, P->evalue_thr, q->off, gate);
+    }
+    q->alnOff.assign((size_t) q->n + 1, 0);
+    q->havePref = false; q->haveAln = false;
+
+    struct Pipe {
+        std::mutex m; std::condition_variable cv;
+        std::deque<std::pair<uint32_t, uint32_t>> items;     // finished prefilter chunks [q0, q1)
+        bool done = false, busy = false;
+        int rc = MK_OK; std::string err;
+    } pipe;
+    size_t nAln = 0;
+    const int hostThreads = omp_get_max_threads();
+    const int half = std::max(1, hostThreads / 2);
+    std::thread consumer([&]() {
+        t_stream = g_stream2;
+        (void) hipSetDevice(g_device);
+        kmp_set_blocktime(0);
+        omp_set_num_threads(half);
+        for (;;) {
+            std::pair<uint32_t, uint32_t> it;
+            {
+                std::unique_lock<std::mutex> lk(pipe.m);
+                pipe.cv.wait(lk, [&] { return !pipe.items.empty() || pipe.done; });
+                if (pipe.items.empty()) break;
+                it = pipe.items.front(); pipe.items.pop_front();
+                pipe.busy = true;
+            }
+            int r = MK_OK;
+            if (pipe.rc == MK_OK) {
+                HostTimer ht("host_align_total");
+                r = align_range(db, q, P, it.first, it.second, gate, g_stream2, nAln);
+            }
+            {
+                std::lock_guard<std::mutex> lk(pipe.m);
+                if (r != MK_OK && pipe.rc == MK_OK) { pipe.rc = r; pipe.err = g_err; }
+                pipe.busy = false;
+            }
+            pipe.cv.notify_all();
+        }
+    });
+    mk::PrefilterHooks hooks;
+    hooks.max_chunk_queries = 1u << 17;
+    hooks.on_chunk = [&](uint32_t a, uint32_t b) {
+        { std::lock_guard<std::mutex> lk(pipe.m); pipe.items.emplace_back(a, b); }
+        pipe.cv.notify_all();
+    };
+    hooks.before_grow = [&]() {                                // the result block moves: nobody may be reading it
+        std::unique_lock<std::mutex> lk(pipe.m);
+        pipe.cv.wait(lk, [&] { return pipe.items.empty() && !pipe.busy; });
+    };
+    std::string err;
+    const int binCount = mk::bin_count_for(db->n, P->host_l2_bytes);
+    omp_set_num_threads(half);
+    {
+        HostTimer ht("host_prefilter_total");
+        rc = mk::run_prefilter(prefilter_view(db, q), q->off, q->res, nullptr, db->off, *P, binCount, g_stream, q->hits, q->nHits, q->hitOff, err,
+                               timed_begin, timed_end, timed_set, hooks);
+    }
+    omp_set_num_threads(hostThreads);
+    timed_flush();
+    { std::lock_guard<std::mutex> lk(pipe.m); pipe.done = true; if (rc != MK_OK && pipe.rc == MK_OK) { pipe.rc = rc; pipe.err = err; } }
+    pipe.cv.notify_all();
+    consumer.join();
+    if (pipe.rc != MK_OK) return fail(pipe.rc, "%s", pipe.err.c_str());
+    q->havePref = true; q->haveAln = true;
     return MK_OK;
 }
 
@@ -609,6 +731,7 @@ int mk_align_result(const mk_queries *q, const mk_alignment **alns, const uint64
 }
 
 int mk_kernel_stats(mk_kernel_stat *out, int cap) {
+    std::lock_guard<std::mutex> g(g_statsMutex);
     int k = 0;
     g_statNames.clear();
     for (auto &kv : g_stats) g_statNames.push_back(kv.first);
@@ -620,7 +743,7 @@ int mk_kernel_stats(mk_kernel_stat *out, int cap) {
     }
     return k;
 }
-void mk_kernel_stats_reset(void) { g_stats.clear(); }
+void mk_kernel_stats_reset(void) { std::lock_guard<std::mutex> g(g_statsMutex); g_stats.clear(); }
 
 size_t mk_format_hit(char *buf, uint32_t key, int32_t score, uint16_t diag) { return mk::format_hit(buf, key, score, diag); }
 size_t mk_format_alignment(char *buf, const mk_alignment *a) { return mk::format_alignment(buf, *a); }

@@ -13,6 +13,7 @@
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -191,7 +192,7 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
         L.q_res = V.q_res; L.q_bias8 = V.q_bias8; L.t_res = V.t_res; L.mat = V.mat_aln;
         L.jobs = jobs; L.out = out; L.n_jobs = hi - lo; L.order = vb.Current() + lo;
         L.boundary = nullptr; L.boundary_stride = 0; L.boundary_job0 = 0;
-        L.wave_start = nullptr; L.n_waves = 0;
+        L.wave_start = nullptr; L.n_waves = 0; L.work_counter = nullptr; L.persistent_blocks = 0;
         L.gap_open = P.gap_open; L.gap_extend = P.gap_extend;
         if (c == SW_NCFG - 1 && V.max_q_len > (uint32_t) sw_cfg_rows(c)) {
             const uint32_t cls = KEY_CLS - 1 - (hb[32 + c] % KEY_CLS);          // largest target-length class in this bucket
@@ -224,7 +225,19 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const SwJob *j
     uint32_t *dNum = (uint32_t *) dev_scratch("align_nwaves", 16);
     uint32_t *dBounds = (uint32_t *) dev_scratch("align_bounds", 64 * sizeof(uint32_t));
     uint32_t *hb = (uint32_t *) pinned_scratch("align_bounds_h", 64 * sizeof(uint32_t));
-    ANULL(dHead); ANULL(dFlag); ANULL(dWave); ANULL(dNum); ANULL(dBounds); ANULL(hb);
+    uint32_t *dWork = (uint32_t *) dev_scratch("align_workcounters", 64);
+    ANULL(dHead); ANULL(dFlag); ANULL(dWave); ANULL(dNum); ANULL(dBounds); ANULL(hb); ANULL(dWork);
+    ACHK(hipMemsetAsync(dWork, 0, 64, stream));
+    // persistent forward launch: this many one-wave workgroups per CU (MK_SW_WAVES_PER_CU, default 16 = half the wave slots)
+    static uint32_t persistentBlocks = 0;
+    if (!persistentBlocks) {
+        int dev = 0, cus = 256;
+        (void) hipGetDevice(&dev);
+        (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        int perCu = 16;
+        if (const char *e = getenv("MK_SW_WAVES_PER_CU")) perCu = std::max(1, atoi(e));
+        persistentBlocks = (uint32_t) (cus * perCu);
+    }
     size_t t1 = 0, t2 = 0, t3 = 0;
     hipcub::CountingInputIterator<uint32_t> iota(0);
     hipcub::DeviceRadixSort::SortPairs(nullptr, t1, kb, vb, (int) n, 0, 47, stream);
@@ -253,6 +266,7 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const SwJob *j
         L.jobs = jobs; L.out = out; L.n_jobs = hi - lo; L.order = vb.Current();      // wave_start holds absolute sorted positions
         L.boundary = nullptr; L.boundary_stride = 0; L.boundary_job0 = lo;
         L.wave_start = dWave + wlo; L.n_waves = whi - wlo;
+        L.work_counter = dWork + c; L.persistent_blocks = persistentBlocks;
         L.gap_open = P.gap_open; L.gap_extend = P.gap_extend;
         if (c == SW_NCFG - 1 && V.max_q_len > (uint32_t) sw_cfg_rows(c)) {
             // queries beyond the largest tile run in row tiles with an HBM border per job; the border is as long as the
@@ -378,7 +392,10 @@ struct Scratch { void *p = nullptr; size_t cap = 0; bool pinned = false; };
 std::map<std::string, Scratch> &scratch_map() { static std::map<std::string, Scratch> m; return m; }
 }
 
+static std::mutex &scratch_mutex() { static std::mutex m; return m; }
+
 void *dev_scratch(const char *name, size_t bytes) {
+    std::lock_guard<std::mutex> g(scratch_mutex());
     Scratch &s = scratch_map()[std::string("d:") + name];
     if (bytes <= s.cap && s.p) return s.p;
     if (s.p) (void) hipFree(s.p);
@@ -390,6 +407,7 @@ void *dev_scratch(const char *name, size_t bytes) {
 }
 
 void *pinned_scratch(const char *name, size_t bytes) {
+    std::lock_guard<std::mutex> g(scratch_mutex());
     Scratch &s = scratch_map()[std::string("h:") + name];
     if (bytes <= s.cap && s.p) return s.p;
     if (s.p) (void) hipHostFree(s.p);

@@ -34,6 +34,8 @@ struct SwLaunch {
     // [wave_start[w], wave_start[w+1]) -- all of one query, at most 64/G of them -- on ONE LDS query profile.
     // null: every job builds its own profile (test path, reverse pass).
     const uint32_t *wave_start; uint64_t n_waves;
+    uint32_t *work_counter;     // shared-query mode: zeroed device counter the persistent workgroups pull wave numbers from
+    uint32_t persistent_blocks; // ... and how many workgroups to launch (0: one per wave)
     uint64_t boundary_job0;     // job index that owns the first boundary_stride entries of `boundary`
 };
 

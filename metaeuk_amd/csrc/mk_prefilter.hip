@@ -748,7 +748,7 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &V, const uint64_t *hOff
             PCHK(sync_wait(stream, "wait_prefilter"));
             totalHits = X.hTotals[0];
             if (X.hTotals[1] != 0) { err = "a query overflows the reference's databaseHits buffer (QueryMatcher.cpp:281-316 is not restated)"; return MK_ERR_UNSUPPORTED; }
-            X.ts(thCount, 8.0 * (double) X.hTotals[2] + 64.0 * (double) nPos, (double) X.hTotals[2]);
+            X.ts(thCount, 4.0 * (double) X.hTotals[2] + 8.0 * (double) totalHits + 1280.0 * (double) nPos, (double) X.hTotals[2]);   // bitmap word per k-mer, offset pair per non-empty k-mer, row heads per start
             hitsPerPos = std::max(1.0, (double) totalHits / (double) nPos);
             if (totalHits > HIT_CAP && q1 - q0 > 1) { q1 = q0 + (q1 - q0) / 2; continue; }
             break;
@@ -764,7 +764,7 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &V, const uint64_t *hOff
             A.hit_count = dHit; A.kmer_count = dKmer; A.keys = dKeys; A.vals = dVals;
             const unsigned blocks = (unsigned) ((nPos + 3) / 4);
             // gather pass: offset pairs again + 8 B per index entry read + 16 B (key,value) written per entry
-            int th = X.tb("kmer_probe_gather", 8.0 * (double) X.hTotals[2] + 24.0 * (double) totalHits + 64.0 * (double) nPos, (double) X.hTotals[2]);
+            int th = X.tb("kmer_probe_gather", 4.0 * (double) X.hTotals[2] + 32.0 * (double) totalHits + 1280.0 * (double) nPos, (double) X.hTotals[2]);
             hipLaunchKernelGGL(probe_kernel<true>, dim3(blocks), dim3(256), 0, stream, A);
             X.te(th);
             PCHK(hipGetLastError());
@@ -822,7 +822,8 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &V, const uint64_t *hOff
 int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOff, const std::vector<uint8_t> &qRes,
                   const int8_t *qCorrHost,
                   const std::vector<uint64_t> &tOff, const mk_params &P, int binCount, hipStream_t stream,
-                  HostBlock &outBlk, size_t &nOut, std::vector<uint64_t> &outOff, std::string &err, timed_begin_fn tb, timed_end_fn te, timed_set_fn ts) {
+                  HostBlock &outBlk, size_t &nOut, std::vector<uint64_t> &outOff, std::string &err, timed_begin_fn tb, timed_end_fn te, timed_set_fn ts,
+                  const PrefilterHooks &hooks) {
     const uint32_t nq = V.n_queries;
     nOut = 0;
     outOff.assign((size_t) nq + 1, 0);
@@ -830,6 +831,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     auto reserve_out = [&](size_t n, uint32_t qDone) -> bool {
         if ((nOut + n) * sizeof(mk_hit) <= outBlk.cap && outBlk.p) return true;
         if (hipStreamSynchronize(stream) != hipSuccess) return false;      // DMA into the old block must have landed
+        if (hooks.before_grow) hooks.before_grow();
         const double frac = std::max(0.02, (double) qDone / (double) nq);
         const size_t want = (size_t) ((double) (nOut + n) / frac * 1.1) + 4096;
         return outBlk.reserve(std::max(want, nOut + n + 4096) * sizeof(mk_hit), nOut * sizeof(mk_hit));
@@ -881,6 +883,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     while (q0 < nq) {
         // ---- chunk size: bounded by the query field of the sort key and by the candidate buffers
         uint32_t want = chunkLimit;
+        if (hooks.max_chunk_queries) want = std::min(want, hooks.max_chunk_queries);
         if (candPerQuery > 0) want = (uint32_t) std::min<double>(want, std::max(1.0, 0.6 * (double) CAND_CAP / candPerQuery));
         else want = std::min<uint32_t>(want, 1u << 16);                    // nothing known yet: a small probe chunk
         const uint32_t q1 = (uint32_t) std::min<uint64_t>(nq, (uint64_t) q0 + std::max<uint32_t>(want, 1));
@@ -969,12 +972,12 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             if (hCounters[0] > CAND_CAP) rc = RC_CAND_OVERFLOW;
             else {
                 nCand = hCounters[0];
-                // algorithmic bytes of the fused launches: 8 B per k-mer (offset pair) + 8 B per index entry + the cached row heads,
-                // split over the tiers by their share of the queries (statistics only)
+                // algorithmic bytes of the fused launches: 4 B bitmap word per similar k-mer + 8 B offset pair per non-empty k-mer
+                // (~ one per index hit) + 8 B per index entry + the row heads of every k-mer start (~1.3 KB)
                 for (int t = 0; t < N_TIERS; t++)
                     if (thFused[t] >= 0) {
-                        const double share = (double) lists[t].size() / (double) std::max<size_t>(nListed, 1);
-                        ts(thFused[t], share * (8.0 * (double) hFTotals[0] + 8.0 * (double) hFTotals[1] + 64.0 * (double) hFTotals[2]), share * (double) hFTotals[0]);
+                        const unsigned long long *T = hFTotals + 16 * (t + 1);
+                        ts(thFused[t], 4.0 * (double) T[0] + 16.0 * (double) T[1] + 1280.0 * (double) T[2], (double) T[0]);
                     }
                 if (getenv("MK_PREFILTER_DEBUG"))
                     fprintf(stderr, "[prefilter] chunk %u..%u: tiers %zu/%zu/%zu/%zu too-long %zu overflow %u | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g (mean wave %.3g) sort %.3g emit %.3g overflowed %.3g | cand %u\n",
@@ -1198,6 +1201,10 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                 }
                 outOff[qg + 1] = nOut;
             }
+        }
+        if (hooks.on_chunk) {
+            PCHK(sync_wait(stream, "wait_prefilter"));                     // the chunk's DMA has landed
+            hooks.on_chunk(q0, q1);
         }
         q0 = q1;
     }

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 #include "../../include/metaeuk_amd.h"
@@ -26,10 +27,18 @@ typedef int (*timed_begin_fn)(const char *name, double bytes, double cells);
 typedef void (*timed_end_fn)(int handle);
 typedef void (*timed_set_fn)(int handle, double bytes, double cells);
 
+// optional hooks for a caller that consumes the result chunk by chunk while the prefilter is still running (mk_search)
+struct PrefilterHooks {
+    uint32_t max_chunk_queries = 0;                                  // 0: no limit beyond the device buffers
+    std::function<void(uint32_t q0, uint32_t q1)> on_chunk;          // hits and offsets of [q0, q1) are final and in host memory
+    std::function<void()> before_grow;                               // the result block is about to be re-allocated
+};
+
 // Runs the whole prefilter for the batch.  q_off_host / t_off_host mirror the device offset arrays.
 int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &q_off_host, const std::vector<uint8_t> &q_res_host,
                   const int8_t *q_corr_host,
                   const std::vector<uint64_t> &t_off_host, const mk_params &P, int binCount, hipStream_t stream,
-                  struct HostBlock &outHits, size_t &nOutHits, std::vector<uint64_t> &outOff, std::string &err, timed_begin_fn tb, timed_end_fn te, timed_set_fn ts);
+                  struct HostBlock &outHits, size_t &nOutHits, std::vector<uint64_t> &outOff, std::string &err, timed_begin_fn tb, timed_end_fn te, timed_set_fn ts,
+                  const PrefilterHooks &hooks);
 
 }  // namespace mk

@@ -24,6 +24,7 @@
 // allowed.  H is therefore identical cell by cell to plain Gotoh for every SIMD width (DESIGN.md,
 // "SW recurrence"); the oracle keeps the literal striped semantics and the tests compare against it.
 #include "mk_kernels.hpp"
+#include <algorithm>
 
 namespace mk {
 
@@ -61,12 +62,12 @@ __device__ __forceinline__ void load_scores(const int8_t *p, int (&sc)[R]) {
     }
 }
 
+// one unit of work: BLOCK/G jobs with their own profiles, or (SHARED) the jobs of wave `unit` on one shared profile
 template <int G, int R, int BLOCK, bool SHARED>
-__global__ __launch_bounds__(BLOCK) void sw_kernel(SwLaunch L) {
+__device__ __forceinline__ void sw_unit(const SwLaunch &L, const uint32_t unit, int8_t *smem) {
     constexpr int GPB = BLOCK / G;
     constexpr int ROWS = G * R;
     static_assert(!SHARED || BLOCK == 64, "shared-query mode runs one wave per workgroup");
-    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     const int lane = threadIdx.x % G;
     const int grp = threadIdx.x / G;
     uint64_t jobId;
@@ -74,14 +75,14 @@ __global__ __launch_bounds__(BLOCK) void sw_kernel(SwLaunch L) {
     SwJob job;
     uint32_t profQStart = 0; int profQStep = 1;       // query whose profile this lane helps to build
     if constexpr (SHARED) {
-        const uint32_t w0 = L.wave_start[blockIdx.x], w1 = L.wave_start[blockIdx.x + 1];
+        const uint32_t w0 = L.wave_start[unit], w1 = L.wave_start[unit + 1];
         const uint32_t count = min((uint32_t) GPB, w1 - w0);
         have = (uint32_t) grp < count;
         jobId = (uint64_t) w0 + (have ? grp : 0);     // idle groups mirror the first job (same query) with no columns
         job = L.jobs[L.order ? (uint64_t) L.order[jobId] : jobId];
         if (!have) job.t_len = 0;
     } else {
-        jobId = (uint64_t) blockIdx.x * GPB + grp;
+        jobId = (uint64_t) unit * GPB + grp;
         have = jobId < L.n_jobs;
         if (have) job = L.jobs[L.order ? (uint64_t) L.order[jobId] : jobId];
         else { job.t_start = 0; job.q_start = 0; job.q_len = 0; job.t_len = 0; job.q_step = 1; job.t_step = 1; job.slot = 0; }
@@ -186,12 +187,33 @@ __global__ __launch_bounds__(BLOCK) void sw_kernel(SwLaunch L) {
     }
 }
 
+// Shared-query mode is a persistent launch: a fixed number of one-wave workgroups per CU pull units from a counter, which
+// leaves wave slots, registers and LDS on every CU for the (memory-latency-bound) prefilter kernels of the other stream.
+template <int G, int R, int BLOCK, bool SHARED>
+__global__ __launch_bounds__(BLOCK) void sw_kernel(SwLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    if constexpr (SHARED) {
+        for (;;) {
+            uint32_t u = 0;
+            if (threadIdx.x == 0) u = atomicAdd(L.work_counter, 1u);
+            u = (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
+            if ((uint64_t) u >= L.n_waves) break;
+            sw_unit<G, R, BLOCK, true>(L, u, smem);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        sw_unit<G, R, BLOCK, false>(L, blockIdx.x, smem);
+    }
+}
+
 template <int G, int R, int BLOCK>
 static hipError_t launch_one(const SwLaunch &L, hipStream_t stream) {
     if (L.wave_start) {                                     // one wave per workgroup, one profile per wave
         const size_t lds = (size_t) 22 * G * R;
         if (L.n_waves == 0) return hipSuccess;
-        hipLaunchKernelGGL((sw_kernel<G, R, 64, true>), dim3((unsigned) L.n_waves), dim3(64), lds, stream, L);
+        const uint64_t grid = std::min<uint64_t>(L.n_waves, L.persistent_blocks ? L.persistent_blocks : L.n_waves);
+        hipLaunchKernelGGL((sw_kernel<G, R, 64, true>), dim3((unsigned) grid), dim3(64), lds, stream, L);
         return hipGetLastError();
     }
     constexpr int GPB = BLOCK / G;

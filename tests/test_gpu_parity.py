@@ -306,3 +306,22 @@ def test_device_derive_matches_oracle(gpu_api, small_workload):
                 exp_kt[k] = max(thr - r, 0)
         assert np.array_equal(dc[lo:hi], exp_corr), "diagonal correction, query %d" % i
         assert np.array_equal(kt[lo:hi], exp_kt), "k-mer threshold, query %d" % i
+
+
+def test_search_equals_prefilter_then_align(gpu_api, pf_path):
+    """mk_search (the two stages pipelined on two streams, chunk by chunk) returns exactly what the two module calls return"""
+    from metaeuk_amd import synth
+    api = gpu_api
+    targets, queries = synth.make_workload(40, 1500, seed=23)
+    params = api.default_params()
+    db = api.TargetDB(targets, params)
+    q1 = api.Queries(queries, params)
+    hits1, hoff1 = api.prefilter(db, q1)
+    alns1, aoff1 = api.align(db, q1)
+    q2 = api.Queries(queries, params)
+    (hits2, hoff2), (alns2, aoff2) = api.search(db, q2)
+    assert np.array_equal(np.asarray(hoff1), np.asarray(hoff2)) and np.array_equal(np.asarray(aoff1), np.asarray(aoff2))
+    assert hits1.tobytes() == hits2.tobytes()
+    n = int(aoff1[-1])
+    assert n > 100
+    assert api.format_alignments(alns1, 0, n) == api.format_alignments(alns2, 0, n)
