@@ -27,6 +27,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T int32 lane-ops/s
+SW_OPS_PER_CELL = 10      # add, min, max3, lshl_or, max, sub, sub, max3, sub, max3 (mk_sw.hip inner loop)
+# HBM bytes per launch from the PMC passes (profiles/r01_pmc_hbm_traffic.txt), keyed by the bench's kernel names
+TRAFFIC_BYTES_PER_LAUNCH = {   # (FETCH_SIZE + WRITE_SIZE) KB x 1024, raw counter values, default workload
+    "prefilter_fused_lds2048": (1334438 + 9694) * 1024, "prefilter_fused_lds4096": (3789574 + 13684) * 1024,
+    "prefilter_fused_lds8192": (13339162 + 35177) * 1024, "prefilter_fused_lds16384": (28832191 + 56330) * 1024,
+    "kmer_probe_count": (13381981 + 43732) * 1024, "kmer_probe_gather": (20488081 + 2947688) * 1024,
+    "sw_fwd_rows32": (355233 + 40358) * 1024, "sw_fwd_rows64": (557509 + 65368) * 1024, "sw_fwd_rows128": (320429 + 37710) * 1024,
+}
 
 
 def make_inputs(n_contigs, n_targets, seed, rank):
@@ -177,9 +186,17 @@ def main():
         "prefilter_hits": nhits, "alignments_passed": npass,
         "setup_s": {"generate": round(t_gen, 2), "target_index_build_upload": round(t_index, 2)},
         "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(stats.items())},
+        # dominant kernel against HBM; `traffic` (PMC FETCH_SIZE + WRITE_SIZE per launch) comes from the rocprofv3 passes kept
+        # under profiles/ -- bench.py cannot read PMC counters itself
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "avg_launch_ms": per_launch_ms, "launches": dom["launches"]},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dom_name),
+                     "avg_launch_ms": per_launch_ms, "launches": dom["launches"],
+                     "note": "neither hot kernel family streams HBM: the fused prefilter kernels wait on dependent random index "
+                             "probes (latency), the Smith-Waterman kernels are int32 vector-ALU bound (see valu_roofline)"},
+        # the Smith-Waterman kernels against the int32 vector-ALU peak: ~10 lane-ops per DP cell
+        "valu_roofline": {"kernels": "sw_fwd_* + sw_rev_*", "achieved": (cells_sw * SW_OPS_PER_CELL / max(sw_ms * 1e-3, 1e-12) / 1e12) if sw_ms else None,
+                          "peak": VALU_PEAK_TOPS, "unit": "Tlane-op/s",
+                          "frac": (cells_sw * SW_OPS_PER_CELL / max(sw_ms * 1e-3, 1e-12) / 1e12 / VALU_PEAK_TOPS) if sw_ms else None},
     }
     if rank == 0:
         if world == 1 and args.cpu_sample > 0:
