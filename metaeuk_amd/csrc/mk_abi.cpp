@@ -251,7 +251,11 @@ const char *mk_last_error(void) { return g_err.c_str(); }
 int mk_host_threads(void) { return effective_cpus(); }
 
 int mk_init(int device) {
-    if (!getenv("OMP_NUM_THREADS")) omp_set_num_threads(effective_cpus());
+    if (!getenv("OMP_NUM_THREADS")) {
+        int share = 1;                                      // one process per GPU: the ranks of a node split its cores
+        if (const char *lw = getenv("LOCAL_WORLD_SIZE")) share = std::max(1, atoi(lw));
+        omp_set_num_threads(std::max(1, effective_cpus() / share));
+    }
     kmp_set_blocktime(0);                                   // idle team threads sleep: two stages share the host cores in mk_search
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
