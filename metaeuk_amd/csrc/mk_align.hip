@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void wave_flag_kernel(const uint64_t *sortedKe
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int cfg = (int) (sortedKeys[i] >> 44);
-    const uint32_t dpw = cfg < 4 ? 4u : (cfg < 6 ? 2u : 1u);       // 64 / G of launch_sw's configurations
+    const uint32_t dpw = cfg < 4 ? 8u : (cfg < 6 ? 2u : 1u);       // packed score kernel: 2 per 16-lane group; else 64 / G
     flag[i] = ((i - head[i]) % dpw) == 0 ? 1 : 0;
 }
 // job and wave ranges of every configuration; closes the wave list with n
@@ -90,23 +90,40 @@ __global__ void bounds_kernel(const uint32_t *sortedKeys, uint32_t n, uint32_t *
     if (c < SW_NCFG) firstKey[c] = lo < n ? sortedKeys[lo] : 0;
 }
 
-__global__ __launch_bounds__(256) void gate_kernel(AlignView V, const SwJob *fwdJobs, const SwOut *fwdOut, uint64_t n, const GateEntry *gate,
-                                                   uint32_t *revCount, uint32_t *revPair, SwJob *revJobs, uint32_t *revKeys, uint32_t *revIdx) {
+// e-value gate on the forward score (table per query length); survivors get a position job (the same DP again, this time
+// with end-position tracking)
+__global__ __launch_bounds__(256) void gate_kernel(const SwJob *fwdJobs, const SwOut *fwdOut, uint64_t n, const GateEntry *gate,
+                                                   uint32_t *posCount, uint32_t *posPair, SwJob *posJobs, uint32_t *posKeys, uint32_t *posIdx) {
     const uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    const SwOut o = fwdOut[p];
-    if (o.score <= 0) return;
-    const SwJob f = fwdJobs[p];
-    const GateEntry g = gate[f.q_len];
-    bool pass = o.score >= g.s0;
-    if (!pass && o.score < 256) pass = (g.mask[o.score >> 5] >> (o.score & 31)) & 1u;
+    const int score = fwdOut[p].score;
+    if (score <= 0) return;
+    SwJob j = fwdJobs[p];
+    const GateEntry g = gate[j.q_len];
+    bool pass = score >= g.s0;
+    if (!pass && score < 256) pass = (g.mask[score >> 5] >> (score & 31)) & 1u;
     if (!pass) return;
-    const uint32_t r = atomicAdd(revCount, 1u);
-    revPair[r] = (uint32_t) p;
+    const uint32_t r = atomicAdd(posCount, 1u);
+    posPair[r] = (uint32_t) p;
+    j.slot = r;
+    posJobs[r] = j;
+    posKeys[r] = sort_key(j.q_len, j.t_len);
+    posIdx[r] = r;
+}
+
+// reverse jobs (reversed prefixes ending at the forward end cell) of the survivors; the position pass must reproduce the
+// score the gate saw
+__global__ __launch_bounds__(256) void rev_jobs_kernel(const SwJob *posJobs, const SwOut *posOut, const uint32_t *posPair, const SwOut *fwdOut, uint32_t n,
+                                                       SwJob *revJobs, uint32_t *revKeys, uint32_t *revIdx, uint32_t *mismatch) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const SwOut o = posOut[r];
+    const SwJob f = posJobs[r];
+    if (o.score != fwdOut[posPair[r]].score || o.end_row < 0 || o.end_col < 0) atomicAdd(mismatch, 1u);
     SwJob j;
-    j.q_len = (uint32_t) o.end_row + 1; j.t_len = (uint32_t) o.end_col + 1;
-    j.q_start = f.q_start + (uint32_t) o.end_row; j.q_step = -1;
-    j.t_start = f.t_start + (uint64_t) o.end_col; j.t_step = -1;
+    j.q_len = (uint32_t) max(o.end_row, 0) + 1; j.t_len = (uint32_t) max(o.end_col, 0) + 1;
+    j.q_start = f.q_start + (uint32_t) max(o.end_row, 0); j.q_step = -1;
+    j.t_start = f.t_start + (uint64_t) max(o.end_col, 0); j.t_step = -1;
     j.slot = r;
     revJobs[r] = j;
     revKeys[r] = sort_key(j.q_len, j.t_len);
@@ -123,7 +140,7 @@ __global__ __launch_bounds__(256) void collect_kernel(const uint32_t *sortedPair
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t p = sortedPair[i], r = sortedRev[i];
-    const SwOut f = fwdOut[p], b = revOut[r];
+    const SwOut f = fwdOut[r], b = revOut[r];          // both indexed by survivor number
     AlnRaw a;
     a.pair = p; a.score = f.score; a.q_end = f.end_row; a.t_end = f.end_col;
     // reverse score kept in q_start when it disagrees (the reference EXITs on that, :466-473)
@@ -280,7 +297,8 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const SwJob *j
         snprintf(nm, sizeof(nm), "sw_fwd_rows%d", sw_cfg_rows(c));
         th = tb(nm, 0, 0);
         handles[c] = th;
-        ACHK(launch_sw(L, c, stream));
+        if (c < 4) ACHK(launch_sw_score(L, c, stream));       // score only, packed int16, two targets per lane group
+        else ACHK(launch_sw(L, c, stream));
         te(th);
     }
     return MK_OK;
@@ -318,12 +336,12 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hi
     int rc = run_shared_fwd(V, P, dJobs, dOut, dKeys64, dIdx, dKeys64b, dIdx2, n, stream, err, tb, te, hFwd);
     for (int c = 0; c < SW_NCFG; c++) if (hFwd[c] >= 0 && fwdWork) ts(hFwd[c], fwdWork[2 * c], fwdWork[2 * c + 1]);
     if (rc != MK_OK) return rc;
-    // gate + reverse jobs (reuse the key/index buffers; at most n survivors)
+    // e-value gate on the forward scores; the survivors (at most n) get a position pass, then the reverse pass
     uint32_t *dRevPair = (uint32_t *) dev_scratch("align_revpair", (size_t) n * 4);
-    SwJob *dRevJobs = (SwJob *) dev_scratch("align_revjobs", (size_t) n * sizeof(SwJob));
-    ANULL(dRevPair); ANULL(dRevJobs);
-    th = tb("align_gate", 48.0 * n, 0);
-    hipLaunchKernelGGL(gate_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, V, dJobs, dOut, (uint64_t) n, dGate, dCount, dRevPair, dRevJobs, dKeys, dIdx);
+    SwJob *dPosJobs = (SwJob *) dev_scratch("align_posjobs", (size_t) n * sizeof(SwJob));
+    ANULL(dRevPair); ANULL(dPosJobs);
+    th = tb("align_gate", 52.0 * n, 0);
+    hipLaunchKernelGGL(gate_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dJobs, dOut, (uint64_t) n, dGate, dCount, dRevPair, dPosJobs, dKeys, dIdx);
     te(th);
     ACHK(hipGetLastError());
     uint32_t *hCount = (uint32_t *) pinned_scratch("align_count_h", 16);
@@ -333,9 +351,17 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hi
     if (hCount[1] != 0) { err = "prefilter hit " + std::to_string(hCount[1] - 1) + " names a target outside the DB"; return MK_ERR_ARG; }
     const uint32_t nRev = hCount[0];
     if (nRev == 0) return MK_OK;
+    SwOut *dPosOut = (SwOut *) dev_scratch("align_posout", (size_t) nRev * sizeof(SwOut));
     SwOut *dRevOut = (SwOut *) dev_scratch("align_revout", (size_t) nRev * sizeof(SwOut));
-    ANULL(dRevOut);
+    SwJob *dRevJobs = (SwJob *) dev_scratch("align_revjobs", (size_t) nRev * sizeof(SwJob));
+    ANULL(dPosOut); ANULL(dRevOut); ANULL(dRevJobs);
+    ACHK(hipMemsetAsync(dPosOut, 0, (size_t) nRev * sizeof(SwOut), stream));
     ACHK(hipMemsetAsync(dRevOut, 0, (size_t) nRev * sizeof(SwOut), stream));
+    int hPos[SW_NCFG];
+    rc = run_sorted_sw(V, P, dPosJobs, dPosOut, dKeys, dIdx, dKeys2, dIdx2, nRev, "sw_pos", stream, err, tb, te, hPos);
+    if (rc != MK_OK) return rc;
+    hipLaunchKernelGGL(rev_jobs_kernel, dim3((nRev + 255) / 256), dim3(256), 0, stream, dPosJobs, dPosOut, dRevPair, dOut, nRev, dRevJobs, dKeys, dIdx, dCount + 2);
+    ACHK(hipGetLastError());
     rc = run_sorted_sw(V, P, dRevJobs, dRevOut, dKeys, dIdx, dKeys2, dIdx2, nRev, "sw_rev", stream, err, tb, te, hRev);
     if (rc != MK_OK) return rc;
     // order the survivors by pair index and collect
@@ -355,13 +381,15 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hi
     ACHK(hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, pb, sb, (int) nRev, 0, bits, stream));
     te(th);
     th = tb("align_collect", 64.0 * nRev, 0);
-    hipLaunchKernelGGL(collect_kernel, dim3((nRev + 255) / 256), dim3(256), 0, stream, pb.Current(), sb.Current(), nRev, dOut, dRevOut, dRaw);
+    hipLaunchKernelGGL(collect_kernel, dim3((nRev + 255) / 256), dim3(256), 0, stream, pb.Current(), sb.Current(), nRev, dPosOut, dRevOut, dRaw);
     te(th);
     ACHK(hipGetLastError());
     AlnRaw *hRaw = (AlnRaw *) pinned_scratch("align_raw_host", (size_t) nRev * sizeof(AlnRaw));
     ANULL(hRaw);
     ACHK(hipMemcpyAsync(hRaw, dRaw, (size_t) nRev * sizeof(AlnRaw), hipMemcpyDeviceToHost, stream));
+    ACHK(hipMemcpyAsync(hCount, dCount, 12, hipMemcpyDeviceToHost, stream));
     ACHK(sync_wait(stream, "wait_align"));
+    if (hCount[2] != 0) { err = "internal: the position pass disagrees with the score pass for " + std::to_string(hCount[2]) + " pairs"; return MK_ERR_DEVICE; }
     *out = hRaw; *nOut = nRev;
     // reverse-pass work per tile configuration, from the results
     {

@@ -52,6 +52,8 @@ __host__ __device__ inline int sw_cfg_of(uint32_t qLen) {
     return c;
 }
 hipError_t launch_sw(const SwLaunch &L, int cfg, hipStream_t stream);
+// score-only forward pass in packed int16, two targets per lane group (configurations 0..3, shared-query mode only)
+hipError_t launch_sw_score(const SwLaunch &L, int cfg, hipStream_t stream);
 
 struct UngappedJob { uint64_t t_start; uint32_t q_start; uint32_t q_len; uint32_t t_len; uint32_t diagonal; };
 struct UngappedLaunch {

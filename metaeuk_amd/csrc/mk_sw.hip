@@ -207,6 +207,128 @@ __global__ __launch_bounds__(BLOCK) void sw_kernel(SwLaunch L) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Score-only forward pass, two DPs per lane group in packed int16 (v_pk_add/max/sub_i16): the low halves of every
+// register belong to one target, the high halves to another; both run against the SAME query (shared-query mode), so
+// all DP state packs perfectly -- the serial F dependence runs down the rows inside each half.  ~5.5 vector ops per cell
+// instead of 10.  It yields the maximum score only: the e-value gate needs nothing else, and the ~9 % of the pairs that
+// pass are re-run by sw_kernel for their end positions.  For tiles of at most 256 rows the int16 arithmetic cannot
+// saturate (256 rows x 127), so it is the reference's arithmetic exactly.
+typedef short pk16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk16 pk_from(uint32_t v) { return __builtin_bit_cast(pk16, v); }
+__device__ __forceinline__ uint32_t pk_bits(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ pk16 pk_max(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ pk16 pk_splat(int v) { pk16 r; r.x = (short) v; r.y = (short) v; return r; }
+
+template <int R>
+__global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
+    constexpr int G = 16, GPB = 64 / G, ROWS = G * R;
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    int16_t *prof = reinterpret_cast<int16_t *>(smem);            // prof[t][row], int16; row 21 = zeros
+    const int lane = threadIdx.x % G, grp = threadIdx.x / G;
+    const pk16 go2 = pk_splat(L.gap_open), ge2 = pk_splat(L.gap_extend), zero2 = pk_splat(0);
+    for (;;) {
+        uint32_t u = 0;
+        if (threadIdx.x == 0) u = atomicAdd(L.work_counter, 1u);
+        u = (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
+        if ((uint64_t) u >= L.n_waves) break;
+        const uint32_t w0 = L.wave_start[u], w1 = L.wave_start[u + 1];
+        const uint32_t count = min((uint32_t) (2 * GPB), w1 - w0);
+        const bool haveA = (uint32_t) (2 * grp) < count, haveB = (uint32_t) (2 * grp + 1) < count;
+        const SwJob jobA = L.jobs[L.order[(uint64_t) w0 + (haveA ? 2 * grp : 0)]];
+        const SwJob jobB = L.jobs[L.order[(uint64_t) w0 + (haveB ? 2 * grp + 1 : 0)]];
+        const int qLen = (int) jobA.q_len;                          // every job of the wave has this query
+        const int tLenA = haveA ? (int) jobA.t_len : 0, tLenB = haveB ? (int) jobB.t_len : 0;
+        for (int idx = (int) threadIdx.x; idx < 22 * ROWS; idx += 64) {
+            const int t = idx / ROWS, row = idx - t * ROWS;
+            int v = 0;
+            if (t < 21 && row < qLen) {
+                const int64_t qi = (int64_t) jobA.q_start + (int64_t) row * jobA.q_step;
+                v = (int) L.mat[t * 21 + L.q_res[qi]] + (int) L.q_bias8[qi];
+            }
+            prof[idx] = (int16_t) v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        pk16 H[R], E[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) { H[r] = zero2; E[r] = zero2; }
+        pk16 best = zero2, hupPrev = zero2;
+        uint32_t outH = 0, outF = 0, outRes = 21u | (21u << 8);    // handed to lane+1: H of the last row, F, the two residues
+        const int tMax = max(tLenA, tLenB);
+        const int steps = tMax > 0 ? tMax + G - 1 : 0;
+        const int laneRow = lane;                                  // G == one DPP row
+        const int lastA = max(tLenA - 1, 0), lastB = max(tLenB - 1, 0);
+        const int64_t baseA = (int64_t) jobA.t_start, baseB = (int64_t) jobB.t_start, stepA = jobA.t_step, stepB = jobB.t_step;
+        uint32_t tnext = (uint32_t) L.t_res[baseA + (int64_t) min(laneRow, lastA) * stepA] | ((uint32_t) L.t_res[baseB + (int64_t) min(laneRow, lastB) * stepB] << 8);
+        for (int s0 = 0; s0 < steps; s0 += 16) {
+            uint32_t tcur = tnext;
+            tnext = (uint32_t) L.t_res[baseA + (int64_t) min(s0 + 16 + laneRow, lastA) * stepA] | ((uint32_t) L.t_res[baseB + (int64_t) min(s0 + 16 + laneRow, lastB) * stepB] << 8);
+            const int sEnd = min(s0 + 16, steps);
+            for (int s = s0; s < sEnd; s++) {
+                const uint32_t resA = s < tLenA ? (tcur & 0xFFu) : 21u, resB = s < tLenB ? ((tcur >> 8) & 0xFFu) : 21u;
+                const uint32_t top = resA | (resB << 8);           // code 21 = "no column": an all-zero profile row
+                tcur = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) tcur, 0x12F /* row_ror:15 */, 0xf, 0xf, false);
+                const pk16 hup = pk_from(shift_up<G>(0u, outH, lane));
+                pk16 F = pk_from(shift_up<G>(0u, outF, lane));
+                const uint32_t tres = shift_up<G>(top, outRes, lane);
+                const int16_t *pa = prof + (tres & 0xFFu) * ROWS + lane * R, *pb = prof + (tres >> 8) * ROWS + lane * R;
+                uint32_t wa[R / 2], wb[R / 2];                     // R int16 scores per target, two per dword
+#pragma unroll
+                for (int k = 0; k < R / 2; k++) { wa[k] = reinterpret_cast<const uint32_t *>(pa)[k]; wb[k] = reinterpret_cast<const uint32_t *>(pb)[k]; }
+                pk16 dsave = hupPrev;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    // (score of target A, score of target B) for row r: one byte permute
+                    const pk16 sc = pk_from(__builtin_amdgcn_perm(wb[r / 2], wa[r / 2], (r & 1) ? 0x07060302u : 0x05040100u));
+                    const pk16 d = dsave + sc;
+                    dsave = H[r];
+                    const pk16 h = pk_max(pk_max(pk_max(d, E[r]), F), zero2);
+                    best = pk_max(best, h);
+                    const pk16 ho = h - go2;
+                    E[r] = pk_max(E[r] - ge2, ho);
+                    F = pk_max(F - ge2, ho);
+                    H[r] = h;
+                }
+                hupPrev = hup;
+                outH = pk_bits(H[R - 1]);
+                outF = pk_bits(F);
+                outRes = tres;
+            }
+        }
+        // group reduction of the two maxima
+        uint32_t b = pk_bits(best);
+#pragma unroll
+        for (int m = G / 2; m >= 1; m >>= 1) b = pk_bits(pk_max(pk_from(b), pk_from((uint32_t) __shfl_xor((int) b, m, G))));
+        if (lane == 0) {
+            SwOut o;
+            o.end_col = -1; o.end_row = -1; o.pad = 0;
+            if (haveA) { o.score = (int32_t) (int16_t) (b & 0xFFFFu); L.out[jobA.slot] = o; }
+            if (haveB) { o.score = (int32_t) (int16_t) (b >> 16); L.out[jobB.slot] = o; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// score-only forward launch for the configurations with at most 256 rows (cfg 0..3); wave_start must cut the job list
+// into waves of at most 2 * 64/16 = 8 jobs of one query
+hipError_t launch_sw_score(const SwLaunch &L, int cfg, hipStream_t stream) {
+    if (!L.wave_start || !L.work_counter || !L.order || cfg < 0 || cfg > 3) return hipErrorInvalidValue;
+    if (L.n_waves == 0) return hipSuccess;
+    const uint64_t grid = std::min<uint64_t>(L.n_waves, L.persistent_blocks ? L.persistent_blocks : L.n_waves);
+    const int rows = sw_cfg_rows(cfg);
+    const size_t lds = (size_t) 22 * rows * sizeof(int16_t);
+    switch (cfg) {
+        case 0: hipLaunchKernelGGL((swp_kernel<2>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
+        case 1: hipLaunchKernelGGL((swp_kernel<4>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
+        case 2: hipLaunchKernelGGL((swp_kernel<8>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
+        default: hipLaunchKernelGGL((swp_kernel<16>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
+    }
+    return hipGetLastError();
+}
+
 template <int G, int R, int BLOCK>
 static hipError_t launch_one(const SwLaunch &L, hipStream_t stream) {
     if (L.wave_start) {                                     // one wave per workgroup, one profile per wave
