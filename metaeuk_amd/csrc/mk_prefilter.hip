@@ -118,6 +118,7 @@ constexpr int FUSED_U = 2;                 // ... in the fused kernels (smaller:
 template <bool GATHER>
 __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
     __shared__ enumk::EnumLds<PROBE_U> sE[4];
+    __builtin_amdgcn_s_setprio(3);                    // latency-bound waves issue ahead of the ALU-bound ones of the other stream
     const int w = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
     const uint64_t p = A.pos_begin + (uint64_t) blockIdx.x * 4 + w;
     if (p >= A.pos_end) return;
@@ -316,6 +317,9 @@ __global__ __launch_bounds__(NW * 64) void fused_kernel(FusedArgs A) {
     __shared__ uint32_t sBump, sOverflow, sEmitBase;
     __shared__ uint32_t sWaveCnt[NW];
 
+    // these waves spend most of their life waiting for index probes: when they do have an instruction, it goes first
+    // (the Smith-Waterman waves of the other stream fill every remaining issue slot)
+    __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, w = tid / WAVE, lane = tid & (WAVE - 1);
     uint32_t q;
     if (blockIdx.x < A.n_own) q = A.queries[blockIdx.x];
