@@ -245,15 +245,26 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const SwJob *j
     uint32_t *dWork = (uint32_t *) dev_scratch("align_workcounters", 64);
     ANULL(dHead); ANULL(dFlag); ANULL(dWave); ANULL(dNum); ANULL(dBounds); ANULL(hb); ANULL(dWork);
     ACHK(hipMemsetAsync(dWork, 0, 64, stream));
-    // persistent forward launch: this many one-wave workgroups per CU (MK_SW_WAVES_PER_CU, default 16 = half the wave slots)
-    static uint32_t persistentBlocks = 0;
-    if (!persistentBlocks) {
+    // persistent forward launch: this many one-wave workgroups per CU and tile configuration (MK_SW_WAVES_PER_CU = one number
+    // or eight, comma separated).  Half the wave slots for the small tiles; fewer for the tiles whose profiles are large, so
+    // that the LDS-hungry prefilter workgroups of the other stream still find room on the CU.
+    static uint32_t persistentBlocks[SW_NCFG] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (!persistentBlocks[0]) {
         int dev = 0, cus = 256;
         (void) hipGetDevice(&dev);
         (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        int perCu = 16;
-        if (const char *e = getenv("MK_SW_WAVES_PER_CU")) perCu = std::max(1, atoi(e));
-        persistentBlocks = (uint32_t) (cus * perCu);
+        int perCu[SW_NCFG] = {16, 16, 12, 8, 8, 8, 8, 8};
+        if (const char *e = getenv("MK_SW_WAVES_PER_CU")) {
+            int k = 0, last = 16;
+            for (const char *p = e; *p && k < SW_NCFG; k++) {
+                last = std::max(1, atoi(p));
+                perCu[k] = last;
+                while (*p && *p != ',') p++;
+                if (*p == ',') p++;
+            }
+            for (; k < SW_NCFG; k++) perCu[k] = last;
+        }
+        for (int c = 0; c < SW_NCFG; c++) persistentBlocks[c] = (uint32_t) (cus * perCu[c]);
     }
     size_t t1 = 0, t2 = 0, t3 = 0;
     hipcub::CountingInputIterator<uint32_t> iota(0);
@@ -283,7 +294,7 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const SwJob *j
         L.jobs = jobs; L.out = out; L.n_jobs = hi - lo; L.order = vb.Current();      // wave_start holds absolute sorted positions
         L.boundary = nullptr; L.boundary_stride = 0; L.boundary_job0 = lo;
         L.wave_start = dWave + wlo; L.n_waves = whi - wlo;
-        L.work_counter = dWork + c; L.persistent_blocks = persistentBlocks;
+        L.work_counter = dWork + c; L.persistent_blocks = persistentBlocks[c];
         L.gap_open = P.gap_open; L.gap_extend = P.gap_extend;
         if (c == SW_NCFG - 1 && V.max_q_len > (uint32_t) sw_cfg_rows(c)) {
             // queries beyond the largest tile run in row tiles with an HBM border per job; the border is as long as the

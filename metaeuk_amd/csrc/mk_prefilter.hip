@@ -10,11 +10,15 @@
 // the double-diagonal rule, per query contiguous and ordered by (target, arrival)):
 //
 //  A. fused_kernel  (queries whose index hits fit in the LDS of one workgroup -- the metagenomic fragment case)
-//     one workgroup per query: the waves enumerate the similar k-mers of their positions (two sorted 3-mer rows,
-//     product order of the reference), read the index lists and drop (target, diagonal) straight into LDS in
-//     arrival order; an in-LDS bitonic sort on (target, arrival) groups the hits per target; the sequential
-//     8-bit-diagonal rule of findDuplicates becomes a neighbour test + short backward walk; only the survivors
-//     leave the CU.  HBM traffic = the index probes, nothing else.
+//     one workgroup per query: the waves take k-mer starts from a shared counter, enumerate their similar k-mers
+//     (mk_enum.hpp: product order of the reference, no searches), probe the index and drop (target, diagonal)
+//     straight into LDS in 64-slot chunks whose arrival rank is (position, chunk, offset); two LDS bitmaps tell which
+//     targets were hit more than once -- only those (and single hits with diagonal low byte 0) can satisfy the
+//     double-diagonal rule; the survivors are compacted in place and sorted on (target, arrival) by an in-LDS bitonic
+//     network; the sequential 8-bit-diagonal rule of findDuplicates becomes a neighbour test + short backward walk;
+//     only the resulting candidates leave the CU.  Four LDS tiers (2 K .. 16 K hits); the host picks the tier from the
+//     exact similar-k-mer count of the query (kmer_count_kernel); a query that overflows its tier is retried by the next
+//     larger tier in the same stream, and by path B after the largest.  HBM traffic = the index probes, nothing else.
 //
 //  B. global path   (everything else: long queries, queries that overflow their LDS tier, big databases)
 //     probe_kernel<COUNT> -> exclusive scan -> probe_kernel<GATHER> (key = (query,target), value = (arrival,diagonal))
@@ -292,13 +296,13 @@ struct FusedArgs {
 
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 // k-mer starts a query may have in the tier with `cap` hit slots (bounds the per-position tables in LDS)
-constexpr int fused_max_positions(int cap) { return cap >= 16384 ? 512 : (cap / 8 < 64 ? 64 : (cap / 8 > 1024 ? 1024 : cap / 8)); }
+constexpr int fused_max_positions(int cap) { return cap / 16 < 64 ? 64 : (cap / 16 > 512 ? 512 : cap / 16); }
 
 template <int CAP, int NW>
 __global__ __launch_bounds__(NW * 64) void fused_kernel(FusedArgs A) {
     constexpr int NCH = CAP / WAVE;               // 64-slot chunks of the hit store
     constexpr int BLOCK = NW * WAVE;
-    constexpr int MBITS = (CAP >= 16384 ? 2 : 4) * CAP;   // buckets of the multi-hit filter (the largest tier is out of LDS)
+    constexpr int MBITS = 2 * CAP;                // buckets of the multi-hit filter (two bitmaps: CAP / 2 bytes)
     constexpr int LOG_MBITS = ilog2(MBITS);
     __shared__ uint32_t sKey[CAP];                // phase 1: target id; afterwards target << ARR_BITS | arrival
     __shared__ uint16_t sDiag[CAP];
@@ -858,6 +862,9 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
         else if (strcmp(e, "default")) { err = "MK_PREFILTER_TIERS must be default or tiny"; return MK_ERR_ARG; }
     }
     const FusedTier *tiers = TIERS + tierBase;
+    int nTiersUsed = N_TIERS;                          // MK_PREFILTER_MAX_TIERS: leave the largest tier(s) to the global path
+    if (const char *e = getenv("MK_PREFILTER_MAX_TIERS")) nTiersUsed = std::min(N_TIERS, std::max(1, atoi(e)));
+    if (hooks.max_tiers > 0) nTiersUsed = std::min(nTiersUsed, hooks.max_tiers);
     if (g_memo.entries != (const void *) V.entries || g_memo.nTargets != V.n_targets) { g_memo = SizingMemo(); g_memo.entries = V.entries; g_memo.nTargets = V.n_targets; }
     double candPerQuery = g_memo.candPerQuery, globalHitsPerPos = 0;
     static_assert(N_TIERS == 4, "SizingMemo holds four tiers");
@@ -928,8 +935,8 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                     const double km = (double) hQK[ql];
                     const int npos = (int) (qOff[(size_t) q0 + ql + 1] - qOff[(size_t) q0 + ql]) - 9;
                     int t = 0;
-                    while (t < N_TIERS && (km > limit[t] || npos > fused_max_positions(tiers[t].cap))) t++;
-                    if (t == N_TIERS) fallback.push_back(ql); else lists[t].push_back(q0 + ql);
+                    while (t < nTiersUsed && (km > limit[t] || npos > fused_max_positions(tiers[t].cap))) t++;
+                    if (t == nTiersUsed) fallback.push_back(ql); else lists[t].push_back(q0 + ql);
                 }
                 for (int t = 0; t < N_TIERS; t++) nListed += lists[t].size();
                 hList = (uint32_t *) pinned_scratch("pf_flist_h", std::max<size_t>(nListed, 1) * 4);
@@ -946,7 +953,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             size_t at = 0, lower = 0;                                       // lower: queries of the smaller tiers (bound on what can overflow into this one)
             for (int t = 0; t < N_TIERS; t++) {
                 thFused[t] = -1;
-                const size_t grid = lists[t].size() + lower;
+                const size_t grid = t < nTiersUsed ? lists[t].size() + lower : 0;
                 if (grid > 0) {
                     FusedArgs A;
                     A.V = V; A.queries = dList + at; A.n_own = (uint32_t) lists[t].size(); A.n_launch = (uint32_t) grid; A.q_first = q0;
@@ -972,7 +979,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                     fprintf(stderr, "[prefilter]   tier %d (lds %d): queries %zu overflowed %llu | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g sort %.3g emit %.3g overflowed %.3g\n",
                             t, tiers[t].cap, lists[t].size(), T[8], (double) T[0], (double) T[1], (double) T[2], (double) T[3], (double) T[4], (double) T[5], (double) T[6]);
                 }
-            const uint32_t nOvf = hCounters[4 + N_TIERS - 1];                  // what even the largest tier could not hold
+            const uint32_t nOvf = hCounters[4 + nTiersUsed - 1];               // what even the largest tier in use could not hold
             if (hCounters[0] > CAND_CAP) rc = RC_CAND_OVERFLOW;
             else {
                 nCand = hCounters[0];
@@ -1001,7 +1008,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                 if (nOvf > 0) {
                     uint32_t *hOvf = (uint32_t *) pinned_scratch("pf_fovf_h", (size_t) nOvf * 4);
                     PNULL(hOvf);
-                    PCHK(hipMemcpyAsync(hOvf, dOvf + (size_t) (N_TIERS - 1) * nqc, (size_t) nOvf * 4, hipMemcpyDeviceToHost, stream));
+                    PCHK(hipMemcpyAsync(hOvf, dOvf + (size_t) (nTiersUsed - 1) * nqc, (size_t) nOvf * 4, hipMemcpyDeviceToHost, stream));
                     PCHK(sync_wait(stream, "wait_prefilter"));
                     fallback.insert(fallback.end(), hOvf, hOvf + nOvf);
                     std::sort(fallback.begin(), fallback.end());
