@@ -202,7 +202,9 @@ def align_result(q):
     _chk(lib().mk_align_result(q.h, C.byref(ap), C.byref(op)))
     off = np.ctypeslib.as_array(C.cast(op, C.POINTER(C.c_uint64)), shape=(q.n + 1,))
     total = int(off[-1])
-    alns = C.cast(ap, C.POINTER(Alignment * max(total, 1))).contents
+    if total == 0 or not ap.value:
+        return (Alignment * 0)(), off
+    alns = C.cast(ap, C.POINTER(Alignment * total)).contents
     return alns, off
 
 

@@ -325,3 +325,28 @@ def test_search_equals_prefilter_then_align(gpu_api, pf_path):
     n = int(aoff1[-1])
     assert n > 100
     assert api.format_alignments(alns1, 0, n) == api.format_alignments(alns2, 0, n)
+
+
+def test_long_and_degenerate_inputs(gpu_api, tmp_path, pf_path):
+    """queries beyond the largest SW tile (row tiles with an HBM border), long targets, query == target (prefilter scores
+    above 255), queries without any k-mer, and an empty batch"""
+    api = gpu_api
+    rng = random.Random(17)
+    base = [_rand_seq(rng, n) for n in (1500, 1100, 700, 3000, 90, 45)]
+    targets = base + [_mutate(rng, base[0], 0.15, 0.02), _mutate(rng, base[1][200:900], 0.1), _mutate(rng, base[3], 0.2, 0.03)]
+    targets += [_rand_seq(rng, rng.randint(40, 400)) for _ in range(120)]
+    queries = [base[0], base[1], _mutate(rng, base[0], 0.1, 0.01), base[3][500:2100], _mutate(rng, base[2], 0.05), base[4], base[5],
+               "ACDEFGHIK", "X" * 40, "", _rand_seq(rng, 10), _mutate(rng, base[1], 0.3, 0.05)]
+    params = api.default_params()
+    db = api.TargetDB(targets, params)
+    q = api.Queries(queries, params)
+    (hits, hoff), (alns, aoff) = api.search(db, q)
+    opref, oaln = oracle.run_pipeline(targets, queries, str(tmp_path), extra=["--l2", str(params.host_l2_bytes)])
+    for i in range(len(queries)):
+        assert api.format_hits(hits, int(hoff[i]), int(hoff[i + 1])) == opref[i], ("pref", i)
+        assert api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1])) == oaln[i], ("aln", i)
+    assert int(aoff[1]) - int(aoff[0]) >= 2            # the 1500-residue query aligns to itself and to its mutated copy
+    # empty batch
+    q0 = api.Queries([], params)
+    (h0, ho0), (a0, ao0) = api.search(db, q0)
+    assert len(ho0) == 1 and int(ho0[0]) == 0 and len(ao0) == 1 and int(ao0[0]) == 0
