@@ -102,7 +102,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("MK_BENCH_FORCE_DIST"):      # the variable exercises the RCCL path on a single GPU
         import torch
         import torch.distributed as dist_
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
