@@ -136,6 +136,13 @@ int mko_aln_compare(const void *a, const void *b);
 size_t mko_format_aln(char *buf, const mko_aln_result *r);
 size_t mko_format_hit(char *buf, const mko_hit *h);
 
+/* ---- extractorfs --translate: M/src/commons/Orf.cpp, TranslateNucl.h, util/extractorfs.cpp ---- */
+typedef struct { size_t from, to; int incomplete_start, incomplete_end, strand; } mko_orf;   /* from/to = header coordinates */
+void mko_translation_table(char table[4096]);     /* amino acid of every IUPAC base-code triple, genetic code 1 */
+size_t mko_extract_orfs(const char *contig, size_t len, size_t minLength, size_t maxLength, size_t maxGaps, int startMode,
+                        mko_orf **orfs, char **aa, size_t **aa_off);
+size_t mko_format_orf_header(char *buf, unsigned int key, const mko_orf *o);
+
 #ifdef __cplusplus
 }
 #endif

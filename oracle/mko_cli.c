@@ -7,6 +7,7 @@
  *   mko_cli submat blosum62|vtml80 <bitFactor> <bias>
  */
 #include "mko.h"
+#include <limits.h>
 #include <float.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -243,10 +244,36 @@ static int cmd_submat(int argc, char **argv) {
     return 0;
 }
 
+/* extractorfs --translate for every contig (one per line): same output format as `ref_harness orfs` */
+static int cmd_orfs(int argc, char **argv) {
+    size_t minLength = 15;
+    for (int i = 4; i + 1 < argc; i++) if (!strcmp(argv[i], "--min-length")) minLength = (size_t) atol(argv[i + 1]);
+    lines_t C = read_lines(argv[2]);
+    FILE *out = fopen(argv[3], "w");
+    if (!out) return 1;
+    size_t total = 0;
+    char hdr[128];
+    for (size_t key = 0; key < C.n; key++) {
+        fprintf(out, ">%zu\n", key);
+        mko_orf *orfs; char *aa; size_t *off;
+        const size_t n = mko_extract_orfs(C.s[key], strlen(C.s[key]), minLength, 32734, (size_t) INT_MAX, 1, &orfs, &aa, &off);
+        for (size_t k = 0; k < n; k++) {
+            mko_format_orf_header(hdr, (unsigned int) key, &orfs[k]);
+            fprintf(out, "%s\t%.*s\n", hdr, (int) (off[k + 1] - off[k]), aa + off[k]);
+        }
+        total += n;
+        free(orfs); free(aa); free(off);
+    }
+    fclose(out);
+    printf("{\"contigs\": %zu, \"orfs\": %zu}\n", C.n, total);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) { fprintf(stderr, "usage: mko_cli pipeline|sw|submat ...\n"); return 2; }
     if (!strcmp(argv[1], "pipeline") && argc >= 5) return cmd_pipeline(argc, argv);
     if (!strcmp(argv[1], "sw") && argc >= 6) return cmd_sw(argc, argv);
     if (!strcmp(argv[1], "submat") && argc >= 5) return cmd_submat(argc, argv);
+    if (!strcmp(argv[1], "orfs") && argc >= 4) return cmd_orfs(argc, argv);
     return 2;
 }

@@ -20,6 +20,10 @@
 //   ref_harness pipeline <matdir> <targets.txt> <queries.txt> <outdir> [-s 5.7] [--threads N] [--dump]
 //   ref_harness sw       <matdir> <targets.txt> <queries.txt> <pairs.txt> <out.txt> [--dbres N]
 //   ref_harness submat   <matfile.out> <bitFactor> <bias>
+//   ref_harness orfs     <contigs.txt> <out.txt> [--min-length 15]
+//     = extractorfs --translate as `predictexons` runs it (util/extractorfs.cpp:19-159 loop, Orf::findAll with
+//       orf-start-mode 1, both strands, all frames, translation table 1): per contig one ">key" line, then one line per
+//       ORF fragment "header<TAB>protein" in the order extractorfs writes them (= the renumbered ORF ids)
 // Sequence files: one amino-acid sequence per line; key = 0-based line number.
 #include "SubstitutionMatrix.h"
 #include "ExtendedSubstitutionMatrix.h"
@@ -33,6 +37,8 @@
 #include "Parameters.h"
 #include "Util.h"
 #include "FastSort.h"
+#include "Orf.h"
+#include "TranslateNucl.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -351,11 +357,56 @@ static int cmdSw(int argc, char **argv) {
     return 0;
 }
 
+// extractorfs.cpp:64-125 for one contig after another (contig/orf start and end modes 2 = keep everything)
+static int cmdOrfs(int argc, char **argv) {
+    if (argc < 4) return 2;
+    size_t minLength = 15;                                       // PredictExons.cpp:11
+    for (int i = 4; i + 1 < argc; i++) if (!strcmp(argv[i], "--min-length")) minLength = (size_t) atol(argv[i + 1]);
+    std::vector<std::string> contigs = readLines(argv[2]);
+    FILE *out = fopen(argv[3], "w");
+    if (!out) return 1;
+    const size_t maxSeqLen = 65535;                              // Parameters.cpp default
+    Orf orf(1, false);
+    TranslateNucl translateNucl(static_cast<TranslateNucl::GenCode>(1));
+    const unsigned int forwardFrames = Orf::getFrames("1,2,3"), reverseFrames = Orf::getFrames("1,2,3");
+    std::vector<Orf::SequenceLocation> res;
+    std::vector<char> aa(maxSeqLen + 3 + 1);
+    char buffer[1024];
+    size_t nOrf = 0;
+    for (size_t key = 0; key < contigs.size(); key++) {
+        fprintf(out, ">%zu\n", key);
+        const std::string data = contigs[key] + "\n";            // DB entries end with a newline
+        const size_t sequenceLength = contigs[key].size();
+        if (!orf.setSequence(data.c_str(), sequenceLength)) continue;
+        res.clear();
+        orf.findAll(res, minLength, 32734, INT_MAX, forwardFrames, reverseFrames, 1);
+        for (size_t k = 0; k < res.size(); k++) {
+            Orf::SequenceLocation loc = res[k];
+            std::pair<const char *, size_t> sequence = orf.getSequence(loc);
+            size_t fromPos = loc.from, toPos = loc.to;
+            if (loc.strand == Orf::STRAND_MINUS) { fromPos = (sequenceLength - 1) - loc.from; toPos = (sequenceLength - 1) - loc.to; }
+            Orf::writeOrfHeader(buffer, (unsigned int) key, fromPos, toPos, loc.hasIncompleteStart, loc.hasIncompleteEnd);
+            if ((data[sequence.second] != '\n' && sequence.second % 3 != 0) && (data[sequence.second - 1] == '\n' && (sequence.second - 1) % 3 != 0))
+                sequence.second = sequence.second - (sequence.second % 3);
+            if (sequence.second < 3) continue;
+            if (sequence.second > (3 * maxSeqLen)) sequence.second = (3 * maxSeqLen);
+            translateNucl.translate(aa.data(), sequence.first, sequence.second);
+            buffer[strlen(buffer) - 1] = '\0';                   // drop the header's newline
+            fprintf(out, "%s\t%.*s\n", buffer, (int) (sequence.second / 3), aa.data());
+            nOrf++;
+        }
+    }
+    fclose(out);
+    printf("{\"contigs\": %zu, \"orfs\": %zu}\n", contigs.size(), nOrf);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) { fprintf(stderr, "usage: ref_harness pipeline|sw|submat ...\n"); return 2; }
     std::string cmd = argv[1];
     if (cmd == "submat") return cmdSubmat(argc, argv);
     if (cmd == "pipeline") return cmdPipeline(argc, argv);
     if (cmd == "sw") return cmdSw(argc, argv);
+    if (cmd == "orfs") return cmdOrfs(argc, argv);
     return 2;
 }

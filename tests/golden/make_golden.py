@@ -84,6 +84,31 @@ def sw_pairs_fixture(tmp):
     return targets, queries, outs[0]
 
 
+def orf_contigs():
+    """contigs for the extractorfs fixture: synthetic metagenome contigs with IUPAC codes, N runs, lower-case stretches,
+    U, gaps and junk characters sprinkled in, plus degenerate ones (shorter than a codon, only stops, no stop at all)"""
+    import random
+    rng = random.Random(3)
+    _, founders = synth.make_targets(120, 5)
+    contigs = []
+    for c in synth.make_contigs(90, founders, 5):
+        s = list("".join("ACGT"[x] for x in c))
+        for _ in range(rng.randint(0, 6)):
+            s[rng.randrange(len(s))] = rng.choice("NRYKMSWBDHVnU-uX*")
+        if rng.random() < 0.3:
+            a = rng.randrange(len(s) - 50)
+            n = rng.randint(1, 40)
+            s[a:a + n] = list("N" * n)
+        if rng.random() < 0.3:
+            a = rng.randrange(len(s) - 200)
+            b = a + rng.randint(1, 200)
+            s[a:b] = list("".join(s[a:b]).lower())
+        contigs.append("".join(s))
+    contigs += ["ACG", "AC", "", "TAATAATAA", "ATGTAA" * 40, "N" * 100, "acgt" * 30, "A" * 46, "TTA" * 15 + "C", "C" + "TAA" * 20 + "GG",
+                "ATG" + "GCA" * 30 + "TAA" + "C" * 10, "ACGTNNNNacgtRYKM" * 20]
+    return contigs
+
+
 def write(name, text):
     with gzip.open(os.path.join(HERE, name), "wt", compresslevel=9) as f:
         f.write(text)
@@ -105,6 +130,17 @@ def main():
         write("sw_queries.txt.gz", "\n".join(q) + "\n")
         write("sw_expected.tsv.gz", sw)
         print("sw pairs", len(q))
+        contigs = orf_contigs()
+        cf, of = os.path.join(tmp, "contigs.txt"), os.path.join(tmp, "orfs.txt")
+        open(cf, "w").write("\n".join(contigs) + "\n")
+        outs = []
+        for binary in (REF_AVX2, REF_SSE):
+            subprocess.check_call([binary, "orfs", cf, of], stdout=subprocess.DEVNULL)
+            outs.append(open(of).read())
+        assert outs[0] == outs[1], "AVX2 and SSE4.1 reference builds disagree on the ORF fixture"
+        write("orf_contigs.txt.gz", "\n".join(contigs) + "\n")
+        write("orf_expected.txt.gz", outs[0])
+        print("orf contigs", len(contigs), "fragments", outs[0].count("\n") - len(contigs))
         l2 = int(subprocess.check_output(["getconf", "LEVEL2_CACHE_SIZE"]).decode().strip() or 0)
         open(os.path.join(HERE, "PROVENANCE.txt"), "w").write(
             "generated by tests/golden/make_golden.py with oracle/_ref/ref_harness (reference sources compiled with g++ -mavx2;\n"

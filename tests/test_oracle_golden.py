@@ -43,6 +43,14 @@ def test_oracle_sw_matches_golden(tmp_path):
         assert (tmp_path / "out.tsv").read_text() == _text("sw_expected.tsv.gz"), lanes
 
 
+def test_oracle_orfs_match_golden(tmp_path):
+    """extractorfs --translate (Orf::findAll, TranslateNucl, header format) against the reference's own output"""
+    oracle.build()
+    (tmp_path / "c.txt").write_text(_text("orf_contigs.txt.gz"))
+    subprocess.check_call([oracle.CLI, "orfs", str(tmp_path / "c.txt"), str(tmp_path / "o.txt")], stdout=subprocess.DEVNULL)
+    assert (tmp_path / "o.txt").read_text() == _text("orf_expected.txt.gz")
+
+
 @pytest.mark.skipif(not os.path.exists(oracle.REF) or not os.path.isdir("/root/reference"), reason="reference harness not built here")
 def test_oracle_matches_live_reference(tmp_path):
     from metaeuk_amd import synth
