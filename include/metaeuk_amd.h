@@ -119,6 +119,24 @@ int mk_prefilter_result_set(mk_queries *q, const mk_hit *hits, const uint64_t *o
 int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *params);
 int mk_align_result(const mk_queries *q, const mk_alignment **alns, const uint64_t **offsets /* n+1 */);
 
+/* ---- producer of the query batch: `extractorfs --translate` as predictexons runs it
+ * (util/extractorfs.cpp:19-159, Orf::findAll with orf-start-mode 1, all six frames, genetic code 1, contig start / end mode
+ * 2).  Contigs are ASCII nucleotides (IUPAC codes, lower case, U allowed), concatenated, offsets[n_contigs + 1].
+ * Fragment k is what the reference's renumbered ORF DB holds under key k. */
+typedef struct mk_orfs mk_orfs;
+typedef struct mk_orf {
+    uint32_t contig;            /* index of the contig */
+    uint32_t from, to;          /* Orf::writeOrfHeader coordinates on the contig (from > to on the minus strand) */
+    uint8_t incomplete_start, incomplete_end, minus_strand, pad_;
+} mk_orf;
+int mk_extract_orfs(const char *nucleotides, const uint64_t *offsets, uint32_t n_contigs, int min_codons, mk_orfs **out);
+/* fragments, their translations (ASCII, case preserved) as aa[aa_offsets[k] .. aa_offsets[k+1]) ; views owned by the handle */
+int mk_orfs_result(const mk_orfs *o, const mk_orf **orfs, const uint64_t **aa_offsets, const char **aa, uint64_t *n_orfs);
+/* the fragments as a query batch: the residue codes go from the translation kernel to the search without leaving HBM */
+int mk_queries_from_orfs(const mk_orfs *o, const mk_params *params, mk_queries **out);
+void mk_orfs_destroy(mk_orfs *o);
+size_t mk_format_orf_header(char *buf, const mk_orf *o);   /* "contig<TAB>from(+|-)len[<TAB>complete]", Orf.cpp:434-452 */
+
 /* ---- prefilter + align of the batch in one pipelined pass: the `search` workflow's two module calls
  * (blastp.sh:70,85 via predictexons.sh:68).  Same results as mk_prefilter followed by mk_align (both result
  * getters work afterwards); the stages run concurrently on two HIP streams, chunk by chunk. */

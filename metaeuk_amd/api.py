@@ -42,7 +42,8 @@ HIT_DTYPE = np.dtype([("seq_id", "<u4"), ("pref_score", "<i4"), ("diagonal", "<u
 EXPORTS = ["mk_init", "mk_last_error", "mk_default_params", "mk_device_name", "mk_encode", "mk_targetdb_create",
            "mk_targetdb_destroy", "mk_targetdb_residues", "mk_targetdb_index_entries", "mk_targetdb_masked",
            "mk_queries_create", "mk_queries_destroy", "mk_queries_derived", "mk_prefilter", "mk_prefilter_result", "mk_prefilter_result_set",
-           "mk_align", "mk_align_result", "mk_search", "mk_sw_pairs", "mk_ungapped",
+           "mk_align", "mk_align_result", "mk_search", "mk_extract_orfs", "mk_orfs_result", "mk_queries_from_orfs",
+           "mk_orfs_destroy", "mk_format_orf_header", "mk_sw_pairs", "mk_ungapped",
            "mk_kernel_stats", "mk_kernel_stats_reset", "mk_format_hit", "mk_format_alignment"]
 
 
@@ -58,6 +59,7 @@ def lib():
         L.mk_targetdb_index_entries.restype = C.c_uint64
         L.mk_format_hit.restype = C.c_size_t
         L.mk_format_alignment.restype = C.c_size_t
+        L.mk_format_orf_header.restype = C.c_size_t
         _LIB = L
     return _LIB
 
@@ -181,6 +183,59 @@ def prefilter_result(q):
         return np.zeros(0, dtype=HIT_DTYPE), off
     raw = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_uint8)), shape=(total * HIT_DTYPE.itemsize,))
     return raw.view(HIT_DTYPE), off
+
+
+ORF_DTYPE = np.dtype([("contig", "<u4"), ("from", "<u4"), ("to", "<u4"), ("incomplete_start", "u1"), ("incomplete_end", "u1"),
+                      ("minus_strand", "u1"), ("pad_", "u1")])
+
+
+class Orfs:
+    """six-frame ORF fragments of a list of contigs (nucleotide strings), translated on the GPU"""
+
+    def __init__(self, contigs, min_codons=15):
+        raw = "".join(contigs).encode("latin-1")
+        off = np.zeros(len(contigs) + 1, dtype=np.uint64)
+        np.cumsum([len(c) for c in contigs], out=off[1:])
+        self.h = C.c_void_p()
+        _chk(lib().mk_extract_orfs(C.c_char_p(raw), _p(off), C.c_uint32(len(contigs)), C.c_int(min_codons), C.byref(self.h)))
+        op, fp, ap, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+        _chk(lib().mk_orfs_result(self.h, C.byref(op), C.byref(fp), C.byref(ap), C.byref(n)))
+        self.n = int(n.value)
+        if self.n:
+            self.orfs = np.ctypeslib.as_array(C.cast(op, C.POINTER(C.c_uint8)), shape=(self.n * ORF_DTYPE.itemsize,)).view(ORF_DTYPE)
+            self.aa_off = np.ctypeslib.as_array(C.cast(fp, C.POINTER(C.c_uint64)), shape=(self.n + 1,))
+            self.aa = C.string_at(ap, int(self.aa_off[-1]))
+        else:
+            self.orfs, self.aa_off, self.aa = np.zeros(0, dtype=ORF_DTYPE), np.zeros(1, dtype=np.uint64), b""
+
+    def protein(self, k):
+        return self.aa[int(self.aa_off[k]):int(self.aa_off[k + 1])].decode("latin-1")
+
+    def header(self, k):
+        buf = C.create_string_buffer(96)
+        n = lib().mk_format_orf_header(buf, self.orfs[k:k + 1].ctypes.data_as(C.c_void_p))
+        return buf.raw[:n].decode()
+
+    def queries(self, params=None):
+        """the fragments as a query batch (device-resident hand-over)"""
+        q = Queries.__new__(Queries)
+        q.params = params or default_params()
+        q.h = C.c_void_p()
+        _chk(lib().mk_queries_from_orfs(self.h, C.byref(q.params), C.byref(q.h)))
+        q.n = self.n
+        q.res, q.off = None, np.array(self.aa_off, dtype=np.uint64)
+        return q
+
+    def close(self):
+        if self.h:
+            lib().mk_orfs_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def search(db, q, params=None):

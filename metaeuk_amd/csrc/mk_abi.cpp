@@ -6,6 +6,7 @@
 #include "mk_align.hpp"
 #include "mk_host.hpp"
 #include "mk_kernels.hpp"
+#include "mk_orf.hpp"
 #include "mk_prefilter.hpp"
 
 #include <algorithm>
@@ -355,7 +356,9 @@ int mk_targetdb_masked(const mk_targetdb *db, uint8_t *out) {
     return MK_OK;
 }
 
-int mk_queries_create(const uint8_t *residues, const uint64_t *offsets, uint32_t n, const mk_params *P, mk_queries **out) {
+// residues come from the host (upload) or are already in HBM (devResidues: device-to-device copy); the host copy is kept
+// for the rare exact self-score of the --max-seqs path
+static int queries_create(const uint8_t *residues, const uint8_t *devResidues, const uint64_t *offsets, uint32_t n, const mk_params *P, mk_queries **out) {
     int rc = ensure_ready();
     if (rc) return rc;
     if (!residues || !offsets || !P || !out) return fail(MK_ERR_ARG, "null argument");
@@ -375,7 +378,12 @@ int mk_queries_create(const uint8_t *residues, const uint64_t *offsets, uint32_t
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; };
     const uint64_t total = offsets[n];
-    ok(q->dRes.upload(residues, total));
+    if (devResidues) {
+        ok(q->dRes.alloc(total));
+        if (e == hipSuccess && total) ok(hipMemcpyAsync(q->dRes.p, devResidues, total, hipMemcpyDeviceToDevice, g_stream));
+    } else {
+        ok(q->dRes.upload(residues, total));
+    }
     ok(q->dOff.upload(offsets, n + 1));
     ok(q->dKmerThr.alloc(total));
     ok(q->dCorr.alloc(total));
@@ -391,6 +399,84 @@ int mk_queries_create(const uint8_t *residues, const uint64_t *offsets, uint32_t
     if (e != hipSuccess) { delete q; return fail(MK_ERR_DEVICE, "query upload failed: %s", hipGetErrorString(e)); }
     *out = q;
     return MK_OK;
+}
+
+int mk_queries_create(const uint8_t *residues, const uint64_t *offsets, uint32_t n, const mk_params *P, mk_queries **out) {
+    return queries_create(residues, nullptr, offsets, n, P, out);
+}
+
+// ---- extractorfs --translate on the device (mk_orf.hip) ----
+struct mk_orfs {
+    mk::OrfDeviceResult dev;
+    std::vector<mk_orf> orfs;
+    std::vector<uint64_t> aaOff;
+    std::vector<char> aa;
+    std::vector<uint8_t> codes;
+    ~mk_orfs() { dev.release(); }
+};
+
+int mk_extract_orfs(const char *nucleotides, const uint64_t *offsets, uint32_t nContigs, int minCodons, mk_orfs **out) {
+    int rc = ensure_ready();
+    if (rc) return rc;
+    if (!offsets || !out || (!nucleotides && offsets[nContigs] > 0) || minCodons < 1) return fail(MK_ERR_ARG, "bad argument");
+    for (uint32_t i = 0; i < nContigs; i++) {
+        if (offsets[i + 1] < offsets[i]) return fail(MK_ERR_ARG, "offsets are not ascending at contig %u", i);
+        if (offsets[i + 1] - offsets[i] >= 0x7FFFFFF0ull) return fail(MK_ERR_UNSUPPORTED, "contig %u is >= 2^31 nucleotides", i);
+    }
+    HostTimer ht("host_extract_orfs_total");
+    mk_orfs *o = new mk_orfs();
+    DevBuf<char> dNucl;
+    DevBuf<uint64_t> dOff;
+    hipError_t e = dNucl.alloc(std::max<uint64_t>(offsets[nContigs], 1));
+    if (e == hipSuccess && offsets[nContigs]) e = hipMemcpyAsync(dNucl.p, nucleotides, offsets[nContigs], hipMemcpyHostToDevice, g_stream);
+    if (e == hipSuccess) e = dOff.upload(offsets, (size_t) nContigs + 1);
+    if (e != hipSuccess) { delete o; return fail(MK_ERR_DEVICE, "contig upload failed: %s", hipGetErrorString(e)); }
+    std::string err;
+    const int th = timed_begin("extract_orfs", (double) offsets[nContigs] * 2.0, 0);
+    rc = mk::run_extract_orfs(dNucl.p, dOff.p, nContigs, (uint32_t) minCodons, 32734u, (uint64_t) INT_MAX, g_stream, o->dev, err);
+    timed_end(th);
+    timed_flush();
+    if (rc != MK_OK) { delete o; return fail(rc, "%s", err.c_str()); }
+    const uint64_t nf = o->dev.n_frag, na = o->dev.n_aa;
+    o->orfs.resize(nf); o->aaOff.assign(nf + 1, 0); o->aa.resize(na); o->codes.resize(na);
+    if (nf) {
+        std::vector<mk::OrfRecord> rec(nf);
+        HIPCHK(hipMemcpy(rec.data(), o->dev.records, nf * sizeof(mk::OrfRecord), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(o->aaOff.data(), o->dev.aa_off, (nf + 1) * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(o->aa.data(), o->dev.aa_ascii, na, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(o->codes.data(), o->dev.aa_code, na, hipMemcpyDeviceToHost));
+#pragma omp parallel for schedule(static)
+        for (uint64_t k = 0; k < nf; k++) {
+            const mk::OrfRecord &r = rec[k];
+            const uint32_t len = (uint32_t) (offsets[r.contig + 1] - offsets[r.contig]);
+            const uint32_t sTo = r.s_from + 3 * r.n_aa - 1;           // strand coordinates; the minus strand is mirrored (extractorfs.cpp:88-93)
+            mk_orf &h = o->orfs[k];
+            h.contig = r.contig;
+            h.minus_strand = (r.flags & 4u) ? 1 : 0;
+            h.from = h.minus_strand ? (len - 1) - r.s_from : r.s_from;
+            h.to = h.minus_strand ? (len - 1) - sTo : sTo;
+            h.incomplete_start = (r.flags & 1u) ? 1 : 0; h.incomplete_end = (r.flags & 2u) ? 1 : 0; h.pad_ = 0;
+        }
+    }
+    *out = o;
+    return MK_OK;
+}
+
+int mk_orfs_result(const mk_orfs *o, const mk_orf **orfs, const uint64_t **aaOffsets, const char **aa, uint64_t *nOrfs) {
+    if (!o || !orfs || !aaOffsets || !aa || !nOrfs) return fail(MK_ERR_ARG, "null argument");
+    *orfs = o->orfs.data(); *aaOffsets = o->aaOff.data(); *aa = o->aa.data(); *nOrfs = o->orfs.size();
+    return MK_OK;
+}
+
+int mk_queries_from_orfs(const mk_orfs *o, const mk_params *P, mk_queries **out) {
+    if (!o || !P || !out) return fail(MK_ERR_ARG, "null argument");
+    static const uint8_t none = 0;
+    return queries_create(o->codes.empty() ? &none : o->codes.data(), o->dev.aa_code, o->aaOff.data(), (uint32_t) o->orfs.size(), P, out);
+}
+
+void mk_orfs_destroy(mk_orfs *o) { delete o; }
+size_t mk_format_orf_header(char *buf, const mk_orf *o) {
+    return mk::format_orf_header(buf, o->contig, o->from, o->to, o->incomplete_start != 0, o->incomplete_end != 0);
 }
 
 void mk_queries_destroy(mk_queries *q) { delete q; }

@@ -415,6 +415,61 @@ int select_hits(std::vector<Cand> &cands, int binCount, int maxHits, int minDiag
     return n;
 }
 
+// Orf::iupacReverseComplementTable (Orf.cpp:48-52) and TranslateNucl::initConversionTable (TranslateNucl.h:305-343)
+void build_orf_tables(char comp[256], uint8_t base[256]) {
+    std::memset(comp, '.', 256);
+    const char *from = "ACGTUMRWSYKVHDBNacgtumrwsykvhdbn", *to = "TGCAAKYWSRMBDHVNtgcaakywsrmbdhvn";
+    for (int i = 0; from[i]; i++) comp[static_cast<unsigned char>(from[i])] = to[i];
+    std::memset(base, 0, 256);
+    const char *codes = "-ACMGRSVTWYHKDBN";                  // eBase_gap .. eBase_N: bit 1 = A, 2 = C, 4 = G, 8 = T
+    for (int i = 0; i < 16; i++) {
+        base[static_cast<unsigned char>(codes[i])] = static_cast<uint8_t>(i);
+        base[static_cast<unsigned char>(std::tolower(codes[i]))] = static_cast<uint8_t>(i);
+    }
+    base['U'] = base['u'] = 8;
+    base['X'] = base['x'] = 15;
+    for (int i = 0; i < 16; i++) base[i] = static_cast<uint8_t>(i);
+}
+
+// TranslateNucl::initTranslationTable (TranslateNucl.h:344-483) for the canonical code: the residue common to all the
+// unambiguous codons an IUPAC codon stands for, with the B (D/N), Z (E/Q), J (I/L) unions, else X
+void build_translation_table(char table[4096]) {
+    const char *aaOf = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";   // TCAG order
+    auto tcag = [](int bit) { return bit == 8 ? 0 : bit == 2 ? 1 : bit == 1 ? 2 : 3; };
+    for (int i = 0; i < 16; i++)
+        for (int j = 0; j < 16; j++)
+            for (int k = 0; k < 16; k++) {
+                char aa = 0;
+                for (int x = 1; x <= 8; x <<= 1) {
+                    if (!(x & i)) continue;
+                    for (int y = 1; y <= 8; y <<= 1) {
+                        if (!(y & j)) continue;
+                        for (int z = 1; z <= 8; z <<= 1) {
+                            if (!(z & k)) continue;
+                            // expansion order of the reference is A, C, G, T on every position (bits 1, 2, 4, 8)
+                            const char ch = aaOf[16 * tcag(x) + 4 * tcag(y) + tcag(z)];
+                            if (!aa) aa = ch;
+                            else if (aa != ch) {
+                                if ((aa == 'B' || aa == 'D' || aa == 'N') && (ch == 'D' || ch == 'N')) aa = 'B';
+                                else if ((aa == 'Z' || aa == 'E' || aa == 'Q') && (ch == 'E' || ch == 'Q')) aa = 'Z';
+                                else if ((aa == 'J' || aa == 'I' || aa == 'L') && (ch == 'I' || ch == 'L')) aa = 'J';
+                                else aa = 'X';
+                            }
+                        }
+                    }
+                }
+                table[256 * i + 16 * j + k] = aa ? aa : 'X';
+            }
+}
+
+size_t format_orf_header(char *buf, uint32_t key, uint32_t from, uint32_t to, bool incompleteStart, bool incompleteEnd) {
+    const int len = std::abs(static_cast<int>(from) - static_cast<int>(to));
+    const int complete = (incompleteStart ? 1 : 0) | ((incompleteEnd ? 1 : 0) << 1);
+    int n = std::snprintf(buf, 64, "%u\t%u%c%d", key, from, from < to ? '+' : '-', len);
+    if (complete) n += std::snprintf(buf + n, 16, "\t%d", complete);
+    return static_cast<size_t>(n);
+}
+
 float compute_cov(unsigned int s, unsigned int e, unsigned int len) {
     return (std::min(len, std::max(s, e)) - std::min(s, e) + 1) / static_cast<float>(len);
 }

@@ -68,6 +68,14 @@ struct Cand { uint32_t id; uint16_t diag; int32_t score; uint32_t ordinal; };
 // hit order (ascending ordinal).  selfScore = exact ungapped self score (only used when saturated).
 int select_hits(std::vector<Cand> &cands, int binCount, int maxHits, int minDiagScore, int selfScore, mk_hit *out);
 
+// ---- extractorfs --translate (Orf.cpp, TranslateNucl.h) ----
+// comp[c] = Orf::iupacReverseComplementTable ('.' = not a nucleotide code); base[c] = TranslateNucl::sm_BaseToIdx (4-bit IUPAC sets)
+void build_orf_tables(char comp[256], uint8_t base[256]);
+// residue of every base-code triple (256 i + 16 j + k) under genetic code 1, ambiguity resolved like TranslateNucl::initTranslationTable
+void build_translation_table(char table[4096]);
+// Orf::writeOrfHeader without the newline: "key<TAB>from(+|-)len[<TAB>complete]"
+size_t format_orf_header(char *buf, uint32_t key, uint32_t from, uint32_t to, bool incompleteStart, bool incompleteEnd);
+
 float compute_cov(unsigned int startPos, unsigned int endPos, unsigned int len);
 size_t format_hit(char *buf, uint32_t key, int32_t score, uint16_t diag);
 size_t format_alignment(char *buf, const mk_alignment &a);

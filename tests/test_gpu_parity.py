@@ -350,3 +350,51 @@ def test_long_and_degenerate_inputs(gpu_api, tmp_path, pf_path):
     q0 = api.Queries([], params)
     (h0, ho0), (a0, ao0) = api.search(db, q0)
     assert len(ho0) == 1 and int(ho0[0]) == 0 and len(ao0) == 1 and int(ao0[0]) == 0
+
+
+def _orf_lines(o, contig_count):
+    """Orfs handle -> the `ref_harness orfs` text format"""
+    out, k = [], 0
+    for c in range(contig_count):
+        out.append(">%d" % c)
+        while k < o.n and int(o.orfs[k]["contig"]) == c:
+            out.append(o.header(k) + "\t" + o.protein(k))
+            k += 1
+    assert k == o.n
+    return "\n".join(out) + "\n"
+
+
+def test_extract_orfs_vs_golden(gpu_api):
+    """extractorfs --translate on the device against the reference's own output (IUPAC codes, N runs, lower case, U, junk
+    characters, contigs shorter than a codon, stop-only and stop-free contigs)"""
+    contigs = _lines("orf_contigs.txt.gz")
+    with gzip.open(os.path.join(GOLD, "orf_expected.txt.gz"), "rt") as f:
+        expected = f.read()
+    o = gpu_api.Orfs(contigs)
+    assert _orf_lines(o, len(contigs)) == expected
+
+
+def test_orfs_feed_the_search(gpu_api, tmp_path):
+    """contigs -> ORF fragments -> query batch without leaving HBM: same fragments as the oracle's extractorfs, and the
+    search over them equals the search over the same proteins handed in as strings"""
+    from metaeuk_amd import synth
+    import subprocess
+    api = gpu_api
+    targets, founders = synth.make_targets(300, 9)
+    tstr = [synth.codes_to_str(t) for t in targets]
+    contigs = ["".join("ACGT"[x] for x in c) for c in synth.make_contigs(25, founders, 9)]
+    o = api.Orfs(contigs)
+    (tmp_path / "c.txt").write_text("\n".join(contigs) + "\n")
+    oracle.build()
+    subprocess.check_call([oracle.CLI, "orfs", str(tmp_path / "c.txt"), str(tmp_path / "o.txt")], stdout=subprocess.DEVNULL)
+    assert _orf_lines(o, len(contigs)) == (tmp_path / "o.txt").read_text()
+    params = api.default_params()
+    db = api.TargetDB(tstr, params)
+    q1 = o.queries(params)
+    (h1, ho1), (a1, ao1) = api.search(db, q1)
+    q2 = api.Queries([o.protein(k) for k in range(o.n)], params)
+    (h2, ho2), (a2, ao2) = api.search(db, q2)
+    assert np.array_equal(np.asarray(ho1), np.asarray(ho2)) and h1.tobytes() == h2.tobytes()
+    assert np.array_equal(np.asarray(ao1), np.asarray(ao2))
+    n = int(ao1[-1])
+    assert n > 20 and api.format_alignments(a1, 0, n) == api.format_alignments(a2, 0, n)
