@@ -6,9 +6,9 @@
 //   TranslateNucl::translate                    M/src/commons/TranslateNucl.h:488-503 (IUPAC-aware table: mk_host.cpp)
 // Layout: contigs stay as the caller's ASCII in HBM; nothing is copied or reverse-complemented -- the minus strand is an
 // index transform + complement lookup.  Three kernels:
-//   orf_scan_kernel<false>   one lane per (contig, strand): the reference's three-frame state machine, counting only
-//   orf_scan_kernel<true>    the same walk, writing one record per fragment at its scanned position -- fragments come out
-//                            in the order the reference writes them (= the renumbered ORF ids)
+//   orf_mark_kernel          one lane per strand position: does a fragment end here, and how many codons has it
+//   prefix sums (hipcub)     rank of every fragment = the reference's output order (= the renumbered ORF ids), residue offsets
+//   orf_write_kernel         one record per fragment at its rank
 //   orf_translate_kernel     one lane per amino acid: codon -> residue (ASCII, case preserved) and aa2num code
 // The fragment codes stay in HBM and become the query batch of mk_search without a host round trip.
 #include "mk_orf.hpp"
@@ -42,56 +42,77 @@ struct Strand {
 __device__ __forceinline__ char upper_or_max(char c) { return c == (char) CHAR_MAX ? c : (char) (c & (unsigned char) ~0x20); }
 __device__ __forceinline__ bool not_nucleotide(char c) { return c == 'N' || cComplement[(unsigned char) c] == '.'; }
 
-template <bool WRITE>
-__global__ __launch_bounds__(64) void orf_scan_kernel(OrfScanArgs A) {
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;       // contig * 2 + strand
-    if (id >= 2 * A.n_contigs) return;
-    const uint32_t contig = id >> 1;
-    Strand S;
-    S.seq = A.nucl + A.offsets[contig]; S.len = (uint32_t) (A.offsets[contig + 1] - A.offsets[contig]); S.minus = id & 1u;
-    uint32_t nFrag = 0;
-    uint64_t nAa = 0;
-    uint64_t fragAt = 0, aaAt = 0;
-    if (WRITE) { fragAt = A.frag_base[id]; aaAt = A.aa_base[id]; }
-    if (S.len >= 3) {
-        bool inside[3] = {true, true, true}, hasStart[3] = {false, false, false};
-        uint32_t count[3] = {0, 0, 0}, from[3] = {0, 1, 2};
-        uint64_t gaps[3] = {0, 0, 0};
-        // sliding window of the upper-cased strand: c0 c1 c2 = codon at `position`, n0 n1 n2 = the frame's next codon
-        for (uint32_t i = 0; i < S.len - 2; i += 3) {
-            for (uint32_t position = i; position < i + 3; position++) {
-                const char c0 = upper_or_max(S.at(position)), c1 = upper_or_max(S.at(position + 1)), c2 = upper_or_max(S.at(position + 2));
-                const uint32_t frame = position % 3;
-                const bool thisIncomplete = c0 == (char) CHAR_MAX || c1 == (char) CHAR_MAX || c2 == (char) CHAR_MAX;
-                const bool nextIncomplete = S.at(position + 3) == (char) CHAR_MAX || S.at(position + 4) == (char) CHAR_MAX || S.at(position + 5) == (char) CHAR_MAX;
-                const bool isLast = !thisIncomplete && nextIncomplete;
-                if (!inside[frame]) {                                  // ANY_TO_STOP: a fragment starts right behind every stop
-                    inside[frame] = true; hasStart[frame] = true; from[frame] = position; gaps[frame] = 0; count[frame] = 0;
-                }
-                const bool stop = c0 == 'T' && ((c1 == 'A' && (c2 == 'A' || c2 == 'G')) || (c1 == 'G' && c2 == 'A'));
-                if (!stop) count[frame]++;
-                if (not_nucleotide(c0) || not_nucleotide(c1) || not_nucleotide(c2)) gaps[frame]++;
-                if (stop || isLast) {
-                    inside[frame] = false;
-                    if (count[frame] == 0 && stop) continue;
-                    const uint32_t to = (isLast && !stop) ? position + 2 : position - 1;
-                    if (gaps[frame] > A.max_gaps || count[frame] > A.max_length || count[frame] < A.min_length) continue;
-                    const uint32_t naa = (to - from[frame] + 1) / 3;
-                    if (WRITE) {
-                        OrfRecord r;
-                        r.contig = contig; r.s_from = from[frame]; r.n_aa = naa;
-                        r.flags = (hasStart[frame] ? 0u : 1u) | (stop ? 0u : 2u) | (S.minus ? 4u : 0u);
-                        A.records[fragAt + nFrag] = r;
-                        A.aa_off[fragAt + nFrag] = aaAt + nAa;
-                    }
-                    nFrag++;
-                    nAa += naa;
-                }
-            }
-        }
-    }
-    if (!WRITE) { A.frag_count[id] = nFrag; A.aa_count[id] = nAa; }
+// With orf-start-mode 1 a fragment is a maximal stop-free codon run of one frame: it ENDS at a stop codon or at the last
+// complete codon of the frame, and STARTS three behind the previous stop of the frame (or at the frame offset: incomplete
+// start).  So every strand position decides on its own whether a fragment ends there (one lane per position, a short
+// backward walk to the previous stop), and the reference's output order -- contig, plus strand then minus strand, end
+// position ascending across the three frames -- is the order of the position index itself: ranks are a prefix sum.
+// (Orf::findForward's per-frame state machine, Orf.cpp:220-345; --max-gaps is the reference's default INT_MAX, i.e. off.)
+__device__ __forceinline__ bool stop_at(const Strand &S, uint32_t p) {
+    const char c0 = upper_or_max(S.at(p));
+    if (c0 != 'T') return false;
+    const char c1 = upper_or_max(S.at(p + 1)), c2 = upper_or_max(S.at(p + 2));
+    return (c1 == 'A' && (c2 == 'A' || c2 == 'G')) || (c1 == 'G' && c2 == 'A');
 }
+
+// fragment ending at strand position p (0 codons = none): start, length, flags
+__device__ __forceinline__ uint32_t fragment_at(const Strand &S, uint32_t p, uint32_t minLength, uint32_t maxLength, uint32_t &from, uint32_t &flags) {
+    if (S.len < 3 || p + 3 > S.len) return 0;                           // incomplete codon: never ends a fragment
+    const bool stop = stop_at(S, p);
+    const bool last = p + 6 > S.len;                                    // the frame's next codon is incomplete
+    if (!stop && !last) return 0;
+    uint32_t q = p;
+    bool hasStart = false;
+    while (q >= 3) {                                                    // previous stop of this frame
+        if (stop_at(S, q - 3)) { hasStart = true; break; }
+        q -= 3;
+    }
+    from = q;                                                           // = p % 3 when no stop precedes
+    const uint32_t count = (p - from) / 3 + (stop ? 0u : 1u);
+    if (count == 0 || count < minLength || count > maxLength) return 0;
+    flags = (hasStart ? 0u : 1u) | (stop ? 0u : 2u) | (S.minus ? 4u : 0u);
+    return count;
+}
+
+// virtual position index x = 2 * offsets[contig] + strand * len + p
+__device__ __forceinline__ bool locate(const OrfScanArgs &A, uint64_t x, uint32_t &contig, Strand &S, uint32_t &p) {
+    uint32_t lo = 0, hi = A.n_contigs;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (2 * A.offsets[mid] <= x) lo = mid; else hi = mid; }
+    contig = lo;
+    const uint64_t base = A.offsets[lo];
+    const uint64_t len = A.offsets[lo + 1] - base;
+    const uint64_t xl = x - 2 * base;
+    if (xl >= 2 * len) return false;                                    // (cannot happen: offsets are ascending)
+    S.seq = A.nucl + base; S.len = (uint32_t) len; S.minus = xl >= len;
+    p = (uint32_t) (xl - (S.minus ? len : 0));
+    return true;
+}
+
+__global__ __launch_bounds__(256) void orf_mark_kernel(OrfScanArgs A, uint64_t nPos, uint16_t *naa) {
+    const uint64_t x = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nPos) return;
+    uint32_t contig, p, from, flags;
+    Strand S;
+    uint32_t n = 0;
+    if (locate(A, x, contig, S, p)) n = fragment_at(S, p, A.min_length, A.max_length, from, flags);
+    naa[x] = (uint16_t) n;                                              // <= 32734 codons
+}
+
+__global__ __launch_bounds__(256) void orf_write_kernel(OrfScanArgs A, uint64_t nPos, const uint16_t *naa, const uint64_t *rank, const uint64_t *aaBase) {
+    const uint64_t x = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nPos || naa[x] == 0) return;
+    uint32_t contig, p, from = 0, flags = 0;
+    Strand S;
+    locate(A, x, contig, S, p);
+    const uint32_t n = fragment_at(S, p, A.min_length, A.max_length, from, flags);
+    OrfRecord r;
+    r.contig = contig; r.s_from = from; r.n_aa = n; r.flags = flags;
+    A.records[rank[x]] = r;
+    A.aa_off[rank[x]] = aaBase[x];
+}
+
+struct NonZero { __host__ __device__ uint64_t operator()(uint16_t v) const { return v ? 1ull : 0ull; } };
+struct Widen { __host__ __device__ uint64_t operator()(uint16_t v) const { return (uint64_t) v; } };
 
 __global__ __launch_bounds__(256) void orf_translate_kernel(OrfScanArgs A, uint64_t nFrag, uint64_t nAa, const char *table /* [4096] */,
                                                             char *aaAscii, uint8_t *aaCode) {
@@ -135,12 +156,19 @@ int run_extract_orfs(const char *dNucl, const uint64_t *dOffsets, uint32_t nCont
     R.n_frag = 0; R.n_aa = 0;
     if (nContigs == 0) return MK_OK;
     if (nContigs >= (1u << 30)) { err = "more than 2^30 contigs in one batch"; return MK_ERR_UNSUPPORTED; }
-    const uint32_t nUnits = 2 * nContigs;
-    uint64_t *dFragCount = (uint64_t *) dev_scratch("orf_fragcount", ((size_t) nUnits + 1) * 8);
-    uint64_t *dAaCount = (uint64_t *) dev_scratch("orf_aacount", ((size_t) nUnits + 1) * 8);
-    char *dTable = (char *) dev_scratch("orf_table", 4096);
+    if (maxGaps < (uint64_t) INT_MAX) { err = "--max-gaps below the reference default (unlimited) is not implemented"; return MK_ERR_UNSUPPORTED; }
     uint64_t *hTotals = (uint64_t *) pinned_scratch("orf_totals_h", 32);
-    ONULL(dFragCount); ONULL(dAaCount); ONULL(dTable); ONULL(hTotals);
+    ONULL(hTotals);
+    OCHK(hipMemcpyAsync(hTotals, dOffsets + nContigs, 8, hipMemcpyDeviceToHost, stream));
+    OCHK(hipStreamSynchronize(stream));
+    const uint64_t nPos = 2 * hTotals[0];                              // both strands of every contig
+    if (nPos == 0) return MK_OK;
+    if (nPos >= 0x7FFFFFFFull) { err = "more than 2^30 nucleotides in one batch: split the contigs"; return MK_ERR_UNSUPPORTED; }
+    uint16_t *dNaa = (uint16_t *) dev_scratch("orf_naa", nPos * 2);
+    uint64_t *dRank = (uint64_t *) dev_scratch("orf_rank", (nPos + 1) * 8);
+    uint64_t *dAaBase = (uint64_t *) dev_scratch("orf_aabase", (nPos + 1) * 8);
+    char *dTable = (char *) dev_scratch("orf_table", 4096);
+    ONULL(dNaa); ONULL(dRank); ONULL(dAaBase); ONULL(dTable);
     {
         char table[4096];
         build_translation_table(table);
@@ -150,20 +178,25 @@ int run_extract_orfs(const char *dNucl, const uint64_t *dOffsets, uint32_t nCont
     OrfScanArgs A;
     A.nucl = dNucl; A.offsets = dOffsets; A.n_contigs = nContigs;
     A.min_length = minLength; A.max_length = maxLength; A.max_gaps = maxGaps;
-    A.frag_count = dFragCount; A.aa_count = dAaCount; A.frag_base = dFragCount; A.aa_base = dAaCount;
     A.records = nullptr; A.aa_off = nullptr;
-    OCHK(hipMemsetAsync(dFragCount + nUnits, 0, 8, stream));
-    OCHK(hipMemsetAsync(dAaCount + nUnits, 0, 8, stream));
-    hipLaunchKernelGGL(orf_scan_kernel<false>, dim3((nUnits + 63) / 64), dim3(64), 0, stream, A);
+    const unsigned blocks = (unsigned) ((nPos + 255) / 256);
+    hipLaunchKernelGGL(orf_mark_kernel, dim3(blocks), dim3(256), 0, stream, A, nPos, dNaa);
     OCHK(hipGetLastError());
-    size_t tb = 0;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, tb, dFragCount, dFragCount, (int) nUnits + 1, stream);
-    void *temp = dev_scratch("orf_temp", tb);
+    hipcub::TransformInputIterator<uint64_t, NonZero, const uint16_t *> itFlag(dNaa, NonZero());
+    hipcub::TransformInputIterator<uint64_t, Widen, const uint16_t *> itAa(dNaa, Widen());
+    size_t tb = 0, tb2 = 0, tb3 = 0, tb4 = 0;
+    hipcub::DeviceScan::ExclusiveSum(nullptr, tb, itFlag, dRank, (int) nPos, stream);
+    hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, itAa, dAaBase, (int) nPos, stream);
+    hipcub::DeviceReduce::Sum(nullptr, tb3, itFlag, dRank + nPos, (int) nPos, stream);
+    hipcub::DeviceReduce::Sum(nullptr, tb4, itAa, dAaBase + nPos, (int) nPos, stream);
+    void *temp = dev_scratch("orf_temp", std::max(std::max(tb, tb2), std::max(tb3, tb4)));
     ONULL(temp);
-    OCHK(hipcub::DeviceScan::ExclusiveSum(temp, tb, dFragCount, dFragCount, (int) nUnits + 1, stream));
-    OCHK(hipcub::DeviceScan::ExclusiveSum(temp, tb, dAaCount, dAaCount, (int) nUnits + 1, stream));
-    OCHK(hipMemcpyAsync(hTotals, dFragCount + nUnits, 8, hipMemcpyDeviceToHost, stream));
-    OCHK(hipMemcpyAsync(hTotals + 1, dAaCount + nUnits, 8, hipMemcpyDeviceToHost, stream));
+    OCHK(hipcub::DeviceScan::ExclusiveSum(temp, tb, itFlag, dRank, (int) nPos, stream));
+    OCHK(hipcub::DeviceScan::ExclusiveSum(temp, tb2, itAa, dAaBase, (int) nPos, stream));
+    OCHK(hipcub::DeviceReduce::Sum(temp, tb3, itFlag, dRank + nPos, (int) nPos, stream));
+    OCHK(hipcub::DeviceReduce::Sum(temp, tb4, itAa, dAaBase + nPos, (int) nPos, stream));
+    OCHK(hipMemcpyAsync(hTotals, dRank + nPos, 8, hipMemcpyDeviceToHost, stream));
+    OCHK(hipMemcpyAsync(hTotals + 1, dAaBase + nPos, 8, hipMemcpyDeviceToHost, stream));
     OCHK(hipStreamSynchronize(stream));
     const uint64_t nFrag = hTotals[0], nAa = hTotals[1];
     if (nFrag >= 0xFFFFFFFFull || nAa >= 0xFFFFFFFFull) { err = "more than 2^32 ORF fragments or residues in one batch: split the contigs"; return MK_ERR_UNSUPPORTED; }
@@ -174,9 +207,9 @@ int run_extract_orfs(const char *dNucl, const uint64_t *dOffsets, uint32_t nCont
     OCHK(hipMalloc((void **) &R.aa_ascii, nAa));
     OCHK(hipMalloc((void **) &R.aa_code, nAa));
     A.records = R.records; A.aa_off = R.aa_off;
-    hipLaunchKernelGGL(orf_scan_kernel<true>, dim3((nUnits + 63) / 64), dim3(64), 0, stream, A);
+    hipLaunchKernelGGL(orf_write_kernel, dim3(blocks), dim3(256), 0, stream, A, nPos, dNaa, dRank, dAaBase);
     OCHK(hipGetLastError());
-    OCHK(hipMemcpyAsync(R.aa_off + nFrag, dAaCount + nUnits, 8, hipMemcpyDeviceToDevice, stream));
+    OCHK(hipMemcpyAsync(R.aa_off + nFrag, dAaBase + nPos, 8, hipMemcpyDeviceToDevice, stream));
     hipLaunchKernelGGL(orf_translate_kernel, dim3((unsigned) ((nAa + 255) / 256)), dim3(256), 0, stream, A, nFrag, nAa, dTable, R.aa_ascii, R.aa_code);
     OCHK(hipGetLastError());
     OCHK(hipStreamSynchronize(stream));

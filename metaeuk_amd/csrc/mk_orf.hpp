@@ -15,8 +15,6 @@ struct OrfRecord { uint32_t contig; uint32_t s_from; uint32_t n_aa; uint32_t fla
 struct OrfScanArgs {
     const char *nucl; const uint64_t *offsets; uint32_t n_contigs;
     uint32_t min_length, max_length; uint64_t max_gaps;              // codons (Orf::findAll's minLength / maxLength / maxGaps)
-    uint64_t *frag_count, *aa_count;                                 // per (contig, strand): counting pass
-    const uint64_t *frag_base, *aa_base;                             // ... exclusive prefix sums: writing pass
     OrfRecord *records; uint64_t *aa_off;
 };
 
