@@ -262,16 +262,111 @@ int cmdPrefilterOrAlign(bool isAlign, int argc, char **argv) {
     return EXIT_SUCCESS;
 }
 
+// extractorfs <i:contigDB> <o:orfDB> [--min-length 15] [--translate 0|1] [--aa-sibling NAME] [--gpu N]
+//   = util/extractorfs.cpp for predictexons' settings: nucleotide (or, --translate 1, amino-acid) ORF fragments under
+//   renumbered keys 0..N-1 plus the header DB <o>_h ("contigKey<TAB>from(+|-)len[<TAB>complete]").  --aa-sibling NAME also
+//   writes the translated fragments as the DB NAME next to <o>: predictexons.sh:47 skips `translatenucs` when aa_6f exists.
+int cmdExtractOrfs(int argc, char **argv) {
+    std::vector<std::string> pos;
+    int minLength = 15, translate = 0, gpu = 0;
+    std::string sibling;
+    if (const char *lr = getenv("LOCAL_RANK")) gpu = atoi(lr);
+    for (int i = 2; i < argc; i++) {
+        const std::string a = argv[i];
+        auto val = [&](int &dst) { if (i + 1 >= argc) return false; dst = atoi(argv[++i]); return true; };
+        if (a == "--min-length") { if (!val(minLength)) return die("missing value for %s", a); }
+        else if (a == "--translate") { if (!val(translate)) return die("missing value for %s", a); }
+        else if (a == "--gpu") { if (!val(gpu)) return die("missing value for %s", a); }
+        else if (a == "--aa-sibling") { if (i + 1 >= argc) return die("missing value for %s", a); sibling = argv[++i]; }
+        else if (a == "--orf-start-mode" || a == "--contig-start-mode" || a == "--contig-end-mode" || a == "--max-length" || a == "--max-gaps" ||
+                 a == "--forward-frames" || a == "--reverse-frames" || a == "--translation-table" || a == "--use-all-table-starts" ||
+                 a == "--threads" || a == "--compressed" || a == "-v" || a == "--id-offset" || a == "--create-lookup") {
+            // accepted when they carry predictexons' values (Parameters.cpp:2525-2554, PredictExons.cpp:9-11); anything else is an error
+            if (i + 1 >= argc) return die("missing value for %s", a);
+            const std::string v = argv[++i];
+            const char *want = a == "--orf-start-mode" ? "1" : a == "--contig-start-mode" ? "2" : a == "--contig-end-mode" ? "2" : a == "--max-length" ? "32734"
+                             : a == "--max-gaps" ? "2147483647" : a == "--forward-frames" ? "1,2,3" : a == "--reverse-frames" ? "1,2,3" : a == "--translation-table" ? "1"
+                             : a == "--use-all-table-starts" ? "0" : a == "--compressed" ? "0" : a == "--id-offset" ? "0" : a == "--create-lookup" ? "0" : nullptr;
+            if (want && v != want) return die(("this build implements " + a + " " + want + " only, got %s").c_str(), v);
+        } else if (!a.empty() && a[0] == '-') return die("Unrecognized parameter %s", a);
+        else pos.push_back(a);
+    }
+    if (pos.size() != 2) return die("usage: metaeuk-amd extractorfs <i:sequenceDB> <o:sequenceDB> [--min-length N] [--translate 0|1]%s", "");
+    if (mk_init(gpu) != MK_OK) return die("%s", mk_last_error());
+    mk::Database contigs;
+    std::string e = contigs.open(pos[0]);
+    if (!e.empty()) return die("%s", e);
+    const double t0 = now();
+    std::vector<char> nucl;
+    std::vector<uint64_t> off(contigs.entries.size() + 1, 0);
+    for (size_t i = 0; i < contigs.entries.size(); i++) {
+        nucl.insert(nucl.end(), contigs.entry(i), contigs.entry(i) + contigs.seqLen(i));
+        off[i + 1] = nucl.size();
+    }
+    mk_orfs *O = nullptr;
+    if (mk_extract_orfs(nucl.data(), off.data(), (uint32_t) contigs.entries.size(), minLength, &O) != MK_OK) return die("%s", mk_last_error());
+    const mk_orf *orfs; const uint64_t *aaOff; const char *aa; uint64_t n = 0;
+    mk_orfs_result(O, &orfs, &aaOff, &aa, &n);
+    static const char *COMP =                                  // Orf::iupacReverseComplementTable, Orf.cpp:48-52
+        "................................................................"
+        ".TVGH..CD..M.KN...YSAABW.R.......tvgh..cd..m.kn...ysaabw.r......"
+        "................................................................"
+        "................................................................";
+    mk::DatabaseWriter seqW(pos[1], translate ? mk::DBTYPE_AMINO_ACIDS : 1 /* DBTYPE_NUCLEOTIDES */), hdrW(pos[1] + "_h", 12 /* DBTYPE_GENERIC_DB */);
+    if (!(e = seqW.open()).empty() || !(e = hdrW.open()).empty()) return die("%s", e);
+    std::string sibPath;
+    mk::DatabaseWriter *aaW = nullptr;
+    if (!sibling.empty()) {
+        const size_t slash = pos[1].find_last_of('/');
+        sibPath = (slash == std::string::npos ? std::string() : pos[1].substr(0, slash + 1)) + sibling;
+        aaW = new mk::DatabaseWriter(sibPath, mk::DBTYPE_AMINO_ACIDS);
+        if (!(e = aaW->open()).empty()) return die("%s", e);
+    }
+    std::string buf;
+    char hdr[128];
+    for (uint64_t k = 0; k < n; k++) {
+        const mk_orf &o = orfs[k];
+        mk_orf keyed = o;
+        keyed.contig = contigs.entries[o.contig].key;            // the header names the contig's DB key
+        size_t hl = mk_format_orf_header(hdr, &keyed);
+        hdr[hl++] = '\n';
+        hdrW.write((uint32_t) k, hdr, hl);
+        buf.assign(aa + aaOff[k], aa + aaOff[k + 1]);
+        buf.push_back('\n');
+        if (aaW) aaW->write((uint32_t) k, buf.data(), buf.size());
+        if (!translate) {                                        // the fragment's nucleotides as Orf::getSequence hands them out
+            const char *c = contigs.entry(o.contig);
+            const size_t len = contigs.seqLen(o.contig), nn = 3 * (size_t) (aaOff[k + 1] - aaOff[k]);
+            buf.resize(nn);
+            for (size_t j = 0; j < nn; j++) {
+                char ch;
+                if (!o.minus_strand) { ch = c[o.from + j]; if (ch == 'u') ch = 't'; }
+                else { ch = c[o.from - j]; if (ch == 'u') ch = 't'; ch = COMP[(unsigned char) ch]; if (ch == '.') ch = 'N'; }
+                buf[j] = ch;
+            }
+            (void) len;
+            buf.push_back('\n');
+        }
+        seqW.write((uint32_t) k, buf.data(), buf.size());
+    }
+    if (!(e = seqW.close()).empty() || !(e = hdrW.close()).empty()) return die("%s", e);
+    if (aaW) { if (!(e = aaW->close()).empty()) return die("%s", e); delete aaW; }
+    fprintf(stderr, "extractorfs: %zu contigs -> %llu fragments, %.2f s\n", contigs.entries.size(), (unsigned long long) n, now() - t0);
+    mk_orfs_destroy(O);
+    return EXIT_SUCCESS;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        fprintf(stderr, "metaeuk-amd: MI355X prefilter+align modules of `metaeuk predictexons`\n  metaeuk-amd prefilter <queryDB> <targetDB> <prefilterDB> [flags]\n  metaeuk-amd align <queryDB> <targetDB> <prefilterDB> <alignmentDB> [flags]\n");
+        fprintf(stderr, "metaeuk-amd: MI355X prefilter+align modules of `metaeuk predictexons`\n  metaeuk-amd prefilter <queryDB> <targetDB> <prefilterDB> [flags]\n  metaeuk-amd align <queryDB> <targetDB> <prefilterDB> <alignmentDB> [flags]\n  metaeuk-amd extractorfs <contigDB> <orfDB> [--min-length N] [--translate 0|1] [--aa-sibling NAME]\n");
         return EXIT_FAILURE;
     }
     const std::string cmd = argv[1];
     if (cmd == "prefilter") return cmdPrefilterOrAlign(false, argc, argv);
     if (cmd == "align") return cmdPrefilterOrAlign(true, argc, argv);
+    if (cmd == "extractorfs") return cmdExtractOrfs(argc, argv);
     fprintf(stderr, "Invalid Command: %s\n", cmd.c_str());
     return EXIT_FAILURE;
 }

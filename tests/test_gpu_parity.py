@@ -398,3 +398,39 @@ def test_orfs_feed_the_search(gpu_api, tmp_path):
     assert np.array_equal(np.asarray(ao1), np.asarray(ao2))
     n = int(ao1[-1])
     assert n > 20 and api.format_alignments(a1, 0, n) == api.format_alignments(a2, 0, n)
+
+
+def test_cli_extractorfs_db_roundtrip(gpu_api, tmp_path):
+    """`metaeuk-amd extractorfs` over MMseqs2 DBs: renumbered ORF keys, header DB, nucleotide fragments, and the translated
+    sibling DB that lets predictexons.sh skip translatenucs -- against the reference's golden output"""
+    import subprocess
+    from metaeuk_amd import build
+    contigs = [c for c in _lines("orf_contigs.txt.gz")]
+    keys = [3 * i + 5 for i in range(len(contigs))]                # DB keys need not be 0..n-1: the headers carry them
+    _write_seq_db(str(tmp_path / "contigs"), contigs, keys)
+    subprocess.check_call([build.BIN, "extractorfs", str(tmp_path / "contigs"), str(tmp_path / "nucl_6f"), "--min-length", "15",
+                           "--orf-start-mode", "1", "--contig-start-mode", "2", "--contig-end-mode", "2", "--translation-table", "1",
+                           "--threads", "4", "--aa-sibling", "aa_6f"])
+    assert open(tmp_path / "nucl_6f.dbtype", "rb").read() == (1).to_bytes(4, "little")
+    assert open(tmp_path / "aa_6f.dbtype", "rb").read() == (0).to_bytes(4, "little")
+    hdr, nuc, aa = _read_result_db(str(tmp_path / "nucl_6f_h")), _read_result_db(str(tmp_path / "nucl_6f")), _read_result_db(str(tmp_path / "aa_6f"))
+    exp = []                                                        # (header with the contig's DB key, protein) in output order
+    with gzip.open(os.path.join(GOLD, "orf_expected.txt.gz"), "rt") as f:
+        for line in f:
+            if line.startswith(">"):
+                continue
+            h, prot = line.rstrip("\n").rsplit("\t", 1)
+            c, rest = h.split("\t", 1)
+            exp.append(("%d\t%s" % (keys[int(c)], rest), prot))
+    assert sorted(hdr) == list(range(len(exp))) and sorted(aa) == list(range(len(exp))) and sorted(nuc) == list(range(len(exp)))
+    codon = {a + b + c: "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"[16 * i + 4 * j + k]
+             for i, a in enumerate("TCAG") for j, b in enumerate("TCAG") for k, c in enumerate("TCAG")}
+    for k, (h, prot) in enumerate(exp):
+        assert hdr[k] == h + "\n", k
+        assert aa[k] == prot + "\n", k
+        n = nuc[k].rstrip("\n")
+        assert len(n) == 3 * len(prot), k
+        if set(n) <= set("ACGT"):                                   # unambiguous upper-case fragments translate with the plain table
+            assert "".join(codon[n[i:i + 3]] for i in range(0, len(n), 3)) == prot, k
+    bad = subprocess.run([build.BIN, "extractorfs", str(tmp_path / "contigs"), str(tmp_path / "x"), "--orf-start-mode", "0"], capture_output=True)
+    assert bad.returncode != 0 and not (tmp_path / "x.dbtype").exists()
