@@ -1198,19 +1198,36 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             for (const auto &hh : hostHits) extra += hh.size();
             if (!reserve_out(nDevHits + extra, q1)) { err = "pinned host allocation for the prefilter result failed"; return MK_ERR_DEVICE; }
             mk_hit *dst = (mk_hit *) outBlk.p;
-            size_t dev = 0, hk = 0;
-            for (uint32_t ql = 0; ql < nqc; ql++) {
-                const size_t qg = (size_t) q0 + ql;
-                if (hk < hostQ.size() && hostQ[hk] == ql) {
-                    if (!hostHits[hk].empty()) std::memcpy(dst + nOut, hostHits[hk].data(), hostHits[hk].size() * sizeof(mk_hit));
-                    nOut += hostHits[hk].size();
-                    hk++;
-                } else {
-                    const uint32_t c = chunkCnt[ql];
-                    if (c) std::memcpy(dst + nOut, devHits + dev, (size_t) c * sizeof(mk_hit));
-                    dev += c; nOut += c;
+            // offsets first (serial, trivial), then the copies in parallel: runs of device-final queries between two
+            // host-selected ones move as one block
+            std::vector<size_t> runDst, runSrc, runLen;                       // device runs
+            std::vector<size_t> hostDst(hostQ.size());
+            {
+                size_t dev = 0, hk = 0, at = nOut, runBegin = 0;
+                bool open = false;
+                for (uint32_t ql = 0; ql < nqc; ql++) {
+                    const size_t qg = (size_t) q0 + ql;
+                    if (hk < hostQ.size() && hostQ[hk] == ql) {
+                        if (open) { runLen.push_back(dev - runBegin); open = false; }
+                        hostDst[hk] = at;
+                        at += hostHits[hk].size();
+                        hk++;
+                    } else {
+                        const uint32_t c = chunkCnt[ql];
+                        if (c && !open) { runDst.push_back(at); runSrc.push_back(dev); runBegin = dev; open = true; }
+                        dev += c; at += c;
+                    }
+                    outOff[qg + 1] = at;
                 }
-                outOff[qg + 1] = nOut;
+                if (open) runLen.push_back(dev - runBegin);
+                nOut = at;
+            }
+            const size_t nRunsDev = runDst.size();
+#pragma omp parallel for schedule(dynamic, 1)
+            for (size_t r = 0; r < nRunsDev + hostQ.size(); r++) {
+                if (r < nRunsDev) std::memcpy(dst + runDst[r], devHits + runSrc[r], runLen[r] * sizeof(mk_hit));
+                else if (!hostHits[r - nRunsDev].empty())
+                    std::memcpy(dst + hostDst[r - nRunsDev], hostHits[r - nRunsDev].data(), hostHits[r - nRunsDev].size() * sizeof(mk_hit));
             }
         }
         if (hooks.on_chunk) {
