@@ -30,11 +30,11 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T int32 lane-ops/s
 SW_OPS_PER_CELL = 10      # add, min, max3, lshl_or, max, sub, sub, max3, sub, max3 (mk_sw.hip inner loop)
 # HBM bytes per launch from the PMC passes (profiles/r01_pmc_hbm_traffic.txt), keyed by the bench's kernel names
-TRAFFIC_BYTES_PER_LAUNCH = {   # (FETCH_SIZE + WRITE_SIZE) KB x 1024, raw counter values, default workload
-    "prefilter_fused_lds2048": (1334438 + 9694) * 1024, "prefilter_fused_lds4096": (3789574 + 13684) * 1024,
-    "prefilter_fused_lds8192": (13339162 + 35177) * 1024, "prefilter_fused_lds16384": (28832191 + 56330) * 1024,
-    "kmer_probe_count": (13381981 + 43732) * 1024, "kmer_probe_gather": (20488081 + 2947688) * 1024,
-    "sw_fwd_rows32": (355233 + 40358) * 1024, "sw_fwd_rows64": (557509 + 65368) * 1024, "sw_fwd_rows128": (320429 + 37710) * 1024,
+TRAFFIC_BYTES_PER_LAUNCH = {   # (FETCH_SIZE + WRITE_SIZE) KB x 1024, raw counter values, default workload, final round-1 build
+    "prefilter_fused_lds2048": (1330290 + 9863) * 1024, "prefilter_fused_lds4096": (3882978 + 14872) * 1024,
+    "prefilter_fused_lds8192": (14035790 + 35204) * 1024,
+    "kmer_probe_count": (31453387 + 110986) * 1024, "kmer_probe_gather": (48149895 + 6796568) * 1024,
+    "sw_fwd_rows32": (336506 + 34092) * 1024, "sw_fwd_rows64": (537378 + 56571) * 1024, "sw_fwd_rows128": (309061 + 33579) * 1024,
 }
 
 
