@@ -1,13 +1,17 @@
 // metaeuk_amd/csrc/mk_align.hip -- the alignment stage as a device-resident pipeline.
-// Per batch: the (query,target) pairs of the prefilter result go up once (4 B per pair); jobs are built,
-// ordered by (tile configuration, target length), run forward, gated by the e-value table, run backward
-// for the survivors, and only the accepted pairs' integers come back (24 B each).
-//   expand_pairs_kernel  pair -> query (binary search in the per-query offsets), forward SwJob + sort key
-//   hipcub radix sort    jobs ordered so that the DPs sharing a wave have the same tile shape / similar length
-//   sw_kernel<G,R>       forward pass (mk_sw.hip), results scattered to pair order
-//   gate_kernel          e-value gate (table per query length) + reverse SwJob for the survivors
-//   sw_kernel<G,R>       reverse pass on the reversed prefixes -> start positions
-//   collect_kernel       AlnRaw records in pair order
+// Per batch (or per prefilter chunk, under mk_search): the prefilter hits go up once (12 B per pair) and only the accepted
+// pairs' integers come back (24 B each).
+//   expand_pairs_kernel      pair -> query (binary search in the per-query offsets), forward SwJob + 64-bit sort key
+//                            (tile configuration, query, target length descending)
+//   hipcub radix sort        the jobs of a query become adjacent and similar in length
+//   seg_mark / max-scan / wave_flag / select   cut every (configuration, query) segment into waves of jobs that share ONE
+//                            LDS query profile
+//   swp_kernel / sw_kernel   score pass (mk_sw.hip): packed int16, two targets per lane group, for tiles <= 256 rows;
+//                            persistent launch (a fixed number of one-wave workgroups per CU pull waves from a counter)
+//   gate_kernel              e-value gate on the score (table per query length) -> position jobs for the ~9 % survivors
+//   sw_kernel                position pass (end cell of the maximum), then rev_jobs_kernel + reverse pass on the reversed
+//                            prefixes (start cell)
+//   collect_kernel           AlnRaw records in pair order
 #include "mk_align.hpp"
 #include "mk_kernels.hpp"
 #include <hipcub/hipcub.hpp>

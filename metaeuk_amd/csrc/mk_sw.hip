@@ -16,7 +16,11 @@
 //   * the running maximum is a packed key (score << 17 | ~column) per row, so the reference's
 //     "first column where the maximum is reached, smallest row in it" costs one v_max_u32 per cell;
 //   * queries longer than G*R rows are processed in row tiles; the bottom row of a tile is parked in
-//     HBM (4 B per column) and re-read by lane 0 of the next tile.
+//     HBM (4 B per column) and re-read by lane 0 of the next tile;
+//   * shared-query mode (pipeline forward pass): the DPs of a wave belong to one query and share ONE LDS profile; the
+//     launch is persistent (one-wave workgroups pull waves of jobs from a counter);
+//   * swp_kernel: the score-only forward pass in packed int16, two targets per lane group (see below) -- the e-value
+//     gate needs nothing but the score, and only the pairs that pass are re-run here for their end cells.
 // Recurrence: affine-gap local alignment, H = max(0, diag+s, E, F), E/F opened from H with gap_open and
 // extended with gap_extend.  The reference's striped kernels never open E out of a lazy-F-corrected
 // cell and restart the in-register F at stripe heads; both only forbid an F-gap directly followed by an
