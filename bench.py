@@ -151,16 +151,20 @@ def main():
         nhits, npass = step()
     barrier()
     elapsed = time.time() - t0
+    total_queries = len(queries)
     if dist is not None:
         import torch
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        tq = torch.tensor([float(len(queries))], dtype=torch.float64, device="cuda")   # ranks draw different contigs
+        dist.all_reduce(tq, op=dist.ReduceOp.SUM)
+        total_queries = int(tq.item())
 
     stats = api.kernel_stats()
     nq = len(queries)
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
-    frag_per_s = world * nq * args.steps / elapsed
+    frag_per_s = total_queries * args.steps / elapsed
     cells_sw = sum(v["cells"] for k, v in stats.items() if k.startswith("sw_"))
     gcups_total = world * cells_sw / elapsed / 1e9
     sw_ms = sum(v["ms"] for k, v in stats.items() if k.startswith("sw_"))
