@@ -14,6 +14,12 @@
  * Prefiltering::getIndexTable (Prefiltering.cpp:514-553) performs.
  * INTEGRATION.md shows the `prefilter` / `align` command bodies a maintainer
  * would register in src/metaeuk.cpp:21-96 on top of this ABI.
+ *
+ * Process model: one process drives one GPU (mk_init(device)); the library owns its HIP streams, its device scratch and
+ * a pool of pinned result blocks.  Calls into the library must come from one thread at a time (the reference's modules
+ * are one process per step as well); the library itself runs the two stages of mk_search on two internal threads.
+ * Sizing knobs for experiments (never needed for correctness): MK_PREFILTER_PATH, MK_PREFILTER_TIERS,
+ * MK_PREFILTER_MAX_TIERS, MK_SW_WAVES_PER_CU, MK_SEARCH_CHUNK_QUERIES, MK_PREFILTER_DEBUG.
  */
 #ifndef METAEUK_AMD_H
 #define METAEUK_AMD_H
