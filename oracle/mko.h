@@ -143,6 +143,18 @@ size_t mko_extract_orfs(const char *contig, size_t len, size_t minLength, size_t
                         mko_orf **orfs, char **aa, size_t **aa_off);
 size_t mko_format_orf_header(char *buf, unsigned int key, const mko_orf *o);
 
+/* ---- resultspercontig + collectoptimalset ---- */
+typedef struct {     /* one ORF->target alignment as the 10 printed columns carry it, plus the ORF's header coordinates */
+    unsigned int target; int bit_score; double seq_id, evalue; int q_start, q_end, db_start, db_end, db_len;
+    unsigned int orf; int orf_from, orf_to;
+} mko_exon_aln;
+typedef struct {
+    double evalue_thr, target_cov_thr; size_t max_intron, min_intron, min_exon_aa, max_aa_overlap, max_exon_sets;
+    int gap_open, gap_extend; uint64_t db_residues;
+} mko_exon_params;
+void mko_exon_params_default(mko_exon_params *P, uint64_t db_residues);
+char *mko_predict_exons(mko_exon_aln *alns, size_t n, const mko_exon_params *P, size_t *n_predictions);
+
 #ifdef __cplusplus
 }
 #endif

@@ -269,11 +269,73 @@ static int cmd_orfs(int argc, char **argv) {
     return 0;
 }
 
+/* resultspercontig + collectoptimalset over the outputs of `orfs` and `pipeline`: same format as `ref_harness exons` */
+static int cmd_exons(int argc, char **argv) {
+    (void) argc;
+    lines_t T = read_lines(argv[2]), C = read_lines(argv[3]), O = read_lines(argv[4]), A = read_lines(argv[5]);
+    FILE *out = fopen(argv[6], "w");
+    if (!out) return 1;
+    uint64_t residues = 0;
+    for (size_t i = 0; i < T.n; i++) residues += (uint64_t) T.len[i];
+    mko_exon_params P;
+    mko_exon_params_default(&P, residues);
+    /* ORF k: contig, header coordinates */
+    size_t nOrf = 0;
+    for (size_t i = 0; i < O.n; i++) if (O.s[i][0] != '>') nOrf++;
+    unsigned int *orfContig = (unsigned int *) malloc((nOrf + 1) * sizeof(unsigned int));
+    int *orfFrom = (int *) malloc((nOrf + 1) * sizeof(int)), *orfTo = (int *) malloc((nOrf + 1) * sizeof(int));
+    size_t k = 0;
+    for (size_t i = 0; i < O.n; i++) {
+        if (O.s[i][0] == '>') continue;
+        unsigned int contig, from; int len; char sign;
+        if (sscanf(O.s[i], "%u\t%u%c%d", &contig, &from, &sign, &len) != 4) { fprintf(stderr, "bad ORF header: %s\n", O.s[i]); return 1; }
+        orfContig[k] = contig; orfFrom[k] = (int) from; orfTo[k] = sign == '+' ? (int) from + len : (int) from - len;
+        k++;
+    }
+    /* alignment blocks: block k = ORF k; collect per contig */
+    size_t nAln = 0;
+    for (size_t i = 0; i < A.n; i++) if (A.s[i][0] != '>') nAln++;
+    mko_exon_aln *alns = (mko_exon_aln *) malloc((nAln + 1) * sizeof(mko_exon_aln));
+    unsigned int *alnContig = (unsigned int *) malloc((nAln + 1) * sizeof(unsigned int));
+    size_t a = 0;
+    long block = -1;
+    for (size_t i = 0; i < A.n; i++) {
+        if (A.s[i][0] == '>') { block++; continue; }
+        mko_exon_aln *x = &alns[a];
+        char sid[64], ev[64];
+        int qlen;
+        if (sscanf(A.s[i], "%u\t%d\t%63s\t%63s\t%d\t%d\t%d\t%d\t%d\t%d", &x->target, &x->bit_score, sid, ev, &x->q_start, &x->q_end, &qlen, &x->db_start, &x->db_end, &x->db_len) != 10) {
+            fprintf(stderr, "bad alignment line: %s\n", A.s[i]); return 1;
+        }
+        x->seq_id = strtod(sid, NULL); x->evalue = strtod(ev, NULL);
+        x->orf = (unsigned int) block; x->orf_from = orfFrom[block]; x->orf_to = orfTo[block];
+        alnContig[a] = orfContig[block];
+        a++;
+    }
+    /* ORFs of a contig are consecutive, so are their alignments */
+    size_t total = 0, at = 0;
+    for (size_t c = 0; c < C.n; c++) {
+        fprintf(out, ">%zu\n", c);
+        size_t e = at;
+        while (e < nAln && alnContig[e] == c) e++;
+        size_t np = 0;
+        char *txt = mko_predict_exons(alns + at, e - at, &P, &np);
+        fputs(txt, out);
+        free(txt);
+        total += np;
+        at = e;
+    }
+    fclose(out);
+    printf("{\"contigs\": %zu, \"predictions\": %zu}\n", C.n, total);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) { fprintf(stderr, "usage: mko_cli pipeline|sw|submat ...\n"); return 2; }
     if (!strcmp(argv[1], "pipeline") && argc >= 5) return cmd_pipeline(argc, argv);
     if (!strcmp(argv[1], "sw") && argc >= 6) return cmd_sw(argc, argv);
     if (!strcmp(argv[1], "submat") && argc >= 5) return cmd_submat(argc, argv);
     if (!strcmp(argv[1], "orfs") && argc >= 4) return cmd_orfs(argc, argv);
+    if (!strcmp(argv[1], "exons") && argc >= 7) return cmd_exons(argc, argv);
     return 2;
 }

@@ -20,6 +20,12 @@
 //   ref_harness pipeline <matdir> <targets.txt> <queries.txt> <outdir> [-s 5.7] [--threads N] [--dump]
 //   ref_harness sw       <matdir> <targets.txt> <queries.txt> <pairs.txt> <out.txt> [--dbres N]
 //   ref_harness submat   <matfile.out> <bitFactor> <bias>
+//   ref_harness exons    <targets.txt> <contigs.txt> <orfs.txt> <aln.txt> <out.txt>
+//     = resultspercontig + collectoptimalset on the outputs of the modes below/above: orfs.txt as
+//       written by `orfs`, aln.txt as written by `pipeline` (one block per ORF fragment, same order).  The joining of the
+//       two inputs per contig and the target-by-target loop are our restatement of resultspercontig.cpp:145-190 and
+//       collectoptimalset.cpp:262-413; PotentialExon::setByAln, findoptimalsetbydp and Prediction::predictionToBuffer are
+//       the reference's own code (src/exonpredictor/collectoptimalset.cpp, src/commons/PredictionParser.h).
 //   ref_harness orfs     <contigs.txt> <out.txt> [--min-length 15]
 //     = extractorfs --translate as `predictexons` runs it (util/extractorfs.cpp:19-159 loop, Orf::findAll with
 //       orf-start-mode 1, both strands, all frames, translation table 1): per contig one ">key" line, then one line per
@@ -39,6 +45,7 @@
 #include "FastSort.h"
 #include "Orf.h"
 #include "TranslateNucl.h"
+#include "PredictionParser.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -401,6 +408,141 @@ static int cmdOrfs(int argc, char **argv) {
     return 0;
 }
 
+// the reference's exon-chaining DP (src/exonpredictor/collectoptimalset.cpp:106-217), linked from its own object file
+int findoptimalsetbydp(std::vector<PotentialExon> &potentialExonCandidates, std::vector<PotentialExon> &optimalExonSet,
+                       const size_t minIntronLength, const size_t maxIntronLength, const size_t maxAaOvelap, const int setGapOpenPenalty,
+                       const int setGapExtendPenalty, const double dMetaeukTargetCovThr);
+
+static int cmdExons(int argc, char **argv) {
+    if (argc < 7) return 2;
+    std::vector<std::string> targets = readLines(argv[2]), contigs = readLines(argv[3]);
+    size_t totNumOfAAsInTargetDb = 0;                              // DBReader::getAminoAcidDBSize
+    for (size_t i = 0; i < targets.size(); i++) totNumOfAAsInTargetDb += targets[i].size();
+    // LocalParameters defaults (src/commons/LocalParameters.h:138-146)
+    const float metaeukEvalueThr = 0.001, metaeukTargetCovThr = 0.5;
+    const size_t maxIntronLength = 10000, minIntronLength = 15, minExonAaLength = 11, maxAaOverlap = 10, maxExonSets = 1;
+    const int setGapOpenPenalty = -1, setGapExtendPenalty = -1;
+    const double dMetaeukEvalueThr = (double) metaeukEvalueThr, dMetaeukTargetCovThr = (double) metaeukTargetCovThr;
+    FILE *forf = fopen(argv[4], "r"), *faln = fopen(argv[5], "r"), *out = fopen(argv[6], "w");
+    if (!forf || !faln || !out) return 1;
+    // ORF fragments: key = running index; per contig the list of (orfKey, header fields)
+    struct OrfRec { unsigned int key, contig; Orf::SequenceLocation loc; };
+    std::vector<std::vector<OrfRec>> orfsOfContig(contigs.size());
+    {
+        char *line = NULL; size_t cap = 0; ssize_t r;
+        unsigned int key = 0;
+        while ((r = getline(&line, &cap, forf)) >= 0) {
+            if (line[0] == '>') continue;
+            std::string hdr(line);
+            const size_t lastTab = hdr.rfind('\t');                // drop the protein column
+            hdr = hdr.substr(0, lastTab) + "\n";
+            OrfRec o;
+            o.key = key++;
+            o.loc = Orf::parseOrfHeader(hdr.c_str());
+            o.contig = o.loc.id;
+            orfsOfContig[o.contig].push_back(o);
+        }
+        free(line);
+    }
+    // alignments: block k (">k") = ORF k, lines = Matcher::resultToBuffer
+    std::vector<std::vector<std::string>> alnOfOrf;
+    {
+        char *line = NULL; size_t cap = 0; ssize_t r;
+        while ((r = getline(&line, &cap, faln)) >= 0) {
+            if (line[0] == '>') { alnOfOrf.emplace_back(); continue; }
+            alnOfOrf.back().emplace_back(line);
+        }
+        free(line);
+    }
+    char buffer[65536], exonLineBuffer[2048];
+    std::string predictionBuffer;
+    size_t nPred = 0;
+    for (size_t contigKey = 0; contigKey < contigs.size(); contigKey++) {
+        fprintf(out, ">%zu\n", contigKey);
+        // resultspercontig.cpp:145-190: (orf -> target, orf -> contig) pairs, stable-sorted by (target key, orf key)
+        std::vector<std::pair<Matcher::result_t, Matcher::result_t>> results;
+        const size_t contigLen = contigs[contigKey].size();
+        for (size_t j = 0; j < orfsOfContig[contigKey].size(); j++) {
+            const OrfRec &o = orfsOfContig[contigKey][j];
+            if (o.key >= alnOfOrf.size()) continue;
+            const size_t orfLen = std::max(o.loc.from, o.loc.to) - std::min(o.loc.from, o.loc.to) + 1;   // Orf::getFromDatabase, Orf.cpp:103-116
+            Matcher::result_t orfToContig((unsigned int) contigKey, 1, 1, 0, 1, 0, orfLen, 0, (orfLen - 1), orfLen, o.loc.from, o.loc.to, contigLen, "");
+            orfToContig.dbKey = o.key;
+            for (size_t a = 0; a < alnOfOrf[o.key].size(); a++)
+                results.emplace_back(std::make_pair(Matcher::parseAlignmentRecord(alnOfOrf[o.key][a].c_str(), true), orfToContig));
+        }
+        std::stable_sort(results.begin(), results.end(), [](const std::pair<Matcher::result_t, Matcher::result_t> &l, const std::pair<Matcher::result_t, Matcher::result_t> &r) {
+            if (l.first.dbKey < r.first.dbKey) return true;
+            if (l.first.dbKey > r.first.dbKey) return false;
+            return l.second.dbKey < r.second.dbKey;
+        });
+        std::string ss;
+        for (size_t i = 0; i < results.size(); i++) {
+            size_t len = Matcher::resultToBuffer(buffer, results[i].first, false, false);
+            ss.append(buffer, len - 1);
+            ss.append("\t");
+            len = Matcher::resultToBuffer(buffer, results[i].second, false, false);
+            ss.append(buffer, len);
+        }
+        // collectoptimalset.cpp:262-413 on this contig's entry
+        std::vector<PotentialExon> plusE, minusE, plusSet, minusSet;
+        std::vector<char> data(ss.begin(), ss.end());
+        data.push_back('\0');
+        char *resultsPtr = data.data();
+        const char *entry[255];
+        unsigned int currTargetKey = 0;
+        bool isFirstIteration = true;
+        auto flush = [&]() {
+            size_t numIters = 0;
+            while ((numIters < maxExonSets) && (plusE.size() > 0 || minusE.size() > 0)) {
+                int totalBitScorePlus = findoptimalsetbydp(plusE, plusSet, minIntronLength, maxIntronLength, maxAaOverlap, setGapOpenPenalty, setGapExtendPenalty, dMetaeukTargetCovThr);
+                int totalBitScoreMinus = findoptimalsetbydp(minusE, minusSet, minIntronLength, maxIntronLength, maxAaOverlap, setGapOpenPenalty, setGapExtendPenalty, dMetaeukTargetCovThr);
+                if (plusSet.size() > 0) {
+                    double log2EvaluePlus = log2(totNumOfAAsInTargetDb) + log2(2) - totalBitScorePlus;
+                    double combinedEvaluePlus = pow(2, log2EvaluePlus);
+                    if (combinedEvaluePlus <= dMetaeukEvalueThr) {
+                        Prediction predToWrite(currTargetKey, PLUS, totalBitScorePlus, combinedEvaluePlus, plusSet);
+                        Prediction::predictionToBuffer(predictionBuffer, exonLineBuffer, predToWrite);
+                        fwrite(predictionBuffer.c_str(), 1, predictionBuffer.size(), out);
+                        predictionBuffer.clear();
+                        nPred++;
+                    }
+                }
+                if (minusSet.size() > 0) {
+                    double log2EvalueMinus = log2(totNumOfAAsInTargetDb) + log2(2) - totalBitScoreMinus;
+                    double combinedEvalueMinus = pow(2, log2EvalueMinus);
+                    if (combinedEvalueMinus <= dMetaeukEvalueThr) {
+                        Prediction predToWrite(currTargetKey, MINUS, totalBitScoreMinus, combinedEvalueMinus, minusSet);
+                        Prediction::predictionToBuffer(predictionBuffer, exonLineBuffer, predToWrite);
+                        fwrite(predictionBuffer.c_str(), 1, predictionBuffer.size(), out);
+                        predictionBuffer.clear();
+                        nPred++;
+                    }
+                }
+                plusSet.clear(); minusSet.clear();
+                numIters++;
+            }
+            plusE.clear(); minusE.clear(); plusSet.clear(); minusSet.clear();
+        };
+        while (*resultsPtr != '\0') {
+            const size_t columns = Util::getWordsOfLine(resultsPtr, entry, 255);
+            if (columns != 20) { fprintf(stderr, "expected 20 columns\n"); return 1; }
+            PotentialExon currExon;
+            currExon.setByAln(entry);
+            const unsigned int targetKey = currExon.targetKey;
+            if (isFirstIteration) { currTargetKey = targetKey; isFirstIteration = false; }
+            if (targetKey != currTargetKey) { flush(); currTargetKey = targetKey; }
+            const size_t potentialExonAALen = std::abs(currExon.nucleotideLen) / 3;
+            if (potentialExonAALen >= minExonAaLength) { if (currExon.strand == PLUS) plusE.emplace_back(currExon); else minusE.emplace_back(currExon); }
+            resultsPtr = Util::skipLine(resultsPtr);
+        }
+        flush();
+    }
+    fclose(out); fclose(forf); fclose(faln);
+    printf("{\"contigs\": %zu, \"predictions\": %zu}\n", contigs.size(), nPred);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) { fprintf(stderr, "usage: ref_harness pipeline|sw|submat ...\n"); return 2; }
     std::string cmd = argv[1];
@@ -408,5 +550,6 @@ int main(int argc, char **argv) {
     if (cmd == "pipeline") return cmdPipeline(argc, argv);
     if (cmd == "sw") return cmdSw(argc, argv);
     if (cmd == "orfs") return cmdOrfs(argc, argv);
+    if (cmd == "exons") return cmdExons(argc, argv);
     return 2;
 }

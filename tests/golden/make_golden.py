@@ -141,10 +141,35 @@ def main():
         write("orf_contigs.txt.gz", "\n".join(contigs) + "\n")
         write("orf_expected.txt.gz", outs[0])
         print("orf contigs", len(contigs), "fragments", outs[0].count("\n") - len(contigs))
+        # end to end: contigs -> ORF fragments -> prefilter + align -> exon sets (resultspercontig + collectoptimalset)
+        tcodes, founders = synth.make_targets(200, 32)
+        e2e_t = [synth.codes_to_str(t) for t in tcodes]
+        e2e_c = ["".join("ACGT"[x] for x in c) for c in synth.make_contigs(120, founders, 32)]
+        outs = []
+        for binary in (REF_AVX2, REF_SSE):
+            d = os.path.join(tmp, "e2e_" + os.path.basename(os.path.dirname(binary)))
+            os.makedirs(d, exist_ok=True)
+            open(os.path.join(d, "t.txt"), "w").write("\n".join(e2e_t) + "\n")
+            open(os.path.join(d, "c.txt"), "w").write("\n".join(e2e_c) + "\n")
+            subprocess.check_call([binary, "orfs", os.path.join(d, "c.txt"), os.path.join(d, "orfs.txt")], stdout=subprocess.DEVNULL)
+            prots = [l.rstrip("\n").rsplit("\t", 1)[1] for l in open(os.path.join(d, "orfs.txt")) if not l.startswith(">")]
+            open(os.path.join(d, "q.txt"), "w").write("\n".join(prots) + "\n")
+            subprocess.check_call([binary, "pipeline", MATDIR, os.path.join(d, "t.txt"), os.path.join(d, "q.txt"), os.path.join(d, "out"), "--threads", "4"],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            subprocess.check_call([binary, "exons", os.path.join(d, "t.txt"), os.path.join(d, "c.txt"), os.path.join(d, "orfs.txt"),
+                                   os.path.join(d, "out", "aln.txt"), os.path.join(d, "exons.txt")], stdout=subprocess.DEVNULL)
+            outs.append(open(os.path.join(d, "exons.txt")).read())
+        assert outs[0] == outs[1], "AVX2 and SSE4.1 reference builds disagree on the end-to-end fixture"
+        write("e2e_targets.txt.gz", "\n".join(e2e_t) + "\n")
+        write("e2e_contigs.txt.gz", "\n".join(e2e_c) + "\n")
+        write("e2e_exons_expected.txt.gz", outs[0])
+        print("end-to-end", len(e2e_c), "contigs", outs[0].count("\n") - len(e2e_c), "exon lines")
         l2 = int(subprocess.check_output(["getconf", "LEVEL2_CACHE_SIZE"]).decode().strip() or 0)
         open(os.path.join(HERE, "PROVENANCE.txt"), "w").write(
             "generated by tests/golden/make_golden.py with oracle/_ref/ref_harness (reference sources compiled with g++ -mavx2;\n"
-            "cross-checked byte-for-byte against the -msse4.1 build).  host L2 (Util::getL2CacheSize) = %d bytes -> BINSIZE 2 for these DB sizes.\n" % l2)
+            "cross-checked byte-for-byte against the -msse4.1 build).  host L2 (Util::getL2CacheSize) = %d bytes -> BINSIZE 2 for these DB sizes.\n"
+            "orf_contigs / orf_expected: `ref_harness orfs` = the reference's Orf.cpp + TranslateNucl.h driven like util/extractorfs.cpp (--translate, predictexons defaults).\n"
+            "e2e_*: contigs -> `orfs` -> `pipeline` -> `exons` (resultspercontig joining + the reference's collectoptimalset.cpp / PredictionParser.h): the exon sets of predictexons.\n" % l2)
 
 
 if __name__ == "__main__":

@@ -51,6 +51,22 @@ def test_oracle_orfs_match_golden(tmp_path):
     assert (tmp_path / "o.txt").read_text() == _text("orf_expected.txt.gz")
 
 
+def test_oracle_end_to_end_exon_sets_match_golden(tmp_path):
+    """contigs -> ORF fragments -> prefilter + align -> exon sets, every stage by the C oracle, against the exon sets the
+    reference's own code produces (extractorfs, prefilter, align, resultspercontig, collectoptimalset)"""
+    oracle.build()
+    t, c = _text("e2e_targets.txt.gz"), _text("e2e_contigs.txt.gz")
+    (tmp_path / "t.txt").write_text(t)
+    (tmp_path / "c.txt").write_text(c)
+    subprocess.check_call([oracle.CLI, "orfs", str(tmp_path / "c.txt"), str(tmp_path / "orfs.txt")], stdout=subprocess.DEVNULL)
+    prots = [l.rstrip("\n").rsplit("\t", 1)[1] for l in open(tmp_path / "orfs.txt") if not l.startswith(">")]
+    (tmp_path / "q.txt").write_text("\n".join(prots) + "\n")
+    subprocess.check_call([oracle.CLI, "pipeline", str(tmp_path / "t.txt"), str(tmp_path / "q.txt"), str(tmp_path / "out"), "--l2", "2097152"], stdout=subprocess.DEVNULL)
+    subprocess.check_call([oracle.CLI, "exons", str(tmp_path / "t.txt"), str(tmp_path / "c.txt"), str(tmp_path / "orfs.txt"),
+                           str(tmp_path / "out" / "aln.txt"), str(tmp_path / "exons.txt")], stdout=subprocess.DEVNULL)
+    assert (tmp_path / "exons.txt").read_text() == _text("e2e_exons_expected.txt.gz")
+
+
 @pytest.mark.skipif(not os.path.exists(oracle.REF) or not os.path.isdir("/root/reference"), reason="reference harness not built here")
 def test_oracle_matches_live_reference(tmp_path):
     from metaeuk_amd import synth
