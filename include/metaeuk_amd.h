@@ -143,6 +143,37 @@ int mk_queries_from_orfs(const mk_orfs *o, const mk_params *params, mk_queries *
 void mk_orfs_destroy(mk_orfs *o);
 size_t mk_format_orf_header(char *buf, const mk_orf *o);   /* "contig<TAB>from(+|-)len[<TAB>complete]", Orf.cpp:434-452 */
 
+/* ---- consumer of the alignments: `resultspercontig` + `collectoptimalset` of predictexons
+ * (src/exonpredictor/resultspercontig.cpp:34-220, collectoptimalset.cpp:33-424) on the arrays in memory: per contig, target
+ * and strand, the chain of compatible putative exons (ORF-fragment alignments) with the highest score.  Host code. */
+typedef struct {               /* LocalParameters.h:138-146 / the predictexons flags */
+    double evalue_thr;         /* --metaeuk-eval 0.001 (combined e-value of a set) */
+    double target_cov_thr;     /* --metaeuk-tcov 0.5 */
+    uint64_t max_intron, min_intron, min_exon_aa, max_aa_overlap, max_exon_sets;   /* 10000, 15, 11, 10, 1 */
+    int32_t gap_open, gap_extend;                                                  /* --set-gap-open -1 --set-gap-extend -1 */
+} mk_exon_params;
+typedef struct {               /* Prediction (src/commons/PredictionParser.h:189-384) */
+    uint32_t target; int32_t strand; uint32_t total_bit_score, n_exons;
+    double evalue;
+    uint32_t low_coord, high_coord;
+    uint64_t first_exon;       /* exons[first_exon .. first_exon + n_exons) */
+} mk_prediction;
+typedef struct {               /* PotentialExon as printed by exonToBuffer (PredictionParser.h:88-137) */
+    uint32_t orf; int32_t bit_score;
+    double seq_id, evalue;     /* as the reference re-reads them from the alignment text */
+    int32_t target_start, target_end, target_len, contig_start, contig_end, nucleotide_len, orf_from, orf_to;
+} mk_exon;
+typedef struct mk_predictions mk_predictions;
+void mk_default_exon_params(mk_exon_params *p);
+/* q = the batch made by mk_queries_from_orfs(orfs) after mk_search / mk_align */
+int mk_predict_exons(const mk_targetdb *db, const mk_orfs *orfs, const mk_queries *q, const mk_exon_params *params, mk_predictions **out);
+/* predictions of contig c = predictions[contig_offsets[c] .. contig_offsets[c+1]); views owned by the handle */
+int mk_predictions_result(const mk_predictions *p, const mk_prediction **predictions, const uint64_t **contig_offsets /* n_contigs+1 */,
+                          const mk_exon **exons, uint64_t *n_predictions);
+void mk_predictions_destroy(mk_predictions *p);
+/* one line of the reference's prediction DB: predictionToBuffer + exonToBuffer */
+size_t mk_format_prediction_exon(char *buf, const mk_prediction *p, const mk_exon *e);
+
 /* ---- prefilter + align of the batch in one pipelined pass: the `search` workflow's two module calls
  * (blastp.sh:70,85 via predictexons.sh:68).  Same results as mk_prefilter followed by mk_align (both result
  * getters work afterwards); the stages run concurrently on two HIP streams, chunk by chunk. */

@@ -60,6 +60,7 @@ def lib():
         L.mk_format_hit.restype = C.c_size_t
         L.mk_format_alignment.restype = C.c_size_t
         L.mk_format_orf_header.restype = C.c_size_t
+        L.mk_format_prediction_exon.restype = C.c_size_t
         _LIB = L
     return _LIB
 
@@ -197,6 +198,7 @@ class Orfs:
         off = np.zeros(len(contigs) + 1, dtype=np.uint64)
         np.cumsum([len(c) for c in contigs], out=off[1:])
         self.h = C.c_void_p()
+        self.n_contigs = len(contigs)
         _chk(lib().mk_extract_orfs(C.c_char_p(raw), _p(off), C.c_uint32(len(contigs)), C.c_int(min_codons), C.byref(self.h)))
         op, fp, ap, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
         _chk(lib().mk_orfs_result(self.h, C.byref(op), C.byref(fp), C.byref(ap), C.byref(n)))
@@ -229,6 +231,66 @@ class Orfs:
     def close(self):
         if self.h:
             lib().mk_orfs_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ExonParams(C.Structure):
+    _fields_ = [("evalue_thr", C.c_double), ("target_cov_thr", C.c_double), ("max_intron", C.c_uint64), ("min_intron", C.c_uint64),
+                ("min_exon_aa", C.c_uint64), ("max_aa_overlap", C.c_uint64), ("max_exon_sets", C.c_uint64), ("gap_open", C.c_int32),
+                ("gap_extend", C.c_int32)]
+
+
+PREDICTION_DTYPE = np.dtype([("target", "<u4"), ("strand", "<i4"), ("total_bit_score", "<u4"), ("n_exons", "<u4"), ("evalue", "<f8"),
+                             ("low_coord", "<u4"), ("high_coord", "<u4"), ("first_exon", "<u8")])
+EXON_DTYPE = np.dtype([("orf", "<u4"), ("bit_score", "<i4"), ("seq_id", "<f8"), ("evalue", "<f8"), ("target_start", "<i4"), ("target_end", "<i4"),
+                       ("target_len", "<i4"), ("contig_start", "<i4"), ("contig_end", "<i4"), ("nucleotide_len", "<i4"), ("orf_from", "<i4"),
+                       ("orf_to", "<i4")])
+
+
+def default_exon_params():
+    p = ExonParams()
+    lib().mk_default_exon_params(C.byref(p))
+    return p
+
+
+class Predictions:
+    """exon sets per contig, target and strand (resultspercontig + collectoptimalset) from an aligned ORF batch"""
+
+    def __init__(self, db, orfs, q, params=None):
+        self.params = params or default_exon_params()
+        self.h = C.c_void_p()
+        _chk(lib().mk_predict_exons(db.h, orfs.h, q.h, C.byref(self.params), C.byref(self.h)))
+        pp, op, ep, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+        _chk(lib().mk_predictions_result(self.h, C.byref(pp), C.byref(op), C.byref(ep), C.byref(n)))
+        self.n = int(n.value)
+        self.contig_off = np.ctypeslib.as_array(C.cast(op, C.POINTER(C.c_uint64)), shape=(orfs.n_contigs + 1,))
+        if self.n:
+            self.predictions = np.ctypeslib.as_array(C.cast(pp, C.POINTER(C.c_uint8)), shape=(self.n * PREDICTION_DTYPE.itemsize,)).view(PREDICTION_DTYPE)
+            ne = int(self.predictions["first_exon"][-1] + self.predictions["n_exons"][-1])
+            self.exons = np.ctypeslib.as_array(C.cast(ep, C.POINTER(C.c_uint8)), shape=(ne * EXON_DTYPE.itemsize,)).view(EXON_DTYPE)
+        else:
+            self.predictions, self.exons = np.zeros(0, dtype=PREDICTION_DTYPE), np.zeros(0, dtype=EXON_DTYPE)
+
+    def lines(self, contig):
+        """the contig's record of the reference's prediction DB (one line per exon)"""
+        buf = C.create_string_buffer(512)
+        out = []
+        for k in range(int(self.contig_off[contig]), int(self.contig_off[contig + 1])):
+            p = self.predictions[k:k + 1]
+            for j in range(int(p["first_exon"][0]), int(p["first_exon"][0] + p["n_exons"][0])):
+                n = lib().mk_format_prediction_exon(buf, p.ctypes.data_as(C.c_void_p), self.exons[j:j + 1].ctypes.data_as(C.c_void_p))
+                out.append(buf.raw[:n].decode())
+        return "".join(out)
+
+    def close(self):
+        if self.h:
+            lib().mk_predictions_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

@@ -7,6 +7,7 @@
 #include "mk_host.hpp"
 #include "mk_kernels.hpp"
 #include "mk_orf.hpp"
+#include "mk_exons.hpp"
 #include "mk_prefilter.hpp"
 
 #include <algorithm>
@@ -412,6 +413,7 @@ struct mk_orfs {
     std::vector<uint64_t> aaOff;
     std::vector<char> aa;
     std::vector<uint8_t> codes;
+    uint32_t nContigs = 0;
     ~mk_orfs() { dev.release(); }
 };
 
@@ -425,6 +427,7 @@ int mk_extract_orfs(const char *nucleotides, const uint64_t *offsets, uint32_t n
     }
     HostTimer ht("host_extract_orfs_total");
     mk_orfs *o = new mk_orfs();
+    o->nContigs = nContigs;
     DevBuf<char> dNucl;
     DevBuf<uint64_t> dOff;
     hipError_t e = dNucl.alloc(std::max<uint64_t>(offsets[nContigs], 1));
@@ -478,6 +481,37 @@ void mk_orfs_destroy(mk_orfs *o) { delete o; }
 size_t mk_format_orf_header(char *buf, const mk_orf *o) {
     return mk::format_orf_header(buf, o->contig, o->from, o->to, o->incomplete_start != 0, o->incomplete_end != 0);
 }
+
+
+// ---- resultspercontig + collectoptimalset on the alignment arrays (mk_exons.cpp) ----
+struct mk_predictions {
+    std::vector<mk_prediction> preds;
+    std::vector<uint64_t> contigOff;
+    std::vector<mk_exon> exons;
+};
+
+void mk_default_exon_params(mk_exon_params *p) { if (p) mk::default_exon_params(*p); }
+
+int mk_predict_exons(const mk_targetdb *db, const mk_orfs *orfs, const mk_queries *q, const mk_exon_params *P, mk_predictions **out) {
+    if (!db || !orfs || !q || !P || !out) return fail(MK_ERR_ARG, "null argument");
+    if (!q->haveAln) return fail(MK_ERR_ARG, "no alignment result in this batch: run mk_search or mk_align first");
+    if (q->n != orfs->orfs.size()) return fail(MK_ERR_ARG, "the batch has %u queries, the ORF set %zu fragments", q->n, orfs->orfs.size());
+    HostTimer ht("host_predict_exons_total");
+    mk_predictions *p = new mk_predictions();
+    mk::predict_exons(orfs->orfs.data(), orfs->orfs.size(), orfs->nContigs, (const mk_alignment *) q->alns.p, q->alnOff.data(), mk_targetdb_residues(db), *P,
+                      p->preds, p->contigOff, p->exons);
+    *out = p;
+    return MK_OK;
+}
+
+int mk_predictions_result(const mk_predictions *p, const mk_prediction **preds, const uint64_t **contigOff, const mk_exon **exons, uint64_t *n) {
+    if (!p || !preds || !contigOff || !exons || !n) return fail(MK_ERR_ARG, "null argument");
+    *preds = p->preds.data(); *contigOff = p->contigOff.data(); *exons = p->exons.data(); *n = p->preds.size();
+    return MK_OK;
+}
+
+void mk_predictions_destroy(mk_predictions *p) { delete p; }
+size_t mk_format_prediction_exon(char *buf, const mk_prediction *p, const mk_exon *e) { return mk::format_prediction_exon(buf, *p, *e); }
 
 void mk_queries_destroy(mk_queries *q) { delete q; }
 

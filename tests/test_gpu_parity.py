@@ -154,6 +154,11 @@ def _lines(name):
         return f.read().split("\n")[:-1]
 
 
+def _text(name):
+    with gzip.open(os.path.join(GOLD, name), "rt") as f:
+        return f.read()
+
+
 def _blocks(name):
     return oracle.read_blocks(os.path.join(GOLD, name))
 
@@ -398,6 +403,74 @@ def test_orfs_feed_the_search(gpu_api, tmp_path):
     assert np.array_equal(np.asarray(ao1), np.asarray(ao2))
     n = int(ao1[-1])
     assert n > 20 and api.format_alignments(a1, 0, n) == api.format_alignments(a2, 0, n)
+
+
+def _prediction_text(pred, n_contigs):
+    return "".join(">%d\n%s" % (c, pred.lines(c)) for c in range(n_contigs))
+
+
+def test_predict_exons_end_to_end_vs_golden(gpu_api):
+    """contigs -> mk_extract_orfs -> mk_search -> mk_predict_exons: the product chain, against the exon sets the reference's
+    own extractorfs / prefilter / align / resultspercontig / collectoptimalset code produced (tests/golden/PROVENANCE.txt)"""
+    api = gpu_api
+    targets, contigs = _lines("e2e_targets.txt.gz"), _lines("e2e_contigs.txt.gz")
+    params = api.default_params()
+    params.host_l2_bytes = 2097152
+    db = api.TargetDB(targets, params)
+    o = api.Orfs(contigs)
+    q = o.queries(params)
+    api.search(db, q)
+    pred = api.Predictions(db, o, q)
+    exp = _text("e2e_exons_expected.txt.gz")
+    assert pred.n > 100 and _prediction_text(pred, len(contigs)) == exp
+    # the arrays say what the text says
+    P, E = pred.predictions, pred.exons
+    assert int(pred.contig_off[-1]) == pred.n and int(P["n_exons"].sum()) == len(E) == exp.count("\n") - len(contigs)
+    assert (P["n_exons"] > 1).any() and (P["strand"] == -1).any()
+    assert (P["low_coord"] <= P["high_coord"]).all()
+    first = E[P["first_exon"]]
+    assert (np.where(P["strand"] == 1, first["contig_start"], 0) >= 0).all()
+
+
+def test_predict_exons_vs_oracle_on_synthetic_contigs(gpu_api, tmp_path):
+    """same chain on a seeded workload with homolog-bearing contigs on both strands, checked against the oracle's exon stage fed
+    with the oracle's own ORFs and alignments; plus non-default exon parameters and the error path"""
+    from metaeuk_amd import synth
+    import subprocess
+    api = gpu_api
+    targets, founders = synth.make_targets(400, 21)
+    tstr = [synth.codes_to_str(t) for t in targets]
+    contigs = ["".join("ACGT"[x] for x in c) for c in synth.make_contigs(60, founders, 21)]
+    params = api.default_params()
+    db = api.TargetDB(tstr, params)
+    o = api.Orfs(contigs)
+    q = o.queries(params)
+    with pytest.raises(api.MkError):
+        api.Predictions(db, o, q)                                   # no alignments in the batch yet
+    api.search(db, q)
+    pred = api.Predictions(db, o, q)
+    oracle.build()
+    (tmp_path / "t.txt").write_text("\n".join(tstr) + "\n")
+    (tmp_path / "c.txt").write_text("\n".join(contigs) + "\n")
+    subprocess.check_call([oracle.CLI, "orfs", str(tmp_path / "c.txt"), str(tmp_path / "orfs.txt")], stdout=subprocess.DEVNULL)
+    prots = [l.rstrip("\n").rsplit("\t", 1)[1] for l in open(tmp_path / "orfs.txt") if not l.startswith(">")]
+    (tmp_path / "q.txt").write_text("\n".join(prots) + "\n")
+    subprocess.check_call([oracle.CLI, "pipeline", str(tmp_path / "t.txt"), str(tmp_path / "q.txt"), str(tmp_path / "out"), "--l2", str(params.host_l2_bytes)],
+                          stdout=subprocess.DEVNULL)
+    subprocess.check_call([oracle.CLI, "exons", str(tmp_path / "t.txt"), str(tmp_path / "c.txt"), str(tmp_path / "orfs.txt"),
+                           str(tmp_path / "out" / "aln.txt"), str(tmp_path / "exons.txt")], stdout=subprocess.DEVNULL)
+    exp = (tmp_path / "exons.txt").read_text()
+    assert pred.n > 20 and _prediction_text(pred, len(contigs)) == exp
+    # a second set per target and strand, looser coverage: more predictions, the default ones still among them
+    xp = api.default_exon_params()
+    xp.max_exon_sets, xp.target_cov_thr = 2, 0.3
+    pred2 = api.Predictions(db, o, q, xp)
+    assert pred2.n >= pred.n
+    # an empty contig set is a valid, empty answer
+    o0 = api.Orfs([])
+    q0 = o0.queries(params)
+    api.search(db, q0)
+    assert api.Predictions(db, o0, q0).n == 0
 
 
 def test_cli_extractorfs_db_roundtrip(gpu_api, tmp_path):
