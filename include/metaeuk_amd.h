@@ -165,8 +165,10 @@ typedef struct {               /* PotentialExon as printed by exonToBuffer (Pred
 } mk_exon;
 typedef struct mk_predictions mk_predictions;
 void mk_default_exon_params(mk_exon_params *p);
-/* q = the batch made by mk_queries_from_orfs(orfs) after mk_search / mk_align */
-int mk_predict_exons(const mk_targetdb *db, const mk_orfs *orfs, const mk_queries *q, const mk_exon_params *params, mk_predictions **out);
+/* q = the batch made by mk_queries_from_orfs(orfs) after mk_search / mk_align.  target_keys (may be NULL: key = index) gives the
+ * DB key of every target: the reference orders a contig's predictions by target KEY and prints it. */
+int mk_predict_exons(const mk_targetdb *db, const mk_orfs *orfs, const mk_queries *q, const mk_exon_params *params,
+                     const uint32_t *target_keys, mk_predictions **out);
 /* predictions of contig c = predictions[contig_offsets[c] .. contig_offsets[c+1]); views owned by the handle */
 int mk_predictions_result(const mk_predictions *p, const mk_prediction **predictions, const uint64_t **contig_offsets /* n_contigs+1 */,
                           const mk_exon **exons, uint64_t *n_predictions);

@@ -262,10 +262,11 @@ def default_exon_params():
 class Predictions:
     """exon sets per contig, target and strand (resultspercontig + collectoptimalset) from an aligned ORF batch"""
 
-    def __init__(self, db, orfs, q, params=None):
+    def __init__(self, db, orfs, q, params=None, target_keys=None):
         self.params = params or default_exon_params()
         self.h = C.c_void_p()
-        _chk(lib().mk_predict_exons(db.h, orfs.h, q.h, C.byref(self.params), C.byref(self.h)))
+        keys = None if target_keys is None else np.ascontiguousarray(target_keys, dtype=np.uint32)
+        _chk(lib().mk_predict_exons(db.h, orfs.h, q.h, C.byref(self.params), None if keys is None else _p(keys), C.byref(self.h)))
         pp, op, ep, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
         _chk(lib().mk_predictions_result(self.h, C.byref(pp), C.byref(op), C.byref(ep), C.byref(n)))
         self.n = int(n.value)

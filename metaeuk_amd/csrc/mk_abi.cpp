@@ -492,13 +492,13 @@ struct mk_predictions {
 
 void mk_default_exon_params(mk_exon_params *p) { if (p) mk::default_exon_params(*p); }
 
-int mk_predict_exons(const mk_targetdb *db, const mk_orfs *orfs, const mk_queries *q, const mk_exon_params *P, mk_predictions **out) {
+int mk_predict_exons(const mk_targetdb *db, const mk_orfs *orfs, const mk_queries *q, const mk_exon_params *P, const uint32_t *targetKeys, mk_predictions **out) {
     if (!db || !orfs || !q || !P || !out) return fail(MK_ERR_ARG, "null argument");
     if (!q->haveAln) return fail(MK_ERR_ARG, "no alignment result in this batch: run mk_search or mk_align first");
     if (q->n != orfs->orfs.size()) return fail(MK_ERR_ARG, "the batch has %u queries, the ORF set %zu fragments", q->n, orfs->orfs.size());
     HostTimer ht("host_predict_exons_total");
     mk_predictions *p = new mk_predictions();
-    mk::predict_exons(orfs->orfs.data(), orfs->orfs.size(), orfs->nContigs, (const mk_alignment *) q->alns.p, q->alnOff.data(), mk_targetdb_residues(db), *P,
+    mk::predict_exons(orfs->orfs.data(), orfs->orfs.size(), orfs->nContigs, (const mk_alignment *) q->alns.p, q->alnOff.data(), targetKeys, mk_targetdb_residues(db), *P,
                       p->preds, p->contigOff, p->exons);
     *out = p;
     return MK_OK;

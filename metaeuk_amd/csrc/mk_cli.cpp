@@ -1,4 +1,4 @@
-// metaeuk_amd/csrc/mk_cli.cpp -- `metaeuk-amd prefilter|align`: the two hot modules of
+// metaeuk_amd/csrc/mk_cli.cpp -- `metaeuk-amd prefilter|align|extractorfs|predictexons`: the two hot modules of
 // `metaeuk predictexons` with the reference's process-level signature, flag names and on-disk DB format,
 // on top of the C ABI (include/metaeuk_amd.h).
 //
@@ -45,6 +45,17 @@ const Flag FLAGS[] = {
     {"--alt-ali", "0", false}, {"--max-rejected", "2147483647", false}, {"--max-accept", "2147483647", false},
     {"--score-bias", "0", false}, {"--realign", "0", false}, {"--realign-score-bias", "-0.2", false}, {"--realign-max-seqs", "2147483647", false},
     {"--corr-score-weight", "0", false}, {"--gap-open", "aa:11,nucl:5", true}, {"--gap-extend", "aa:1,nucl:2", true}, {"--zdrop", "40", false},
+    // predictexons only: extractorfs (Parameters.cpp:2525-2554), search workflow extras, collectoptimalset (LocalParameters.h:92-104)
+    {"--min-length", "15", true}, {"--max-length", "32734", false}, {"--max-gaps", "2147483647", false}, {"--contig-start-mode", "2", false},
+    {"--contig-end-mode", "2", false}, {"--orf-start-mode", "1", false}, {"--forward-frames", "1,2,3", false}, {"--reverse-frames", "1,2,3", false},
+    {"--translation-table", "1", false}, {"--translate", "0", false}, {"--use-all-table-starts", "0", false}, {"--id-offset", "0", false},
+    {"--create-lookup", "0", false}, {"--add-orf-stop", "0", false}, {"--num-iterations", "1", false}, {"--start-sens", "4", false},
+    {"--sens-steps", "1", false}, {"--exhaustive-search", "0", false}, {"--exhaustive-search-filter", "0", false}, {"--strand", "1", false},
+    {"--remove-tmp-files", "0", false}, {"--reuse-latest", "0", false}, {"--force-reuse", "0", false}, {"--disk-space-limit", "0", false},
+    {"--mpi-runner", "", false}, {"--reverse-fragments", "0", false},
+    {"--metaeuk-eval", "0.001", true}, {"--metaeuk-tcov", "0.5", true}, {"--max-intron", "10000", true}, {"--min-intron", "15", true},
+    {"--min-exon-aa", "11", true}, {"--max-overlap", "10", true}, {"--max-exon-sets", "1", true}, {"--set-gap-open", "-1", true},
+    {"--set-gap-extend", "-1", true},
     // properties of the reference build/host being reproduced (see mk_params in the ABI header)
     {"--ref-simd", "avx2", true}, {"--ref-l2-bytes", "", true}, {"--gpu", "0", true},
 };
@@ -98,7 +109,10 @@ int parse(int argc, char **argv, Args &a) {
             std::string(k.name) == "--db-load-mode" || std::string(k.name) == "--split" || std::string(k.name) == "--split-mode" ||
             std::string(k.name) == "--pca" || std::string(k.name) == "--pcb" || std::string(k.name) == "--zdrop" || std::string(k.name) == "--realign-score-bias" ||
             std::string(k.name) == "--realign-max-seqs" || std::string(k.name) == "--seq-id-mode" || std::string(k.name) == "--mask-lower-case" ||
-            std::string(k.name) == "--threads") continue;     // no effect on this path
+            std::string(k.name) == "--threads" || std::string(k.name) == "--remove-tmp-files" || std::string(k.name) == "--reuse-latest" ||
+            std::string(k.name) == "--force-reuse" || std::string(k.name) == "--disk-space-limit" || std::string(k.name) == "--mpi-runner" ||
+            std::string(k.name) == "--start-sens" || std::string(k.name) == "--sens-steps" || std::string(k.name) == "--max-length" ||
+            std::string(k.name) == "--max-gaps") continue;    // no effect on this path
         if (std::string(k.name) == "-k") {                    // 0 = automatic = 6 below 3.35e9 target residues (IndexTable.h:439-449)
             if (v != "0" && v != "6") { fprintf(stderr, "-k %s: only k = 6 (or 0 = auto) is implemented\n", v.c_str()); return EXIT_FAILURE; }
             continue;
@@ -298,9 +312,10 @@ int cmdExtractOrfs(int argc, char **argv) {
     if (!e.empty()) return die("%s", e);
     const double t0 = now();
     std::vector<char> nucl;
-    std::vector<uint64_t> off(contigs.entries.size() + 1, 0);
-    for (size_t i = 0; i < contigs.entries.size(); i++) {
-        nucl.insert(nucl.end(), contigs.entry(i), contigs.entry(i) + contigs.seqLen(i));
+    const std::vector<size_t> ord = contigs.keyOrder();           // fragments are renumbered by ascending contig key (extractorfs.cpp:140-155)
+    std::vector<uint64_t> off(ord.size() + 1, 0);
+    for (size_t i = 0; i < ord.size(); i++) {
+        nucl.insert(nucl.end(), contigs.entry(ord[i]), contigs.entry(ord[i]) + contigs.seqLen(ord[i]));
         off[i + 1] = nucl.size();
     }
     mk_orfs *O = nullptr;
@@ -327,7 +342,7 @@ int cmdExtractOrfs(int argc, char **argv) {
     for (uint64_t k = 0; k < n; k++) {
         const mk_orf &o = orfs[k];
         mk_orf keyed = o;
-        keyed.contig = contigs.entries[o.contig].key;            // the header names the contig's DB key
+        keyed.contig = contigs.entries[ord[o.contig]].key;            // the header names the contig's DB key
         size_t hl = mk_format_orf_header(hdr, &keyed);
         hdr[hl++] = '\n';
         hdrW.write((uint32_t) k, hdr, hl);
@@ -335,8 +350,8 @@ int cmdExtractOrfs(int argc, char **argv) {
         buf.push_back('\n');
         if (aaW) aaW->write((uint32_t) k, buf.data(), buf.size());
         if (!translate) {                                        // the fragment's nucleotides as Orf::getSequence hands them out
-            const char *c = contigs.entry(o.contig);
-            const size_t len = contigs.seqLen(o.contig), nn = 3 * (size_t) (aaOff[k + 1] - aaOff[k]);
+            const char *c = contigs.entry(ord[o.contig]);
+            const size_t len = contigs.seqLen(ord[o.contig]), nn = 3 * (size_t) (aaOff[k + 1] - aaOff[k]);
             buf.resize(nn);
             for (size_t j = 0; j < nn; j++) {
                 char ch;
@@ -356,17 +371,105 @@ int cmdExtractOrfs(int argc, char **argv) {
     return EXIT_SUCCESS;
 }
 
+// predictexons <i:contigsDB> <i:targetsDB> <o:calledExonsDB> <tmpDir> [flags]   src/workflow/PredictExons.cpp:18-57, data/predictexons.sh
+//   the whole workflow in one process: extractorfs + translatenucs + search (prefilter, align) + resultspercontig +
+//   collectoptimalset, with nothing written between the stages.  Output = the dp_predictions DB the script moves to <o> (:96): one
+//   record per contig (key = contig key, empty when nothing was predicted), one line per exon.  tmpDir is accepted and not used.
+int cmdPredictExons(int argc, char **argv) {
+    Args a;
+    if (int rc = parse(argc, argv, a)) return rc;
+    if (a.pos.size() != 4) return die("usage: metaeuk-amd predictexons <i:contigsDB> <i:targetsDB> <o:calledExonsDB> <tmpDir> [options]%s");
+    mk_params P;
+    int gpu = 0;
+    if (int rc = fillParams(a, P, gpu)) return rc;
+    auto get = [&](const char *k) -> const std::string * { auto it = a.opt.find(k); return it == a.opt.end() ? nullptr : &it->second; };
+    mk_exon_params X;
+    mk_default_exon_params(&X);
+    int minLength = 15;
+    if (auto v = get("--min-length")) minLength = atoi(v->c_str());
+    if (auto v = get("--metaeuk-eval")) X.evalue_thr = (double) (float) atof(v->c_str());      // float parameters (LocalParameters.h:76-77)
+    if (auto v = get("--metaeuk-tcov")) X.target_cov_thr = (double) (float) atof(v->c_str());
+    if (auto v = get("--max-intron")) X.max_intron = strtoull(v->c_str(), nullptr, 10);
+    if (auto v = get("--min-intron")) X.min_intron = strtoull(v->c_str(), nullptr, 10);
+    if (auto v = get("--min-exon-aa")) X.min_exon_aa = strtoull(v->c_str(), nullptr, 10);
+    if (auto v = get("--max-overlap")) X.max_aa_overlap = strtoull(v->c_str(), nullptr, 10);
+    if (auto v = get("--max-exon-sets")) X.max_exon_sets = strtoull(v->c_str(), nullptr, 10);
+    if (auto v = get("--set-gap-open")) X.gap_open = atoi(v->c_str());
+    if (auto v = get("--set-gap-extend")) X.gap_extend = atoi(v->c_str());
+    if (!get("-e")) P.evalue_thr = 100;                          // setPredictExonsDefaults (PredictExons.cpp:8-16)
+    if (!get("--min-aln-len")) P.min_aln_len = (int) X.min_exon_aa;   // par.alnLenThr = par.minExonAaLength (:46)
+    if (mk::Database::exists(a.pos[2] + ".dbtype")) return die("%s exists already!", a.pos[2]);          // predictexons.sh:32
+    const double t0 = now();
+    mk::Database contigs, tdb;
+    std::string e = contigs.open(a.pos[0]);
+    if (!e.empty()) return die("%s", e);
+    e = tdb.open(a.pos[1]);
+    if (!e.empty()) return die("%s", e);
+    if ((tdb.dbtype & 0xFFFF) != mk::DBTYPE_AMINO_ACIDS) return die("only amino-acid target databases are implemented (profile targets: SURVEY 8f-4)%s");
+    if (mk_init(gpu) != MK_OK) return die("%s", mk_last_error());
+    // contigs by ascending key: the order in which createRenumberedDB numbers their fragments (extractorfs.cpp:140-155)
+    const std::vector<size_t> ord = contigs.keyOrder();
+    std::vector<char> nucl;
+    std::vector<uint64_t> off(ord.size() + 1, 0);
+    for (size_t i = 0; i < ord.size(); i++) {
+        nucl.insert(nucl.end(), contigs.entry(ord[i]), contigs.entry(ord[i]) + contigs.seqLen(ord[i]));
+        off[i + 1] = nucl.size();
+    }
+    std::vector<uint8_t> tres;
+    std::vector<uint64_t> toff;
+    encodeDb(tdb, tres, toff);
+    std::vector<uint32_t> tkeys(tdb.entries.size());
+    for (size_t i = 0; i < tkeys.size(); i++) tkeys[i] = tdb.entries[i].key;
+    mk_targetdb *T = nullptr;
+    mk_orfs *O = nullptr;
+    mk_queries *Q = nullptr;
+    mk_predictions *R = nullptr;
+    if (mk_targetdb_create(tres.data(), toff.data(), (uint32_t) tdb.entries.size(), &P, &T) != MK_OK) return die("%s", mk_last_error());
+    const double t1 = now();
+    if (mk_extract_orfs(nucl.data(), off.data(), (uint32_t) ord.size(), minLength, &O) != MK_OK) return die("%s", mk_last_error());
+    if (mk_queries_from_orfs(O, &P, &Q) != MK_OK) return die("%s", mk_last_error());
+    if (mk_search(T, Q, &P) != MK_OK) return die("%s", mk_last_error());
+    if (mk_predict_exons(T, O, Q, &X, tkeys.data(), &R) != MK_OK) return die("%s", mk_last_error());
+    const double t2 = now();
+    const mk_prediction *preds; const uint64_t *coff; const mk_exon *exons; uint64_t np = 0;
+    mk_predictions_result(R, &preds, &coff, &exons, &np);
+    mk::DatabaseWriter w(a.pos[2], 12 /* DBTYPE_GENERIC_DB, collectoptimalset.cpp:244 */);
+    e = w.open();
+    if (!e.empty()) return die("%s", e);
+    std::string buf;
+    char line[512];
+    for (size_t c = 0; c < ord.size(); c++) {
+        buf.clear();
+        for (uint64_t k = coff[c]; k < coff[c + 1]; k++)
+            for (uint64_t x = preds[k].first_exon; x < preds[k].first_exon + preds[k].n_exons; x++)
+                buf.append(line, mk_format_prediction_exon(line, &preds[k], &exons[x]));
+        w.write(contigs.entries[ord[c]].key, buf.data(), buf.size());
+    }
+    e = w.close();
+    if (!e.empty()) return die("%s", e);
+    const mk_orf *orfs; const uint64_t *aaOff; const char *aa; uint64_t nOrfs = 0;
+    mk_orfs_result(O, &orfs, &aaOff, &aa, &nOrfs);
+    fprintf(stderr, "predictexons: %zu contigs -> %llu fragments x %zu targets -> %llu predictions; %.2f s (target index %.2f s, fragments to exon sets %.2f s)\n",
+            ord.size(), (unsigned long long) nOrfs, tdb.entries.size(), (unsigned long long) np, now() - t0, t1 - t0, t2 - t1);
+    mk_predictions_destroy(R);
+    mk_queries_destroy(Q);
+    mk_orfs_destroy(O);
+    mk_targetdb_destroy(T);
+    return EXIT_SUCCESS;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        fprintf(stderr, "metaeuk-amd: MI355X prefilter+align modules of `metaeuk predictexons`\n  metaeuk-amd prefilter <queryDB> <targetDB> <prefilterDB> [flags]\n  metaeuk-amd align <queryDB> <targetDB> <prefilterDB> <alignmentDB> [flags]\n  metaeuk-amd extractorfs <contigDB> <orfDB> [--min-length N] [--translate 0|1] [--aa-sibling NAME]\n");
+        fprintf(stderr, "metaeuk-amd: MI355X prefilter+align modules of `metaeuk predictexons`\n  metaeuk-amd prefilter <queryDB> <targetDB> <prefilterDB> [flags]\n  metaeuk-amd align <queryDB> <targetDB> <prefilterDB> <alignmentDB> [flags]\n  metaeuk-amd extractorfs <contigDB> <orfDB> [--min-length N] [--translate 0|1] [--aa-sibling NAME]\n  metaeuk-amd predictexons <contigsDB> <targetsDB> <calledExonsDB> <tmpDir> [flags]\n");
         return EXIT_FAILURE;
     }
     const std::string cmd = argv[1];
     if (cmd == "prefilter") return cmdPrefilterOrAlign(false, argc, argv);
     if (cmd == "align") return cmdPrefilterOrAlign(true, argc, argv);
     if (cmd == "extractorfs") return cmdExtractOrfs(argc, argv);
+    if (cmd == "predictexons") return cmdPredictExons(argc, argv);
     fprintf(stderr, "Invalid Command: %s\n", cmd.c_str());
     return EXIT_FAILURE;
 }

@@ -79,6 +79,13 @@ struct Database {
         return "";
     }
 
+    // entry positions by ascending key (ties: data offset) -- DBReader's SORT_BY_ID_OFFSET
+    std::vector<size_t> keyOrder() const {
+        std::vector<size_t> ord(entries.size());
+        for (size_t i = 0; i < ord.size(); i++) ord[i] = i;
+        std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return entries[x].key < entries[y].key; });
+        return ord;
+    }
     const char *entry(size_t i) const { return data.data() + entries[i].offset; }
     size_t seqLen(size_t i) const { return entries[i].length >= 2 ? (size_t) entries[i].length - 2 : 0; }
 };

@@ -30,9 +30,9 @@ struct Exon {
 };
 
 // PotentialExon::setByAln (:15-62)
-Exon make_exon(const mk_alignment &a, uint64_t alnIndex, uint32_t orfKey, int orfFrom, int orfTo) {
+Exon make_exon(const mk_alignment &a, uint64_t alnIndex, uint32_t target, uint32_t orfKey, int orfFrom, int orfTo) {
     Exon e;
-    e.orf = orfKey; e.target = a.db_key; e.bitScore = a.bit_score; e.aln = alnIndex;
+    e.orf = orfKey; e.target = target; e.bitScore = a.bit_score; e.aln = alnIndex;
     e.targetStart = a.db_start; e.targetEnd = a.db_end; e.targetLen = a.db_len;
     e.orfFrom = orfFrom; e.orfTo = orfTo;
     if (orfFrom < orfTo) { e.contigStart = orfFrom + a.q_start * 3; e.contigEnd = orfFrom + a.q_end * 3 + 2; e.strand = 1; }
@@ -141,8 +141,8 @@ void default_exon_params(mk_exon_params &P) {                               // L
     P.gap_open = -1; P.gap_extend = -1;
 }
 
-void predict_exons(const mk_orf *orfs, uint64_t nOrfs, uint32_t nContigs, const mk_alignment *alns, const uint64_t *alnOff, uint64_t dbResidues,
-                   const mk_exon_params &P, std::vector<mk_prediction> &preds, std::vector<uint64_t> &contigOff, std::vector<mk_exon> &exons) {
+void predict_exons(const mk_orf *orfs, uint64_t nOrfs, uint32_t nContigs, const mk_alignment *alns, const uint64_t *alnOff, const uint32_t *targetKeys,
+                   uint64_t dbResidues, const mk_exon_params &P, std::vector<mk_prediction> &preds, std::vector<uint64_t> &contigOff, std::vector<mk_exon> &exons) {
     // the fragments of a contig are consecutive (mk_extract_orfs writes them contig by contig)
     std::vector<uint64_t> firstOrf((size_t) nContigs + 1, nOrfs);
     {
@@ -164,7 +164,7 @@ void predict_exons(const mk_orf *orfs, uint64_t nOrfs, uint32_t nContigs, const 
             // resultspercontig.cpp:145-182: the contig's (orf -> target) records, ordered by (target, orf)
             items.clear();
             for (uint64_t k = firstOrf[c]; k < firstOrf[c + 1]; k++)
-                for (uint64_t a = alnOff[k]; a < alnOff[k + 1]; a++) items.push_back(Item{alns[a].db_key, (uint32_t) k, a});
+                for (uint64_t a = alnOff[k]; a < alnOff[k + 1]; a++) items.push_back(Item{targetKeys ? targetKeys[alns[a].db_key] : alns[a].db_key, (uint32_t) k, a});
             std::sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.target != y.target ? x.target < y.target : x.orf < y.orf; });
             // collectoptimalset.cpp:262-413, target by target
             size_t i = 0;
@@ -173,7 +173,7 @@ void predict_exons(const mk_orf *orfs, uint64_t nOrfs, uint32_t nContigs, const 
                 plus.clear(); minus.clear();
                 for (; i < items.size() && items[i].target == target; i++) {
                     const mk_orf &o = orfs[items[i].orf];
-                    const Exon e = make_exon(alns[items[i].aln], items[i].aln, items[i].orf, (int) o.from, (int) o.to);
+                    const Exon e = make_exon(alns[items[i].aln], items[i].aln, target, items[i].orf, (int) o.from, (int) o.to);
                     if ((size_t) (std::abs(e.nucleotideLen) / 3) >= P.min_exon_aa) (e.strand == 1 ? plus : minus).push_back(e);
                 }
                 size_t iter = 0;

@@ -507,3 +507,42 @@ def test_cli_extractorfs_db_roundtrip(gpu_api, tmp_path):
             assert "".join(codon[n[i:i + 3]] for i in range(0, len(n), 3)) == prot, k
     bad = subprocess.run([build.BIN, "extractorfs", str(tmp_path / "contigs"), str(tmp_path / "x"), "--orf-start-mode", "0"], capture_output=True)
     assert bad.returncode != 0 and not (tmp_path / "x.dbtype").exists()
+
+
+def test_cli_predictexons_db_in_db_out(gpu_api, tmp_path):
+    """`metaeuk-amd predictexons contigsDB targetsDB outDB tmp`: the whole workflow in one process over MMseqs2 DBs whose data
+    order differs from their key order and whose keys are not 0..n-1, against the reference-made exon sets"""
+    import subprocess
+    from metaeuk_amd import build
+    targets, contigs = _lines("e2e_targets.txt.gz"), _lines("e2e_contigs.txt.gz")
+    rs = np.random.RandomState(5)
+    tp, cp = rs.permutation(len(targets)), rs.permutation(len(contigs))
+    tkey, ckey = (lambda i: 7 * i + 3), (lambda i: 2 * i + 10)
+    _write_seq_db(str(tmp_path / "targets"), [targets[i] for i in tp], [tkey(int(i)) for i in tp])
+    _write_seq_db(str(tmp_path / "contigs"), [contigs[i] for i in cp], [ckey(int(i)) for i in cp])
+    for base in ("targets", "contigs"):                            # a real .index is sorted by key
+        rows = sorted(open(tmp_path / (base + ".index")).read().splitlines(), key=lambda r: int(r.split("\t")[0]))
+        (tmp_path / (base + ".index")).write_text("\n".join(rows) + "\n")
+    (tmp_path / "contigs.dbtype").write_bytes((1).to_bytes(4, "little"))
+    cmd = [build.BIN, "predictexons", str(tmp_path / "contigs"), str(tmp_path / "targets"), str(tmp_path / "calls"), str(tmp_path / "tmp"),
+           "-s", "5.7", "--ref-l2-bytes", "2097152", "--metaeuk-eval", "0.001", "--metaeuk-tcov", "0.5", "--max-intron", "10000", "--min-intron", "15",
+           "--min-exon-aa", "11", "--max-overlap", "10", "--max-exon-sets", "1", "--set-gap-open", "-1", "--set-gap-extend", "-1", "--min-length", "15",
+           "--threads", "4", "--remove-tmp-files", "1"]
+    subprocess.check_call(cmd)
+    assert open(tmp_path / "calls.dbtype", "rb").read() == (12).to_bytes(4, "little")
+    got = _read_result_db(str(tmp_path / "calls"))
+    exp, cur = {}, None
+    for line in _text("e2e_exons_expected.txt.gz").splitlines(True):
+        if line.startswith(">"):
+            cur = ckey(int(line[1:]))
+            exp[cur] = ""
+        else:
+            t, rest = line.split("\t", 1)
+            exp[cur] += "%d\t%s" % (tkey(int(t)), rest)
+    assert sorted(got) == sorted(exp) and sum(1 for v in exp.values() if v) > 50
+    assert got == exp
+    # the finished output is the workflow's "done" marker: a second run refuses to overwrite it (predictexons.sh:32)
+    assert subprocess.call(cmd, stderr=subprocess.DEVNULL) != 0
+    # a flag value this build does not implement is an error, not a silent default
+    assert subprocess.call(cmd[:4] + [str(tmp_path / "calls2"), cmd[5], "--translation-table", "4"], stderr=subprocess.DEVNULL) != 0
+    assert not os.path.exists(tmp_path / "calls2.dbtype")
