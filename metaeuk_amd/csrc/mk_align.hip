@@ -28,6 +28,7 @@ namespace mk {
 namespace {
 
 constexpr uint32_t KEY_CLS = 4096;
+static_assert(SW_NCFG <= 16, "job sort keys keep 4 bits for the tile configuration");
 
 __device__ __forceinline__ uint32_t sort_key(uint32_t qLen, uint32_t tLen) {
     return (uint32_t) sw_cfg_of(qLen) * KEY_CLS + (KEY_CLS - 1 - min(tLen >> 4, KEY_CLS - 1));
@@ -63,12 +64,12 @@ __global__ __launch_bounds__(256) void wave_flag_kernel(const uint64_t *sortedKe
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int cfg = (int) (sortedKeys[i] >> 44);
-    const uint32_t dpw = cfg < 4 ? 8u : (cfg < 6 ? 2u : 1u);       // packed score kernel: 2 per 16-lane group; else 64 / G
+    const uint32_t dpw = sw_cfg_jobs_per_wave(cfg);                // packed score kernel: 2 per 16-lane group; else 64 / G
     flag[i] = ((i - head[i]) % dpw) == 0 ? 1 : 0;
 }
 // job and wave ranges of every configuration; closes the wave list with n
 __global__ void shared_bounds_kernel(const uint64_t *sortedKeys, uint32_t n, uint32_t *waveStart, const uint32_t *nWaves,
-                                     uint32_t *out /* [0..8] job bounds, [16..24] wave bounds, [32..39] first target-length class */) {
+                                     uint32_t *out /* [0..SW_NCFG] job bounds, [16..16+SW_NCFG] wave bounds, [32..] first target-length class */) {
     const uint32_t c = threadIdx.x;
     const uint32_t nw = nWaves[0];
     if (c == 0) waveStart[nw] = n;
@@ -192,11 +193,11 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
     if (n == 0) return MK_OK;
     hipcub::DoubleBuffer<uint32_t> kb(keys, keys2), vb(idx, idx2);
     size_t tempBytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, kb, vb, (int) n, 0, 15, stream);
+    hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, kb, vb, (int) n, 0, 16, stream);
     void *temp = dev_scratch("align_sort_temp", tempBytes);
     ANULL(temp);
     int th = tb("align_sort", 16.0 * n, 0);
-    ACHK(hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, kb, vb, (int) n, 0, 15, stream));
+    ACHK(hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, kb, vb, (int) n, 0, 16, stream));
     te(th);
     uint32_t *dBounds = (uint32_t *) dev_scratch("align_bounds", 64 * sizeof(uint32_t));
     ANULL(dBounds);
@@ -250,14 +251,14 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const SwJob *j
     ANULL(dHead); ANULL(dFlag); ANULL(dWave); ANULL(dNum); ANULL(dBounds); ANULL(hb); ANULL(dWork);
     ACHK(hipMemsetAsync(dWork, 0, 64, stream));
     // persistent forward launch: this many one-wave workgroups per CU and tile configuration (MK_SW_WAVES_PER_CU = one number
-    // or eight, comma separated).  Half the wave slots for the small tiles; fewer for the tiles whose profiles are large, so
+    // or one per tile configuration, comma separated).  Half the wave slots for the small tiles; fewer for the tiles whose profiles are large, so
     // that the LDS-hungry prefilter workgroups of the other stream still find room on the CU.
-    static uint32_t persistentBlocks[SW_NCFG] = {0, 0, 0, 0, 0, 0, 0, 0};
+    static uint32_t persistentBlocks[SW_NCFG] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (!persistentBlocks[0]) {
         int dev = 0, cus = 256;
         (void) hipGetDevice(&dev);
         (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        int perCu[SW_NCFG] = {16, 16, 12, 8, 8, 8, 8, 8};
+        int perCu[SW_NCFG] = {16, 16, 16, 12, 8, 6, 6, 8, 8};
         if (const char *e = getenv("MK_SW_WAVES_PER_CU")) {
             int k = 0, last = 16;
             for (const char *p = e; *p && k < SW_NCFG; k++) {
@@ -272,13 +273,13 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const SwJob *j
     }
     size_t t1 = 0, t2 = 0, t3 = 0;
     hipcub::CountingInputIterator<uint32_t> iota(0);
-    hipcub::DeviceRadixSort::SortPairs(nullptr, t1, kb, vb, (int) n, 0, 47, stream);
+    hipcub::DeviceRadixSort::SortPairs(nullptr, t1, kb, vb, (int) n, 0, 48, stream);
     hipcub::DeviceScan::InclusiveScan(nullptr, t2, dHead, dHead, hipcub::Max(), (int) n, stream);
     hipcub::DeviceSelect::Flagged(nullptr, t3, iota, dFlag, dWave, dNum, (int) n, stream);
     void *temp = dev_scratch("align_sort_temp", std::max(t1, std::max(t2, t3)));
     ANULL(temp);
     int th = tb("align_sort", 6.0 * 24.0 * n, 0);
-    ACHK(hipcub::DeviceRadixSort::SortPairs(temp, t1, kb, vb, (int) n, 0, 47, stream));
+    ACHK(hipcub::DeviceRadixSort::SortPairs(temp, t1, kb, vb, (int) n, 0, 48, stream));
     te(th);
     th = tb("align_waves", 30.0 * n, 0);
     hipLaunchKernelGGL(seg_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, kb.Current(), n, dHead);
@@ -312,7 +313,7 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const SwJob *j
         snprintf(nm, sizeof(nm), "sw_fwd_rows%d", sw_cfg_rows(c));
         th = tb(nm, 0, 0);
         handles[c] = th;
-        if (c < 4) ACHK(launch_sw_score(L, c, stream));       // score only, packed int16, two targets per lane group
+        if (sw_cfg_packed(c)) ACHK(launch_sw_score(L, c, stream));   // score only, packed int16, two targets per lane group
         else ACHK(launch_sw(L, c, stream));
         te(th);
     }

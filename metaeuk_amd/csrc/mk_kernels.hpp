@@ -41,18 +41,22 @@ struct SwLaunch {
 
 // tile configurations: G lanes per DP x R rows per lane; a job uses the smallest one whose G*R >= q_len
 // (the last one also handles longer queries in row tiles)
-constexpr int SW_NCFG = 8;
+constexpr int SW_NCFG = 9;
 __host__ __device__ inline int sw_cfg_rows(int c) {
-    const int rows[SW_NCFG] = {32, 64, 128, 256, 384, 512, 768, 1024};
+    const int rows[SW_NCFG] = {32, 48, 64, 128, 256, 384, 512, 768, 1024};
     return rows[c];
 }
+// forward pass of the pipeline: tiles of at most 512 rows run in packed int16, two targets per lane group (16 lanes up to 256
+// rows: 8 jobs per wave; 32 lanes: 4 jobs per wave); larger tiles in int32 on 64 lanes (1 job per wave)
+__host__ __device__ inline bool sw_cfg_packed(int c) { return sw_cfg_rows(c) <= 512; }
+__host__ __device__ inline uint32_t sw_cfg_jobs_per_wave(int c) { return sw_cfg_rows(c) <= 256 ? 8u : (sw_cfg_rows(c) <= 512 ? 4u : 1u); }
 __host__ __device__ inline int sw_cfg_of(uint32_t qLen) {
     int c = 0;
     while (c < SW_NCFG - 1 && (uint32_t) sw_cfg_rows(c) < qLen) c++;
     return c;
 }
 hipError_t launch_sw(const SwLaunch &L, int cfg, hipStream_t stream);
-// score-only forward pass in packed int16, two targets per lane group (configurations 0..3, shared-query mode only)
+// score-only forward pass in packed int16, two targets per lane group (sw_cfg_packed configurations, shared-query mode only)
 hipError_t launch_sw_score(const SwLaunch &L, int cfg, hipStream_t stream);
 
 struct UngappedJob { uint64_t t_start; uint32_t q_start; uint32_t q_len; uint32_t t_len; uint32_t diagonal; };

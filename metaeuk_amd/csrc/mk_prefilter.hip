@@ -99,10 +99,11 @@ struct ProbeArgs {
     PrefilterDeviceView V;
     uint64_t pos_begin, pos_end;      // residue range (of the view) handled by this launch
     uint32_t q_first;                 // first view query of the range
-    uint32_t seq_bits;                // key = (q - q_first) << seq_bits | target
+    uint32_t seq_bits;                // group = (q - q_first) << seq_bits | target
+    uint32_t hit_bits;                // record = group << (8 + hit_bits) | (diagonal & 255) << hit_bits | arrival number of the hit within its query
     uint32_t *hit_count;              // [pos] (COUNT: written; GATHER: exclusive prefix, read)
     uint32_t *kmer_count;             // [pos] statistics
-    uint64_t *keys; uint64_t *vals;   // GATHER outputs
+    uint64_t *keys; uint8_t *diag_hi; // GATHER outputs: one 8-byte record per index hit + the diagonal's high byte
 };
 
 // index offset pair of a k-mer (adjacent 32-bit entries; one 8-byte load)
@@ -166,8 +167,9 @@ __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
                         const uint32_t seq = (uint32_t) ent;
                         const uint32_t posj = (uint32_t) (ent >> 32) & 0xFFFFu;
                         const uint32_t diag = (iPos - posj) & 0xFFFFu;
-                        A.keys[dst + e] = ((uint64_t) qLocal << A.seq_bits) | seq;
-                        A.vals[dst + e] = ((uint64_t) (dst + e - qFirstHit) << 16) | diag;
+                        // low bits: the hit's arrival number within its query (the sort only looks at the group bits and is stable)
+                        A.keys[dst + e] = (((((uint64_t) qLocal << A.seq_bits) | seq) << 8 | (diag & 0xFFu)) << A.hit_bits) | (dst + e - qFirstHit);
+                        A.diag_hi[dst + e] = (uint8_t) (diag >> 8);
                     }
                     hits += enumk::wave_last(incl);
                 }
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
 // (QueryMatcher.cpp:43,281-316: a query gathering >= 2*max(1e6,dbSize) entries takes the overflow path)
 __global__ __launch_bounds__(256) void chunk_totals_kernel(const uint64_t *qOff, uint32_t qFirst, uint32_t nq, uint64_t posBegin, uint64_t nPos,
                                                           const uint32_t *scan, const uint32_t *lastCount, uint64_t maxDbMatches,
-                                                          unsigned long long *totals /* [0]=hits [1]=first overflowing query+1 */) {
+                                                          unsigned long long *totals /* [0]=hits [1]=first overflowing query+1 [3]=most hits of a query */) {
     const uint32_t ql = blockIdx.x * blockDim.x + threadIdx.x;
     if (ql == 0) totals[0] = (unsigned long long) scan[nPos - 1] + lastCount[0];
     if (ql >= nq) return;
@@ -192,28 +194,32 @@ __global__ __launch_bounds__(256) void chunk_totals_kernel(const uint64_t *qOff,
     if (e == b) return;
     const uint64_t endv = (e < nPos) ? scan[e] : (uint64_t) scan[nPos - 1] + lastCount[0];
     if (endv - scan[b] >= maxDbMatches) atomicMax(&totals[1], (unsigned long long) (qFirst + ql) + 1ull);
+    atomicMax(&totals[3], (unsigned long long) (endv - scan[b]));
 }
 
 // findDuplicates (computeTotalScore == false) on the (query,target)-sorted hit stream.
 //   kept(t)    : low 8 bits of the diagonal equal those of the previous hit of the same (query,target);
 //                the first hit of a target is compared with 0 (duplicateBitArray starts zeroed)
 //   emitted(t) : kept(t) and the nearest earlier kept hit of the run has a different low byte (or none exists)
-__global__ __launch_bounds__(256) void double_hit_flag_kernel(const uint64_t *keys, const uint64_t *vals, uint32_t n, uint8_t *flag) {
+__global__ __launch_bounds__(256) void double_hit_flag_kernel(const uint64_t *rec, uint32_t hitBits, uint32_t n, uint8_t *flag) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    const uint64_t key = keys[t];
-    const uint32_t lo = (uint32_t) vals[t] & 0xFFu;
-    const bool samePrev = t > 0 && keys[t - 1] == key;
-    const uint32_t prevLo = samePrev ? ((uint32_t) vals[t - 1] & 0xFFu) : 0u;
+    const uint64_t r = rec[t] >> hitBits;
+    const uint64_t group = r >> 8;
+    const uint32_t lo = (uint32_t) r & 0xFFu;
+    const uint64_t rp = t > 0 ? rec[t - 1] >> hitBits : 0;
+    const bool samePrev = t > 0 && (rp >> 8) == group;
+    const uint32_t prevLo = samePrev ? ((uint32_t) rp & 0xFFu) : 0u;
     uint8_t emit = 0;
     if (lo == prevLo) {
         emit = 1;
         if (samePrev) {
             uint32_t u = t - 1;
             while (true) {
-                const uint32_t ulo = (uint32_t) vals[u] & 0xFFu;
-                const bool uSame = u > 0 && keys[u - 1] == key;
-                const uint32_t uprev = uSame ? ((uint32_t) vals[u - 1] & 0xFFu) : 0u;
+                const uint32_t ulo = (uint32_t) (rec[u] >> hitBits) & 0xFFu;
+                const uint64_t rq = u > 0 ? rec[u - 1] >> hitBits : 0;
+                const bool uSame = u > 0 && (rq >> 8) == group;
+                const uint32_t uprev = uSame ? ((uint32_t) rq & 0xFFu) : 0u;
                 if (ulo == uprev) { emit = (ulo != lo) ? 1 : 0; break; }
                 if (!uSame) break;
                 u--;
@@ -225,17 +231,20 @@ __global__ __launch_bounds__(256) void double_hit_flag_kernel(const uint64_t *ke
 
 // selected sorted hits -> candidate arrays (appended at `base`); qMap translates the range-local query index
 // into the chunk-local one (null: qLocal + qAdd)
-__global__ __launch_bounds__(256) void cand_from_sorted_kernel(const uint64_t *keys, const uint64_t *vals, const uint32_t *sel, uint32_t n, uint32_t seqBits,
+__global__ __launch_bounds__(256) void cand_from_sorted_kernel(const uint64_t *rec, const uint8_t *diagHi, const uint32_t *sel, uint32_t n, uint32_t seqBits,
+                                                               uint32_t hitBits, const uint64_t *qOff, uint32_t qFirst, uint64_t posBegin, const uint32_t *hitScan,
                                                                const uint32_t *qMap, uint32_t qAdd, CandArrays C, uint32_t base) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
-    const uint32_t t = sel[c];
-    const uint64_t key = keys[t], val = vals[t];
-    const uint32_t ql = (uint32_t) (key >> seqBits);
+    const uint64_t r = rec[sel[c]];
+    const uint32_t ord = (uint32_t) (r & ((1ull << hitBits) - 1));
+    const uint64_t group = r >> (hitBits + 8);
+    const uint32_t ql = (uint32_t) (group >> seqBits);
     C.q[base + c] = qMap ? qMap[ql] : ql + qAdd;
-    C.id[base + c] = (uint32_t) (key & ((1ull << seqBits) - 1));
-    C.ordinal[base + c] = (uint32_t) (val >> 16);
-    C.diag[base + c] = (uint16_t) (val & 0xFFFFu);
+    C.id[base + c] = (uint32_t) (group & ((1ull << seqBits) - 1));
+    C.ordinal[base + c] = ord;
+    const uint32_t hit = hitScan[qOff[qFirst + ql] - posBegin] + ord;          // where the gather pass put this hit
+    C.diag[base + c] = (uint16_t) (((uint32_t) diagHi[hit] << 8) | ((uint32_t) (r >> hitBits) & 0xFFu));
 }
 
 // compact copy of selected queries (the ones the fused kernel could not take) into a small batch for the global path
@@ -697,6 +706,7 @@ constexpr int RC_CAND_OVERFLOW = 1000;            // internal: the chunk produce
 struct Ctx {
     hipStream_t stream; std::string *err; timed_begin_fn tb; timed_end_fn te; timed_set_fn ts;
     uint32_t seqBits; uint64_t maxDbMatches;
+    int lastHitBits = 16;
     CandArrays C; uint32_t candCap;
     unsigned long long *dTotals, *hTotals;
 };
@@ -707,7 +717,7 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &V, const uint64_t *hOff
                       const uint32_t *qMap, uint32_t qAddBase, uint32_t &nCand, double &hitsPerPos) {
     std::string &err = *X.err;
     hipStream_t stream = X.stream;
-    const size_t HIT_CAP = 768u << 20;                // index hits per piece kept in HBM: 32 B each (key+value, double buffered)
+    const size_t HIT_CAP = 768u << 20;                // index hits per piece kept in HBM: 17 B each (record double buffered + high diagonal byte)
     const uint64_t POS_CAP = 24u << 20;               // residues per piece
     const uint32_t QCAP = 1u << 20;
     uint32_t q0 = a;
@@ -716,10 +726,18 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &V, const uint64_t *hOff
         {
             uint64_t posBudget = hitsPerPos > 0 ? std::min<uint64_t>(POS_CAP, (uint64_t) (0.8 * (double) HIT_CAP / hitsPerPos))
                                                 : std::min<uint64_t>(POS_CAP, 1u << 20);   // first piece: small probe
-            while (q1 < b && q1 - q0 < QCAP && (hOff[q1 + 1] - hOff[q0] <= posBudget || q1 == q0)) q1++;
+            // queries per piece: what the 64-bit hit record leaves after target, diagonal byte and arrival number (as wide as the last
+            // piece needed, plus one bit of slack)
+            const int qBitsLeft = 64 - 8 - (int) X.seqBits - std::min(X.lastHitBits + 1, 31);
+            // ... and what keeps the sorted (query, target) bits at a whole number of 8-bit radix passes, pieces of >= 8192 queries
+            const int qBitsPass = (((int) X.seqBits + 13 + 7) / 8) * 8 - (int) X.seqBits;
+            const int qBitsCap = std::min(qBitsLeft, qBitsPass);
+            const uint32_t qCap = qBitsCap >= 20 ? QCAP : (qBitsCap < 1 ? 1u : (1u << qBitsCap));
+            while (q1 < b && q1 - q0 < qCap && (hOff[q1 + 1] - hOff[q0] <= posBudget || q1 == q0)) q1++;
         }
         uint64_t totalHits = 0, nPos = 0;
         uint32_t *dHit = nullptr, *dKmer = nullptr;
+        int qBits = 1, hitBits = 1;
         for (;;) {
             nPos = hOff[q1] - hOff[q0];
             if (nPos == 0) break;
@@ -728,8 +746,8 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &V, const uint64_t *hOff
             uint32_t *dLast = (uint32_t *) dev_scratch("pf_last", 16);
             PNULL(dHit); PNULL(dKmer); PNULL(dLast);
             ProbeArgs A;
-            A.V = V; A.pos_begin = hOff[q0]; A.pos_end = hOff[q1]; A.q_first = q0; A.seq_bits = X.seqBits;
-            A.hit_count = dHit; A.kmer_count = dKmer; A.keys = nullptr; A.vals = nullptr;
+            A.V = V; A.pos_begin = hOff[q0]; A.pos_end = hOff[q1]; A.q_first = q0; A.seq_bits = X.seqBits; A.hit_bits = 0;
+            A.hit_count = dHit; A.kmer_count = dKmer; A.keys = nullptr; A.diag_hi = nullptr;
             const unsigned blocks = (unsigned) ((nPos + 3) / 4);
             const int thCount = X.tb("kmer_probe_count", 0, 0);
             hipLaunchKernelGGL(probe_kernel<false>, dim3(blocks), dim3(256), 0, stream, A);
@@ -749,52 +767,60 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &V, const uint64_t *hOff
             PCHK(hipcub::DeviceScan::ExclusiveSum(temp, tb2, dHit, dHit, (int) nPos, stream));
             X.te(th);
             PCHK(hipMemsetAsync(X.dTotals, 0, 16, stream));
+            PCHK(hipMemsetAsync(X.dTotals + 3, 0, 8, stream));
             hipLaunchKernelGGL(chunk_totals_kernel, dim3((q1 - q0 + 255) / 256), dim3(256), 0, stream, V.q_off, q0, q1 - q0, hOff[q0], nPos,
                                dHit, dLast, X.maxDbMatches, X.dTotals);
             PCHK(hipGetLastError());
-            PCHK(hipMemcpyAsync(X.hTotals, X.dTotals, 24, hipMemcpyDeviceToHost, stream));
+            PCHK(hipMemcpyAsync(X.hTotals, X.dTotals, 32, hipMemcpyDeviceToHost, stream));
             PCHK(sync_wait(stream, "wait_prefilter"));
             totalHits = X.hTotals[0];
             if (X.hTotals[1] != 0) { err = "a query overflows the reference's databaseHits buffer (QueryMatcher.cpp:281-316 is not restated)"; return MK_ERR_UNSUPPORTED; }
             X.ts(thCount, 4.0 * (double) X.hTotals[2] + 8.0 * (double) totalHits + 1280.0 * (double) nPos, (double) X.hTotals[2]);   // bitmap word per k-mer, offset pair per non-empty k-mer, row heads per start
             hitsPerPos = std::max(1.0, (double) totalHits / (double) nPos);
             if (totalHits > HIT_CAP && q1 - q0 > 1) { q1 = q0 + (q1 - q0) / 2; continue; }
+            // one 64-bit record per hit: query | target | low diagonal byte | arrival number within the query must fit
+            qBits = 1; while ((1u << qBits) < q1 - q0) qBits++;
+            hitBits = 1; while ((1ull << hitBits) < X.hTotals[3]) hitBits++;
+            X.lastHitBits = hitBits;
+            if (8 + hitBits + (int) X.seqBits + qBits > 64) {
+                if (q1 - q0 > 1) { q1 = q0 + (q1 - q0) / 2; continue; }
+                err = "a single query produces more index hits than the 64-bit hit record can number"; return MK_ERR_UNSUPPORTED;
+            }
             break;
         }
         if (nPos > 0 && totalHits > 0) {
             if (totalHits >= 0x7FFFFFFFull) { err = "a single query produces >= 2^31 index hits"; return MK_ERR_UNSUPPORTED; }
             const uint32_t nHits = (uint32_t) totalHits;
             uint64_t *dKeys = (uint64_t *) dev_scratch("pf_keys", (size_t) nHits * 8), *dKeys2 = (uint64_t *) dev_scratch("pf_keys2", (size_t) nHits * 8);
-            uint64_t *dVals = (uint64_t *) dev_scratch("pf_vals", (size_t) nHits * 8), *dVals2 = (uint64_t *) dev_scratch("pf_vals2", (size_t) nHits * 8);
-            PNULL(dKeys); PNULL(dKeys2); PNULL(dVals); PNULL(dVals2);
+            uint8_t *dDiagHi = (uint8_t *) dev_scratch("pf_diaghi", (size_t) nHits);
+            PNULL(dKeys); PNULL(dKeys2); PNULL(dDiagHi);
             ProbeArgs A;
-            A.V = V; A.pos_begin = hOff[q0]; A.pos_end = hOff[q1]; A.q_first = q0; A.seq_bits = X.seqBits;
-            A.hit_count = dHit; A.kmer_count = dKmer; A.keys = dKeys; A.vals = dVals;
+            A.V = V; A.pos_begin = hOff[q0]; A.pos_end = hOff[q1]; A.q_first = q0; A.seq_bits = X.seqBits; A.hit_bits = (uint32_t) hitBits;
+            A.hit_count = dHit; A.kmer_count = dKmer; A.keys = dKeys; A.diag_hi = dDiagHi;
             const unsigned blocks = (unsigned) ((nPos + 3) / 4);
-            // gather pass: offset pairs again + 8 B per index entry read + 16 B (key,value) written per entry
-            int th = X.tb("kmer_probe_gather", 4.0 * (double) X.hTotals[2] + 32.0 * (double) totalHits + 1280.0 * (double) nPos, (double) X.hTotals[2]);
+            // gather pass: offset pairs again + 8 B per index entry read + 9 B (record, high diagonal byte) written per entry
+            int th = X.tb("kmer_probe_gather", 4.0 * (double) X.hTotals[2] + 25.0 * (double) totalHits + 1280.0 * (double) nPos, (double) X.hTotals[2]);
             hipLaunchKernelGGL(probe_kernel<true>, dim3(blocks), dim3(256), 0, stream, A);
             X.te(th);
             PCHK(hipGetLastError());
-            // stable sort by (query, target)
-            const uint32_t nqc = q1 - q0;
-            int qBits = 1; while ((1u << qBits) < nqc) qBits++;
-            hipcub::DoubleBuffer<uint64_t> kb(dKeys, dKeys2), vb(dVals, dVals2);
+            // sort by (query, target): only those bits are sorted, the records of a pair stay in arrival order
+            const int bit0 = 8 + hitBits, bit1 = 8 + hitBits + (int) X.seqBits + qBits;
+            hipcub::DoubleBuffer<uint64_t> kb(dKeys, dKeys2);
             size_t tempBytes = 0;
-            hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, kb, vb, (int) nHits, 0, (int) X.seqBits + qBits, stream);
+            hipcub::DeviceRadixSort::SortKeys(nullptr, tempBytes, kb, (int) nHits, bit0, bit1, stream);
             void *temp = dev_scratch("pf_temp", tempBytes);
             PNULL(temp);
-            const int passes = ((int) X.seqBits + qBits + 7) / 8;
-            th = X.tb("sort_hits", 32.0 * passes * (double) nHits, 0);
-            PCHK(hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, kb, vb, (int) nHits, 0, (int) X.seqBits + qBits, stream));
+            const int passes = (bit1 - bit0 + 7) / 8;
+            th = X.tb("sort_hits", 16.0 * passes * (double) nHits, 0);
+            PCHK(hipcub::DeviceRadixSort::SortKeys(temp, tempBytes, kb, (int) nHits, bit0, bit1, stream));
             X.te(th);
             // double-hit rule -> flags -> ordered compaction
             uint8_t *dFlag = (uint8_t *) dev_scratch("pf_flag", nHits);
             uint32_t *dSel = (uint32_t *) dev_scratch("pf_sel", (size_t) nHits * 4);
             uint32_t *dNum = (uint32_t *) dev_scratch("pf_num", 64);
             PNULL(dFlag); PNULL(dSel); PNULL(dNum);
-            th = X.tb("double_hit", 17.0 * nHits, 0);
-            hipLaunchKernelGGL(double_hit_flag_kernel, dim3((nHits + 255) / 256), dim3(256), 0, stream, kb.Current(), vb.Current(), nHits, dFlag);
+            th = X.tb("double_hit", 9.0 * nHits, 0);
+            hipLaunchKernelGGL(double_hit_flag_kernel, dim3((nHits + 255) / 256), dim3(256), 0, stream, kb.Current(), (uint32_t) hitBits, nHits, dFlag);
             X.te(th);
             PCHK(hipGetLastError());
             {
@@ -814,8 +840,8 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &V, const uint64_t *hOff
             const uint32_t nSel = hNum[0];
             if ((uint64_t) nCand + nSel > X.candCap) return RC_CAND_OVERFLOW;
             if (nSel > 0) {
-                hipLaunchKernelGGL(cand_from_sorted_kernel, dim3((nSel + 255) / 256), dim3(256), 0, stream, kb.Current(), vb.Current(), dSel, nSel, X.seqBits,
-                                   qMap ? qMap + q0 : nullptr, qAddBase + q0, X.C, nCand);
+                hipLaunchKernelGGL(cand_from_sorted_kernel, dim3((nSel + 255) / 256), dim3(256), 0, stream, kb.Current(), dDiagHi, dSel, nSel, X.seqBits,
+                                   (uint32_t) hitBits, V.q_off, q0, hOff[q0], dHit, qMap ? qMap + q0 : nullptr, qAddBase + q0, X.C, nCand);
                 PCHK(hipGetLastError());
                 nCand += nSel;
             }

@@ -217,16 +217,22 @@ __global__ __launch_bounds__(BLOCK) void sw_kernel(SwLaunch L) {
 // all DP state packs perfectly -- the serial F dependence runs down the rows inside each half.  ~5.5 vector ops per cell
 // instead of 10.  It yields the maximum score only: the e-value gate needs nothing else, and the ~9 % of the pairs that
 // pass are re-run by sw_kernel for their end positions.  For tiles of at most 256 rows the int16 arithmetic cannot
-// saturate (256 rows x 127), so it is the reference's arithmetic exactly.
+// saturate (256 rows x 127); beyond, diag + score saturates at 32767 exactly like the reference's word pass.
 typedef short pk16 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ pk16 pk_from(uint32_t v) { return __builtin_bit_cast(pk16, v); }
 __device__ __forceinline__ uint32_t pk_bits(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ pk16 pk_max(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ pk16 pk_splat(int v) { pk16 r; r.x = (short) v; r.y = (short) v; return r; }
 
-template <int R>
+// R rows per lane; the LDS profile keeps RP >= R (even) int16 slots per lane so that a lane's scores are whole dwords.
+// G = 16 lanes per pair of DPs for tiles of at most 256 rows; G = 32 for 384 / 512 rows, where diag + score can pass 32767
+// and the add saturates like the reference's word pass (simdi16_adds, StripedSmithWaterman.cpp:1059).
+template <int R, int RP = R, int G = 16>
 __global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
-    constexpr int G = 16, GPB = 64 / G, ROWS = G * R;
+    constexpr int GPB = 64 / G, ROWS = G * RP;
+    constexpr bool SAT = G * R * 127 > 32767;
+    static_assert(RP >= R && RP % 2 == 0, "profile slots per lane: even and at least R");
+    static_assert(G == 16 || G == 32, "a pair of DPs runs on one or two DPP rows");
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     int16_t *prof = reinterpret_cast<int16_t *>(smem);            // prof[t][row], int16; row 21 = zeros
     const int lane = threadIdx.x % G, grp = threadIdx.x / G;
@@ -244,9 +250,10 @@ __global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
         const int qLen = (int) jobA.q_len;                          // every job of the wave has this query
         const int tLenA = haveA ? (int) jobA.t_len : 0, tLenB = haveB ? (int) jobB.t_len : 0;
         for (int idx = (int) threadIdx.x; idx < 22 * ROWS; idx += 64) {
-            const int t = idx / ROWS, row = idx - t * ROWS;
+            const int t = idx / ROWS, slot = idx - t * ROWS;
+            const int row = RP == R ? slot : (slot / RP) * R + slot % RP;    // lane-major: lane * R + r
             int v = 0;
-            if (t < 21 && row < qLen) {
+            if (t < 21 && row < qLen && (RP == R || slot % RP < R)) {
                 const int64_t qi = (int64_t) jobA.q_start + (int64_t) row * jobA.q_step;
                 v = (int) L.mat[t * 21 + L.q_res[qi]] + (int) L.q_bias8[qi];
             }
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
         uint32_t outH = 0, outF = 0, outRes = 21u | (21u << 8);    // handed to lane+1: H of the last row, F, the two residues
         const int tMax = max(tLenA, tLenB);
         const int steps = tMax > 0 ? tMax + G - 1 : 0;
-        const int laneRow = lane;                                  // G == one DPP row
+        const int laneRow = lane & 15;                             // position in the DPP row (both rows of a 32-lane group fetch the same residues)
         const int lastA = max(tLenA - 1, 0), lastB = max(tLenB - 1, 0);
         const int64_t baseA = (int64_t) jobA.t_start, baseB = (int64_t) jobB.t_start, stepA = jobA.t_step, stepB = jobB.t_step;
         uint32_t tnext = (uint32_t) L.t_res[baseA + (int64_t) min(laneRow, lastA) * stepA] | ((uint32_t) L.t_res[baseB + (int64_t) min(laneRow, lastB) * stepB] << 8);
@@ -277,16 +284,16 @@ __global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
                 const pk16 hup = pk_from(shift_up<G>(0u, outH, lane));
                 pk16 F = pk_from(shift_up<G>(0u, outF, lane));
                 const uint32_t tres = shift_up<G>(top, outRes, lane);
-                const int16_t *pa = prof + (tres & 0xFFu) * ROWS + lane * R, *pb = prof + (tres >> 8) * ROWS + lane * R;
-                uint32_t wa[R / 2], wb[R / 2];                     // R int16 scores per target, two per dword
+                const int16_t *pa = prof + (tres & 0xFFu) * ROWS + lane * RP, *pb = prof + (tres >> 8) * ROWS + lane * RP;
+                uint32_t wa[RP / 2], wb[RP / 2];                   // R int16 scores per target, two per dword
 #pragma unroll
-                for (int k = 0; k < R / 2; k++) { wa[k] = reinterpret_cast<const uint32_t *>(pa)[k]; wb[k] = reinterpret_cast<const uint32_t *>(pb)[k]; }
+                for (int k = 0; k < RP / 2; k++) { wa[k] = reinterpret_cast<const uint32_t *>(pa)[k]; wb[k] = reinterpret_cast<const uint32_t *>(pb)[k]; }
                 pk16 dsave = hupPrev;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     // (score of target A, score of target B) for row r: one byte permute
                     const pk16 sc = pk_from(__builtin_amdgcn_perm(wb[r / 2], wa[r / 2], (r & 1) ? 0x07060302u : 0x05040100u));
-                    const pk16 d = dsave + sc;
+                    const pk16 d = SAT ? __builtin_elementwise_add_sat(dsave, sc) : dsave + sc;
                     dsave = H[r];
                     const pk16 h = pk_max(pk_max(pk_max(d, E[r]), F), zero2);
                     best = pk_max(best, h);
@@ -316,19 +323,23 @@ __global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
     }
 }
 
-// score-only forward launch for the configurations with at most 256 rows (cfg 0..3); wave_start must cut the job list
-// into waves of at most 2 * 64/16 = 8 jobs of one query
+// score-only forward launch for the sw_cfg_packed configurations; wave_start must cut the job list into waves of at most
+// sw_cfg_jobs_per_wave = 2 * 64/G jobs of one query
 hipError_t launch_sw_score(const SwLaunch &L, int cfg, hipStream_t stream) {
-    if (!L.wave_start || !L.work_counter || !L.order || cfg < 0 || cfg > 3) return hipErrorInvalidValue;
+    if (!L.wave_start || !L.work_counter || !L.order || cfg < 0 || cfg >= SW_NCFG || !sw_cfg_packed(cfg)) return hipErrorInvalidValue;
     if (L.n_waves == 0) return hipSuccess;
     const uint64_t grid = std::min<uint64_t>(L.n_waves, L.persistent_blocks ? L.persistent_blocks : L.n_waves);
     const int rows = sw_cfg_rows(cfg);
-    const size_t lds = (size_t) 22 * rows * sizeof(int16_t);
-    switch (cfg) {
-        case 0: hipLaunchKernelGGL((swp_kernel<2>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
-        case 1: hipLaunchKernelGGL((swp_kernel<4>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
-        case 2: hipLaunchKernelGGL((swp_kernel<8>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
-        default: hipLaunchKernelGGL((swp_kernel<16>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
+    const size_t lds = (size_t) 22 * (rows == 48 ? 64 : rows) * sizeof(int16_t);
+    switch (rows) {
+        case 32: hipLaunchKernelGGL((swp_kernel<2>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
+        case 48: hipLaunchKernelGGL((swp_kernel<3, 4>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
+        case 64: hipLaunchKernelGGL((swp_kernel<4>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
+        case 128: hipLaunchKernelGGL((swp_kernel<8>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
+        case 256: hipLaunchKernelGGL((swp_kernel<16>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
+        case 384: hipLaunchKernelGGL((swp_kernel<12, 12, 32>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
+        case 512: hipLaunchKernelGGL((swp_kernel<16, 16, 32>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
+        default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
@@ -357,15 +368,17 @@ static hipError_t launch_one(const SwLaunch &L, hipStream_t stream) {
 }
 
 hipError_t launch_sw(const SwLaunch &L, int cfg, hipStream_t stream) {
-    switch (cfg) {
-        case 0: return launch_one<16, 2, 256>(L, stream);
-        case 1: return launch_one<16, 4, 256>(L, stream);
-        case 2: return launch_one<16, 8, 256>(L, stream);
-        case 3: return launch_one<16, 16, 128>(L, stream);
-        case 4: return launch_one<32, 12, 128>(L, stream);
-        case 5: return launch_one<32, 16, 128>(L, stream);
-        case 6: return launch_one<64, 12, 128>(L, stream);
-        case 7: return launch_one<64, 16, 128>(L, stream);
+    if (cfg < 0 || cfg >= SW_NCFG) return hipErrorInvalidValue;
+    switch (sw_cfg_rows(cfg)) {
+        case 32: return launch_one<16, 2, 256>(L, stream);
+        case 48:                                              // the int32 kernel has no 3-row lanes: a 64-row tile, padded
+        case 64: return launch_one<16, 4, 256>(L, stream);
+        case 128: return launch_one<16, 8, 256>(L, stream);
+        case 256: return launch_one<16, 16, 128>(L, stream);
+        case 384: return launch_one<32, 12, 128>(L, stream);
+        case 512: return launch_one<32, 16, 128>(L, stream);
+        case 768: return launch_one<64, 12, 128>(L, stream);
+        case 1024: return launch_one<64, 16, 128>(L, stream);
         default: return hipErrorInvalidValue;
     }
 }
