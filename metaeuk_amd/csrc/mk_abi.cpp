@@ -154,7 +154,7 @@ struct mk_targetdb {
     uint32_t maxLen = 0;
     DevBuf<uint8_t> dRes, dMasked;
     DevBuf<uint64_t> dOff;
-    DevBuf<uint32_t> dKmerOff;       // 20^6 + 1 (entries < 2^32)
+    DevBuf<uint64_t> dKmerSlot;      // 20^6: inline single entry, or first entry index | list length << 32 (entries < 2^32)
     DevBuf<uint32_t> dKmerBits;      // 20^6 bits: list non-empty
     DevBuf<uint64_t> dEntries;       // seqId | pos << 32
     DevBuf<int16_t> dScore3;
@@ -312,8 +312,20 @@ int mk_targetdb_create(const uint8_t *residues, const uint64_t *offsets, uint32_
     if (ix.entries.size() >= 0xFFFFFFFFull) { delete db; return fail(MK_ERR_UNSUPPORTED, "index has >= 2^32 entries"); }
     db->nEntries = ix.entries.size();
     db->maskedHost = ix.masked;
-    std::vector<uint32_t> off32(ix.offsets.size());
-    for (size_t k = 0; k < ix.offsets.size(); k++) off32[k] = (uint32_t) ix.offsets[k];
+    const size_t nKmers = ix.offsets.size() - 1;
+    std::vector<uint64_t> slots(nKmers);
+    std::vector<uint32_t> bits((nKmers + 31) / 32, 0u);
+#pragma omp parallel for schedule(static)
+    for (size_t wd = 0; wd < bits.size(); wd++) {
+        uint32_t m = 0;
+        const size_t k0 = wd * 32, k1 = std::min(k0 + 32, nKmers);
+        for (size_t k = k0; k < k1; k++) {
+            const uint64_t first = ix.offsets[k], len = ix.offsets[k + 1] - first;
+            if (len) m |= 1u << (k - k0);
+            slots[k] = len == 1 ? ((1ull << 63) | ix.entries[first]) : (first | (len << 32));
+        }
+        bits[wd] = m;
+    }
     mk::ScoreMat3 sm;
     mk::build_scoremat3(db->kmerMat, sm);
     int8_t matAln[441], matUng[441];
@@ -324,15 +336,7 @@ int mk_targetdb_create(const uint8_t *residues, const uint64_t *offsets, uint32_
     ok(db->dRes.upload(residues, offsets[n]));
     ok(db->dMasked.upload(ix.masked.data(), ix.masked.size()));
     ok(db->dOff.upload(offsets, n + 1));
-    ok(db->dKmerOff.upload(off32.data(), off32.size()));
-    std::vector<uint32_t> bits((off32.size() - 1 + 31) / 32, 0u);
-#pragma omp parallel for schedule(static)
-    for (size_t wd = 0; wd < bits.size(); wd++) {
-        uint32_t m = 0;
-        const size_t k0 = wd * 32, k1 = std::min(k0 + 32, off32.size() - 1);
-        for (size_t k = k0; k < k1; k++) if (off32[k + 1] != off32[k]) m |= 1u << (k - k0);
-        bits[wd] = m;
-    }
+    ok(db->dKmerSlot.upload(slots.data(), slots.size()));
     ok(db->dKmerBits.upload(bits.data(), bits.size()));
     ok(db->dEntries.upload(ix.entries.data(), ix.entries.size()));
     ok(db->dScore3.upload(sm.score.data(), sm.score.size()));
@@ -605,7 +609,7 @@ static mk::PrefilterDeviceView prefilter_view(const mk_targetdb *db, const mk_qu
     mk::PrefilterDeviceView V;
     V.q_res = q->dRes.p; V.q_off = q->dOff.p; V.q_kmer_thr = q->dKmerThr.p; V.q_corr = q->dCorr.p; V.n_queries = q->n;
     V.t_masked = db->dMasked.p; V.t_off = db->dOff.p; V.n_targets = db->n;
-    V.kmer_off = db->dKmerOff.p; V.kmer_bits = db->dKmerBits.p; V.entries = db->dEntries.p; V.score3 = db->dScore3.p; V.index3 = db->dIndex3.p;
+    V.kmer_slot = db->dKmerSlot.p; V.kmer_bits = db->dKmerBits.p; V.entries = db->dEntries.p; V.score3 = db->dScore3.p; V.index3 = db->dIndex3.p;
     V.hist3 = db->dHist3.p; V.cum3 = db->dCum3.p; V.hist_lo = db->histLo; V.hist_range = db->histRange; V.n_entries = db->nEntries;
     V.mat_ung = db->dMatUng.p;
     return V;

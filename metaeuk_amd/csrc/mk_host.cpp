@@ -95,6 +95,16 @@ int bin_count_for(uint64_t dbSize, uint64_t l2) {
     return 2048;
 }
 
+// Where a k-mer lives in the device tables (presence bitmap, list slots, entry lists).  The reference's Indexer numbers a k-mer
+// sum(aa_i * 20^i); here the letters are first renumbered so that amino acids that substitute for each other are neighbours
+// (C | V I L M | F Y W | H | R K | Q E D N | S T A G P).  The similar k-mers of a query k-mer differ from it by exactly such
+// substitutions, so their table cells share 64-byte sectors instead of being spread over the table.  Only addresses change: rows
+// of the 3-mer score table are still looked up and ordered by the reference's numbering, so the enumeration order (and with it
+// the order in which hits arrive) is the reference's.
+static const uint8_t KMER_ADDR_LETTER[20] = {
+    /* A */ 17, /* C */ 0, /* D */ 13, /* E */ 12, /* F */ 5, /* G */ 18, /* H */ 8, /* I */ 2, /* K */ 10, /* L */ 3,
+    /* M */ 4, /* N */ 14, /* P */ 19, /* Q */ 11, /* R */ 9, /* S */ 15, /* T */ 16, /* V */ 1, /* W */ 7, /* Y */ 6};
+
 // ExtendedSubstitutionMatrix::calcScoreMatrix (M/src/prefiltering/ExtendedSubstitutionMatrix.cpp:20-69),
 // kmerSize 3 over the 20-letter alphabet (Prefiltering.cpp:208-213).  std::stable_sort by descending
 // score over candidates enumerated in cartesian order with the FIRST letter slowest.
@@ -102,12 +112,14 @@ void build_scoremat3(const SubMat &km, ScoreMat3 &out) {
     const int N = 8000;
     out.score.assign(static_cast<size_t>(N) * N, 0);
     out.index.assign(static_cast<size_t>(N) * N, 0);
-    std::vector<uint16_t> enumIdx(N);      // enumeration order -> Indexer index (a0 + 20 a1 + 400 a2)
+    std::vector<uint16_t> enumIdx(N);      // enumeration order -> Indexer index (a0 + 20 a1 + 400 a2): the row of a query 3-mer
+    std::vector<uint16_t> addrIdx(N);      // enumeration order -> table address digits of the candidate 3-mer
     std::vector<uint8_t> letter(N * 3);
     for (int e = 0; e < N; e++) {
         const int a0 = e / 400, a1 = (e / 20) % 20, a2 = e % 20;
         letter[e * 3] = a0; letter[e * 3 + 1] = a1; letter[e * 3 + 2] = a2;
         enumIdx[e] = static_cast<uint16_t>(a0 + 20 * a1 + 400 * a2);
+        addrIdx[e] = static_cast<uint16_t>(KMER_ADDR_LETTER[a0] + 20 * KMER_ADDR_LETTER[a1] + 400 * KMER_ADDR_LETTER[a2]);
     }
 #pragma omp parallel
     {
@@ -131,7 +143,7 @@ void build_scoremat3(const SubMat &km, ScoreMat3 &out) {
             for (int f = 0; f < N; f++) {
                 const int p = start[hi - sc[f]]++;
                 out.score[base + p] = sc[f];
-                out.index[base + p] = enumIdx[f];
+                out.index[base + p] = addrIdx[f];
             }
         }
     }
@@ -271,7 +283,7 @@ void build_index(const SubMat &km, const uint8_t *residues, const uint64_t *seqO
                     const uint8_t c = seq[i + SPACED6[p]];
                     hasX |= (c == XCODE);
                     score += self[c];
-                    idx += c * pw;
+                    idx += (c < 20 ? KMER_ADDR_LETTER[c] : 0) * pw;     // table address (k-mers with X are skipped below)
                     pw *= 20;
                 }
                 if (hasX || (kmerThr > 0 && score < kmerThr)) continue;

@@ -106,9 +106,17 @@ struct ProbeArgs {
     uint64_t *keys; uint8_t *diag_hi; // GATHER outputs: one 8-byte record per index hit + the diagonal's high byte
 };
 
-// index offset pair of a k-mer (adjacent 32-bit entries; one 8-byte load)
-struct __attribute__((packed, aligned(4))) OffPair { uint32_t lo, hi; };
-__device__ __forceinline__ OffPair load_off_pair(const uint32_t *kmerOff, uint32_t kmer) { return *reinterpret_cast<const OffPair *>(kmerOff + kmer); }
+// index list of a k-mer from its slot: length, first entry index, and the first entry itself when the slot holds it
+struct KmerList { uint32_t size, first; uint64_t ent0; bool isInline; };
+__device__ __forceinline__ KmerList load_kmer_list(const uint64_t *slots, uint32_t kmer) {
+    const uint64_t s = slots[kmer];
+    KmerList l;
+    l.isInline = (s >> 63) != 0;
+    l.size = l.isInline ? 1u : (uint32_t) (s >> 32);
+    l.first = (uint32_t) s;
+    l.ent0 = s & 0x0000FFFFFFFFFFFFull;
+    return l;
+}
 __device__ __forceinline__ bool kmer_present(const uint32_t *bits, uint32_t kmer) { return (bits[kmer >> 5] >> (kmer & 31u)) & 1u; }
 
 #ifndef MK_PROBE_U
@@ -146,30 +154,38 @@ __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
     const uint32_t kmers = enumk::enumerate_position<PROBE_U>(A.V, A.V.q_res + p, thr, lane, sE[w],
         [&](const uint32_t (&kmer)[PROBE_U], const bool (&has)[PROBE_U]) -> bool {
             uint32_t size[PROBE_U], o0[PROBE_U];
+            uint64_t ent0[PROBE_U];
+            bool inl[PROBE_U];
 #pragma unroll
             for (int u = 0; u < PROBE_U; u++) {
-                size[u] = 0; o0[u] = 0;
-                if (has[u] && kmer_present(A.V.kmer_bits, kmer[u])) { const OffPair o = load_off_pair(A.V.kmer_off, kmer[u]); o0[u] = o.lo; size[u] = o.hi - o.lo; }
+                size[u] = 0; o0[u] = 0; ent0[u] = 0; inl[u] = true;
+                if (has[u] && kmer_present(A.V.kmer_bits, kmer[u])) { const KmerList l = load_kmer_list(A.V.kmer_slot, kmer[u]); o0[u] = l.first; size[u] = l.size; ent0[u] = l.ent0; inl[u] = l.isInline; }
             }
             if (!GATHER) {
 #pragma unroll
                 for (int u = 0; u < PROBE_U; u++) hits += size[u];
             } else {
-                uint64_t ent0[PROBE_U];
 #pragma unroll
-                for (int u = 0; u < PROBE_U; u++) ent0[u] = size[u] ? A.V.entries[o0[u]] : 0ull;
+                for (int u = 0; u < PROBE_U; u++) if (!inl[u]) ent0[u] = A.V.entries[o0[u]];
+                const auto put = [&](uint64_t ent, uint64_t at) {
+                    const uint32_t seq = (uint32_t) ent;
+                    const uint32_t posj = (uint32_t) (ent >> 32) & 0xFFFFu;
+                    const uint32_t diag = (iPos - posj) & 0xFFFFu;
+                    // low bits: the hit's arrival number within its query (the sort only looks at the group bits and is stable)
+                    A.keys[at] = (((((uint64_t) qLocal << A.seq_bits) | seq) << 8 | (diag & 0xFFu)) << A.hit_bits) | (at - qFirstHit);
+                    A.diag_hi[at] = (uint8_t) (diag >> 8);
+                };
 #pragma unroll
                 for (int u = 0; u < PROBE_U; u++) {
                     const uint32_t incl = enumk::wave_incl_scan(size[u]);
                     const uint64_t dst = (uint64_t) hitBase + hits + (incl - size[u]);
-                    for (uint32_t e = 0; e < size[u]; e++) {
-                        const uint64_t ent = e == 0 ? ent0[u] : A.V.entries[o0[u] + e];
-                        const uint32_t seq = (uint32_t) ent;
-                        const uint32_t posj = (uint32_t) (ent >> 32) & 0xFFFFu;
-                        const uint32_t diag = (iPos - posj) & 0xFFFFu;
-                        // low bits: the hit's arrival number within its query (the sort only looks at the group bits and is stable)
-                        A.keys[dst + e] = (((((uint64_t) qLocal << A.seq_bits) | seq) << 8 | (diag & 0xFFu)) << A.hit_bits) | (dst + e - qFirstHit);
-                        A.diag_hi[dst + e] = (uint8_t) (diag >> 8);
+                    if (size[u]) put(ent0[u], dst);
+                    for (uint32_t e = 1; e < size[u]; e += 4) {              // the rest of a longer list, four loads in flight
+                        uint64_t t[4];
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++) t[k] = e + k < size[u] ? A.V.entries[o0[u] + e + k] : 0ull;
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++) if (e + k < size[u]) put(t[k], dst + e + k);
                     }
                     hits += enumk::wave_last(incl);
                 }
@@ -370,13 +386,14 @@ __global__ __launch_bounds__(NW * 64) void fused_kernel(FusedArgs A) {
             [&](const uint32_t (&kmer)[FUSED_U], const bool (&has)[FUSED_U]) -> bool {
                 uint32_t size[FUSED_U], o0[FUSED_U], ex[FUSED_U];
                 uint64_t ent0[FUSED_U];
+                bool inl[FUSED_U];
 #pragma unroll
                 for (int u = 0; u < FUSED_U; u++) {
-                    size[u] = 0; o0[u] = 0;
-                    if (has[u] && kmer_present(A.V.kmer_bits, kmer[u])) { const OffPair o = load_off_pair(A.V.kmer_off, kmer[u]); o0[u] = o.lo; size[u] = o.hi - o.lo; }
+                    size[u] = 0; o0[u] = 0; ent0[u] = 0; inl[u] = true;
+                    if (has[u] && kmer_present(A.V.kmer_bits, kmer[u])) { const KmerList l = load_kmer_list(A.V.kmer_slot, kmer[u]); o0[u] = l.first; size[u] = l.size; ent0[u] = l.ent0; inl[u] = l.isInline; }
                 }
 #pragma unroll
-                for (int u = 0; u < FUSED_U; u++) ent0[u] = size[u] ? A.V.entries[o0[u]] : 0ull;   // first entry of every list (most lists have one)
+                for (int u = 0; u < FUSED_U; u++) if (!inl[u]) ent0[u] = A.V.entries[o0[u]];       // first entry of the longer lists (single-entry lists came with the slot)
                 uint32_t totAll = 0;
 #pragma unroll
                 for (int u = 0; u < FUSED_U; u++) { const uint32_t incl = enumk::wave_incl_scan(size[u]); ex[u] = incl - size[u] + totAll; totAll += enumk::wave_last(incl); }
@@ -394,9 +411,7 @@ __global__ __launch_bounds__(NW * 64) void fused_kernel(FusedArgs A) {
 #pragma unroll
                 for (int u = 0; u < FUSED_U; u++) {
                     const uint32_t v0 = wcount + ex[u];
-                    for (uint32_t e = 0; e < size[u]; e++) {
-                        const uint64_t ent = e == 0 ? ent0[u] : A.V.entries[o0[u] + e];
-                        const uint32_t v = v0 + e;
+                    const auto put = [&](uint64_t ent, uint32_t v) {
                         const uint32_t phys = (uint32_t) sChunkOf[w][v >> 6] * WAVE + (v & 63u);
                         sKey[phys] = (uint32_t) ent;
                         sDiag[phys] = (uint16_t) (((uint32_t) i - ((uint32_t) (ent >> 32) & 0xFFFFu)) & 0xFFFFu);
@@ -404,6 +419,14 @@ __global__ __launch_bounds__(NW * 64) void fused_kernel(FusedArgs A) {
                         const uint32_t hb = ((uint32_t) ent * 2654435761u) >> (32 - LOG_MBITS);
                         const uint32_t bit = 1u << (hb & 31u);
                         if (atomicOr(&sBm1[hb >> 5], bit) & bit) atomicOr(&sBm2[hb >> 5], bit);
+                    };
+                    if (size[u]) put(ent0[u], v0);
+                    for (uint32_t e = 1; e < size[u]; e += 4) {              // the rest of a longer list, four loads in flight
+                        uint64_t t[4];
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++) t[k] = e + k < size[u] ? A.V.entries[o0[u] + e + k] : 0ull;
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++) if (e + k < size[u]) put(t[k], v0 + e + k);
                     }
                 }
                 wcount += totAll;

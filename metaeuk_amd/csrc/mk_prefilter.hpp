@@ -15,7 +15,9 @@ struct PrefilterDeviceView {
     const uint8_t *q_res; const uint64_t *q_off; const int16_t *q_kmer_thr; const int8_t *q_corr; uint32_t n_queries;
     // target side
     const uint8_t *t_masked; const uint64_t *t_off; uint32_t n_targets;
-    const uint32_t *kmer_off; const uint64_t *entries;
+    // one 8-byte slot per k-mer: a single-entry list is stored inline (bit 63 | the entry: target | position << 32), any other list as
+    // first entry index | length << 32 -- the most frequent case costs one dependent random read instead of two
+    const uint64_t *kmer_slot; const uint64_t *entries;
     const uint32_t *kmer_bits;     // 20^6 bits: k-mer has a non-empty index list (8 MB: stays in L2/MALL, filters the offset probes)
     const int16_t *score3; const uint16_t *index3;
     const uint16_t *hist3; const uint16_t *cum3; int hist_lo, hist_range;   // per-row score histograms (sizing)
