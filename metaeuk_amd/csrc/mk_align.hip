@@ -253,12 +253,12 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const SwJob *j
     // persistent forward launch: this many one-wave workgroups per CU and tile configuration (MK_SW_WAVES_PER_CU = one number
     // or one per tile configuration, comma separated).  Half the wave slots for the small tiles; fewer for the tiles whose profiles are large, so
     // that the LDS-hungry prefilter workgroups of the other stream still find room on the CU.
-    static uint32_t persistentBlocks[SW_NCFG] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    static uint32_t persistentBlocks[SW_NCFG] = {};
     if (!persistentBlocks[0]) {
         int dev = 0, cus = 256;
         (void) hipGetDevice(&dev);
         (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        int perCu[SW_NCFG] = {16, 16, 16, 12, 8, 6, 6, 8, 8};
+        int perCu[SW_NCFG] = {16, 16, 16, 12, 12, 8, 8, 6, 6, 8, 8};
         if (const char *e = getenv("MK_SW_WAVES_PER_CU")) {
             int k = 0, last = 16;
             for (const char *p = e; *p && k < SW_NCFG; k++) {

@@ -41,9 +41,9 @@ struct SwLaunch {
 
 // tile configurations: G lanes per DP x R rows per lane; a job uses the smallest one whose G*R >= q_len
 // (the last one also handles longer queries in row tiles)
-constexpr int SW_NCFG = 9;
+constexpr int SW_NCFG = 11;
 __host__ __device__ inline int sw_cfg_rows(int c) {
-    const int rows[SW_NCFG] = {32, 48, 64, 128, 256, 384, 512, 768, 1024};
+    const int rows[SW_NCFG] = {32, 48, 64, 96, 128, 192, 256, 384, 512, 768, 1024};
     return rows[c];
 }
 // forward pass of the pipeline: tiles of at most 512 rows run in packed int16, two targets per lane group (16 lanes up to 256

@@ -223,6 +223,11 @@ __device__ __forceinline__ pk16 pk_from(uint32_t v) { return __builtin_bit_cast(
 __device__ __forceinline__ uint32_t pk_bits(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ pk16 pk_max(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ pk16 pk_splat(int v) { pk16 r; r.x = (short) v; r.y = (short) v; return r; }
+// a - b clamped at 0 for non-negative halves (v_pk_sub_u16 clamp): the reference's simdui16_subs on gap penalties
+typedef unsigned short pku16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk16 pk_subs0(pk16 a, pk16 b) {
+    return __builtin_bit_cast(pk16, __builtin_elementwise_sub_sat(__builtin_bit_cast(pku16, a), __builtin_bit_cast(pku16, b)));
+}
 
 // R rows per lane; the LDS profile keeps RP >= R (even) int16 slots per lane so that a lane's scores are whole dwords.
 // G = 16 lanes per pair of DPs for tiles of at most 256 rows; G = 32 for 384 / 512 rows, where diag + score can pass 32767
@@ -295,11 +300,11 @@ __global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
                     const pk16 sc = pk_from(__builtin_amdgcn_perm(wb[r / 2], wa[r / 2], (r & 1) ? 0x07060302u : 0x05040100u));
                     const pk16 d = SAT ? __builtin_elementwise_add_sat(dsave, sc) : dsave + sc;
                     dsave = H[r];
-                    const pk16 h = pk_max(pk_max(pk_max(d, E[r]), F), zero2);
+                    const pk16 h = pk_max(pk_max(d, E[r]), F);         // E, F >= 0 (clamped subtractions) keep H non-negative
                     best = pk_max(best, h);
-                    const pk16 ho = h - go2;
-                    E[r] = pk_max(E[r] - ge2, ho);
-                    F = pk_max(F - ge2, ho);
+                    const pk16 ho = pk_subs0(h, go2);
+                    E[r] = pk_max(pk_subs0(E[r], ge2), ho);
+                    F = pk_max(pk_subs0(F, ge2), ho);
                     H[r] = h;
                 }
                 hupPrev = hup;
@@ -335,7 +340,9 @@ hipError_t launch_sw_score(const SwLaunch &L, int cfg, hipStream_t stream) {
         case 32: hipLaunchKernelGGL((swp_kernel<2>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
         case 48: hipLaunchKernelGGL((swp_kernel<3, 4>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
         case 64: hipLaunchKernelGGL((swp_kernel<4>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
+        case 96: hipLaunchKernelGGL((swp_kernel<6>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
         case 128: hipLaunchKernelGGL((swp_kernel<8>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
+        case 192: hipLaunchKernelGGL((swp_kernel<12>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
         case 256: hipLaunchKernelGGL((swp_kernel<16>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
         case 384: hipLaunchKernelGGL((swp_kernel<12, 12, 32>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
         case 512: hipLaunchKernelGGL((swp_kernel<16, 16, 32>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
@@ -371,9 +378,11 @@ hipError_t launch_sw(const SwLaunch &L, int cfg, hipStream_t stream) {
     if (cfg < 0 || cfg >= SW_NCFG) return hipErrorInvalidValue;
     switch (sw_cfg_rows(cfg)) {
         case 32: return launch_one<16, 2, 256>(L, stream);
-        case 48:                                              // the int32 kernel has no 3-row lanes: a 64-row tile, padded
+        case 48:                                              // tiles the int32 kernel has no lane shape for run in the next one, padded
         case 64: return launch_one<16, 4, 256>(L, stream);
+        case 96:
         case 128: return launch_one<16, 8, 256>(L, stream);
+        case 192:
         case 256: return launch_one<16, 16, 128>(L, stream);
         case 384: return launch_one<32, 12, 128>(L, stream);
         case 512: return launch_one<32, 16, 128>(L, stream);
