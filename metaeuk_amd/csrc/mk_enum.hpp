@@ -33,11 +33,45 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2,3
     return (uint32_t) x;
 }
+// inclusive prefix maximum over the 64 lanes (values >= 0)
+__device__ __forceinline__ uint32_t wave_incl_max_scan(uint32_t v) {
+    int x = (int) v;
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false));
+    return (uint32_t) x;
+}
 __device__ __forceinline__ uint32_t wave_last(uint32_t v) { return (uint32_t) __builtin_amdgcn_readlane((int) v, 63); }
 
 __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ uint32_t wave_read_lane(uint32_t v, uint32_t srcLane) { return (uint32_t) __builtin_amdgcn_ds_bpermute((int) (srcLane << 2), (int) v); }
+
+// Index lists longer than one entry: every lane holds `rem` further entries of its list.  Instead of each lane walking its own
+// list (a wave then loops as often as its longest list, with one or two lanes busy), the entries are dealt out one per lane:
+// item x of the wave belongs to the lane whose [exclusive prefix, +rem) range covers it; the owners mark their range starts in a
+// 64-byte LDS window and a prefix maximum spreads the owner over its range.  fn(ownerLane, e) is called by the lane that got
+// entry e (>= 1) of ownerLane's list; it fetches what it needs from the owner with wave_read_lane.
+template <typename F>
+__device__ __forceinline__ void wave_deal_tail(uint32_t rem, int lane, uint8_t *mark /* [64] per wave */, F &&fn) {
+    const uint32_t incl = wave_incl_scan(rem), excl = incl - rem, total = wave_last(incl);
+    for (uint32_t base = 0; base < total; base += WAVE) {
+        mark[lane] = 0;
+        wave_sync_lds();
+        if (rem && excl < base + WAVE && incl > base) mark[max(excl, base) - base] = (uint8_t) (lane + 1);
+        wave_sync_lds();
+        const uint32_t owner = wave_incl_max_scan(mark[lane]);      // 1 + owner lane (an item of the window always has one)
+        const uint32_t src = owner ? owner - 1 : 0;
+        const uint32_t ownerExcl = wave_read_lane(excl, src);
+        const bool valid = base + (uint32_t) lane < total;
+        fn(src, 1u + (base + (uint32_t) lane - ownerExcl), valid);
+        wave_sync_lds();
+    }
 }
 
 constexpr int AJ = 4;                    // first-half candidates per lane and step

@@ -131,6 +131,7 @@ constexpr int FUSED_U = 2;                 // ... in the fused kernels (smaller:
 template <bool GATHER>
 __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
     __shared__ enumk::EnumLds<PROBE_U> sE[4];
+    __shared__ uint8_t sMark[4][WAVE];
     __builtin_amdgcn_s_setprio(3);                    // latency-bound waves issue ahead of the ALU-bound ones of the other stream
     const int w = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
     const uint64_t p = A.pos_begin + (uint64_t) blockIdx.x * 4 + w;
@@ -180,13 +181,12 @@ __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
                     const uint32_t incl = enumk::wave_incl_scan(size[u]);
                     const uint64_t dst = (uint64_t) hitBase + hits + (incl - size[u]);
                     if (size[u]) put(ent0[u], dst);
-                    for (uint32_t e = 1; e < size[u]; e += 4) {              // the rest of a longer list, four loads in flight
-                        uint64_t t[4];
-#pragma unroll
-                        for (uint32_t k = 0; k < 4; k++) t[k] = e + k < size[u] ? A.V.entries[o0[u] + e + k] : 0ull;
-#pragma unroll
-                        for (uint32_t k = 0; k < 4; k++) if (e + k < size[u]) put(t[k], dst + e + k);
-                    }
+                    // the rest of the longer lists, one entry per lane
+                    enumk::wave_deal_tail(size[u] > 1 ? size[u] - 1 : 0u, lane, sMark[w], [&](uint32_t owner, uint32_t e, bool valid) {
+                        const uint32_t oFirst = enumk::wave_read_lane(o0[u], owner);
+                        const uint32_t oLo = enumk::wave_read_lane((uint32_t) dst, owner), oHi = enumk::wave_read_lane((uint32_t) (dst >> 32), owner);
+                        if (valid) put(A.V.entries[oFirst + e], (((uint64_t) oHi << 32) | oLo) + e);
+                    });
                     hits += enumk::wave_last(incl);
                 }
             }
@@ -333,6 +333,7 @@ __global__ __launch_bounds__(NW * 64) void fused_kernel(FusedArgs A) {
     __shared__ uint16_t sDiag[CAP];
     __shared__ uint32_t sBm1[MBITS / 32], sBm2[MBITS / 32];   // bucket hit once / more than once
     __shared__ enumk::EnumLds<FUSED_U> sE[NW];
+    __shared__ uint8_t sMark[NW][WAVE];
     constexpr int MAXPOS = fused_max_positions(CAP);
     __shared__ uint16_t sChunkOf[NW][NCH];        // chunk number within the wave's current position -> physical chunk
     __shared__ uint16_t sRankToChunk[NCH];        // arrival rank of a chunk -> physical chunk
@@ -421,13 +422,11 @@ __global__ __launch_bounds__(NW * 64) void fused_kernel(FusedArgs A) {
                         if (atomicOr(&sBm1[hb >> 5], bit) & bit) atomicOr(&sBm2[hb >> 5], bit);
                     };
                     if (size[u]) put(ent0[u], v0);
-                    for (uint32_t e = 1; e < size[u]; e += 4) {              // the rest of a longer list, four loads in flight
-                        uint64_t t[4];
-#pragma unroll
-                        for (uint32_t k = 0; k < 4; k++) t[k] = e + k < size[u] ? A.V.entries[o0[u] + e + k] : 0ull;
-#pragma unroll
-                        for (uint32_t k = 0; k < 4; k++) if (e + k < size[u]) put(t[k], v0 + e + k);
-                    }
+                    // the rest of the longer lists, one entry per lane
+                    enumk::wave_deal_tail(size[u] > 1 ? size[u] - 1 : 0u, lane, sMark[w], [&](uint32_t owner, uint32_t e, bool valid) {
+                        const uint32_t oFirst = enumk::wave_read_lane(o0[u], owner), oV0 = enumk::wave_read_lane(v0, owner);
+                        if (valid) put(A.V.entries[oFirst + e], oV0 + e);
+                    });
                 }
                 wcount += totAll;
                 return true;
