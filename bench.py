@@ -28,13 +28,15 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T int32 lane-ops/s
-SW_OPS_PER_CELL = 10      # add, min, max3, lshl_or, max, sub, sub, max3, sub, max3 (mk_sw.hip inner loop)
+SW_OPS_PER_CELL = 10      # int32 kernel: add, min, max3, lshl_or, max, sub, sub, max3, sub, max3 per cell; the packed int16 score pass spends
+                          # 10 per PAIR of cells (perm, add, max, max, max, sub, sub, max, sub, max) -- priced at the int32 rate
 # HBM bytes per launch from the PMC passes (profiles/r01_pmc_hbm_traffic.txt), keyed by the bench's kernel names
 TRAFFIC_BYTES_PER_LAUNCH = {   # (FETCH_SIZE + WRITE_SIZE) KB x 1024, raw counter values, default workload, final round-1 build
-    "prefilter_fused_lds2048": (1330290 + 9863) * 1024, "prefilter_fused_lds4096": (3882978 + 14872) * 1024,
-    "prefilter_fused_lds8192": (14035790 + 35204) * 1024,
-    "kmer_probe_count": (31453387 + 110986) * 1024, "kmer_probe_gather": (48149895 + 6796568) * 1024,
-    "sw_fwd_rows32": (336506 + 34092) * 1024, "sw_fwd_rows64": (537378 + 56571) * 1024, "sw_fwd_rows128": (309061 + 33579) * 1024,
+    "prefilter_fused_lds2048": (1015013 + 9582) * 1024, "prefilter_fused_lds4096": (2904793 + 14501) * 1024,
+    "prefilter_fused_lds8192": (10675400 + 35414) * 1024,
+    "kmer_probe_count": (16365778 + 60271) * 1024, "kmer_probe_gather": (20477354 + 2323548) * 1024,
+    "sw_fwd_rows32": (336422 + 33746) * 1024, "sw_fwd_rows48": (314477 + 32922) * 1024, "sw_fwd_rows64": (224260 + 23701) * 1024,
+    "sw_fwd_rows96": (223861 + 23900) * 1024, "sw_fwd_rows128": (85757 + 9349) * 1024, "sw_fwd_rows192": (64843 + 6914) * 1024,
 }
 
 
