@@ -99,6 +99,22 @@ uint64_t mk_targetdb_index_entries(const mk_targetdb *db);
 /* copies of host-built artefacts, for tests */
 int mk_targetdb_masked(const mk_targetdb *db, uint8_t *out /* residues */);
 
+/* ---- precomputed index: the index DB of `createindex` / `indexdb` (type 9,
+ * M/src/prefiltering/PrefilteringIndexReader.cpp:54-326): sequence DB + masked sequences + k-mer lists, so that a database is
+ * masked and indexed once.  Both directions are interchangeable with the reference: it reads what mk_index_write writes and
+ * mk_targetdb_open_index reads what its createindex writes (amino-acid targets, k = 6, one split).
+ * mk_index_write needs no GPU.  The sequence DB is passed as it lies on disk: the data file(s) and the rows of its .index
+ * (key, offset, length incl. "\n\0") in file order; target ids of the index = positions in that order (DBReader NOSORT,
+ * util/indexdb.cpp:67-68).  Writes <index_db>, <index_db>.index, <index_db>.dbtype. */
+int mk_index_write(const char *index_db, const char *seq_data, uint64_t seq_data_size, const uint32_t *keys, const uint64_t *offsets,
+                   const uint32_t *lengths, uint32_t n, int seq_dbtype, const mk_params *params);
+/* target side from an index DB instead of mk_targetdb_create: nothing is masked or indexed again */
+int mk_targetdb_open_index(const char *index_db, const mk_params *params, mk_targetdb **out);
+/* DB keys of the targets of a database opened from an index (keys = NULL when it was created from residues) */
+int mk_targetdb_keys(const mk_targetdb *db, const uint32_t **keys, uint32_t *n);
+/* test hook, no GPU: the parts of an index DB a reader takes, as text files in out_dir (masked_targets.txt, index.txt, seqs.txt, meta.txt) */
+int mk_index_dump(const char *index_db, const char *out_dir);
+
 /* ---- query batch: Sequence::mapSequence + the per-residue inputs of calcLocalAaBiasCorrection /
  * createProfile / ssw_init.  Uploads the batch to HBM.  The batch handle also carries the results
  * of the two stages, the way the reference passes them through the pref_0 / search_res DBs. */

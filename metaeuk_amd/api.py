@@ -113,6 +113,19 @@ class TargetDB:
         _chk(lib().mk_targetdb_create(_p(self.res), _p(self.off), C.c_uint32(self.n), C.byref(self.params), C.byref(self.h)))
 
     @classmethod
+    def from_index(cls, index_db, params=None):
+        """target side from a createindex DB (type 9) written by this library or by the reference"""
+        self = cls.__new__(cls)
+        self.params = params or default_params()
+        self.h = C.c_void_p()
+        _chk(lib().mk_targetdb_open_index(C.c_char_p(index_db.encode()), C.byref(self.params), C.byref(self.h)))
+        kp, n = C.c_void_p(), C.c_uint32()
+        _chk(lib().mk_targetdb_keys(self.h, C.byref(kp), C.byref(n)))
+        self.n = int(n.value)
+        self.keys = np.array(np.ctypeslib.as_array(C.cast(kp, C.POINTER(C.c_uint32)), shape=(self.n,))) if kp.value else None
+        return self
+
+    @classmethod
     def from_codes(cls, res, off, params=None):
         """res: uint8 codes 0..20 in matrix alphabet order (ACDEFGHIKLMNPQRSTVWYX), off: uint64[n+1]"""
         return cls(None, params, _codes=(np.ascontiguousarray(res, dtype=np.uint8), np.ascontiguousarray(off, dtype=np.uint64)))
@@ -135,6 +148,46 @@ class TargetDB:
             self.close()
         except Exception:
             pass
+
+
+def seq_db_image(seqs, keys=None, order=None):
+    """an MMseqs2 sequence DB in memory: data blob of 'SEQ\\n\\0' entries laid out in `order`, and the .index rows (key, offset, length)
+    sorted by key, the way createdb leaves them"""
+    n = len(seqs)
+    keys = list(range(n)) if keys is None else list(keys)
+    order = list(range(n)) if order is None else list(order)
+    off, pos, chunks = [0] * n, 0, []
+    for i in order:
+        b = seqs[i].encode("latin-1") + b"\n\0"
+        off[i] = pos
+        pos += len(b)
+        chunks.append(b)
+    rows = sorted(range(n), key=lambda i: keys[i])
+    return (b"".join(chunks), np.array([keys[i] for i in rows], dtype=np.uint32), np.array([off[i] for i in rows], dtype=np.uint64),
+            np.array([len(seqs[i]) + 2 for i in rows], dtype=np.uint32))
+
+
+def write_seq_db(base, image, dbtype=0):
+    data, keys, offs, lens = image
+    with open(base, "wb") as f:
+        f.write(data)
+    with open(base + ".index", "w") as f:
+        for k, o, l in zip(keys, offs, lens):
+            f.write("%d\t%d\t%d\n" % (k, o, l))
+    with open(base + ".dbtype", "wb") as f:
+        f.write(int(dbtype).to_bytes(4, "little"))
+
+
+def index_write(index_db, image, params=None, dbtype=0):
+    """createindex: <index_db>, .index, .dbtype in the reference's format (no GPU needed)"""
+    data, keys, offs, lens = image
+    p = params or default_params()
+    _chk(lib().mk_index_write(C.c_char_p(index_db.encode()), C.c_char_p(data), C.c_uint64(len(data)), _p(keys), _p(offs), _p(lens), C.c_uint32(len(keys)),
+                              C.c_int(dbtype), C.byref(p)))
+
+
+def index_dump(index_db, out_dir):
+    _chk(lib().mk_index_dump(C.c_char_p(index_db.encode()), C.c_char_p(out_dir.encode())))
 
 
 class Queries:

@@ -8,6 +8,7 @@
 #include "mk_kernels.hpp"
 #include "mk_orf.hpp"
 #include "mk_exons.hpp"
+#include "mk_indexfile.hpp"
 #include "mk_prefilter.hpp"
 
 #include <algorithm>
@@ -147,6 +148,7 @@ struct mk_targetdb {
     uint32_t n = 0;
     std::vector<uint64_t> off;
     std::vector<uint8_t> maskedHost;
+    std::vector<uint32_t> keys;      // DB keys of the targets when the database came from an index file
     mk::SubMat kmerMat, ungMat, alnMat;
     mk::Evaluer evaluer;
     int kmerThr = 0;
@@ -290,7 +292,8 @@ void mk_default_params(mk_params *p) {
 
 void mk_encode(const char *ascii, size_t len, uint8_t *codes) { mk::encode(ascii, len, codes); }
 
-int mk_targetdb_create(const uint8_t *residues, const uint64_t *offsets, uint32_t n, const mk_params *P, mk_targetdb **out) {
+// target side, given the k-mer lists (built here or read from an index file): matrices, tables, upload
+static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uint32_t n, const mk_params *P, mk::TargetIndex *prebuilt, mk_targetdb **out) {
     int rc = ensure_ready();
     if (rc) return rc;
     if (!residues || !offsets || !P || !out) return fail(MK_ERR_ARG, "null argument");
@@ -307,8 +310,9 @@ int mk_targetdb_create(const uint8_t *residues, const uint64_t *offsets, uint32_
     mk::build_submat(db->alnMat, mk::MAT_BLOSUM62, 2.0f, 0.0f);     // Alignment.cpp:152
     db->kmerThr = mk::kmer_threshold(P->sensitivity, P->kmer_score);
     db->evaluer.init(offsets[n]);
-    mk::TargetIndex ix;
-    mk::build_index(db->kmerMat, residues, offsets, n, db->kmerThr, P->mask != 0, P->mask_prob, P->simd_lanes_double, ix);
+    mk::TargetIndex built;
+    if (!prebuilt) mk::build_index(db->kmerMat, residues, offsets, n, db->kmerThr, P->mask != 0, P->mask_prob, P->simd_lanes_double, built);
+    mk::TargetIndex &ix = prebuilt ? *prebuilt : built;
     if (ix.entries.size() >= 0xFFFFFFFFull) { delete db; return fail(MK_ERR_UNSUPPORTED, "index has >= 2^32 entries"); }
     db->nEntries = ix.entries.size();
     db->maskedHost = ix.masked;
@@ -353,6 +357,109 @@ int mk_targetdb_create(const uint8_t *residues, const uint64_t *offsets, uint32_
 }
 
 void mk_targetdb_destroy(mk_targetdb *db) { delete db; }
+int mk_targetdb_create(const uint8_t *residues, const uint64_t *offsets, uint32_t n, const mk_params *P, mk_targetdb **out) {
+    return targetdb_create(residues, offsets, n, P, nullptr, out);
+}
+
+// ---- createindex's precomputed index DB (mk_indexfile.cpp) ----
+static void encode_seq_db(const mk::SeqDbImage &db, std::vector<uint8_t> &res, std::vector<uint64_t> &off) {
+    const size_t n = db.keys.size();
+    off.assign(n + 1, 0);
+    for (size_t i = 0; i < n; i++) off[i + 1] = off[i] + (db.lengths[i] >= 2 ? db.lengths[i] - 2 : 0);      // entries are "SEQ\n\0"
+    res.assign(off[n] + 1, 0);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (size_t i = 0; i < n; i++) mk::encode(db.data.data() + db.offsets[i], off[i + 1] - off[i], res.data() + off[i]);
+}
+
+int mk_index_write(const char *indexDb, const char *seqData, uint64_t seqDataSize, const uint32_t *keys, const uint64_t *offsets,
+                   const uint32_t *lengths, uint32_t n, int seqDbtype, const mk_params *P) {
+    if (!indexDb || !keys || !offsets || !lengths || !P || (!seqData && seqDataSize)) return fail(MK_ERR_ARG, "null argument");
+    if ((seqDbtype & 0xFFFF) != 0) return fail(MK_ERR_UNSUPPORTED, "only amino-acid sequence databases can be indexed (profile targets: SURVEY 8f-4)");
+    mk::IndexFileContent c;
+    c.seqs.keys.assign(keys, keys + n); c.seqs.offsets.assign(offsets, offsets + n); c.seqs.lengths.assign(lengths, lengths + n);
+    c.seqs.data.assign(seqData, seqData + seqDataSize);
+    c.seqs.dbtype = seqDbtype;
+    for (uint32_t i = 0; i < n; i++) {
+        if (offsets[i] + lengths[i] > seqDataSize || lengths[i] < 2) return fail(MK_ERR_ARG, "entry %u lies outside the sequence data", i);
+        if (lengths[i] - 2 >= 32768) return fail(MK_ERR_UNSUPPORTED, "target %u is >= 32768 residues: the reference's wrapped-diagonal path (UngappedAlignment.cpp:312-329) is not restated", i);
+    }
+    std::vector<uint8_t> res;
+    encode_seq_db(c.seqs, res, c.seqOffsets);
+    mk::SubMat km;
+    mk::build_submat(km, mk::MAT_VTML80, 8.0f, -0.2f);
+    c.meta.kmerThr = mk::kmer_threshold(P->sensitivity, P->kmer_score);
+    c.meta.mask = P->mask != 0; c.meta.compBiasCorr = P->comp_bias_corr != 0; c.meta.seqType = seqDbtype; c.meta.srcSeqType = seqDbtype;
+    mk::build_index(km, res.data(), c.seqOffsets.data(), n, c.meta.kmerThr, P->mask != 0, P->mask_prob, P->simd_lanes_double, c.index, false);
+    const std::string e = mk::write_index_file(indexDb, km, c);
+    if (!e.empty()) return fail(MK_ERR_ARG, "%s", e.c_str());
+    return MK_OK;
+}
+
+int mk_targetdb_open_index(const char *indexDb, const mk_params *P, mk_targetdb **out) {
+    int rc = ensure_ready();
+    if (rc) return rc;
+    if (!indexDb || !P || !out) return fail(MK_ERR_ARG, "null argument");
+    mk::IndexFileContent c;
+    const std::string e = mk::read_index_file(indexDb, c);
+    if (!e.empty()) return fail(MK_ERR_UNSUPPORTED, "%s", e.c_str());
+    std::vector<uint8_t> res;
+    std::vector<uint64_t> off;
+    encode_seq_db(c.seqs, res, off);
+    if (off != c.seqOffsets) return fail(MK_ERR_ARG, "%s: the masked sequences do not line up with the sequence database", indexDb);
+    mk::index_to_address_order(c.index);
+    rc = targetdb_create(res.data(), off.data(), (uint32_t) c.seqs.keys.size(), P, &c.index, out);
+    if (rc == MK_OK) (*out)->keys = c.seqs.keys;
+    return rc;
+}
+
+// test hook (host only): what a reader takes from an index DB, as text -- masked_targets.txt (one masked sequence per line),
+// index.txt ("kmer seqId:pos ..." per non-empty list, the reference's k-mer numbering), seqs.txt ("key<TAB>sequence")
+int mk_index_dump(const char *indexDb, const char *outDir) {
+    if (!indexDb || !outDir) return fail(MK_ERR_ARG, "null argument");
+    mk::IndexFileContent c;
+    const std::string e = mk::read_index_file(indexDb, c);
+    if (!e.empty()) return fail(MK_ERR_UNSUPPORTED, "%s", e.c_str());
+    static const char LETTERS[] = "ACDEFGHIKLMNPQRSTVWYX";
+    const std::string d = outDir;
+    FILE *f = fopen((d + "/masked_targets.txt").c_str(), "w");
+    if (!f) return fail(MK_ERR_ARG, "cannot write to %s", outDir);
+    for (size_t i = 0; i + 1 < c.seqOffsets.size(); i++) {
+        for (uint64_t p = c.seqOffsets[i]; p < c.seqOffsets[i + 1]; p++) fputc(LETTERS[c.index.masked[p] <= 20 ? c.index.masked[p] : 20], f);
+        fputc('\n', f);
+    }
+    fclose(f);
+    f = fopen((d + "/index.txt").c_str(), "w");
+    if (!f) return fail(MK_ERR_ARG, "cannot write to %s", outDir);
+    for (size_t k = 0; k + 1 < c.index.offsets.size(); k++) {
+        if (c.index.offsets[k + 1] == c.index.offsets[k]) continue;
+        fprintf(f, "%zu", k);
+        for (uint64_t j = c.index.offsets[k]; j < c.index.offsets[k + 1]; j++) fprintf(f, " %u:%u", (unsigned) (uint32_t) c.index.entries[j], (unsigned) (uint16_t) (c.index.entries[j] >> 32));
+        fputc('\n', f);
+    }
+    fclose(f);
+    f = fopen((d + "/seqs.txt").c_str(), "w");
+    if (!f) return fail(MK_ERR_ARG, "cannot write to %s", outDir);
+    for (size_t i = 0; i < c.seqs.keys.size(); i++) {
+        fprintf(f, "%u\t", c.seqs.keys[i]);
+        fwrite(c.seqs.data.data() + c.seqs.offsets[i], 1, c.seqs.lengths[i] >= 2 ? c.seqs.lengths[i] - 2 : 0, f);
+        fputc('\n', f);
+    }
+    fclose(f);
+    f = fopen((d + "/meta.txt").c_str(), "w");
+    if (!f) return fail(MK_ERR_ARG, "cannot write to %s", outDir);
+    fprintf(f, "maxSeqLen %d\nkmerSize %d\ncompBiasCorr %d\nalphabetSize %d\nmask %d\nspacedKmer %d\nkmerThr %d\nseqType %d\nsrcSeqType %d\nheaders1 %d\nheaders2 %d\nsplits %d\nmatrix %s\n",
+            c.meta.maxSeqLen, c.meta.kmerSize, c.meta.compBiasCorr, c.meta.alphabetSize, c.meta.mask, c.meta.spacedKmer, c.meta.kmerThr, c.meta.seqType,
+            c.meta.srcSeqType, c.meta.headers1, c.meta.headers2, c.meta.splits, c.matrixName.c_str());
+    fclose(f);
+    return MK_OK;
+}
+
+int mk_targetdb_keys(const mk_targetdb *db, const uint32_t **keys, uint32_t *n) {
+    if (!db || !keys || !n) return fail(MK_ERR_ARG, "null argument");
+    *keys = db->keys.empty() ? nullptr : db->keys.data(); *n = db->n;
+    return MK_OK;
+}
+
 uint64_t mk_targetdb_residues(const mk_targetdb *db) { return db ? db->off[db->n] : 0; }
 uint64_t mk_targetdb_index_entries(const mk_targetdb *db) { return db ? db->nEntries : 0; }
 int mk_targetdb_masked(const mk_targetdb *db, uint8_t *out) {

@@ -1,4 +1,4 @@
-// metaeuk_amd/csrc/mk_cli.cpp -- `metaeuk-amd prefilter|align|extractorfs|predictexons`: the two hot modules of
+// metaeuk_amd/csrc/mk_cli.cpp -- `metaeuk-amd prefilter|align|extractorfs|predictexons|createindex`: the two hot modules of
 // `metaeuk predictexons` with the reference's process-level signature, flag names and on-disk DB format,
 // on top of the C ABI (include/metaeuk_amd.h).
 //
@@ -170,6 +170,46 @@ void encodeDb(const mk::Database &db, std::vector<uint8_t> &res, std::vector<uin
     for (size_t i = 0; i < db.entries.size(); i++) mk_encode(db.entry(i), db.seqLen(i), res.data() + off[i]);
 }
 
+// target side of a command: from the precomputed index DB when there is one (the path itself is an index DB, or <path>.idx exists and
+// MMSEQS_IGNORE_INDEX is unset -- PrefilteringIndexReader::searchForIndex, PrefilteringIndexReader.cpp:568-579), else built from the
+// sequence DB.  keys[i] = DB key of target i.
+struct TargetSide { mk_targetdb *T = nullptr; std::vector<uint32_t> keys; bool fromIndex = false; };
+int openTarget(const std::string &path, const mk_params &P, TargetSide &ts) {
+    std::string idx;
+    {
+        FILE *f = fopen((path + ".dbtype").c_str(), "rb");
+        int32_t t = -1;
+        if (f) { if (fread(&t, 4, 1, f) != 1) t = -1; fclose(f); }
+        if (t >= 0 && (t & 0xFFFF) == 9) idx = path;
+        else if (!getenv("MMSEQS_IGNORE_INDEX") && mk::Database::exists(path + ".idx.dbtype")) idx = path + ".idx";
+    }
+    if (!idx.empty()) {
+        if (mk_targetdb_open_index(idx.c_str(), &P, &ts.T) != MK_OK) return die("%s", mk_last_error());
+        const uint32_t *k; uint32_t n;
+        mk_targetdb_keys(ts.T, &k, &n);
+        ts.keys.assign(k, k + n);
+        ts.fromIndex = true;
+        return 0;
+    }
+    mk::Database tdb;
+    const std::string e = tdb.open(path);
+    if (!e.empty()) return die("%s", e);
+    if ((tdb.dbtype & 0xFFFF) != mk::DBTYPE_AMINO_ACIDS) return die("only amino-acid target databases are implemented (profile targets: SURVEY 8f-4)%s");
+    std::vector<uint8_t> tres;
+    std::vector<uint64_t> toff;
+    tres.reserve(tdb.data.size());
+    {
+        toff.assign(tdb.entries.size() + 1, 0);
+        for (size_t i = 0; i < tdb.entries.size(); i++) toff[i + 1] = toff[i] + tdb.seqLen(i);
+        tres.assign(toff.back() + 1, 0);
+        for (size_t i = 0; i < tdb.entries.size(); i++) mk_encode(tdb.entry(i), tdb.seqLen(i), tres.data() + toff[i]);
+    }
+    if (mk_targetdb_create(tres.data(), toff.data(), (uint32_t) tdb.entries.size(), &P, &ts.T) != MK_OK) return die("%s", mk_last_error());
+    ts.keys.resize(tdb.entries.size());
+    for (size_t i = 0; i < ts.keys.size(); i++) ts.keys[i] = tdb.entries[i].key;
+    return 0;
+}
+
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int cmdPrefilterOrAlign(bool isAlign, int argc, char **argv) {
@@ -185,21 +225,19 @@ int cmdPrefilterOrAlign(bool isAlign, int argc, char **argv) {
     int gpu = 0;
     if (int rc = fillParams(a, P, gpu)) return rc;
     const double t0 = now();
-    mk::Database qdb, tdb;
+    mk::Database qdb;
     std::string e = qdb.open(a.pos[0]);
     if (!e.empty()) return die("%s", e);
-    e = tdb.open(a.pos[1]);
-    if (!e.empty()) return die("%s", e);
-    if ((qdb.dbtype & 0xFFFF) != mk::DBTYPE_AMINO_ACIDS || (tdb.dbtype & 0xFFFF) != mk::DBTYPE_AMINO_ACIDS)
-        return die("only amino-acid query and target databases are implemented (profile targets: SURVEY 8f-4)%s");
+    if ((qdb.dbtype & 0xFFFF) != mk::DBTYPE_AMINO_ACIDS) return die("only amino-acid query databases are implemented%s");
     if (mk_init(gpu) != MK_OK) return die("%s", mk_last_error());
-    std::vector<uint8_t> qres, tres;
-    std::vector<uint64_t> qoff, toff;
+    std::vector<uint8_t> qres;
+    std::vector<uint64_t> qoff;
     encodeDb(qdb, qres, qoff);
-    encodeDb(tdb, tres, toff);
-    mk_targetdb *T = nullptr;
+    TargetSide ts;
+    if (int rc = openTarget(a.pos[1], P, ts)) return rc;
+    mk_targetdb *T = ts.T;
+    const std::vector<uint32_t> &tkeys = ts.keys;
     mk_queries *Q = nullptr;
-    if (mk_targetdb_create(tres.data(), toff.data(), (uint32_t) tdb.entries.size(), &P, &T) != MK_OK) return die("%s", mk_last_error());
     if (mk_queries_create(qres.data(), qoff.data(), (uint32_t) qdb.entries.size(), &P, &Q) != MK_OK) return die("%s", mk_last_error());
     const size_t nq = qdb.entries.size();
     char line[512];
@@ -214,12 +252,12 @@ int cmdPrefilterOrAlign(bool isAlign, int argc, char **argv) {
         for (size_t i = 0; i < nq; i++) {
             buf.clear();
             for (uint64_t h = hoff[i]; h < hoff[i + 1]; h++)    // seqId -> dbKey (Prefiltering.cpp:845-852)
-                buf.append(line, mk_format_hit(line, tdb.entries[hits[h].seq_id].key, hits[h].pref_score, hits[h].diagonal));
+                buf.append(line, mk_format_hit(line, tkeys[hits[h].seq_id], hits[h].pref_score, hits[h].diagonal));
             w.write(qdb.entries[i].key, buf.data(), buf.size());
         }
         e = w.close();
         if (!e.empty()) return die("%s", e);
-        fprintf(stderr, "prefilter: %zu queries x %zu targets, %llu hits, %.2f s\n", nq, tdb.entries.size(), (unsigned long long) hoff[nq], now() - t0);
+        fprintf(stderr, "prefilter: %zu queries x %zu targets%s, %llu hits, %.2f s\n", nq, tkeys.size(), ts.fromIndex ? " (precomputed index)" : "", (unsigned long long) hoff[nq], now() - t0);
     } else {
         // read the prefilter DB: key \t score \t diagonal lines (QueryMatcher::parsePrefilterHit, QueryMatcher.h:87-102)
         mk::Database pdb;
@@ -227,7 +265,7 @@ int cmdPrefilterOrAlign(bool isAlign, int argc, char **argv) {
         if (!e.empty()) return die("%s", e);
         std::map<uint32_t, uint32_t> qKeyToIdx, tKeyToIdx;
         for (size_t i = 0; i < nq; i++) qKeyToIdx[qdb.entries[i].key] = (uint32_t) i;
-        for (size_t i = 0; i < tdb.entries.size(); i++) tKeyToIdx[tdb.entries[i].key] = (uint32_t) i;
+        for (size_t i = 0; i < tkeys.size(); i++) tKeyToIdx[tkeys[i]] = (uint32_t) i;
         std::vector<std::vector<mk_hit>> perQ(nq);
         for (size_t i = 0; i < pdb.entries.size(); i++) {
             auto qi = qKeyToIdx.find(pdb.entries[i].key);
@@ -262,7 +300,7 @@ int cmdPrefilterOrAlign(bool isAlign, int argc, char **argv) {
             buf.clear();
             for (uint64_t k = aoff[i]; k < aoff[i + 1]; k++) {
                 mk_alignment al = alns[k];
-                al.db_key = tdb.entries[al.db_key].key;
+                al.db_key = tkeys[al.db_key];
                 buf.append(line, mk_format_alignment(line, &al));
             }
             w.write(qdb.entries[i].key, buf.data(), buf.size());
@@ -400,12 +438,9 @@ int cmdPredictExons(int argc, char **argv) {
     if (!get("--min-aln-len")) P.min_aln_len = (int) X.min_exon_aa;   // par.alnLenThr = par.minExonAaLength (:46)
     if (mk::Database::exists(a.pos[2] + ".dbtype")) return die("%s exists already!", a.pos[2]);          // predictexons.sh:32
     const double t0 = now();
-    mk::Database contigs, tdb;
+    mk::Database contigs;
     std::string e = contigs.open(a.pos[0]);
     if (!e.empty()) return die("%s", e);
-    e = tdb.open(a.pos[1]);
-    if (!e.empty()) return die("%s", e);
-    if ((tdb.dbtype & 0xFFFF) != mk::DBTYPE_AMINO_ACIDS) return die("only amino-acid target databases are implemented (profile targets: SURVEY 8f-4)%s");
     if (mk_init(gpu) != MK_OK) return die("%s", mk_last_error());
     // contigs by ascending key: the order in which createRenumberedDB numbers their fragments (extractorfs.cpp:140-155)
     const std::vector<size_t> ord = contigs.keyOrder();
@@ -415,16 +450,13 @@ int cmdPredictExons(int argc, char **argv) {
         nucl.insert(nucl.end(), contigs.entry(ord[i]), contigs.entry(ord[i]) + contigs.seqLen(ord[i]));
         off[i + 1] = nucl.size();
     }
-    std::vector<uint8_t> tres;
-    std::vector<uint64_t> toff;
-    encodeDb(tdb, tres, toff);
-    std::vector<uint32_t> tkeys(tdb.entries.size());
-    for (size_t i = 0; i < tkeys.size(); i++) tkeys[i] = tdb.entries[i].key;
-    mk_targetdb *T = nullptr;
+    TargetSide ts;
+    if (int rc = openTarget(a.pos[1], P, ts)) return rc;
+    mk_targetdb *T = ts.T;
+    const std::vector<uint32_t> &tkeys = ts.keys;
     mk_orfs *O = nullptr;
     mk_queries *Q = nullptr;
     mk_predictions *R = nullptr;
-    if (mk_targetdb_create(tres.data(), toff.data(), (uint32_t) tdb.entries.size(), &P, &T) != MK_OK) return die("%s", mk_last_error());
     const double t1 = now();
     if (mk_extract_orfs(nucl.data(), off.data(), (uint32_t) ord.size(), minLength, &O) != MK_OK) return die("%s", mk_last_error());
     if (mk_queries_from_orfs(O, &P, &Q) != MK_OK) return die("%s", mk_last_error());
@@ -450,7 +482,7 @@ int cmdPredictExons(int argc, char **argv) {
     const mk_orf *orfs; const uint64_t *aaOff; const char *aa; uint64_t nOrfs = 0;
     mk_orfs_result(O, &orfs, &aaOff, &aa, &nOrfs);
     fprintf(stderr, "predictexons: %zu contigs -> %llu fragments x %zu targets -> %llu predictions; %.2f s (target index %.2f s, fragments to exon sets %.2f s)\n",
-            ord.size(), (unsigned long long) nOrfs, tdb.entries.size(), (unsigned long long) np, now() - t0, t1 - t0, t2 - t1);
+            ord.size(), (unsigned long long) nOrfs, tkeys.size(), (unsigned long long) np, now() - t0, t1 - t0, t2 - t1);
     mk_predictions_destroy(R);
     mk_queries_destroy(Q);
     mk_orfs_destroy(O);
@@ -458,11 +490,37 @@ int cmdPredictExons(int argc, char **argv) {
     return EXIT_SUCCESS;
 }
 
+// createindex <i:sequenceDB> <tmpDir> [-s 7.5 ...]   M/src/workflow/CreateIndex.cpp:108-175 -> indexdb (util/indexdb.cpp:42-186)
+//   masks the targets, builds the k-mer lists and writes <sequenceDB>.idx in the reference's index DB format (type 9); no GPU is
+//   involved.  The reference's `prefilter` / `search` pick the file up like one of their own; so do the commands above.
+int cmdCreateIndex(int argc, char **argv) {
+    Args a;
+    if (int rc = parse(argc, argv, a)) return rc;
+    if (a.pos.size() != 2) return die("usage: metaeuk-amd createindex <i:sequenceDB> <tmpDir> [options]%s");
+    mk_params P;
+    int gpu = 0;
+    if (a.opt.find("-s") == a.opt.end()) a.opt["-s"] = "7.5";           // CreateIndex.cpp:114
+    if (int rc = fillParams(a, P, gpu)) return rc;
+    const double t0 = now();
+    mk::Database db;
+    const std::string e = db.open(a.pos[0]);
+    if (!e.empty()) return die("%s", e);
+    const std::vector<size_t> ord = db.keyOrder();                     // DBReader NOSORT over a key-sorted .index (indexdb.cpp:67-68)
+    std::vector<uint32_t> keys(ord.size()), lens(ord.size());
+    std::vector<uint64_t> offs(ord.size());
+    for (size_t i = 0; i < ord.size(); i++) { keys[i] = db.entries[ord[i]].key; offs[i] = db.entries[ord[i]].offset; lens[i] = (uint32_t) db.entries[ord[i]].length; }
+    const std::string out = a.pos[0] + ".idx";
+    if (mk_index_write(out.c_str(), db.data.data(), db.data.size(), keys.data(), offs.data(), lens.data(), (uint32_t) ord.size(), db.dbtype, &P) != MK_OK)
+        return die("%s", mk_last_error());
+    fprintf(stderr, "createindex: %zu sequences -> %s, %.2f s\n", ord.size(), out.c_str(), now() - t0);
+    return EXIT_SUCCESS;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        fprintf(stderr, "metaeuk-amd: MI355X prefilter+align modules of `metaeuk predictexons`\n  metaeuk-amd prefilter <queryDB> <targetDB> <prefilterDB> [flags]\n  metaeuk-amd align <queryDB> <targetDB> <prefilterDB> <alignmentDB> [flags]\n  metaeuk-amd extractorfs <contigDB> <orfDB> [--min-length N] [--translate 0|1] [--aa-sibling NAME]\n  metaeuk-amd predictexons <contigsDB> <targetsDB> <calledExonsDB> <tmpDir> [flags]\n");
+        fprintf(stderr, "metaeuk-amd: MI355X prefilter+align modules of `metaeuk predictexons`\n  metaeuk-amd prefilter <queryDB> <targetDB> <prefilterDB> [flags]\n  metaeuk-amd align <queryDB> <targetDB> <prefilterDB> <alignmentDB> [flags]\n  metaeuk-amd extractorfs <contigDB> <orfDB> [--min-length N] [--translate 0|1] [--aa-sibling NAME]\n  metaeuk-amd predictexons <contigsDB> <targetsDB> <calledExonsDB> <tmpDir> [flags]\n  metaeuk-amd createindex <targetsDB> <tmpDir> [-s 7.5]\n");
         return EXIT_FAILURE;
     }
     const std::string cmd = argv[1];
@@ -470,6 +528,7 @@ int main(int argc, char **argv) {
     if (cmd == "align") return cmdPrefilterOrAlign(true, argc, argv);
     if (cmd == "extractorfs") return cmdExtractOrfs(argc, argv);
     if (cmd == "predictexons") return cmdPredictExons(argc, argv);
+    if (cmd == "createindex" || cmd == "indexdb") return cmdCreateIndex(argc, argv);
     fprintf(stderr, "Invalid Command: %s\n", cmd.c_str());
     return EXIT_FAILURE;
 }

@@ -250,8 +250,37 @@ int tantan_mask(const SubMat &km, uint8_t *seq, int L, double minMaskProb, int l
 
 // IndexBuilder::fillDatabase (M/src/prefiltering/IndexBuilder.cpp:55-239) + IndexTable::addKmerCount /
 // addSequence / sortDBSeqLists (M/src/prefiltering/IndexTable.h:133-173,348-401,182-189), AA targets, k=6.
+void kmer3_address_table(uint16_t addrOf[8000]) {
+    for (int k = 0; k < 8000; k++)
+        addrOf[k] = static_cast<uint16_t>(KMER_ADDR_LETTER[k % 20] + 20 * KMER_ADDR_LETTER[(k / 20) % 20] + 400 * KMER_ADDR_LETTER[k / 400]);
+}
+
+// k-mer lists in the reference's numbering -> in table-address order (what the device tables use)
+void index_to_address_order(TargetIndex &ix) {
+    const uint64_t TABLE = 64000000ull;
+    uint16_t addr3[8000];
+    kmer3_address_table(addr3);
+    std::vector<uint64_t> offsets(TABLE + 1, 0);
+#pragma omp parallel for schedule(static)
+    for (uint64_t hi = 0; hi < 8000; hi++)
+        for (uint64_t lo = 0; lo < 8000; lo++) {
+            const uint64_t k = lo + 8000 * hi, a = static_cast<uint64_t>(addr3[lo]) + 8000ull * addr3[hi];
+            offsets[a + 1] = ix.offsets[k + 1] - ix.offsets[k];
+        }
+    for (uint64_t a = 0; a < TABLE; a++) offsets[a + 1] += offsets[a];
+    std::vector<uint64_t> entries(ix.entries.size());
+#pragma omp parallel for schedule(static)
+    for (uint64_t hi = 0; hi < 8000; hi++)
+        for (uint64_t lo = 0; lo < 8000; lo++) {
+            const uint64_t k = lo + 8000 * hi, a = static_cast<uint64_t>(addr3[lo]) + 8000ull * addr3[hi];
+            std::copy(ix.entries.begin() + ix.offsets[k], ix.entries.begin() + ix.offsets[k + 1], entries.begin() + offsets[a]);
+        }
+    ix.offsets.swap(offsets);
+    ix.entries.swap(entries);
+}
+
 void build_index(const SubMat &km, const uint8_t *residues, const uint64_t *seqOff, uint32_t nSeq,
-                 int kmerThr, bool mask, float maskProb, int tantanLanes, TargetIndex &out) {
+                 int kmerThr, bool mask, float maskProb, int tantanLanes, TargetIndex &out, bool addressOrder) {
     const uint64_t TABLE = 64000000ull;
     const uint64_t total = seqOff[nSeq];
     out.masked.assign(residues, residues + total);
@@ -283,7 +312,7 @@ void build_index(const SubMat &km, const uint8_t *residues, const uint64_t *seqO
                     const uint8_t c = seq[i + SPACED6[p]];
                     hasX |= (c == XCODE);
                     score += self[c];
-                    idx += (c < 20 ? KMER_ADDR_LETTER[c] : 0) * pw;     // table address (k-mers with X are skipped below)
+                    idx += (c < 20 ? (addressOrder ? KMER_ADDR_LETTER[c] : c) : 0) * pw;     // table address or Indexer::int2index (k-mers with X are skipped below)
                     pw *= 20;
                 }
                 if (hasX || (kmerThr > 0 && score < kmerThr)) continue;

@@ -52,8 +52,12 @@ struct TargetIndex {
     std::vector<uint8_t> masked;     // masked residues (SequenceLookup)
     uint64_t maskedResidues = 0;
 };
+// addressOrder: lists ordered by the k-mers' device table address (mk_host.cpp, KMER_ADDR_LETTER); false = the reference's
+// Indexer numbering (what an index file holds)
 void build_index(const SubMat &kmerMat, const uint8_t *residues, const uint64_t *seqOff, uint32_t nSeq,
-                 int kmerThr, bool mask, float maskProb, int tantanLanes, TargetIndex &out);
+                 int kmerThr, bool mask, float maskProb, int tantanLanes, TargetIndex &out, bool addressOrder = true);
+void index_to_address_order(TargetIndex &ix);
+void kmer3_address_table(uint16_t addrOf[8000]);   // reference 3-mer number -> table address digits
 
 struct Evaluer {
     double lambda, K, logK, a_I, b_I, a_J, b_J, alpha_I, beta_I, alpha_J, beta_J, sigma, tau, vi_y_thr, vj_y_thr, c_y_thr, dbRes;

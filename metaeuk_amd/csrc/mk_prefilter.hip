@@ -797,7 +797,7 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &V, const uint64_t *hOff
             PCHK(sync_wait(stream, "wait_prefilter"));
             totalHits = X.hTotals[0];
             if (X.hTotals[1] != 0) { err = "a query overflows the reference's databaseHits buffer (QueryMatcher.cpp:281-316 is not restated)"; return MK_ERR_UNSUPPORTED; }
-            X.ts(thCount, 4.0 * (double) X.hTotals[2] + 8.0 * (double) totalHits + 1280.0 * (double) nPos, (double) X.hTotals[2]);   // bitmap word per k-mer, offset pair per non-empty k-mer, row heads per start
+            X.ts(thCount, 4.0 * (double) X.hTotals[2] + 8.0 * (double) totalHits + 1280.0 * (double) nPos, (double) X.hTotals[2]);   // bitmap word per k-mer, slot per non-empty k-mer, row heads per start
             hitsPerPos = std::max(1.0, (double) totalHits / (double) nPos);
             if (totalHits > HIT_CAP && q1 - q0 > 1) { q1 = q0 + (q1 - q0) / 2; continue; }
             // one 64-bit record per hit: query | target | low diagonal byte | arrival number within the query must fit
@@ -820,7 +820,7 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &V, const uint64_t *hOff
             A.V = V; A.pos_begin = hOff[q0]; A.pos_end = hOff[q1]; A.q_first = q0; A.seq_bits = X.seqBits; A.hit_bits = (uint32_t) hitBits;
             A.hit_count = dHit; A.kmer_count = dKmer; A.keys = dKeys; A.diag_hi = dDiagHi;
             const unsigned blocks = (unsigned) ((nPos + 3) / 4);
-            // gather pass: offset pairs again + 8 B per index entry read + 9 B (record, high diagonal byte) written per entry
+            // gather pass: slots again + 8 B per index entry read + 9 B (record, high diagonal byte) written per entry
             int th = X.tb("kmer_probe_gather", 4.0 * (double) X.hTotals[2] + 25.0 * (double) totalHits + 1280.0 * (double) nPos, (double) X.hTotals[2]);
             hipLaunchKernelGGL(probe_kernel<true>, dim3(blocks), dim3(256), 0, stream, A);
             X.te(th);
@@ -1031,7 +1031,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             if (hCounters[0] > CAND_CAP) rc = RC_CAND_OVERFLOW;
             else {
                 nCand = hCounters[0];
-                // algorithmic bytes of the fused launches: 4 B bitmap word per similar k-mer + 8 B offset pair per non-empty k-mer
+                // algorithmic bytes of the fused launches: 4 B bitmap word per similar k-mer + 8 B slot per non-empty k-mer
                 // (~ one per index hit) + 8 B per index entry + the row heads of every k-mer start (~1.3 KB)
                 for (int t = 0; t < N_TIERS; t++)
                     if (thFused[t] >= 0) {

@@ -17,7 +17,11 @@
 // compiled code.
 //
 // Modes:
-//   ref_harness pipeline <matdir> <targets.txt> <queries.txt> <outdir> [-s 5.7] [--threads N] [--dump]
+//   ref_harness pipeline <matdir> <targets.txt> <queries.txt> <outdir> [-s 5.7] [--threads N] [--dump] [--index <indexDB>]
+//     --index: the target side comes from a precomputed index DB through the reference's PrefilteringIndexReader (sequence DB,
+//     SequenceLookup, IndexTable, score matrices, seed matrix), the way Prefiltering.cpp:84-160,530-545 uses it; targets.txt is ignored
+//   ref_harness createindex <matdir> <seqDB> [-s 5.7]
+//     = indexdb (util/indexdb.cpp:67-186): PrefilteringIndexReader::createIndexFile over the sequence DB on disk -> <seqDB>.idx
 //   ref_harness sw       <matdir> <targets.txt> <queries.txt> <pairs.txt> <out.txt> [--dbres N]
 //   ref_harness submat   <matfile.out> <bitFactor> <bias>
 //   ref_harness exons    <targets.txt> <contigs.txt> <orfs.txt> <aln.txt> <out.txt>
@@ -46,6 +50,7 @@
 #include "Orf.h"
 #include "TranslateNucl.h"
 #include "PredictionParser.h"
+#include "PrefilteringIndexReader.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -61,6 +66,10 @@
 // Debug.h declares this global; the reference defines it in Application.cpp
 // (which pulls the whole CLI).  It is only the program name for messages.
 const char *binary_name = "ref_harness";
+// the application's other two globals (mmseqs.cpp:12-13, metaeuk.cpp:14): the generator string written into an index DB and the
+// index version it accepts (MMSEQS_CURRENT_INDEX_VERSION, MMseqsBase.cpp:6)
+const char *version = "ref_harness";
+const char *index_version_compatible = "16";
 
 static std::vector<std::string> readLines(const char *path) {
     std::vector<std::string> v;
@@ -129,6 +138,7 @@ static int cmdPipeline(int argc, char **argv) {
     bool dump = false;
     bool doAlign = true;
     size_t maxResListLen = 300;
+    std::string indexDb;
     for (int a = 6; a < argc; a++) {
         std::string s = argv[a];
         if (s == "-s") sensitivity = atof(argv[++a]);
@@ -136,6 +146,7 @@ static int cmdPipeline(int argc, char **argv) {
         else if (s == "--dump") dump = true;
         else if (s == "--no-align") doAlign = false;
         else if (s == "--max-seqs") maxResListLen = atol(argv[++a]);
+        else if (s == "--index") indexDb = argv[++a];
     }
     mkdir(outdir.c_str(), 0755);
     omp_set_num_threads(threads);
@@ -143,8 +154,17 @@ static int cmdPipeline(int argc, char **argv) {
     writeSeqDb(tdb, targets);
     writeSeqDb(qdb, queries);
 
-    DBReader<unsigned int> tdbr(tdb.c_str(), (tdb + ".index").c_str(), threads, DBReader<unsigned int>::USE_INDEX | DBReader<unsigned int>::USE_DATA);
-    tdbr.open(DBReader<unsigned int>::LINEAR_ACCCESS);
+    DBReader<unsigned int> *tidxdbr = NULL, *tdbrp = NULL;
+    if (!indexDb.empty()) {                                 // Prefiltering.cpp:84-96
+        tidxdbr = new DBReader<unsigned int>(indexDb.c_str(), (indexDb + ".index").c_str(), threads, DBReader<unsigned int>::USE_INDEX | DBReader<unsigned int>::USE_DATA);
+        tidxdbr->open(DBReader<unsigned int>::NOSORT);
+        if (!PrefilteringIndexReader::checkIfIndexFile(tidxdbr)) { fprintf(stderr, "Outdated index version\n"); return 3; }
+        tdbrp = PrefilteringIndexReader::openNewReader(tidxdbr, PrefilteringIndexReader::DBR1DATA, PrefilteringIndexReader::DBR1INDEX, true, threads, false, false);
+    } else {
+        tdbrp = new DBReader<unsigned int>(tdb.c_str(), (tdb + ".index").c_str(), threads, DBReader<unsigned int>::USE_INDEX | DBReader<unsigned int>::USE_DATA);
+        tdbrp->open(DBReader<unsigned int>::LINEAR_ACCCESS);
+    }
+    DBReader<unsigned int> &tdbr = *tdbrp;
     DBReader<unsigned int> qdbr(qdb.c_str(), (qdb + ".index").c_str(), threads, DBReader<unsigned int>::USE_INDEX | DBReader<unsigned int>::USE_DATA);
     qdbr.open(DBReader<unsigned int>::LINEAR_ACCCESS);
 
@@ -152,26 +172,41 @@ static int cmdPipeline(int argc, char **argv) {
     const size_t maxSeqLen = 65535;
     // Prefiltering.cpp:68-70
     std::string blosum = matdir + "/blosum62.out", vtml = matdir + "/VTML80.out";
+    // with an index: the seed matrix it carries ("VTML80.out:<text>", Prefiltering.cpp:151 + getSubstitutionMatrix)
+    if (tidxdbr) vtml = PrefilteringIndexReader::getSubstitutionMatrix(tidxdbr);
     BaseMatrix *kmerSubMat = new SubstitutionMatrix(vtml.c_str(), 8.0, -0.2f);
     BaseMatrix *ungappedSubMat = new SubstitutionMatrix(blosum.c_str(), 2.0, -0.2f);
     const int alphabetSize = kmerSubMat->alphabetSize;
     int kmerSize = IndexTable::computeKmerSize(tdbr.getAminoAcidDBSize());
+    if (tidxdbr) kmerSize = PrefilteringIndexReader::getMetadata(tidxdbr).kmerSize;
     const int kmerThr = kmerThreshold(sensitivity, kmerSize);
     maxResListLen = std::min(tdbr.getSize(), maxResListLen);
     double t0 = now();
     // Prefiltering.cpp:208-213
-    kmerSubMat->alphabetSize = kmerSubMat->alphabetSize - 1;
-    ScoreMatrix _2mer = ExtendedSubstitutionMatrix::calcScoreMatrix(*kmerSubMat, 2);
-    ScoreMatrix _3mer = ExtendedSubstitutionMatrix::calcScoreMatrix(*kmerSubMat, 3);
-    kmerSubMat->alphabetSize = alphabetSize;
+    ScoreMatrix _2mer, _3mer;
+    if (tidxdbr) {                                          // Prefiltering.cpp:197-206
+        _2mer = PrefilteringIndexReader::get2MerScoreMatrix(tidxdbr, Parameters::PRELOAD_MODE_MMAP);
+        _3mer = PrefilteringIndexReader::get3MerScoreMatrix(tidxdbr, Parameters::PRELOAD_MODE_MMAP);
+    } else {
+        kmerSubMat->alphabetSize = kmerSubMat->alphabetSize - 1;
+        _2mer = ExtendedSubstitutionMatrix::calcScoreMatrix(*kmerSubMat, 2);
+        _3mer = ExtendedSubstitutionMatrix::calcScoreMatrix(*kmerSubMat, 3);
+        kmerSubMat->alphabetSize = alphabetSize;
+    }
     double tExt = now() - t0;
     // Prefiltering.cpp:514-553
     t0 = now();
     SequenceLookup *sequenceLookup = NULL;
-    Sequence tseq(maxSeqLen, targetSeqType, kmerSubMat, kmerSize, true, true, true, "");
-    IndexTable *indexTable = new IndexTable(alphabetSize - 1, kmerSize, false);
-    IndexBuilder::fillDatabase(indexTable, &sequenceLookup, *kmerSubMat, _3mer, _2mer, &tseq, &tdbr, 0, tdbr.getSize(),
-                               kmerThr, true /*mask*/, false /*maskLowerCase*/, 0.9f /*maskProb*/, 0 /*maskNrepeats*/, 0 /*targetSearchMode*/);
+    IndexTable *indexTable = NULL;
+    if (tidxdbr) {                                          // Prefiltering.cpp:530-545
+        indexTable = PrefilteringIndexReader::getIndexTable(0, tidxdbr, Parameters::PRELOAD_MODE_MMAP);
+        sequenceLookup = PrefilteringIndexReader::getSequenceLookup(0, tidxdbr, Parameters::PRELOAD_MODE_MMAP);
+    } else {
+        Sequence tseq(maxSeqLen, targetSeqType, kmerSubMat, kmerSize, true, true, true, "");
+        indexTable = new IndexTable(alphabetSize - 1, kmerSize, false);
+        IndexBuilder::fillDatabase(indexTable, &sequenceLookup, *kmerSubMat, _3mer, _2mer, &tseq, &tdbr, 0, tdbr.getSize(),
+                                   kmerThr, true /*mask*/, false /*maskLowerCase*/, 0.9f /*maskProb*/, 0 /*maskNrepeats*/, 0 /*targetSearchMode*/);
+    }
     double tIndex = now() - t0;
 
     if (dump) {
@@ -319,6 +354,25 @@ static int cmdPipeline(int argc, char **argv) {
            "\"pref_hits\": %zu, \"kmers_per_pos\": %.4f, \"db_matches\": %zu, \"alignments\": %zu, \"passed\": %zu, \"cells_fwd\": %.0f}\n",
            queries.size(), targets.size(), qres, (size_t) tdbr.getAminoAcidDBSize(), kmerSize, kmerThr, threads, tExt, tIndex, tPref, tAln,
            totalHits, kmersPerPos / (double) nq, dbMatches, alignmentsNum, totalPassed, cellsFwd);
+    return 0;
+}
+
+// indexdb (util/indexdb.cpp:67-186) for an amino-acid sequence DB with predictexons' target-side settings
+static int cmdCreateIndex(int argc, char **argv) {
+    if (argc < 4) return 2;
+    std::string matdir = argv[2], db = argv[3];
+    float sensitivity = 5.7f;
+    for (int a = 4; a < argc; a++) if (std::string(argv[a]) == "-s") sensitivity = atof(argv[++a]);
+    DBReader<unsigned int> dbr(db.c_str(), (db + ".index").c_str(), 1, DBReader<unsigned int>::USE_INDEX | DBReader<unsigned int>::USE_DATA);
+    dbr.open(DBReader<unsigned int>::NOSORT);
+    std::string vtml = matdir + "/VTML80.out";
+    BaseMatrix *seedSubMat = new SubstitutionMatrix(vtml.c_str(), 8.0, -0.2f);
+    const int kmerSize = IndexTable::computeKmerSize(dbr.getAminoAcidDBSize());
+    const int kmerThr = kmerThreshold(sensitivity, kmerSize);
+    PrefilteringIndexReader::createIndexFile(PrefilteringIndexReader::indexName(db), &dbr, NULL, NULL, NULL, NULL, seedSubMat, 65535,
+                                             true, "", true, seedSubMat->alphabetSize, kmerSize, 1 /*maskMode*/, 0 /*maskLowerCase*/, 0.9f,
+                                             0 /*maskNrepeats*/, kmerThr, 0 /*targetSearchMode*/, 1 /*splits*/, 0 /*indexSubset*/);
+    printf("{\"index\": \"%s\", \"k\": %d, \"kmer_thr\": %d}\n", PrefilteringIndexReader::indexName(db).c_str(), kmerSize, kmerThr);
     return 0;
 }
 
@@ -544,6 +598,7 @@ static int cmdExons(int argc, char **argv) {
 }
 
 int main(int argc, char **argv) {
+    if (argc >= 2 && std::string(argv[1]) == "createindex") return cmdCreateIndex(argc, argv);
     if (argc < 2) { fprintf(stderr, "usage: ref_harness pipeline|sw|submat ...\n"); return 2; }
     std::string cmd = argv[1];
     if (cmd == "submat") return cmdSubmat(argc, argv);

@@ -546,3 +546,64 @@ def test_cli_predictexons_db_in_db_out(gpu_api, tmp_path):
     # a flag value this build does not implement is an error, not a silent default
     assert subprocess.call(cmd[:4] + [str(tmp_path / "calls2"), cmd[5], "--translation-table", "4"], stderr=subprocess.DEVNULL) != 0
     assert not os.path.exists(tmp_path / "calls2.dbtype")
+
+
+def test_targetdb_from_index_db(gpu_api, tmp_path):
+    """a target database opened from a createindex DB -- written by this library and, where the harness exists, by the
+    reference's own createIndexFile -- searches exactly like the one built from the sequences"""
+    import subprocess
+    from metaeuk_amd import synth
+    api = gpu_api
+    targets, queries = synth.make_workload(25, 300, seed=8)
+    targets, queries = list(targets), list(queries)
+    n = len(targets)
+    rs = random.Random(2)
+    order = list(range(n))
+    rs.shuffle(order)
+    keys = [3 * i + 1 for i in range(n)]
+    image = api.seq_db_image(targets, keys, order)
+    params = api.default_params()
+    api.index_write(str(tmp_path / "own.idx"), image, params)
+    idx = [str(tmp_path / "own.idx")]
+    if os.path.exists(oracle.REF):
+        api.write_seq_db(str(tmp_path / "T"), image)
+        subprocess.check_call([oracle.REF, "createindex", oracle.write_matrix_files(str(tmp_path / "mat")), str(tmp_path / "T"), "-s", "5.7"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        idx.append(str(tmp_path / "T.idx"))
+    db0 = api.TargetDB(targets, params)                             # ids = key order = what the index numbers
+    q0 = api.Queries(queries, params)
+    (h0, ho0), (a0, ao0) = api.search(db0, q0)
+    na = int(ao0[-1])
+    assert len(h0) > 300 and na > 50
+    for path in idx:
+        db = api.TargetDB.from_index(path, params)
+        assert db.n == n and list(db.keys) == keys
+        q = api.Queries(queries, params)
+        (h, ho), (a, ao) = api.search(db, q)
+        assert np.array_equal(np.asarray(ho), np.asarray(ho0)) and h.tobytes() == h0.tobytes(), path
+        assert np.array_equal(np.asarray(ao), np.asarray(ao0)) and api.format_alignments(a, 0, na) == api.format_alignments(a0, 0, na), path
+
+
+def test_cli_createindex_then_predictexons(gpu_api, tmp_path):
+    """`metaeuk-amd createindex` writes <targets>.idx; `predictexons` picks it up (and ignores it under MMSEQS_IGNORE_INDEX) with
+    the same called exons"""
+    import subprocess
+    from metaeuk_amd import build
+    targets, contigs = _lines("e2e_targets.txt.gz"), _lines("e2e_contigs.txt.gz")
+    _write_seq_db(str(tmp_path / "targets"), targets)
+    _write_seq_db(str(tmp_path / "contigs"), contigs)
+    (tmp_path / "contigs.dbtype").write_bytes((1).to_bytes(4, "little"))
+    subprocess.check_call([build.BIN, "createindex", str(tmp_path / "targets"), str(tmp_path / "tmp"), "-s", "5.7", "--threads", "4"])
+    assert open(tmp_path / "targets.idx.dbtype", "rb").read() == (9).to_bytes(4, "little")
+    common = ["-s", "5.7", "--ref-l2-bytes", "2097152", "--threads", "4"]
+    log = subprocess.run([build.BIN, "predictexons", str(tmp_path / "contigs"), str(tmp_path / "targets"), str(tmp_path / "calls_idx"), str(tmp_path / "tmp")] + common,
+                         check=True, stderr=subprocess.PIPE).stderr.decode()
+    env = dict(os.environ, MMSEQS_IGNORE_INDEX="1")
+    subprocess.check_call([build.BIN, "predictexons", str(tmp_path / "contigs"), str(tmp_path / "targets"), str(tmp_path / "calls_seq"), str(tmp_path / "tmp")] + common, env=env)
+    got_idx, got_seq = _read_result_db(str(tmp_path / "calls_idx")), _read_result_db(str(tmp_path / "calls_seq"))
+    exp = _text("e2e_exons_expected.txt.gz")
+    assert got_idx == got_seq
+    assert "".join(">%d\n%s" % (c, got_idx[c]) for c in range(len(contigs))) == exp
+    # the index DB itself as the target argument (what the search workflow passes on, blastp.sh)
+    subprocess.check_call([build.BIN, "predictexons", str(tmp_path / "contigs"), str(tmp_path / "targets.idx"), str(tmp_path / "calls_idx2"), str(tmp_path / "tmp")] + common)
+    assert _read_result_db(str(tmp_path / "calls_idx2")) == got_idx
