@@ -297,6 +297,8 @@ static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uin
     int rc = ensure_ready();
     if (rc) return rc;
     if (!residues || !offsets || !P || !out) return fail(MK_ERR_ARG, "null argument");
+    // IndexTable::computeKmerSize (IndexTable.h:439-449): from 3.35e9 target residues on the reference searches with k = 7
+    if (offsets[n] >= 3350000000ull) return fail(MK_ERR_UNSUPPORTED, "the target database has %llu residues: the reference switches to k = 7 at 3.35e9, only k = 6 is implemented", (unsigned long long) offsets[n]);
     mk_targetdb *db = new mk_targetdb();
     db->n = n;
     db->off.assign(offsets, offsets + n + 1);
@@ -385,6 +387,7 @@ int mk_index_write(const char *indexDb, const char *seqData, uint64_t seqDataSiz
     }
     std::vector<uint8_t> res;
     encode_seq_db(c.seqs, res, c.seqOffsets);
+    if (c.seqOffsets[n] >= 3350000000ull) return fail(MK_ERR_UNSUPPORTED, "the database has %llu residues: the reference indexes with k = 7 from 3.35e9 on, only k = 6 is implemented", (unsigned long long) c.seqOffsets[n]);
     mk::SubMat km;
     mk::build_submat(km, mk::MAT_VTML80, 8.0f, -0.2f);
     c.meta.kmerThr = mk::kmer_threshold(P->sensitivity, P->kmer_score);
