@@ -221,7 +221,7 @@ int run_sw_jobs(const mk_targetdb *db, const mk_queries *q, const mk_params *P, 
         L.q_res = q->dRes.p; L.q_bias8 = q->dBias8.p; L.t_res = db->dRes.p; L.mat = db->dMatAln.p;
         L.jobs = dJobs.p + lo; L.out = dOut.p; L.n_jobs = hi - lo; L.order = nullptr;
         L.boundary = nullptr; L.boundary_stride = 0; L.boundary_job0 = 0;
-        L.wave_start = nullptr; L.n_waves = 0; L.work_counter = nullptr; L.persistent_blocks = 0;
+        L.wave_start = nullptr; L.n_waves = 0; L.work_counter = nullptr; L.persistent_blocks = 0; L.units_per_block = 0;
         L.gap_open = P->gap_open; L.gap_extend = P->gap_extend;
         double cells = 0, bytes = 0;
         uint32_t maxT = 0; bool multi = false;
@@ -266,8 +266,15 @@ int mk_init(int device) {
     if (e != hipSuccess || count <= 0) return fail(MK_ERR_DEVICE, "no HIP device visible (%s)", hipGetErrorString(e));
     if (device < 0 || device >= count) return fail(MK_ERR_ARG, "device ordinal %d out of range (%d devices)", device, count);
     HIPCHK(hipSetDevice(device));
-    if (!g_stream) HIPCHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-    if (!g_stream2) HIPCHK(hipStreamCreateWithFlags(&g_stream2, hipStreamNonBlocking));
+    {
+        // two streams for the two stages of mk_search; MK_STREAM_PRIORITY=1: the prefilter's (latency-bound, few instructions) ahead
+        // of the alignment's in the dispatcher
+        int least = 0, greatest = 0;
+        const char *pr = getenv("MK_STREAM_PRIORITY");
+        const bool prio = pr && atoi(pr) != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
+        if (!g_stream) HIPCHK(prio ? hipStreamCreateWithPriority(&g_stream, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+        if (!g_stream2) HIPCHK(prio ? hipStreamCreateWithPriority(&g_stream2, hipStreamNonBlocking, least) : hipStreamCreateWithFlags(&g_stream2, hipStreamNonBlocking));
+    }
     g_device = device;
     g_ready = true;
     return MK_OK;

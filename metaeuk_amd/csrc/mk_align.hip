@@ -214,7 +214,7 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
         L.q_res = V.q_res; L.q_bias8 = V.q_bias8; L.t_res = V.t_res; L.mat = V.mat_aln;
         L.jobs = jobs; L.out = out; L.n_jobs = hi - lo; L.order = vb.Current() + lo;
         L.boundary = nullptr; L.boundary_stride = 0; L.boundary_job0 = 0;
-        L.wave_start = nullptr; L.n_waves = 0; L.work_counter = nullptr; L.persistent_blocks = 0;
+        L.wave_start = nullptr; L.n_waves = 0; L.work_counter = nullptr; L.persistent_blocks = 0; L.units_per_block = 0;
         L.gap_open = P.gap_open; L.gap_extend = P.gap_extend;
         if (c == SW_NCFG - 1 && V.max_q_len > (uint32_t) sw_cfg_rows(c)) {
             const uint32_t cls = KEY_CLS - 1 - (hb[32 + c] % KEY_CLS);          // largest target-length class in this bucket
@@ -254,6 +254,7 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const SwJob *j
     // or one per tile configuration, comma separated).  Half the wave slots for the small tiles; fewer for the tiles whose profiles are large, so
     // that the LDS-hungry prefilter workgroups of the other stream still find room on the CU.
     static uint32_t persistentBlocks[SW_NCFG] = {};
+    static uint32_t unitsPerBlock = 0;              // MK_SW_UNITS_PER_BLOCK: short-lived workgroups instead of the persistent launch
     if (!persistentBlocks[0]) {
         int dev = 0, cus = 256;
         (void) hipGetDevice(&dev);
@@ -270,6 +271,7 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const SwJob *j
             for (; k < SW_NCFG; k++) perCu[k] = last;
         }
         for (int c = 0; c < SW_NCFG; c++) persistentBlocks[c] = (uint32_t) (cus * perCu[c]);
+        if (const char *e = getenv("MK_SW_UNITS_PER_BLOCK")) unitsPerBlock = (uint32_t) std::max(0, atoi(e));
     }
     size_t t1 = 0, t2 = 0, t3 = 0;
     hipcub::CountingInputIterator<uint32_t> iota(0);
@@ -299,7 +301,7 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const SwJob *j
         L.jobs = jobs; L.out = out; L.n_jobs = hi - lo; L.order = vb.Current();      // wave_start holds absolute sorted positions
         L.boundary = nullptr; L.boundary_stride = 0; L.boundary_job0 = lo;
         L.wave_start = dWave + wlo; L.n_waves = whi - wlo;
-        L.work_counter = dWork + c; L.persistent_blocks = persistentBlocks[c];
+        L.work_counter = dWork + c; L.persistent_blocks = persistentBlocks[c]; L.units_per_block = unitsPerBlock;
         L.gap_open = P.gap_open; L.gap_extend = P.gap_extend;
         if (c == SW_NCFG - 1 && V.max_q_len > (uint32_t) sw_cfg_rows(c)) {
             // queries beyond the largest tile run in row tiles with an HBM border per job; the border is as long as the

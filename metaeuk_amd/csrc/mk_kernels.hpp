@@ -36,6 +36,7 @@ struct SwLaunch {
     const uint32_t *wave_start; uint64_t n_waves;
     uint32_t *work_counter;     // shared-query mode: zeroed device counter the persistent workgroups pull wave numbers from
     uint32_t persistent_blocks; // ... and how many workgroups to launch (0: one per wave)
+    uint32_t units_per_block;   // a workgroup retires after this many waves of jobs (0: runs until the counter is exhausted)
     uint64_t boundary_job0;     // job index that owns the first boundary_stride entries of `boundary`
 };
 

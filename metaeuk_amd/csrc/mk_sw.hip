@@ -197,7 +197,7 @@ template <int G, int R, int BLOCK, bool SHARED>
 __global__ __launch_bounds__(BLOCK) void sw_kernel(SwLaunch L) {
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     if constexpr (SHARED) {
-        for (;;) {
+        for (uint32_t done = 0; L.units_per_block == 0 || done < L.units_per_block; done++) {
             uint32_t u = 0;
             if (threadIdx.x == 0) u = atomicAdd(L.work_counter, 1u);
             u = (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
     int16_t *prof = reinterpret_cast<int16_t *>(smem);            // prof[t][row], int16; row 21 = zeros
     const int lane = threadIdx.x % G, grp = threadIdx.x / G;
     const pk16 go2 = pk_splat(L.gap_open), ge2 = pk_splat(L.gap_extend), zero2 = pk_splat(0);
-    for (;;) {
+    for (uint32_t done = 0; L.units_per_block == 0 || done < L.units_per_block; done++) {
         uint32_t u = 0;
         if (threadIdx.x == 0) u = atomicAdd(L.work_counter, 1u);
         u = (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
@@ -333,7 +333,8 @@ __global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
 hipError_t launch_sw_score(const SwLaunch &L, int cfg, hipStream_t stream) {
     if (!L.wave_start || !L.work_counter || !L.order || cfg < 0 || cfg >= SW_NCFG || !sw_cfg_packed(cfg)) return hipErrorInvalidValue;
     if (L.n_waves == 0) return hipSuccess;
-    const uint64_t grid = std::min<uint64_t>(L.n_waves, L.persistent_blocks ? L.persistent_blocks : L.n_waves);
+    const uint64_t grid = L.units_per_block ? (L.n_waves + L.units_per_block - 1) / L.units_per_block
+                                            : std::min<uint64_t>(L.n_waves, L.persistent_blocks ? L.persistent_blocks : L.n_waves);
     const int rows = sw_cfg_rows(cfg);
     const size_t lds = (size_t) 22 * (rows == 48 ? 64 : rows) * sizeof(int16_t);
     switch (rows) {
@@ -356,7 +357,8 @@ static hipError_t launch_one(const SwLaunch &L, hipStream_t stream) {
     if (L.wave_start) {                                     // one wave per workgroup, one profile per wave
         const size_t lds = (size_t) 22 * G * R;
         if (L.n_waves == 0) return hipSuccess;
-        const uint64_t grid = std::min<uint64_t>(L.n_waves, L.persistent_blocks ? L.persistent_blocks : L.n_waves);
+        const uint64_t grid = L.units_per_block ? (L.n_waves + L.units_per_block - 1) / L.units_per_block
+                                                : std::min<uint64_t>(L.n_waves, L.persistent_blocks ? L.persistent_blocks : L.n_waves);
         hipLaunchKernelGGL((sw_kernel<G, R, 64, true>), dim3((unsigned) grid), dim3(64), lds, stream, L);
         return hipGetLastError();
     }
