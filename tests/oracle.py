@@ -93,7 +93,8 @@ def run_ref_pipeline(targets, queries, outdir, extra=()):
     tf, qf = os.path.join(outdir, "targets.txt"), os.path.join(outdir, "queries.txt")
     open(tf, "w").write("\n".join(targets) + "\n")
     open(qf, "w").write("\n".join(queries) + "\n")
-    subprocess.check_call([REF, "pipeline", REF_MATDIR, tf, qf, os.path.join(outdir, "ref")] + list(extra),
+    matdir = REF_MATDIR if os.path.isdir(REF_MATDIR) else write_matrix_files(os.path.join(outdir, "mat"))   # no reference tree on a GPU box
+    subprocess.check_call([REF, "pipeline", matdir, tf, qf, os.path.join(outdir, "ref")] + list(extra),
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return read_blocks(os.path.join(outdir, "ref", "pref.txt")), read_blocks(os.path.join(outdir, "ref", "aln.txt"))
 

@@ -142,6 +142,30 @@ def test_pipeline_vs_oracle(gpu_api, small_workload, tmp_path, pf_path):
     assert int(hoff[-1]) > 100 and int(aoff[-1]) > 50
 
 
+@pytest.mark.parametrize("sens", [4.0, 7.5])
+def test_other_sensitivities_vs_oracle(gpu_api, small_workload, tmp_path, pf_path, sens):
+    """-s 4 (predictexons' own default) and -s 7.5 (createindex's): other k-mer thresholds -- at 7.5 a k-mer start has several
+    times the similar k-mers of 5.7 and the enumerator needs more than one step of first-half candidates -- through mk_search,
+    and where the harness exists against the reference's own code as well"""
+    targets, queries = small_workload
+    queries = queries[:600]
+    api = gpu_api
+    params = api.default_params()
+    params.sensitivity = sens
+    db = api.TargetDB(targets, params)
+    q = api.Queries(queries, params)
+    (hits, hoff), (alns, aoff) = api.search(db, q)
+    extra = ["--l2", str(params.host_l2_bytes), "-s", str(sens)]
+    opref, oaln = oracle.run_pipeline(targets, queries, str(tmp_path), extra=extra)
+    bad = [i for i in range(len(queries)) if api.format_hits(hits, int(hoff[i]), int(hoff[i + 1])) != opref[i]
+           or api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1])) != oaln[i]]
+    assert not bad, bad[:10]
+    assert int(hoff[-1]) > 50
+    if os.path.exists(oracle.REF):
+        rpref, raln = oracle.run_ref_pipeline(targets, queries, str(tmp_path), extra=["-s", str(sens), "--threads", "4"])
+        assert rpref == opref and raln == oaln
+
+
 # ---- golden fixtures (produced by the reference's own compiled code, tests/golden/make_golden.py) ----
 import gzip
 import os
