@@ -100,9 +100,21 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=400000, help="queries in the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
+    # the one JSON line goes to the real stdout; whatever libraries print there (RCCL's version banner at communicator creation) is
+    # sent to stderr instead
+    real_stdout = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # torch.distributed.run exports OMP_NUM_THREADS=1 to its workers unless the caller set the variable.  The host side of the path
+    # (result assembly, --max-seqs tie logic, e-value tables) is OpenMP code that the library sizes itself -- the cores this process
+    # may use divided by LOCAL_WORLD_SIZE (mk_init) -- so the launcher's placeholder is dropped; MK_HOST_THREADS pins it explicitly.
+    if world > 1 and os.environ.get("OMP_NUM_THREADS") == "1":
+        del os.environ["OMP_NUM_THREADS"]
+    if os.environ.get("MK_HOST_THREADS"):
+        os.environ["OMP_NUM_THREADS"] = os.environ["MK_HOST_THREADS"]
     dist = None
     if world > 1 or os.environ.get("MK_BENCH_FORCE_DIST"):      # the variable exercises the RCCL path on a single GPU
         import torch
@@ -212,7 +224,8 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(targets, queries, min(args.cpu_sample, nq), int(api.lib().mk_host_threads()))
             except Exception as e:  # the baseline is reported, never required
                 line["cpu_baseline"] = {"value": None, "unit": "fragments/s", "cores": os.cpu_count(), "kind": "reference", "sample": "failed: %r" % (e,)}
-        print(json.dumps(line))
+        real_stdout.write(json.dumps(line) + "\n")
+        real_stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 
