@@ -217,42 +217,54 @@ __global__ __launch_bounds__(256) void chunk_totals_kernel(const uint64_t *qOff,
 //   kept(t)    : low 8 bits of the diagonal equal those of the previous hit of the same (query,target);
 //                the first hit of a target is compared with 0 (duplicateBitArray starts zeroed)
 //   emitted(t) : kept(t) and the nearest earlier kept hit of the run has a different low byte (or none exists)
-__global__ __launch_bounds__(256) void double_hit_flag_kernel(const uint64_t *rec, uint32_t hitBits, uint32_t n, uint8_t *flag) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
+__device__ __forceinline__ bool double_hit_emits(const uint64_t *rec, uint32_t hitBits, uint32_t t) {
     const uint64_t r = rec[t] >> hitBits;
     const uint64_t group = r >> 8;
     const uint32_t lo = (uint32_t) r & 0xFFu;
     const uint64_t rp = t > 0 ? rec[t - 1] >> hitBits : 0;
     const bool samePrev = t > 0 && (rp >> 8) == group;
     const uint32_t prevLo = samePrev ? ((uint32_t) rp & 0xFFu) : 0u;
-    uint8_t emit = 0;
-    if (lo == prevLo) {
-        emit = 1;
-        if (samePrev) {
-            uint32_t u = t - 1;
-            while (true) {
-                const uint32_t ulo = (uint32_t) (rec[u] >> hitBits) & 0xFFu;
-                const uint64_t rq = u > 0 ? rec[u - 1] >> hitBits : 0;
-                const bool uSame = u > 0 && (rq >> 8) == group;
-                const uint32_t uprev = uSame ? ((uint32_t) rq & 0xFFu) : 0u;
-                if (ulo == uprev) { emit = (ulo != lo) ? 1 : 0; break; }
-                if (!uSame) break;
-                u--;
-            }
+    if (lo != prevLo) return false;
+    bool emit = true;
+    if (samePrev) {
+        uint32_t u = t - 1;
+        while (true) {
+            const uint32_t ulo = (uint32_t) (rec[u] >> hitBits) & 0xFFu;
+            const uint64_t rq = u > 0 ? rec[u - 1] >> hitBits : 0;
+            const bool uSame = u > 0 && (rq >> 8) == group;
+            const uint32_t uprev = uSame ? ((uint32_t) rq & 0xFFu) : 0u;
+            if (ulo == uprev) { emit = ulo != lo; break; }
+            if (!uSame) break;
+            u--;
         }
     }
-    flag[t] = emit;
+    return emit;
 }
 
-// selected sorted hits -> candidate arrays (appended at `base`); qMap translates the range-local query index
-// into the chunk-local one (null: qLocal + qAdd)
-__global__ __launch_bounds__(256) void cand_from_sorted_kernel(const uint64_t *rec, const uint8_t *diagHi, const uint32_t *sel, uint32_t n, uint32_t seqBits,
-                                                               uint32_t hitBits, const uint64_t *qOff, uint32_t qFirst, uint64_t posBegin, const uint32_t *hitScan,
-                                                               const uint32_t *qMap, uint32_t qAdd, CandArrays C, uint32_t base) {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
-    const uint64_t r = rec[sel[c]];
+// ordered compaction of the emitted records in two sweeps: candidates per 256-record block, (scan), then every block writes its
+// candidates behind those of the blocks before it -- runs of one (query, target) stay contiguous and in arrival order
+__global__ __launch_bounds__(256) void double_hit_count_kernel(const uint64_t *rec, uint32_t hitBits, uint32_t n, uint32_t *blockCount) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = __syncthreads_count(t < n && double_hit_emits(rec, hitBits, t));
+    if (threadIdx.x == 0) blockCount[blockIdx.x] = (uint32_t) c;
+}
+
+// second sweep: emitted records -> candidate arrays (appended at `base`); qMap translates the range-local query index into the
+// chunk-local one (null: qLocal + qAdd)
+__global__ __launch_bounds__(256) void double_hit_emit_kernel(const uint64_t *rec, const uint8_t *diagHi, const uint32_t *blockStart, uint32_t n, uint32_t seqBits,
+                                                              uint32_t hitBits, const uint64_t *qOff, uint32_t qFirst, uint64_t posBegin, const uint32_t *hitScan,
+                                                              const uint32_t *qMap, uint32_t qAdd, CandArrays C, uint32_t base) {
+    __shared__ uint32_t sWave[4];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+    const bool emit = t < n && double_hit_emits(rec, hitBits, t);
+    const unsigned long long m = __ballot(emit);
+    if (lane == 0) sWave[w] = (uint32_t) __popcll(m);
+    __syncthreads();
+    if (!emit) return;
+    uint32_t c = blockStart[blockIdx.x] + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+    for (int k = 0; k < w; k++) c += sWave[k];
+    const uint64_t r = rec[t];
     const uint32_t ord = (uint32_t) (r & ((1ull << hitBits) - 1));
     const uint64_t group = r >> (hitBits + 8);
     const uint32_t ql = (uint32_t) (group >> seqBits);
@@ -836,37 +848,36 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &V, const uint64_t *hOff
             th = X.tb("sort_hits", 16.0 * passes * (double) nHits, 0);
             PCHK(hipcub::DeviceRadixSort::SortKeys(temp, tempBytes, kb, (int) nHits, bit0, bit1, stream));
             X.te(th);
-            // double-hit rule -> flags -> ordered compaction
-            uint8_t *dFlag = (uint8_t *) dev_scratch("pf_flag", nHits);
-            uint32_t *dSel = (uint32_t *) dev_scratch("pf_sel", (size_t) nHits * 4);
-            uint32_t *dNum = (uint32_t *) dev_scratch("pf_num", 64);
-            PNULL(dFlag); PNULL(dSel); PNULL(dNum);
-            th = X.tb("double_hit", 9.0 * nHits, 0);
-            hipLaunchKernelGGL(double_hit_flag_kernel, dim3((nHits + 255) / 256), dim3(256), 0, stream, kb.Current(), (uint32_t) hitBits, nHits, dFlag);
-            X.te(th);
+            // double-hit rule, two sweeps: candidates per block -> scan -> ordered write into the candidate arrays
+            const uint32_t nBlocks = (nHits + 255) / 256;
+            uint32_t *dBlk = (uint32_t *) dev_scratch("pf_blk", ((size_t) nBlocks + 1) * 4);
+            uint32_t *dLastBlk = (uint32_t *) dev_scratch("pf_num", 64);
+            PNULL(dBlk); PNULL(dLastBlk);
+            th = X.tb("double_hit", 16.0 * nHits, 0);
+            hipLaunchKernelGGL(double_hit_count_kernel, dim3(nBlocks), dim3(256), 0, stream, kb.Current(), (uint32_t) hitBits, nHits, dBlk);
             PCHK(hipGetLastError());
+            PCHK(hipMemcpyAsync(dLastBlk, dBlk + (nBlocks - 1), 4, hipMemcpyDeviceToDevice, stream));
             {
-                hipcub::CountingInputIterator<uint32_t> iota(0);
                 size_t t2 = 0;
-                hipcub::DeviceSelect::Flagged(nullptr, t2, iota, dFlag, dSel, dNum, (int) nHits, stream);
+                hipcub::DeviceScan::ExclusiveSum(nullptr, t2, dBlk, dBlk, (int) nBlocks, stream);
                 temp = dev_scratch("pf_temp", t2);
                 PNULL(temp);
-                th = X.tb("select_candidates", 5.0 * nHits, 0);
-                PCHK(hipcub::DeviceSelect::Flagged(temp, t2, iota, dFlag, dSel, dNum, (int) nHits, stream));
-                X.te(th);
+                PCHK(hipcub::DeviceScan::ExclusiveSum(temp, t2, dBlk, dBlk, (int) nBlocks, stream));
             }
             uint32_t *hNum = (uint32_t *) pinned_scratch("pf_num_h", 64);
             PNULL(hNum);
-            PCHK(hipMemcpyAsync(hNum, dNum, 4, hipMemcpyDeviceToHost, stream));
+            PCHK(hipMemcpyAsync(hNum, dBlk + (nBlocks - 1), 4, hipMemcpyDeviceToHost, stream));
+            PCHK(hipMemcpyAsync(hNum + 1, dLastBlk, 4, hipMemcpyDeviceToHost, stream));
             PCHK(sync_wait(stream, "wait_prefilter"));
-            const uint32_t nSel = hNum[0];
-            if ((uint64_t) nCand + nSel > X.candCap) return RC_CAND_OVERFLOW;
+            const uint32_t nSel = hNum[0] + hNum[1];
+            if ((uint64_t) nCand + nSel > X.candCap) { X.te(th); return RC_CAND_OVERFLOW; }
             if (nSel > 0) {
-                hipLaunchKernelGGL(cand_from_sorted_kernel, dim3((nSel + 255) / 256), dim3(256), 0, stream, kb.Current(), dDiagHi, dSel, nSel, X.seqBits,
+                hipLaunchKernelGGL(double_hit_emit_kernel, dim3(nBlocks), dim3(256), 0, stream, kb.Current(), dDiagHi, dBlk, nHits, X.seqBits,
                                    (uint32_t) hitBits, V.q_off, q0, hOff[q0], dHit, qMap ? qMap + q0 : nullptr, qAddBase + q0, X.C, nCand);
                 PCHK(hipGetLastError());
                 nCand += nSel;
             }
+            X.te(th);
         }
         q0 = q1;
     }
