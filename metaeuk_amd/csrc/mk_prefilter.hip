@@ -213,6 +213,15 @@ __global__ __launch_bounds__(256) void chunk_totals_kernel(const uint64_t *qOff,
     atomicMax(&totals[3], (unsigned long long) (endv - scan[b]));
 }
 
+// first record of every query of a piece (+ the end): the exclusive hit scan at the query's first position
+__global__ __launch_bounds__(256) void segment_offsets_kernel(const uint64_t *qOff, uint32_t qFirst, uint32_t nq, uint64_t posBegin, uint64_t nPos,
+                                                             const uint32_t *hitScan, uint32_t nHits, uint32_t *seg) {
+    const uint32_t ql = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ql > nq) return;
+    const uint64_t p = ql == nq ? nPos : qOff[qFirst + ql] - posBegin;
+    seg[ql] = p >= nPos ? nHits : hitScan[p];                       // (empty queries at the end of the piece start at the end)
+}
+
 // findDuplicates (computeTotalScore == false) on the (query,target)-sorted hit stream.
 //   kept(t)    : low 8 bits of the diagonal equal those of the previous hit of the same (query,target);
 //                the first hit of a target is compared with 0 (duplicateBitArray starts zeroed)
@@ -765,7 +774,8 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &V, const uint64_t *hOff
             const int qBitsLeft = 64 - 8 - (int) X.seqBits - std::min(X.lastHitBits + 1, 31);
             // ... and what keeps the sorted (query, target) bits at a whole number of 8-bit radix passes, pieces of >= 8192 queries
             const int qBitsPass = (((int) X.seqBits + 13 + 7) / 8) * 8 - (int) X.seqBits;
-            const int qBitsCap = std::min(qBitsLeft, qBitsPass);
+            static const bool wholeSort = getenv("MK_PREFILTER_SEGSORT") && atoi(getenv("MK_PREFILTER_SEGSORT")) == 0;   // (only matters for the one-sort variant)
+            const int qBitsCap = wholeSort ? std::min(qBitsLeft, qBitsPass) : qBitsLeft;
             const uint32_t qCap = qBitsCap >= 20 ? QCAP : (qBitsCap < 1 ? 1u : (1u << qBitsCap));
             while (q1 < b && q1 - q0 < qCap && (hOff[q1 + 1] - hOff[q0] <= posBudget || q1 == q0)) q1++;
         }
@@ -837,17 +847,36 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &V, const uint64_t *hOff
             hipLaunchKernelGGL(probe_kernel<true>, dim3(blocks), dim3(256), 0, stream, A);
             X.te(th);
             PCHK(hipGetLastError());
-            // sort by (query, target): only those bits are sorted, the records of a pair stay in arrival order
-            const int bit0 = 8 + hitBits, bit1 = 8 + hitBits + (int) X.seqBits + qBits;
+            // sort by (query, target): only those bits are sorted, the records of a pair stay in arrival order.  The gather pass wrote the
+            // records query by query, so the sort is per query over the target bits alone (segments of ~20 K records stay in L2)
             hipcub::DoubleBuffer<uint64_t> kb(dKeys, dKeys2);
-            size_t tempBytes = 0;
-            hipcub::DeviceRadixSort::SortKeys(nullptr, tempBytes, kb, (int) nHits, bit0, bit1, stream);
-            void *temp = dev_scratch("pf_temp", tempBytes);
-            PNULL(temp);
-            const int passes = (bit1 - bit0 + 7) / 8;
-            th = X.tb("sort_hits", 16.0 * passes * (double) nHits, 0);
-            PCHK(hipcub::DeviceRadixSort::SortKeys(temp, tempBytes, kb, (int) nHits, bit0, bit1, stream));
-            X.te(th);
+            static const bool segSort = !getenv("MK_PREFILTER_SEGSORT") || atoi(getenv("MK_PREFILTER_SEGSORT")) != 0;
+            void *temp = nullptr;
+            if (segSort) {
+                const uint32_t nqc = q1 - q0;
+                uint32_t *dSeg = (uint32_t *) dev_scratch("pf_seg", ((size_t) nqc + 1) * 4);
+                PNULL(dSeg);
+                hipLaunchKernelGGL(segment_offsets_kernel, dim3((nqc + 256) / 256), dim3(256), 0, stream, V.q_off, q0, nqc, hOff[q0], nPos, dHit, nHits, dSeg);
+                PCHK(hipGetLastError());
+                const int bit0 = 8 + hitBits, bit1 = 8 + hitBits + (int) X.seqBits;
+                size_t tempBytes = 0;
+                hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, tempBytes, kb, (int) nHits, (int) nqc, dSeg, dSeg + 1, bit0, bit1, stream);
+                temp = dev_scratch("pf_temp", tempBytes);
+                PNULL(temp);
+                th = X.tb("sort_hits", 16.0 * (double) nHits, 0);
+                PCHK(hipcub::DeviceSegmentedRadixSort::SortKeys(temp, tempBytes, kb, (int) nHits, (int) nqc, dSeg, dSeg + 1, bit0, bit1, stream));
+                X.te(th);
+            } else {
+                const int bit0 = 8 + hitBits, bit1 = 8 + hitBits + (int) X.seqBits + qBits;
+                size_t tempBytes = 0;
+                hipcub::DeviceRadixSort::SortKeys(nullptr, tempBytes, kb, (int) nHits, bit0, bit1, stream);
+                temp = dev_scratch("pf_temp", tempBytes);
+                PNULL(temp);
+                const int passes = (bit1 - bit0 + 7) / 8;
+                th = X.tb("sort_hits", 16.0 * passes * (double) nHits, 0);
+                PCHK(hipcub::DeviceRadixSort::SortKeys(temp, tempBytes, kb, (int) nHits, bit0, bit1, stream));
+                X.te(th);
+            }
             // double-hit rule, two sweeps: candidates per block -> scan -> ordered write into the candidate arrays
             const uint32_t nBlocks = (nHits + 255) / 256;
             uint32_t *dBlk = (uint32_t *) dev_scratch("pf_blk", ((size_t) nBlocks + 1) * 4);
