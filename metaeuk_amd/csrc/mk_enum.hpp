@@ -153,7 +153,9 @@ __device__ __forceinline__ uint32_t enumerate_position(const PrefilterDeviceView
                 kmer[u] = 0;
                 if (has[u]) {
                     const uint32_t b = x - S.start[owner];
-                    kmer[u] = (uint32_t) S.idx0[owner] + (uint32_t) N3 * (uint32_t) i1[b];
+                    // table address: the first half picks the 8000-cell window, the second half the cell -- the lanes of a batch mostly share
+                    // their first half (product order: second half fastest), so their probes fall into a few cache lines of one window
+                    kmer[u] = (uint32_t) N3 * (uint32_t) S.idx0[owner] + (uint32_t) i1[b];
                 }
             }
             if (!onBatch(kmer, has)) return kmers;

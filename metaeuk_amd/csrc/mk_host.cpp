@@ -264,7 +264,7 @@ void index_to_address_order(TargetIndex &ix) {
 #pragma omp parallel for schedule(static)
     for (uint64_t hi = 0; hi < 8000; hi++)
         for (uint64_t lo = 0; lo < 8000; lo++) {
-            const uint64_t k = lo + 8000 * hi, a = static_cast<uint64_t>(addr3[lo]) + 8000ull * addr3[hi];
+            const uint64_t k = lo + 8000 * hi, a = static_cast<uint64_t>(addr3[hi]) + 8000ull * addr3[lo];
             offsets[a + 1] = ix.offsets[k + 1] - ix.offsets[k];
         }
     for (uint64_t a = 0; a < TABLE; a++) offsets[a + 1] += offsets[a];
@@ -272,7 +272,7 @@ void index_to_address_order(TargetIndex &ix) {
 #pragma omp parallel for schedule(static)
     for (uint64_t hi = 0; hi < 8000; hi++)
         for (uint64_t lo = 0; lo < 8000; lo++) {
-            const uint64_t k = lo + 8000 * hi, a = static_cast<uint64_t>(addr3[lo]) + 8000ull * addr3[hi];
+            const uint64_t k = lo + 8000 * hi, a = static_cast<uint64_t>(addr3[hi]) + 8000ull * addr3[lo];
             std::copy(ix.entries.begin() + ix.offsets[k], ix.entries.begin() + ix.offsets[k + 1], entries.begin() + offsets[a]);
         }
     ix.offsets.swap(offsets);
@@ -312,7 +312,8 @@ void build_index(const SubMat &km, const uint8_t *residues, const uint64_t *seqO
                     const uint8_t c = seq[i + SPACED6[p]];
                     hasX |= (c == XCODE);
                     score += self[c];
-                    idx += (c < 20 ? (addressOrder ? KMER_ADDR_LETTER[c] : c) : 0) * pw;     // table address or Indexer::int2index (k-mers with X are skipped below)
+                    // Indexer::int2index, or the table address: renumbered letters, and the FIRST 3-mer in the high digits (mk_enum.hpp)
+                    idx += (c < 20 ? (addressOrder ? KMER_ADDR_LETTER[c] * (p < 3 ? 8000u : 1u) * (p < 3 ? pw : pw / 8000u) : c * pw) : 0);
                     pw *= 20;
                 }
                 if (hasX || (kmerThr > 0 && score < kmerThr)) continue;

@@ -953,6 +953,8 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     int nTiersUsed = N_TIERS;                          // MK_PREFILTER_MAX_TIERS: leave the largest tier(s) to the global path
     if (const char *e = getenv("MK_PREFILTER_MAX_TIERS")) nTiersUsed = std::min(N_TIERS, std::max(1, atoi(e)));
     if (hooks.max_tiers > 0) nTiersUsed = std::min(nTiersUsed, hooks.max_tiers);
+    int firstTier = 0;                                 // MK_PREFILTER_FIRST_TIER: queries that would fit a smaller tier go to the global path
+    if (const char *e = getenv("MK_PREFILTER_FIRST_TIER")) firstTier = std::max(0, atoi(e));
     if (g_memo.entries != (const void *) V.entries || g_memo.nTargets != V.n_targets) { g_memo = SizingMemo(); g_memo.entries = V.entries; g_memo.nTargets = V.n_targets; }
     double candPerQuery = g_memo.candPerQuery, globalHitsPerPos = 0;
     static_assert(N_TIERS == 4, "SizingMemo holds four tiers");
@@ -1024,7 +1026,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                     const int npos = (int) (qOff[(size_t) q0 + ql + 1] - qOff[(size_t) q0 + ql]) - 9;
                     int t = 0;
                     while (t < nTiersUsed && (km > limit[t] || npos > fused_max_positions(tiers[t].cap))) t++;
-                    if (t == nTiersUsed) fallback.push_back(ql); else lists[t].push_back(q0 + ql);
+                    if (t == nTiersUsed || t < firstTier) fallback.push_back(ql); else lists[t].push_back(q0 + ql);
                 }
                 for (int t = 0; t < N_TIERS; t++) nListed += lists[t].size();
                 hList = (uint32_t *) pinned_scratch("pf_flist_h", std::max<size_t>(nListed, 1) * 4);
