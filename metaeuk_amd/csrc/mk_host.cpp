@@ -98,7 +98,8 @@ int bin_count_for(uint64_t dbSize, uint64_t l2) {
 // Where a k-mer lives in the device tables (presence bitmap, list slots, entry lists).  The reference's Indexer numbers a k-mer
 // sum(aa_i * 20^i); here the letters are first renumbered so that amino acids that substitute for each other are neighbours
 // (C | V I L M | F Y W | H | R K | Q E D N | S T A G P).  The similar k-mers of a query k-mer differ from it by exactly such
-// substitutions, so their table cells share 64-byte sectors instead of being spread over the table.  Only addresses change: rows
+// substitutions, so their table cells share 64-byte sectors instead of being spread over the table; and the FIRST 3-mer of a k-mer
+// sits in the high digits of its address, because the lanes of a probe batch mostly share it (mk_enum.hpp).  Only addresses change: rows
 // of the 3-mer score table are still looked up and ordered by the reference's numbering, so the enumeration order (and with it
 // the order in which hits arrive) is the reference's.
 static const uint8_t KMER_ADDR_LETTER[20] = {
