@@ -84,6 +84,8 @@ struct EnumLds {
     uint32_t start[ABLOCK];      // exclusive prefix of nb over the first-half candidates of the current step
     uint16_t idx0[ABLOCK];       // their 3-mer indices
     uint32_t cnt[U * WAVE];      // histogram of the inclusive prefixes over the current product window
+    uint16_t sec[WAVE];          // the 64 best second halves (table addresses): fetched with the row heads, one dependent load less for
+                                 // nearly every product (a first half rarely pairs with more than a few second halves)
 };
 
 // Calls onBatch(kmer[U], has[U]) for consecutive windows of U*64 products of the k-mer start whose residues are r[0..9]
@@ -98,6 +100,7 @@ __device__ __forceinline__ uint32_t enumerate_position(const PrefilterDeviceView
     const int R = V.hist_range, lo = V.hist_lo;
     const uint16_t *cum1 = V.cum3 + (size_t) idx1 * R;
     const int cutoff1 = thr - (int) V.score3[(size_t) idx1 * N3];   // first halves below this cannot reach the threshold
+    S.sec[lane] = i1[lane];
     uint32_t kmers = 0;
     for (uint32_t a0 = 0; a0 < (uint32_t) N3; a0 += ABLOCK) {
         // candidate a = a0 + j*64 + lane: (j, lane) ascending = a ascending
@@ -155,7 +158,7 @@ __device__ __forceinline__ uint32_t enumerate_position(const PrefilterDeviceView
                     const uint32_t b = x - S.start[owner];
                     // table address: the first half picks the 8000-cell window, the second half the cell -- the lanes of a batch mostly share
                     // their first half (product order: second half fastest), so their probes fall into a few cache lines of one window
-                    kmer[u] = (uint32_t) N3 * (uint32_t) S.idx0[owner] + (uint32_t) i1[b];
+                    kmer[u] = (uint32_t) N3 * (uint32_t) S.idx0[owner] + (uint32_t) (b < (uint32_t) WAVE ? S.sec[b] : i1[b]);
                 }
             }
             if (!onBatch(kmer, has)) return kmers;
