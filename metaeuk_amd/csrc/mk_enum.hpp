@@ -74,7 +74,7 @@ __device__ __forceinline__ void wave_deal_tail(uint32_t rem, int lane, uint8_t *
     }
 }
 
-constexpr int AJ = 4;                    // first-half candidates per lane and step
+constexpr int AJ = 2;                    // first-half candidates per lane and step
 constexpr int ABLOCK = AJ * WAVE;        // ... per step (one step covers almost every position: the dependent-load chain
                                          // of a position is rows -> cumulative counts -> second-half indices -> index probes)
 
