@@ -32,9 +32,9 @@ SW_OPS_PER_CELL = 10      # int32 kernel: add, min, max3, lshl_or, max, sub, sub
                           # 10 per PAIR of cells (perm, add, max, max, max, sub, sub, max, sub, max) -- priced at the int32 rate
 # HBM bytes per launch from the PMC passes (profiles/r01_pmc_hbm_traffic.txt), keyed by the bench's kernel names
 TRAFFIC_BYTES_PER_LAUNCH = {   # (FETCH_SIZE + WRITE_SIZE) KB x 1024, raw counter values, default workload, final round-1 build
-    "prefilter_fused_lds2048": (1014945 + 9517) * 1024, "prefilter_fused_lds4096": (2904577 + 14471) * 1024,
-    "prefilter_fused_lds8192": (10675171 + 35408) * 1024,
-    "kmer_probe_count": (30172043 + 111079) * 1024, "kmer_probe_gather": (37751806 + 4283147) * 1024,
+    "prefilter_fused_lds2048": (943449 + 9249) * 1024, "prefilter_fused_lds4096": (2746646 + 12944) * 1024,
+    "prefilter_fused_lds8192": (10129156 + 35347) * 1024,
+    "kmer_probe_count": (24991722 + 103882) * 1024, "kmer_probe_gather": (31999734 + 3940003) * 1024,
     "sw_fwd_rows32": (336422 + 33746) * 1024, "sw_fwd_rows48": (314477 + 32922) * 1024, "sw_fwd_rows64": (224260 + 23701) * 1024,
     "sw_fwd_rows96": (223861 + 23900) * 1024, "sw_fwd_rows128": (85757 + 9349) * 1024, "sw_fwd_rows192": (64843 + 6914) * 1024,
 }
