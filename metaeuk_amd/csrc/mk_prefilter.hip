@@ -21,8 +21,10 @@
 //     larger tier in the same stream, and by path B after the largest.  HBM traffic = the index probes, nothing else.
 //
 //  B. global path   (everything else: long queries, queries that overflow their LDS tier, big databases)
-//     probe_kernel<COUNT> -> exclusive scan -> probe_kernel<GATHER> (key = (query,target), value = (arrival,diagonal))
-//     -> stable radix sort (hipcub) -> double_hit_flag_kernel -> ordered compaction (hipcub select).
+//     probe_kernel<COUNT> -> exclusive scan -> probe_kernel<GATHER> (one 64-bit record per index hit: query | target | low
+//     diagonal byte | arrival number within the query, written query-major) -> per-query segmented radix sort over the target
+//     bits (hipcub; stable, so a pair's records stay in arrival order) -> double_hit_count_kernel -> block scan ->
+//     double_hit_emit_kernel (the rule evaluated twice instead of flag + select: candidates come out ordered).
 //
 // Common back end per chunk, everything in HBM, the host sees only the final hit lists:
 //     diag_score_kernel   exact ungapped score of every candidate
