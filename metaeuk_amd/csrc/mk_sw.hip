@@ -45,6 +45,13 @@ __device__ __forceinline__ uint32_t shift_up(uint32_t top, uint32_t x, int laneI
     }
 }
 
+// the same with zero for lane 0 of the group: within a DPP row the hardware's bound control supplies the zero
+template <int G>
+__device__ __forceinline__ uint32_t shift_up_zero(uint32_t x, int laneInGroup) {
+    if constexpr (G == 16) return (uint32_t) __builtin_amdgcn_update_dpp((int) x, (int) x, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+    else return shift_up<G>(0u, x, laneInGroup);
+}
+
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 
 template <int R>
@@ -271,25 +278,35 @@ __global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
 #pragma unroll
         for (int r = 0; r < R; r++) { H[r] = zero2; E[r] = zero2; }
         pk16 best = zero2, hupPrev = zero2;
-        uint32_t outH = 0, outF = 0, outRes = 21u | (21u << 8);    // handed to lane+1: H of the last row, F, the two residues
+        // what travels with a column is not the two residues but the byte offsets of their profile rows (residue * ROWS * 2, code 21 =
+        // "no column": an all-zero row), packed in one dword and prepared when the column is fetched -- nothing per step
+        constexpr uint32_t ROWB = (uint32_t) ROWS * 2u, NOCOL = 21u * ROWB | (21u * ROWB) << 16;
+        uint32_t outH = 0, outF = 0, outRes = NOCOL;              // handed to lane+1: H of the last row, F, the two profile-row offsets
         const int tMax = max(tLenA, tLenB);
-        const int steps = tMax > 0 ? tMax + G - 1 : 0;
+        // whole blocks of 16 steps (the steps past the last column see all-zero profile rows, which cannot raise the maximum): the
+        // block is unrolled, so the lane-to-lane hand-over needs no register copies and no loop control
+        const int steps = tMax > 0 ? (tMax + G - 1 + 15) & ~15 : 0;
         const int laneRow = lane & 15;                             // position in the DPP row (both rows of a 32-lane group fetch the same residues)
         const int lastA = max(tLenA - 1, 0), lastB = max(tLenB - 1, 0);
         const int64_t baseA = (int64_t) jobA.t_start, baseB = (int64_t) jobB.t_start, stepA = jobA.t_step, stepB = jobB.t_step;
-        uint32_t tnext = (uint32_t) L.t_res[baseA + (int64_t) min(laneRow, lastA) * stepA] | ((uint32_t) L.t_res[baseB + (int64_t) min(laneRow, lastB) * stepB] << 8);
+        const auto fetch = [&](int col) -> uint32_t {
+            const uint32_t ra = col < tLenA ? (uint32_t) L.t_res[baseA + (int64_t) min(col, lastA) * stepA] : 21u;
+            const uint32_t rb = col < tLenB ? (uint32_t) L.t_res[baseB + (int64_t) min(col, lastB) * stepB] : 21u;
+            return ra * ROWB | (rb * ROWB) << 16;
+        };
+        const char *profLane = reinterpret_cast<const char *>(prof + lane * RP);
+        uint32_t tnext = fetch(laneRow);
         for (int s0 = 0; s0 < steps; s0 += 16) {
             uint32_t tcur = tnext;
-            tnext = (uint32_t) L.t_res[baseA + (int64_t) min(s0 + 16 + laneRow, lastA) * stepA] | ((uint32_t) L.t_res[baseB + (int64_t) min(s0 + 16 + laneRow, lastB) * stepB] << 8);
-            const int sEnd = min(s0 + 16, steps);
-            for (int s = s0; s < sEnd; s++) {
-                const uint32_t resA = s < tLenA ? (tcur & 0xFFu) : 21u, resB = s < tLenB ? ((tcur >> 8) & 0xFFu) : 21u;
-                const uint32_t top = resA | (resB << 8);           // code 21 = "no column": an all-zero profile row
+            tnext = fetch(s0 + 16 + laneRow);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t top = tcur;
                 tcur = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) tcur, 0x12F /* row_ror:15 */, 0xf, 0xf, false);
-                const pk16 hup = pk_from(shift_up<G>(0u, outH, lane));
-                pk16 F = pk_from(shift_up<G>(0u, outF, lane));
+                const pk16 hup = pk_from(shift_up_zero<G>(outH, lane));
+                pk16 F = pk_from(shift_up_zero<G>(outF, lane));
                 const uint32_t tres = shift_up<G>(top, outRes, lane);
-                const int16_t *pa = prof + (tres & 0xFFu) * ROWS + lane * RP, *pb = prof + (tres >> 8) * ROWS + lane * RP;
+                const int16_t *pa = reinterpret_cast<const int16_t *>(profLane + (tres & 0xFFFFu)), *pb = reinterpret_cast<const int16_t *>(profLane + (tres >> 16));
                 uint32_t wa[RP / 2], wb[RP / 2];                   // R int16 scores per target, two per dword
 #pragma unroll
                 for (int k = 0; k < RP / 2; k++) { wa[k] = reinterpret_cast<const uint32_t *>(pa)[k]; wb[k] = reinterpret_cast<const uint32_t *>(pb)[k]; }
