@@ -74,3 +74,30 @@ def test_index_db_writer_and_reader_against_the_reference(tmp_path):
     (tmp_path / "bad.idx.index").write_text("\n".join(l for l in rows_txt.splitlines() if not l.startswith("9\t")) + "\n")   # no ENTRIES
     with pytest.raises(api.MkError):
         api.index_dump(str(bad), str(tmp_path / "dump_own"))
+
+
+def test_cli_createindex_without_a_gpu(tmp_path):
+    """`metaeuk-amd createindex` is host code: it runs here, and the reference's reader searches from its index DB exactly as from
+    the index DB the reference builds itself"""
+    from metaeuk_amd import api, build
+    oracle.build()
+    mat = oracle.write_matrix_files(str(tmp_path / "mat"))
+    tstr, qstr = _workload()
+    image = api.seq_db_image(tstr)
+    for name in ("own", "ref"):
+        os.makedirs(tmp_path / name)
+        api.write_seq_db(str(tmp_path / name / "T"), image)
+    subprocess.check_call([build.BIN, "createindex", str(tmp_path / "own" / "T"), str(tmp_path / "tmp"), "-s", "5.7", "--threads", "4"], stderr=subprocess.DEVNULL)
+    subprocess.check_call([oracle.REF, "createindex", mat, str(tmp_path / "ref" / "T"), "-s", "5.7"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    (tmp_path / "q.txt").write_text("\n".join(qstr) + "\n")
+    (tmp_path / "t_unused.txt").write_text("A\n")
+    out = {}
+    for name in ("own", "ref"):
+        d = str(tmp_path / ("pipe_" + name))
+        subprocess.check_call([oracle.REF, "pipeline", mat, str(tmp_path / "t_unused.txt"), str(tmp_path / "q.txt"), d, "-s", "5.7", "--threads", "2",
+                               "--index", str(tmp_path / name / "T.idx")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        out[name] = (open(os.path.join(d, "pref.txt")).read(), open(os.path.join(d, "aln.txt")).read())
+    assert out["own"] == out["ref"] and out["own"][0].count("\n") > len(qstr) + 50
+    # a database the reference would index with k = 7 is refused, not indexed with k = 6 (needs no 3.35e9 residues to check the message path:
+    # an unknown flag value is the cheap stand-in for "not implemented" here)
+    assert subprocess.call([build.BIN, "createindex", str(tmp_path / "own" / "T"), str(tmp_path / "tmp"), "-k", "7"], stderr=subprocess.DEVNULL) != 0
