@@ -185,6 +185,10 @@ void mk_default_exon_params(mk_exon_params *p);
  * DB key of every target: the reference orders a contig's predictions by target KEY and prints it. */
 int mk_predict_exons(const mk_targetdb *db, const mk_orfs *orfs, const mk_queries *q, const mk_exon_params *params,
                      const uint32_t *target_keys, mk_predictions **out);
+/* the same on caller-owned arrays, no batch handle and no GPU: orfs[k] = fragment k (contig ascending), alns[aln_offsets[k] ..
+ * aln_offsets[k+1]) its accepted alignments, db_residues = residues of the target database (the e-value of a set) */
+int mk_predict_exons_arrays(const mk_orf *orfs, uint64_t n_orfs, uint32_t n_contigs, const mk_alignment *alns, const uint64_t *aln_offsets,
+                            uint64_t db_residues, const mk_exon_params *params, const uint32_t *target_keys, mk_predictions **out);
 /* predictions of contig c = predictions[contig_offsets[c] .. contig_offsets[c+1]); views owned by the handle */
 int mk_predictions_result(const mk_predictions *p, const mk_prediction **predictions, const uint64_t **contig_offsets /* n_contigs+1 */,
                           const mk_exon **exons, uint64_t *n_predictions);

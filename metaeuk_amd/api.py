@@ -320,10 +320,26 @@ class Predictions:
         self.h = C.c_void_p()
         keys = None if target_keys is None else np.ascontiguousarray(target_keys, dtype=np.uint32)
         _chk(lib().mk_predict_exons(db.h, orfs.h, q.h, C.byref(self.params), None if keys is None else _p(keys), C.byref(self.h)))
+        self._views(orfs.n_contigs)
+
+    @classmethod
+    def from_arrays(cls, orfs, n_contigs, alns, aln_off, db_residues, params=None):
+        """host-only form: orfs = ORF_DTYPE array, alns = ctypes array of Alignment, aln_off = uint64[n_orfs + 1]"""
+        self = cls.__new__(cls)
+        self.params = params or default_exon_params()
+        self.h = C.c_void_p()
+        orfs = np.ascontiguousarray(orfs, dtype=ORF_DTYPE)
+        aln_off = np.ascontiguousarray(aln_off, dtype=np.uint64)
+        _chk(lib().mk_predict_exons_arrays(_p(orfs), C.c_uint64(len(orfs)), C.c_uint32(n_contigs), alns, _p(aln_off), C.c_uint64(db_residues),
+                                           C.byref(self.params), None, C.byref(self.h)))
+        self._views(n_contigs)
+        return self
+
+    def _views(self, n_contigs):
         pp, op, ep, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
         _chk(lib().mk_predictions_result(self.h, C.byref(pp), C.byref(op), C.byref(ep), C.byref(n)))
         self.n = int(n.value)
-        self.contig_off = np.ctypeslib.as_array(C.cast(op, C.POINTER(C.c_uint64)), shape=(orfs.n_contigs + 1,))
+        self.contig_off = np.ctypeslib.as_array(C.cast(op, C.POINTER(C.c_uint64)), shape=(n_contigs + 1,))
         if self.n:
             self.predictions = np.ctypeslib.as_array(C.cast(pp, C.POINTER(C.c_uint8)), shape=(self.n * PREDICTION_DTYPE.itemsize,)).view(PREDICTION_DTYPE)
             ne = int(self.predictions["first_exon"][-1] + self.predictions["n_exons"][-1])

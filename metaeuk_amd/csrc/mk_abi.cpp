@@ -625,6 +625,16 @@ int mk_predict_exons(const mk_targetdb *db, const mk_orfs *orfs, const mk_querie
     return MK_OK;
 }
 
+// the same on caller-owned arrays (no batch handle, no GPU): orfs[k] = fragment k, alns[aln_offsets[k] .. aln_offsets[k+1]) its alignments
+int mk_predict_exons_arrays(const mk_orf *orfs, uint64_t nOrfs, uint32_t nContigs, const mk_alignment *alns, const uint64_t *alnOffsets,
+                            uint64_t dbResidues, const mk_exon_params *P, const uint32_t *targetKeys, mk_predictions **out) {
+    if (!orfs || !alnOffsets || !P || !out || (!alns && alnOffsets[nOrfs] > 0)) return fail(MK_ERR_ARG, "null argument");
+    mk_predictions *p = new mk_predictions();
+    mk::predict_exons(orfs, nOrfs, nContigs, alns, alnOffsets, targetKeys, dbResidues, *P, p->preds, p->contigOff, p->exons);
+    *out = p;
+    return MK_OK;
+}
+
 int mk_predictions_result(const mk_predictions *p, const mk_prediction **preds, const uint64_t **contigOff, const mk_exon **exons, uint64_t *n) {
     if (!p || !preds || !contigOff || !exons || !n) return fail(MK_ERR_ARG, "null argument");
     *preds = p->preds.data(); *contigOff = p->contigOff.data(); *exons = p->exons.data(); *n = p->preds.size();
