@@ -57,7 +57,7 @@ const Flag FLAGS[] = {
     {"--min-exon-aa", "11", true}, {"--max-overlap", "10", true}, {"--max-exon-sets", "1", true}, {"--set-gap-open", "-1", true},
     {"--set-gap-extend", "-1", true},
     // properties of the reference build/host being reproduced (see mk_params in the ABI header)
-    {"--ref-simd", "avx2", true}, {"--ref-l2-bytes", "", true}, {"--gpu", "0", true},
+    {"--ref-simd", "avx2", true}, {"--ref-l2-bytes", "", true}, {"--gpu", "0", true}, {"--shard", "", true},
 };
 
 int die(const char *fmt, const std::string &a = "") {
@@ -210,6 +210,35 @@ int openTarget(const std::string &path, const mk_params &P, TargetSide &ts) {
     return 0;
 }
 
+// One process per GPU over one query DB: worker `rank` of `world` takes the reference's residue-balanced query range
+// and writes <out>_<rank>; worker 0 waits for the other shards (their .dbtype is written last) and merges them into <out>.  No
+// collective: the workers only meet in the file system.  --shard r/N, else RANK / WORLD_SIZE of the launcher (torch.distributed.run,
+// the RUNNER hook of blastp.sh:70,85).
+struct Shard { int rank = 0, world = 1; };
+int shardOf(const Args &a, Shard &sh) {
+    auto it = a.opt.find("--shard");
+    if (it != a.opt.end() && !it->second.empty()) {
+        if (sscanf(it->second.c_str(), "%d/%d", &sh.rank, &sh.world) != 2) return die("--shard wants rank/world, got %s", it->second);
+    } else if (getenv("RANK") && getenv("WORLD_SIZE")) {
+        sh.rank = atoi(getenv("RANK")); sh.world = atoi(getenv("WORLD_SIZE"));
+    }
+    if (sh.world < 1 || sh.rank < 0 || sh.rank >= sh.world) return die("bad shard %s", std::to_string(sh.rank) + "/" + std::to_string(sh.world));
+    return 0;
+}
+int finishShards(const std::string &out, const Shard &sh, int dbtype) {
+    if (sh.world <= 1 || sh.rank != 0) return EXIT_SUCCESS;
+    for (int r = 1; r < sh.world; r++) {
+        const std::string marker = out + "_" + std::to_string(r) + ".dbtype";
+        for (long waited = 0; !mk::Database::exists(marker); waited++) {
+            if (waited == 20L * 3600L * 24L) return die("gave up waiting for %s", marker);
+            usleep(50000);
+        }
+    }
+    const std::string e = mk::mergeShards(out, sh.world, dbtype);
+    if (!e.empty()) return die("%s", e);
+    return EXIT_SUCCESS;
+}
+
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int cmdPrefilterOrAlign(bool isAlign, int argc, char **argv) {
@@ -229,6 +258,16 @@ int cmdPrefilterOrAlign(bool isAlign, int argc, char **argv) {
     std::string e = qdb.open(a.pos[0]);
     if (!e.empty()) return die("%s", e);
     if ((qdb.dbtype & 0xFFFF) != mk::DBTYPE_AMINO_ACIDS) return die("only amino-acid query databases are implemented%s");
+    Shard sh;
+    if (int rc = shardOf(a, sh)) return rc;
+    if (sh.world > 1) {                                       // this worker's queries only
+        size_t first = 0, count = 0;
+        mk::decomposeByLength(qdb.entries, sh.rank, sh.world, first, count);
+        qdb.entries.erase(qdb.entries.begin() + (std::ptrdiff_t) (first + count), qdb.entries.end());
+        qdb.entries.erase(qdb.entries.begin(), qdb.entries.begin() + (std::ptrdiff_t) first);
+    }
+    const std::string outBase = a.pos[isAlign ? 3 : 2];
+    const std::string outPath = sh.world > 1 ? outBase + "_" + std::to_string(sh.rank) : outBase;
     if (mk_init(gpu) != MK_OK) return die("%s", mk_last_error());
     std::vector<uint8_t> qres;
     std::vector<uint64_t> qoff;
@@ -246,7 +285,7 @@ int cmdPrefilterOrAlign(bool isAlign, int argc, char **argv) {
         if (mk_prefilter(T, Q, &P) != MK_OK) return die("%s", mk_last_error());
         const mk_hit *hits; const uint64_t *hoff;
         mk_prefilter_result(Q, &hits, &hoff);
-        mk::DatabaseWriter w(a.pos[2], mk::DBTYPE_PREFILTER_RES);
+        mk::DatabaseWriter w(outPath, mk::DBTYPE_PREFILTER_RES);
         e = w.open();
         if (!e.empty()) return die("%s", e);
         for (size_t i = 0; i < nq; i++) {
@@ -269,7 +308,10 @@ int cmdPrefilterOrAlign(bool isAlign, int argc, char **argv) {
         std::vector<std::vector<mk_hit>> perQ(nq);
         for (size_t i = 0; i < pdb.entries.size(); i++) {
             auto qi = qKeyToIdx.find(pdb.entries[i].key);
-            if (qi == qKeyToIdx.end()) return die("Query sequence %s is required in the prefiltering, but is not contained in the query sequence database", std::to_string(pdb.entries[i].key));
+            if (qi == qKeyToIdx.end()) {
+                if (sh.world > 1) continue;                      // another worker's query
+                return die("Query sequence %s is required in the prefiltering, but is not contained in the query sequence database", std::to_string(pdb.entries[i].key));
+            }
             const char *p = pdb.entry(i);
             while (*p != '\0') {
                 char *q;
@@ -293,7 +335,7 @@ int cmdPrefilterOrAlign(bool isAlign, int argc, char **argv) {
         if (mk_align(T, Q, &P) != MK_OK) return die("%s", mk_last_error());
         const mk_alignment *alns; const uint64_t *aoff;
         mk_align_result(Q, &alns, &aoff);
-        mk::DatabaseWriter w(a.pos[3], mk::DBTYPE_ALIGNMENT_RES);
+        mk::DatabaseWriter w(outPath, mk::DBTYPE_ALIGNMENT_RES);
         e = w.open();
         if (!e.empty()) return die("%s", e);
         for (size_t i = 0; i < nq; i++) {
@@ -311,7 +353,7 @@ int cmdPrefilterOrAlign(bool isAlign, int argc, char **argv) {
     }
     mk_queries_destroy(Q);
     mk_targetdb_destroy(T);
-    return EXIT_SUCCESS;
+    return finishShards(outBase, sh, isAlign ? mk::DBTYPE_ALIGNMENT_RES : mk::DBTYPE_PREFILTER_RES);
 }
 
 // extractorfs <i:contigDB> <o:orfDB> [--min-length 15] [--translate 0|1] [--aa-sibling NAME] [--gpu N]
@@ -526,6 +568,24 @@ int main(int argc, char **argv) {
     const std::string cmd = argv[1];
     if (cmd == "prefilter") return cmdPrefilterOrAlign(false, argc, argv);
     if (cmd == "align") return cmdPrefilterOrAlign(true, argc, argv);
+    if (cmd == "shardinfo" && argc >= 4) {                       // <db> r/N: the worker's entry range (first, count) -- for tests and scripts
+        mk::Database db;
+        const std::string e = db.open(argv[2]);
+        if (!e.empty()) return die("%s", e);
+        int r = 0, n = 1;
+        if (sscanf(argv[3], "%d/%d", &r, &n) != 2 || n < 1 || r < 0 || r >= n) return die("bad shard %s", argv[3]);
+        size_t first = 0, count = 0;
+        mk::decomposeByLength(db.entries, r, n, first, count);
+        printf("%zu %zu\n", first, count);
+        return EXIT_SUCCESS;
+    }
+    if (cmd == "mergeshards" && argc >= 5) {                     // <out> <n> <dbtype>: merge <out>_0 .. <out>_{n-1} by hand
+        const std::string e = mk::mergeShards(argv[2], atoi(argv[3]), atoi(argv[4]));
+        if (!e.empty()) return die("%s", e);
+        return EXIT_SUCCESS;
+    }
+    // the other commands are not sharded: under a multi-process launcher worker 0 does the job
+    if (getenv("RANK") && atoi(getenv("RANK")) > 0) return EXIT_SUCCESS;
     if (cmd == "extractorfs") return cmdExtractOrfs(argc, argv);
     if (cmd == "predictexons") return cmdPredictExons(argc, argv);
     if (cmd == "createindex" || cmd == "indexdb") return cmdCreateIndex(argc, argv);

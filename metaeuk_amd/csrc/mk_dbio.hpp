@@ -128,4 +128,73 @@ struct DatabaseWriter {
     }
 };
 
+// DBReader::decomposeDomainByAminoAcid (DBReader.cpp:1216-1257): the contiguous entry range of worker `rank` of `world` when the
+// entries (lengths as in the index, in processing order) are dealt out in chunks of ceil(total / world) bytes
+inline void decomposeByLength(const std::vector<DbEntry> &entries, int rank, int world, size_t &start, size_t &count) {
+    const size_t n = entries.size();
+    start = 0; count = n;
+    if (world <= 1) return;
+    if (n <= (size_t) world) { start = (size_t) rank < n ? (size_t) rank : 0; count = (size_t) rank < n ? 1 : 0; return; }
+    uint64_t total = 0;
+    for (const DbEntry &e : entries) total += e.length;
+    const uint64_t chunk = (total + (uint64_t) world - 1) / (uint64_t) world;
+    std::vector<size_t> per((size_t) world, 0);
+    size_t w = 0;
+    uint64_t acc = 0;
+    for (const DbEntry &e : entries) {
+        if (acc >= chunk) { acc = 0; w++; }
+        acc += e.length;
+        per[w]++;
+    }
+    start = 0;
+    for (int r = 0; r < rank; r++) start += per[(size_t) r];
+    count = per[(size_t) rank];
+}
+
+// DBWriter::mergeResults (DBWriter.cpp:531-623) over the result DBs <out>_0 .. <out>_{n-1} the workers wrote: data files back to
+// back, index offsets rebased, index sorted by key; the shards are removed.  "" on success.
+inline std::string mergeShards(const std::string &out, int n, int dbtype) {
+    remove((out + ".dbtype").c_str());
+    FILE *d = fopen(out.c_str(), "wb");
+    if (!d) return "cannot create " + out;
+    std::vector<DbEntry> index;
+    uint64_t base = 0;
+    for (int r = 0; r < n; r++) {
+        const std::string shard = out + "_" + std::to_string(r);
+        std::vector<char> data, idx;
+        if (!Database::slurp(shard, data) || !Database::slurp(shard + ".index", idx)) { fclose(d); return "cannot read shard " + shard; }
+        if (!data.empty() && fwrite(data.data(), 1, data.size(), d) != data.size()) { fclose(d); return "cannot write " + out; }
+        const char *p = idx.data(), *end = idx.data() + idx.size();
+        while (p < end) {
+            char *q;
+            DbEntry e;
+            e.key = (uint32_t) strtoul(p, &q, 10);
+            if (q == p) break;
+            e.offset = strtoull(q, &q, 10) + base;
+            e.length = strtoull(q, &q, 10);
+            index.push_back(e);
+            p = q;
+            while (p < end && *p != '\n') p++;
+            if (p < end) p++;
+        }
+        base += data.size();
+    }
+    if (fclose(d) != 0) return "cannot close " + out;
+    std::stable_sort(index.begin(), index.end(), [](const DbEntry &a, const DbEntry &b) { return a.key < b.key; });
+    FILE *i = fopen((out + ".index").c_str(), "wb");
+    if (!i) return "cannot create " + out + ".index";
+    for (const DbEntry &e : index) fprintf(i, "%u\t%llu\t%llu\n", e.key, (unsigned long long) e.offset, (unsigned long long) e.length);
+    if (fclose(i) != 0) return "cannot close " + out + ".index";
+    for (int r = 0; r < n; r++) {
+        const std::string shard = out + "_" + std::to_string(r);
+        remove(shard.c_str()); remove((shard + ".index").c_str()); remove((shard + ".dbtype").c_str());
+    }
+    FILE *t = fopen((out + ".dbtype").c_str(), "wb");
+    if (!t) return "cannot create " + out + ".dbtype";
+    const int32_t v = dbtype;
+    fwrite(&v, 4, 1, t);
+    if (fclose(t) != 0) return "cannot close " + out + ".dbtype";
+    return "";
+}
+
 }  // namespace mk

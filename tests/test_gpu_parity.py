@@ -631,3 +631,34 @@ def test_cli_createindex_then_predictexons(gpu_api, tmp_path):
     # the index DB itself as the target argument (what the search workflow passes on, blastp.sh)
     subprocess.check_call([build.BIN, "predictexons", str(tmp_path / "contigs"), str(tmp_path / "targets.idx"), str(tmp_path / "calls_idx2"), str(tmp_path / "tmp")] + common)
     assert _read_result_db(str(tmp_path / "calls_idx2")) == got_idx
+
+
+def test_cli_two_workers_share_the_queries(gpu_api, tmp_path):
+    """`prefilter` and `align` as two workers (RANK / WORLD_SIZE of a launcher, both on this GPU): each takes its residue-balanced
+    query range and writes its shard, worker 0 merges -- same DBs as the single-process run, no collective anywhere"""
+    import subprocess
+    from metaeuk_amd import build, shard, synth
+    targets, queries = synth.make_workload(6, 300, seed=12)
+    targets, queries = list(targets), list(queries)
+    _write_seq_db(str(tmp_path / "q"), queries, [2 * i + 7 for i in range(len(queries))])
+    _write_seq_db(str(tmp_path / "t"), targets)
+    flags = ["-s", "5.7", "--ref-l2-bytes", "2097152", "--threads", "2", "--gpu", "0"]
+    def run(cmd, out, world):
+        procs = []
+        for r in range(world):
+            env = dict(os.environ)
+            if world > 1:
+                env.update(RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen([build.BIN] + cmd + [out] + flags, env=env, stderr=subprocess.DEVNULL))
+        assert all(p.wait() == 0 for p in procs)
+    run(["prefilter", str(tmp_path / "q"), str(tmp_path / "t")], str(tmp_path / "pref1"), 1)
+    run(["prefilter", str(tmp_path / "q"), str(tmp_path / "t")], str(tmp_path / "pref2"), 2)
+    p1, p2 = shard.read_result_db(str(tmp_path / "pref1")), shard.read_result_db(str(tmp_path / "pref2"))
+    assert p1 == p2 and len(p1) == len(queries) and sum(len(v) for v in p1.values()) > 1000
+    assert not os.path.exists(tmp_path / "pref2_0") and not os.path.exists(tmp_path / "pref2_1.dbtype")
+    aflags = ["-e", "100", "--min-aln-len", "11"]
+    run(["align", str(tmp_path / "q"), str(tmp_path / "t"), str(tmp_path / "pref1")] + aflags, str(tmp_path / "res1"), 1)
+    run(["align", str(tmp_path / "q"), str(tmp_path / "t"), str(tmp_path / "pref2")] + aflags, str(tmp_path / "res2"), 2)
+    a1, a2 = shard.read_result_db(str(tmp_path / "res1")), shard.read_result_db(str(tmp_path / "res2"))
+    assert a1 == a2 and len(a1) == len(queries) and sum(len(v) for v in a1.values()) > 300
+    assert open(tmp_path / "res2.dbtype", "rb").read() == (5).to_bytes(4, "little")

@@ -65,3 +65,27 @@ def test_decompose_matches_reference_rule():
         s, n = shard.decompose_by_residues(big, r, 8)
         cover += list(range(s, s + n))
     assert cover == list(range(1000))
+
+
+def test_cli_shard_rule_and_merge(tmp_path):
+    """the CLI's worker ranges follow the same reference rule as shard.py, and `mergeshards` is DBWriter::mergeResults"""
+    import random
+    import subprocess
+    from metaeuk_amd import build, shard
+    rs = random.Random(9)
+    lens = [rs.randint(1, 400) for _ in range(137)]
+    base = str(tmp_path / "q")
+    shard.write_result_db(base, [(3 * i + 1, "A" * (l - 1)) for i, l in enumerate(lens)], 0)     # entry length = text + NUL
+    for world in (1, 2, 3, 8):
+        for rank in range(world):
+            out = subprocess.check_output([build.BIN, "shardinfo", base, "%d/%d" % (rank, world)]).decode().split()
+            assert (int(out[0]), int(out[1])) == shard.decompose_by_residues(lens, rank, world)
+    # three shards with interleaved keys -> one DB, index sorted by key, shards removed
+    items = [(k, "entry %d\n" % k) for k in range(40)]
+    rs.shuffle(items)
+    for r in range(3):
+        shard.write_result_db(str(tmp_path / ("res_%d" % r)), items[r::3], 5)
+    subprocess.check_call([build.BIN, "mergeshards", str(tmp_path / "res"), "3", "5"])
+    assert shard.read_result_db(str(tmp_path / "res")) == dict(items)
+    assert [int(l.split("\t")[0]) for l in open(tmp_path / "res.index")] == list(range(40))
+    assert open(tmp_path / "res.dbtype", "rb").read() == (5).to_bytes(4, "little") and not os.path.exists(tmp_path / "res_1")
