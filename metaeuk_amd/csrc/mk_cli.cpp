@@ -455,6 +455,7 @@ int cmdExtractOrfs(int argc, char **argv) {
 //   the whole workflow in one process: extractorfs + translatenucs + search (prefilter, align) + resultspercontig +
 //   collectoptimalset, with nothing written between the stages.  Output = the dp_predictions DB the script moves to <o> (:96): one
 //   record per contig (key = contig key, empty when nothing was predicted), one line per exon.  tmpDir is accepted and not used.
+//   Under a multi-process launcher the contigs are split over the workers like the queries of prefilter / align.
 int cmdPredictExons(int argc, char **argv) {
     Args a;
     if (int rc = parse(argc, argv, a)) return rc;
@@ -485,7 +486,18 @@ int cmdPredictExons(int argc, char **argv) {
     if (!e.empty()) return die("%s", e);
     if (mk_init(gpu) != MK_OK) return die("%s", mk_last_error());
     // contigs by ascending key: the order in which createRenumberedDB numbers their fragments (extractorfs.cpp:140-155)
-    const std::vector<size_t> ord = contigs.keyOrder();
+    std::vector<size_t> ord = contigs.keyOrder();
+    Shard sh;
+    if (int rc = shardOf(a, sh)) return rc;
+    if (sh.world > 1) {                                           // this worker's contigs (a contiguous range of the key order)
+        std::vector<mk::DbEntry> inOrder(ord.size());
+        for (size_t i = 0; i < ord.size(); i++) inOrder[i] = contigs.entries[ord[i]];
+        size_t first = 0, count = 0;
+        mk::decomposeByLength(inOrder, sh.rank, sh.world, first, count);
+        ord = std::vector<size_t>(ord.begin() + (std::ptrdiff_t) first, ord.begin() + (std::ptrdiff_t) (first + count));
+    }
+    const std::string outPath = sh.world > 1 ? a.pos[2] + "_" + std::to_string(sh.rank) : a.pos[2];
+    if (sh.world > 1) { remove((outPath + ".orfs").c_str()); remove((outPath + ".dbtype").c_str()); }   // leftovers of a run that died
     std::vector<char> nucl;
     std::vector<uint64_t> off(ord.size() + 1, 0);
     for (size_t i = 0; i < ord.size(); i++) {
@@ -500,14 +512,39 @@ int cmdPredictExons(int argc, char **argv) {
     mk_queries *Q = nullptr;
     mk_predictions *R = nullptr;
     const double t1 = now();
-    if (mk_extract_orfs(nucl.data(), off.data(), (uint32_t) ord.size(), minLength, &O) != MK_OK) return die("%s", mk_last_error());
+    static const char none = 0;
+    if (mk_extract_orfs(nucl.empty() ? &none : nucl.data(), off.data(), (uint32_t) ord.size(), minLength, &O) != MK_OK) return die("%s", mk_last_error());
+    const mk_orf *orfs; const uint64_t *aaOff; const char *aa; uint64_t nOrfs = 0;
+    mk_orfs_result(O, &orfs, &aaOff, &aa, &nOrfs);
+    // fragment keys are numbered over ALL contigs (createRenumberedDB): a worker publishes how many it found and adds what the workers
+    // before it found -- a prefix over the workers through the file system
+    uint64_t orfBase = 0;
+    if (sh.world > 1) {
+        FILE *f = fopen((outPath + ".orfs.tmp").c_str(), "w");
+        if (!f) return die("cannot write %s", outPath + ".orfs.tmp");
+        fprintf(f, "%llu\n", (unsigned long long) nOrfs);
+        fclose(f);
+        rename((outPath + ".orfs.tmp").c_str(), (outPath + ".orfs").c_str());
+        for (int r = 0; r < sh.rank; r++) {
+            const std::string cf = a.pos[2] + "_" + std::to_string(r) + ".orfs";
+            for (long waited = 0; !mk::Database::exists(cf); waited++) {
+                if (waited == 20L * 3600L * 24L) return die("gave up waiting for %s", cf);
+                usleep(50000);
+            }
+            unsigned long long v = 0;
+            FILE *g = fopen(cf.c_str(), "r");
+            if (!g || fscanf(g, "%llu", &v) != 1) return die("cannot read %s", cf);
+            fclose(g);
+            orfBase += v;
+        }
+    }
     if (mk_queries_from_orfs(O, &P, &Q) != MK_OK) return die("%s", mk_last_error());
     if (mk_search(T, Q, &P) != MK_OK) return die("%s", mk_last_error());
     if (mk_predict_exons(T, O, Q, &X, tkeys.data(), &R) != MK_OK) return die("%s", mk_last_error());
     const double t2 = now();
     const mk_prediction *preds; const uint64_t *coff; const mk_exon *exons; uint64_t np = 0;
     mk_predictions_result(R, &preds, &coff, &exons, &np);
-    mk::DatabaseWriter w(a.pos[2], 12 /* DBTYPE_GENERIC_DB, collectoptimalset.cpp:244 */);
+    mk::DatabaseWriter w(outPath, 12 /* DBTYPE_GENERIC_DB, collectoptimalset.cpp:244 */);
     e = w.open();
     if (!e.empty()) return die("%s", e);
     std::string buf;
@@ -515,20 +552,23 @@ int cmdPredictExons(int argc, char **argv) {
     for (size_t c = 0; c < ord.size(); c++) {
         buf.clear();
         for (uint64_t k = coff[c]; k < coff[c + 1]; k++)
-            for (uint64_t x = preds[k].first_exon; x < preds[k].first_exon + preds[k].n_exons; x++)
-                buf.append(line, mk_format_prediction_exon(line, &preds[k], &exons[x]));
+            for (uint64_t x = preds[k].first_exon; x < preds[k].first_exon + preds[k].n_exons; x++) {
+                mk_exon ex = exons[x];
+                ex.orf += (uint32_t) orfBase;
+                buf.append(line, mk_format_prediction_exon(line, &preds[k], &ex));
+            }
         w.write(contigs.entries[ord[c]].key, buf.data(), buf.size());
     }
     e = w.close();
     if (!e.empty()) return die("%s", e);
-    const mk_orf *orfs; const uint64_t *aaOff; const char *aa; uint64_t nOrfs = 0;
-    mk_orfs_result(O, &orfs, &aaOff, &aa, &nOrfs);
     fprintf(stderr, "predictexons: %zu contigs -> %llu fragments x %zu targets -> %llu predictions; %.2f s (target index %.2f s, fragments to exon sets %.2f s)\n",
             ord.size(), (unsigned long long) nOrfs, tkeys.size(), (unsigned long long) np, now() - t0, t1 - t0, t2 - t1);
     mk_predictions_destroy(R);
     mk_queries_destroy(Q);
     mk_orfs_destroy(O);
     mk_targetdb_destroy(T);
+    if (int rc = finishShards(a.pos[2], sh, 12)) return rc;
+    if (sh.world > 1 && sh.rank == 0) for (int r = 0; r < sh.world; r++) remove((a.pos[2] + "_" + std::to_string(r) + ".orfs").c_str());
     return EXIT_SUCCESS;
 }
 
@@ -584,6 +624,7 @@ int main(int argc, char **argv) {
         if (!e.empty()) return die("%s", e);
         return EXIT_SUCCESS;
     }
+    if (cmd == "predictexons") return cmdPredictExons(argc, argv);
     // the other commands are not sharded: under a multi-process launcher worker 0 does the job
     if (getenv("RANK") && atoi(getenv("RANK")) > 0) return EXIT_SUCCESS;
     if (cmd == "extractorfs") return cmdExtractOrfs(argc, argv);

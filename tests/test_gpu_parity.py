@@ -662,3 +662,23 @@ def test_cli_two_workers_share_the_queries(gpu_api, tmp_path):
     a1, a2 = shard.read_result_db(str(tmp_path / "res1")), shard.read_result_db(str(tmp_path / "res2"))
     assert a1 == a2 and len(a1) == len(queries) and sum(len(v) for v in a1.values()) > 300
     assert open(tmp_path / "res2.dbtype", "rb").read() == (5).to_bytes(4, "little")
+
+
+def test_cli_predictexons_two_workers(gpu_api, tmp_path):
+    """the whole-workflow command split over two workers by contigs: fragment keys stay numbered over all contigs (each worker
+    adds what the workers before it found), the merged called-exons DB equals the reference-made exon sets"""
+    import subprocess
+    from metaeuk_amd import build
+    targets, contigs = _lines("e2e_targets.txt.gz"), _lines("e2e_contigs.txt.gz")
+    _write_seq_db(str(tmp_path / "targets"), targets)
+    _write_seq_db(str(tmp_path / "contigs"), contigs)
+    (tmp_path / "contigs.dbtype").write_bytes((1).to_bytes(4, "little"))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([build.BIN, "predictexons", str(tmp_path / "contigs"), str(tmp_path / "targets"), str(tmp_path / "calls"), str(tmp_path / "tmp"),
+                                       "-s", "5.7", "--ref-l2-bytes", "2097152", "--threads", "2", "--gpu", "0"], env=env, stderr=subprocess.DEVNULL))
+    assert all(p.wait() == 0 for p in procs)
+    got = _read_result_db(str(tmp_path / "calls"))
+    assert "".join(">%d\n%s" % (c, got[c]) for c in range(len(contigs))) == _text("e2e_exons_expected.txt.gz")
+    assert not os.path.exists(tmp_path / "calls_0") and not os.path.exists(tmp_path / "calls_1.orfs")
