@@ -1,4 +1,4 @@
-// metaeuk_amd/csrc/mk_cli.cpp -- `metaeuk-amd prefilter|align|extractorfs|predictexons|createindex`: the two hot modules of
+// metaeuk_amd/csrc/mk_cli.cpp -- `metaeuk-amd prefilter|align|search|extractorfs|predictexons|createindex`: the two hot modules of
 // `metaeuk predictexons` with the reference's process-level signature, flag names and on-disk DB format,
 // on top of the C ABI (include/metaeuk_amd.h).
 //
@@ -241,17 +241,21 @@ int finishShards(const std::string &out, const Shard &sh, int dbtype) {
 
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-int cmdPrefilterOrAlign(bool isAlign, int argc, char **argv) {
+// mode: 0 = prefilter, 1 = align, 2 = search (the `search` workflow's two modules as one pipelined pass: <queryDB> <targetDB> <alignmentDB>
+// <tmpDir>, nothing written in between -- blastp.sh:70,85 without the pref_0 round trip)
+int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
+    const bool isAlign = mode != 0, isSearch = mode == 2;
     Args a;
     if (int rc = parse(argc, argv, a)) return rc;
     const size_t need = isAlign ? 4 : 3;
     if (a.pos.size() != need) {
-        fprintf(stderr, "usage: metaeuk-amd %s <i:queryDB> <i:targetDB> %s[options]\n", isAlign ? "align" : "prefilter",
-                isAlign ? "<i:resultDB> <o:alignmentDB> " : "<o:prefilterDB> ");
+        fprintf(stderr, "usage: metaeuk-amd %s <i:queryDB> <i:targetDB> %s[options]\n", isSearch ? "search" : (isAlign ? "align" : "prefilter"),
+                isSearch ? "<o:alignmentDB> <tmpDir> " : (isAlign ? "<i:resultDB> <o:alignmentDB> " : "<o:prefilterDB> "));
         return EXIT_FAILURE;
     }
     mk_params P;
     int gpu = 0;
+    if (isSearch && a.opt.find("-s") == a.opt.end()) a.opt["-s"] = "5.7";   // the search workflow's own default (Search.cpp:24)
     if (int rc = fillParams(a, P, gpu)) return rc;
     const double t0 = now();
     mk::Database qdb;
@@ -266,7 +270,7 @@ int cmdPrefilterOrAlign(bool isAlign, int argc, char **argv) {
         qdb.entries.erase(qdb.entries.begin() + (std::ptrdiff_t) (first + count), qdb.entries.end());
         qdb.entries.erase(qdb.entries.begin(), qdb.entries.begin() + (std::ptrdiff_t) first);
     }
-    const std::string outBase = a.pos[isAlign ? 3 : 2];
+    const std::string outBase = a.pos[isAlign && !isSearch ? 3 : 2];
     const std::string outPath = sh.world > 1 ? outBase + "_" + std::to_string(sh.rank) : outBase;
     if (mk_init(gpu) != MK_OK) return die("%s", mk_last_error());
     std::vector<uint8_t> qres;
@@ -298,6 +302,13 @@ int cmdPrefilterOrAlign(bool isAlign, int argc, char **argv) {
         if (!e.empty()) return die("%s", e);
         fprintf(stderr, "prefilter: %zu queries x %zu targets%s, %llu hits, %.2f s\n", nq, tkeys.size(), ts.fromIndex ? " (precomputed index)" : "", (unsigned long long) hoff[nq], now() - t0);
     } else {
+        std::vector<mk_hit> hits;
+        if (isSearch) {
+            if (mk_search(T, Q, &P) != MK_OK) return die("%s", mk_last_error());
+            const mk_hit *hp; const uint64_t *ho;
+            mk_prefilter_result(Q, &hp, &ho);
+            hits.resize(ho[nq]);                                     // (only their number is reported)
+        } else {
         // read the prefilter DB: key \t score \t diagonal lines (QueryMatcher::parsePrefilterHit, QueryMatcher.h:87-102)
         mk::Database pdb;
         e = pdb.open(a.pos[2]);
@@ -329,10 +340,10 @@ int cmdPrefilterOrAlign(bool isAlign, int argc, char **argv) {
             }
         }
         std::vector<uint64_t> hoff(nq + 1, 0);
-        std::vector<mk_hit> hits;
         for (size_t i = 0; i < nq; i++) { hits.insert(hits.end(), perQ[i].begin(), perQ[i].end()); hoff[i + 1] = hits.size(); }
         if (mk_prefilter_result_set(Q, hits.data(), hoff.data()) != MK_OK) return die("%s", mk_last_error());
         if (mk_align(T, Q, &P) != MK_OK) return die("%s", mk_last_error());
+        }
         const mk_alignment *alns; const uint64_t *aoff;
         mk_align_result(Q, &alns, &aoff);
         mk::DatabaseWriter w(outPath, mk::DBTYPE_ALIGNMENT_RES);
@@ -349,7 +360,7 @@ int cmdPrefilterOrAlign(bool isAlign, int argc, char **argv) {
         }
         e = w.close();
         if (!e.empty()) return die("%s", e);
-        fprintf(stderr, "align: %llu alignments calculated, %llu passed, %.2f s\n", (unsigned long long) hits.size(), (unsigned long long) aoff[nq], now() - t0);
+        fprintf(stderr, "%s: %llu alignments calculated, %llu passed, %.2f s\n", isSearch ? "search" : "align", (unsigned long long) hits.size(), (unsigned long long) aoff[nq], now() - t0);
     }
     mk_queries_destroy(Q);
     mk_targetdb_destroy(T);
@@ -602,12 +613,13 @@ int cmdCreateIndex(int argc, char **argv) {
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        fprintf(stderr, "metaeuk-amd: MI355X prefilter+align modules of `metaeuk predictexons`\n  metaeuk-amd prefilter <queryDB> <targetDB> <prefilterDB> [flags]\n  metaeuk-amd align <queryDB> <targetDB> <prefilterDB> <alignmentDB> [flags]\n  metaeuk-amd extractorfs <contigDB> <orfDB> [--min-length N] [--translate 0|1] [--aa-sibling NAME]\n  metaeuk-amd predictexons <contigsDB> <targetsDB> <calledExonsDB> <tmpDir> [flags]\n  metaeuk-amd createindex <targetsDB> <tmpDir> [-s 7.5]\n");
+        fprintf(stderr, "metaeuk-amd: MI355X prefilter+align modules of `metaeuk predictexons`\n  metaeuk-amd prefilter <queryDB> <targetDB> <prefilterDB> [flags]\n  metaeuk-amd align <queryDB> <targetDB> <prefilterDB> <alignmentDB> [flags]\n  metaeuk-amd search <queryDB> <targetDB> <alignmentDB> <tmpDir> [flags]\n  metaeuk-amd extractorfs <contigDB> <orfDB> [--min-length N] [--translate 0|1] [--aa-sibling NAME]\n  metaeuk-amd predictexons <contigsDB> <targetsDB> <calledExonsDB> <tmpDir> [flags]\n  metaeuk-amd createindex <targetsDB> <tmpDir> [-s 7.5]\n");
         return EXIT_FAILURE;
     }
     const std::string cmd = argv[1];
-    if (cmd == "prefilter") return cmdPrefilterOrAlign(false, argc, argv);
-    if (cmd == "align") return cmdPrefilterOrAlign(true, argc, argv);
+    if (cmd == "prefilter") return cmdPrefilterOrAlign(0, argc, argv);
+    if (cmd == "align") return cmdPrefilterOrAlign(1, argc, argv);
+    if (cmd == "search") return cmdPrefilterOrAlign(2, argc, argv);
     if (cmd == "shardinfo" && argc >= 4) {                       // <db> r/N: the worker's entry range (first, count) -- for tests and scripts
         mk::Database db;
         const std::string e = db.open(argv[2]);

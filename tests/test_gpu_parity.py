@@ -643,25 +643,30 @@ def test_cli_two_workers_share_the_queries(gpu_api, tmp_path):
     _write_seq_db(str(tmp_path / "q"), queries, [2 * i + 7 for i in range(len(queries))])
     _write_seq_db(str(tmp_path / "t"), targets)
     flags = ["-s", "5.7", "--ref-l2-bytes", "2097152", "--threads", "2", "--gpu", "0"]
+    aflags = ["-e", "100", "--min-aln-len", "11"]
     def run(cmd, out, world):
         procs = []
         for r in range(world):
             env = dict(os.environ)
             if world > 1:
                 env.update(RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r))
-            procs.append(subprocess.Popen([build.BIN] + cmd + [out] + flags, env=env, stderr=subprocess.DEVNULL))
+            tail = [str(tmp_path / "tmp")] if cmd[0] == "search" else []
+            procs.append(subprocess.Popen([build.BIN] + cmd + [out] + tail + flags + (aflags if cmd[0] == "search" else []), env=env, stderr=subprocess.DEVNULL))
         assert all(p.wait() == 0 for p in procs)
     run(["prefilter", str(tmp_path / "q"), str(tmp_path / "t")], str(tmp_path / "pref1"), 1)
     run(["prefilter", str(tmp_path / "q"), str(tmp_path / "t")], str(tmp_path / "pref2"), 2)
     p1, p2 = shard.read_result_db(str(tmp_path / "pref1")), shard.read_result_db(str(tmp_path / "pref2"))
     assert p1 == p2 and len(p1) == len(queries) and sum(len(v) for v in p1.values()) > 1000
     assert not os.path.exists(tmp_path / "pref2_0") and not os.path.exists(tmp_path / "pref2_1.dbtype")
-    aflags = ["-e", "100", "--min-aln-len", "11"]
     run(["align", str(tmp_path / "q"), str(tmp_path / "t"), str(tmp_path / "pref1")] + aflags, str(tmp_path / "res1"), 1)
     run(["align", str(tmp_path / "q"), str(tmp_path / "t"), str(tmp_path / "pref2")] + aflags, str(tmp_path / "res2"), 2)
     a1, a2 = shard.read_result_db(str(tmp_path / "res1")), shard.read_result_db(str(tmp_path / "res2"))
     assert a1 == a2 and len(a1) == len(queries) and sum(len(v) for v in a1.values()) > 300
     assert open(tmp_path / "res2.dbtype", "rb").read() == (5).to_bytes(4, "little")
+    # `search` = the two modules as one pass, nothing written in between; alone and as two workers
+    run(["search", str(tmp_path / "q"), str(tmp_path / "t")], str(tmp_path / "sres1"), 1)
+    run(["search", str(tmp_path / "q"), str(tmp_path / "t")], str(tmp_path / "sres2"), 2)
+    assert shard.read_result_db(str(tmp_path / "sres1")) == a1 and shard.read_result_db(str(tmp_path / "sres2")) == a1
 
 
 def test_cli_predictexons_two_workers(gpu_api, tmp_path):
