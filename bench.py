@@ -8,8 +8,15 @@ A step = one full pass of the hot path (query-side derivation, k-mer prefilter, 
 scoring, hit selection, gapped SW forward/reverse, e-values) over one batch of synthetic ORF
 fragments against the HBM-resident target DB + index.  The workload is BASELINE.json configs[1]
 (10k synthetic 5-kb contigs x 100k proteins, -s 5.7) unless --contigs/--targets shrink it.
-Multi-GPU = query sharding (weak scaling: every rank searches its own 10k contigs against a full
-replica of the target index; no collective on the data path, only the timing barrier/max).
+Multi-GPU = query sharding, no collective on the data path (only the timing barrier/max):
+  --scaling strong (default for --gpus > 1, BASELINE config 3): the SAME 10k-contig workload is split over the
+                   ranks with the reference's residue-balanced rule (DBReader::decomposeDomainByAminoAcid);
+  --scaling weak   every rank searches its own 10k contigs.
+Every rank holds a full replica of the target index.
+
+The JSON line carries `result_digest`: a SHA-256 over the formatted prefilter hits and alignments of the last
+timed step, restricted to the queries of the CPU-baseline sample, next to the same digest of what the CPU
+baseline (the reference's own code) wrote for that sample -- "bit-exact" is checked, not asserted.
 
 Prints ONE JSON line on rank 0.
 """
@@ -30,14 +37,26 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T int32 lane-ops/s
 SW_OPS_PER_CELL = 10      # int32 kernel: add, min, max3, lshl_or, max, sub, sub, max3, sub, max3 per cell; the packed int16 score pass spends
                           # 10 per PAIR of cells (perm, add, max, max, max, sub, sub, max, sub, max) -- priced at the int32 rate
-# HBM bytes per launch from the PMC passes (profiles/r01_pmc_hbm_traffic.txt), keyed by the bench's kernel names
-TRAFFIC_BYTES_PER_LAUNCH = {   # (FETCH_SIZE + WRITE_SIZE) KB x 1024, raw counter values, default workload, final round-1 build
-    "prefilter_fused_lds2048": (943449 + 9249) * 1024, "prefilter_fused_lds4096": (2746646 + 12944) * 1024,
-    "prefilter_fused_lds8192": (10129156 + 35347) * 1024,
-    "kmer_probe_count": (24991722 + 103882) * 1024, "kmer_probe_gather": (31999734 + 3940003) * 1024,
-    "sw_fwd_rows32": (336422 + 33746) * 1024, "sw_fwd_rows48": (314477 + 32922) * 1024, "sw_fwd_rows64": (224260 + 23701) * 1024,
-    "sw_fwd_rows96": (223861 + 23900) * 1024, "sw_fwd_rows128": (85757 + 9349) * 1024, "sw_fwd_rows192": (64843 + 6914) * 1024,
-}
+
+
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of a kernel from the newest PMC artefact under profiles/ (written by tools/pmc_aggregate.py
+    from separate rocprofv3 --pmc passes): {"build": <sha of the kernel sources>, "kernels": {name: {"fetch_bytes":..,
+    "write_bytes":.., "launches":..}}}.  None when there is no artefact or it was taken on other kernel sources."""
+    import glob
+    import hashlib
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+    if not cands:
+        return None, None
+    art = json.load(open(cands[-1]))
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "metaeuk_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "metaeuk_amd", "csrc", "mk_enum.hpp"))):
+        h.update(open(f, "rb").read())
+    k = art.get("kernels", {}).get(kernel_name)
+    if not k:
+        return None, os.path.basename(cands[-1])
+    note = os.path.basename(cands[-1]) + ("" if art.get("build") == h.hexdigest()[:16] else " (taken on an older build of the kernels)")
+    return (k["fetch_bytes"] + k["write_bytes"]) / max(k["launches"], 1), note
 
 
 def make_inputs(n_contigs, n_targets, seed, rank):
@@ -52,6 +71,13 @@ def pack(codes_list):
     off[1:] = np.cumsum([len(c) for c in codes_list], dtype=np.uint64)
     res = np.concatenate(codes_list).astype(np.uint8) if codes_list else np.zeros(1, np.uint8)
     return np.ascontiguousarray(res), off
+
+
+def gpu_digest(api, hits, hoff, alns, aoff, n):
+    import oracle
+    hb = api.format_hits_bulk(hits, 0, int(hoff[n]))
+    ab = api.format_alignments_bulk(alns, 0, int(aoff[n]))
+    return {"prefilter": oracle.digest_arrays(hoff, hb, n), "alignments": oracle.digest_arrays(aoff, ab, n)}
 
 
 def cpu_baseline(targets, queries, budget_queries, threads):
@@ -75,6 +101,7 @@ def cpu_baseline(targets, queries, budget_queries, threads):
             st = json.loads(out)
             t = st["t_prefilter"] + st["t_align"]
             kind = "reference"
+            odir = os.path.join(tmp, "o")
         else:
             oracle.build()
             env = dict(os.environ, OMP_NUM_THREADS=str(threads))
@@ -82,10 +109,13 @@ def cpu_baseline(targets, queries, budget_queries, threads):
             st = json.loads(out)
             t = st["t_prefilter_align"]
             kind = "port"
+            odir = os.path.join(tmp, "o")
+        digest = {"prefilter": oracle.digest_blocks_file(os.path.join(odir, "pref.txt"))[0],
+                  "alignments": oracle.digest_blocks_file(os.path.join(odir, "aln.txt"))[0]}
     return {"value": len(sample) / t, "unit": "fragments/s", "cores": threads, "kind": kind,
             "sample": "first %d ORF fragments of the same workload vs the full target DB; prefilter %.2fs + align %.2fs (index build excluded)" % (
                 len(sample), st.get("t_prefilter", t), st.get("t_align", 0.0)),
-            "gcups_align": st["cells_fwd"] / max(st.get("t_align", t), 1e-9) / 1e9}
+            "gcups_align": st["cells_fwd"] / max(st.get("t_align", t), 1e-9) / 1e9, "digest": digest}
 
 
 def main():
@@ -98,6 +128,7 @@ def main():
     ap.add_argument("--seed", type=int, default=11)
     ap.add_argument("--two-calls", action="store_true", help="mk_prefilter then mk_align instead of the pipelined mk_search")
     ap.add_argument("--cpu-sample", type=int, default=400000, help="queries in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default=None, help="multi-GPU mode (default: strong when --gpus > 1)")
     args = ap.parse_args()
 
     # the one JSON line goes to the real stdout; whatever libraries print there (RCCL's version banner at communicator creation) is
@@ -127,9 +158,20 @@ def main():
     from metaeuk_amd import api
     api.init(local_rank)
     params = api.default_params()
+    # the reference sizes its hit bins from the L2 of the host it runs on (Util::getL2CacheSize, Util.cpp:317-332), which decides
+    # the tie order at the --max-seqs cut: reproduce THIS host's reference run, like the metaeuk-amd commands do (mk_cli.cpp)
+    import ctypes
+    l2 = ctypes.CDLL(None).sysconf(191)          # _SC_LEVEL2_CACHE_SIZE
+    params.host_l2_bytes = l2 if l2 and l2 > 0 else 262144
 
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
     t0 = time.time()
-    targets, queries = make_inputs(args.contigs, args.targets, args.seed, rank)
+    targets, queries = make_inputs(args.contigs, args.targets, args.seed, rank if scaling == "weak" else 0)
+    if scaling == "strong" and world > 1:
+        # BASELINE config 3: the same workload, query-sharded with the reference's residue-balanced rule
+        from metaeuk_amd import shard
+        first, count = shard.decompose_by_residues([len(x) + 2 for x in queries], rank, world)
+        queries = queries[first:first + count]
     t_res, t_off = pack(targets)
     q_res, q_off = pack(queries)
     t_gen = time.time() - t0
@@ -146,7 +188,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def step():
+    last = {}
+
+    def step(keep=False):
         q = api.Queries.from_codes(q_res, q_off, params)
         if args.two_calls:
             hits, hoff = api.prefilter(db, q)
@@ -154,7 +198,10 @@ def main():
         else:
             (hits, hoff), (alns, aoff) = api.search(db, q)
         res = (int(hoff[-1]), int(aoff[-1]))
-        q.close()
+        if keep:                                   # the last step's results stay alive for the digest (outside the timed region)
+            last.update(q=q, hits=hits, hoff=hoff, alns=alns, aoff=aoff)
+        else:
+            q.close()
         return res
 
     for _ in range(args.warmup):
@@ -163,8 +210,8 @@ def main():
     barrier()
     t0 = time.time()
     nhits = npass = 0
-    for _ in range(args.steps):
-        nhits, npass = step()
+    for k in range(args.steps):
+        nhits, npass = step(keep=(k == args.steps - 1))
     barrier()
     elapsed = time.time() - t0
     total_queries = len(queries)
@@ -193,10 +240,11 @@ def main():
     dom_name, dom = max(kstats.items(), key=lambda kv: kv[1]["ms"]) if kstats else ("none", dict(ms=0, launches=1, alg_bytes=0, cells=0))
     per_launch_ms = dom["ms"] / max(dom["launches"], 1)
     achieved = (dom["alg_bytes"] / max(dom["launches"], 1)) / max(per_launch_ms * 1e-3, 1e-12) / 1e9
+    traffic, traffic_note = pmc_traffic(dom_name)
     line = {
         "metric": "prefilter+align ORF-fragments/sec (bit-exact hits)",
         "value": frag_per_s, "unit": "fragments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "packed i16 / i32 DP on u8 residues, i8 scores", "data": "synthetic",
         "config": {"workload": "predictexons hot path: %d synthetic 5-kb contigs (%d ORF fragments/rank, %d aa) x %d-protein DB (%d aa), -s 5.7" % (
             args.contigs, nq, int(q_off[-1]), args.targets, int(t_off[-1])), "parallelism": "query-shard x%d" % world,
@@ -209,7 +257,7 @@ def main():
         # dominant kernel against HBM; `traffic` (PMC FETCH_SIZE + WRITE_SIZE per launch) comes from the rocprofv3 passes kept
         # under profiles/ -- bench.py cannot read PMC counters itself
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dom_name),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                      "avg_launch_ms": per_launch_ms, "launches": dom["launches"],
                      "note": "neither hot kernel family streams HBM: the fused prefilter kernels wait on dependent random index "
                              "probes (latency), the Smith-Waterman kernels are int32 vector-ALU bound (see valu_roofline)"},
@@ -220,10 +268,22 @@ def main():
     }
     if rank == 0:
         if world == 1 and args.cpu_sample > 0:
+            n_s = min(args.cpu_sample, nq)
             try:
-                line["cpu_baseline"] = cpu_baseline(targets, queries, min(args.cpu_sample, nq), int(api.lib().mk_host_threads()))
+                line["cpu_baseline"] = cpu_baseline(targets, queries, n_s, int(api.lib().mk_host_threads()))
             except Exception as e:  # the baseline is reported, never required
                 line["cpu_baseline"] = {"value": None, "unit": "fragments/s", "cores": os.cpu_count(), "kind": "reference", "sample": "failed: %r" % (e,)}
+            # "bit-exact": SHA-256 over the formatted hits + alignments of the LAST TIMED STEP, restricted to the CPU sample's queries,
+            # against the same digest of what the CPU baseline wrote (tests/oracle.py: digest_arrays / digest_blocks_file)
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                g = gpu_digest(api, last["hits"], last["hoff"], last["alns"], last["aoff"], n_s)
+                c = line["cpu_baseline"].pop("digest", None)
+                line["result_digest"] = {"queries": n_s, "gpu": g, "cpu": c, "match": (c == g) if c else None}
+                if c and c != g:
+                    line["metric"] = "prefilter+align ORF-fragments/sec (RESULT MISMATCH vs the CPU baseline)"
+            except Exception as e:
+                line["result_digest"] = {"queries": n_s, "error": repr(e)}
         real_stdout.write(json.dumps(line) + "\n")
         real_stdout.flush()
     if dist is not None:

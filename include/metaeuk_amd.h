@@ -222,6 +222,11 @@ void mk_kernel_stats_reset(void);
  * Matcher::resultToBuffer (Matcher.cpp:280-327) ---- */
 size_t mk_format_hit(char *buf, uint32_t db_key, int32_t score, uint16_t diagonal);
 size_t mk_format_alignment(char *buf, const mk_alignment *a);
+/* bulk forms (the result DB writers, bench.py's result digest, the at-scale parity test): the lines of hits[0..n) /
+ * alns[0..n) back to back.  target_keys (may be NULL: key = index) maps seq_id to the DB key.  Return the bytes written;
+ * 0 when cap is too small (32 B per hit, 160 B per alignment always suffice). */
+size_t mk_format_hits(char *buf, size_t cap, const mk_hit *hits, uint64_t n, const uint32_t *target_keys);
+size_t mk_format_alignments(char *buf, size_t cap, const mk_alignment *alns, uint64_t n);
 
 #ifdef __cplusplus
 }

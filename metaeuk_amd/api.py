@@ -44,7 +44,7 @@ EXPORTS = ["mk_init", "mk_last_error", "mk_default_params", "mk_device_name", "m
            "mk_queries_create", "mk_queries_destroy", "mk_queries_derived", "mk_prefilter", "mk_prefilter_result", "mk_prefilter_result_set",
            "mk_align", "mk_align_result", "mk_search", "mk_extract_orfs", "mk_orfs_result", "mk_queries_from_orfs",
            "mk_orfs_destroy", "mk_format_orf_header", "mk_sw_pairs", "mk_ungapped",
-           "mk_kernel_stats", "mk_kernel_stats_reset", "mk_format_hit", "mk_format_alignment"]
+           "mk_kernel_stats", "mk_kernel_stats_reset", "mk_format_hit", "mk_format_alignment", "mk_format_hits", "mk_format_alignments"]
 
 
 def lib():
@@ -59,6 +59,8 @@ def lib():
         L.mk_targetdb_index_entries.restype = C.c_uint64
         L.mk_format_hit.restype = C.c_size_t
         L.mk_format_alignment.restype = C.c_size_t
+        L.mk_format_hits.restype = C.c_size_t
+        L.mk_format_alignments.restype = C.c_size_t
         L.mk_format_orf_header.restype = C.c_size_t
         L.mk_format_prediction_exon.restype = C.c_size_t
         _LIB = L
@@ -421,6 +423,25 @@ def kernel_stats(reset=False):
     if reset:
         lib().mk_kernel_stats_reset()
     return res
+
+
+def format_hits_bulk(hits, lo, hi):
+    """bytes of the prefilter lines of hits[lo:hi] (key = target index), formatted by the library in one call"""
+    n = hi - lo
+    if n <= 0:
+        return b""
+    buf = np.empty(32 * n, dtype=np.uint8)
+    w = lib().mk_format_hits(_p(buf), C.c_size_t(buf.size), C.c_void_p(hits.ctypes.data + lo * HIT_DTYPE.itemsize), C.c_uint64(n), None)
+    return buf[:w].tobytes()
+
+
+def format_alignments_bulk(alns, lo, hi):
+    n = hi - lo
+    if n <= 0:
+        return b""
+    buf = np.empty(160 * n, dtype=np.uint8)
+    w = lib().mk_format_alignments(_p(buf), C.c_size_t(buf.size), C.c_void_p(C.addressof(alns) + lo * C.sizeof(Alignment)), C.c_uint64(n))
+    return buf[:w].tobytes()
 
 
 def format_hits(hits, lo, hi, key_of=None):

@@ -249,6 +249,30 @@ int run_sw_jobs(const mk_targetdb *db, const mk_queries *q, const mk_params *P, 
 
 }  // namespace
 
+// bulk forms: pieces of the record range are formatted in parallel into per-piece strings, then laid out in order
+template <typename T, typename F>
+size_t format_bulk(char *buf, size_t cap, const T *rec, uint64_t n, size_t maxLine, F &&one) {
+    if (!buf || (!rec && n)) return 0;
+    if (cap < n * maxLine) return 0;
+    const uint64_t PIECE = 1u << 16;
+    const uint64_t nPieces = (n + PIECE - 1) / PIECE;
+    std::vector<size_t> len(nPieces + 1, 0);
+    // every piece is written at its worst-case position first, then moved down to close the gaps (pieces only move forward)
+#pragma omp parallel for schedule(dynamic, 1)
+    for (uint64_t p = 0; p < nPieces; p++) {
+        char *dst = buf + p * PIECE * maxLine, *w = dst;
+        const uint64_t e = std::min(n, (p + 1) * PIECE);
+        for (uint64_t i = p * PIECE; i < e; i++) w += one(w, rec[i]);
+        len[p + 1] = (size_t) (w - dst);
+    }
+    size_t at = 0;
+    for (uint64_t p = 0; p < nPieces; p++) {
+        if (p) std::memmove(buf + at, buf + p * PIECE * maxLine, len[p + 1]);
+        at += len[p + 1];
+    }
+    return at;
+}
+
 extern "C" {
 
 const char *mk_last_error(void) { return g_err.c_str(); }
@@ -1004,5 +1028,12 @@ void mk_kernel_stats_reset(void) { std::lock_guard<std::mutex> g(g_statsMutex); 
 
 size_t mk_format_hit(char *buf, uint32_t key, int32_t score, uint16_t diag) { return mk::format_hit(buf, key, score, diag); }
 size_t mk_format_alignment(char *buf, const mk_alignment *a) { return mk::format_alignment(buf, *a); }
+
+size_t mk_format_hits(char *buf, size_t cap, const mk_hit *hits, uint64_t n, const uint32_t *targetKeys) {
+    return format_bulk(buf, cap, hits, n, 32, [&](char *w, const mk_hit &h) { return mk::format_hit(w, targetKeys ? targetKeys[h.seq_id] : h.seq_id, h.pref_score, h.diagonal); });
+}
+size_t mk_format_alignments(char *buf, size_t cap, const mk_alignment *alns, uint64_t n) {
+    return format_bulk(buf, cap, alns, n, 160, [&](char *w, const mk_alignment &a) { return mk::format_alignment(w, a); });
+}
 
 }  // extern "C"

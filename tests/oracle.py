@@ -137,3 +137,44 @@ def write_matrix_files(outdir):
             for a, r in zip(alpha, rows):
                 f.write(a + " " + " ".join(r) + "\n")
     return outdir
+
+
+def digest_blocks_file(path, n_blocks=None):
+    """Canonical SHA-256 of a '>key'-separated block file (pref.txt / aln.txt of the oracle or the reference harness):
+    the per-block line counts as little-endian uint64 followed by the block bodies back to back.  The HIP side hashes
+    its offsets and mk_format_hits / mk_format_alignments output the same way (digest_arrays)."""
+    import hashlib
+    raw = np.fromfile(path, dtype=np.uint8)
+    if raw.size == 0:
+        return hashlib.sha256(b"").hexdigest(), 0
+    nl = np.flatnonzero(raw == 10)
+    starts = np.concatenate(([0], nl[:-1] + 1)) if nl.size else np.zeros(1, dtype=np.int64)
+    is_head = raw[starts] == ord(">")
+    heads = np.flatnonzero(is_head)
+    total = heads.size
+    counts = np.diff(np.concatenate((heads, [starts.size]))) - 1
+    if n_blocks is not None and n_blocks < total:
+        end_line = heads[n_blocks]                     # first line of block n_blocks
+        cut = starts[end_line]
+        raw, counts = raw[:cut], counts[:n_blocks]
+        starts, is_head, nl = starts[:end_line], is_head[:end_line], nl[:end_line]
+    delta = np.zeros(raw.size + 1, dtype=np.int32)
+    hs = starts[is_head]
+    he = nl[is_head] + 1
+    np.add.at(delta, hs, 1)
+    np.add.at(delta, he, -1)
+    keep = np.cumsum(delta[:-1]) == 0
+    h = hashlib.sha256()
+    h.update(counts.astype("<u8").tobytes())
+    h.update(raw[keep].tobytes())
+    return h.hexdigest(), int(counts.size)
+
+
+def digest_arrays(offsets, body, n_blocks):
+    """the same digest from per-query offsets (uint64[n+1]) and the formatted lines of the first n_blocks queries"""
+    import hashlib
+    off = np.asarray(offsets[:n_blocks + 1], dtype=np.uint64)
+    h = hashlib.sha256()
+    h.update(np.diff(off).astype("<u8").tobytes())
+    h.update(body)
+    return h.hexdigest()

@@ -55,3 +55,25 @@ def test_format_helpers():
     a.seq_id = 1.0
     n = api.lib().mk_format_alignment(buf, ctypes.byref(a))
     assert b"\t1.00\t" in buf.raw[:n]          # reference quirk: Util::fastSeqIdToBuffer + Matcher::resultToBuffer
+
+
+def test_bulk_formatters_equal_the_line_formatters():
+    import numpy as np
+    from metaeuk_amd import api
+    rng = np.random.RandomState(3)
+    n = 200000                                   # several parallel pieces
+    hits = np.zeros(n, dtype=api.HIT_DTYPE)
+    hits["seq_id"] = rng.randint(0, 1 << 27, n)
+    hits["pref_score"] = rng.randint(0, 70000, n)
+    hits["diagonal"] = rng.randint(0, 65536, n)
+    body = api.format_hits_bulk(hits, 0, n)
+    assert body.count(b"\n") == n
+    for k in (0, 1, 65535, 65536, 65537, n - 1):
+        assert body.split(b"\n")[k] + b"\n" == api.format_hits(hits, k, k + 1).encode()
+    assert api.format_hits_bulk(hits, 70000, 70003) == api.format_hits(hits, 70000, 70003).encode()
+    alns = (api.Alignment * 3)()
+    for k in range(3):
+        alns[k] = api.Alignment(db_key=10 + k, bit_score=163, seq_id=0.771 if k else 1.0, evalue=1.618e-49 * (k + 1), q_start=1, q_end=102, q_len=109,
+                                db_start=147, db_end=248, db_len=249)
+    assert api.format_alignments_bulk(alns, 0, 3) == api.format_alignments(alns, 0, 3).encode()
+    assert api.format_alignments_bulk(alns, 1, 3) == api.format_alignments(alns, 1, 3).encode()

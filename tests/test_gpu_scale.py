@@ -1,0 +1,64 @@
+"""GPU parity at the headline scale: the 100 000-protein target DB of BASELINE config 2 (the queries are a 300-contig
+slice of its 10 000), mk_search against the reference's own compiled code (oracle/_ref/ref_harness, when it travelled
+to the box) or the C oracle.  At this size the prefilter behaves differently in kind from the small fixtures: most
+similar k-mers belong to queries whose index hits do not fit one workgroup's LDS, --max-seqs truncation with the real
+BINSIZE fires, and the alignments cross every Smith-Waterman tile shape.
+Reference: QueryMatcher::matchQuery (M/src/prefiltering/QueryMatcher.cpp:149-209,422-450), Alignment::run."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _blocks(body, off):
+    lines = body.split(b"\n")
+    return [b"".join(l + b"\n" for l in lines[int(off[i]):int(off[i + 1])]).decode() for i in range(len(off) - 1)]
+
+
+def test_headline_scale_parity(gpu_api, tmp_path):
+    from metaeuk_amd import synth
+    api = gpu_api
+    targets, queries = synth.make_workload(300, 100000, seed=11)
+    assert len(targets) == 100000 and len(queries) > 50000
+    params = api.default_params()
+    use_ref = os.path.exists(oracle.REF)
+    if use_ref:       # the reference sizes BINSIZE from the L2 of the host it runs on (Util::getL2CacheSize, Util.cpp:317-332)
+        l2 = ctypes.CDLL(None).sysconf(191)
+        params.host_l2_bytes = l2 if l2 and l2 > 0 else 262144
+    db = api.TargetDB(targets, params)
+    q = api.Queries(queries, params)
+    api.kernel_stats(reset=True)
+    (hits, hoff), (alns, aoff) = api.search(db, q)
+    stats = api.kernel_stats()
+    hbody = api.format_hits_bulk(hits, 0, int(hoff[-1]))
+    abody = api.format_alignments_bulk(alns, 0, int(aoff[-1]))
+    if use_ref:
+        rpref, raln = oracle.run_ref_pipeline(targets, queries, str(tmp_path), extra=["--threads", str(api.lib().mk_host_threads())])
+        sub = "ref"
+    else:
+        rpref, raln = oracle.run_pipeline(targets, queries, str(tmp_path), extra=["--l2", str(params.host_l2_bytes)])
+        sub = "oracle"
+    gp, ga = _blocks(hbody, hoff), _blocks(abody, aoff)
+    bad_p = [i for i in range(len(queries)) if gp[i] != rpref[i]]
+    bad_a = [i for i in range(len(queries)) if ga[i] != raln[i]]
+    assert not bad_p, "%d prefilter blocks differ, first: query %d\n%s\nvs\n%s" % (len(bad_p), bad_p[0], gp[bad_p[0]][:300], rpref[bad_p[0]][:300])
+    assert not bad_a, "%d alignment blocks differ, first: query %d\n%s\nvs\n%s" % (len(bad_a), bad_a[0], ga[bad_a[0]][:400], raln[bad_a[0]][:400])
+    # the same through the digests bench.py prints
+    for name, off, body in (("pref.txt", hoff, hbody), ("aln.txt", aoff, abody)):
+        d_cpu, n = oracle.digest_blocks_file(os.path.join(str(tmp_path), sub, name))
+        assert n == len(queries)
+        assert oracle.digest_arrays(off, body, len(queries)) == d_cpu
+    # this workload must exercise what the small fixtures cannot
+    counts = np.diff(np.asarray(hoff))
+    max_hits = min(params.max_seqs, len(targets))
+    assert int((counts == max_hits).sum()) >= 1, "no query reached the --max-seqs cut"
+    assert stats.get("host_prefilter_maxseqs", {"ms": 0})["ms"] > 0 or stats.get("select_maxseqs", {"launches": 0})["launches"] > 0
+    k_lds = sum(v["cells"] for k, v in stats.items() if k.startswith("prefilter_fused_lds"))
+    k_big = sum(v["cells"] for k, v in stats.items() if k in ("kmer_probe_gather", "prefilter_big"))
+    assert k_big > k_lds, "most similar k-mers should belong to queries beyond one workgroup's LDS (%g vs %g)" % (k_big, k_lds)
+    assert int(aoff[-1]) > 100000 and int(hoff[-1]) > 1000000
