@@ -977,7 +977,6 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     mk::PrefilterHooks hooks;
     hooks.max_chunk_queries = 1u << 17;
     if (const char *e = getenv("MK_SEARCH_CHUNK_QUERIES")) hooks.max_chunk_queries = (uint32_t) std::max(1024L, atol(e));
-    hooks.max_tiers = 3;        // the 16 K-hit tier needs a whole CU's LDS, which it never gets while SW waves are resident
     hooks.on_chunk = [&](uint32_t a, uint32_t b) {
         { std::lock_guard<std::mutex> lk(pipe.m); pipe.items.emplace_back(a, b); }
         pipe.cv.notify_all();

@@ -602,22 +602,334 @@ __global__ __launch_bounds__(NW * 64) void fused_kernel(FusedArgs A) {
     }
 }
 
-struct FusedTier { int cap; int waves; };
+// =====================================================================================================
+//  A2. streamed per-query path: the index hits of a query pass through a workgroup-private region in HBM
+// =====================================================================================================
+// One enumeration, any query the region holds.  The workgroups are persistent (a fixed number per CU pull queries from a
+// counter), so every workgroup owns ONE hit region for its whole life: the region is rewritten query after query and stays in
+// L2 / Infinity Cache.  Pass 1 is the fused kernel's (waves take k-mer starts from a shared counter, enumerate, probe) except
+// that a hit does not go to LDS: every probe batch reserves its slots in the region with one LDS atomic and writes 8-byte
+// records target | diagonal | k-mer start | ordinal within the start -- the arrival order is IN the record, no chunk tables.
+// LDS only holds the two "target bucket seen once / twice" bitmaps, which can therefore be much larger per hit than in the
+// fused kernel.  Pass 2 streams the region back (coalesced), keeps the records whose target bucket was hit more than once
+// (plus single hits with diagonal low byte 0) and sorts those survivors in LDS by (target, arrival rank); the rule and the
+// emission are the fused kernel's.  When a query has more survivors than the LDS sort holds (the share of targets hit twice
+// by chance grows with hits^2 / targets), the targets are split into hash classes and pass 2 runs once per class: the runs
+// of a (query, target) pair stay contiguous, which is all the back end needs.
+struct StreamArgs {
+    PrefilterDeviceView V;
+    const uint32_t *queries; uint32_t n_own;          // (global) query ids assigned to this tier ...
+    const uint32_t *prev_list;                        // ... followed by the queries that overflowed the next smaller tier (chunk-local ids,
+    const uint32_t *prev_count;                       //     count known on the device only)
+    uint32_t q_first;
+    CandArrays C; uint32_t cand_cap;
+    uint32_t *counters;                               // [0] candidates appended
+    uint32_t *overflow_list; uint32_t *overflow_count;
+    unsigned long long *totals;                       // as FusedArgs::totals; [9] class passes beyond the first
+    uint32_t *work_counter;                           // next item of (own list ++ overflow list)
+    uint64_t *pool;                                   // gridDim.x regions of CAPH records
+};
+
+constexpr uint32_t REC_T_BITS = 22, REC_POS_BITS = 12, REC_ORD_BITS = 14;     // + 16 bits of diagonal = 64
+constexpr int STREAM_MAX_CLASSES = 64;
+
+template <int CAPH, int SURV, int MBITS, int MAXPOS, int NW, int U>
+__global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {       // 8 waves per SIMD: the kernel lives on memory-level parallelism
+    constexpr int BLOCK = NW * WAVE;
+    constexpr int LOG_MBITS = ilog2(MBITS);
+    constexpr int RBITS = ilog2(CAPH);                // arrival rank of a hit within its query (< CAPH)
+    constexpr int TSHIFT = 16 + RBITS;                // sort key: target << TSHIFT | rank << 16 | diagonal
+    static_assert((CAPH & (CAPH - 1)) == 0 && (SURV & (SURV - 1)) == 0 && (MBITS & (MBITS - 1)) == 0, "powers of two");
+    static_assert(MAXPOS <= (1 << REC_POS_BITS) && REC_T_BITS + TSHIFT <= 64, "record / key fields");
+    // the enumerator's scratch (pass 1) and the sort keys (pass 2) share their LDS
+    struct Pass1Lds { enumk::EnumLds<U> e[NW]; uint8_t mark[NW][WAVE]; };
+    constexpr size_t RAW = sizeof(Pass1Lds) > sizeof(uint64_t) * SURV ? sizeof(Pass1Lds) : sizeof(uint64_t) * SURV;
+    __shared__ __attribute__((aligned(16))) uint8_t sRaw[RAW];
+    uint64_t *sKey = reinterpret_cast<uint64_t *>(sRaw);
+    Pass1Lds &P1 = *reinterpret_cast<Pass1Lds *>(sRaw);
+    __shared__ uint32_t sBm1[MBITS / 32], sBm2[MBITS / 32];
+    __shared__ uint32_t sPosBase[MAXPOS];             // hits of a k-mer start, then their exclusive prefix
+    __shared__ uint32_t sFlagBits[SURV / 32 + 2], sWordPrefix[SURV / 32 + 2];
+    __shared__ uint32_t sWaveHits[NW], sWaveKmers[NW], sWavePos[NW];
+    __shared__ uint32_t sClassCnt[STREAM_MAX_CLASSES];
+    __shared__ uint32_t sNextPos, sUsed, sOverflow, sItem, sSurv, sEmitBase, sEmitCount, sClassMax;
+
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, w = tid / WAVE, lane = tid & (WAVE - 1);
+    uint64_t *region = A.pool + (size_t) blockIdx.x * CAPH;
+    const uint32_t nItems = A.n_own + A.prev_count[0];
+    constexpr uint64_t TMASK = (1ull << REC_T_BITS) - 1ull;
+    const auto survives = [&](uint64_t rec) -> bool {
+        const uint32_t hb = ((uint32_t) (rec & TMASK) * 2654435761u) >> (32 - LOG_MBITS);
+        return ((sBm2[hb >> 5] >> (hb & 31u)) & 1u) || ((uint32_t) (rec >> REC_T_BITS) & 0xFFu) == 0u;
+    };
+    for (;;) {
+        __syncthreads();                                  // the previous query's LDS is no longer read
+        if (tid == 0) sItem = atomicAdd(A.work_counter, 1u);
+        __syncthreads();
+        const uint32_t item = sItem;
+        if (item >= nItems) break;
+        const uint32_t q = item < A.n_own ? A.queries[item] : A.q_first + A.prev_list[item - A.n_own];
+        const uint64_t qs = A.V.q_off[q];
+        const int L = (int) (A.V.q_off[q + 1] - qs);
+        const int nStart = L >= 10 ? L - 9 : 0;
+        if (tid == 0) { sUsed = 0; sOverflow = nStart > MAXPOS ? 1u : 0u; sNextPos = 0; sSurv = 0; }
+        for (int k = tid; k < MBITS / 32; k += BLOCK) { sBm1[k] = 0; sBm2[k] = 0; }
+        for (int k = tid; k < min(nStart, MAXPOS); k += BLOCK) sPosBase[k] = 0;
+        __syncthreads();
+        const unsigned long long tStart = wall_clock64();
+
+        // ---- pass 1: enumerate + probe; hits -> region, target buckets -> the two bitmaps
+        uint32_t whits = 0, kmers = 0, npos = 0;
+        bool dead = false;
+        while (!dead) {
+            uint32_t iu = 0;
+            if (lane == 0) iu = atomicAdd(&sNextPos, 1u);
+            const int i = __builtin_amdgcn_readfirstlane((int) iu);
+            if (i >= nStart) break;
+            const uint64_t p = qs + (uint64_t) i;
+            const int thr = (int) A.V.q_kmer_thr[p];
+            if (thr < 0) continue;
+            if (*(volatile uint32_t *) &sOverflow) { dead = true; break; }
+            npos++;
+            uint32_t wcount = 0;                           // hits of this k-mer start so far
+            kmers += enumk::enumerate_position<U>(A.V, A.V.q_res + p, thr, lane, P1.e[w],
+                [&](const uint32_t (&kmer)[U], const bool (&has)[U]) -> bool {
+                    uint32_t size[U], o0[U], ex[U];
+                    uint64_t ent0[U];
+                    bool inl[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        size[u] = 0; o0[u] = 0; ent0[u] = 0; inl[u] = true;
+                        if (has[u] && kmer_present(A.V.kmer_bits, kmer[u])) { const KmerList l = load_kmer_list(A.V.kmer_slot, kmer[u]); o0[u] = l.first; size[u] = l.size; ent0[u] = l.ent0; inl[u] = l.isInline; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) if (!inl[u]) ent0[u] = A.V.entries[o0[u]];
+                    uint32_t totAll = 0;
+#pragma unroll
+                    for (int u = 0; u < U; u++) { const uint32_t incl = enumk::wave_incl_scan(size[u]); ex[u] = incl - size[u] + totAll; totAll += enumk::wave_last(incl); }
+                    if (totAll == 0) return true;
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&sUsed, totAll);           // the batch's slots: contiguous, hence coalesced stores
+                    base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
+                    if (base + totAll > (uint32_t) CAPH || wcount + totAll > (1u << REC_ORD_BITS)) { dead = true; if (lane == 0) sOverflow = 1; return false; }
+                    const auto put = [&](uint64_t ent, uint32_t rel) {
+                        const uint32_t tgt = (uint32_t) ent;
+                        const uint32_t diag = ((uint32_t) i - ((uint32_t) (ent >> 32) & 0xFFFFu)) & 0xFFFFu;
+                        region[base + rel] = (uint64_t) tgt | ((uint64_t) diag << REC_T_BITS) | ((uint64_t) (uint32_t) i << (REC_T_BITS + 16)) |
+                                             ((uint64_t) (wcount + rel) << (REC_T_BITS + 16 + REC_POS_BITS));
+                        const uint32_t hb = (tgt * 2654435761u) >> (32 - LOG_MBITS);
+                        const uint32_t bit = 1u << (hb & 31u);
+                        if (atomicOr(&sBm1[hb >> 5], bit) & bit) atomicOr(&sBm2[hb >> 5], bit);
+                    };
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const uint32_t r0 = ex[u];
+                        if (size[u]) put(ent0[u], r0);
+                        enumk::wave_deal_tail(size[u] > 1 ? size[u] - 1 : 0u, lane, P1.mark[w], [&](uint32_t owner, uint32_t e, bool valid) {
+                            const uint32_t oFirst = enumk::wave_read_lane(o0[u], owner), oR0 = enumk::wave_read_lane(r0, owner);
+                            if (valid) put(A.V.entries[oFirst + e], oR0 + e);
+                        });
+                    }
+                    wcount += totAll;
+                    return true;
+                });
+            if (lane == 0) sPosBase[i] = wcount;
+            whits += wcount;
+        }
+        if (lane == 0) { sWaveHits[w] = whits; sWaveKmers[w] = kmers; sWavePos[w] = npos; atomicAdd(&A.totals[7], (wall_clock64() - tStart) / NW); }
+        __syncthreads();                                   // (also orders the region stores before the reads of pass 2)
+        const unsigned long long tGather = wall_clock64();
+        if (sOverflow) {
+            if (tid == 0) { A.overflow_list[atomicAdd(A.overflow_count, 1u)] = q - A.q_first; atomicAdd(&A.totals[6], tGather - tStart); atomicAdd(&A.totals[8], 1ull); }
+            continue;
+        }
+        if (tid == 0) {
+            uint32_t hits = 0, km = 0, np = 0;
+            for (int k = 0; k < NW; k++) { hits += sWaveHits[k]; km += sWaveKmers[k]; np += sWavePos[k]; }
+            atomicAdd(&A.totals[0], (unsigned long long) km);
+            atomicAdd(&A.totals[1], (unsigned long long) hits);
+            atomicAdd(&A.totals[2], (unsigned long long) np);
+        }
+        const uint32_t used = sUsed;
+        if (used == 0) continue;
+        // arrival rank of a hit = hits of the earlier k-mer starts + its ordinal
+        if (w == 0) {
+            const uint32_t perLane = ((uint32_t) nStart + WAVE - 1) / WAVE;
+            const uint32_t b = min((uint32_t) nStart, (uint32_t) lane * perLane), e = min((uint32_t) nStart, b + perLane);
+            uint32_t sum = 0;
+            for (uint32_t k = b; k < e; k++) sum += sPosBase[k];
+            uint32_t run = enumk::wave_incl_scan(sum) - sum;
+            for (uint32_t k = b; k < e; k++) { const uint32_t c = sPosBase[k]; sPosBase[k] = run; run += c; }
+        }
+        // ---- pass 2a: how many records survive the filter; target classes if they do not fit the LDS sort at once
+        {
+            uint32_t local = 0;
+            for (uint32_t s = (uint32_t) tid; s < used; s += BLOCK) local += survives(region[s]) ? 1u : 0u;
+            local = wave_sum(local);
+            if (lane == 0 && local) atomicAdd(&sSurv, local);
+        }
+        __syncthreads();
+        const uint32_t nSurvAll = sSurv;
+        if (nSurvAll == 0) continue;
+        uint32_t nClasses = 1;
+        if (nSurvAll > (uint32_t) SURV) {
+            nClasses = (nSurvAll + (uint32_t) (SURV * 3 / 4) - 1) / (uint32_t) (SURV * 3 / 4);
+            for (;;) {
+                if (nClasses > (uint32_t) STREAM_MAX_CLASSES) break;
+                for (uint32_t k = (uint32_t) tid; k < nClasses; k += BLOCK) sClassCnt[k] = 0;
+                if (tid == 0) sClassMax = 0;
+                __syncthreads();
+                for (uint32_t s = (uint32_t) tid; s < used; s += BLOCK) {
+                    const uint64_t rec = region[s];
+                    if (survives(rec)) atomicAdd(&sClassCnt[(((uint32_t) (rec & TMASK) * 0x9E3779B1u) >> 8) % nClasses], 1u);
+                }
+                __syncthreads();
+                for (uint32_t k = (uint32_t) tid; k < nClasses; k += BLOCK) atomicMax(&sClassMax, sClassCnt[k]);
+                __syncthreads();
+                if (sClassMax <= (uint32_t) SURV) break;
+                nClasses += 1 + nClasses / 4;
+                __syncthreads();
+            }
+            if (nClasses > (uint32_t) STREAM_MAX_CLASSES) {    // (an extreme query: the global path sorts it)
+                if (tid == 0) { A.overflow_list[atomicAdd(A.overflow_count, 1u)] = q - A.q_first; atomicAdd(&A.totals[8], 1ull); }
+                continue;
+            }
+            if (tid == 0) atomicAdd(&A.totals[9], (unsigned long long) (nClasses - 1));
+        }
+        unsigned long long tSortAcc = 0, tEmitAcc = 0;
+        for (uint32_t cls = 0; cls < nClasses; cls++) {
+            const unsigned long long tc0 = wall_clock64();
+            __syncthreads();
+            if (tid == 0) sSurv = 0;
+            __syncthreads();
+            // ---- pass 2b: survivors of this class -> LDS sort keys (any order: the key carries the arrival rank)
+            for (uint32_t s0 = 0; s0 < used; s0 += BLOCK) {
+                const uint32_t s = s0 + (uint32_t) tid;
+                bool surv = false;
+                uint64_t rec = 0;
+                if (s < used) {
+                    rec = region[s];
+                    surv = survives(rec) && (nClasses == 1 || (((uint32_t) (rec & TMASK) * 0x9E3779B1u) >> 8) % nClasses == cls);
+                }
+                const unsigned long long m = __ballot(surv);
+                if (m == 0) continue;
+                uint32_t wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&sSurv, (uint32_t) __popcll(m));
+                wbase = (uint32_t) __builtin_amdgcn_readfirstlane((int) wbase);
+                if (surv) {
+                    const uint32_t pos = (uint32_t) (rec >> (REC_T_BITS + 16)) & ((1u << REC_POS_BITS) - 1u);
+                    const uint32_t rank = sPosBase[pos] + (uint32_t) (rec >> (REC_T_BITS + 16 + REC_POS_BITS));
+                    sKey[wbase + (uint32_t) __popcll(m & ((1ull << lane) - 1ull))] =
+                        ((rec & TMASK) << TSHIFT) | ((uint64_t) rank << 16) | ((rec >> REC_T_BITS) & 0xFFFFull);
+                }
+            }
+            __syncthreads();
+            const uint32_t nSurv = sSurv;
+            if (nSurv == 0) continue;
+            uint32_t P = WAVE;
+            while (P < nSurv) P <<= 1;
+            for (uint32_t s = nSurv + (uint32_t) tid; s < P; s += BLOCK) sKey[s] = ~0ull;
+            __syncthreads();
+            // ---- bitonic sort (keys are distinct: (target, rank) is unique)
+            for (uint32_t k = 2; k <= P; k <<= 1) {
+                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                    for (uint32_t i = (uint32_t) tid; i < (P >> 1); i += BLOCK) {
+                        const uint32_t l = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
+                        const uint32_t r2 = l | j;
+                        const uint64_t x = sKey[l], y = sKey[r2];
+                        const bool up = (l & k) == 0;
+                        if ((x > y) == up) { sKey[l] = y; sKey[r2] = x; }
+                    }
+                    __syncthreads();
+                }
+            }
+            const unsigned long long tc1 = wall_clock64();
+            // ---- the double-diagonal rule on the target runs -> flag bits
+            for (uint32_t t0 = 0; t0 < P; t0 += BLOCK) {
+                const uint32_t t = t0 + (uint32_t) tid;
+                bool emit = false;
+                const uint64_t key = t < P ? sKey[t] : ~0ull;
+                if (key != ~0ull) {
+                    const uint64_t target = key >> TSHIFT;
+                    const uint32_t lo = (uint32_t) key & 0xFFu;
+                    const bool samePrev = t > 0 && (sKey[t - 1] >> TSHIFT) == target;
+                    const uint32_t prevLo = samePrev ? ((uint32_t) sKey[t - 1] & 0xFFu) : 0u;
+                    if (lo == prevLo) {
+                        emit = true;
+                        if (samePrev) {
+                            uint32_t u = t - 1;
+                            while (true) {
+                                const uint32_t ulo = (uint32_t) sKey[u] & 0xFFu;
+                                const bool uSame = u > 0 && (sKey[u - 1] >> TSHIFT) == target;
+                                const uint32_t uprev = uSame ? ((uint32_t) sKey[u - 1] & 0xFFu) : 0u;
+                                if (ulo == uprev) { emit = (ulo != lo); break; }
+                                if (!uSame) break;
+                                u--;
+                            }
+                        }
+                    }
+                }
+                const unsigned long long m = __ballot(emit);
+                if (lane == 0 && t < P) { sFlagBits[t >> 5] = (uint32_t) m; sFlagBits[(t >> 5) + 1] = (uint32_t) (m >> 32); }
+            }
+            __syncthreads();
+            const uint32_t nWords = P >> 5;
+            if (w == 0) {
+                const uint32_t perLane = (nWords + WAVE - 1) / WAVE;
+                const uint32_t b = min(nWords, (uint32_t) lane * perLane), e = min(nWords, b + perLane);
+                uint32_t sum = 0;
+                for (uint32_t k = b; k < e; k++) sum += (uint32_t) __popc(sFlagBits[k]);
+                uint32_t total;
+                uint32_t run = wave_excl_scan(sum, total);
+                for (uint32_t k = b; k < e; k++) { sWordPrefix[k] = run; run += (uint32_t) __popc(sFlagBits[k]); }
+                if (lane == 0) { sEmitBase = total ? atomicAdd(&A.counters[0], total) : 0u; sEmitCount = total; }
+            }
+            __syncthreads();
+            const uint32_t nEmit = sEmitCount, ebase = sEmitBase;
+            if (nEmit != 0 && (unsigned long long) ebase + nEmit <= (unsigned long long) A.cand_cap) {   // else: the host sees counters[0] > cap and retries
+                for (uint32_t t = (uint32_t) tid; t < P; t += BLOCK) {
+                    const uint32_t word = sFlagBits[t >> 5];
+                    if (!((word >> (t & 31u)) & 1u)) continue;
+                    const uint32_t dst = ebase + sWordPrefix[t >> 5] + (uint32_t) __popc(word & ((1u << (t & 31u)) - 1u));
+                    const uint64_t key = sKey[t];
+                    A.C.q[dst] = q - A.q_first;
+                    A.C.id[dst] = (uint32_t) (key >> TSHIFT);
+                    A.C.ordinal[dst] = (uint32_t) (key >> 16) & ((1u << RBITS) - 1u);
+                    A.C.diag[dst] = (uint16_t) key;
+                }
+            }
+            tSortAcc += tc1 - tc0; tEmitAcc += wall_clock64() - tc1;
+        }
+        if (tid == 0) { atomicAdd(&A.totals[3], tGather - tStart); atomicAdd(&A.totals[4], tSortAcc); atomicAdd(&A.totals[5], tEmitAcc); }
+    }
+}
+
+// LDS tiers (kind 0: hits in LDS, fused_kernel) and streamed tiers (kind 1: hits in a workgroup-private HBM region, stream_kernel)
+struct FusedTier { int cap; int waves; int kind; int maxpos; int wgPerCu; };
 constexpr int N_TIERS = 4;
 // production tiers, then a miniature set (MK_PREFILTER_TIERS=tiny) with which small test inputs exercise every
-// workgroup shape, the overflow hand-over and the global path
-const FusedTier TIERS[2 * N_TIERS] = {{2048, 4}, {4096, 4}, {8192, MK_T2_WAVES}, {16384, 16}, {256, 4}, {512, 4}, {1024, 8}, {2048, 16}};
+// workgroup shape, the overflow hand-over, the class passes of the streamed tiers and the global path
+const FusedTier TIERS[2 * N_TIERS] = {{2048, 4, 0, fused_max_positions(2048), 0}, {4096, 4, 0, fused_max_positions(4096), 0},
+                                      {8192, 8, 1, 512, 4}, {65536, 16, 1, 2048, 2},
+                                      {256, 4, 0, fused_max_positions(256), 0}, {512, 4, 0, fused_max_positions(512), 0},
+                                      {1024, 4, 1, 64, 4}, {4096, 8, 1, 256, 4}};
 
 void launch_fused(int tier, const FusedArgs &A, hipStream_t stream) {
     switch (tier) {
         case 0: hipLaunchKernelGGL((fused_kernel<2048, 4>), dim3(A.n_launch), dim3(256), 0, stream, A); break;
         case 1: hipLaunchKernelGGL((fused_kernel<4096, 4>), dim3(A.n_launch), dim3(256), 0, stream, A); break;
-        case 2: hipLaunchKernelGGL((fused_kernel<8192, MK_T2_WAVES>), dim3(A.n_launch), dim3(64 * MK_T2_WAVES), 0, stream, A); break;
-        case 3: hipLaunchKernelGGL((fused_kernel<16384, 16>), dim3(A.n_launch), dim3(1024), 0, stream, A); break;
         case 4: hipLaunchKernelGGL((fused_kernel<256, 4>), dim3(A.n_launch), dim3(256), 0, stream, A); break;
-        case 5: hipLaunchKernelGGL((fused_kernel<512, 4>), dim3(A.n_launch), dim3(256), 0, stream, A); break;
-        case 6: hipLaunchKernelGGL((fused_kernel<1024, 8>), dim3(A.n_launch), dim3(512), 0, stream, A); break;
-        default: hipLaunchKernelGGL((fused_kernel<2048, 16>), dim3(A.n_launch), dim3(1024), 0, stream, A); break;
+        default: hipLaunchKernelGGL((fused_kernel<512, 4>), dim3(A.n_launch), dim3(256), 0, stream, A); break;
+    }
+}
+//                                    region (hits)  LDS sort  bitmap bits  k-mer starts  waves  probe groups
+void launch_stream(int tier, const StreamArgs &A, unsigned grid, hipStream_t stream) {
+    switch (tier) {
+        case 2: hipLaunchKernelGGL((stream_kernel<8192, 2048, 65536, 512, 8, 2>), dim3(grid), dim3(512), 0, stream, A); break;
+        case 3: hipLaunchKernelGGL((stream_kernel<65536, 4096, 131072, 2048, 16, 2>), dim3(grid), dim3(1024), 0, stream, A); break;
+        case 6: hipLaunchKernelGGL((stream_kernel<1024, 128, 2048, 64, 4, 2>), dim3(grid), dim3(256), 0, stream, A); break;
+        default: hipLaunchKernelGGL((stream_kernel<4096, 256, 8192, 256, 8, 2>), dim3(grid), dim3(512), 0, stream, A); break;
     }
 }
 
@@ -940,8 +1252,9 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     const uint32_t CAND_CAP = 96u << 20;              // candidates per chunk held in HBM (~44 B each)
     if (dbSize >= (1ull << 27)) { err = "more than 2^27 targets"; return MK_ERR_UNSUPPORTED; }
     uint32_t seqBits = 1; while ((1ull << seqBits) < dbSize) seqBits++;
-    // front end: "fused" needs the target id to fit beside the 14-bit arrival index in a 32-bit LDS key
-    bool useFused = seqBits + ARR_BITS <= 32;
+    // front end: "fused" needs the target id to fit beside the 14-bit arrival index in a 32-bit LDS key (and the 22-bit field of
+    // the streamed tiers' records)
+    bool useFused = seqBits + ARR_BITS <= 32 && seqBits <= REC_T_BITS;
     if (const char *e = getenv("MK_PREFILTER_PATH")) {
         if (!strcmp(e, "global")) useFused = false;
         else if (strcmp(e, "fused") && strcmp(e, "auto")) { err = "MK_PREFILTER_PATH must be auto, fused or global"; return MK_ERR_ARG; }
@@ -1020,14 +1333,15 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                 double limit[N_TIERS];                                      // most k-mers a query may have to be tried in tier t
                 for (int t = 0; t < N_TIERS; t++) {
                     const double hpk = g_memo.hitsPerKmer[t] > 0 ? g_memo.hitsPerKmer[t] : std::max(0.05, (double) V.n_entries / 64.0e6);
-                    limit[t] = ((double) tiers[t].cap - 32.0 * tiers[t].waves) / (hpk * g_memo.margin[t]);   // half a 64-slot chunk lost per wave
+                    const double lost = tiers[t].kind == 0 ? 32.0 * tiers[t].waves : 0.0;       // LDS tiers: half a 64-slot chunk lost per wave
+                    limit[t] = ((double) tiers[t].cap - lost) / (hpk * g_memo.margin[t]);
                 }
                 for (uint32_t ql = 0; ql < nqc; ql++) {
                     if (hQK[ql] == 0) continue;                             // no k-mer: no hits
                     const double km = (double) hQK[ql];
                     const int npos = (int) (qOff[(size_t) q0 + ql + 1] - qOff[(size_t) q0 + ql]) - 9;
                     int t = 0;
-                    while (t < nTiersUsed && (km > limit[t] || npos > fused_max_positions(tiers[t].cap))) t++;
+                    while (t < nTiersUsed && (km > limit[t] || npos > tiers[t].maxpos)) t++;
                     if (t == nTiersUsed || t < firstTier) fallback.push_back(ql); else lists[t].push_back(q0 + ql);
                 }
                 for (int t = 0; t < N_TIERS; t++) nListed += lists[t].size();
@@ -1046,7 +1360,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             for (int t = 0; t < N_TIERS; t++) {
                 thFused[t] = -1;
                 const size_t grid = t < nTiersUsed ? lists[t].size() + lower : 0;
-                if (grid > 0) {
+                if (grid > 0 && tiers[t].kind == 0) {
                     FusedArgs A;
                     A.V = V; A.queries = dList + at; A.n_own = (uint32_t) lists[t].size(); A.n_launch = (uint32_t) grid; A.q_first = q0;
                     A.prev_list = t > 0 ? dOvf + (size_t) (t - 1) * nqc : nullptr; A.prev_count = t > 0 ? dCounters + 4 + (t - 1) : dCounters + 15;   // [15] stays 0
@@ -1056,6 +1370,29 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                     snprintf(nm, sizeof(nm), "prefilter_fused_lds%d", tiers[t].cap);
                     thFused[t] = tb(nm, 0, 0);
                     launch_fused(tierBase + t, A, stream);
+                    te(thFused[t]);
+                    PCHK(hipGetLastError());
+                } else if (grid > 0) {
+                    // streamed tier: persistent workgroups, each with its own hit region
+                    static int cus = 0;
+                    if (!cus) { int dev = 0; (void) hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
+                    int perCu = tiers[t].wgPerCu;
+                    if (const char *e = getenv(t == 2 ? "MK_STREAM_WG_PER_CU_A" : "MK_STREAM_WG_PER_CU_B")) perCu = std::max(1, atoi(e));
+                    const unsigned launch = (unsigned) std::min<size_t>(grid, (size_t) cus * perCu);
+                    char pn[32];
+                    snprintf(pn, sizeof(pn), "pf_pool%d", t);
+                    StreamArgs A;
+                    A.pool = (uint64_t *) dev_scratch(pn, (size_t) launch * tiers[t].cap * 8);
+                    PNULL(A.pool);
+                    A.V = V; A.queries = dList + at; A.n_own = (uint32_t) lists[t].size(); A.q_first = q0;
+                    A.prev_list = t > 0 ? dOvf + (size_t) (t - 1) * nqc : nullptr; A.prev_count = t > 0 ? dCounters + 4 + (t - 1) : dCounters + 15;
+                    A.C = C; A.cand_cap = CAND_CAP; A.counters = dCounters;
+                    A.overflow_list = dOvf + (size_t) t * nqc; A.overflow_count = dCounters + 4 + t; A.totals = dFTotals + 16 * t;
+                    A.work_counter = dCounters + 8 + t;
+                    char nm[48];
+                    snprintf(nm, sizeof(nm), "prefilter_stream_cap%d", tiers[t].cap);
+                    thFused[t] = tb(nm, 0, 0);
+                    launch_stream(tierBase + t, A, launch, stream);
                     te(thFused[t]);
                     PCHK(hipGetLastError());
                 }
@@ -1068,8 +1405,8 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             if (getenv("MK_PREFILTER_DEBUG"))
                 for (int t = 0; t < N_TIERS; t++) {
                     const unsigned long long *T = hFTotals + 16 * (t + 1);
-                    fprintf(stderr, "[prefilter]   tier %d (lds %d): queries %zu overflowed %llu | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g sort %.3g emit %.3g overflowed %.3g\n",
-                            t, tiers[t].cap, lists[t].size(), T[8], (double) T[0], (double) T[1], (double) T[2], (double) T[3], (double) T[4], (double) T[5], (double) T[6]);
+                    fprintf(stderr, "[prefilter]   tier %d (%s %d): queries %zu overflowed %llu | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g sort %.3g emit %.3g overflowed %.3g | extra class passes %llu\n",
+                            t, tiers[t].kind ? "region" : "lds", tiers[t].cap, lists[t].size(), T[8], (double) T[0], (double) T[1], (double) T[2], (double) T[3], (double) T[4], (double) T[5], (double) T[6], T[9]);
                 }
             const uint32_t nOvf = hCounters[4 + nTiersUsed - 1];               // what even the largest tier in use could not hold
             if (hCounters[0] > CAND_CAP) rc = RC_CAND_OVERFLOW;
@@ -1231,13 +1568,22 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                 PCHK(hipMemcpyAsync(hHC, dHC, (size_t) nFlagged * sizeof(HostCand), hipMemcpyDeviceToHost, stream));
                 PCHK(sync_wait(stream, "wait_prefilter"));
                 ScopedHost sh("host_prefilter_maxseqs");
-                std::vector<uint32_t> runStart;                    // candidate runs, one per flagged query
+                // candidate runs of the flagged queries: one per query, or one per class pass of a streamed query (the runs of one
+                // query need not be adjacent) -- grouped by query below
+                std::vector<uint32_t> runStart;
                 for (uint32_t k = 0; k < nFlagged; k++) if (k == 0 || hHC[k].q != hHC[k - 1].q) runStart.push_back(k);
                 runStart.push_back(nFlagged);
-                const size_t nRuns = runStart.size() - 1;
-                std::vector<uint32_t> runOrder(nRuns);             // the merge below walks the queries in ascending order
+                const size_t nRunsRaw = runStart.size() - 1;
+                std::vector<uint32_t> runOrder(nRunsRaw);          // the merge below walks the queries in ascending order
                 std::iota(runOrder.begin(), runOrder.end(), 0u);
-                std::sort(runOrder.begin(), runOrder.end(), [&](uint32_t x, uint32_t y) { return hHC[runStart[x]].q < hHC[runStart[y]].q; });
+                std::sort(runOrder.begin(), runOrder.end(), [&](uint32_t x, uint32_t y) {
+                    const uint32_t qx = hHC[runStart[x]].q, qy = hHC[runStart[y]].q;
+                    return qx != qy ? qx < qy : x < y;
+                });
+                std::vector<uint32_t> groupStart;                  // first entry of runOrder of every flagged query
+                for (size_t r = 0; r < nRunsRaw; r++) if (r == 0 || hHC[runStart[runOrder[r]]].q != hHC[runStart[runOrder[r - 1]]].q) groupStart.push_back((uint32_t) r);
+                groupStart.push_back((uint32_t) nRunsRaw);
+                const size_t nRuns = groupStart.size() - 1;
                 hostQ.resize(nRuns);
                 hostHits.resize(nRuns);
                 int failed = 0;
@@ -1246,10 +1592,12 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                     std::vector<Cand> perQuery;
 #pragma omp for schedule(dynamic, 4)
                     for (size_t r = 0; r < nRuns; r++) {
-                        const uint32_t k0 = runStart[runOrder[r]], k1 = runStart[runOrder[r] + 1];
-                        const uint32_t ql = hHC[k0].q;
+                        const uint32_t ql = hHC[runStart[runOrder[groupStart[r]]]].q;
                         perQuery.clear();
-                        for (uint32_t k = k0; k < k1; k++) perQuery.push_back(Cand{hHC[k].id, hHC[k].diag, hHC[k].score, hHC[k].ordinal});
+                        for (uint32_t g = groupStart[r]; g < groupStart[r + 1]; g++) {
+                            const uint32_t k0 = runStart[runOrder[g]], k1 = runStart[runOrder[g] + 1];
+                            for (uint32_t k = k0; k < k1; k++) perQuery.push_back(Cand{hHC[k].id, hHC[k].diag, hHC[k].score, hHC[k].ordinal});
+                        }
                         std::sort(perQuery.begin(), perQuery.end(), [](const Cand &a, const Cand &b) { return a.ordinal < b.ordinal; });
                         const uint32_t q = q0 + ql;
                         int n255 = 0;
