@@ -7,20 +7,24 @@
 //   keepMaxScoreElementOnly / threshold / getResult / sort    M/src/prefiltering/QueryMatcher.cpp:149-209
 //
 // Two front ends produce the CANDIDATES of a chunk of queries (the (query, target, diagonal) triples that survive
-// the double-diagonal rule, per query contiguous and ordered by (target, arrival)):
+// the double-diagonal rule; the candidates of a (query, target) pair are contiguous and in arrival order):
 //
-//  A. fused_kernel  (queries whose index hits fit in the LDS of one workgroup -- the metagenomic fragment case)
-//     one workgroup per query: the waves take k-mer starts from a shared counter, enumerate their similar k-mers
-//     (mk_enum.hpp: product order of the reference, no searches), probe the index and drop (target, diagonal)
-//     straight into LDS in 64-slot chunks whose arrival rank is (position, chunk, offset); two LDS bitmaps tell which
-//     targets were hit more than once -- only those (and single hits with diagonal low byte 0) can satisfy the
-//     double-diagonal rule; the survivors are compacted in place and sorted on (target, arrival) by an in-LDS bitonic
-//     network; the sequential 8-bit-diagonal rule of findDuplicates becomes a neighbour test + short backward walk;
-//     only the resulting candidates leave the CU.  Four LDS tiers (2 K .. 16 K hits); the host picks the tier from the
-//     exact similar-k-mer count of the query (kmer_count_kernel); a query that overflows its tier is retried by the next
-//     larger tier in the same stream, and by path B after the largest.  HBM traffic = the index probes, nothing else.
+//  A. stream_kernel  (every query whose index hits fit a 64 K-hit region -- practically all ORF fragments)
+//     persistent workgroups pull queries from a counter; each owns one hit region in HBM that it rewrites query after
+//     query (it stays in L2 / Infinity Cache).  The waves take the k-mer starts of the query, most expensive first,
+//     enumerate their similar k-mers (mk_enum.hpp: product order of the reference, no searches), probe the index and
+//     append 8-byte hit records target | diagonal | start | ordinal to the region: the arrival order is in the record.
+//     Two LDS bitmaps tell which targets were hit more than once -- only those (and single hits with diagonal low byte 0)
+//     can satisfy the double-diagonal rule; pass 2 streams the region back, keeps those survivors, sorts them in LDS by
+//     (target, arrival) with a bitonic network and evaluates the sequential 8-bit-diagonal rule of findDuplicates as a
+//     neighbour test + short backward walk; only the resulting candidates leave the CU.  A query with more survivors
+//     than the LDS sort holds is processed in target classes, one pass each.  Four shapes (one wave per query for the
+//     tiny fragments, 4 and 16 waves for the larger ones); the host picks the tier from the exact similar-k-mer count
+//     of the query (kmer_count_kernel); a query that overflows its region is retried by the next larger tier in the same
+//     stream, and by path B after the largest.  One enumeration, one probe of the index per similar k-mer.
 //
-//  B. global path   (everything else: long queries, queries that overflow their LDS tier, big databases)
+//  B. global path   (everything else: very long queries, queries that overflow the largest region, databases with
+//     more than 2^22 targets)
 //     probe_kernel<COUNT> -> exclusive scan -> probe_kernel<GATHER> (one 64-bit record per index hit: query | target | low
 //     diagonal byte | arrival number within the query, written query-major) -> per-query segmented radix sort over the target
 //     bits (hipcub; stable, so a pair's records stay in arrival order) -> double_hit_count_kernel -> block scan ->
@@ -108,10 +112,22 @@ struct ProbeArgs {
     uint64_t *keys; uint8_t *diag_hi; // GATHER outputs: one 8-byte record per index hit + the diagonal's high byte
 };
 
+// slot and entry reads are one-touch random probes of tables far larger than L2; MK_NT_LOADS=1 marks them non-temporal so that
+// they do not push the k-mer presence bitmap (8 MB, re-read all the time) out of the 4 MB L2s
+#ifndef MK_NT_LOADS
+#define MK_NT_LOADS 0
+#endif
+__device__ __forceinline__ uint64_t ld_probe(const uint64_t *p) {
+#if MK_NT_LOADS
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
 // index list of a k-mer from its slot: length, first entry index, and the first entry itself when the slot holds it
 struct KmerList { uint32_t size, first; uint64_t ent0; bool isInline; };
 __device__ __forceinline__ KmerList load_kmer_list(const uint64_t *slots, uint32_t kmer) {
-    const uint64_t s = slots[kmer];
+    const uint64_t s = ld_probe(slots + kmer);
     KmerList l;
     l.isInline = (s >> 63) != 0;
     l.size = l.isInline ? 1u : (uint32_t) (s >> 32);
@@ -124,11 +140,7 @@ __device__ __forceinline__ bool kmer_present(const uint32_t *bits, uint32_t kmer
 #ifndef MK_PROBE_U
 #define MK_PROBE_U 4
 #endif
-#ifndef MK_T2_WAVES
-#define MK_T2_WAVES 8
-#endif
 constexpr int PROBE_U = MK_PROBE_U;        // 64-k-mer groups whose index probes are issued together (global path)
-constexpr int FUSED_U = 2;                 // ... in the fused kernels (smaller: the window scratch competes with the hit store for LDS)
 
 template <bool GATHER>
 __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
@@ -299,11 +311,12 @@ __global__ __launch_bounds__(256) void gather_queries_kernel(PrefilterDeviceView
 // Exact number of similar k-mers of every k-mer start, without enumerating them: with the per-row score histograms the
 // staircase sum over (first half, second half) collapses to sum_s hist0[s] * cum1[thr - s].  Summed per query; the host
 // sizes the LDS tier of each query with it.
-__global__ __launch_bounds__(256) void kmer_count_kernel(PrefilterDeviceView V, uint64_t posBegin, uint64_t posEnd, uint32_t qFirst, uint32_t *perQuery) {
+__global__ __launch_bounds__(256) void kmer_count_kernel(PrefilterDeviceView V, uint64_t posBegin, uint64_t posEnd, uint32_t qFirst, uint32_t *perQuery,
+                                                        uint16_t *perPos /* [p - posBegin]: similar k-mers of the start / 4, saturated (work estimate) */) {
     const uint64_t p = posBegin + (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= posEnd) return;
     const int thr = (int) V.q_kmer_thr[p];
-    if (thr < 0) return;
+    if (thr < 0) { perPos[p - posBegin] = 0; return; }
     const uint8_t *r = V.q_res + p;
     const uint32_t idx0 = r[0] + 20u * r[1] + 400u * r[3];
     const uint32_t idx1 = r[5] + 20u * r[8] + 400u * r[9];
@@ -317,293 +330,14 @@ __global__ __launch_bounds__(256) void kmer_count_kernel(PrefilterDeviceView V, 
         if (x >= R) break;                             // the second half cannot reach the cutoff any more (scores only fall)
         total += h * (x <= 0 ? (uint32_t) N3 : (uint32_t) c1[x]);
     }
+    perPos[p - posBegin] = (uint16_t) min((total + 3u) >> 2, 65535u);
     if (total) atomicAdd(&perQuery[find_query(V.q_off, V.n_queries, p) - qFirst], total);
 }
 
-// =====================================================================================================
-//  A. fused per-query path
-// =====================================================================================================
-constexpr uint32_t ARR_BITS = 14;                 // arrival index field of the LDS sort key (<= 16384 slots)
-constexpr uint32_t ARR_MASK = (1u << ARR_BITS) - 1u;
-constexpr uint32_t KEY_SENTINEL = 0xFFFFFFFFu;
-
-struct FusedArgs {
-    PrefilterDeviceView V;
-    const uint32_t *queries;          // (global) query ids assigned to this tier, one workgroup each ...
-    uint32_t n_own;
-    const uint32_t *prev_list;        // ... followed by the queries that overflowed the next smaller tier (chunk-local ids,
-    const uint32_t *prev_count;       //     count known on the device only; surplus workgroups exit)
-    uint32_t n_launch;
-    uint32_t q_first;                 // first query of the chunk: candidates carry q - q_first
-    CandArrays C; uint32_t cand_cap;
-    uint32_t *counters;               // [0] candidates appended
-    uint32_t *overflow_list;          // chunk-local ids of the queries that did not fit this tier
-    uint32_t *overflow_count;
-    unsigned long long *totals;       // [0] k-mers [1] index hits [2] k-mer start positions (statistics / tier sizing) [3..6] workgroup time: gather, sort, rule+emit, overflowed
-};
-
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
-// k-mer starts a query may have in the tier with `cap` hit slots (bounds the per-position tables in LDS)
-constexpr int fused_max_positions(int cap) { return cap / 16 < 64 ? 64 : (cap / 16 > 512 ? 512 : cap / 16); }
-
-template <int CAP, int NW>
-__global__ __launch_bounds__(NW * 64) void fused_kernel(FusedArgs A) {
-    constexpr int NCH = CAP / WAVE;               // 64-slot chunks of the hit store
-    constexpr int BLOCK = NW * WAVE;
-    constexpr int MBITS = 2 * CAP;                // buckets of the multi-hit filter (two bitmaps: CAP / 2 bytes)
-    constexpr int LOG_MBITS = ilog2(MBITS);
-    __shared__ uint32_t sKey[CAP];                // phase 1: target id; afterwards target << ARR_BITS | arrival
-    __shared__ uint16_t sDiag[CAP];
-    __shared__ uint32_t sBm1[MBITS / 32], sBm2[MBITS / 32];   // bucket hit once / more than once
-    __shared__ enumk::EnumLds<FUSED_U> sE[NW];
-    __shared__ uint8_t sMark[NW][WAVE];
-    constexpr int MAXPOS = fused_max_positions(CAP);
-    __shared__ uint16_t sChunkOf[NW][NCH];        // chunk number within the wave's current position -> physical chunk
-    __shared__ uint16_t sRankToChunk[NCH];        // arrival rank of a chunk -> physical chunk
-    __shared__ uint16_t sChunkRank[NCH];          // physical chunk -> arrival rank
-    __shared__ uint16_t sChunkPos[NCH], sChunkSeq[NCH];   // owner position of a chunk, its number within that position
-    __shared__ uint16_t sPosChunks[MAXPOS], sPosHits[MAXPOS], sPosBase[MAXPOS];
-    __shared__ uint32_t sWaveHits[NW], sWaveKmers[NW], sWavePos[NW];
-    __shared__ uint32_t sNextPos;
-    __shared__ uint32_t sFlagBits[CAP / 32];
-    __shared__ uint32_t sWordPrefix[CAP / 32];
-    __shared__ uint32_t sBump, sOverflow, sEmitBase;
-    __shared__ uint32_t sWaveCnt[NW];
-
-    // these waves spend most of their life waiting for index probes: when they do have an instruction, it goes first
-    // (the Smith-Waterman waves of the other stream fill every remaining issue slot)
-    __builtin_amdgcn_s_setprio(3);
-    const int tid = threadIdx.x, w = tid / WAVE, lane = tid & (WAVE - 1);
-    uint32_t q;
-    if (blockIdx.x < A.n_own) q = A.queries[blockIdx.x];
-    else {
-        const uint32_t k = blockIdx.x - A.n_own;
-        if (k >= A.prev_count[0]) return;
-        q = A.q_first + A.prev_list[k];
-    }
-    const uint64_t qs = A.V.q_off[q];
-    const int L = (int) (A.V.q_off[q + 1] - qs);
-    const int nStart = L >= 10 ? L - 9 : 0;       // k-mer starts (<= MAXPOS: the host sends longer queries elsewhere)
-    if (tid == 0) { sBump = 0; sOverflow = nStart > MAXPOS ? 1u : 0u; sNextPos = 0; }
-    for (int k = tid; k < MBITS / 32; k += BLOCK) { sBm1[k] = 0; sBm2[k] = 0; }
-    for (int k = tid; k < MAXPOS; k += BLOCK) { sPosChunks[k] = 0; sPosHits[k] = 0; }
-    __syncthreads();
-    const unsigned long long tStart = wall_clock64();
-
-    // ---- phase 1: enumerate + gather into LDS.  The waves take the k-mer starts one at a time from a shared counter; the
-    //      hits of a position go to 64-entry chunks from a workgroup-wide bump allocator, so the arrival order of a slot is
-    //      (position, chunk number within the position, offset) whatever wave produced it.
-    uint32_t whits = 0, kmers = 0, npos = 0;
-    bool dead = false;
-    while (!dead) {
-        uint32_t iu = 0;
-        if (lane == 0) iu = atomicAdd(&sNextPos, 1u);
-        const int i = __builtin_amdgcn_readfirstlane((int) iu);
-        if (i >= nStart) break;
-        const uint64_t p = qs + (uint64_t) i;
-        const int thr = (int) A.V.q_kmer_thr[p];
-        if (thr < 0) continue;
-        if (*(volatile uint32_t *) &sOverflow) { dead = true; break; }
-        npos++;
-        uint32_t wcount = 0, nCh = 0;               // hits / chunks of this position
-        kmers += enumk::enumerate_position<FUSED_U>(A.V, A.V.q_res + p, thr, lane, sE[w],
-            [&](const uint32_t (&kmer)[FUSED_U], const bool (&has)[FUSED_U]) -> bool {
-                uint32_t size[FUSED_U], o0[FUSED_U], ex[FUSED_U];
-                uint64_t ent0[FUSED_U];
-                bool inl[FUSED_U];
-#pragma unroll
-                for (int u = 0; u < FUSED_U; u++) {
-                    size[u] = 0; o0[u] = 0; ent0[u] = 0; inl[u] = true;
-                    if (has[u] && kmer_present(A.V.kmer_bits, kmer[u])) { const KmerList l = load_kmer_list(A.V.kmer_slot, kmer[u]); o0[u] = l.first; size[u] = l.size; ent0[u] = l.ent0; inl[u] = l.isInline; }
-                }
-#pragma unroll
-                for (int u = 0; u < FUSED_U; u++) if (!inl[u]) ent0[u] = A.V.entries[o0[u]];       // first entry of the longer lists (single-entry lists came with the slot)
-                uint32_t totAll = 0;
-#pragma unroll
-                for (int u = 0; u < FUSED_U; u++) { const uint32_t incl = enumk::wave_incl_scan(size[u]); ex[u] = incl - size[u] + totAll; totAll += enumk::wave_last(incl); }
-                if (totAll == 0) return true;
-                while (nCh * WAVE < wcount + totAll) {                  // wave-uniform: more slots for these groups
-                    uint32_t c = 0;
-                    if (lane == 0) c = atomicAdd(&sBump, 1u);
-                    c = (uint32_t) __builtin_amdgcn_readfirstlane((int) c);
-                    if (c >= (uint32_t) NCH) { dead = true; break; }
-                    if (lane == 0) { sChunkOf[w][nCh] = (uint16_t) c; sChunkPos[c] = (uint16_t) i; sChunkSeq[c] = (uint16_t) nCh; }
-                    nCh++;
-                }
-                if (dead) { if (lane == 0) sOverflow = 1; return false; }
-                wave_sync_lds();
-#pragma unroll
-                for (int u = 0; u < FUSED_U; u++) {
-                    const uint32_t v0 = wcount + ex[u];
-                    const auto put = [&](uint64_t ent, uint32_t v) {
-                        const uint32_t phys = (uint32_t) sChunkOf[w][v >> 6] * WAVE + (v & 63u);
-                        sKey[phys] = (uint32_t) ent;
-                        sDiag[phys] = (uint16_t) (((uint32_t) i - ((uint32_t) (ent >> 32) & 0xFFFFu)) & 0xFFFFu);
-                        // multi-hit filter: a bucket seen twice keeps all its hits for the sort (same target => same bucket)
-                        const uint32_t hb = ((uint32_t) ent * 2654435761u) >> (32 - LOG_MBITS);
-                        const uint32_t bit = 1u << (hb & 31u);
-                        if (atomicOr(&sBm1[hb >> 5], bit) & bit) atomicOr(&sBm2[hb >> 5], bit);
-                    };
-                    if (size[u]) put(ent0[u], v0);
-                    // the rest of the longer lists, one entry per lane
-                    enumk::wave_deal_tail(size[u] > 1 ? size[u] - 1 : 0u, lane, sMark[w], [&](uint32_t owner, uint32_t e, bool valid) {
-                        const uint32_t oFirst = enumk::wave_read_lane(o0[u], owner), oV0 = enumk::wave_read_lane(v0, owner);
-                        if (valid) put(A.V.entries[oFirst + e], oV0 + e);
-                    });
-                }
-                wcount += totAll;
-                return true;
-            });
-        if (lane == 0) { sPosChunks[i] = (uint16_t) nCh; sPosHits[i] = (uint16_t) wcount; }
-        whits += wcount;
-    }
-    if (lane == 0) { sWaveHits[w] = whits; sWaveKmers[w] = kmers; sWavePos[w] = npos; atomicAdd(&A.totals[7], (wall_clock64() - tStart) / NW); }
-    __syncthreads();
-    const unsigned long long tGather = wall_clock64();
-    if (sOverflow) {                                   // does not fit this tier: the global path takes the query
-        if (tid == 0) { A.overflow_list[atomicAdd(A.overflow_count, 1u)] = q - A.q_first; atomicAdd(&A.totals[6], tGather - tStart); atomicAdd(&A.totals[8], 1ull); }
-        return;
-    }
-    if (tid == 0) {
-        uint32_t hits = 0, km = 0, np = 0;
-        for (int k = 0; k < NW; k++) { hits += sWaveHits[k]; km += sWaveKmers[k]; np += sWavePos[k]; }
-        atomicAdd(&A.totals[0], (unsigned long long) km);
-        atomicAdd(&A.totals[1], (unsigned long long) hits);
-        atomicAdd(&A.totals[2], (unsigned long long) np);
-    }
-    const uint32_t nChunks = sBump;
-    if (nChunks == 0) return;
-    const uint32_t used = nChunks * WAVE;
-    // chunk ranks: exclusive prefix of the chunk counts over the positions (one wave), then rank = base(position) + number
-    if (w == 0) {
-        const uint32_t perLane = ((uint32_t) nStart + WAVE - 1) / WAVE;
-        const uint32_t b = min((uint32_t) nStart, (uint32_t) lane * perLane), e = min((uint32_t) nStart, b + perLane);
-        uint32_t sum = 0;
-        for (uint32_t k = b; k < e; k++) sum += sPosChunks[k];
-        uint32_t run = enumk::wave_incl_scan(sum) - sum;
-        for (uint32_t k = b; k < e; k++) { sPosBase[k] = (uint16_t) run; run += sPosChunks[k]; }
-    }
-    __syncthreads();
-    for (uint32_t c = (uint32_t) tid; c < nChunks; c += BLOCK) {
-        const uint32_t rank = (uint32_t) sPosBase[sChunkPos[c]] + sChunkSeq[c];
-        sRankToChunk[rank] = (uint16_t) c;
-        sChunkRank[c] = (uint16_t) rank;
-    }
-    __syncthreads();
-    // Only targets hit more than once can satisfy the double-diagonal rule, plus single hits whose diagonal low byte is 0
-    // (the first hit of a target is compared with 0).  Survivors get their sort key target << ARR_BITS | arrival and are
-    // compacted in place: a batch is read, then written at or before its own slots.
-    uint32_t nSurv = 0;
-    for (uint32_t s0 = 0; s0 < used; s0 += BLOCK) {
-        const uint32_t s = s0 + (uint32_t) tid;
-        bool surv = false;
-        uint32_t key = KEY_SENTINEL;
-        if (s < used) {
-            const uint32_t c = s >> 6, rank = sChunkRank[c];
-            const uint32_t v = (uint32_t) sChunkSeq[c] * WAVE + (s & 63u);    // slot number within the position
-            if (v < (uint32_t) sPosHits[sChunkPos[c]]) {
-                const uint32_t tgt = sKey[s];
-                const uint32_t hb = (tgt * 2654435761u) >> (32 - LOG_MBITS);
-                surv = ((sBm2[hb >> 5] >> (hb & 31u)) & 1u) || ((uint32_t) sDiag[s] & 0xFFu) == 0u;
-                key = (tgt << ARR_BITS) | (rank * WAVE + (s & 63u));
-            }
-        }
-        const unsigned long long m = __ballot(surv);
-        if (lane == 0) sWaveCnt[w] = (uint32_t) __popcll(m);
-        __syncthreads();
-        uint32_t before = nSurv, all = 0;
-        for (int k = 0; k < NW; k++) { const uint32_t cnt = sWaveCnt[k]; if (k < w) before += cnt; all += cnt; }
-        if (surv) sKey[before + (uint32_t) __popcll(m & ((1ull << lane) - 1ull))] = key;
-        nSurv += all;
-        __syncthreads();
-    }
-    if (nSurv == 0) return;
-    uint32_t P = WAVE;
-    while (P < nSurv) P <<= 1;
-    for (uint32_t s = nSurv + (uint32_t) tid; s < P; s += BLOCK) sKey[s] = KEY_SENTINEL;
-    __syncthreads();
-
-    // ---- phase 2: bitonic sort of the keys (all distinct: the arrival index makes the order total)
-    for (uint32_t k = 2; k <= P; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = (uint32_t) tid; i < (P >> 1); i += BLOCK) {
-                const uint32_t l = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
-                const uint32_t r2 = l | j;
-                const uint32_t x = sKey[l], y = sKey[r2];
-                const bool up = (l & k) == 0;
-                if ((x > y) == up) { sKey[l] = y; sKey[r2] = x; }
-            }
-            __syncthreads();
-        }
-    }
-
-    const unsigned long long tSort = wall_clock64();
-    // ---- phase 3: the double-diagonal rule on the target runs -> flag bits
-    auto lo_of = [&](uint32_t key) -> uint32_t {
-        const uint32_t arr = key & ARR_MASK;
-        return (uint32_t) sDiag[(uint32_t) sRankToChunk[arr >> 6] * WAVE + (arr & 63u)] & 0xFFu;
-    };
-    for (uint32_t t0 = 0; t0 < P; t0 += BLOCK) {
-        const uint32_t t = t0 + (uint32_t) tid;
-        bool emit = false;
-        if (t < P) {
-            const uint32_t key = sKey[t];
-            if (key != KEY_SENTINEL) {
-                const uint32_t target = key >> ARR_BITS, lo = lo_of(key);
-                const bool samePrev = t > 0 && (sKey[t - 1] >> ARR_BITS) == target;
-                const uint32_t prevLo = samePrev ? lo_of(sKey[t - 1]) : 0u;
-                if (lo == prevLo) {
-                    emit = true;
-                    if (samePrev) {
-                        uint32_t u = t - 1;
-                        while (true) {
-                            const uint32_t ulo = lo_of(sKey[u]);
-                            const bool uSame = u > 0 && (sKey[u - 1] >> ARR_BITS) == target;
-                            const uint32_t uprev = uSame ? lo_of(sKey[u - 1]) : 0u;
-                            if (ulo == uprev) { emit = (ulo != lo); break; }
-                            if (!uSame) break;
-                            u--;
-                        }
-                    }
-                }
-            }
-        }
-        const unsigned long long m = __ballot(emit);
-        if (lane == 0 && t < P) { sFlagBits[t >> 5] = (uint32_t) m; sFlagBits[(t >> 5) + 1] = (uint32_t) (m >> 32); }
-    }
-    __syncthreads();
-    // exclusive prefix of the per-word popcounts (one wave; <= 512 words)
-    const uint32_t nWords = P >> 5;
-    if (w == 0) {
-        const uint32_t perLane = (nWords + WAVE - 1) / WAVE;
-        const uint32_t b = min(nWords, (uint32_t) lane * perLane), e = min(nWords, b + perLane);
-        uint32_t sum = 0;
-        for (uint32_t k = b; k < e; k++) sum += (uint32_t) __popc(sFlagBits[k]);
-        uint32_t total;
-        uint32_t run = wave_excl_scan(sum, total);
-        for (uint32_t k = b; k < e; k++) { sWordPrefix[k] = run; run += (uint32_t) __popc(sFlagBits[k]); }
-        if (lane == 0) { sEmitBase = total ? atomicAdd(&A.counters[0], total) : 0u; sBump = total; }
-    }
-    __syncthreads();
-    const uint32_t nEmit = sBump, base = sEmitBase;
-    if (tid == 0) {                                    // time split of the workgroup (100 MHz ticks), statistics only
-        atomicAdd(&A.totals[3], tGather - tStart); atomicAdd(&A.totals[4], tSort - tGather); atomicAdd(&A.totals[5], wall_clock64() - tSort);
-    }
-    if (nEmit == 0 || (unsigned long long) base + nEmit > (unsigned long long) A.cand_cap) return;   // host sees counters[0] > cap and retries
-    for (uint32_t t = (uint32_t) tid; t < P; t += BLOCK) {
-        const uint32_t word = sFlagBits[t >> 5];
-        if (!((word >> (t & 31u)) & 1u)) continue;
-        const uint32_t dst = base + sWordPrefix[t >> 5] + (uint32_t) __popc(word & ((1u << (t & 31u)) - 1u));
-        const uint32_t key = sKey[t], arr = key & ARR_MASK;
-        A.C.q[dst] = q - A.q_first;
-        A.C.id[dst] = key >> ARR_BITS;
-        A.C.ordinal[dst] = arr;
-        A.C.diag[dst] = sDiag[(uint32_t) sRankToChunk[arr >> 6] * WAVE + (arr & 63u)];
-    }
-}
 
 // =====================================================================================================
-//  A2. streamed per-query path: the index hits of a query pass through a workgroup-private region in HBM
+//  A. per-query path: the index hits of a query pass through a workgroup-private region in HBM
 // =====================================================================================================
 // One enumeration, any query the region holds.  The workgroups are persistent (a fixed number per CU pull queries from a
 // counter), so every workgroup owns ONE hit region for its whole life: the region is rewritten query after query and stays in
@@ -625,11 +359,34 @@ struct StreamArgs {
     CandArrays C; uint32_t cand_cap;
     uint32_t *counters;                               // [0] candidates appended
     uint32_t *overflow_list; uint32_t *overflow_count;
-    unsigned long long *totals;                       // as FusedArgs::totals; [9] class passes beyond the first
+    unsigned long long *totals;                       // [0] k-mers [1] index hits [2] k-mer starts (statistics / tier sizing) [3..6] workgroup time: pass 1, collect + sort, rule + emit, overflowed; [7] mean wave time of pass 1 [8] overflowed queries [9] class passes beyond the first
     uint32_t *work_counter;                           // next item of (own list ++ overflow list)
     uint64_t *pool;                                   // gridDim.x regions of CAPH records
+    const uint16_t *pos_cost; uint64_t pos_begin;     // work estimate of every k-mer start of the chunk (kmer_count_kernel), [p - pos_begin]
 };
 
+#ifndef MK_STREAM_U
+#define MK_STREAM_U 2
+#endif
+#ifndef MK_STREAM_SKIP
+#define MK_STREAM_SKIP 0
+#endif
+// shapes of the two streamed tiers: waves per workgroup, LDS sort size, bitmap bits, workgroups per CU
+#ifndef MK_STREAM_NW_A
+#define MK_STREAM_NW_A 4
+#define MK_STREAM_SURV_A 1024
+#define MK_STREAM_MBITS_A 32768
+#define MK_STREAM_WG_A 8
+#endif
+#ifndef MK_STREAM_NW_B
+#define MK_STREAM_NW_B 16
+#define MK_STREAM_SURV_B 4096
+#define MK_STREAM_MBITS_B 131072
+#define MK_STREAM_WG_B 2
+#endif
+#ifndef MK_STREAM_PROF
+#define MK_STREAM_PROF 0        // 1: per-phase cycle counters in totals[10..15] (costs ~10 %)
+#endif
 constexpr uint32_t REC_T_BITS = 22, REC_POS_BITS = 12, REC_ORD_BITS = 14;     // + 16 bits of diagonal = 64
 constexpr int STREAM_MAX_CLASSES = 64;
 
@@ -649,6 +406,11 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
     Pass1Lds &P1 = *reinterpret_cast<Pass1Lds *>(sRaw);
     __shared__ uint32_t sBm1[MBITS / 32], sBm2[MBITS / 32];
     __shared__ uint32_t sPosBase[MAXPOS];             // hits of a k-mer start, then their exclusive prefix
+    constexpr int ORDER_N = MAXPOS < 64 ? 64 : MAXPOS;
+    static_assert(RAW >= sizeof(uint32_t) * ORDER_N, "the start order is sorted in the shared scratch");
+    __shared__ uint16_t sOrder[ORDER_N];              // k-mer starts by falling work estimate: the waves take the expensive ones first,
+                                                      // so they reach the end of pass 1 together
+    __shared__ uint32_t sNumOrder;                    // starts with k-mers
     __shared__ uint32_t sFlagBits[SURV / 32 + 2], sWordPrefix[SURV / 32 + 2];
     __shared__ uint32_t sWaveHits[NW], sWaveKmers[NW], sWavePos[NW];
     __shared__ uint32_t sClassCnt[STREAM_MAX_CLASSES];
@@ -675,18 +437,51 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
         const int nStart = L >= 10 ? L - 9 : 0;
         if (tid == 0) { sUsed = 0; sOverflow = nStart > MAXPOS ? 1u : 0u; sNextPos = 0; sSurv = 0; }
         for (int k = tid; k < MBITS / 32; k += BLOCK) { sBm1[k] = 0; sBm2[k] = 0; }
-        for (int k = tid; k < min(nStart, MAXPOS); k += BLOCK) sPosBase[k] = 0;
+        const int nOrd = min(nStart, MAXPOS);
+        uint32_t PO = WAVE;
+        while ((int) PO < nOrd) PO <<= 1;
+        for (int k = tid; k < nOrd; k += BLOCK) sPosBase[k] = 0;
+        uint32_t *sOrdKey = reinterpret_cast<uint32_t *>(sRaw);      // cost << 12 | start (the scratch is free until pass 1 begins)
+        for (int k = tid; k < (int) PO; k += BLOCK) sOrdKey[k] = k < nOrd ? ((uint32_t) A.pos_cost[qs - A.pos_begin + (uint64_t) k] << 12) | (uint32_t) k : 0u;
+        if (tid == 0) sNumOrder = 0;
         __syncthreads();
+        // descending bitonic sort of the k-mer starts by cost (starts without k-mers, cost 0, come last)
+        for (uint32_t k = 2; k <= PO; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = (uint32_t) tid; i < (PO >> 1); i += BLOCK) {
+                    const uint32_t l = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
+                    const uint32_t r2 = l | j;
+                    const uint32_t x = sOrdKey[l], y = sOrdKey[r2];
+                    const bool up = (l & k) == 0;
+                    if ((x < y) == up) { sOrdKey[l] = y; sOrdKey[r2] = x; }
+                }
+                __syncthreads();
+            }
+        }
+        for (int k = tid; k < nOrd; k += BLOCK) {
+            const uint32_t key = sOrdKey[k];
+            sOrder[k] = (uint16_t) (key & 0xFFFu);
+            if ((key >> 12) != 0u && (k + 1 == nOrd || (sOrdKey[k + 1] >> 12) == 0u)) sNumOrder = (uint32_t) k + 1u;
+        }
+        __syncthreads();
+        const int nWork = (int) sNumOrder;
         const unsigned long long tStart = wall_clock64();
 
         // ---- pass 1: enumerate + probe; hits -> region, target buckets -> the two bitmaps
         uint32_t whits = 0, kmers = 0, npos = 0;
         bool dead = false;
+#if MK_STREAM_PROF
+        unsigned long long pEnum = 0, pProbe = 0, pStore = 0, pMark = __builtin_readcyclecounter();
+#define PROF_LAP(acc) do { const unsigned long long n_ = __builtin_readcyclecounter(); acc += n_ - pMark; pMark = n_; } while (0)
+#else
+#define PROF_LAP(acc) do { } while (0)
+#endif
         while (!dead) {
             uint32_t iu = 0;
             if (lane == 0) iu = atomicAdd(&sNextPos, 1u);
-            const int i = __builtin_amdgcn_readfirstlane((int) iu);
-            if (i >= nStart) break;
+            const int io = __builtin_amdgcn_readfirstlane((int) iu);
+            if (io >= nWork) break;                        // (what is left are starts without k-mers)
+            const int i = (int) sOrder[io];
             const uint64_t p = qs + (uint64_t) i;
             const int thr = (int) A.V.q_kmer_thr[p];
             if (thr < 0) continue;
@@ -695,19 +490,38 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
             uint32_t wcount = 0;                           // hits of this k-mer start so far
             kmers += enumk::enumerate_position<U>(A.V, A.V.q_res + p, thr, lane, P1.e[w],
                 [&](const uint32_t (&kmer)[U], const bool (&has)[U]) -> bool {
+                    PROF_LAP(pEnum);
                     uint32_t size[U], o0[U], ex[U];
                     uint64_t ent0[U];
                     bool inl[U];
 #pragma unroll
                     for (int u = 0; u < U; u++) {
                         size[u] = 0; o0[u] = 0; ent0[u] = 0; inl[u] = true;
+#if MK_STREAM_SKIP == 3        // (timing experiments only: results are wrong) no bitmap, no slot, no entries
+                        if (has[u] && (kmer[u] % 3u) == 0u) { size[u] = 1; ent0[u] = (kmer[u] * 2654435761u) % A.V.n_targets | ((uint64_t) (kmer[u] & 255u) << 32); }
+#elif MK_STREAM_SKIP == 2      // bitmap only
+                        if (has[u] && kmer_present(A.V.kmer_bits, kmer[u])) { size[u] = 1; ent0[u] = (kmer[u] * 2654435761u) % A.V.n_targets | ((uint64_t) (kmer[u] & 255u) << 32); }
+#else
                         if (has[u] && kmer_present(A.V.kmer_bits, kmer[u])) { const KmerList l = load_kmer_list(A.V.kmer_slot, kmer[u]); o0[u] = l.first; size[u] = l.size; ent0[u] = l.ent0; inl[u] = l.isInline; }
+#endif
                     }
+#if MK_STREAM_SKIP == 1            // bitmap + slots, no entries
 #pragma unroll
-                    for (int u = 0; u < U; u++) if (!inl[u]) ent0[u] = A.V.entries[o0[u]];
+                    for (int u = 0; u < U; u++) if (!inl[u]) { ent0[u] = o0[u] % A.V.n_targets; size[u] = 1; }
+#else
+#pragma unroll
+                    for (int u = 0; u < U; u++) if (!inl[u]) ent0[u] = ld_probe(A.V.entries + o0[u]);
+#endif
                     uint32_t totAll = 0;
 #pragma unroll
                     for (int u = 0; u < U; u++) { const uint32_t incl = enumk::wave_incl_scan(size[u]); ex[u] = incl - size[u] + totAll; totAll += enumk::wave_last(incl); }
+#if MK_STREAM_PROF
+                    { uint64_t sink = 0;
+#pragma unroll
+                      for (int u = 0; u < U; u++) sink |= ent0[u];
+                      asm volatile("" :: "v"(sink)); }                          // the entry loads have landed
+#endif
+                    PROF_LAP(pProbe);
                     if (totAll == 0) return true;
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(&sUsed, totAll);           // the batch's slots: contiguous, hence coalesced stores
@@ -728,17 +542,26 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
                         if (size[u]) put(ent0[u], r0);
                         enumk::wave_deal_tail(size[u] > 1 ? size[u] - 1 : 0u, lane, P1.mark[w], [&](uint32_t owner, uint32_t e, bool valid) {
                             const uint32_t oFirst = enumk::wave_read_lane(o0[u], owner), oR0 = enumk::wave_read_lane(r0, owner);
-                            if (valid) put(A.V.entries[oFirst + e], oR0 + e);
+                            if (valid) put(ld_probe(A.V.entries + oFirst + e), oR0 + e);
                         });
                     }
                     wcount += totAll;
+                    PROF_LAP(pStore);
                     return true;
                 });
             if (lane == 0) sPosBase[i] = wcount;
             whits += wcount;
         }
+        PROF_LAP(pEnum);
+#if MK_STREAM_PROF
+        const unsigned long long pEnd1 = __builtin_readcyclecounter();
+#endif
         if (lane == 0) { sWaveHits[w] = whits; sWaveKmers[w] = kmers; sWavePos[w] = npos; atomicAdd(&A.totals[7], (wall_clock64() - tStart) / NW); }
         __syncthreads();                                   // (also orders the region stores before the reads of pass 2)
+#if MK_STREAM_PROF
+        if (lane == 0) { atomicAdd(&A.totals[10], pEnum); atomicAdd(&A.totals[11], pProbe); atomicAdd(&A.totals[12], pStore); atomicAdd(&A.totals[13], __builtin_readcyclecounter() - pEnd1); }
+        unsigned long long pP2 = __builtin_readcyclecounter();
+#endif
         const unsigned long long tGather = wall_clock64();
         if (sOverflow) {
             if (tid == 0) { A.overflow_list[atomicAdd(A.overflow_count, 1u)] = q - A.q_first; atomicAdd(&A.totals[6], tGather - tStart); atomicAdd(&A.totals[8], 1ull); }
@@ -770,6 +593,9 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
             if (lane == 0 && local) atomicAdd(&sSurv, local);
         }
         __syncthreads();
+#if MK_STREAM_PROF
+        if (tid == 0) atomicAdd(&A.totals[14], __builtin_readcyclecounter() - pP2);
+#endif
         const uint32_t nSurvAll = sSurv;
         if (nSurvAll == 0) continue;
         uint32_t nClasses = 1;
@@ -825,6 +651,9 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
                 }
             }
             __syncthreads();
+#if MK_STREAM_PROF
+            if (tid == 0) atomicAdd(&A.totals[15], (wall_clock64() - tc0));
+#endif
             const uint32_t nSurv = sSurv;
             if (nSurv == 0) continue;
             uint32_t P = WAVE;
@@ -905,29 +734,26 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
     }
 }
 
-// LDS tiers (kind 0: hits in LDS, fused_kernel) and streamed tiers (kind 1: hits in a workgroup-private HBM region, stream_kernel)
-struct FusedTier { int cap; int waves; int kind; int maxpos; int wgPerCu; };
+// Tiers of the per-query path: region size (hits), waves per workgroup, most k-mer starts, persistent workgroups per CU.  The two
+// small tiers are one-wave workgroups (no barriers; most ORF fragments are tiny), the larger ones spread the k-mer starts of a
+// query over 4 / 16 waves.
+struct FusedTier { int cap; int waves; int maxpos; int wgPerCu; };
 constexpr int N_TIERS = 4;
 // production tiers, then a miniature set (MK_PREFILTER_TIERS=tiny) with which small test inputs exercise every
-// workgroup shape, the overflow hand-over, the class passes of the streamed tiers and the global path
-const FusedTier TIERS[2 * N_TIERS] = {{2048, 4, 0, fused_max_positions(2048), 0}, {4096, 4, 0, fused_max_positions(4096), 0},
-                                      {8192, 8, 1, 512, 4}, {65536, 16, 1, 2048, 2},
-                                      {256, 4, 0, fused_max_positions(256), 0}, {512, 4, 0, fused_max_positions(512), 0},
-                                      {1024, 4, 1, 64, 4}, {4096, 8, 1, 256, 4}};
+// workgroup shape, the overflow hand-over, the class passes and the global path
+const FusedTier TIERS[2 * N_TIERS] = {{2048, 1, 64, 28}, {4096, 1, 128, 24},
+                                      {8192, MK_STREAM_NW_A, 512, MK_STREAM_WG_A}, {65536, MK_STREAM_NW_B, 2048, MK_STREAM_WG_B},
+                                      {256, 1, 32, 8}, {512, 1, 64, 8}, {1024, 4, 64, 4}, {4096, 8, 256, 4}};
 
-void launch_fused(int tier, const FusedArgs &A, hipStream_t stream) {
-    switch (tier) {
-        case 0: hipLaunchKernelGGL((fused_kernel<2048, 4>), dim3(A.n_launch), dim3(256), 0, stream, A); break;
-        case 1: hipLaunchKernelGGL((fused_kernel<4096, 4>), dim3(A.n_launch), dim3(256), 0, stream, A); break;
-        case 4: hipLaunchKernelGGL((fused_kernel<256, 4>), dim3(A.n_launch), dim3(256), 0, stream, A); break;
-        default: hipLaunchKernelGGL((fused_kernel<512, 4>), dim3(A.n_launch), dim3(256), 0, stream, A); break;
-    }
-}
 //                                    region (hits)  LDS sort  bitmap bits  k-mer starts  waves  probe groups
 void launch_stream(int tier, const StreamArgs &A, unsigned grid, hipStream_t stream) {
     switch (tier) {
-        case 2: hipLaunchKernelGGL((stream_kernel<8192, 2048, 65536, 512, 8, 2>), dim3(grid), dim3(512), 0, stream, A); break;
-        case 3: hipLaunchKernelGGL((stream_kernel<65536, 4096, 131072, 2048, 16, 2>), dim3(grid), dim3(1024), 0, stream, A); break;
+        case 0: hipLaunchKernelGGL((stream_kernel<2048, 256, 8192, 64, 1, MK_STREAM_U>), dim3(grid), dim3(64), 0, stream, A); break;
+        case 1: hipLaunchKernelGGL((stream_kernel<4096, 256, 8192, 128, 1, MK_STREAM_U>), dim3(grid), dim3(64), 0, stream, A); break;
+        case 2: hipLaunchKernelGGL((stream_kernel<8192, MK_STREAM_SURV_A, MK_STREAM_MBITS_A, 512, MK_STREAM_NW_A, MK_STREAM_U>), dim3(grid), dim3(64 * MK_STREAM_NW_A), 0, stream, A); break;
+        case 3: hipLaunchKernelGGL((stream_kernel<65536, MK_STREAM_SURV_B, MK_STREAM_MBITS_B, 2048, MK_STREAM_NW_B, MK_STREAM_U>), dim3(grid), dim3(64 * MK_STREAM_NW_B), 0, stream, A); break;
+        case 4: hipLaunchKernelGGL((stream_kernel<256, 64, 1024, 32, 1, 2>), dim3(grid), dim3(64), 0, stream, A); break;
+        case 5: hipLaunchKernelGGL((stream_kernel<512, 64, 1024, 64, 1, 2>), dim3(grid), dim3(64), 0, stream, A); break;
         case 6: hipLaunchKernelGGL((stream_kernel<1024, 128, 2048, 64, 4, 2>), dim3(grid), dim3(256), 0, stream, A); break;
         default: hipLaunchKernelGGL((stream_kernel<4096, 256, 8192, 256, 8, 2>), dim3(grid), dim3(512), 0, stream, A); break;
     }
@@ -1252,9 +1078,8 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     const uint32_t CAND_CAP = 96u << 20;              // candidates per chunk held in HBM (~44 B each)
     if (dbSize >= (1ull << 27)) { err = "more than 2^27 targets"; return MK_ERR_UNSUPPORTED; }
     uint32_t seqBits = 1; while ((1ull << seqBits) < dbSize) seqBits++;
-    // front end: "fused" needs the target id to fit beside the 14-bit arrival index in a 32-bit LDS key (and the 22-bit field of
-    // the streamed tiers' records)
-    bool useFused = seqBits + ARR_BITS <= 32 && seqBits <= REC_T_BITS;
+    // front end: the per-query kernels keep the target id in a 22-bit field of their hit records
+    bool useFused = seqBits <= REC_T_BITS;
     if (const char *e = getenv("MK_PREFILTER_PATH")) {
         if (!strcmp(e, "global")) useFused = false;
         else if (strcmp(e, "fused") && strcmp(e, "auto")) { err = "MK_PREFILTER_PATH must be auto, fused or global"; return MK_ERR_ARG; }
@@ -1313,6 +1138,8 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             size_t nListed = 0;
             uint32_t *hList = nullptr, *dList = nullptr, *dOvf = nullptr;
             // exact similar-k-mer count per query -> expected index hits -> LDS tier
+            uint16_t *dPosCost = (uint16_t *) dev_scratch("pf_poscost", (size_t) (qOff[q1] - qOff[q0] + 16) * 2);
+            PNULL(dPosCost);
             uint32_t *dQK = (uint32_t *) dev_scratch("pf_qkmers", (size_t) nqc * 4);
             uint32_t *hQK = (uint32_t *) pinned_scratch("pf_qkmers_h", (size_t) nqc * 4);
             PNULL(dQK); PNULL(hQK);
@@ -1321,7 +1148,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                 PCHK(hipMemsetAsync(dQK, 0, (size_t) nqc * 4, stream));
                 if (pe > pb) {
                     const int th = tb("kmer_count", 5.0 * (double) (pe - pb), 0);
-                    hipLaunchKernelGGL(kmer_count_kernel, dim3((unsigned) ((pe - pb + 255) / 256)), dim3(256), 0, stream, V, pb, pe, q0, dQK);
+                    hipLaunchKernelGGL(kmer_count_kernel, dim3((unsigned) ((pe - pb + 255) / 256)), dim3(256), 0, stream, V, pb, pe, q0, dQK, dPosCost);
                     te(th);
                     PCHK(hipGetLastError());
                 }
@@ -1333,8 +1160,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                 double limit[N_TIERS];                                      // most k-mers a query may have to be tried in tier t
                 for (int t = 0; t < N_TIERS; t++) {
                     const double hpk = g_memo.hitsPerKmer[t] > 0 ? g_memo.hitsPerKmer[t] : std::max(0.05, (double) V.n_entries / 64.0e6);
-                    const double lost = tiers[t].kind == 0 ? 32.0 * tiers[t].waves : 0.0;       // LDS tiers: half a 64-slot chunk lost per wave
-                    limit[t] = ((double) tiers[t].cap - lost) / (hpk * g_memo.margin[t]);
+                    limit[t] = (double) tiers[t].cap / (hpk * g_memo.margin[t]);
                 }
                 for (uint32_t ql = 0; ql < nqc; ql++) {
                     if (hQK[ql] == 0) continue;                             // no k-mer: no hits
@@ -1344,6 +1170,19 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                     while (t < nTiersUsed && (km > limit[t] || npos > tiers[t].maxpos)) t++;
                     if (t == nTiersUsed || t < firstTier) fallback.push_back(ql); else lists[t].push_back(q0 + ql);
                 }
+                // streamed tiers: persistent workgroups pull from the list -- largest queries first, so that no workgroup starts a
+                // long query when the others are about to run dry
+                for (int t = 0; t < N_TIERS; t++)
+                    if (lists[t].size() > 1) {       // (counting sort over 64 size classes: the order only has to be roughly by size)
+                        const double scale = 63.0 / std::max(1.0, limit[t]);
+                        size_t cnt[65] = {0};
+                        std::vector<uint8_t> cls(lists[t].size());
+                        for (size_t k = 0; k < lists[t].size(); k++) { cls[k] = (uint8_t) (63 - std::min(63, (int) ((double) hQK[lists[t][k] - q0] * scale))); cnt[cls[k] + 1]++; }
+                        for (int c = 0; c < 64; c++) cnt[c + 1] += cnt[c];
+                        std::vector<uint32_t> ordered(lists[t].size());
+                        for (size_t k = 0; k < lists[t].size(); k++) ordered[cnt[cls[k]]++] = lists[t][k];
+                        lists[t].swap(ordered);
+                    }
                 for (int t = 0; t < N_TIERS; t++) nListed += lists[t].size();
                 hList = (uint32_t *) pinned_scratch("pf_flist_h", std::max<size_t>(nListed, 1) * 4);
                 dList = (uint32_t *) dev_scratch("pf_flist", std::max<size_t>(nListed, 1) * 4);
@@ -1360,24 +1199,12 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             for (int t = 0; t < N_TIERS; t++) {
                 thFused[t] = -1;
                 const size_t grid = t < nTiersUsed ? lists[t].size() + lower : 0;
-                if (grid > 0 && tiers[t].kind == 0) {
-                    FusedArgs A;
-                    A.V = V; A.queries = dList + at; A.n_own = (uint32_t) lists[t].size(); A.n_launch = (uint32_t) grid; A.q_first = q0;
-                    A.prev_list = t > 0 ? dOvf + (size_t) (t - 1) * nqc : nullptr; A.prev_count = t > 0 ? dCounters + 4 + (t - 1) : dCounters + 15;   // [15] stays 0
-                    A.C = C; A.cand_cap = CAND_CAP; A.counters = dCounters;
-                    A.overflow_list = dOvf + (size_t) t * nqc; A.overflow_count = dCounters + 4 + t; A.totals = dFTotals + 16 * t;
-                    char nm[48];
-                    snprintf(nm, sizeof(nm), "prefilter_fused_lds%d", tiers[t].cap);
-                    thFused[t] = tb(nm, 0, 0);
-                    launch_fused(tierBase + t, A, stream);
-                    te(thFused[t]);
-                    PCHK(hipGetLastError());
-                } else if (grid > 0) {
+                if (grid > 0) {
                     // streamed tier: persistent workgroups, each with its own hit region
                     static int cus = 0;
                     if (!cus) { int dev = 0; (void) hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
                     int perCu = tiers[t].wgPerCu;
-                    if (const char *e = getenv(t == 2 ? "MK_STREAM_WG_PER_CU_A" : "MK_STREAM_WG_PER_CU_B")) perCu = std::max(1, atoi(e));
+                    if (const char *e = getenv(t == 2 ? "MK_PREFILTER_WG_PER_CU_A" : (t == 3 ? "MK_PREFILTER_WG_PER_CU_B" : "MK_PREFILTER_WG_PER_CU_S"))) perCu = std::max(1, atoi(e));
                     const unsigned launch = (unsigned) std::min<size_t>(grid, (size_t) cus * perCu);
                     char pn[32];
                     snprintf(pn, sizeof(pn), "pf_pool%d", t);
@@ -1389,8 +1216,9 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                     A.C = C; A.cand_cap = CAND_CAP; A.counters = dCounters;
                     A.overflow_list = dOvf + (size_t) t * nqc; A.overflow_count = dCounters + 4 + t; A.totals = dFTotals + 16 * t;
                     A.work_counter = dCounters + 8 + t;
+                    A.pos_cost = dPosCost; A.pos_begin = qOff[q0];
                     char nm[48];
-                    snprintf(nm, sizeof(nm), "prefilter_stream_cap%d", tiers[t].cap);
+                    snprintf(nm, sizeof(nm), "prefilter_query_cap%d", tiers[t].cap);
                     thFused[t] = tb(nm, 0, 0);
                     launch_stream(tierBase + t, A, launch, stream);
                     te(thFused[t]);
@@ -1406,7 +1234,10 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                 for (int t = 0; t < N_TIERS; t++) {
                     const unsigned long long *T = hFTotals + 16 * (t + 1);
                     fprintf(stderr, "[prefilter]   tier %d (%s %d): queries %zu overflowed %llu | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g sort %.3g emit %.3g overflowed %.3g | extra class passes %llu\n",
-                            t, tiers[t].kind ? "region" : "lds", tiers[t].cap, lists[t].size(), T[8], (double) T[0], (double) T[1], (double) T[2], (double) T[3], (double) T[4], (double) T[5], (double) T[6], T[9]);
+                            t, "region", tiers[t].cap, lists[t].size(), T[8], (double) T[0], (double) T[1], (double) T[2], (double) T[3], (double) T[4], (double) T[5], (double) T[6], T[9]);
+                    if (MK_STREAM_PROF)
+                        fprintf(stderr, "[prefilter]     wave-cycles pass 1: enumerate %.3g probe-wait %.3g store+bitmaps %.3g idle-at-barrier %.3g | wg-cycles survivor count %.3g | wg-ticks collect %.3g\n",
+                                (double) T[10], (double) T[11], (double) T[12], (double) T[13], (double) T[14], (double) T[15]);
                 }
             const uint32_t nOvf = hCounters[4 + nTiersUsed - 1];               // what even the largest tier in use could not hold
             if (hCounters[0] > CAND_CAP) rc = RC_CAND_OVERFLOW;
