@@ -111,7 +111,10 @@ int mk_index_write(const char *index_db, const char *seq_data, uint64_t seq_data
                    const uint32_t *lengths, uint32_t n, int seq_dbtype, const mk_params *params);
 /* target side from an index DB instead of mk_targetdb_create: nothing is masked or indexed again */
 int mk_targetdb_open_index(const char *index_db, const mk_params *params, mk_targetdb **out);
-/* DB keys of the targets of a database opened from an index (keys = NULL when it was created from residues) */
+/* DB keys of the targets (Matcher::compareHits breaks its last tie on the DB key, Matcher.h:157-168): a database created from residues
+ * has none until they are installed -- the alignment order then ties on the target index.  mk_alignment.db_key stays the target index. */
+int mk_targetdb_set_keys(mk_targetdb *db, const uint32_t *keys, uint32_t n_targets);
+/* DB keys of the targets of a database opened from an index or installed with mk_targetdb_set_keys (NULL otherwise) */
 int mk_targetdb_keys(const mk_targetdb *db, const uint32_t **keys, uint32_t *n);
 /* test hook, no GPU: the parts of an index DB a reader takes, as text files in out_dir (masked_targets.txt, index.txt, seqs.txt, meta.txt) */
 int mk_index_dump(const char *index_db, const char *out_dir);

@@ -44,7 +44,7 @@ EXPORTS = ["mk_init", "mk_last_error", "mk_default_params", "mk_device_name", "m
            "mk_queries_create", "mk_queries_destroy", "mk_queries_derived", "mk_prefilter", "mk_prefilter_result", "mk_prefilter_result_set",
            "mk_align", "mk_align_result", "mk_search", "mk_extract_orfs", "mk_orfs_result", "mk_queries_from_orfs",
            "mk_orfs_destroy", "mk_format_orf_header", "mk_sw_pairs", "mk_ungapped",
-           "mk_kernel_stats", "mk_kernel_stats_reset", "mk_format_hit", "mk_format_alignment", "mk_format_hits", "mk_format_alignments"]
+           "mk_kernel_stats", "mk_kernel_stats_reset", "mk_format_hit", "mk_format_alignment", "mk_format_hits", "mk_format_alignments", "mk_targetdb_set_keys"]
 
 
 def lib():

@@ -163,6 +163,8 @@ struct mk_targetdb {
     DevBuf<uint16_t> dIndex3, dHist3, dCum3;
     int histLo = 0, histRange = 0;
     DevBuf<int8_t> dMatAln, dMatUng;
+    DevBuf<uint32_t> dKeys;          // device copy of `keys` (last tie-break of the alignment order)
+    std::vector<int32_t> bitScoreTable;   // static_cast<int>(bitScore(score) + 0.5), score < 32768
 };
 
 struct mk_queries {
@@ -343,6 +345,8 @@ static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uin
     mk::build_submat(db->alnMat, mk::MAT_BLOSUM62, 2.0f, 0.0f);     // Alignment.cpp:152
     db->kmerThr = mk::kmer_threshold(P->sensitivity, P->kmer_score);
     db->evaluer.init(offsets[n]);
+    db->bitScoreTable.resize(32768);
+    for (int sc = 0; sc < 32768; sc++) db->bitScoreTable[sc] = static_cast<int>(db->evaluer.bitScore((double) sc) + 0.5);
     mk::TargetIndex built;
     if (!prebuilt) mk::build_index(db->kmerMat, residues, offsets, n, db->kmerThr, P->mask != 0, P->mask_prob, P->simd_lanes_double, built);
     mk::TargetIndex &ix = prebuilt ? *prebuilt : built;
@@ -442,7 +446,7 @@ int mk_targetdb_open_index(const char *indexDb, const mk_params *P, mk_targetdb 
     if (off != c.seqOffsets) return fail(MK_ERR_ARG, "%s: the masked sequences do not line up with the sequence database", indexDb);
     mk::index_to_address_order(c.index);
     rc = targetdb_create(res.data(), off.data(), (uint32_t) c.seqs.keys.size(), P, &c.index, out);
-    if (rc == MK_OK) (*out)->keys = c.seqs.keys;
+    if (rc == MK_OK) rc = mk_targetdb_set_keys(*out, c.seqs.keys.data(), (uint32_t) c.seqs.keys.size());
     return rc;
 }
 
@@ -485,6 +489,16 @@ int mk_index_dump(const char *indexDb, const char *outDir) {
             c.meta.maxSeqLen, c.meta.kmerSize, c.meta.compBiasCorr, c.meta.alphabetSize, c.meta.mask, c.meta.spacedKmer, c.meta.kmerThr, c.meta.seqType,
             c.meta.srcSeqType, c.meta.headers1, c.meta.headers2, c.meta.splits, c.matrixName.c_str());
     fclose(f);
+    return MK_OK;
+}
+
+int mk_targetdb_set_keys(mk_targetdb *db, const uint32_t *keys, uint32_t n) {
+    int rc = ensure_ready();
+    if (rc) return rc;
+    if (!db || !keys || n != db->n) return fail(MK_ERR_ARG, "mk_targetdb_set_keys: one key per target");
+    db->keys.assign(keys, keys + n);
+    HIPCHK(db->dKeys.upload(keys, n));
+    HIPCHK(hipStreamSynchronize(g_stream));
     return MK_OK;
 }
 
@@ -806,7 +820,7 @@ int mk_prefilter_result_set(mk_queries *q, const mk_hit *hits, const uint64_t *o
 // float/double tail (Matcher.cpp:60-142), Alignment::checkCriteria (:548-567) and the per-query sort (:403-405).
 // Appends the accepted alignments at alns[nAlnOut...] and fills alnOff[q0+1 .. q1].
 static int align_range(mk_targetdb *db, mk_queries *q, const mk_params *P, uint32_t q0, uint32_t q1, const std::vector<mk::GateEntry> &gate,
-                       hipStream_t stream, size_t &nAlnOut) {
+                       const mk::AssembleTables *tables, hipStream_t stream, size_t &nAlnOut) {
     const uint32_t nqc = q1 - q0;
     const uint64_t h0 = q->hitOff[q0];
     const size_t n = (size_t) (q->hitOff[q1] - h0);
@@ -841,9 +855,27 @@ static int align_range(mk_targetdb *db, mk_queries *q, const mk_params *P, uint3
     const mk::AlnRaw *raw = nullptr;
     size_t m = 0;
     std::string err;
-    int rc = mk::run_align_device(V, hitOff.data(), hits, n, gate, *P, stream, work, &raw, &m, err, timed_begin, timed_end, timed_set);
+    // the float/double tail of getSWResult, the criteria and the per-query order run on the device; the host path below only
+    // serves a range in which a score lies beyond the e-value table
+    mk::AssembleArgs asmArgs;
+    static const bool hostAssemble = getenv("MK_ALIGN_HOST_ASSEMBLE") && atoi(getenv("MK_ALIGN_HOST_ASSEMBLE")) != 0;
+    asmArgs.tables = hostAssemble ? nullptr : tables;
+    asmArgs.dSortKey = db->dKeys.p;
+    asmArgs.counts = (uint32_t *) mk::pinned_scratch(stream == g_stream2 ? "asm_counts_h2" : "asm_counts_h", std::max<size_t>(nqc, 1) * 4);
+    if (!asmArgs.counts) return fail(MK_ERR_DEVICE, "pinned host allocation failed");
+    asmArgs.reserve = [&](size_t cnt) -> mk_alignment * {
+        if (!q->alns.reserve(std::max<size_t>(nAlnOut + cnt, 1) * sizeof(mk_alignment), nAlnOut * sizeof(mk_alignment))) return nullptr;
+        return (mk_alignment *) q->alns.p + nAlnOut;
+    };
+    int rc = mk::run_align_device(V, hitOff.data(), hits, n, gate, *P, stream, work, &raw, &m, err, timed_begin, timed_end, timed_set, &asmArgs);
     timed_flush();
     if (rc != MK_OK) return fail(rc, "%s", err.c_str());
+    if (asmArgs.done) {
+        uint64_t o = 0;
+        for (uint32_t i = 0; i < nqc; i++) { o += asmArgs.counts[i]; q->alnOff[(size_t) q0 + i + 1] = nAlnOut + o; }
+        nAlnOut += asmArgs.nOut;
+        return MK_OK;
+    }
     HostTimer ht("host_align_assemble");
     // raw is ordered by pair index == by query: query i owns raw[first[i] .. first[i+1])
     std::vector<uint64_t> first((size_t) nqc + 1);
@@ -886,7 +918,13 @@ static int align_range(mk_targetdb *db, mk_queries *q, const mk_params *P, uint3
             a.bit_score = static_cast<int>(db->evaluer.bitScore((double) r.score) + 0.5);
             if (a.evalue <= P->evalue_thr && a.aln_len >= P->min_aln_len) alns[w++] = a;
         }
-        if (w - begin > 1) std::sort(alns + begin, alns + w, mk::alignment_less);
+        if (w - begin > 1) {
+            if (db->keys.empty()) std::sort(alns + begin, alns + w, mk::alignment_less);
+            else std::sort(alns + begin, alns + w, [&](const mk_alignment &x, const mk_alignment &y) {      // Matcher::compareHits ties on the DB key
+                mk_alignment kx = x, ky = y; kx.db_key = db->keys[x.db_key]; ky.db_key = db->keys[y.db_key];
+                return mk::alignment_less(kx, ky);
+            });
+        }
         cnt[i] = (uint32_t) (w - begin);
         holes += first[i + 1] - w;
     }
@@ -912,9 +950,15 @@ int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *P) {
         HostTimer ht("host_gate_table");
         mk::build_gate_table(db->evaluer, P->evalue_thr, q->off, gate);
     }
+    mk::AssembleTables tables;
+    {
+        HostTimer ht("host_evalue_table");
+        tables.bitScore = db->bitScoreTable;
+        mk::build_assemble_tables(db->evaluer, q->off, tables);
+    }
     q->alnOff.assign((size_t) q->n + 1, 0);
     size_t nAln = 0;
-    rc = align_range(db, q, P, 0, q->n, gate, g_stream, nAln);
+    rc = align_range(db, q, P, 0, q->n, gate, &tables, g_stream, nAln);
     if (rc != MK_OK) return rc;
     q->haveAln = true;
     return MK_OK;
@@ -934,6 +978,12 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     {
         HostTimer ht("host_gate_table");
         mk::build_gate_table(db->evaluer, P->evalue_thr, q->off, gate);
+    }
+    mk::AssembleTables tables;
+    {
+        HostTimer ht("host_evalue_table");
+        tables.bitScore = db->bitScoreTable;
+        mk::build_assemble_tables(db->evaluer, q->off, tables);
     }
     q->alnOff.assign((size_t) q->n + 1, 0);
     q->havePref = false; q->haveAln = false;
@@ -964,7 +1014,7 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
             int r = MK_OK;
             if (pipe.rc == MK_OK) {
                 HostTimer ht("host_align_total");
-                r = align_range(db, q, P, it.first, it.second, gate, g_stream2, nAln);
+                r = align_range(db, q, P, it.first, it.second, gate, &tables, g_stream2, nAln);
             }
             {
                 std::lock_guard<std::mutex> lk(pipe.m);

@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <omp.h>
@@ -154,7 +155,121 @@ __global__ __launch_bounds__(256) void collect_kernel(const uint32_t *sortedPair
     out[i] = a;
 }
 
+// ---- device-side assembly of the accepted alignments -------------------------------------------------------------------------
+struct AssembleView {
+    const AlnRaw *raw; uint32_t n;
+    const uint64_t *hitOff; const mk_hit *hits; uint32_t nq;
+    const uint64_t *q_off; const uint64_t *t_off;
+    const double *evalTab; const int32_t *lenIdx; uint32_t maxLen, smax; const int32_t *bitScore; const uint32_t *sortKey;
+    double evalThr; int minAlnLen;
+    mk_alignment *tmp; uint8_t *pass; uint32_t *flags /* [0] score beyond the table [1] forward/backward mismatch */;
+    unsigned long long *revWork;     // [2 * cfg]: bytes, [2 * cfg + 1]: cells of the reverse pass (statistics)
+};
+
+// one lane per accepted pair: Matcher::getSWResult's tail (Matcher.cpp:100-164) + Alignment::checkCriteria (Alignment.cpp:548-567)
+__global__ __launch_bounds__(256) void assemble_kernel(AssembleView A) {
+    __shared__ unsigned long long sWork[2 * SW_NCFG];
+    for (int k = threadIdx.x; k < 2 * SW_NCFG; k += blockDim.x) sWork[k] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < A.n) {
+        const uint32_t ql = (uint32_t) A.raw[i].q_end + 1u, tl = (uint32_t) A.raw[i].t_end + 1u;
+        const int c = sw_cfg_of(ql);
+        atomicAdd(&sWork[2 * c], (unsigned long long) (tl + 2u * ql + (uint32_t) (sizeof(SwJob) + sizeof(SwOut))));
+        atomicAdd(&sWork[2 * c + 1], (unsigned long long) ql * tl);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * SW_NCFG; k += blockDim.x) if (sWork[k]) atomicAdd(&A.revWork[k], sWork[k]);
+    if (i >= A.n) return;
+    const AlnRaw r = A.raw[i];
+    A.pass[i] = 0;
+    if (r.q_start == -2) { atomicAdd(&A.flags[1], 1u); return; }
+    uint32_t lo = 0, hi = A.nq;                       // largest q with hitOff[q] <= pair
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (A.hitOff[mid] <= (uint64_t) r.pair) lo = mid; else hi = mid; }
+    const uint32_t t = A.hits[r.pair].seq_id;
+    const int qLen = (int) (A.q_off[lo + 1] - A.q_off[lo]);
+    const int tLen = (int) (A.t_off[t + 1] - A.t_off[t]);
+    if ((uint32_t) r.score >= A.smax || (uint32_t) qLen > A.maxLen || A.lenIdx[qLen] < 0) { atomicAdd(&A.flags[0], 1u); return; }
+    mk_alignment a;
+    a.db_key = t; a.q_len = qLen; a.db_len = tLen; a.raw_score = r.score;
+    a.evalue = A.evalTab[(size_t) A.lenIdx[qLen] * A.smax + (uint32_t) r.score];
+    const auto cov = [](unsigned s, unsigned e, unsigned len) { return (float) (min(len, max(s, e)) - min(s, e) + 1u) / (float) len; };
+    a.qcov = cov((unsigned) r.q_start, (unsigned) r.q_end, (unsigned) qLen);
+    a.dbcov = cov((unsigned) r.t_start, (unsigned) r.t_end, (unsigned) tLen);
+    a.q_start = r.q_start; a.q_end = r.q_end; a.db_start = r.t_start; a.db_end = r.t_end;
+    a.aln_len = max(abs(r.q_end - r.q_start), abs(r.t_end - r.t_start)) + 1;
+    const unsigned qAln = max((unsigned) r.q_end - (unsigned) r.q_start, 1u), dbAln = max((unsigned) r.t_end - (unsigned) r.t_start, 1u);
+    const uint16_t s16 = (uint16_t) r.score;
+    float sid = (float) ((double) ((float) (int) s16 / (float) max(qAln, dbAln)) * 0.1656 + 0.1141);   // Matcher.cpp:160-164 (float / float, then double)
+    sid = fminf(sid, 1.0f);
+    a.seq_id = fmaxf(0.0f, sid);
+    a.bit_score = A.bitScore[r.score];
+    A.tmp[i] = a;
+    A.pass[i] = (a.evalue <= A.evalThr && a.aln_len >= A.minAlnLen) ? 1 : 0;
+}
+
+__device__ __forceinline__ bool aln_less(const mk_alignment &a, uint32_t ka, const mk_alignment &b, uint32_t kb) {   // Matcher::compareHits (Matcher.h:157-168)
+    if (a.evalue != b.evalue) return a.evalue < b.evalue;
+    if (a.bit_score != b.bit_score) return a.bit_score > b.bit_score;
+    if (a.db_len != b.db_len) return a.db_len < b.db_len;
+    return ka < kb;
+}
+
+// one lane per query: its records are raw[first .. next) (raw is ordered by pair = by query); COUNT: how many pass; else: insertion
+// sort of the passing ones into out[off[q] ...] (a query has a handful of alignments, at most --max-seqs)
+template <bool COUNT>
+__global__ __launch_bounds__(256) void assemble_finish_kernel(AssembleView A, uint32_t *cnt, const uint32_t *off, mk_alignment *out) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= A.nq) return;
+    const auto first_at = [&](uint64_t want) { uint32_t lo = 0, hi = A.n; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t) A.raw[mid].pair < want) lo = mid + 1; else hi = mid; } return lo; };
+    const uint32_t b = first_at(A.hitOff[q]), e = first_at(A.hitOff[q + 1]);
+    if (COUNT) {
+        uint32_t c = 0;
+        for (uint32_t k = b; k < e; k++) c += A.pass[k];
+        cnt[q] = c;
+        return;
+    }
+    mk_alignment *dst = out + off[q];
+    uint32_t m = 0;
+    for (uint32_t k = b; k < e; k++) {
+        if (!A.pass[k]) continue;
+        const mk_alignment a = A.tmp[k];
+        const uint32_t ka = A.sortKey ? A.sortKey[a.db_key] : a.db_key;
+        uint32_t j = m;
+        while (j > 0) {
+            const mk_alignment p = dst[j - 1];
+            if (!aln_less(a, ka, p, A.sortKey ? A.sortKey[p.db_key] : p.db_key)) break;
+            dst[j] = p;
+            j--;
+        }
+        dst[j] = a;
+        m++;
+    }
+}
+
 }  // namespace
+
+void build_assemble_tables(const Evaluer &ev, const std::vector<uint64_t> &qOff, AssembleTables &t) {
+    uint32_t maxLen = 0;
+    const size_t n = qOff.size() - 1;
+    for (size_t i = 0; i < n; i++) maxLen = std::max<uint32_t>(maxLen, (uint32_t) (qOff[i + 1] - qOff[i]));
+    static std::atomic<uint64_t> nextId{1};
+    t.id = nextId.fetch_add(1);
+    t.smax = 4096;
+    t.lenIdx.assign((size_t) maxLen + 1, -1);
+    std::vector<uint32_t> lens;
+    for (size_t i = 0; i < n; i++) { const uint32_t L = (uint32_t) (qOff[i + 1] - qOff[i]); if (t.lenIdx[L] < 0) { t.lenIdx[L] = 0; lens.push_back(L); } }
+    std::sort(lens.begin(), lens.end());
+    for (size_t k = 0; k < lens.size(); k++) t.lenIdx[lens[k]] = (int32_t) k;
+    t.evalue.assign(lens.size() * (size_t) t.smax, 0.0);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (size_t k = 0; k < lens.size(); k++)
+        for (uint32_t s = 0; s < t.smax; s++) t.evalue[k * t.smax + s] = ev.evalue((double) s, (double) lens[k]);
+    if (t.bitScore.empty()) {
+        t.bitScore.resize(32768);
+        for (int s = 0; s < 32768; s++) t.bitScore[s] = static_cast<int>(ev.bitScore((double) s) + 0.5);
+    }
+}
 
 // pass(score) table per query length present in the batch
 void build_gate_table(const Evaluer &ev, double evalThr, const std::vector<uint64_t> &qOff, std::vector<GateEntry> &table) {
@@ -325,8 +440,10 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const SwJob *j
 int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hit *hitsHost, uint64_t nPairs,
                      const std::vector<GateEntry> &gate, const mk_params &P, hipStream_t stream,
                      const double *fwdWork /* per cfg: bytes, cells; may be null */,
-                     const AlnRaw **out, size_t *nOut, std::string &err, timed_begin_fn tb, timed_end_fn te, timed_set_fn ts) {
+                     const AlnRaw **out, size_t *nOut, std::string &err, timed_begin_fn tb, timed_end_fn te, timed_set_fn ts,
+                     AssembleArgs *assemble) {
     *out = nullptr; *nOut = 0;
+    if (assemble) { assemble->done = assemble->tables != nullptr; assemble->nOut = 0; if (assemble->counts) std::fill(assemble->counts, assemble->counts + V.n_queries, 0u); }
     if (nPairs == 0) return MK_OK;
     if (nPairs >= 0x7FFFFFFFull) { err = "more than 2^31 pairs in one batch: split the batch"; return MK_ERR_UNSUPPORTED; }
     const uint32_t n = (uint32_t) nPairs;
@@ -404,6 +521,81 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hi
     ACHK(hipGetLastError());
     AlnRaw *hRaw = (AlnRaw *) pinned_scratch("align_raw_host", (size_t) nRev * sizeof(AlnRaw));
     ANULL(hRaw);
+    bool assembled = false;
+    if (assemble && assemble->tables) {
+        // e-value (table), bit score, sequence identity, coverage, criteria and the per-query order on the device: the host only
+        // receives the finished records
+        const AssembleTables &T = *assemble->tables;
+        double *dEval = (double *) dev_scratch("asm_evalue", T.evalue.size() * sizeof(double) + 8);
+        int32_t *dLenIdx = (int32_t *) dev_scratch("asm_lenidx", T.lenIdx.size() * sizeof(int32_t));
+        int32_t *dBit = (int32_t *) dev_scratch("asm_bitscore", T.bitScore.size() * sizeof(int32_t));
+        mk_alignment *dTmp = (mk_alignment *) dev_scratch("asm_tmp", (size_t) nRev * sizeof(mk_alignment));
+        mk_alignment *dFinal = (mk_alignment *) dev_scratch("asm_final", (size_t) nRev * sizeof(mk_alignment));
+        uint8_t *dPass = (uint8_t *) dev_scratch("asm_pass", nRev);
+        uint32_t *dCnt = (uint32_t *) dev_scratch("asm_cnt", ((size_t) V.n_queries + 1) * 4), *dOff = (uint32_t *) dev_scratch("asm_off", ((size_t) V.n_queries + 1) * 4);
+        uint32_t *dFlags = (uint32_t *) dev_scratch("asm_flags", 16);
+        uint32_t *hFlags = (uint32_t *) pinned_scratch("asm_flags_h", 16);
+        ANULL(dEval); ANULL(dLenIdx); ANULL(dBit); ANULL(dTmp); ANULL(dFinal); ANULL(dPass); ANULL(dCnt); ANULL(dOff); ANULL(dFlags); ANULL(hFlags);
+        // the tables belong to the batch (same for every range of an mk_search): uploaded when they change
+        static uint64_t uploadedId = 0; static std::mutex upMutex;
+        {
+            std::lock_guard<std::mutex> g(upMutex);
+            if (uploadedId != T.id) {
+                ACHK(hipMemcpyAsync(dEval, T.evalue.data(), T.evalue.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+                ACHK(hipMemcpyAsync(dLenIdx, T.lenIdx.data(), T.lenIdx.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+                ACHK(hipMemcpyAsync(dBit, T.bitScore.data(), T.bitScore.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+                uploadedId = T.id;
+            }
+        }
+        unsigned long long *dWork = (unsigned long long *) dev_scratch("asm_revwork", 2 * SW_NCFG * 8);
+        unsigned long long *hWork = (unsigned long long *) pinned_scratch("asm_revwork_h", 2 * SW_NCFG * 8);
+        ANULL(dWork); ANULL(hWork);
+        ACHK(hipMemsetAsync(dWork, 0, 2 * SW_NCFG * 8, stream));
+        ACHK(hipMemsetAsync(dFlags, 0, 16, stream));
+        AssembleView AV;
+        AV.revWork = dWork;
+        AV.raw = dRaw; AV.n = nRev; AV.hitOff = dHitOff; AV.hits = dHits; AV.nq = V.n_queries; AV.q_off = V.q_off; AV.t_off = V.t_off;
+        AV.evalTab = dEval; AV.lenIdx = dLenIdx; AV.maxLen = (uint32_t) T.lenIdx.size() - 1; AV.smax = T.smax; AV.bitScore = dBit; AV.sortKey = assemble->dSortKey;
+        AV.evalThr = P.evalue_thr; AV.minAlnLen = P.min_aln_len; AV.tmp = dTmp; AV.pass = dPass; AV.flags = dFlags;
+        th = tb("align_assemble", (double) nRev * (sizeof(AlnRaw) + 2.0 * sizeof(mk_alignment)), 0);
+        hipLaunchKernelGGL(assemble_kernel, dim3((nRev + 255) / 256), dim3(256), 0, stream, AV);
+        hipLaunchKernelGGL((assemble_finish_kernel<true>), dim3((V.n_queries + 255) / 256), dim3(256), 0, stream, AV, dCnt, (const uint32_t *) nullptr, (mk_alignment *) nullptr);
+        size_t tS = 0;
+        hipcub::DeviceScan::ExclusiveSum(nullptr, tS, dCnt, dOff, (int) V.n_queries + 1, stream);
+        void *tempS = dev_scratch("align_sort_temp", tS);
+        ANULL(tempS);
+        ACHK(hipcub::DeviceScan::ExclusiveSum(tempS, tS, dCnt, dOff, (int) V.n_queries + 1, stream));
+        hipLaunchKernelGGL((assemble_finish_kernel<false>), dim3((V.n_queries + 255) / 256), dim3(256), 0, stream, AV, dCnt, (const uint32_t *) dOff, dFinal);
+        te(th);
+        ACHK(hipGetLastError());
+        ACHK(hipMemcpyAsync(hFlags, dFlags, 8, hipMemcpyDeviceToHost, stream));
+        ACHK(hipMemcpyAsync(hWork, dWork, 2 * SW_NCFG * 8, hipMemcpyDeviceToHost, stream));
+        ACHK(hipMemcpyAsync(hFlags + 2, dOff + V.n_queries, 4, hipMemcpyDeviceToHost, stream));
+        ACHK(hipMemcpyAsync(assemble->counts, dCnt, (size_t) V.n_queries * 4, hipMemcpyDeviceToHost, stream));
+        ACHK(hipMemcpyAsync(hCount, dCount, 12, hipMemcpyDeviceToHost, stream));
+        ACHK(sync_wait(stream, "wait_align"));
+        if (hCount[2] != 0) { err = "internal: the position pass disagrees with the score pass for " + std::to_string(hCount[2]) + " pairs"; return MK_ERR_DEVICE; }
+        if (hFlags[1] != 0) { err = "Score of forward/backward SW differ for " + std::to_string(hFlags[1]) + " pairs"; return MK_ERR_SW_MISMATCH; }
+        if (hFlags[0] == 0) {
+            const size_t nFinal = hFlags[2];
+            if (nFinal > 0) {
+                mk_alignment *dst = assemble->reserve(nFinal);
+                if (!dst) { err = "pinned host allocation failed"; return MK_ERR_DEVICE; }
+                ACHK(hipMemcpyAsync(dst, dFinal, nFinal * sizeof(mk_alignment), hipMemcpyDeviceToHost, stream));
+                ACHK(sync_wait(stream, "wait_align"));
+            }
+            assemble->nOut = nFinal;
+            assembled = true;
+        } else {
+            std::fill(assemble->counts, assemble->counts + V.n_queries, 0u);       // a score beyond the e-value table: the caller assembles this range
+        }
+    }
+    if (assemble) assemble->done = assembled;
+    if (assembled) {
+        unsigned long long *hWork = (unsigned long long *) pinned_scratch("asm_revwork_h", 2 * SW_NCFG * 8);
+        for (int c = 0; c < SW_NCFG; c++) if (hRev[c] >= 0) ts(hRev[c], (double) hWork[2 * c], (double) hWork[2 * c + 1]);
+        return MK_OK;
+    }
     ACHK(hipMemcpyAsync(hRaw, dRaw, (size_t) nRev * sizeof(AlnRaw), hipMemcpyDeviceToHost, stream));
     ACHK(hipMemcpyAsync(hCount, dCount, 12, hipMemcpyDeviceToHost, stream));
     ACHK(sync_wait(stream, "wait_align"));

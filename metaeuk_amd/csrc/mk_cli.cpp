@@ -207,6 +207,8 @@ int openTarget(const std::string &path, const mk_params &P, TargetSide &ts) {
     if (mk_targetdb_create(tres.data(), toff.data(), (uint32_t) tdb.entries.size(), &P, &ts.T) != MK_OK) return die("%s", mk_last_error());
     ts.keys.resize(tdb.entries.size());
     for (size_t i = 0; i < ts.keys.size(); i++) ts.keys[i] = tdb.entries[i].key;
+    // the alignment order's last tie-break is the DB key (Matcher::compareHits), which need not follow the target order
+    if (mk_targetdb_set_keys(ts.T, ts.keys.data(), (uint32_t) ts.keys.size()) != MK_OK) return die("%s", mk_last_error());
     return 0;
 }
 
