@@ -827,29 +827,6 @@ static int align_range(mk_targetdb *db, mk_queries *q, const mk_params *P, uint3
     const mk_hit *hits = (const mk_hit *) q->hits.p + h0;
     std::vector<uint64_t> hitOff((size_t) nqc + 1);            // pair offsets of the range
     for (uint32_t i = 0; i <= nqc; i++) hitOff[i] = q->hitOff[(size_t) q0 + i] - h0;
-    double work[2 * mk::SW_NCFG];
-    for (int c = 0; c < 2 * mk::SW_NCFG; c++) work[c] = 0;
-    {
-        HostTimer ht("host_align_prepare");           // forward-pass work per tile configuration (statistics only)
-#pragma omp parallel
-        {
-            double w[2 * mk::SW_NCFG];
-            for (int c = 0; c < 2 * mk::SW_NCFG; c++) w[c] = 0;
-#pragma omp for schedule(static) nowait
-            for (uint32_t i = 0; i < nqc; i++) {
-                const uint32_t qLen = (uint32_t) (q->off[(size_t) q0 + i + 1] - q->off[(size_t) q0 + i]);
-                const int c = mk::sw_cfg_of(qLen);
-                for (uint64_t h = hitOff[i]; h < hitOff[i + 1]; h++) {
-                    const uint32_t t = hits[h].seq_id;
-                    const uint32_t tLen = t < db->n ? (uint32_t) (db->off[t + 1] - db->off[t]) : 0;
-                    w[2 * c] += (double) tLen + 2.0 * qLen + sizeof(mk::SwJob) + sizeof(mk::SwOut);
-                    w[2 * c + 1] += (double) qLen * (double) tLen;
-                }
-            }
-#pragma omp critical(mk_align_fwdwork)
-            for (int c = 0; c < 2 * mk::SW_NCFG; c++) work[c] += w[c];
-        }
-    }
     mk::AlignView V = align_view(db, q);
     V.q_off = q->dOff.p + q0; V.n_queries = nqc;
     const mk::AlnRaw *raw = nullptr;
@@ -867,7 +844,7 @@ static int align_range(mk_targetdb *db, mk_queries *q, const mk_params *P, uint3
         if (!q->alns.reserve(std::max<size_t>(nAlnOut + cnt, 1) * sizeof(mk_alignment), nAlnOut * sizeof(mk_alignment))) return nullptr;
         return (mk_alignment *) q->alns.p + nAlnOut;
     };
-    int rc = mk::run_align_device(V, hitOff.data(), hits, n, gate, *P, stream, work, &raw, &m, err, timed_begin, timed_end, timed_set, &asmArgs);
+    int rc = mk::run_align_device(V, hitOff.data(), hits, n, gate, *P, stream, nullptr, &raw, &m, err, timed_begin, timed_end, timed_set, &asmArgs);
     timed_flush();
     if (rc != MK_OK) return fail(rc, "%s", err.c_str());
     if (asmArgs.done) {
@@ -975,16 +952,7 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     if (!db || !q || !P) return fail(MK_ERR_ARG, "null argument");
     HostTimer htAll("host_search_total");
     std::vector<mk::GateEntry> gate;
-    {
-        HostTimer ht("host_gate_table");
-        mk::build_gate_table(db->evaluer, P->evalue_thr, q->off, gate);
-    }
     mk::AssembleTables tables;
-    {
-        HostTimer ht("host_evalue_table");
-        tables.bitScore = db->bitScoreTable;
-        mk::build_assemble_tables(db->evaluer, q->off, tables);
-    }
     q->alnOff.assign((size_t) q->n + 1, 0);
     q->havePref = false; q->haveAln = false;
 
@@ -1002,6 +970,12 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
         (void) hipSetDevice(g_device);
         kmp_set_blocktime(0);
         omp_set_num_threads(half);
+        {   // the per-length score tables of the batch, while the prefilter works on its first chunk
+            HostTimer ht("host_gate_table");
+            mk::build_gate_table(db->evaluer, P->evalue_thr, q->off, gate);
+            tables.bitScore = db->bitScoreTable;
+            mk::build_assemble_tables(db->evaluer, q->off, tables);
+        }
         for (;;) {
             std::pair<uint32_t, uint32_t> it;
             {
@@ -1026,6 +1000,7 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     });
     mk::PrefilterHooks hooks;
     hooks.max_chunk_queries = 1u << 17;
+    hooks.co_resident = true;
     if (const char *e = getenv("MK_SEARCH_CHUNK_QUERIES")) hooks.max_chunk_queries = (uint32_t) std::max(1024L, atol(e));
     hooks.on_chunk = [&](uint32_t a, uint32_t b) {
         { std::lock_guard<std::mutex> lk(pipe.m); pipe.items.emplace_back(a, b); }

@@ -38,8 +38,23 @@ __device__ __forceinline__ uint32_t sort_key(uint32_t qLen, uint32_t tLen) {
 // forward jobs are ordered by (tile configuration, query, target length descending): the DPs of a wave share their query
 // (one LDS profile per wave) and have similar numbers of columns
 __global__ __launch_bounds__(256) void expand_pairs_kernel(AlignView V, const uint64_t *hitOff, const mk_hit *hits, uint64_t n,
-                                                           SwJob *jobs, uint64_t *keys, uint32_t *idx, uint32_t *badTarget) {
+                                                           SwJob *jobs, uint64_t *keys, uint32_t *idx, uint32_t *badTarget,
+                                                           unsigned long long *work /* [2 * cfg]: bytes, [2 * cfg + 1]: cells of the forward pass (statistics) */) {
+    __shared__ unsigned long long sWork[2 * SW_NCFG];
+    for (int k = threadIdx.x; k < 2 * SW_NCFG; k += blockDim.x) sWork[k] = 0;
+    __syncthreads();
     const uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) {
+        uint32_t lo = 0, hi = V.n_queries;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (hitOff[mid] <= p) lo = mid; else hi = mid; }
+        const uint32_t t = hits[p].seq_id;
+        const uint32_t qLen = (uint32_t) (V.q_off[lo + 1] - V.q_off[lo]), tLen = t < V.n_targets ? (uint32_t) (V.t_off[t + 1] - V.t_off[t]) : 0u;
+        const int c = sw_cfg_of(qLen);
+        atomicAdd(&sWork[2 * c], (unsigned long long) (tLen + 2u * qLen + (uint32_t) (sizeof(SwJob) + sizeof(SwOut))));
+        atomicAdd(&sWork[2 * c + 1], (unsigned long long) qLen * tLen);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * SW_NCFG; k += blockDim.x) if (sWork[k]) atomicAdd(&work[k], sWork[k]);
     if (p >= n) return;
     uint32_t lo = 0, hi = V.n_queries;              // largest q with hitOff[q] <= p
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (hitOff[mid] <= p) lo = mid; else hi = mid; }
@@ -463,13 +478,19 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hi
     ACHK(hipMemsetAsync(dCount, 0, 16, stream));
     uint64_t *dKeys64 = (uint64_t *) dev_scratch("align_keys64", (size_t) n * 8), *dKeys64b = (uint64_t *) dev_scratch("align_keys64b", (size_t) n * 8);
     ANULL(dKeys64); ANULL(dKeys64b);
+    unsigned long long *dFwdWork = (unsigned long long *) dev_scratch("align_fwdwork", 2 * SW_NCFG * 8);
+    unsigned long long *hFwdWork = (unsigned long long *) pinned_scratch("align_fwdwork_h", 2 * SW_NCFG * 8);
+    ANULL(dFwdWork); ANULL(hFwdWork);
+    ACHK(hipMemsetAsync(dFwdWork, 0, 2 * SW_NCFG * 8, stream));
     int th = tb("align_expand", 52.0 * n, 0);
-    hipLaunchKernelGGL(expand_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, V, dHitOff, dHits, (uint64_t) n, dJobs, dKeys64, dIdx, dCount + 1);
+    hipLaunchKernelGGL(expand_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, V, dHitOff, dHits, (uint64_t) n, dJobs, dKeys64, dIdx, dCount + 1, dFwdWork);
     te(th);
     ACHK(hipGetLastError());
+    ACHK(hipMemcpyAsync(hFwdWork, dFwdWork, 2 * SW_NCFG * 8, hipMemcpyDeviceToHost, stream));     // (lands before run_shared_fwd's synchronisation)
     int hFwd[SW_NCFG], hRev[SW_NCFG];
     int rc = run_shared_fwd(V, P, dJobs, dOut, dKeys64, dIdx, dKeys64b, dIdx2, n, stream, err, tb, te, hFwd);
-    for (int c = 0; c < SW_NCFG; c++) if (hFwd[c] >= 0 && fwdWork) ts(hFwd[c], fwdWork[2 * c], fwdWork[2 * c + 1]);
+    (void) fwdWork;
+    for (int c = 0; c < SW_NCFG; c++) if (hFwd[c] >= 0) ts(hFwd[c], (double) hFwdWork[2 * c], (double) hFwdWork[2 * c + 1]);
     if (rc != MK_OK) return rc;
     // e-value gate on the forward scores; the survivors (at most n) get a position pass, then the reverse pass
     uint32_t *dRevPair = (uint32_t *) dev_scratch("align_revpair", (size_t) n * 4);

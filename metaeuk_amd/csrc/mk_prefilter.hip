@@ -1204,6 +1204,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                     static int cus = 0;
                     if (!cus) { int dev = 0; (void) hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
                     int perCu = tiers[t].wgPerCu;
+                    if (hooks.co_resident) perCu = std::max(1, tiers[t].waves * perCu > 16 ? 16 / tiers[t].waves : perCu);   // at most 16 waves per CU
                     if (const char *e = getenv(t == 2 ? "MK_PREFILTER_WG_PER_CU_A" : (t == 3 ? "MK_PREFILTER_WG_PER_CU_B" : "MK_PREFILTER_WG_PER_CU_S"))) perCu = std::max(1, atoi(e));
                     const unsigned launch = (unsigned) std::min<size_t>(grid, (size_t) cus * perCu);
                     char pn[32];

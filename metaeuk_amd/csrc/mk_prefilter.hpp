@@ -32,7 +32,9 @@ typedef void (*timed_set_fn)(int handle, double bytes, double cells);
 // optional hooks for a caller that consumes the result chunk by chunk while the prefilter is still running (mk_search)
 struct PrefilterHooks {
     uint32_t max_chunk_queries = 0;                                  // 0: no limit beyond the device buffers
-    int max_tiers = 0;                                               // > 0: use only the first LDS tiers of the fused front end
+    int max_tiers = 0;                                               // > 0: use only the first tiers of the per-query front end
+    bool co_resident = false;                                        // another stage (the Smith-Waterman waves of mk_search) shares the CUs: the
+                                                                     // persistent prefilter workgroups take about half of the wave slots
     std::function<void(uint32_t q0, uint32_t q1)> on_chunk;          // hits and offsets of [q0, q1) are final and in host memory
     std::function<void()> before_grow;                               // the result block is about to be re-allocated
 };

@@ -75,7 +75,7 @@ __device__ __forceinline__ void load_scores(const int8_t *p, int (&sc)[R]) {
 
 // one unit of work: BLOCK/G jobs with their own profiles, or (SHARED) the jobs of wave `unit` on one shared profile
 template <int G, int R, int BLOCK, bool SHARED>
-__device__ __forceinline__ void sw_unit(const SwLaunch &L, const uint32_t unit, int8_t *smem) {
+__device__ __forceinline__ void sw_unit(const SwLaunch &L, const uint32_t unit, int8_t *smem, const int8_t *sMat) {
     constexpr int GPB = BLOCK / G;
     constexpr int ROWS = G * R;
     static_assert(!SHARED || BLOCK == 64, "shared-query mode runs one wave per workgroup");
@@ -99,7 +99,7 @@ __device__ __forceinline__ void sw_unit(const SwLaunch &L, const uint32_t unit, 
         else { job.t_start = 0; job.q_start = 0; job.q_len = 0; job.t_len = 0; job.q_step = 1; job.t_step = 1; job.slot = 0; }
     }
     profQStart = job.q_start; profQStep = job.q_step;
-    int8_t *prof = SHARED ? smem : smem + (size_t) grp * 22 * ROWS;
+    int8_t *prof = SHARED ? smem : smem + (size_t) grp * 24 * ROWS;      // 22 profile rows + the staged residues and bias of the tile
     const int go = L.gap_open, ge = L.gap_extend;
     const int qLen = (int) job.q_len, tLen = (int) job.t_len;
     const int nTiles = (qLen + ROWS - 1) / ROWS;
@@ -110,15 +110,25 @@ __device__ __forceinline__ void sw_unit(const SwLaunch &L, const uint32_t unit, 
     for (int tile = 0; tile < nTiles; tile++) {
         const int row0 = tile * ROWS;
         // ---- LDS query profile for this row tile: prof[t][row] = mat[t][q_row] + bias8[q_row]; row 21 = zeros ----
-        for (int idx = SHARED ? (int) threadIdx.x : lane; idx < 22 * ROWS; idx += SHARED ? BLOCK : G) {
-            const int t = idx / ROWS, row = idx - t * ROWS;
-            const int q = row0 + row;
-            int v = 0;
-            if (t < 21 && q < qLen) {
-                const int64_t qi = (int64_t) profQStart + (int64_t) q * profQStep;
-                v = (int) L.mat[t * 21 + L.q_res[qi]] + (int) L.q_bias8[qi];
+        // (residues and bias of the tile's rows are staged in LDS first, the matrix sits there too: two global loads per row instead of a
+        //  dependent pair per profile entry -- these kernels must not stall when the prefilter of the other stream saturates HBM)
+        {
+            uint8_t *sQ = reinterpret_cast<uint8_t *>(prof) + 22 * ROWS;           // behind the group's / wave's profile
+            int8_t *sB = reinterpret_cast<int8_t *>(sQ) + ROWS;
+            for (int row = SHARED ? (int) threadIdx.x : lane; row < ROWS; row += SHARED ? BLOCK : G) {
+                const int q = row0 + row;
+                const bool real = q < qLen;
+                const int64_t qi = (int64_t) profQStart + (int64_t) (real ? q : 0) * profQStep;
+                sQ[row] = real ? L.q_res[qi] : (uint8_t) 255;
+                sB[row] = real ? L.q_bias8[qi] : (int8_t) 0;
             }
-            prof[idx] = (int8_t) v;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int idx = SHARED ? (int) threadIdx.x : lane; idx < 22 * ROWS; idx += SHARED ? BLOCK : G) {
+                const int t = idx / ROWS, row = idx - t * ROWS;
+                const uint32_t qc = sQ[row];
+                prof[idx] = (t < 21 && qc != 255u) ? (int8_t) ((int) sMat[t * 21 + (int) qc] + (int) sB[row]) : (int8_t) 0;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -138,10 +148,13 @@ __device__ __forceinline__ void sw_unit(const SwLaunch &L, const uint32_t unit, 
         const int64_t tBase = (int64_t) job.t_start;
         const int64_t tStep = (int64_t) job.t_step;
         const int tLast = max(tLen - 1, 0);
-        uint32_t tnext = L.t_res[tBase + (int64_t) min(laneRow, tLast) * tStep];
+        // (fetched three blocks ahead, like the score kernel)
+        uint32_t tq0 = L.t_res[tBase + (int64_t) min(laneRow, tLast) * tStep], tq1 = L.t_res[tBase + (int64_t) min(16 + laneRow, tLast) * tStep],
+                 tq2 = L.t_res[tBase + (int64_t) min(32 + laneRow, tLast) * tStep];
         for (int s0 = 0; s0 < steps; s0 += 16) {
-            uint32_t tcur = tnext;
-            tnext = L.t_res[tBase + (int64_t) min(s0 + 16 + laneRow, tLast) * tStep];
+            uint32_t tcur = tq0;
+            tq0 = tq1; tq1 = tq2;
+            tq2 = L.t_res[tBase + (int64_t) min(s0 + 48 + laneRow, tLast) * tStep];
             const int sEnd = min(s0 + 16, steps);
             for (int s = s0; s < sEnd; s++) {
                 uint32_t top0 = 0;
@@ -203,18 +216,21 @@ __device__ __forceinline__ void sw_unit(const SwLaunch &L, const uint32_t unit, 
 template <int G, int R, int BLOCK, bool SHARED>
 __global__ __launch_bounds__(BLOCK) void sw_kernel(SwLaunch L) {
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    __shared__ int8_t sMat[448];
+    for (int k = (int) threadIdx.x; k < 441; k += BLOCK) sMat[k] = L.mat[k];
+    __syncthreads();
     if constexpr (SHARED) {
         for (uint32_t done = 0; L.units_per_block == 0 || done < L.units_per_block; done++) {
             uint32_t u = 0;
             if (threadIdx.x == 0) u = atomicAdd(L.work_counter, 1u);
             u = (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
             if ((uint64_t) u >= L.n_waves) break;
-            sw_unit<G, R, BLOCK, true>(L, u, smem);
+            sw_unit<G, R, BLOCK, true>(L, u, smem, sMat);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
     } else {
-        sw_unit<G, R, BLOCK, false>(L, blockIdx.x, smem);
+        sw_unit<G, R, BLOCK, false>(L, blockIdx.x, smem, sMat);
     }
 }
 
@@ -247,6 +263,12 @@ __global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
     static_assert(G == 16 || G == 32, "a pair of DPs runs on one or two DPP rows");
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     int16_t *prof = reinterpret_cast<int16_t *>(smem);            // prof[t][row], int16; row 21 = zeros
+    // behind the profile: the substitution matrix (loaded once per persistent wave) and the query's residues / composition bias of the
+    // current unit -- the profile is then built from LDS, two global loads per lane instead of a dependent pair per profile entry
+    int8_t *sMat = smem + (size_t) 22 * ROWS * sizeof(int16_t);
+    uint8_t *sQ = reinterpret_cast<uint8_t *>(sMat + 448);
+    int8_t *sB = reinterpret_cast<int8_t *>(sQ + ROWS);
+    for (int k = (int) threadIdx.x; k < 441; k += 64) sMat[k] = L.mat[k];
     const int lane = threadIdx.x % G, grp = threadIdx.x / G;
     const pk16 go2 = pk_splat(L.gap_open), ge2 = pk_splat(L.gap_extend), zero2 = pk_splat(0);
     for (uint32_t done = 0; L.units_per_block == 0 || done < L.units_per_block; done++) {
@@ -261,15 +283,19 @@ __global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
         const SwJob jobB = L.jobs[L.order[(uint64_t) w0 + (haveB ? 2 * grp + 1 : 0)]];
         const int qLen = (int) jobA.q_len;                          // every job of the wave has this query
         const int tLenA = haveA ? (int) jobA.t_len : 0, tLenB = haveB ? (int) jobB.t_len : 0;
+        for (int slot = (int) threadIdx.x; slot < ROWS; slot += 64) {
+            const int row = RP == R ? slot : (slot / RP) * R + slot % RP;    // lane-major: lane * R + r
+            const bool real = row < qLen && (RP == R || slot % RP < R);
+            const int64_t qi = (int64_t) jobA.q_start + (int64_t) (real ? row : 0) * jobA.q_step;
+            sQ[slot] = real ? L.q_res[qi] : (uint8_t) 255;
+            sB[slot] = real ? L.q_bias8[qi] : (int8_t) 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         for (int idx = (int) threadIdx.x; idx < 22 * ROWS; idx += 64) {
             const int t = idx / ROWS, slot = idx - t * ROWS;
-            const int row = RP == R ? slot : (slot / RP) * R + slot % RP;    // lane-major: lane * R + r
-            int v = 0;
-            if (t < 21 && row < qLen && (RP == R || slot % RP < R)) {
-                const int64_t qi = (int64_t) jobA.q_start + (int64_t) row * jobA.q_step;
-                v = (int) L.mat[t * 21 + L.q_res[qi]] + (int) L.q_bias8[qi];
-            }
-            prof[idx] = (int16_t) v;
+            const uint32_t qc = sQ[slot];
+            prof[idx] = (t < 21 && qc != 255u) ? (int16_t) ((int) sMat[t * 21 + (int) qc] + (int) sB[slot]) : (int16_t) 0;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -295,10 +321,13 @@ __global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
             return ra * ROWB | (rb * ROWB) << 16;
         };
         const char *profLane = reinterpret_cast<const char *>(prof + lane * RP);
-        uint32_t tnext = fetch(laneRow);
+        // the residues of a block of 16 steps are fetched three blocks ahead: the loads have ~3 x 16 steps to land, which also covers the
+        // memory latency of a chip whose HBM the prefilter of the other stream keeps saturated
+        uint32_t tq0 = fetch(laneRow), tq1 = fetch(16 + laneRow), tq2 = fetch(32 + laneRow);
         for (int s0 = 0; s0 < steps; s0 += 16) {
-            uint32_t tcur = tnext;
-            tnext = fetch(s0 + 16 + laneRow);
+            uint32_t tcur = tq0;
+            tq0 = tq1; tq1 = tq2;
+            tq2 = fetch(s0 + 48 + laneRow);
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const uint32_t top = tcur;
@@ -353,7 +382,8 @@ hipError_t launch_sw_score(const SwLaunch &L, int cfg, hipStream_t stream) {
     const uint64_t grid = L.units_per_block ? (L.n_waves + L.units_per_block - 1) / L.units_per_block
                                             : std::min<uint64_t>(L.n_waves, L.persistent_blocks ? L.persistent_blocks : L.n_waves);
     const int rows = sw_cfg_rows(cfg);
-    const size_t lds = (size_t) 22 * (rows == 48 ? 64 : rows) * sizeof(int16_t);
+    const size_t prows = rows == 48 ? 64 : rows;
+    const size_t lds = (size_t) 22 * prows * sizeof(int16_t) + 448 + 2 * prows;     // profile + matrix + query residues / bias
     switch (rows) {
         case 32: hipLaunchKernelGGL((swp_kernel<2>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
         case 48: hipLaunchKernelGGL((swp_kernel<3, 4>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
@@ -372,7 +402,7 @@ hipError_t launch_sw_score(const SwLaunch &L, int cfg, hipStream_t stream) {
 template <int G, int R, int BLOCK>
 static hipError_t launch_one(const SwLaunch &L, hipStream_t stream) {
     if (L.wave_start) {                                     // one wave per workgroup, one profile per wave
-        const size_t lds = (size_t) 22 * G * R;
+        const size_t lds = (size_t) 24 * G * R;
         if (L.n_waves == 0) return hipSuccess;
         const uint64_t grid = L.units_per_block ? (L.n_waves + L.units_per_block - 1) / L.units_per_block
                                                 : std::min<uint64_t>(L.n_waves, L.persistent_blocks ? L.persistent_blocks : L.n_waves);
@@ -380,7 +410,7 @@ static hipError_t launch_one(const SwLaunch &L, hipStream_t stream) {
         return hipGetLastError();
     }
     constexpr int GPB = BLOCK / G;
-    const size_t lds = (size_t) GPB * 22 * G * R;
+    const size_t lds = (size_t) GPB * 24 * G * R;
     const uint64_t blocks = (L.n_jobs + GPB - 1) / GPB;
     if (blocks == 0) return hipSuccess;
     static bool attr = false;
