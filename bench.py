@@ -34,9 +34,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T int32 lane-ops/s
-SW_OPS_PER_CELL = 10      # int32 kernel: add, min, max3, lshl_or, max, sub, sub, max3, sub, max3 per cell; the packed int16 score pass spends
-                          # 10 per PAIR of cells (perm, add, max, max, max, sub, sub, max, sub, max) -- priced at the int32 rate
+# Integer / packed-int16 / DPP vector instructions issue once per 4 cycles per SIMD for a 64-lane wave (measured: 0.60 T wave-instructions/s
+# on the whole chip, profiles/r02_valu_issue_rates.txt) -- half the fp32 FMA rate the microarchitecture guide quotes for the SIMDs:
+VALU_PEAK_TOPS = 256 * 4 * 64 * 2.4e9 / 4 / 1e12   # = 39.3 T lane-ops/s
+# lane-ops per DP cell: the int32 kernels (position / reverse pass, large tiles) spend 10 (add, min, max3, lshl_or, max, sub, sub, max3, sub,
+# max3), the packed int16 score pass 10 per PAIR of cells (perm, add, max, max, max, sub, sub, max, sub, max) = 5 per cell
+SW_OPS_PER_CELL_INT32, SW_OPS_PER_CELL_PACKED = 10, 5
+PACKED_ROWS_MAX = 512     # tiles of at most 512 rows run the packed score pass (mk_kernels.hpp: sw_cfg_packed)
 
 
 def pmc_traffic(kernel_name):
@@ -231,6 +235,10 @@ def main():
     cells_sw = sum(v["cells"] for k, v in stats.items() if k.startswith("sw_"))
     gcups_total = world * cells_sw / elapsed / 1e9
     sw_ms = sum(v["ms"] for k, v in stats.items() if k.startswith("sw_"))
+
+    def _packed(name):
+        return name.startswith("sw_fwd_rows") and int(name[len("sw_fwd_rows"):]) <= PACKED_ROWS_MAX
+    sw_lane_ops = sum(v["cells"] * (SW_OPS_PER_CELL_PACKED if _packed(k) else SW_OPS_PER_CELL_INT32) for k, v in stats.items() if k.startswith("sw_"))
     kstats = {k: v for k, v in stats.items() if not k.startswith(("host_", "wait_"))}
     if rank == 0:
         for k, v in sorted(stats.items()):
@@ -261,10 +269,12 @@ def main():
                      "avg_launch_ms": per_launch_ms, "launches": dom["launches"],
                      "note": "neither hot kernel family streams HBM: the fused prefilter kernels wait on dependent random index "
                              "probes (latency), the Smith-Waterman kernels are int32 vector-ALU bound (see valu_roofline)"},
-        # the Smith-Waterman kernels against the int32 vector-ALU peak: ~10 lane-ops per DP cell
-        "valu_roofline": {"kernels": "sw_fwd_* + sw_rev_*", "achieved": (cells_sw * SW_OPS_PER_CELL / max(sw_ms * 1e-3, 1e-12) / 1e12) if sw_ms else None,
+        # the Smith-Waterman kernels against the integer vector-ALU issue rate: the cell arithmetic alone (5 lane-ops per cell in the packed
+        # score pass, 10 in the int32 passes), not counting the wavefront's hand-over instructions, padding rows or fill / drain steps
+        "valu_roofline": {"kernels": "sw_fwd_* + sw_pos_* + sw_rev_*", "achieved": (sw_lane_ops / max(sw_ms * 1e-3, 1e-12) / 1e12) if sw_ms else None,
                           "peak": VALU_PEAK_TOPS, "unit": "Tlane-op/s",
-                          "frac": (cells_sw * SW_OPS_PER_CELL / max(sw_ms * 1e-3, 1e-12) / 1e12 / VALU_PEAK_TOPS) if sw_ms else None},
+                          "frac": (sw_lane_ops / max(sw_ms * 1e-3, 1e-12) / 1e12 / VALU_PEAK_TOPS) if sw_ms else None,
+                          "note": "peak = one integer / packed-int16 wave-instruction per 4 cycles per SIMD (measured, profiles/r02_valu_issue_rates.txt)"},
     }
     if rank == 0:
         if world == 1 and args.cpu_sample > 0:

@@ -114,15 +114,30 @@ __global__ void bounds_kernel(const uint32_t *sortedKeys, uint32_t n, uint32_t *
 // e-value gate on the forward score (table per query length); survivors get a position job (the same DP again, this time
 // with end-position tracking)
 __global__ __launch_bounds__(256) void gate_kernel(const SwJob *fwdJobs, const SwOut *fwdOut, uint64_t n, const GateEntry *gate,
-                                                   uint32_t *posCount, uint32_t *posPair, SwJob *posJobs, uint32_t *posKeys, uint32_t *posIdx) {
+                                                   uint32_t *posCount, uint32_t *posPair, SwJob *posJobs, uint32_t *posKeys, uint32_t *posIdx,
+                                                   unsigned long long *work /* [2 * cfg]: bytes, [2 * cfg + 1]: cells of the position pass (statistics) */) {
+    __shared__ unsigned long long sWork[2 * SW_NCFG];
+    for (int k = threadIdx.x; k < 2 * SW_NCFG; k += blockDim.x) sWork[k] = 0;
+    __syncthreads();
     const uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const int score = fwdOut[p].score;
-    if (score <= 0) return;
-    SwJob j = fwdJobs[p];
-    const GateEntry g = gate[j.q_len];
-    bool pass = score >= g.s0;
-    if (!pass && score < 256) pass = (g.mask[score >> 5] >> (score & 31)) & 1u;
+    bool pass = false;
+    SwJob j;
+    if (p < n) {
+        const int score = fwdOut[p].score;
+        if (score > 0) {
+            j = fwdJobs[p];
+            const GateEntry g = gate[j.q_len];
+            pass = score >= g.s0;
+            if (!pass && score < 256) pass = (g.mask[score >> 5] >> (score & 31)) & 1u;
+            if (pass) {
+                const int c = sw_cfg_of(j.q_len);
+                atomicAdd(&sWork[2 * c], (unsigned long long) (j.t_len + 2u * j.q_len + (uint32_t) (sizeof(SwJob) + sizeof(SwOut))));
+                atomicAdd(&sWork[2 * c + 1], (unsigned long long) j.q_len * j.t_len);
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * SW_NCFG; k += blockDim.x) if (sWork[k]) atomicAdd(&work[k], sWork[k]);
     if (!pass) return;
     const uint32_t r = atomicAdd(posCount, 1u);
     posPair[r] = (uint32_t) p;
@@ -497,11 +512,16 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hi
     SwJob *dPosJobs = (SwJob *) dev_scratch("align_posjobs", (size_t) n * sizeof(SwJob));
     ANULL(dRevPair); ANULL(dPosJobs);
     th = tb("align_gate", 52.0 * n, 0);
-    hipLaunchKernelGGL(gate_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dJobs, dOut, (uint64_t) n, dGate, dCount, dRevPair, dPosJobs, dKeys, dIdx);
+    unsigned long long *dPosWork = (unsigned long long *) dev_scratch("align_poswork", 2 * SW_NCFG * 8);
+    unsigned long long *hPosWork = (unsigned long long *) pinned_scratch("align_poswork_h", 2 * SW_NCFG * 8);
+    ANULL(dPosWork); ANULL(hPosWork);
+    ACHK(hipMemsetAsync(dPosWork, 0, 2 * SW_NCFG * 8, stream));
+    hipLaunchKernelGGL(gate_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dJobs, dOut, (uint64_t) n, dGate, dCount, dRevPair, dPosJobs, dKeys, dIdx, dPosWork);
     te(th);
     ACHK(hipGetLastError());
     uint32_t *hCount = (uint32_t *) pinned_scratch("align_count_h", 16);
     ANULL(hCount);
+    ACHK(hipMemcpyAsync(hPosWork, dPosWork, 2 * SW_NCFG * 8, hipMemcpyDeviceToHost, stream));
     ACHK(hipMemcpyAsync(hCount, dCount, 8, hipMemcpyDeviceToHost, stream));
     ACHK(sync_wait(stream, "wait_align"));
     if (hCount[1] != 0) { err = "prefilter hit " + std::to_string(hCount[1] - 1) + " names a target outside the DB"; return MK_ERR_ARG; }
@@ -516,6 +536,7 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hi
     int hPos[SW_NCFG];
     rc = run_sorted_sw(V, P, dPosJobs, dPosOut, dKeys, dIdx, dKeys2, dIdx2, nRev, "sw_pos", stream, err, tb, te, hPos);
     if (rc != MK_OK) return rc;
+    for (int c = 0; c < SW_NCFG; c++) if (hPos[c] >= 0) ts(hPos[c], (double) hPosWork[2 * c], (double) hPosWork[2 * c + 1]);
     hipLaunchKernelGGL(rev_jobs_kernel, dim3((nRev + 255) / 256), dim3(256), 0, stream, dPosJobs, dPosOut, dRevPair, dOut, nRev, dRevJobs, dKeys, dIdx, dCount + 2);
     ACHK(hipGetLastError());
     rc = run_sorted_sw(V, P, dRevJobs, dRevOut, dKeys, dIdx, dKeys2, dIdx2, nRev, "sw_rev", stream, err, tb, te, hRev);

@@ -1244,12 +1244,12 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             if (hCounters[0] > CAND_CAP) rc = RC_CAND_OVERFLOW;
             else {
                 nCand = hCounters[0];
-                // algorithmic bytes of the fused launches: 4 B bitmap word per similar k-mer + 8 B slot per non-empty k-mer
-                // (~ one per index hit) + 8 B per index entry + the row heads of every k-mer start (~1.3 KB)
+                // algorithmic bytes of the per-query launches, SURVEY.md 8(d): B_lookup = 16 B per probed k-mer + 6 B per index entry read
+                // (+ 7 B per candidate written, booked with the back end)
                 for (int t = 0; t < N_TIERS; t++)
                     if (thFused[t] >= 0) {
                         const unsigned long long *T = hFTotals + 16 * (t + 1);
-                        ts(thFused[t], 4.0 * (double) T[0] + 16.0 * (double) T[1] + 1280.0 * (double) T[2], (double) T[0]);
+                        ts(thFused[t], 16.0 * (double) T[0] + 6.0 * (double) T[1], (double) T[0]);
                     }
                 if (getenv("MK_PREFILTER_DEBUG"))
                     fprintf(stderr, "[prefilter] chunk %u..%u: tiers %zu/%zu/%zu/%zu too-long %zu overflow %u | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g (mean wave %.3g) sort %.3g emit %.3g overflowed %.3g | cand %u\n",

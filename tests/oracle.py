@@ -178,3 +178,22 @@ def digest_arrays(offsets, body, n_blocks):
     h.update(np.diff(off).astype("<u8").tobytes())
     h.update(body)
     return h.hexdigest()
+
+
+def saturated_threshold_workload(seed=5):
+    """Targets with more than --max-seqs near-copies of every query: the prefilter's score threshold saturates at 255 and the
+    reference rescales by the query's self score (QueryMatcher.cpp:163-170, rescoreHits :525-544)."""
+    import random
+    rng = random.Random(seed)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    rs = lambda n: "".join(rng.choice(aa) for _ in range(n))
+    mut = lambda s, r: "".join(ch if rng.random() > r else rng.choice(aa) for ch in s)
+    queries = [rs(130), rs(95), rs(210)]
+    targets = []
+    for q in queries:
+        for k in range(130):
+            targets.append(rs(rng.randrange(0, 30)) + mut(q, 0.02 + 0.002 * k) + rs(rng.randrange(0, 30)))
+    targets += [rs(rng.randrange(60, 300)) for _ in range(60)]
+    rng.shuffle(targets)
+    queries += [rs(60), mut(queries[0], 0.3)]
+    return targets, queries

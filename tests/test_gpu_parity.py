@@ -222,6 +222,46 @@ def test_sw_vs_golden(gpu_api):
         assert int(got[k][0]) == oracle.sw(q[k], t[k])[0]
 
 
+@pytest.mark.parametrize("max_seqs", [100, 300])
+def test_saturated_score_threshold(gpu_api, tmp_path, pf_path, max_seqs):
+    """more than --max-seqs targets reach 255 on the diagonal: QueryMatcher's threshold saturates and is rescaled by the query's exact
+    self score (QueryMatcher.cpp:163-170, :525-544); the hit list, its tie order at the cut and the alignments vs the oracle"""
+    api = gpu_api
+    targets, queries = oracle.saturated_threshold_workload()
+    params = api.default_params()
+    params.max_seqs = max_seqs
+    db = api.TargetDB(targets, params)
+    q = api.Queries(queries, params)
+    hits, hoff = api.prefilter(db, q, params)
+    alns, aoff = api.align(db, q, params)
+    opref, oaln = oracle.run_pipeline(targets, queries, str(tmp_path), extra=["--l2", str(params.host_l2_bytes), "--max-seqs", str(max_seqs)])
+    for i in range(len(queries)):
+        assert api.format_hits(hits, int(hoff[i]), int(hoff[i + 1])) == opref[i], i
+        assert api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1])) == oaln[i], i
+    if max_seqs == 100:
+        assert max(sum(1 for h in hits[int(hoff[i]):int(hoff[i + 1])] if int(h["pref_score"]) >= 255) for i in range(3)) >= 100
+
+
+def test_sw_golden_top_of_int16_range(gpu_api):
+    """identical / near-identical pairs of 2000 .. 6500 residues: scores up to the saturation value 32767 of the reference's word
+    pass, multi-tile queries; coordinates printed by the reference vs the kernel's, raw score vs the oracle's"""
+    api = gpu_api
+    t, q = _lines("sw2_targets.txt.gz"), _lines("sw2_queries.txt.gz")
+    with gzip.open(os.path.join(GOLD, "sw2_expected.tsv.gz"), "rt") as f:
+        exp = [l.rstrip("\n").split("\t") for l in f]
+    params = api.default_params()
+    db = api.TargetDB(t, params)
+    qq = api.Queries(q, params)
+    idx = np.arange(len(q), dtype=np.uint32)
+    got = api.sw_pairs(db, qq, idx, idx, with_start=True)
+    top = 0
+    for k, e in enumerate(exp):
+        assert (int(got[k][3]), int(got[k][1]), int(got[k][4]), int(got[k][2])) == (int(e[6]), int(e[7]), int(e[9]), int(e[10])), (k, got[k], e)
+        assert int(got[k][0]) == oracle.sw(q[k], t[k])[0]
+        top = max(top, int(got[k][0]))
+    assert top == 32767, "the fixture should contain a pair that saturates int16"
+
+
 def test_max_seqs_truncation_order(gpu_api, small_workload, tmp_path, pf_path):
     """--max-seqs smaller than the number of qualifying targets: the cut follows the reference's bin order"""
     targets, queries = small_workload

@@ -43,6 +43,19 @@ def test_oracle_sw_matches_golden(tmp_path):
         assert (tmp_path / "out.tsv").read_text() == _text("sw_expected.tsv.gz"), lanes
 
 
+def test_oracle_sw_matches_golden_at_the_top_of_the_int16_range(tmp_path):
+    """pairs scoring 10 000 .. 32 767 (the last one saturates the reference's word pass), every stripe length"""
+    oracle.build()
+    t, q = _lines("sw2_targets.txt.gz"), _lines("sw2_queries.txt.gz")
+    (tmp_path / "t.txt").write_text("\n".join(t) + "\n")
+    (tmp_path / "q.txt").write_text("\n".join(q) + "\n")
+    (tmp_path / "p.txt").write_text("\n".join("%d %d" % (i, i) for i in range(len(q))) + "\n")
+    for lanes in ((32, 16), (16, 8)):
+        subprocess.check_call([oracle.CLI, "sw", str(tmp_path / "t.txt"), str(tmp_path / "q.txt"), str(tmp_path / "p.txt"),
+                               str(tmp_path / "out.tsv"), "--dbres", "7500000", "--lanes-byte", str(lanes[0]), "--lanes-word", str(lanes[1])])
+        assert (tmp_path / "out.tsv").read_text() == _text("sw2_expected.tsv.gz"), lanes
+
+
 def test_oracle_orfs_match_golden(tmp_path):
     """extractorfs --translate (Orf::findAll, TranslateNucl, header format) against the reference's own output"""
     oracle.build()
@@ -76,6 +89,20 @@ def test_oracle_matches_live_reference(tmp_path):
     assert opref == rpref and oaln == raln
     for f in ("masked_targets.txt", "index.txt", "stats.txt"):
         assert open(tmp_path / "oracle" / f).read() == open(tmp_path / "ref" / f).read(), f
+
+
+@pytest.mark.skipif(not os.path.exists(oracle.REF) or not os.path.isdir("/root/reference"), reason="reference harness not built here")
+@pytest.mark.parametrize("max_seqs", [100, 300])
+def test_oracle_matches_live_reference_when_the_score_threshold_saturates(tmp_path, max_seqs):
+    """more than --max-seqs targets score 255 or more on the diagonal: threshold rescale by the self score + tie order at the cut"""
+    import ctypes
+    targets, queries = oracle.saturated_threshold_workload()
+    l2 = ctypes.CDLL(None).sysconf(191)
+    opref, oaln = oracle.run_pipeline(targets, queries, str(tmp_path), extra=["--l2", str(l2 if l2 > 0 else 262144), "--max-seqs", str(max_seqs)])
+    rpref, raln = oracle.run_ref_pipeline(targets, queries, str(tmp_path), extra=["--threads", "2", "--max-seqs", str(max_seqs)])
+    assert opref == rpref and oaln == raln
+    n255 = [sum(1 for l in b.splitlines() if int(l.split("\t")[1]) >= 255) for b in rpref]
+    assert max(n255) >= max_seqs or max_seqs == 300, n255        # (130 copies per query: the 100-hit cut saturates, the 300-hit cut does not)
 
 
 def test_matrix_tables_reproduce_reference_matrices(tmp_path):
