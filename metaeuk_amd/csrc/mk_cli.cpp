@@ -9,7 +9,13 @@
 // Parameters::createParameterString (Parameters.cpp:2811-2881), i.e. every flag of the module's list is
 // passed explicitly.  All of them are accepted here; the ones the predictexons path actually varies are
 // honoured, and a value that would change results in a way this build does not restate is a hard error
-// (the reference parser also fails hard on anything it does not know).  On failure nothing named
+// in EVERY command (the reference parser also fails hard on anything it does not know).  Omitted flags take
+// the module defaults of the reference (-e 0.001 for align / search, -s 4 for prefilter, 5.7 for search) with
+// one exception: `align` and `search` must be given --alignment-mode 2, because the module default (0 = auto)
+// resolves to score-only output, which is not built.  predictexons applies setPredictExonsDefaults.
+// Sharded commands (RANK / WORLD_SIZE or --shard r/N): every worker removes its own leftovers and stamps its
+// shard with the launch token before it computes, a failing worker leaves <out>_<r>.failed, worker 0 merges
+// only shards of its own launch and gives up after MK_SHARD_TIMEOUT_S (7200) seconds.  On failure nothing named
 // <out>.dbtype is left behind, because the workflows use that file as their "step done" marker
 // (blastp.sh:59,77).  Exit status non-zero on any error, as `EXIT(EXIT_FAILURE)` does (Util.h:14).
 #include "../../include/metaeuk_amd.h"
@@ -60,9 +66,11 @@ const Flag FLAGS[] = {
     {"--ref-simd", "avx2", true}, {"--ref-l2-bytes", "", true}, {"--gpu", "0", true}, {"--shard", "", true},
 };
 
+std::string g_failMarker;        // <out>_<rank>.failed of a sharded worker: written by die(), seen by worker 0 (which stops waiting)
 int die(const char *fmt, const std::string &a = "") {
     fprintf(stderr, fmt, a.c_str());
     fprintf(stderr, "\n");
+    if (!g_failMarker.empty()) { FILE *f = fopen(g_failMarker.c_str(), "w"); if (f) { fprintf(f, fmt, a.c_str()); fclose(f); } }
     return EXIT_FAILURE;
 }
 
@@ -110,9 +118,12 @@ int parse(int argc, char **argv, Args &a) {
             std::string(k.name) == "--pca" || std::string(k.name) == "--pcb" || std::string(k.name) == "--zdrop" || std::string(k.name) == "--realign-score-bias" ||
             std::string(k.name) == "--realign-max-seqs" || std::string(k.name) == "--seq-id-mode" || std::string(k.name) == "--mask-lower-case" ||
             std::string(k.name) == "--threads" || std::string(k.name) == "--remove-tmp-files" || std::string(k.name) == "--reuse-latest" ||
-            std::string(k.name) == "--force-reuse" || std::string(k.name) == "--disk-space-limit" || std::string(k.name) == "--mpi-runner" ||
-            std::string(k.name) == "--start-sens" || std::string(k.name) == "--sens-steps" || std::string(k.name) == "--max-length" ||
-            std::string(k.name) == "--max-gaps") continue;    // no effect on this path
+            std::string(k.name) == "--force-reuse" || std::string(k.name) == "--disk-space-limit" || std::string(k.name) == "--mpi-runner") continue;    // no effect on this path
+        if (std::string(k.name) == "--start-sens") continue;          // only read when --sens-steps > 1, which is refused below
+        if (std::string(k.name) == "--max-seq-len") {                 // sequences are never cut here: the value must admit everything the reference admits
+            if (atol(v.c_str()) < 65535) { fprintf(stderr, "--max-seq-len %s: shorter limits than the default 65535 (sequence splitting) are not implemented\n", v.c_str()); return EXIT_FAILURE; }
+            continue;
+        }
         if (std::string(k.name) == "-k") {                    // 0 = automatic = 6 below 3.35e9 target residues (IndexTable.h:439-449)
             if (v != "0" && v != "6") { fprintf(stderr, "-k %s: only k = 6 (or 0 = auto) is implemented\n", v.c_str()); return EXIT_FAILURE; }
             continue;
@@ -216,8 +227,23 @@ int openTarget(const std::string &path, const mk_params &P, TargetSide &ts) {
 // and writes <out>_<rank>; worker 0 waits for the other shards (their .dbtype is written last) and merges them into <out>.  No
 // collective: the workers only meet in the file system.  --shard r/N, else RANK / WORLD_SIZE of the launcher (torch.distributed.run,
 // the RUNNER hook of blastp.sh:70,85).
-struct Shard { int rank = 0, world = 1; };
-int shardOf(const Args &a, Shard &sh) {
+struct Shard { int rank = 0, world = 1; std::string token; };
+// what identifies ONE launch of the workers: the launcher's run id, else a hash of the command line (without the per-worker flags).
+// A shard left behind by an earlier, crashed launch carries another token (or none) and is never merged.
+std::string launchToken(int argc, char **argv) {
+    if (const char *id = getenv("TORCHELASTIC_RUN_ID")) if (*id && strcmp(id, "none") != 0) return std::string("run-") + id;
+    if (const char *id = getenv("MK_LAUNCH_ID")) if (*id) return std::string("id-") + id;
+    uint64_t h = 1469598103934665603ull;
+    for (int i = 1; i < argc; i++) {
+        if (!strcmp(argv[i], "--shard") || !strcmp(argv[i], "--gpu")) { i++; continue; }
+        for (const char *c = argv[i]; *c; c++) { h ^= (unsigned char) *c; h *= 1099511628211ull; }
+        h ^= 0xFF; h *= 1099511628211ull;
+    }
+    char buf[32];
+    snprintf(buf, sizeof(buf), "argv-%016llx", (unsigned long long) h);
+    return buf;
+}
+int shardOf(const Args &a, Shard &sh, int argc, char **argv) {
     auto it = a.opt.find("--shard");
     if (it != a.opt.end() && !it->second.empty()) {
         if (sscanf(it->second.c_str(), "%d/%d", &sh.rank, &sh.world) != 2) return die("--shard wants rank/world, got %s", it->second);
@@ -225,19 +251,48 @@ int shardOf(const Args &a, Shard &sh) {
         sh.rank = atoi(getenv("RANK")); sh.world = atoi(getenv("WORLD_SIZE"));
     }
     if (sh.world < 1 || sh.rank < 0 || sh.rank >= sh.world) return die("bad shard %s", std::to_string(sh.rank) + "/" + std::to_string(sh.world));
+    sh.token = launchToken(argc, argv);
     return 0;
+}
+// first thing a sharded worker does, before any compute: its own leftovers of an earlier launch disappear, and its token says which launch
+// the shard it is about to write belongs to
+void beginShard(const std::string &out, const Shard &sh) {
+    if (sh.world <= 1) return;
+    const std::string mine = out + "_" + std::to_string(sh.rank);
+    for (const char *ext : {".dbtype", ".index", "", ".orfs", ".failed", ".token"}) remove((mine + ext).c_str());
+    g_failMarker = mine + ".failed";
+    FILE *f = fopen((mine + ".token").c_str(), "w");
+    if (f) { fputs(sh.token.c_str(), f); fclose(f); }
+}
+long shardTimeoutTicks() {            // 50 ms ticks; MK_SHARD_TIMEOUT_S (default two hours): a peer that died without a marker
+    const char *e = getenv("MK_SHARD_TIMEOUT_S");
+    const long sec = e && atol(e) > 0 ? atol(e) : 7200;
+    return sec * 20;
+}
+// waits until worker r has published `file` (a path under <out>_<r>) in THIS launch; false: the worker failed or never showed up
+bool waitForPeer(const std::string &out, int r, const std::string &file, const std::string &token) {
+    const std::string base = out + "_" + std::to_string(r);
+    const long limit = shardTimeoutTicks();
+    for (long waited = 0; waited < limit; waited++) {
+        if (mk::Database::exists(base + ".failed")) { die("worker %s failed", std::to_string(r)); return false; }
+        if (mk::Database::exists(file)) {
+            char buf[128] = {0};
+            FILE *f = fopen((base + ".token").c_str(), "r");
+            if (f) { if (!fgets(buf, sizeof(buf), f)) buf[0] = 0; fclose(f); }
+            if (token == buf) return true;                      // else: a stale file of an earlier launch, its owner has not started yet
+        }
+        usleep(50000);
+    }
+    die("gave up waiting for %s", file);
+    return false;
 }
 int finishShards(const std::string &out, const Shard &sh, int dbtype) {
     if (sh.world <= 1 || sh.rank != 0) return EXIT_SUCCESS;
-    for (int r = 1; r < sh.world; r++) {
-        const std::string marker = out + "_" + std::to_string(r) + ".dbtype";
-        for (long waited = 0; !mk::Database::exists(marker); waited++) {
-            if (waited == 20L * 3600L * 24L) return die("gave up waiting for %s", marker);
-            usleep(50000);
-        }
-    }
+    for (int r = 1; r < sh.world; r++)
+        if (!waitForPeer(out, r, out + "_" + std::to_string(r) + ".dbtype", sh.token)) return EXIT_FAILURE;
     const std::string e = mk::mergeShards(out, sh.world, dbtype);
     if (!e.empty()) return die("%s", e);
+    for (int r = 0; r < sh.world; r++) remove((out + "_" + std::to_string(r) + ".token").c_str());
     return EXIT_SUCCESS;
 }
 
@@ -258,6 +313,11 @@ int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
     mk_params P;
     int gpu = 0;
     if (isSearch && a.opt.find("-s") == a.opt.end()) a.opt["-s"] = "5.7";   // the search workflow's own default (Search.cpp:24)
+    if (isAlign && a.opt.find("-e") == a.opt.end()) a.opt["-e"] = "0.001"; // Parameters.cpp:2414 (predictexons passes -e 100 explicitly)
+    // the module's own default --alignment-mode 0 resolves to score-only output (Alignment.cpp:168-178), which is not built:
+    // the caller has to ask for mode 2, as predictexons does (PredictExons.cpp:13)
+    if (isAlign && a.opt.find("--alignment-mode") == a.opt.end())
+        return die("%s needs --alignment-mode 2 (the module default, 0 = score only, is not implemented)", isSearch ? "search" : "align");
     if (int rc = fillParams(a, P, gpu)) return rc;
     const double t0 = now();
     mk::Database qdb;
@@ -265,7 +325,8 @@ int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
     if (!e.empty()) return die("%s", e);
     if ((qdb.dbtype & 0xFFFF) != mk::DBTYPE_AMINO_ACIDS) return die("only amino-acid query databases are implemented%s");
     Shard sh;
-    if (int rc = shardOf(a, sh)) return rc;
+    if (int rc = shardOf(a, sh, argc, argv)) return rc;
+    beginShard(a.pos[isAlign && !isSearch ? 3 : 2], sh);
     if (sh.world > 1) {                                       // this worker's queries only
         size_t first = 0, count = 0;
         mk::decomposeByLength(qdb.entries, sh.rank, sh.world, first, count);
@@ -369,6 +430,17 @@ int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
     return finishShards(outBase, sh, isAlign ? mk::DBTYPE_ALIGNMENT_RES : mk::DBTYPE_PREFILTER_RES);
 }
 
+// end of the batch of contigs (positions in `ord`) that starts at c0: as many as fit the per-call nucleotide budget (MK_CLI_BATCH_NT,
+// default 2^29: six-frame translation of a batch stays well below the library's 2^32 query residues), at least one
+size_t contigBatchEnd(const mk::Database &contigs, const std::vector<size_t> &ord, size_t c0) {
+    uint64_t budget = 1ull << 29;
+    if (const char *e = getenv("MK_CLI_BATCH_NT")) if (atoll(e) > 0) budget = (uint64_t) atoll(e);
+    uint64_t nt = 0;
+    size_t c1 = c0;
+    while (c1 < ord.size() && (c1 == c0 || nt + contigs.seqLen(ord[c1]) <= budget)) { nt += contigs.seqLen(ord[c1]); c1++; }
+    return c1;
+}
+
 // extractorfs <i:contigDB> <o:orfDB> [--min-length 15] [--translate 0|1] [--aa-sibling NAME] [--gpu N]
 //   = util/extractorfs.cpp for predictexons' settings: nucleotide (or, --translate 1, amino-acid) ORF fragments under
 //   renumbered keys 0..N-1 plus the header DB <o>_h ("contigKey<TAB>from(+|-)len[<TAB>complete]").  --aa-sibling NAME also
@@ -404,17 +476,7 @@ int cmdExtractOrfs(int argc, char **argv) {
     std::string e = contigs.open(pos[0]);
     if (!e.empty()) return die("%s", e);
     const double t0 = now();
-    std::vector<char> nucl;
     const std::vector<size_t> ord = contigs.keyOrder();           // fragments are renumbered by ascending contig key (extractorfs.cpp:140-155)
-    std::vector<uint64_t> off(ord.size() + 1, 0);
-    for (size_t i = 0; i < ord.size(); i++) {
-        nucl.insert(nucl.end(), contigs.entry(ord[i]), contigs.entry(ord[i]) + contigs.seqLen(ord[i]));
-        off[i + 1] = nucl.size();
-    }
-    mk_orfs *O = nullptr;
-    if (mk_extract_orfs(nucl.data(), off.data(), (uint32_t) contigs.entries.size(), minLength, &O) != MK_OK) return die("%s", mk_last_error());
-    const mk_orf *orfs; const uint64_t *aaOff; const char *aa; uint64_t n = 0;
-    mk_orfs_result(O, &orfs, &aaOff, &aa, &n);
     static const char *COMP =                                  // Orf::iupacReverseComplementTable, Orf.cpp:48-52
         "................................................................"
         ".TVGH..CD..M.KN...YSAABW.R.......tvgh..cd..m.kn...ysaabw.r......"
@@ -432,35 +494,55 @@ int cmdExtractOrfs(int argc, char **argv) {
     }
     std::string buf;
     char hdr[128];
-    for (uint64_t k = 0; k < n; k++) {
-        const mk_orf &o = orfs[k];
-        mk_orf keyed = o;
-        keyed.contig = contigs.entries[ord[o.contig]].key;            // the header names the contig's DB key
-        size_t hl = mk_format_orf_header(hdr, &keyed);
-        hdr[hl++] = '\n';
-        hdrW.write((uint32_t) k, hdr, hl);
-        buf.assign(aa + aaOff[k], aa + aaOff[k + 1]);
-        buf.push_back('\n');
-        if (aaW) aaW->write((uint32_t) k, buf.data(), buf.size());
-        if (!translate) {                                        // the fragment's nucleotides as Orf::getSequence hands them out
-            const char *c = contigs.entry(ord[o.contig]);
-            const size_t len = contigs.seqLen(ord[o.contig]), nn = 3 * (size_t) (aaOff[k + 1] - aaOff[k]);
-            buf.resize(nn);
-            for (size_t j = 0; j < nn; j++) {
-                char ch;
-                if (!o.minus_strand) { ch = c[o.from + j]; if (ch == 'u') ch = 't'; }
-                else { ch = c[o.from - j]; if (ch == 'u') ch = 't'; ch = COMP[(unsigned char) ch]; if (ch == '.') ch = 'N'; }
-                buf[j] = ch;
-            }
-            (void) len;
-            buf.push_back('\n');
+    uint64_t n = 0;                                             // fragments so far = key of the next one
+    // the contigs go through the device in batches bounded by their nucleotides (the library takes < 2^30 per call); the fragment
+    // keys run on from batch to batch
+    std::vector<char> nucl;
+    std::vector<uint64_t> off;
+    for (size_t c0 = 0; c0 < ord.size(); ) {
+        const size_t c1 = contigBatchEnd(contigs, ord, c0);
+        nucl.clear(); off.assign(1, 0);
+        for (size_t i = c0; i < c1; i++) {
+            nucl.insert(nucl.end(), contigs.entry(ord[i]), contigs.entry(ord[i]) + contigs.seqLen(ord[i]));
+            off.push_back(nucl.size());
         }
-        seqW.write((uint32_t) k, buf.data(), buf.size());
+        mk_orfs *O = nullptr;
+        static const char none = 0;
+        if (mk_extract_orfs(nucl.empty() ? &none : nucl.data(), off.data(), (uint32_t) (c1 - c0), minLength, &O) != MK_OK) return die("%s", mk_last_error());
+        const mk_orf *orfs; const uint64_t *aaOff; const char *aa; uint64_t nb = 0;
+        mk_orfs_result(O, &orfs, &aaOff, &aa, &nb);
+        for (uint64_t k = 0; k < nb; k++) {
+            const mk_orf &o = orfs[k];
+            const size_t ci = ord[c0 + o.contig];
+            mk_orf keyed = o;
+            keyed.contig = contigs.entries[ci].key;                       // the header names the contig's DB key
+            size_t hl = mk_format_orf_header(hdr, &keyed);
+            hdr[hl++] = '\n';
+            hdrW.write((uint32_t) (n + k), hdr, hl);
+            buf.assign(aa + aaOff[k], aa + aaOff[k + 1]);
+            buf.push_back('\n');
+            if (aaW) aaW->write((uint32_t) (n + k), buf.data(), buf.size());
+            if (!translate) {                                        // the fragment's nucleotides as Orf::getSequence hands them out
+                const char *c = contigs.entry(ci);
+                const size_t nn = 3 * (size_t) (aaOff[k + 1] - aaOff[k]);
+                buf.resize(nn);
+                for (size_t j = 0; j < nn; j++) {
+                    char ch;
+                    if (!o.minus_strand) { ch = c[o.from + j]; if (ch == 'u') ch = 't'; }
+                    else { ch = c[o.from - j]; if (ch == 'u') ch = 't'; ch = COMP[(unsigned char) ch]; if (ch == '.') ch = 'N'; }
+                    buf[j] = ch;
+                }
+                buf.push_back('\n');
+            }
+            seqW.write((uint32_t) (n + k), buf.data(), buf.size());
+        }
+        n += nb;
+        mk_orfs_destroy(O);
+        c0 = c1;
     }
     if (!(e = seqW.close()).empty() || !(e = hdrW.close()).empty()) return die("%s", e);
     if (aaW) { if (!(e = aaW->close()).empty()) return die("%s", e); delete aaW; }
     fprintf(stderr, "extractorfs: %zu contigs -> %llu fragments, %.2f s\n", contigs.entries.size(), (unsigned long long) n, now() - t0);
-    mk_orfs_destroy(O);
     return EXIT_SUCCESS;
 }
 
@@ -501,7 +583,8 @@ int cmdPredictExons(int argc, char **argv) {
     // contigs by ascending key: the order in which createRenumberedDB numbers their fragments (extractorfs.cpp:140-155)
     std::vector<size_t> ord = contigs.keyOrder();
     Shard sh;
-    if (int rc = shardOf(a, sh)) return rc;
+    if (int rc = shardOf(a, sh, argc, argv)) return rc;
+    beginShard(a.pos[2], sh);
     if (sh.world > 1) {                                           // this worker's contigs (a contiguous range of the key order)
         std::vector<mk::DbEntry> inOrder(ord.size());
         for (size_t i = 0; i < ord.size(); i++) inOrder[i] = contigs.entries[ord[i]];
@@ -510,40 +593,45 @@ int cmdPredictExons(int argc, char **argv) {
         ord = std::vector<size_t>(ord.begin() + (std::ptrdiff_t) first, ord.begin() + (std::ptrdiff_t) (first + count));
     }
     const std::string outPath = sh.world > 1 ? a.pos[2] + "_" + std::to_string(sh.rank) : a.pos[2];
-    if (sh.world > 1) { remove((outPath + ".orfs").c_str()); remove((outPath + ".dbtype").c_str()); }   // leftovers of a run that died
-    std::vector<char> nucl;
-    std::vector<uint64_t> off(ord.size() + 1, 0);
-    for (size_t i = 0; i < ord.size(); i++) {
-        nucl.insert(nucl.end(), contigs.entry(ord[i]), contigs.entry(ord[i]) + contigs.seqLen(ord[i]));
-        off[i + 1] = nucl.size();
-    }
     TargetSide ts;
     if (int rc = openTarget(a.pos[1], P, ts)) return rc;
     mk_targetdb *T = ts.T;
     const std::vector<uint32_t> &tkeys = ts.keys;
-    mk_orfs *O = nullptr;
-    mk_queries *Q = nullptr;
-    mk_predictions *R = nullptr;
     const double t1 = now();
     static const char none = 0;
-    if (mk_extract_orfs(nucl.empty() ? &none : nucl.data(), off.data(), (uint32_t) ord.size(), minLength, &O) != MK_OK) return die("%s", mk_last_error());
-    const mk_orf *orfs; const uint64_t *aaOff; const char *aa; uint64_t nOrfs = 0;
-    mk_orfs_result(O, &orfs, &aaOff, &aa, &nOrfs);
-    // fragment keys are numbered over ALL contigs (createRenumberedDB): a worker publishes how many it found and adds what the workers
-    // before it found -- a prefix over the workers through the file system
+    std::vector<char> nucl;
+    std::vector<uint64_t> off;
+    auto loadBatch = [&](size_t c0, size_t c1) {
+        nucl.clear(); off.assign(1, 0);
+        for (size_t i = c0; i < c1; i++) {
+            nucl.insert(nucl.end(), contigs.entry(ord[i]), contigs.entry(ord[i]) + contigs.seqLen(ord[i]));
+            off.push_back(nucl.size());
+        }
+    };
+    // fragment keys are numbered over ALL contigs (createRenumberedDB): a worker publishes how many fragments its contigs have (a counting
+    // pass of the ORF kernels over its batches) and adds what the workers before it found -- a prefix over the workers through the file system
     uint64_t orfBase = 0;
     if (sh.world > 1) {
+        uint64_t mine = 0;
+        for (size_t c0 = 0; c0 < ord.size(); ) {
+            const size_t c1 = contigBatchEnd(contigs, ord, c0);
+            loadBatch(c0, c1);
+            mk_orfs *O = nullptr;
+            if (mk_extract_orfs(nucl.empty() ? &none : nucl.data(), off.data(), (uint32_t) (c1 - c0), minLength, &O) != MK_OK) return die("%s", mk_last_error());
+            const mk_orf *orfs; const uint64_t *aaOff; const char *aa; uint64_t nb = 0;
+            mk_orfs_result(O, &orfs, &aaOff, &aa, &nb);
+            mine += nb;
+            mk_orfs_destroy(O);
+            c0 = c1;
+        }
         FILE *f = fopen((outPath + ".orfs.tmp").c_str(), "w");
         if (!f) return die("cannot write %s", outPath + ".orfs.tmp");
-        fprintf(f, "%llu\n", (unsigned long long) nOrfs);
+        fprintf(f, "%llu\n", (unsigned long long) mine);
         fclose(f);
         rename((outPath + ".orfs.tmp").c_str(), (outPath + ".orfs").c_str());
         for (int r = 0; r < sh.rank; r++) {
             const std::string cf = a.pos[2] + "_" + std::to_string(r) + ".orfs";
-            for (long waited = 0; !mk::Database::exists(cf); waited++) {
-                if (waited == 20L * 3600L * 24L) return die("gave up waiting for %s", cf);
-                usleep(50000);
-            }
+            if (!waitForPeer(a.pos[2], r, cf, sh.token)) return EXIT_FAILURE;
             unsigned long long v = 0;
             FILE *g = fopen(cf.c_str(), "r");
             if (!g || fscanf(g, "%llu", &v) != 1) return die("cannot read %s", cf);
@@ -551,34 +639,50 @@ int cmdPredictExons(int argc, char **argv) {
             orfBase += v;
         }
     }
-    if (mk_queries_from_orfs(O, &P, &Q) != MK_OK) return die("%s", mk_last_error());
-    if (mk_search(T, Q, &P) != MK_OK) return die("%s", mk_last_error());
-    if (mk_predict_exons(T, O, Q, &X, tkeys.data(), &R) != MK_OK) return die("%s", mk_last_error());
-    const double t2 = now();
-    const mk_prediction *preds; const uint64_t *coff; const mk_exon *exons; uint64_t np = 0;
-    mk_predictions_result(R, &preds, &coff, &exons, &np);
     mk::DatabaseWriter w(outPath, 12 /* DBTYPE_GENERIC_DB, collectoptimalset.cpp:244 */);
     e = w.open();
     if (!e.empty()) return die("%s", e);
     std::string buf;
     char line[512];
-    for (size_t c = 0; c < ord.size(); c++) {
-        buf.clear();
-        for (uint64_t k = coff[c]; k < coff[c + 1]; k++)
-            for (uint64_t x = preds[k].first_exon; x < preds[k].first_exon + preds[k].n_exons; x++) {
-                mk_exon ex = exons[x];
-                ex.orf += (uint32_t) orfBase;
-                buf.append(line, mk_format_prediction_exon(line, &preds[k], &ex));
-            }
-        w.write(contigs.entries[ord[c]].key, buf.data(), buf.size());
+    uint64_t nOrfs = 0, np = 0;
+    // the contigs go through the chain in batches bounded by their nucleotides (a metagenome assembly does not fit one library call);
+    // the target index stays resident, the fragment keys run on from batch to batch
+    for (size_t c0 = 0; c0 < ord.size() || (c0 == 0 && ord.empty()); ) {
+        const size_t c1 = contigBatchEnd(contigs, ord, c0);
+        loadBatch(c0, c1);
+        mk_orfs *O = nullptr;
+        mk_queries *Q = nullptr;
+        mk_predictions *R = nullptr;
+        if (mk_extract_orfs(nucl.empty() ? &none : nucl.data(), off.data(), (uint32_t) (c1 - c0), minLength, &O) != MK_OK) return die("%s", mk_last_error());
+        const mk_orf *orfs; const uint64_t *aaOff; const char *aa; uint64_t nb = 0;
+        mk_orfs_result(O, &orfs, &aaOff, &aa, &nb);
+        if (mk_queries_from_orfs(O, &P, &Q) != MK_OK) return die("%s", mk_last_error());
+        if (mk_search(T, Q, &P) != MK_OK) return die("%s", mk_last_error());
+        if (mk_predict_exons(T, O, Q, &X, tkeys.data(), &R) != MK_OK) return die("%s", mk_last_error());
+        const mk_prediction *preds; const uint64_t *coff; const mk_exon *exons; uint64_t npb = 0;
+        mk_predictions_result(R, &preds, &coff, &exons, &npb);
+        for (size_t c = c0; c < c1; c++) {
+            buf.clear();
+            for (uint64_t k = coff[c - c0]; k < coff[c - c0 + 1]; k++)
+                for (uint64_t x = preds[k].first_exon; x < preds[k].first_exon + preds[k].n_exons; x++) {
+                    mk_exon ex = exons[x];
+                    ex.orf += (uint32_t) (orfBase + nOrfs);
+                    buf.append(line, mk_format_prediction_exon(line, &preds[k], &ex));
+                }
+            w.write(contigs.entries[ord[c]].key, buf.data(), buf.size());
+        }
+        nOrfs += nb; np += npb;
+        mk_predictions_destroy(R);
+        mk_queries_destroy(Q);
+        mk_orfs_destroy(O);
+        if (c1 == c0) break;                                       // (no contigs at all)
+        c0 = c1;
     }
+    const double t2 = now();
     e = w.close();
     if (!e.empty()) return die("%s", e);
     fprintf(stderr, "predictexons: %zu contigs -> %llu fragments x %zu targets -> %llu predictions; %.2f s (target index %.2f s, fragments to exon sets %.2f s)\n",
             ord.size(), (unsigned long long) nOrfs, tkeys.size(), (unsigned long long) np, now() - t0, t1 - t0, t2 - t1);
-    mk_predictions_destroy(R);
-    mk_queries_destroy(Q);
-    mk_orfs_destroy(O);
     mk_targetdb_destroy(T);
     if (int rc = finishShards(a.pos[2], sh, 12)) return rc;
     if (sh.world > 1 && sh.rank == 0) for (int r = 0; r < sh.world; r++) remove((a.pos[2] + "_" + std::to_string(r) + ".orfs").c_str());

@@ -683,7 +683,7 @@ def test_cli_two_workers_share_the_queries(gpu_api, tmp_path):
     _write_seq_db(str(tmp_path / "q"), queries, [2 * i + 7 for i in range(len(queries))])
     _write_seq_db(str(tmp_path / "t"), targets)
     flags = ["-s", "5.7", "--ref-l2-bytes", "2097152", "--threads", "2", "--gpu", "0"]
-    aflags = ["-e", "100", "--min-aln-len", "11"]
+    aflags = ["-e", "100", "--min-aln-len", "11", "--alignment-mode", "2"]
     def run(cmd, out, world):
         procs = []
         for r in range(world):
@@ -727,3 +727,64 @@ def test_cli_predictexons_two_workers(gpu_api, tmp_path):
     got = _read_result_db(str(tmp_path / "calls"))
     assert "".join(">%d\n%s" % (c, got[c]) for c in range(len(contigs))) == _text("e2e_exons_expected.txt.gz")
     assert not os.path.exists(tmp_path / "calls_0") and not os.path.exists(tmp_path / "calls_1.orfs")
+
+
+def test_cli_shards_of_a_crashed_launch_are_not_merged(gpu_api, tmp_path):
+    """a shard file left behind by an earlier launch (another token, or none) must not reach the merged DB, and a worker that fails
+    makes worker 0 give up instead of waiting"""
+    import subprocess
+    import time
+    from metaeuk_amd import build, shard, synth
+    targets, queries = synth.make_workload(4, 200, seed=13)
+    _write_seq_db(str(tmp_path / "q"), list(queries))
+    _write_seq_db(str(tmp_path / "t"), list(targets))
+    flags = ["-s", "5.7", "--ref-l2-bytes", "2097152", "--threads", "2", "--gpu", "0"]
+    subprocess.check_call([build.BIN, "prefilter", str(tmp_path / "q"), str(tmp_path / "t"), str(tmp_path / "one")] + flags, stderr=subprocess.DEVNULL)
+    # leftovers of a "crashed" launch: a complete-looking shard 1 with foreign content and no token, and a stale fragment count
+    shard.write_result_db(str(tmp_path / "two_1"), [(0, "999\t1\t0\n")], 7)
+    (tmp_path / "two_1.orfs").write_text("12345\n")
+    procs = []
+    for r in (0, 1):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MK_SHARD_TIMEOUT_S="120")
+        procs.append(subprocess.Popen([build.BIN, "prefilter", str(tmp_path / "q"), str(tmp_path / "t"), str(tmp_path / "two")] + flags, env=env, stderr=subprocess.DEVNULL))
+        if r == 0:
+            time.sleep(3.0)                 # worker 0 finishes its half and meets the stale shard before worker 1 has started
+    assert all(p.wait() == 0 for p in procs)
+    assert shard.read_result_db(str(tmp_path / "two")) == shard.read_result_db(str(tmp_path / "one"))
+    # worker 1 dies (its target DB does not exist): worker 0 sees its .failed marker and exits non-zero, nothing named <out>.dbtype appears
+    t0 = time.time()
+    procs = []
+    for r in (0, 1):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MK_SHARD_TIMEOUT_S="120")
+        procs.append(subprocess.Popen([build.BIN, "prefilter", str(tmp_path / "q"), str(tmp_path / ("t" if r == 0 else "missing")), str(tmp_path / "three")] + flags,
+                                      env=env, stderr=subprocess.DEVNULL))
+    assert [p.wait() != 0 for p in procs] == [True, True]
+    assert time.time() - t0 < 60 and not os.path.exists(tmp_path / "three.dbtype")
+
+
+def test_cli_contig_batches(gpu_api, tmp_path):
+    """predictexons and extractorfs walk the contigs in batches bounded by nucleotides (MK_CLI_BATCH_NT forces tiny ones here): fragment
+    keys run on from batch to batch, the output equals the single-batch run; also as two workers"""
+    import subprocess
+    from metaeuk_amd import build
+    targets, contigs = _lines("e2e_targets.txt.gz"), _lines("e2e_contigs.txt.gz")
+    _write_seq_db(str(tmp_path / "targets"), targets)
+    _write_seq_db(str(tmp_path / "contigs"), contigs)
+    (tmp_path / "contigs.dbtype").write_bytes((1).to_bytes(4, "little"))
+    flags = ["-s", "5.7", "--ref-l2-bytes", "2097152", "--threads", "2", "--gpu", "0"]
+    env = dict(os.environ, MK_CLI_BATCH_NT="60000")                 # ~12 contigs of 5 kb per batch
+    subprocess.check_call([build.BIN, "predictexons", str(tmp_path / "contigs"), str(tmp_path / "targets"), str(tmp_path / "calls"), str(tmp_path / "tmp")] + flags,
+                          env=env, stderr=subprocess.DEVNULL)
+    got = _read_result_db(str(tmp_path / "calls"))
+    assert "".join(">%d\n%s" % (c, got[c]) for c in range(len(contigs))) == _text("e2e_exons_expected.txt.gz")
+    procs = []
+    for r in range(2):
+        e2 = dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0")
+        procs.append(subprocess.Popen([build.BIN, "predictexons", str(tmp_path / "contigs"), str(tmp_path / "targets"), str(tmp_path / "calls2"), str(tmp_path / "tmp")] + flags,
+                                      env=e2, stderr=subprocess.DEVNULL))
+    assert all(p.wait() == 0 for p in procs)
+    assert _read_result_db(str(tmp_path / "calls2")) == got
+    for name, e in (("orfs_one", dict(os.environ)), ("orfs_batched", env)):
+        subprocess.check_call([build.BIN, "extractorfs", str(tmp_path / "contigs"), str(tmp_path / name), "--translate", "1", "--min-length", "15"], env=e, stderr=subprocess.DEVNULL)
+    assert _read_result_db(str(tmp_path / "orfs_one")) == _read_result_db(str(tmp_path / "orfs_batched"))
+    assert _read_result_db(str(tmp_path / "orfs_one_h")) == _read_result_db(str(tmp_path / "orfs_batched_h"))
