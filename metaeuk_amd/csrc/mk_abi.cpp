@@ -41,6 +41,10 @@ int fail(int code, const char *fmt, ...) {
 }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(MK_ERR_DEVICE, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
+// Sequences of 32768 residues and more take the reference's wrapped-diagonal path in the prefilter (16-bit index positions and
+// diagonals, UngappedAlignment::computeLongScore); the alignment kernels number target columns in 17 bits.
+constexpr uint32_t MK_MAX_SEQ_LEN = 1u << 17;
+
 bool g_ready = false;
 int g_device = -1;
 hipStream_t g_stream = nullptr;
@@ -337,7 +341,7 @@ static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uin
     db->off.assign(offsets, offsets + n + 1);
     for (uint32_t i = 0; i < n; i++) {
         const uint64_t L = offsets[i + 1] - offsets[i];
-        if (L >= 32768) { delete db; return fail(MK_ERR_UNSUPPORTED, "target %u is >= 32768 residues: the reference's wrapped-diagonal path (UngappedAlignment.cpp:312-329) is not restated", i); }
+        if (L >= MK_MAX_SEQ_LEN) { delete db; return fail(MK_ERR_UNSUPPORTED, "target %u has %llu residues: at most %u are supported (17-bit column field of the alignment kernels)", i, (unsigned long long) L, MK_MAX_SEQ_LEN - 1); }
         db->maxLen = std::max<uint32_t>(db->maxLen, (uint32_t) L);
     }
     mk::build_submat(db->kmerMat, mk::MAT_VTML80, 8.0f, -0.2f);     // Prefiltering.cpp:68
@@ -418,7 +422,7 @@ int mk_index_write(const char *indexDb, const char *seqData, uint64_t seqDataSiz
     c.seqs.dbtype = seqDbtype;
     for (uint32_t i = 0; i < n; i++) {
         if (offsets[i] + lengths[i] > seqDataSize || lengths[i] < 2) return fail(MK_ERR_ARG, "entry %u lies outside the sequence data", i);
-        if (lengths[i] - 2 >= 32768) return fail(MK_ERR_UNSUPPORTED, "target %u is >= 32768 residues: the reference's wrapped-diagonal path (UngappedAlignment.cpp:312-329) is not restated", i);
+        if (lengths[i] - 2 >= MK_MAX_SEQ_LEN) return fail(MK_ERR_UNSUPPORTED, "target %u has %u residues: at most %u are supported", i, lengths[i] - 2, MK_MAX_SEQ_LEN - 1);
     }
     std::vector<uint8_t> res;
     encode_seq_db(c.seqs, res, c.seqOffsets);
@@ -529,7 +533,7 @@ static int queries_create(const uint8_t *residues, const uint8_t *devResidues, c
     q->res.assign(residues, residues + offsets[n]);
     for (uint32_t i = 0; i < n; i++) {
         const uint64_t L = offsets[i + 1] - offsets[i];
-        if (L >= 32768) { delete q; return fail(MK_ERR_UNSUPPORTED, "query %u is >= 32768 residues", i); }
+        if (L >= MK_MAX_SEQ_LEN) { delete q; return fail(MK_ERR_UNSUPPORTED, "query %u has %llu residues: at most %u are supported", i, (unsigned long long) L, MK_MAX_SEQ_LEN - 1); }
         q->maxLen = std::max<uint32_t>(q->maxLen, (uint32_t) L);
     }
     mk::SubMat kmerMat, alnMat;
@@ -923,15 +927,12 @@ int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     if (!q->havePref) return fail(MK_ERR_ARG, "mk_align: the batch has no prefilter result");
     HostTimer htAll("host_align_total");
     std::vector<mk::GateEntry> gate;
-    {
-        HostTimer ht("host_gate_table");
-        mk::build_gate_table(db->evaluer, P->evalue_thr, q->off, gate);
-    }
     mk::AssembleTables tables;
     {
-        HostTimer ht("host_evalue_table");
+        HostTimer ht("host_gate_table");
         tables.bitScore = db->bitScoreTable;
         mk::build_assemble_tables(db->evaluer, q->off, tables);
+        mk::build_gate_table(db->evaluer, P->evalue_thr, q->off, gate, &tables);
     }
     q->alnOff.assign((size_t) q->n + 1, 0);
     size_t nAln = 0;
@@ -972,9 +973,9 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
         omp_set_num_threads(half);
         {   // the per-length score tables of the batch, while the prefilter works on its first chunk
             HostTimer ht("host_gate_table");
-            mk::build_gate_table(db->evaluer, P->evalue_thr, q->off, gate);
             tables.bitScore = db->bitScoreTable;
             mk::build_assemble_tables(db->evaluer, q->off, tables);
+            mk::build_gate_table(db->evaluer, P->evalue_thr, q->off, gate, &tables);
         }
         for (;;) {
             std::pair<uint32_t, uint32_t> it;

@@ -302,7 +302,7 @@ void build_assemble_tables(const Evaluer &ev, const std::vector<uint64_t> &qOff,
 }
 
 // pass(score) table per query length present in the batch
-void build_gate_table(const Evaluer &ev, double evalThr, const std::vector<uint64_t> &qOff, std::vector<GateEntry> &table) {
+void build_gate_table(const Evaluer &ev, double evalThr, const std::vector<uint64_t> &qOff, std::vector<GateEntry> &table, const AssembleTables *T) {
     uint32_t maxLen = 0;
     const size_t n = qOff.size() - 1;
     for (size_t i = 0; i < n; i++) maxLen = std::max<uint32_t>(maxLen, (uint32_t) (qOff[i + 1] - qOff[i]));
@@ -316,14 +316,17 @@ void build_gate_table(const Evaluer &ev, double evalThr, const std::vector<uint6
         std::memset(&g, 0, sizeof(g));
         // e-values fall monotonically with the score beyond the finite-size regime; scan high -> low for the last failure
         const int SCAN = 4096;
+        // (the e-values of the scores below smax are in the assembly table when there is one: computed once)
+        const double *row = (T && L < T->lenIdx.size() && T->lenIdx[L] >= 0) ? T->evalue.data() + (size_t) T->lenIdx[L] * T->smax : nullptr;
+        const auto eval = [&](int s) { return (row && (uint32_t) s < T->smax) ? row[s] : ev.evalue((double) s, (double) L); };
         int lastFail = 0;
         for (int s = SCAN; s >= 1; s--) {
-            const bool pass = !(ev.evalue((double) s, (double) L) > evalThr);
+            const bool pass = !(eval(s) > evalThr);
             if (!pass) { lastFail = s; break; }
         }
         g.s0 = lastFail >= SCAN ? (1 << 30) : lastFail + 1;
         for (int s = 1; s < 256 && s < g.s0; s++)
-            if (!(ev.evalue((double) s, (double) L) > evalThr)) g.mask[s >> 5] |= 1u << (s & 31);
+            if (!(eval(s) > evalThr)) g.mask[s >> 5] |= 1u << (s & 31);
         table[L] = g;
     }
 }

@@ -25,7 +25,8 @@ struct AlnRaw { uint32_t pair; int32_t score, q_end, t_end, q_start, t_start; };
 // e-value gate as a per-query-length table: pass(score) = score >= s0 || bit(score) for score < 256
 // (ssw_align_private's `evalue > evalueThr` early return, StripedSmithWaterman.cpp:390-398)
 struct GateEntry { int32_t s0; uint32_t mask[8]; };
-void build_gate_table(const Evaluer &ev, double evalThr, const std::vector<uint64_t> &qOff, std::vector<GateEntry> &table);
+struct AssembleTables;
+void build_gate_table(const Evaluer &ev, double evalThr, const std::vector<uint64_t> &qOff, std::vector<GateEntry> &table, const AssembleTables *T = nullptr);
 
 // Matcher::getSWResult's float/double tail (Matcher.cpp:60-164), Alignment::checkCriteria and the per-query sort on the device.
 // The e-value is the one transcendental quantity: it comes from a table the host fills with the reference's double arithmetic

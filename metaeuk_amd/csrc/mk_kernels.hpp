@@ -60,6 +60,45 @@ hipError_t launch_sw(const SwLaunch &L, int cfg, hipStream_t stream);
 // score-only forward pass in packed int16, two targets per lane group (sw_cfg_packed configurations, shared-query mode only)
 hipError_t launch_sw_score(const SwLaunch &L, int cfg, hipStream_t stream);
 
+// Ungapped score of a (query, target, 16-bit diagonal) candidate: UngappedAlignment::scoreSingleSequence
+// (M/src/prefiltering/UngappedAlignment.cpp:438-447).  Both sequences below 32768 residues: the diagonal is the signed 16-bit value.
+// Otherwise the 16-bit diagonal is ambiguous and the reference takes the best of every real diagonal it can stand for
+// (computeLongScore, :312-329): -d * 65536 + diagonal for d = 1 .. 1 + tLen / 32768, and d * 65536 + diagonal for d = 0 .. qLen / 65536.
+// smat = 21 x 21 int8 scores [q * 21 + t]; corr = the query's int8 diagonal correction.  Same code on the device and on the host.
+template <typename MatT>
+__host__ __device__ inline int ungapped_on_diagonal(const MatT *smat, const uint8_t *q, const int8_t *corr, uint32_t qLen, const uint8_t *t, uint32_t tLen,
+                                                    int diagonal, uint32_t minDist) {      // computeSingelSequenceScores (:416-430)
+    uint32_t len = 0, q0 = 0, t0 = 0;
+    if (diagonal >= 0 && minDist < qLen) { len = tLen < qLen - minDist ? tLen : qLen - minDist; q0 = minDist; }
+    else if (diagonal < 0 && minDist < tLen) { len = tLen - minDist < qLen ? tLen - minDist : qLen; t0 = minDist; }
+    int score = 0, best = 0;
+    for (uint32_t k = 0; k < len; k++) {
+        const int curr = (int) (int8_t) ((int8_t) smat[q[q0 + k] * 21 + t[t0 + k]] + corr[q0 + k]);
+        score = score + curr > 0 ? score + curr : 0;
+        best = best > score ? best : score;
+    }
+    return best;
+}
+template <typename MatT>
+__host__ __device__ inline int ungapped_score(const MatT *smat, const uint8_t *q, const int8_t *corr, uint32_t qLen, const uint8_t *t, uint32_t tLen, uint32_t d16) {
+    if (qLen >= 32768u || tLen >= 32768u) {
+        int best = 0;
+        for (uint32_t d = 1; d <= 1u + tLen / 32768u; d++) {
+            const int real = (int) (0u - d * 65536u + d16);                   // unsigned wrap, then int: as the reference computes it
+            const int m = ungapped_on_diagonal(smat, q, corr, qLen, t, tLen, real, (uint32_t) (real < 0 ? -real : real));
+            best = best > m ? best : m;
+        }
+        for (uint32_t d = 0; d <= qLen / 65536u; d++) {
+            const int real = (int) (d * 65536u + d16);
+            const int m = ungapped_on_diagonal(smat, q, corr, qLen, t, tLen, real, (uint32_t) (real < 0 ? -real : real));
+            best = best > m ? best : m;
+        }
+        return best;
+    }
+    const uint32_t dist = ((0x10000u - d16) & 0xFFFFu) < d16 ? ((0x10000u - d16) & 0xFFFFu) : d16;      // distanceFromDiagonal (:364-369)
+    return ungapped_on_diagonal(smat, q, corr, qLen, t, tLen, (int) (short) (uint16_t) d16, dist);
+}
+
 struct UngappedJob { uint64_t t_start; uint32_t q_start; uint32_t q_len; uint32_t t_len; uint32_t diagonal; };
 struct UngappedLaunch {
     const uint8_t *q_res; const int8_t *q_corr;

@@ -773,27 +773,15 @@ __global__ __launch_bounds__(256) void diag_score_kernel(PrefilterDeviceView V, 
     const uint32_t d16 = (uint32_t) C.diag[c];
     const uint64_t qs = V.q_off[q], ts = V.t_off[id];
     const uint32_t qLen = (uint32_t) (V.q_off[q + 1] - qs), tLen = (uint32_t) (V.t_off[id + 1] - ts);
-    const int diag = (int) (short) (uint16_t) d16;
-    const uint32_t dist = min((0x10000u - d16) & 0xFFFFu, d16);
-    uint32_t len = 0, q0 = 0, t0 = 0;
-    if (diag >= 0 && dist < qLen) { len = min(tLen, qLen - dist); q0 = dist; }
-    else if (diag < 0 && dist < tLen) { len = min(tLen - dist, qLen); t0 = dist; }
-    const uint8_t *qr = V.q_res + qs + q0;
-    const int8_t *corr = V.q_corr + qs + q0;
-    const uint8_t *tr = V.t_masked + ts + t0;
-    int score = 0, best = 0;
-    for (uint32_t k = 0; k < len; k++) {
-        const int curr = (int) (int8_t) (smat[qr[k] * 21 + tr[k]] + corr[k]);
-        score = max(score + curr, 0);
-        best = max(best, score);
-    }
+    const int best = ungapped_score(smat, V.q_res + qs, V.q_corr + qs, qLen, V.t_masked + ts, tLen, d16);
     C.score[c] = best;
 }
 
 // keepMaxScoreElementOnly on the candidates (per (query,target) contiguous, in arrival order): a candidate survives
 // when its clamped score is the maximum of its run and no earlier candidate of the run has the same clamped score.
 // Survivors below --min-ungapped-score can never be reported (diagonalThr >= minDiagScoreThr) and are dropped here.
-__global__ __launch_bounds__(256) void keep_kernel(CandArrays C, uint32_t n, int minDiag, uint8_t *kept, uint32_t *perQuery) {
+__global__ __launch_bounds__(256) void keep_kernel(CandArrays C, uint32_t n, int minDiag, uint8_t *kept, uint32_t *perQuery,
+                                                   uint32_t *perQuery255 /* survivors at the clamp value 255 (>= 2^30: the query goes to the host) */) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     const uint32_t q = C.q[c], id = C.id[c];
@@ -809,19 +797,52 @@ __global__ __launch_bounds__(256) void keep_kernel(CandArrays C, uint32_t n, int
         if (min(C.score[u], 255) > s) keep = false;
     }
     kept[c] = keep ? 1 : 0;
-    if (keep) atomicAdd(&perQuery[q], 1u);
+    if (keep) {
+        atomicAdd(&perQuery[q], 1u);
+        if (s == 255) atomicAdd(&perQuery255[q], 1u);
+        if (C.ordinal[c] >= (1u << 26)) atomicOr(&perQuery255[q], 1u << 30);       // does not fit the selection key below
+    }
+}
+
+// Queries with at least --max-seqs surviving targets: the reference keeps the first max-seqs of them in the order (clamped score
+// descending, hash bin of the target = id & (BINSIZE - 1), arrival) -- QueryMatcher.cpp:149-209, radixSortByScoreSize :498-523 over the
+// bin-major element order of CacheFriendlyOperations.  That order as ONE 64-bit key per surviving candidate: query | 255 - clamped |
+// bin | arrival; after a radix sort a candidate is selected when fewer than max-seqs keys of its query precede it.  Only the case in
+// which max-seqs survivors sit AT the clamp value (the threshold saturates and is rescaled by the self score, :163-170) stays on the host.
+__global__ __launch_bounds__(256) void maxseqs_key_kernel(CandArrays C, uint32_t n, const uint8_t *kept, const uint32_t *perQuery, const uint32_t *perQuery255,
+                                                          uint32_t maxHits, uint32_t binMask, uint64_t *key, uint32_t *idx) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const uint32_t q = C.q[c];
+    uint64_t k = ~0ull;
+    if (kept[c] && perQuery[q] >= maxHits && perQuery255[q] < maxHits)
+        k = ((uint64_t) q << 44) | ((uint64_t) (255u - (uint32_t) min(C.score[c], 255)) << 36) | ((uint64_t) (C.id[c] & binMask) << 26) | (uint64_t) C.ordinal[c];
+    key[c] = k;
+    idx[c] = c;
+}
+__global__ __launch_bounds__(256) void maxseqs_rank_kernel(const uint64_t *sortedKey, const uint32_t *sortedIdx, uint32_t n, uint32_t maxHits, uint8_t *selected) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = sortedKey[i];
+    if (k == ~0ull) { selected[sortedIdx[i]] = 0; return; }
+    const uint64_t q = k >> 44;
+    uint32_t lo = 0, hi = i;                          // first key of this query
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((sortedKey[mid] >> 44) < q) lo = mid + 1; else hi = mid; }
+    selected[sortedIdx[i]] = (i - lo) < maxHits ? 1 : 0;
 }
 
 // sort key of a reportable hit: (query, score descending, target ascending); everything else sorts last
-__global__ __launch_bounds__(256) void outkey_kernel(CandArrays C, uint32_t n, const uint8_t *kept, const uint32_t *perQuery, uint32_t maxHits,
+__global__ __launch_bounds__(256) void outkey_kernel(CandArrays C, uint32_t n, const uint8_t *kept, const uint32_t *perQuery, const uint32_t *perQuery255,
+                                                     const uint8_t *selected, uint32_t maxHits,
                                                      uint32_t seqBits, uint64_t *outKey, uint32_t *outIdx, uint8_t *hostFlag) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     const uint32_t q = C.q[c];
-    const bool flagged = perQuery[q] >= maxHits;       // --max-seqs reached: the tie order needs the reference's bin logic
-    hostFlag[c] = flagged ? 1 : 0;
+    const bool cut = perQuery[q] >= maxHits;           // --max-seqs reached: the first max-seqs in the reference's order (selected[]) ...
+    const bool toHost = cut && perQuery255[q] >= maxHits;   // ... or, with a saturated threshold, the host's restatement
+    hostFlag[c] = toHost ? 1 : 0;
     uint64_t key = ~0ull;
-    if (kept[c] && !flagged) {
+    if (kept[c] && !toHost && (!cut || selected[c])) {
         // 20 bits query | (44 - seqBits) bits inverted score | seqBits bits target  (score field >= 17 bits)
         const uint32_t smax = (1u << min(44u - seqBits, 31u)) - 1u;
         const uint32_t sc = (uint32_t) min((uint32_t) C.score[c], smax);
@@ -859,13 +880,9 @@ __global__ void first_invalid_kernel(const uint64_t *sortedKeys, uint32_t n, uin
 // exact ungapped self score of a query on diagonal 0 (QueryMatcher::rescoreHits, QueryMatcher.cpp:525-531);
 // only needed when the score threshold saturates at 255
 int self_score(const SubMat &ung, const uint8_t *q, const int8_t *corr, int L) {
-    int s = 0, best = 0;
-    for (int k = 0; k < L; k++) {
-        const int curr = (int) (int8_t) ((int8_t) ung.sub[q[k]][q[k]] + corr[k]);
-        s = std::max(s + curr, 0);
-        best = std::max(best, s);
-    }
-    return best;
+    int8_t m[21 * 21];
+    for (int a = 0; a < 21; a++) for (int b = 0; b < 21; b++) m[a * 21 + b] = (int8_t) ung.sub[a][b];
+    return ungapped_score(m, q, corr, (uint32_t) L, q, (uint32_t) L, 0u);
 }
 
 // sizing state carried from one batch to the next (same database): index hits per similar k-mer, candidates per query
@@ -1329,7 +1346,9 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
         std::vector<uint32_t> hostQ;
         if (nCand > 0) {
             uint8_t *dKept = (uint8_t *) dev_scratch("pf_kept", nCand), *dHostFlag = (uint8_t *) dev_scratch("pf_hostflag", nCand);
-            uint32_t *dPerQ = (uint32_t *) dev_scratch("pf_perq", (size_t) nqc * 4);
+            uint32_t *dPerQ = (uint32_t *) dev_scratch("pf_perq", (size_t) nqc * 8), *dPerQ255 = dPerQ ? dPerQ + nqc : nullptr;
+            uint8_t *dSelected = (uint8_t *) dev_scratch("pf_selected", nCand);
+            PNULL(dSelected);
             uint64_t *dOutKey = (uint64_t *) dev_scratch("pf_okey", (size_t) nCand * 8), *dOutKey2 = (uint64_t *) dev_scratch("pf_okey2", (size_t) nCand * 8);
             uint32_t *dOutIdx = (uint32_t *) dev_scratch("pf_oidx", (size_t) nCand * 4), *dOutIdx2 = (uint32_t *) dev_scratch("pf_oidx2", (size_t) nCand * 4);
             uint32_t *dFlagSel = (uint32_t *) dev_scratch("pf_flagsel", (size_t) nCand * 4);
@@ -1340,17 +1359,30 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             hipLaunchKernelGGL(diag_score_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, V, q0, nCand, C);
             te(th);
             PCHK(hipGetLastError());
-            PCHK(hipMemsetAsync(dPerQ, 0, (size_t) nqc * 4, stream));
+            PCHK(hipMemsetAsync(dPerQ, 0, (size_t) nqc * 8, stream));
             th = tb("select_hits", 20.0 * nCand, 0);
-            hipLaunchKernelGGL(keep_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, C, nCand, P.min_ungapped_score, dKept, dPerQ);
-            hipLaunchKernelGGL(outkey_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, C, nCand, dKept, dPerQ, (uint32_t) maxHits, seqBits, dOutKey, dOutIdx, dHostFlag);
-            PCHK(hipGetLastError());
+            hipLaunchKernelGGL(keep_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, C, nCand, P.min_ungapped_score, dKept, dPerQ, dPerQ255);
             hipcub::DoubleBuffer<uint64_t> ob(dOutKey, dOutKey2);
             hipcub::DoubleBuffer<uint32_t> ib(dOutIdx, dOutIdx2);
             size_t t2 = 0;
             hipcub::DeviceRadixSort::SortPairs(nullptr, t2, ob, ib, (int) nCand, 0, 64, stream);
             void *temp = dev_scratch("pf_temp", t2);
             PNULL(temp);
+            {   // the --max-seqs cut of the queries that reach it (the buffers of the output sort serve both sorts)
+                static const bool hostCut = getenv("MK_PREFILTER_HOST_MAXSEQS") && atoi(getenv("MK_PREFILTER_HOST_MAXSEQS")) != 0;
+                // (min-ungapped-score 0 keeps zero-score elements under rules of their own: left to the host's restatement)
+                const uint32_t deviceCut = (hostCut || P.min_ungapped_score <= 0) ? 0xFFFFFFFFu : (uint32_t) maxHits;
+                if (deviceCut != 0xFFFFFFFFu) {
+                    hipLaunchKernelGGL(maxseqs_key_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, C, nCand, dKept, dPerQ, dPerQ255, (uint32_t) maxHits, (uint32_t) (binCount - 1), dOutKey, dOutIdx);
+                    PCHK(hipcub::DeviceRadixSort::SortPairs(temp, t2, ob, ib, (int) nCand, 0, 64, stream));
+                    hipLaunchKernelGGL(maxseqs_rank_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, ob.Current(), ib.Current(), nCand, (uint32_t) maxHits, dSelected);
+                } else {
+                    PCHK(hipMemsetAsync(dSelected, 0, nCand, stream));
+                    PCHK(hipMemsetAsync(dPerQ255, 0x7F, (size_t) nqc * 4, stream));      // every query at the cut goes to the host
+                }
+            }
+            hipLaunchKernelGGL(outkey_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, C, nCand, dKept, dPerQ, dPerQ255, dSelected, (uint32_t) maxHits, seqBits, ob.Current(), ib.Current(), dHostFlag);
+            PCHK(hipGetLastError());
             PCHK(hipcub::DeviceRadixSort::SortPairs(temp, t2, ob, ib, (int) nCand, 0, 64, stream));
             hipLaunchKernelGGL(first_invalid_kernel, dim3(1), dim3(1), 0, stream, ob.Current(), nCand, dNum + 1);
             // candidates of flagged queries, per query contiguous and in (target, arrival) order, for the host
@@ -1362,9 +1394,12 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             PCHK(hipcub::DeviceSelect::Flagged(temp2, t3, iota, dHostFlag, dFlagSel, dNum + 2, (int) nCand, stream));
             te(th);
             PCHK(hipMemcpyAsync(hNum, dNum, 12, hipMemcpyDeviceToHost, stream));
-            uint32_t *hPerQ = (uint32_t *) pinned_scratch("pf_perq_h", (size_t) nqc * 4);
+            uint32_t *hPerQ = (uint32_t *) pinned_scratch("pf_perq_h", (size_t) nqc * 8);
             PNULL(hPerQ);
-            PCHK(hipMemcpyAsync(hPerQ, dPerQ, (size_t) nqc * 4, hipMemcpyDeviceToHost, stream));
+            PCHK(hipMemcpyAsync(hPerQ, dPerQ, (size_t) nqc * 8, hipMemcpyDeviceToHost, stream));
+            const uint32_t *hPerQ255 = hPerQ + nqc;
+            // hits of a query in the device-final array: all survivors, or exactly max-seqs of them; 0 when the host selects
+            const auto dev_count = [&](uint32_t ql) -> uint32_t { return hPerQ[ql] < (uint32_t) maxHits ? hPerQ[ql] : (hPerQ255[ql] >= (uint32_t) maxHits ? 0u : (uint32_t) maxHits); };
             PCHK(sync_wait(stream, "wait_prefilter"));
             const uint32_t nValid = hNum[1], nFlagged = hNum[2];
             mk_hit *dHitsOut = nullptr;
@@ -1380,7 +1415,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                     if (!reserve_out(nValid, q1)) { err = "pinned host allocation for the prefilter result failed"; return MK_ERR_DEVICE; }
                     PCHK(hipMemcpyAsync((mk_hit *) outBlk.p + nOut, dHitsOut, (size_t) nValid * sizeof(mk_hit), hipMemcpyDeviceToHost, stream));
                 }
-                for (uint32_t ql = 0; ql < nqc; ql++) chunkCnt[ql] = hPerQ[ql];
+                for (uint32_t ql = 0; ql < nqc; ql++) chunkCnt[ql] = dev_count(ql);
                 devDirect = true;
                 nDevHits = nValid;
             } else {
@@ -1390,7 +1425,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                     PCHK(hipMemcpyAsync(hHitsOut, dHitsOut, (size_t) nValid * sizeof(mk_hit), hipMemcpyDeviceToHost, stream));
                     devHits = hHitsOut; nDevHits = nValid;
                 }
-                for (uint32_t ql = 0; ql < nqc; ql++) chunkCnt[ql] = hPerQ[ql] >= (uint32_t) maxHits ? 0 : hPerQ[ql];
+                for (uint32_t ql = 0; ql < nqc; ql++) chunkCnt[ql] = dev_count(ql);
                 // exact reference logic for the queries that reached --max-seqs (tie order depends on BINSIZE)
                 HostCand *dHC = (HostCand *) dev_scratch("pf_hostcand", (size_t) nFlagged * sizeof(HostCand));
                 HostCand *hHC = (HostCand *) pinned_scratch("pf_hostcand_h", (size_t) nFlagged * sizeof(HostCand));

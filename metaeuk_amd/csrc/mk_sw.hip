@@ -452,21 +452,7 @@ __global__ __launch_bounds__(256) void ungapped_kernel(UngappedLaunch L) {
     const uint64_t id = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= L.n_jobs) return;
     const UngappedJob j = L.jobs[id];
-    const int diag = (int) (short) (uint16_t) j.diagonal;
-    const uint32_t d16 = j.diagonal & 0xFFFFu;
-    const uint32_t dist = min((0x10000u - d16) & 0xFFFFu, d16);   // UngappedAlignment::distanceFromDiagonal
-    uint32_t n = 0, q0 = 0, t0 = 0;
-    if (diag >= 0 && dist < j.q_len) { n = min(j.t_len, j.q_len - dist); q0 = dist; }
-    else if (diag < 0 && dist < j.t_len) { n = min(j.t_len - dist, j.q_len); t0 = dist; }
-    const uint8_t *q = L.q_res + j.q_start + q0;
-    const int8_t *corr = L.q_corr + j.q_start + q0;
-    const uint8_t *t = L.t_masked + j.t_start + t0;
-    int score = 0, best = 0;
-    for (uint32_t k = 0; k < n; k++) {
-        const int curr = (int) (int8_t) (smat[q[k] * 21 + t[k]] + corr[k]);
-        score = max(score + curr, 0);
-        best = max(best, score);
-    }
+    const int best = ungapped_score(smat, L.q_res + j.q_start, L.q_corr + j.q_start, j.q_len, L.t_masked + j.t_start, j.t_len, j.diagonal & 0xFFFFu);
     L.out[id] = best;
 }
 

@@ -197,3 +197,24 @@ def saturated_threshold_workload(seed=5):
     rng.shuffle(targets)
     queries += [rs(60), mut(queries[0], 0.3)]
     return targets, queries
+
+
+def long_sequence_workload(seed=9):
+    """Sequences of 32768 residues and more: 16-bit index positions and diagonals wrap, the prefilter scores every real diagonal
+    a wrapped one can stand for (UngappedAlignment::computeLongScore, UngappedAlignment.cpp:312-329)."""
+    import random
+    rng = random.Random(seed)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    rs = lambda n: "".join(rng.choice(aa) for _ in range(n))
+    mut = lambda s, r: "".join(ch if rng.random() > r else rng.choice(aa) for ch in s)
+    qa, qb, qc = rs(120), rs(200), rs(90)
+    fam = [rs(rng.randrange(150, 400)) for _ in range(6)]
+    targets = [rs(rng.randrange(100, 500)) for _ in range(120)]
+    targets += [mut(f, 0.1) for f in fam for _ in range(3)]
+    targets.append(rs(34000) + mut(qa, 0.08) + rs(5500))              # a homolog of qa behind position 32768 (titin-sized target)
+    targets.append(rs(300) + mut(qb, 0.1) + rs(33000) + mut(qc, 0.05) + rs(40))
+    targets.append(mut(qa, 0.15) + rs(66000) + mut(qa, 0.05))          # ... and beyond 65536: the index position itself wraps
+    rng.shuffle(targets)
+    long_q = rs(20000) + mut(fam[0], 0.1) + rs(13000) + mut(fam[1], 0.12) + rs(1500)      # 35 k-residue query, homologs on both sides of 32768
+    queries = [qa, qb, qc, long_q, rs(80), mut(fam[2], 0.2)[:140]]
+    return targets, queries

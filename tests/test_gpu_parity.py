@@ -242,6 +242,23 @@ def test_saturated_score_threshold(gpu_api, tmp_path, pf_path, max_seqs):
         assert max(sum(1 for h in hits[int(hoff[i]):int(hoff[i + 1])] if int(h["pref_score"]) >= 255) for i in range(3)) >= 100
 
 
+def test_long_sequences(gpu_api, tmp_path, pf_path):
+    """targets of 40 k / 66 k residues and a 35 k-residue query: wrapped 16-bit index positions and diagonals, every real diagonal
+    scored (UngappedAlignment::computeLongScore), multi-tile alignment of the long query; hit lists and alignments vs the oracle"""
+    api = gpu_api
+    targets, queries = oracle.long_sequence_workload()
+    params = api.default_params()
+    db = api.TargetDB(targets, params)
+    q = api.Queries(queries, params)
+    (hits, hoff), (alns, aoff) = api.search(db, q)
+    opref, oaln = oracle.run_pipeline(targets, queries, str(tmp_path), extra=["--l2", str(params.host_l2_bytes)])
+    for i in range(len(queries)):
+        assert api.format_hits(hits, int(hoff[i]), int(hoff[i + 1])) == opref[i], i
+        assert api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1])) == oaln[i], i
+    long_ids = {i for i, t in enumerate(targets) if len(t) >= 32768}
+    assert any(int(h["seq_id"]) in long_ids for h in hits) and int(hoff[4]) - int(hoff[3]) >= 2
+
+
 def test_sw_golden_top_of_int16_range(gpu_api):
     """identical / near-identical pairs of 2000 .. 6500 residues: scores up to the saturation value 32767 of the reference's word
     pass, multi-tile queries; coordinates printed by the reference vs the kernel's, raw score vs the oracle's"""

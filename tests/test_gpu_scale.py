@@ -57,7 +57,7 @@ def test_headline_scale_parity(gpu_api, tmp_path):
     counts = np.diff(np.asarray(hoff))
     max_hits = min(params.max_seqs, len(targets))
     assert int((counts == max_hits).sum()) >= 1, "no query reached the --max-seqs cut"
-    assert stats.get("host_prefilter_maxseqs", {"ms": 0})["ms"] > 0 or stats.get("select_maxseqs", {"launches": 0})["launches"] > 0
+    assert int((counts > max_hits).sum()) == 0
     # similar k-mers by front end: per-query kernels by region size (2 K / 4 K one wave per query, 8 K / 64 K several waves), global path
     k_small = sum(v["cells"] for k, v in stats.items() if k in ("prefilter_query_cap2048", "prefilter_query_cap4096", "prefilter_query_cap8192"))
     k_big = stats.get("prefilter_query_cap65536", {"cells": 0})["cells"]

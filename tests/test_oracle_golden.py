@@ -105,6 +105,20 @@ def test_oracle_matches_live_reference_when_the_score_threshold_saturates(tmp_pa
     assert max(n255) >= max_seqs or max_seqs == 300, n255        # (130 copies per query: the 100-hit cut saturates, the 300-hit cut does not)
 
 
+@pytest.mark.skipif(not os.path.exists(oracle.REF) or not os.path.isdir("/root/reference"), reason="reference harness not built here")
+def test_oracle_matches_live_reference_on_long_sequences(tmp_path):
+    """targets of 40 k and 66 k residues, a 35 k-residue query: wrapped 16-bit positions / diagonals, computeLongScore"""
+    import ctypes
+    targets, queries = oracle.long_sequence_workload()
+    l2 = ctypes.CDLL(None).sysconf(191)
+    opref, oaln = oracle.run_pipeline(targets, queries, str(tmp_path), extra=["--l2", str(l2 if l2 > 0 else 262144)])
+    rpref, raln = oracle.run_ref_pipeline(targets, queries, str(tmp_path), extra=["--threads", "4"])
+    assert opref == rpref and oaln == raln
+    long_ids = {i for i, t in enumerate(targets) if len(t) >= 32768}
+    assert any(int(l.split("\t")[0]) in long_ids for b in rpref for l in b.splitlines()), "a long target should be hit"
+    assert len(rpref[3].splitlines()) >= 2, "the long query should have hits"
+
+
 def test_matrix_tables_reproduce_reference_matrices(tmp_path):
     """the .out text regenerated from the repository's matrix table parses back to identical numbers"""
     d = oracle.write_matrix_files(str(tmp_path / "mat"))
