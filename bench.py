@@ -267,8 +267,10 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                      "avg_launch_ms": per_launch_ms, "launches": dom["launches"],
-                     "note": "neither hot kernel family streams HBM: the fused prefilter kernels wait on dependent random index "
-                             "probes (latency), the Smith-Waterman kernels are int32 vector-ALU bound (see valu_roofline)"},
+                     "note": "achieved = SURVEY 8(d) algorithmic bytes (16 B per probed k-mer + 6 B per index entry) / launch time; traffic = "
+                             "fabric bytes per launch from the L2 request counters (PMC): every 8-byte index probe that misses L2 fetches a "
+                             "128-byte line, so the prefilter kernels move ~5x their algorithmic bytes and are bound by HBM line bandwidth "
+                             "(~5 TB/s when they run alone); the Smith-Waterman kernels are vector-ALU bound (valu_roofline)"},
         # the Smith-Waterman kernels against the integer vector-ALU issue rate: the cell arithmetic alone (5 lane-ops per cell in the packed
         # score pass, 10 in the int32 passes), not counting the wavefront's hand-over instructions, padding rows or fill / drain steps
         "valu_roofline": {"kernels": "sw_fwd_* + sw_pos_* + sw_rev_*", "achieved": (sw_lane_ops / max(sw_ms * 1e-3, 1e-12) / 1e12) if sw_ms else None,

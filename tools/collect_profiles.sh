@@ -1,45 +1,36 @@
 #!/bin/bash
-# Round-end evidence on a GPU box: rocprofv3 kernel statistics of the default bench run, and the HBM traffic counters in their
-# own passes (the pool refuses --pmc together with the API trace domains).  Writes summaries under gpurun_out/ ; copy the ones to
-# be judged into profiles/.
-#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/collect_profiles.sh'
+# Round evidence on a GPU box: the default bench line, rocprofv3 kernel statistics of the same command, the HBM traffic artefact
+# (tools/pmc_traffic.sh), SQ counters, the two-stage timeline and the host-thread sensitivity.  Writes under gpurun_out/evidence/ ; copy
+# the files to be judged into profiles/.
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r02'
 set -u
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out
+OUT=$R/gpurun_out/evidence
 mkdir -p $OUT
+cd $R
+python bench.py --steps 2 --warmup 1 > $OUT/${TAG}_bench_n1.json 2> $OUT/bench.err
+for th in 16 2; do MK_HOST_THREADS=$th python bench.py --steps 2 --warmup 1 --cpu-sample 0 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.read());print('MK_HOST_THREADS=$th  ms_per_step %.1f  fragments/s %.0f  host phases (ms/step): %s' % (d['ms_per_step'], d['value'], {k: round(v / d['steps'], 1) for k, v in d['kernels_ms'].items() if k.startswith('host_')}))"; done > $OUT/${TAG}_bench_host_threads.txt
+python bench.py --steps 2 --warmup 1 --cpu-sample 0 --two-calls > $OUT/${TAG}_bench_two_calls.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0"
-rm -rf $OUT/prof_stats $OUT/pmc_fetch $OUT/pmc_write
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- $BENCH > $OUT/prof_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1
+rm -rf $OUT/prof_stats
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 > $OUT/prof_stats.log 2>&1
 python - <<PY
-import csv, glob, collections
+import csv, glob
 out = "$OUT"
 f = sorted(glob.glob(out + "/prof_stats/**/*kernel_stats.csv", recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
-with open(out + "/kernel_stats_summary.txt", "w") as w:
-    w.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-sample 0\n")
-    w.write("%-88s %8s %12s %10s %7s\n" % ("kernel", "calls", "total_ms", "avg_ms", "pct"))
-    for r in rows[:48]:
-        w.write("%-88s %8d %12.2f %10.3f %7.2f\n" % (r["Name"].replace("(anonymous namespace)::", "")[:88], int(r["Calls"]), float(r["TotalDurationNs"]) / 1e6,
+with open(out + "/${TAG}_bench_kernel_stats.txt", "w") as w:
+    w.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-sample 0   (3 passes: warm-up + 2 steps, 16 chunks each)\n")
+    w.write("%-96s %8s %12s %10s %7s\n" % ("kernel", "calls", "total_ms", "avg_ms", "pct"))
+    for r in rows[:56]:
+        w.write("%-96s %8d %12.2f %10.3f %7.2f\n" % (r["Name"].replace("(anonymous namespace)::", "")[:96], int(r["Calls"]), float(r["TotalDurationNs"]) / 1e6,
                                                    float(r["AverageNs"]) / 1e6, float(r["Percentage"])))
-agg = collections.defaultdict(lambda: {"n": 0, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
-for d, c in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    f = sorted(glob.glob(out + "/" + d + "/**/*counter_collection.csv", recursive=True))[-1]
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] != c: continue
-        k = r["Kernel_Name"].replace("(anonymous namespace)::", "")[:70]
-        agg[k][c] += float(r["Counter_Value"])
-        if c == "FETCH_SIZE": agg[k]["n"] += 1
-with open(out + "/pmc_hbm_traffic_summary.txt", "w") as w:
-    w.write("# rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) --kernel-trace -- python bench.py --steps 2 --warmup 1 --cpu-sample 0\n")
-    w.write("# KB as reported (summed over the counter's instances per dispatch), per dispatch; raw, uncorrected\n")
-    w.write("%-72s %10s %18s %18s\n" % ("kernel", "dispatches", "FETCH_KB/dispatch", "WRITE_KB/dispatch"))
-    for k, v in sorted(agg.items(), key=lambda x: -(x[1]["FETCH_SIZE"] + x[1]["WRITE_SIZE"]))[:28]:
-        n = max(v["n"], 1)
-        w.write("%-72s %10d %18d %18d\n" % (k, v["n"], v["FETCH_SIZE"] / n, v["WRITE_SIZE"] / n))
 PY
-head -20 $OUT/kernel_stats_summary.txt
-head -14 $OUT/pmc_hbm_traffic_summary.txt
-grep -h '"metric"' $OUT/prof_stats.log | cut -c1-300
+cd $R
+bash tools/pmc_traffic.sh $TAG > $OUT/pmc_traffic.log 2>&1; cp gpurun_out/pmc/${TAG}_pmc_hbm_traffic.json $OUT/ 2>/dev/null
+bash tools/sq_profile.sh > /dev/null 2>&1; cp gpurun_out/sq/sq_summary.txt $OUT/${TAG}_sq_counters.txt 2>/dev/null
+bash tools/overlap_trace.sh 2>&1 | tail -22 > $OUT/${TAG}_stage_timeline.txt
+bash tools/mem_profile.sh > /dev/null 2>&1; cp gpurun_out/mem/mem_summary.txt $OUT/${TAG}_mem_counters.txt 2>/dev/null
+rm -rf $OUT/prof_stats gpurun_out/pmc/rd gpurun_out/pmc/wr gpurun_out/sq/pmc gpurun_out/trace/kt gpurun_out/mem/p1 gpurun_out/mem/p2 gpurun_out/mem/p3
+head -12 $OUT/${TAG}_bench_kernel_stats.txt; cat $OUT/${TAG}_bench_host_threads.txt; tail -14 $OUT/pmc_traffic.log; python -c "import json;d=json.load(open('$OUT/${TAG}_bench_n1.json'));print(d['ms_per_step'], d['value'], d['roofline'], d['valu_roofline'], d['cpu_baseline'], d['result_digest'])"
