@@ -82,11 +82,16 @@ constexpr int ABLOCK = AJ * WAVE;        // ... per step (one step covers almost
 template <int U>
 struct EnumLds {
     uint32_t start[ABLOCK];      // exclusive prefix of nb over the first-half candidates of the current step
-    uint16_t idx0[ABLOCK];       // their 3-mer indices
+    uint32_t idx0[ABLOCK];       // their share of the k-mer's table cell (cell_first of the 3-mer's address code)
     uint32_t cnt[U * WAVE];      // histogram of the inclusive prefixes over the current product window
-    uint16_t sec[WAVE];          // the 64 best second halves (table addresses): fetched with the row heads, one dependent load less for
-                                 // nearly every product (a first half rarely pairs with more than a few second halves)
+    uint32_t sec[WAVE];          // the 64 best second halves (cell_second of their address codes): fetched with the row heads, one dependent
+                                 // load less for nearly every product (a first half rarely pairs with more than a few second halves)
 };
+
+// Table cell of a k-mer = cell_first(address code of its first 3-mer) + cell_second(code of its second 3-mer); a code is tile << 6 | w
+// (mk_host.cpp: the tiled address order -- k-mers that differ by substitutions inside the residue quads share 128-byte lines)
+__device__ __forceinline__ uint32_t cell_first(uint32_t code) { return (code >> 6) * 4096u + (code & 63u); }
+__device__ __forceinline__ uint32_t cell_second(uint32_t code) { return (code >> 6) * 512000u + (code & 63u) * 64u; }
 
 // Calls onBatch(kmer[U], has[U]) for consecutive windows of U*64 products of the k-mer start whose residues are r[0..9]
 // (spaced seed 1101010011), in product order; onBatch returns false to stop early.  Returns the number of similar k-mers.
@@ -100,7 +105,7 @@ __device__ __forceinline__ uint32_t enumerate_position(const PrefilterDeviceView
     const int R = V.hist_range, lo = V.hist_lo;
     const uint16_t *cum1 = V.cum3 + (size_t) idx1 * R;
     const int cutoff1 = thr - (int) V.score3[(size_t) idx1 * N3];   // first halves below this cannot reach the threshold
-    S.sec[lane] = i1[lane];
+    S.sec[lane] = cell_second(i1[lane]);
     uint32_t kmers = 0;
     for (uint32_t a0 = 0; a0 < (uint32_t) N3; a0 += ABLOCK) {
         // candidate a = a0 + j*64 + lane: (j, lane) ascending = a ascending
@@ -127,7 +132,7 @@ __device__ __forceinline__ uint32_t enumerate_position(const PrefilterDeviceView
             incl[j] = total + sc;
             total += wave_last(sc);
             S.start[j * WAVE + lane] = incl[j] - nb[j];
-            S.idx0[j * WAVE + lane] = (uint16_t) ia[j];
+            S.idx0[j * WAVE + lane] = cell_first(ia[j]);
         }
         const bool more = __builtin_amdgcn_readlane(sa[AJ - 1], WAVE - 1) >= cutoff1;   // the step's last candidate is still valid
         kmers += total;
@@ -156,9 +161,7 @@ __device__ __forceinline__ uint32_t enumerate_position(const PrefilterDeviceView
                 kmer[u] = 0;
                 if (has[u]) {
                     const uint32_t b = x - S.start[owner];
-                    // table address: the first half picks the 8000-cell window, the second half the cell -- the lanes of a batch mostly share
-                    // their first half (product order: second half fastest), so their probes fall into a few cache lines of one window
-                    kmer[u] = (uint32_t) N3 * (uint32_t) S.idx0[owner] + (uint32_t) (b < (uint32_t) WAVE ? S.sec[b] : i1[b]);
+                    kmer[u] = S.idx0[owner] + (b < (uint32_t) WAVE ? S.sec[b] : cell_second(i1[b]));
                 }
             }
             if (!onBatch(kmer, has)) return kmers;

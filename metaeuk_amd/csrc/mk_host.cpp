@@ -95,16 +95,24 @@ int bin_count_for(uint64_t dbSize, uint64_t l2) {
     return 2048;
 }
 
-// Where a k-mer lives in the device tables (presence bitmap, list slots, entry lists).  The reference's Indexer numbers a k-mer
-// sum(aa_i * 20^i); here the letters are first renumbered so that amino acids that substitute for each other are neighbours
-// (C | V I L M | F Y W | H | R K | Q E D N | S T A G P).  The similar k-mers of a query k-mer differ from it by exactly such
-// substitutions, so their table cells share 64-byte sectors instead of being spread over the table; and the FIRST 3-mer of a k-mer
-// sits in the high digits of its address, because the lanes of a probe batch mostly share it (mk_enum.hpp).  Only addresses change: rows
-// of the 3-mer score table are still looked up and ordered by the reference's numbering, so the enumeration order (and with it
-// the order in which hits arrive) is the reference's.
+// Table addresses of the k-mers (bitmap, slots, lists) -- addresses only: rows of the 3-mer score table are still looked up and
+// ordered by the reference's numbering, so the enumeration order (and with it the order in which hits arrive) is the reference's.
+// The similar k-mers of a query k-mer differ from it by substitutions of similar residues at several of the six positions, and every
+// 8-byte probe that misses L2 costs a 128-byte line from HBM (1024 bitmap cells, 16 slots): the address order is TILED so that such a
+// cloud falls into few lines.  The 20 letters form five quads of similar residues (VILM | FYWH | RKQE | DNST | AGPC); a letter is
+// (quad, position in the quad).  A 3-mer's address code is tile << 6 | w with tile = the three quads (base 5) and w = the three in-quad
+// positions (base 4): a bijection onto 0..7999.  A k-mer's cell is 4096 * (tile(first 3-mer) + 125 * tile(second)) + w(first) + 64 * w(second):
+// all 4^6 k-mers that agree in their six quads share one 4096-cell tile (four 128-byte lines of the bitmap).
 static const uint8_t KMER_ADDR_LETTER[20] = {
-    /* A */ 17, /* C */ 0, /* D */ 13, /* E */ 12, /* F */ 5, /* G */ 18, /* H */ 8, /* I */ 2, /* K */ 10, /* L */ 3,
-    /* M */ 4, /* N */ 14, /* P */ 19, /* Q */ 11, /* R */ 9, /* S */ 15, /* T */ 16, /* V */ 1, /* W */ 7, /* Y */ 6};
+    /* A */ 16, /* C */ 19, /* D */ 12, /* E */ 11, /* F */ 4, /* G */ 17, /* H */ 7, /* I */ 1, /* K */ 9, /* L */ 2,
+    /* M */ 3, /* N */ 13, /* P */ 18, /* Q */ 10, /* R */ 8, /* S */ 14, /* T */ 15, /* V */ 0, /* W */ 6, /* Y */ 5};
+static inline uint16_t addr3_of_letters(int l0, int l1, int l2) {
+    const int d0 = KMER_ADDR_LETTER[l0], d1 = KMER_ADDR_LETTER[l1], d2 = KMER_ADDR_LETTER[l2];
+    return static_cast<uint16_t>((((d0 >> 2) + 5 * (d1 >> 2) + 25 * (d2 >> 2)) << 6) | ((d0 & 3) + 4 * (d1 & 3) + 16 * (d2 & 3)));
+}
+uint32_t kmer_cell(uint32_t addrFirst, uint32_t addrSecond) {
+    return 4096u * ((addrFirst >> 6) + 125u * (addrSecond >> 6)) + (addrFirst & 63u) + 64u * (addrSecond & 63u);
+}
 
 // ExtendedSubstitutionMatrix::calcScoreMatrix (M/src/prefiltering/ExtendedSubstitutionMatrix.cpp:20-69),
 // kmerSize 3 over the 20-letter alphabet (Prefiltering.cpp:208-213).  std::stable_sort by descending
@@ -120,7 +128,7 @@ void build_scoremat3(const SubMat &km, ScoreMat3 &out) {
         const int a0 = e / 400, a1 = (e / 20) % 20, a2 = e % 20;
         letter[e * 3] = a0; letter[e * 3 + 1] = a1; letter[e * 3 + 2] = a2;
         enumIdx[e] = static_cast<uint16_t>(a0 + 20 * a1 + 400 * a2);
-        addrIdx[e] = static_cast<uint16_t>(KMER_ADDR_LETTER[a0] + 20 * KMER_ADDR_LETTER[a1] + 400 * KMER_ADDR_LETTER[a2]);
+        addrIdx[e] = addr3_of_letters(a0, a1, a2);            // (a0 = the letter of the reference's fastest digit, see enumIdx)
     }
 #pragma omp parallel
     {
@@ -253,7 +261,7 @@ int tantan_mask(const SubMat &km, uint8_t *seq, int L, double minMaskProb, int l
 // addSequence / sortDBSeqLists (M/src/prefiltering/IndexTable.h:133-173,348-401,182-189), AA targets, k=6.
 void kmer3_address_table(uint16_t addrOf[8000]) {
     for (int k = 0; k < 8000; k++)
-        addrOf[k] = static_cast<uint16_t>(KMER_ADDR_LETTER[k % 20] + 20 * KMER_ADDR_LETTER[(k / 20) % 20] + 400 * KMER_ADDR_LETTER[k / 400]);
+        addrOf[k] = addr3_of_letters(k % 20, (k / 20) % 20, k / 400);
 }
 
 // k-mer lists in the reference's numbering -> in table-address order (what the device tables use)
@@ -265,7 +273,7 @@ void index_to_address_order(TargetIndex &ix) {
 #pragma omp parallel for schedule(static)
     for (uint64_t hi = 0; hi < 8000; hi++)
         for (uint64_t lo = 0; lo < 8000; lo++) {
-            const uint64_t k = lo + 8000 * hi, a = static_cast<uint64_t>(addr3[hi]) + 8000ull * addr3[lo];
+            const uint64_t k = lo + 8000 * hi, a = kmer_cell(addr3[lo], addr3[hi]);
             offsets[a + 1] = ix.offsets[k + 1] - ix.offsets[k];
         }
     for (uint64_t a = 0; a < TABLE; a++) offsets[a + 1] += offsets[a];
@@ -273,7 +281,7 @@ void index_to_address_order(TargetIndex &ix) {
 #pragma omp parallel for schedule(static)
     for (uint64_t hi = 0; hi < 8000; hi++)
         for (uint64_t lo = 0; lo < 8000; lo++) {
-            const uint64_t k = lo + 8000 * hi, a = static_cast<uint64_t>(addr3[hi]) + 8000ull * addr3[lo];
+            const uint64_t k = lo + 8000 * hi, a = kmer_cell(addr3[lo], addr3[hi]);
             std::copy(ix.entries.begin() + ix.offsets[k], ix.entries.begin() + ix.offsets[k + 1], entries.begin() + offsets[a]);
         }
     ix.offsets.swap(offsets);
@@ -309,15 +317,17 @@ void build_index(const SubMat &km, const uint8_t *residues, const uint64_t *seqO
                 uint32_t idx = 0, pw = 1;
                 int score = 0;
                 bool hasX = false;
+                uint8_t let[KMER];
                 for (int p = 0; p < KMER; p++) {
                     const uint8_t c = seq[i + SPACED6[p]];
                     hasX |= (c == XCODE);
                     score += self[c];
-                    // Indexer::int2index, or the table address: renumbered letters, and the FIRST 3-mer in the high digits (mk_enum.hpp)
-                    idx += (c < 20 ? (addressOrder ? KMER_ADDR_LETTER[c] * (p < 3 ? 8000u : 1u) * (p < 3 ? pw : pw / 8000u) : c * pw) : 0);
+                    let[p] = c < 20 ? c : 0;
+                    idx += (c < 20 ? c * pw : 0);                  // Indexer::int2index
                     pw *= 20;
                 }
                 if (hasX || (kmerThr > 0 && score < kmerThr)) continue;
+                if (addressOrder) idx = kmer_cell(addr3_of_letters(let[0], let[1], let[2]), addr3_of_letters(let[3], let[4], let[5]));   // the table address
                 buf.push_back((static_cast<uint64_t>(idx) << 16) | static_cast<uint64_t>(i & 0xFFFF));
             }
             std::sort(buf.begin(), buf.end());

@@ -57,7 +57,8 @@ struct TargetIndex {
 void build_index(const SubMat &kmerMat, const uint8_t *residues, const uint64_t *seqOff, uint32_t nSeq,
                  int kmerThr, bool mask, float maskProb, int tantanLanes, TargetIndex &out, bool addressOrder = true);
 void index_to_address_order(TargetIndex &ix);
-void kmer3_address_table(uint16_t addrOf[8000]);   // reference 3-mer number -> table address digits
+void kmer3_address_table(uint16_t addrOf[8000]);   // reference 3-mer number -> address code (tile << 6 | in-quad positions), a permutation of 0..7999
+uint32_t kmer_cell(uint32_t addrFirst, uint32_t addrSecond);   // table cell of the k-mer made of two 3-mers (their address codes)
 
 struct Evaluer {
     double lambda, K, logK, a_I, b_I, a_J, b_J, alpha_I, beta_I, alpha_J, beta_J, sigma, tau, vi_y_thr, vj_y_thr, c_y_thr, dbRes;

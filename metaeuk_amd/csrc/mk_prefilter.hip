@@ -309,29 +309,47 @@ __global__ __launch_bounds__(256) void gather_queries_kernel(PrefilterDeviceView
 }
 
 // Exact number of similar k-mers of every k-mer start, without enumerating them: with the per-row score histograms the
-// staircase sum over (first half, second half) collapses to sum_s hist0[s] * cum1[thr - s].  Summed per query; the host
-// sizes the LDS tier of each query with it.
+// staircase sum over (first half, second half) collapses to sum_s hist0[s] * cum1[thr - s].  Summed per query (the host sizes
+// the tier of each query with it) and kept per start as the work estimate of the per-query kernels.
+// A wave walks 64 consecutive starts; for one start the lanes hold the score levels (two each: the histogram rows are read as two
+// coalesced lines instead of ~80 dependent scalar loads per lane), a DPP sum folds them, and the counts of consecutive starts of one
+// query leave the wave in one atomic.
 __global__ __launch_bounds__(256) void kmer_count_kernel(PrefilterDeviceView V, uint64_t posBegin, uint64_t posEnd, uint32_t qFirst, uint32_t *perQuery,
                                                         uint16_t *perPos /* [p - posBegin]: similar k-mers of the start / 4, saturated (work estimate) */) {
-    const uint64_t p = posBegin + (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= posEnd) return;
-    const int thr = (int) V.q_kmer_thr[p];
-    if (thr < 0) { perPos[p - posBegin] = 0; return; }
-    const uint8_t *r = V.q_res + p;
-    const uint32_t idx0 = r[0] + 20u * r[1] + 400u * r[3];
-    const uint32_t idx1 = r[5] + 20u * r[8] + 400u * r[9];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const uint64_t wave = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const uint64_t p0 = posBegin + wave * WAVE;
+    if (p0 >= posEnd) return;
+    const uint64_t p1 = min(p0 + (uint64_t) WAVE, posEnd);
     const int R = V.hist_range, lo = V.hist_lo;
-    const uint16_t *h0 = V.hist3 + (size_t) idx0 * R, *c1 = V.cum3 + (size_t) idx1 * R;
-    uint32_t total = 0;
-    for (int k = R - 1; k >= 0; k--) {
-        const uint32_t h = h0[k];
-        if (!h) continue;
-        const int x = thr - (lo + k) - lo;            // index of the cutoff in the cumulative row
-        if (x >= R) break;                             // the second half cannot reach the cutoff any more (scores only fall)
-        total += h * (x <= 0 ? (uint32_t) N3 : (uint32_t) c1[x]);
+    uint32_t q = find_query(V.q_off, V.n_queries, p0);
+    uint64_t qEnd = V.q_off[q + 1];
+    uint32_t acc = 0;
+    for (uint64_t p = p0; p < p1; p++) {
+        while (p >= qEnd) {                                    // (wave-uniform) next query: flush
+            if (acc && lane == 0) atomicAdd(&perQuery[q - qFirst], acc);
+            acc = 0; q++; qEnd = V.q_off[q + 1];
+        }
+        const int thr = (int) V.q_kmer_thr[p];
+        uint32_t total = 0;
+        if (thr >= 0) {
+            const uint8_t *r = V.q_res + p;
+            const uint32_t idx0 = r[0] + 20u * r[1] + 400u * r[3];
+            const uint32_t idx1 = r[5] + 20u * r[8] + 400u * r[9];
+            const uint16_t *h0 = V.hist3 + (size_t) idx0 * R, *c1 = V.cum3 + (size_t) idx1 * R;
+            uint32_t part = 0;
+            for (int k = lane; k < R; k += WAVE) {
+                const uint32_t h = h0[k];
+                const int x = thr - (lo + k) - lo;             // index of the cutoff in the cumulative row
+                const uint32_t c = x <= 0 ? (uint32_t) N3 : (x >= R ? 0u : (uint32_t) c1[x]);
+                part += h * c;
+            }
+            total = wave_sum(part);
+        }
+        if (lane == 0) perPos[p - posBegin] = (uint16_t) min((total + 3u) >> 2, 65535u);
+        acc += total;
     }
-    perPos[p - posBegin] = (uint16_t) min((total + 3u) >> 2, 65535u);
-    if (total) atomicAdd(&perQuery[find_query(V.q_off, V.n_queries, p) - qFirst], total);
+    if (acc && lane == 0) atomicAdd(&perQuery[q - qFirst], acc);
 }
 
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
@@ -1165,7 +1183,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                 PCHK(hipMemsetAsync(dQK, 0, (size_t) nqc * 4, stream));
                 if (pe > pb) {
                     const int th = tb("kmer_count", 5.0 * (double) (pe - pb), 0);
-                    hipLaunchKernelGGL(kmer_count_kernel, dim3((unsigned) ((pe - pb + 255) / 256)), dim3(256), 0, stream, V, pb, pe, q0, dQK, dPosCost);
+                    hipLaunchKernelGGL(kmer_count_kernel, dim3((unsigned) (((pe - pb + WAVE - 1) / WAVE + 3) / 4)), dim3(256), 0, stream, V, pb, pe, q0, dQK, dPosCost);
                     te(th);
                     PCHK(hipGetLastError());
                 }

@@ -805,3 +805,39 @@ def test_cli_contig_batches(gpu_api, tmp_path):
         subprocess.check_call([build.BIN, "extractorfs", str(tmp_path / "contigs"), str(tmp_path / name), "--translate", "1", "--min-length", "15"], env=e, stderr=subprocess.DEVNULL)
     assert _read_result_db(str(tmp_path / "orfs_one")) == _read_result_db(str(tmp_path / "orfs_batched"))
     assert _read_result_db(str(tmp_path / "orfs_one_h")) == _read_result_db(str(tmp_path / "orfs_batched_h"))
+
+
+def test_cli_equals_the_real_process(gpu_api, tmp_path):
+    """the commands against the DBs the REAL `metaeuk predictexons` binary wrote (tests/golden/e2e_process_*): extractorfs --translate,
+    prefilter, align with the argv the workflow passes (-s 5.7), and predictexons with NO -s (the workflow's own default, -s 4)"""
+    import subprocess
+    from metaeuk_amd import build
+    targets, contigs = _lines("e2e_targets.txt.gz"), _lines("e2e_contigs.txt.gz")
+    _write_seq_db(str(tmp_path / "targets"), targets)
+    _write_seq_db(str(tmp_path / "contigs"), contigs)
+    (tmp_path / "contigs.dbtype").write_bytes((1).to_bytes(4, "little"))
+    run = lambda *a: subprocess.check_call([build.BIN] + [str(x) for x in a], stderr=subprocess.DEVNULL)
+    run("extractorfs", tmp_path / "contigs", tmp_path / "aa_6f", "--translate", "1", "--min-length", "15", "--max-length", "32734", "--max-gaps", "2147483647",
+        "--contig-start-mode", "2", "--contig-end-mode", "2", "--orf-start-mode", "1", "--forward-frames", "1,2,3", "--reverse-frames", "1,2,3",
+        "--translation-table", "1", "--use-all-table-starts", "0", "--id-offset", "0", "--create-lookup", "0", "--threads", "4", "--compressed", "0", "-v", "3")
+    aa, hdr = _read_result_db(str(tmp_path / "aa_6f")), _read_result_db(str(tmp_path / "aa_6f_h"))
+    assert "".join("%s\t%s" % (hdr[k].rstrip("\n"), aa[k]) for k in sorted(aa)) == _text("e2e_process_orfs.txt.gz")
+    run("prefilter", tmp_path / "aa_6f", tmp_path / "targets", tmp_path / "pref_0", "--sub-mat", "aa:blosum62.out,nucl:nucleotide.out",
+        "--seed-sub-mat", "aa:VTML80.out,nucl:nucleotide.out", "-k", "0", "--target-search-mode", "0", "--k-score", "seq:2147483647,prof:2147483647",
+        "--alph-size", "aa:21,nucl:5", "--max-seq-len", "65535", "--max-seqs", "300", "--split", "0", "--split-mode", "2", "--split-memory-limit", "0",
+        "-c", "0", "--cov-mode", "0", "--comp-bias-corr", "1", "--comp-bias-corr-scale", "1", "--diag-score", "1", "--exact-kmer-matching", "0",
+        "--mask", "1", "--mask-prob", "0.9", "--mask-lower-case", "0", "--mask-n-repeat", "0", "--min-ungapped-score", "15", "--add-self-matches", "0",
+        "--spaced-kmer-mode", "1", "--db-load-mode", "0", "--pca", "substitution:1.100,context:1.400", "--pcb", "substitution:4.100,context:5.800",
+        "--threads", "4", "--compressed", "0", "-v", "3", "-s", "5.7", "--ref-l2-bytes", "2097152")
+    blocks = lambda d: "".join(">%d\n%s" % (k, d[k]) for k in sorted(d))
+    assert blocks(_read_result_db(str(tmp_path / "pref_0"))) == _text("e2e_process_pref.txt.gz")
+    run("align", tmp_path / "aa_6f", tmp_path / "targets", tmp_path / "pref_0", tmp_path / "search_res", "--sub-mat", "aa:blosum62.out,nucl:nucleotide.out",
+        "-a", "0", "--alignment-mode", "2", "--alignment-output-mode", "0", "--wrapped-scoring", "0", "-e", "100", "--min-seq-id", "0", "--min-aln-len", "11",
+        "--seq-id-mode", "0", "--alt-ali", "0", "-c", "0", "--cov-mode", "0", "--max-seq-len", "65535", "--comp-bias-corr", "1", "--comp-bias-corr-scale", "1",
+        "--max-rejected", "2147483647", "--max-accept", "2147483647", "--add-self-matches", "0", "--db-load-mode", "0", "--pca", "substitution:1.100,context:1.400",
+        "--pcb", "substitution:4.100,context:5.800", "--score-bias", "0", "--realign", "0", "--realign-score-bias", "-0.2", "--realign-max-seqs", "2147483647",
+        "--corr-score-weight", "0", "--gap-open", "aa:11,nucl:5", "--gap-extend", "aa:1,nucl:2", "--zdrop", "40", "--threads", "4", "--compressed", "0", "-v", "3",
+        "--ref-l2-bytes", "2097152")
+    assert blocks(_read_result_db(str(tmp_path / "search_res"))) == _text("e2e_process_aln.txt.gz")
+    run("predictexons", tmp_path / "contigs", tmp_path / "targets", tmp_path / "calls4", tmp_path / "tmp", "--threads", "4", "--ref-l2-bytes", "2097152")
+    assert blocks(_read_result_db(str(tmp_path / "calls4"))) == _text("e2e_process_calls_default_s4.txt.gz")

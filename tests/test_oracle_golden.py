@@ -80,6 +80,22 @@ def test_oracle_end_to_end_exon_sets_match_golden(tmp_path):
     assert (tmp_path / "exons.txt").read_text() == _text("e2e_exons_expected.txt.gz")
 
 
+def test_oracle_matches_the_real_process(tmp_path):
+    """Process-level goldens: the DBs the REAL `metaeuk predictexons -s 5.7` binary left behind (tests/golden/make_process_golden.sh) --
+    aa_6f (+ headers), pref_0, search_res -- against the oracle's stages on the same contigs and targets.  This pins the module DRIVERS
+    (Prefiltering::runSplit, Alignment::run) that the harness restates, not only the algorithm classes."""
+    oracle.build()
+    (tmp_path / "t.txt").write_text(_text("e2e_targets.txt.gz"))
+    (tmp_path / "c.txt").write_text(_text("e2e_contigs.txt.gz"))
+    subprocess.check_call([oracle.CLI, "orfs", str(tmp_path / "c.txt"), str(tmp_path / "orfs.txt")], stdout=subprocess.DEVNULL)
+    frags = [l for l in open(tmp_path / "orfs.txt") if not l.startswith(">")]
+    assert "".join(frags) == _text("e2e_process_orfs.txt.gz")
+    (tmp_path / "q.txt").write_text("".join(l.rsplit("\t", 1)[1] for l in frags))
+    subprocess.check_call([oracle.CLI, "pipeline", str(tmp_path / "t.txt"), str(tmp_path / "q.txt"), str(tmp_path / "out"), "--l2", "2097152"], stdout=subprocess.DEVNULL)
+    assert open(tmp_path / "out" / "pref.txt").read() == _text("e2e_process_pref.txt.gz")
+    assert open(tmp_path / "out" / "aln.txt").read() == _text("e2e_process_aln.txt.gz")
+
+
 @pytest.mark.skipif(not os.path.exists(oracle.REF) or not os.path.isdir("/root/reference"), reason="reference harness not built here")
 def test_oracle_matches_live_reference(tmp_path):
     from metaeuk_amd import synth
