@@ -227,7 +227,7 @@ int run_sw_jobs(const mk_targetdb *db, const mk_queries *q, const mk_params *P, 
         L.q_res = q->dRes.p; L.q_bias8 = q->dBias8.p; L.t_res = db->dRes.p; L.mat = db->dMatAln.p;
         L.jobs = dJobs.p + lo; L.out = dOut.p; L.n_jobs = hi - lo; L.order = nullptr;
         L.boundary = nullptr; L.boundary_stride = 0; L.boundary_job0 = 0;
-        L.wave_start = nullptr; L.n_waves = 0; L.work_counter = nullptr; L.persistent_blocks = 0; L.units_per_block = 0;
+        L.wave_start = nullptr; L.n_waves = 0; L.work_counter = nullptr; L.persistent_blocks = 0; L.units_per_block = 0; L.known_score = nullptr;
         L.gap_open = P->gap_open; L.gap_extend = P->gap_extend;
         double cells = 0, bytes = 0;
         uint32_t maxT = 0; bool multi = false;

@@ -114,7 +114,7 @@ __global__ void bounds_kernel(const uint32_t *sortedKeys, uint32_t n, uint32_t *
 // e-value gate on the forward score (table per query length); survivors get a position job (the same DP again, this time
 // with end-position tracking)
 __global__ __launch_bounds__(256) void gate_kernel(const SwJob *fwdJobs, const SwOut *fwdOut, uint64_t n, const GateEntry *gate,
-                                                   uint32_t *posCount, uint32_t *posPair, SwJob *posJobs, uint32_t *posKeys, uint32_t *posIdx,
+                                                   uint32_t *posCount, uint32_t *posPair, SwJob *posJobs, uint32_t *posKeys, uint32_t *posIdx, int32_t *posScore,
                                                    unsigned long long *work /* [2 * cfg]: bytes, [2 * cfg + 1]: cells of the position pass (statistics) */) {
     __shared__ unsigned long long sWork[2 * SW_NCFG];
     for (int k = threadIdx.x; k < 2 * SW_NCFG; k += blockDim.x) sWork[k] = 0;
@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void gate_kernel(const SwJob *fwdJobs, const S
     if (!pass) return;
     const uint32_t r = atomicAdd(posCount, 1u);
     posPair[r] = (uint32_t) p;
+    posScore[r] = fwdOut[p].score;
     j.slot = r;
     posJobs[r] = j;
     posKeys[r] = sort_key(j.q_len, j.t_len);
@@ -336,7 +337,8 @@ void build_gate_table(const Evaluer &ev, double evalThr, const std::vector<uint6
 
 static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jobs, SwOut *out, uint32_t *keys, uint32_t *idx,
                          uint32_t *keys2, uint32_t *idx2, uint32_t n, const char *tag, hipStream_t stream, std::string &err,
-                         timed_begin_fn tb, timed_end_fn te, int *handles /* SW_NCFG, may be null */) {
+                         timed_begin_fn tb, timed_end_fn te, int *handles /* SW_NCFG, may be null */,
+                         const int32_t *knownScore /* device, by job slot: the maximum every job will reach (null: unknown) */) {
     if (handles) for (int c = 0; c < SW_NCFG; c++) handles[c] = -1;
     if (n == 0) return MK_OK;
     hipcub::DoubleBuffer<uint32_t> kb(keys, keys2), vb(idx, idx2);
@@ -362,7 +364,7 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
         L.q_res = V.q_res; L.q_bias8 = V.q_bias8; L.t_res = V.t_res; L.mat = V.mat_aln;
         L.jobs = jobs; L.out = out; L.n_jobs = hi - lo; L.order = vb.Current() + lo;
         L.boundary = nullptr; L.boundary_stride = 0; L.boundary_job0 = 0;
-        L.wave_start = nullptr; L.n_waves = 0; L.work_counter = nullptr; L.persistent_blocks = 0; L.units_per_block = 0;
+        L.wave_start = nullptr; L.n_waves = 0; L.work_counter = nullptr; L.persistent_blocks = 0; L.units_per_block = 0; L.known_score = nullptr;
         L.gap_open = P.gap_open; L.gap_extend = P.gap_extend;
         if (c == SW_NCFG - 1 && V.max_q_len > (uint32_t) sw_cfg_rows(c)) {
             const uint32_t cls = KEY_CLS - 1 - (hb[32 + c] % KEY_CLS);          // largest target-length class in this bucket
@@ -375,7 +377,22 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
         snprintf(nm, sizeof(nm), "%s_rows%d", tag, sw_cfg_rows(c));
         th = tb(nm, 0, 0);
         if (handles) handles[c] = th;
-        ACHK(launch_sw(L, c, stream));
+        static const bool int32Only = getenv("MK_SW_KNOWN_INT32") && atoi(getenv("MK_SW_KNOWN_INT32")) != 0;
+        if (knownScore && sw_cfg_known(c) && !int32Only) {
+            // the score is known: packed int16, eight independent DPs per wave, persistent
+            static int cus = 0;
+            if (!cus) { int dev = 0; (void) hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
+            uint32_t *dWork = (uint32_t *) dev_scratch("align_knowncounters", 64 * sizeof(uint32_t));
+            ANULL(dWork);
+            static uint32_t slot = 0;
+            uint32_t *counter = dWork + (slot++ % 64);
+            ACHK(hipMemsetAsync(counter, 0, sizeof(uint32_t), stream));
+            L.known_score = knownScore; L.work_counter = counter;
+            L.persistent_blocks = (uint32_t) cus * (sw_cfg_rows(c) <= 32 ? 12u : 6u);      // 11 / 22.5 KB of profiles per wave
+            ACHK(launch_sw_known(L, c, stream));
+        } else {
+            ACHK(launch_sw(L, c, stream));
+        }
         te(th);
     }
     return MK_OK;
@@ -519,7 +536,9 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hi
     unsigned long long *hPosWork = (unsigned long long *) pinned_scratch("align_poswork_h", 2 * SW_NCFG * 8);
     ANULL(dPosWork); ANULL(hPosWork);
     ACHK(hipMemsetAsync(dPosWork, 0, 2 * SW_NCFG * 8, stream));
-    hipLaunchKernelGGL(gate_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dJobs, dOut, (uint64_t) n, dGate, dCount, dRevPair, dPosJobs, dKeys, dIdx, dPosWork);
+    int32_t *dPosScore = (int32_t *) dev_scratch("align_posscore", (size_t) n * 4);
+    ANULL(dPosScore);
+    hipLaunchKernelGGL(gate_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dJobs, dOut, (uint64_t) n, dGate, dCount, dRevPair, dPosJobs, dKeys, dIdx, dPosScore, dPosWork);
     te(th);
     ACHK(hipGetLastError());
     uint32_t *hCount = (uint32_t *) pinned_scratch("align_count_h", 16);
@@ -537,12 +556,12 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hi
     ACHK(hipMemsetAsync(dPosOut, 0, (size_t) nRev * sizeof(SwOut), stream));
     ACHK(hipMemsetAsync(dRevOut, 0, (size_t) nRev * sizeof(SwOut), stream));
     int hPos[SW_NCFG];
-    rc = run_sorted_sw(V, P, dPosJobs, dPosOut, dKeys, dIdx, dKeys2, dIdx2, nRev, "sw_pos", stream, err, tb, te, hPos);
+    rc = run_sorted_sw(V, P, dPosJobs, dPosOut, dKeys, dIdx, dKeys2, dIdx2, nRev, "sw_pos", stream, err, tb, te, hPos, dPosScore);
     if (rc != MK_OK) return rc;
     for (int c = 0; c < SW_NCFG; c++) if (hPos[c] >= 0) ts(hPos[c], (double) hPosWork[2 * c], (double) hPosWork[2 * c + 1]);
     hipLaunchKernelGGL(rev_jobs_kernel, dim3((nRev + 255) / 256), dim3(256), 0, stream, dPosJobs, dPosOut, dRevPair, dOut, nRev, dRevJobs, dKeys, dIdx, dCount + 2);
     ACHK(hipGetLastError());
-    rc = run_sorted_sw(V, P, dRevJobs, dRevOut, dKeys, dIdx, dKeys2, dIdx2, nRev, "sw_rev", stream, err, tb, te, hRev);
+    rc = run_sorted_sw(V, P, dRevJobs, dRevOut, dKeys, dIdx, dKeys2, dIdx2, nRev, "sw_rev", stream, err, tb, te, hRev, dPosScore);    // (rev job r = survivor r: same score)
     if (rc != MK_OK) return rc;
     // order the survivors by pair index and collect
     uint32_t *dSeq = (uint32_t *) dev_scratch("align_seq", (size_t) nRev * 4), *dSeq2 = (uint32_t *) dev_scratch("align_seq2", (size_t) nRev * 4);

@@ -38,6 +38,7 @@ struct SwLaunch {
     uint32_t persistent_blocks; // ... and how many workgroups to launch (0: one per wave)
     uint32_t units_per_block;   // a workgroup retires after this many waves of jobs (0: runs until the counter is exhausted)
     uint64_t boundary_job0;     // job index that owns the first boundary_stride entries of `boundary`
+    const int32_t *known_score; // position / reverse pass of the small tiles (launch_sw_known): the maximum score of job j is known_score[jobs[j].slot]
 };
 
 // tile configurations: G lanes per DP x R rows per lane; a job uses the smallest one whose G*R >= q_len
@@ -59,6 +60,10 @@ __host__ __device__ inline int sw_cfg_of(uint32_t qLen) {
 hipError_t launch_sw(const SwLaunch &L, int cfg, hipStream_t stream);
 // score-only forward pass in packed int16, two targets per lane group (sw_cfg_packed configurations, shared-query mode only)
 hipError_t launch_sw_score(const SwLaunch &L, int cfg, hipStream_t stream);
+// position of a KNOWN maximum (end cell: first column that reaches it, smallest row there) in packed int16, eight independent DPs per wave,
+// for the tiles sw_cfg_known() names; L.order / L.n_jobs / L.work_counter / L.persistent_blocks as in the persistent launches
+__host__ __device__ inline bool sw_cfg_known(int c) { return sw_cfg_rows(c) <= 64; }
+hipError_t launch_sw_known(const SwLaunch &L, int cfg, hipStream_t stream);
 
 // Ungapped score of a (query, target, 16-bit diagonal) candidate: UngappedAlignment::scoreSingleSequence
 // (M/src/prefiltering/UngappedAlignment.cpp:438-447).  Both sequences below 32768 residues: the diagonal is the signed 16-bit value.

@@ -374,6 +374,176 @@ __global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// End cell of a KNOWN maximum, packed int16: the position pass (the ~9 % of the pairs that pass the e-value gate: their score is
+// known from the score pass) and the reverse pass (reversed prefixes ending at the forward end cell: same score).  The reference
+// reports the first column in which the maximum is reached and the smallest row in it; with the value S known in advance that is
+// the first step at which a lane's running maximum equals S -- no per-cell position key, so the DP runs at the score pass's price.
+// Eight INDEPENDENT DPs per wave: each 16-lane group runs two jobs in the packed halves, every job with its own query profile
+// (the survivors of a query are too few to fill a wave with one query), any direction (q_step / t_step = -1 for the reverse pass).
+// For tiles of at most 64 rows (no saturation, no row tiles); larger tiles keep the int32 kernel.
+template <int R, int RP>
+__global__ __launch_bounds__(64) void swq_kernel(SwLaunch L) {
+    constexpr int G = 16, ROWS = G * RP, NDP = 8;
+    static_assert(RP >= R && RP % 2 == 0 && G * R * 127 <= 32767, "small tiles only");
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    int16_t *prof = reinterpret_cast<int16_t *>(smem);            // prof[dp][t][slot]
+    constexpr int PROF1 = 22 * ROWS;                              // int16 entries of one profile
+    int8_t *sMat = smem + (size_t) NDP * PROF1 * sizeof(int16_t);
+    uint8_t *sQ = reinterpret_cast<uint8_t *>(sMat + 448);         // [dp][slot]
+    int8_t *sB = reinterpret_cast<int8_t *>(sQ + NDP * ROWS);
+    for (int k = (int) threadIdx.x; k < 441; k += 64) sMat[k] = L.mat[k];
+    const int lane = threadIdx.x % G, grp = threadIdx.x / G;
+    const pk16 go2 = pk_splat(L.gap_open), ge2 = pk_splat(L.gap_extend), zero2 = pk_splat(0);
+    const uint64_t nUnits = (L.n_jobs + NDP - 1) / NDP;
+    for (;;) {
+        uint32_t u = 0;
+        if (threadIdx.x == 0) u = atomicAdd(L.work_counter, 1u);
+        u = (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
+        if ((uint64_t) u >= nUnits) break;
+        const uint64_t j0 = (uint64_t) u * NDP;
+        // every lane's two jobs; the lanes 0..7 of the wave also describe job j0 + lane for the profile staging below
+        const uint64_t ja = j0 + 2 * grp, jb = ja + 1;
+        const bool haveA = ja < L.n_jobs, haveB = jb < L.n_jobs;
+        const SwJob jobA = L.jobs[L.order[haveA ? ja : j0]], jobB = L.jobs[L.order[haveB ? jb : j0]];
+        const int tLenA = haveA ? (int) jobA.t_len : 0, tLenB = haveB ? (int) jobB.t_len : 0;
+        const uint32_t SA = haveA ? (uint32_t) L.known_score[jobA.slot] & 0xFFFFu : 0xFFFFu, SB = haveB ? (uint32_t) L.known_score[jobB.slot] & 0xFFFFu : 0xFFFFu;
+        const uint32_t S2 = SA | (SB << 16);
+        // ---- the eight query profiles: residues + bias staged in LDS, then prof[dp][t][slot] = mat[t][q] + bias ----
+        for (int i = (int) threadIdx.x; i < NDP * ROWS; i += 64) {
+            const int dp = i / ROWS, slot = i - dp * ROWS;
+            const uint64_t j = j0 + (uint64_t) dp;
+            uint8_t qc = 255; int8_t bc = 0;
+            if (j < L.n_jobs) {
+                const SwJob jj = L.jobs[L.order[j]];
+                const int row = RP == R ? slot : (slot / RP) * R + slot % RP;
+                if (row < (int) jj.q_len && (RP == R || slot % RP < R)) {
+                    const int64_t qi = (int64_t) jj.q_start + (int64_t) row * jj.q_step;
+                    qc = L.q_res[qi]; bc = L.q_bias8[qi];
+                }
+            }
+            sQ[i] = qc; sB[i] = bc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int i = (int) threadIdx.x; i < NDP * PROF1; i += 64) {
+            const int dp = i / PROF1, rem = i - dp * PROF1, t = rem / ROWS, slot = rem - t * ROWS;
+            const uint32_t qc = sQ[dp * ROWS + slot];
+            prof[i] = (t < 21 && qc != 255u) ? (int16_t) ((int) sMat[t * 21 + (int) qc] + (int) sB[dp * ROWS + slot]) : (int16_t) 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        pk16 H[R], E[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) { H[r] = zero2; E[r] = zero2; }
+        pk16 best = zero2, hupPrev = zero2;
+        constexpr uint32_t ROWB = (uint32_t) ROWS * 2u, NOCOL = 21u * ROWB | (21u * ROWB) << 16;
+        uint32_t outH = 0, outF = 0, outRes = NOCOL;
+        const int tMax = max(tLenA, tLenB);
+        const int steps = tMax > 0 ? (tMax + G - 1 + 15) & ~15 : 0;
+        const int laneRow = lane & 15;
+        const int lastA = max(tLenA - 1, 0), lastB = max(tLenB - 1, 0);
+        const int64_t baseA = (int64_t) jobA.t_start, baseB = (int64_t) jobB.t_start, stepA = jobA.t_step, stepB = jobB.t_step;
+        const auto fetch = [&](int col) -> uint32_t {
+            const uint32_t ra = col < tLenA ? (uint32_t) L.t_res[baseA + (int64_t) min(col, lastA) * stepA] : 21u;
+            const uint32_t rb = col < tLenB ? (uint32_t) L.t_res[baseB + (int64_t) min(col, lastB) * stepB] : 21u;
+            return ra * ROWB | (rb * ROWB) << 16;
+        };
+        const char *profA = reinterpret_cast<const char *>(prof + (size_t) (2 * grp) * PROF1 + lane * RP);
+        const char *profB = reinterpret_cast<const char *>(prof + (size_t) (2 * grp + 1) * PROF1 + lane * RP);
+        uint32_t foundA = 0xFFFFFFFFu, foundB = 0xFFFFFFFFu;     // column << 12 | row of the lane's first cell at the known score
+        uint32_t closed2 = 0u;                                     // 0x0001 in the halves that have found theirs (keeps them out of the test below)
+        uint32_t tq0 = fetch(laneRow), tq1 = fetch(16 + laneRow), tq2 = fetch(32 + laneRow);
+        for (int s0 = 0; s0 < steps; s0 += 16) {
+            uint32_t tcur = tq0;
+            tq0 = tq1; tq1 = tq2;
+            tq2 = fetch(s0 + 48 + laneRow);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t top = tcur;
+                tcur = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) tcur, 0x12F /* row_ror:15 */, 0xf, 0xf, false);
+                const pk16 hup = pk_from(shift_up_zero<G>(outH, lane));
+                pk16 F = pk_from(shift_up_zero<G>(outF, lane));
+                const uint32_t tres = shift_up<G>(top, outRes, lane);
+                const int16_t *pa = reinterpret_cast<const int16_t *>(profA + (tres & 0xFFFFu)), *pb = reinterpret_cast<const int16_t *>(profB + (tres >> 16));
+                uint32_t wa[RP / 2], wb[RP / 2];
+#pragma unroll
+                for (int kk = 0; kk < RP / 2; kk++) { wa[kk] = reinterpret_cast<const uint32_t *>(pa)[kk]; wb[kk] = reinterpret_cast<const uint32_t *>(pb)[kk]; }
+                pk16 dsave = hupPrev;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const pk16 sc = pk_from(__builtin_amdgcn_perm(wb[r / 2], wa[r / 2], (r & 1) ? 0x07060302u : 0x05040100u));
+                    const pk16 d = dsave + sc;
+                    dsave = H[r];
+                    const pk16 h = pk_max(pk_max(d, E[r]), F);
+                    best = pk_max(best, h);
+                    const pk16 ho = pk_subs0(h, go2);
+                    E[r] = pk_max(pk_subs0(E[r], ge2), ho);
+                    F = pk_max(pk_subs0(F, ge2), ho);
+                    H[r] = h;
+                }
+                hupPrev = hup;
+                outH = pk_bits(H[R - 1]);
+                outF = pk_bits(F);
+                outRes = tres;
+                // a half of (best ^ S2) is zero when that DP's running maximum has reached its known score; zero-half test
+                // (x - 0x00010001) & ~x & 0x80008000 -- it can flag the high half falsely when the low half is zero, so the branch re-checks
+                const uint32_t x = (pk_bits(best) ^ S2) | closed2;
+                const uint32_t hit = (x - 0x00010001u) & ~x & 0x80008000u;
+                if (__builtin_amdgcn_ballot_w64(hit != 0u) != 0ull) {                  // rare: once per DP and lane (plus the odd false alarm)
+                    const int c = s0 + k - lane;                                       // this lane's column at this step
+                    if ((x & 0xFFFFu) == 0u) {
+                        int row = 0;
+#pragma unroll
+                        for (int r = R - 1; r >= 0; r--) if ((pk_bits(H[r]) & 0xFFFFu) == SA) row = r;
+                        foundA = ((uint32_t) c << 12) | (uint32_t) (lane * R + row);
+                        closed2 |= 0x1u;
+                    }
+                    if ((x >> 16) == 0u) {
+                        int row = 0;
+#pragma unroll
+                        for (int r = R - 1; r >= 0; r--) if ((pk_bits(H[r]) >> 16) == SB) row = r;
+                        foundB = ((uint32_t) c << 12) | (uint32_t) (lane * R + row);
+                        closed2 |= 0x10000u;
+                    }
+                }
+            }
+        }
+        // first column, then smallest row: the minimum of the lanes' findings
+#pragma unroll
+        for (int m = G / 2; m >= 1; m >>= 1) {
+            foundA = min(foundA, (uint32_t) __shfl_xor((int) foundA, m, G));
+            foundB = min(foundB, (uint32_t) __shfl_xor((int) foundB, m, G));
+        }
+        if (lane == 0) {
+            SwOut o;
+            o.pad = 0;
+            if (haveA) { const bool ok = foundA != 0xFFFFFFFFu; o.score = ok ? (int32_t) SA : 0; o.end_col = ok ? (int32_t) (foundA >> 12) : -1; o.end_row = ok ? (int32_t) (foundA & 0xFFFu) : -1; L.out[jobA.slot] = o; }
+            if (haveB) { const bool ok = foundB != 0xFFFFFFFFu; o.score = ok ? (int32_t) SB : 0; o.end_col = ok ? (int32_t) (foundB >> 12) : -1; o.end_row = ok ? (int32_t) (foundB & 0xFFFu) : -1; L.out[jobB.slot] = o; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+hipError_t launch_sw_known(const SwLaunch &L, int cfg, hipStream_t stream) {
+    if (!L.order || !L.work_counter || !L.known_score || cfg < 0 || cfg >= SW_NCFG || !sw_cfg_known(cfg)) return hipErrorInvalidValue;
+    if (L.n_jobs == 0) return hipSuccess;
+    const uint64_t nUnits = (L.n_jobs + 7) / 8;
+    const uint64_t grid = std::min<uint64_t>(nUnits, L.persistent_blocks ? L.persistent_blocks : nUnits);
+    const int rows = sw_cfg_rows(cfg);
+    const size_t prows = rows == 48 ? 64 : rows;
+    const size_t lds = (size_t) 8 * 22 * prows * sizeof(int16_t) + 448 + 2 * 8 * prows;
+    switch (rows) {
+        case 32: hipLaunchKernelGGL((swq_kernel<2, 2>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
+        case 48: hipLaunchKernelGGL((swq_kernel<3, 4>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
+        case 64: hipLaunchKernelGGL((swq_kernel<4, 4>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 // score-only forward launch for the sw_cfg_packed configurations; wave_start must cut the job list into waves of at most
 // sw_cfg_jobs_per_wave = 2 * 64/G jobs of one query
 hipError_t launch_sw_score(const SwLaunch &L, int cfg, hipStream_t stream) {
