@@ -833,6 +833,7 @@ static int align_range(mk_targetdb *db, mk_queries *q, const mk_params *P, uint3
     for (uint32_t i = 0; i <= nqc; i++) hitOff[i] = q->hitOff[(size_t) q0 + i] - h0;
     mk::AlignView V = align_view(db, q);
     V.q_off = q->dOff.p + q0; V.n_queries = nqc;
+    V.co_resident = stream == g_stream2;            // the alignment stage of mk_search runs beside the prefilter
     const mk::AlnRaw *raw = nullptr;
     size_t m = 0;
     std::string err;

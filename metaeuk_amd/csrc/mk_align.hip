@@ -377,9 +377,11 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
         snprintf(nm, sizeof(nm), "%s_rows%d", tag, sw_cfg_rows(c));
         th = tb(nm, 0, 0);
         if (handles) handles[c] = th;
-        static const bool int32Only = getenv("MK_SW_KNOWN_INT32") && atoi(getenv("MK_SW_KNOWN_INT32")) != 0;
-        if (knownScore && sw_cfg_known(c) && !int32Only) {
-            // the score is known: packed int16, eight independent DPs per wave, persistent
+        // the score is known: packed int16, eight independent DPs per wave, persistent -- when the stage has the GPU to itself (mk_align:
+        // 108 ms instead of 121 ms per config-2 pass).  Beside the prefilter of mk_search its 11-22 KB of profiles per wave cost the other
+        // stage more LDS than the kernel saves (measured: 1.12 s per step against 1.10 s), so the int32 kernels stay there.  MK_SW_KNOWN=0/1 forces.
+        static const int force = getenv("MK_SW_KNOWN") ? atoi(getenv("MK_SW_KNOWN")) : -1;
+        if (knownScore && sw_cfg_known(c) && (force >= 0 ? force != 0 : !V.co_resident)) {
             static int cus = 0;
             if (!cus) { int dev = 0; (void) hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
             uint32_t *dWork = (uint32_t *) dev_scratch("align_knowncounters", 64 * sizeof(uint32_t));
@@ -388,7 +390,9 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
             uint32_t *counter = dWork + (slot++ % 64);
             ACHK(hipMemsetAsync(counter, 0, sizeof(uint32_t), stream));
             L.known_score = knownScore; L.work_counter = counter;
-            L.persistent_blocks = (uint32_t) cus * (sw_cfg_rows(c) <= 32 ? 12u : 6u);      // 11 / 22.5 KB of profiles per wave
+            // 11 / 22.5 KB of profiles per wave: few waves per CU, the LDS is shared with the prefilter workgroups of the other stream
+            static const int perCuSmall = getenv("MK_SW_KNOWN_WAVES") ? std::max(1, atoi(getenv("MK_SW_KNOWN_WAVES"))) : 12;
+            L.persistent_blocks = (uint32_t) cus * (uint32_t) (sw_cfg_rows(c) <= 32 ? perCuSmall : std::max(1, perCuSmall / 2));
             ACHK(launch_sw_known(L, c, stream));
         } else {
             ACHK(launch_sw(L, c, stream));

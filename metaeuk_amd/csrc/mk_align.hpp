@@ -17,6 +17,7 @@ struct AlignView {
     const uint8_t *t_res; const uint64_t *t_off; uint32_t n_targets;
     const int8_t *mat_aln;
     uint32_t max_q_len, max_t_len;
+    bool co_resident = false;      // the prefilter of mk_search shares the CUs: kernels with a small LDS footprint are preferred
 };
 
 // integer result of one accepted pair (everything else is derived on the host in double/float)
