@@ -136,6 +136,28 @@ int mko_aln_compare(const void *a, const void *b);
 size_t mko_format_aln(char *buf, const mko_aln_result *r);
 size_t mko_format_hit(char *buf, const mko_hit *h);
 
+/* ---- profile queries (Sequence::mapProfile, profile k-mer lists, PROFILE_SEQ Smith-Waterman, swapresults) ---- */
+typedef struct {
+    int L;
+    uint8_t *query, *consensus;      /* the profile's query / consensus letters (numSequence / numConsensusSequence) */
+    int8_t *aln;                     /* profile_for_alignment: [21][L], score / 4, X row 0 */
+    short *sorted_score;             /* [L][20] descending (Util::rankedDescSort20) */
+    uint8_t *sorted_idx;             /* [L][20] residue numbers in that order */
+} mko_profile;
+mko_profile *mko_profile_map(const char *data, int seqLen);     /* seqLen = (entry length - 1) / 25 (DBReader::getSeqLen) */
+void mko_profile_free(mko_profile *p);
+void mko_ranked_desc_sort20(short *val, uint8_t *index);
+size_t mko_profile_kmer_list(const mko_profile *p, int pos, short threshold, uint64_t *out, size_t cap);
+int mko_prefilter_profile(const mko_prefilter_ctx *ctx, const mko_profile *p, mko_hit *out, mko_prefilter_stats *st);
+int mko_sw_profile_bias(const mko_profile *p);
+void mko_sw_forward_profile(const mko_profile *p, int bias, const uint8_t *t, int tlen, int gap_open, int gap_extend,
+                            int lanes_byte, int lanes_word, mko_sw_result *r);
+void mko_sw_reverse_profile(const mko_profile *p, int bias, const uint8_t *t, int gap_open, int gap_extend,
+                            int lanes_byte, int lanes_word, mko_sw_result *r);
+int mko_align_pair_profile(const mko_align_ctx *ctx, const mko_profile *prof, int bias, const uint8_t *t, int tlen, uint32_t db_key,
+                           mko_aln_result *out);
+void mko_swap_result(const mko_evaluer *ev, mko_aln_result *r, uint32_t new_db_key);
+
 /* ---- extractorfs --translate: M/src/commons/Orf.cpp, TranslateNucl.h, util/extractorfs.cpp ---- */
 typedef struct { size_t from, to; int incomplete_start, incomplete_end, strand; } mko_orf;   /* from/to = header coordinates */
 void mko_translation_table(char table[4096]);     /* amino acid of every IUPAC base-code triple, genetic code 1 */

@@ -38,7 +38,12 @@ void mko_sw_query_init(const mko_submat *m, const uint8_t *q, int L, float bias_
  *   column max / global max / end coordinates over H (:873-912).
  * word != 0: int16 saturating add (:1063).  Returns through out params; *overflow set when byte
  * mode would have reported 255 (:879-883). */
-static void sw_pass(const mko_submat *m, const uint8_t *qs, const int8_t *cb, int qlen,
+/* Profile queries (ssw_align_private<PROFILE_SEQ>, :296-298; createQueryProfile<.., PROFILE> :175-181): prof != NULL, the score of
+ * row q against residue tc is prof[tc * pL + pq0 + q * pqstep] (mat / mat_rev of ssw_init: [aa][pos], X row 0) and there is no
+ * composition bias.  GAP_POS_SCORING is not defined in this reference, so posSpecificGaps changes nothing. */
+typedef struct { const int8_t *prof; int pL, pq0, pqstep; } sw_prof_t;
+
+static void sw_pass(const mko_submat *m, const uint8_t *qs, const int8_t *cb, int qlen, const sw_prof_t *P,
                     const uint8_t *t, int t0, int step, int n_cols,
                     int go, int ge, int lanes, int word, int bias, int terminate,
                     int *o_max, int *o_end_t, int *o_end_q, int *overflow) {
@@ -54,7 +59,8 @@ static void sw_pass(const mko_submat *m, const uint8_t *qs, const int8_t *cb, in
         const uint8_t tc = t[ti];
         int Fm = 0, F = 0, colmax = 0;
         for (int q = 0; q < qlen; q++) {
-            const int s = (int) (int8_t) m->sub[tc][qs[q]] + (int) cb[q];   /* createQueryProfile :162-187 */
+            const int s = P ? (int) P->prof[(size_t) tc * P->pL + P->pq0 + q * P->pqstep]
+                            : (int) (int8_t) m->sub[tc][qs[q]] + (int) cb[q];   /* createQueryProfile :162-187 */
             int diag = (q > 0 ? Hprev[q - 1] : 0) + s;
             if (word && diag > 32767) diag = 32767;
             if (q % segLen == 0) Fm = 0;
@@ -90,9 +96,9 @@ void mko_sw_forward(const mko_submat *m, const uint8_t *q, const int8_t *cb, int
                     const uint8_t *t, int tlen, int go, int ge, int lanes_byte, int lanes_word, mko_sw_result *r) {
     int mx, et, eq, ovf;
     r->word = 0; r->rev_mismatch = 0; r->q_start = -1; r->t_start = -1;
-    sw_pass(m, q, cb, qlen, t, 0, 1, tlen, go, ge, lanes_byte, 0, bias, 255 /* UCHAR_MAX */, &mx, &et, &eq, &ovf);
+    sw_pass(m, q, cb, qlen, NULL, t, 0, 1, tlen, go, ge, lanes_byte, 0, bias, 255 /* UCHAR_MAX */, &mx, &et, &eq, &ovf);
     if (ovf) {
-        sw_pass(m, q, cb, qlen, t, 0, 1, tlen, go, ge, lanes_word, 1, 0, 65535, &mx, &et, &eq, &ovf);
+        sw_pass(m, q, cb, qlen, NULL, t, 0, 1, tlen, go, ge, lanes_word, 1, 0, 65535, &mx, &et, &eq, &ovf);
         r->word = 1;
     }
     r->score = mx; r->t_end = et; r->q_end = eq;
@@ -107,12 +113,37 @@ void mko_sw_reverse(const mko_submat *m, const uint8_t *q, const int8_t *cb, int
     int8_t *rcb = (int8_t *) malloc((size_t) n);
     for (int k = 0; k < n; k++) { rq[k] = q[r->q_end - k]; rcb[k] = cb[r->q_end - k]; }
     int mx, et, eq, ovf;
-    sw_pass(m, rq, rcb, n, t, r->t_end, -1, r->t_end + 1, go, ge, r->word ? lanes_word : lanes_byte, r->word,
+    sw_pass(m, rq, rcb, n, NULL, t, r->t_end, -1, r->t_end + 1, go, ge, r->word ? lanes_word : lanes_byte, r->word,
             r->word ? 0 : bias, r->score, &mx, &et, &eq, &ovf);
     if (mx != r->score) r->rev_mismatch = 1;
     r->t_start = et;
     r->q_start = r->q_end - eq;
     free(rq); free(rcb);
+}
+
+/* the two passes for a profile query: forward over the whole profile, reverse over the reversed profile prefix [0..q_end]
+ * (mat_rev + queryOffset, :401-403 / :429-433) */
+void mko_sw_forward_profile(const mko_profile *p, int bias, const uint8_t *t, int tlen, int go, int ge, int lanes_byte, int lanes_word,
+                            mko_sw_result *r) {
+    int mx, et, eq, ovf;
+    const sw_prof_t P = {p->aln, p->L, 0, 1};
+    r->word = 0; r->rev_mismatch = 0; r->q_start = -1; r->t_start = -1;
+    sw_pass(NULL, NULL, NULL, p->L, &P, t, 0, 1, tlen, go, ge, lanes_byte, 0, bias, 255, &mx, &et, &eq, &ovf);
+    if (ovf) {
+        sw_pass(NULL, NULL, NULL, p->L, &P, t, 0, 1, tlen, go, ge, lanes_word, 1, 0, 65535, &mx, &et, &eq, &ovf);
+        r->word = 1;
+    }
+    r->score = mx; r->t_end = et; r->q_end = eq;
+}
+
+void mko_sw_reverse_profile(const mko_profile *p, int bias, const uint8_t *t, int go, int ge, int lanes_byte, int lanes_word, mko_sw_result *r) {
+    int mx, et, eq, ovf;
+    const sw_prof_t P = {p->aln, p->L, r->q_end, -1};
+    sw_pass(NULL, NULL, NULL, r->q_end + 1, &P, t, r->t_end, -1, r->t_end + 1, go, ge, r->word ? lanes_word : lanes_byte, r->word,
+            r->word ? 0 : bias, r->score, &mx, &et, &eq, &ovf);
+    if (mx != r->score) r->rev_mismatch = 1;
+    r->t_start = et;
+    r->q_start = r->q_end - eq;
 }
 
 /* EvalueComputation (M/src/alignment/EvalueComputation.h:64-69 hard-coded BLOSUM62 11/1 Gumbel set)
@@ -182,10 +213,25 @@ static float compute_cov(unsigned int startPos, unsigned int endPos, unsigned in
 
 /* Matcher::getSWResult (Matcher.cpp:60-142) in SCORE_COV mode + Alignment::checkCriteria
  * (Alignment.cpp:548-567) with covThr 0, seqIdThr 0. */
+static int align_pair(const mko_align_ctx *ctx, const uint8_t *q, const int8_t *cb, const mko_profile *prof, int bias, int qlen,
+                      const uint8_t *t, int tlen, uint32_t db_key, mko_aln_result *out);
+
 int mko_align_pair(const mko_align_ctx *ctx, const uint8_t *q, const int8_t *cb, int bias, int qlen,
                    const uint8_t *t, int tlen, uint32_t db_key, mko_aln_result *out) {
+    return align_pair(ctx, q, cb, NULL, bias, qlen, t, tlen, db_key, out);
+}
+
+/* the same for a profile query (Matcher::initQuery, Matcher.cpp:53-54) */
+int mko_align_pair_profile(const mko_align_ctx *ctx, const mko_profile *prof, int bias, const uint8_t *t, int tlen, uint32_t db_key,
+                           mko_aln_result *out) {
+    return align_pair(ctx, NULL, NULL, prof, bias, prof->L, t, tlen, db_key, out);
+}
+
+static int align_pair(const mko_align_ctx *ctx, const uint8_t *q, const int8_t *cb, const mko_profile *prof, int bias, int qlen,
+                      const uint8_t *t, int tlen, uint32_t db_key, mko_aln_result *out) {
     mko_sw_result r;
-    mko_sw_forward(ctx->mat, q, cb, bias, qlen, t, tlen, ctx->gap_open, ctx->gap_extend, ctx->lanes_byte, ctx->lanes_word, &r);
+    if (prof) mko_sw_forward_profile(prof, bias, t, tlen, ctx->gap_open, ctx->gap_extend, ctx->lanes_byte, ctx->lanes_word, &r);
+    else mko_sw_forward(ctx->mat, q, cb, bias, qlen, t, tlen, ctx->gap_open, ctx->gap_extend, ctx->lanes_byte, ctx->lanes_word, &r);
     memset(out, 0, sizeof(*out));
     out->db_key = db_key; out->q_len = qlen; out->db_len = tlen; out->raw_score = r.score;
     if (r.t_end == -1) return 0;   /* nothing aligned: the reference returns uninitialised fields here (:385-388) */
@@ -193,7 +239,8 @@ int mko_align_pair(const mko_align_ctx *ctx, const uint8_t *q, const int8_t *cb,
     float qcov = compute_cov(0, (unsigned) r.q_end, (unsigned) qlen);
     float tcov = compute_cov(0, (unsigned) r.t_end, (unsigned) tlen);
     if (!(evalue > ctx->eval_thr)) {
-        mko_sw_reverse(ctx->mat, q, cb, bias, qlen, t, tlen, ctx->gap_open, ctx->gap_extend, ctx->lanes_byte, ctx->lanes_word, &r);
+        if (prof) mko_sw_reverse_profile(prof, bias, t, ctx->gap_open, ctx->gap_extend, ctx->lanes_byte, ctx->lanes_word, &r);
+        else mko_sw_reverse(ctx->mat, q, cb, bias, qlen, t, tlen, ctx->gap_open, ctx->gap_extend, ctx->lanes_byte, ctx->lanes_word, &r);
         qcov = compute_cov((unsigned) r.q_start, (unsigned) r.q_end, (unsigned) qlen);
         tcov = compute_cov((unsigned) r.t_start, (unsigned) r.t_end, (unsigned) tlen);
     }

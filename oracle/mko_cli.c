@@ -271,12 +271,12 @@ static int cmd_orfs(int argc, char **argv) {
 
 /* resultspercontig + collectoptimalset over the outputs of `orfs` and `pipeline`: same format as `ref_harness exons` */
 static int cmd_exons(int argc, char **argv) {
-    (void) argc;
     lines_t T = read_lines(argv[2]), C = read_lines(argv[3]), O = read_lines(argv[4]), A = read_lines(argv[5]);
     FILE *out = fopen(argv[6], "w");
     if (!out) return 1;
     uint64_t residues = 0;
     for (size_t i = 0; i < T.n; i++) residues += (uint64_t) T.len[i];
+    for (int i = 7; i + 1 < argc; i++) if (!strcmp(argv[i], "--dbres")) residues = (uint64_t) atoll(argv[i + 1]);   /* a profile DB */
     mko_exon_params P;
     mko_exon_params_default(&P, residues);
     /* ORF k: contig, header coordinates */
@@ -330,6 +330,177 @@ static int cmd_exons(int argc, char **argv) {
     return 0;
 }
 
+
+/* The profile-target search of predictexons (M/data/workflow/searchslicedtargetprofile.sh): profiles = queries, the
+ * fragments = indexed targets; prefilter, align, swapresults.
+ *   mko_cli profilesearch <profile DB data file> <its .index> <fragments.txt> <outdir> [-s 4] [-e 100] [--l2 BYTES] [--lanes-byte 32] ...
+ * writes pref.txt / aln.txt ('>profile key' blocks in key order) and swapped.txt ('>fragment number' blocks, every fragment).
+ * Parameters as Search.cpp:357-399 sets them: --max-seqs = max(300, #fragments) for the prefilter, the e-value threshold scaled by
+ * #fragments / #profiles and passed on as text ("%g": Parameters::createParameterString streams the double), swapresults -e DBL_MAX.
+ * The workflow aligns twice (key lists per slice, then the merged lists again): with --max-accept / --max-rejected at INT_MAX both
+ * passes accept the same pairs, so one pass is the result. */
+typedef struct { unsigned int key; size_t off, len; } pindex_t;
+static int pindex_cmp(const void *a, const void *b) { unsigned int x = ((const pindex_t *) a)->key, y = ((const pindex_t *) b)->key; return x < y ? -1 : x > y; }
+
+static int cmd_profilesearch(int argc, char **argv) {
+    const char *outdir = argv[5];
+    float sens = 4.0f; double evalThr = 100.0; int lb = 32, lw = 16, tl = 4;
+    const char *keysPath = NULL;   /* line i = DB key of fragment i; fragments.txt is in the order of the data offsets of the fragment DB
+                                      (the prefilter's target numbering, DBReader LINEAR_ACCCESS: Prefiltering.cpp:163) */
+    long l2 = sysconf(_SC_LEVEL2_CACHE_SIZE);
+    if (l2 <= 0) l2 = 262144;
+    for (int a = 6; a < argc; a++) {
+        if (!strcmp(argv[a], "-s")) sens = (float) atof(argv[++a]);
+        else if (!strcmp(argv[a], "-e")) evalThr = atof(argv[++a]);
+        else if (!strcmp(argv[a], "--lanes-byte")) lb = atoi(argv[++a]);
+        else if (!strcmp(argv[a], "--lanes-word")) lw = atoi(argv[++a]);
+        else if (!strcmp(argv[a], "--tantan-lanes")) tl = atoi(argv[++a]);
+        else if (!strcmp(argv[a], "--l2")) l2 = atol(argv[++a]);
+        else if (!strcmp(argv[a], "--keys")) keysPath = argv[++a];
+    }
+    mkdir(outdir, 0755);
+    /* profile DB */
+    FILE *f = fopen(argv[2], "rb");
+    if (!f) { fprintf(stderr, "cannot open %s\n", argv[2]); return 2; }
+    fseek(f, 0, SEEK_END); const size_t dataSize = (size_t) ftell(f); fseek(f, 0, SEEK_SET);
+    char *pdata = (char *) malloc(dataSize + 1);
+    if (fread(pdata, 1, dataSize, f) != dataSize) return 2;
+    fclose(f);
+    lines_t IX = read_lines(argv[3]);
+    const size_t nProf = IX.n;
+    pindex_t *pix = (pindex_t *) malloc((nProf + 1) * sizeof(pindex_t));
+    size_t lengthSum = 0;
+    for (size_t i = 0; i < nProf; i++) {
+        unsigned long long o, l;
+        if (sscanf(IX.s[i], "%u\t%llu\t%llu", &pix[i].key, &o, &l) != 3) return 2;
+        pix[i].off = (size_t) o; pix[i].len = (size_t) l; lengthSum += (size_t) l;
+    }
+    qsort(pix, nProf, sizeof(pindex_t), pindex_cmp);
+    const uint64_t profDbRes = (uint64_t) (lengthSum / 25 - nProf);          /* DBReader::getAminoAcidDBSize, DBReader.cpp:589-598 */
+    /* fragments */
+    lines_t T = read_lines(argv[4]);
+    uint8_t *tres; uint64_t *toff;
+    encode(&T, &tres, &toff);
+    uint32_t *fragKey = (uint32_t *) malloc((T.n + 1) * sizeof(uint32_t)), *fragOfKey = (uint32_t *) malloc((T.n + 1) * sizeof(uint32_t));
+    for (size_t i = 0; i < T.n; i++) fragKey[i] = (uint32_t) i;
+    if (keysPath) {
+        lines_t K = read_lines(keysPath);
+        if (K.n != T.n) { fprintf(stderr, "--keys: %zu keys for %zu fragments\n", K.n, T.n); return 2; }
+        for (size_t i = 0; i < T.n; i++) fragKey[i] = (uint32_t) strtoul(K.s[i], NULL, 10);
+    }
+    for (size_t i = 0; i < T.n; i++) {
+        if (fragKey[i] >= T.n) { fprintf(stderr, "fragment keys must be 0 .. n-1\n"); return 2; }
+        fragOfKey[fragKey[i]] = (uint32_t) i;
+    }
+    mko_submat kmerMat, ungMat, alnMat;
+    mko_submat_init(&kmerMat, MKO_MAT_BLOSUM62, 8.0f, -0.2f);   /* Prefiltering.cpp:72-76: for profile queries the k-mer matrix (here
+                                                                    only the background of the target masking) is --sub-mat, not the seed matrix */
+    mko_submat_init(&ungMat, MKO_MAT_BLOSUM62, 2.0f, -0.2f);
+    mko_submat_init(&alnMat, MKO_MAT_BLOSUM62, 2.0f, 0.0f);
+    float base = 134.35;                                                     /* Prefiltering.cpp:1038-1040: profile search, k = 6 */
+    float kmerThrBest = base - (sens * 6.15);
+    const int kmerThr = (int) kmerThrBest;
+    mko_index *ix = mko_index_build(&kmerMat, tres, toff, (uint32_t) T.n, 0 /* Prefiltering.cpp:525-527 */, 1, tl);
+    mko_prefilter_ctx pc;
+    pc.kmer_mat = &kmerMat; pc.ungapped_mat = &ungMat; pc.three = NULL; pc.index = ix; pc.kmer_thr = kmerThr;
+    pc.max_hits = (int) (T.n > 300 ? T.n : 300);                              /* Search.cpp:372 */
+    pc.min_diag_score = 15; pc.bin_count = mko_bin_count_for(T.n, (uint64_t) l2); pc.bias_scale = 1.0f;
+    {   /* Search.cpp:366-368 and the text round trip of the parameter string */
+        evalThr *= ((float) T.n) / nProf;
+        char txt[64];
+        snprintf(txt, sizeof(txt), "%g", evalThr);
+        evalThr = strtod(txt, NULL);
+    }
+    mko_evaluer ev, evSwap;
+    mko_evaluer_init(&ev, toff[T.n]);                                         /* Alignment.cpp:262: the target DB = the fragments */
+    mko_evaluer_init(&evSwap, profDbRes);                                     /* swapresults.cpp:76-77,102 */
+    mko_align_ctx ac;
+    ac.mat = &alnMat; ac.evaluer = &ev; ac.gap_open = 11; ac.gap_extend = 1; ac.eval_thr = evalThr; ac.aln_len_thr = 11;
+    ac.lanes_byte = lb; ac.lanes_word = lw; ac.bias_scale = 1.0f;
+    char **prefOut = (char **) calloc(nProf, sizeof(char *)), **alnOut = (char **) calloc(nProf, sizeof(char *));
+    mko_aln_result **alnRes = (mko_aln_result **) calloc(nProf, sizeof(mko_aln_result *));
+    int *alnCnt = (int *) calloc(nProf, sizeof(int));
+    unsigned long long totalHits = 0, passed = 0, kmers = 0, dbm = 0, positions = 0;
+#pragma omp parallel
+    {
+        mko_hit *hits = (mko_hit *) malloc(((size_t) pc.max_hits + 1) * sizeof(mko_hit));
+#pragma omp for schedule(dynamic, 1) reduction(+: totalHits, passed, kmers, dbm, positions)
+        for (size_t id = 0; id < nProf; id++) {
+            const int L = (int) (((pix[id].len > 1 ? pix[id].len : 1) - 1) / 25);   /* DBReader::getSeqLen, DBReader.h:224-227 */
+            mko_profile *p = mko_profile_map(pdata + pix[id].off, L);
+            mko_prefilter_stats st;
+            int nh = mko_prefilter_profile(&pc, p, hits, &st);
+            if (nh < 0) { fprintf(stderr, "profile %u: unsupported overflow path\n", pix[id].key); nh = 0; }
+            totalHits += (unsigned long long) nh; kmers += st.kmer_list_len; dbm += st.db_matches; positions += (unsigned long long) L;
+            size_t n = 0;
+            prefOut[id] = (char *) malloc((size_t) nh * 40 + 1);
+            for (int h = 0; h < nh; h++) { mko_hit pr = hits[h]; pr.seq_id = fragKey[pr.seq_id]; n += mko_format_hit(prefOut[id] + n, &pr); }
+            prefOut[id][n] = 0;
+            mko_aln_result *res = (mko_aln_result *) malloc(((size_t) nh + 1) * sizeof(mko_aln_result));
+            int nr = 0;
+            const int bias = mko_sw_profile_bias(p);
+            for (int h = 0; h < nh; h++) {
+                const uint32_t t = hits[h].seq_id;
+                int ok = mko_align_pair_profile(&ac, p, bias, tres + toff[t], (int) (toff[t + 1] - toff[t]), fragKey[t], &res[nr]);
+                if (ok < 0) { fprintf(stderr, "Score of forward/backward SW differ (profile %u fragment %u)\n", pix[id].key, t); exit(1); }
+                if (ok) { nr++; passed++; }
+            }
+            if (nr > 1) qsort(res, (size_t) nr, sizeof(mko_aln_result), mko_aln_compare);
+            alnOut[id] = (char *) malloc((size_t) nr * 128 + 1);
+            n = 0;
+            for (int r = 0; r < nr; r++) n += mko_format_aln(alnOut[id] + n, &res[r]);
+            alnOut[id][n] = 0;
+            alnRes[id] = res; alnCnt[id] = nr;
+            mko_profile_free(p);
+        }
+        free(hits);
+    }
+    char path[4096];
+    snprintf(path, sizeof(path), "%s/pref.txt", outdir);
+    f = fopen(path, "w");
+    for (size_t id = 0; id < nProf; id++) { fprintf(f, ">%u\n", pix[id].key); fputs(prefOut[id], f); }
+    fclose(f);
+    snprintf(path, sizeof(path), "%s/aln.txt", outdir);
+    f = fopen(path, "w");
+    for (size_t id = 0; id < nProf; id++) { fprintf(f, ">%u\n", pix[id].key); fputs(alnOut[id], f); }
+    fclose(f);
+    /* swapresults (util/swapresults.cpp:283-333): every printed record is parsed back (bit score, 3-decimal identity), its e-value
+     * recomputed for the swapped search, the lists sorted with Matcher::compareHits; every fragment gets an entry */
+    size_t *cnt = (size_t *) calloc(T.n + 1, sizeof(size_t));
+    for (size_t id = 0; id < nProf; id++) for (int r = 0; r < alnCnt[id]; r++) cnt[alnRes[id][r].db_key + 1]++;
+    for (size_t t = 0; t < T.n; t++) cnt[t + 1] += cnt[t];
+    mko_aln_result *sw = (mko_aln_result *) malloc((cnt[T.n] + 1) * sizeof(mko_aln_result));
+    size_t *fill = (size_t *) malloc((T.n + 1) * sizeof(size_t));
+    memcpy(fill, cnt, (T.n + 1) * sizeof(size_t));
+    for (size_t id = 0; id < nProf; id++) {
+        for (int r = 0; r < alnCnt[id]; r++) {
+            mko_aln_result x = alnRes[id][r];
+            const uint32_t frag = x.db_key;
+            char buf[256], sid[32];
+            mko_format_aln(buf, &x);
+            sscanf(buf, "%*u\t%*d\t%31s", sid);
+            x.seq_id = (float) strtod(sid, NULL);                            /* Matcher::parseAlignmentRecord, Matcher.cpp:218-219 */
+            mko_swap_result(&evSwap, &x, pix[id].key);
+            sw[fill[frag]++] = x;
+        }
+    }
+    snprintf(path, sizeof(path), "%s/swapped.txt", outdir);
+    f = fopen(path, "w");
+    char buf[256];
+    for (size_t t = 0; t < T.n; t++) {
+        fprintf(f, ">%zu\n", t);
+        const size_t n = cnt[t + 1] - cnt[t];
+        if (n > 1) qsort(sw + cnt[t], n, sizeof(mko_aln_result), mko_aln_compare);
+        for (size_t k = 0; k < n; k++) { size_t l = mko_format_aln(buf, &sw[cnt[t] + k]); fwrite(buf, 1, l, f); }
+    }
+    fclose(f);
+    printf("{\"profiles\": %zu, \"fragments\": %zu, \"kmer_thr\": %d, \"eval_thr\": %.17g, \"profile_db_residues\": %llu, \"masked_residues\": %llu, \"pref_hits\": %llu, "
+           "\"passed\": %llu, \"kmers_per_pos\": %.4f, \"db_matches_per_profile\": %.1f}\n",
+           nProf, T.n, kmerThr, evalThr, (unsigned long long) profDbRes, (unsigned long long) ix->masked_residues, totalHits, passed,
+           positions ? (double) kmers / (double) positions : 0.0, nProf ? (double) dbm / (double) nProf : 0.0);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) { fprintf(stderr, "usage: mko_cli pipeline|sw|submat ...\n"); return 2; }
     if (!strcmp(argv[1], "pipeline") && argc >= 5) return cmd_pipeline(argc, argv);
@@ -337,5 +508,6 @@ int main(int argc, char **argv) {
     if (!strcmp(argv[1], "submat") && argc >= 5) return cmd_submat(argc, argv);
     if (!strcmp(argv[1], "orfs") && argc >= 4) return cmd_orfs(argc, argv);
     if (!strcmp(argv[1], "exons") && argc >= 7) return cmd_exons(argc, argv);
+    if (!strcmp(argv[1], "profilesearch") && argc >= 6) return cmd_profilesearch(argc, argv);
     return 2;
 }

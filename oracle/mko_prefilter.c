@@ -95,7 +95,82 @@ static int hit_cmp(const void *a, const void *b) {   /* hit_t::compareHitsByScor
     return 0;
 }
 
+/* The k-mer list of one k-mer start: the sequence path multiplies two 3-mer rows (mko_kmer_list6), the profile path six
+ * position rows (mko_profile_kmer_list).  Returns the list length, or (size_t) -1 for a start that is skipped (an X in the window). */
+typedef size_t (*kmer_gen_fn)(void *user, int pos, uint64_t **klist, size_t *kcap, uint64_t *listLen);
+
+static int prefilter_core(const mko_prefilter_ctx *ctx, const uint8_t *q, int L, const int8_t *profile, kmer_gen_fn gen, void *user,
+                          mko_hit *out, mko_prefilter_stats *st);
+
+typedef struct { const mko_prefilter_ctx *ctx; const uint8_t *q; const float *bias; } seq_gen_t;
+
+static size_t seq_kmer_gen(void *user, int i, uint64_t **klist, size_t *kcap, uint64_t *listLen) {
+    const seq_gen_t *g = (const seq_gen_t *) user;
+    uint8_t kmer[6];
+    int hasX = 0;
+    float biasCorrection = 0;
+    for (int p = 0; p < 6; p++) {
+        kmer[p] = g->q[i + SPACED6[p]];
+        hasX |= (kmer[p] == MKO_X);
+        biasCorrection += g->bias[i + SPACED6[p]];
+    }
+    if (hasX) return (size_t) -1;
+    short b = (short) ((biasCorrection < 0.0) ? (double) biasCorrection - 0.5 : (double) biasCorrection + 0.5);
+    int kms = g->ctx->kmer_thr - b;
+    short kmerMatchScore = (short) (kms > 0 ? kms : 0);
+    size_t nk = mko_kmer_list6(g->ctx->three, kmer, kmerMatchScore, *klist, *kcap);
+    if (nk > *kcap) {
+        *kcap = nk;
+        *klist = (uint64_t *) realloc(*klist, *kcap * sizeof(uint64_t));
+        nk = mko_kmer_list6(g->ctx->three, kmer, kmerMatchScore, *klist, *kcap);
+    }
+    *listLen += nk;
+    return nk;
+}
+
 int mko_prefilter_query(const mko_prefilter_ctx *ctx, const uint8_t *q, int L, mko_hit *out, mko_prefilter_stats *st) {
+    float *bias = (float *) malloc((size_t) (L > 0 ? L : 1) * sizeof(float));
+    int8_t *profile = (int8_t *) malloc((size_t) (L > 0 ? L : 1) * 21);
+    mko_comp_bias(ctx->kmer_mat, q, L, ctx->bias_scale, bias);               /* QueryMatcher.cpp:91-99 */
+    mko_ungapped_profile(ctx->ungapped_mat, q, L, bias, profile);            /* :100-102 */
+    seq_gen_t g = {ctx, q, bias};
+    int rc = prefilter_core(ctx, q, L, profile, seq_kmer_gen, &g, out, st);
+    free(bias); free(profile);
+    return rc;
+}
+
+/* Profile query (QueryMatcher.cpp:91-99: no composition bias; UngappedAlignment::createProfile :385-408: the diagonal scores come
+ * from profile_for_alignment, the X column stays 0; Sequence::kmerContainsX looks at the profile's query letters). */
+typedef struct { const mko_prefilter_ctx *ctx; const mko_profile *p; } prof_gen_t;
+
+static size_t prof_kmer_gen(void *user, int i, uint64_t **klist, size_t *kcap, uint64_t *listLen) {
+    const prof_gen_t *g = (const prof_gen_t *) user;
+    for (int p = 0; p < 6; p++) if (g->p->query[i + SPACED6[p]] == MKO_X) return (size_t) -1;
+    int kms = g->ctx->kmer_thr;                                              /* bias 0: max(kmerThr - 0, 0), :242-243 */
+    short kmerMatchScore = (short) (kms > 0 ? kms : 0);
+    size_t nk = mko_profile_kmer_list(g->p, i, kmerMatchScore, *klist, *kcap);
+    if (nk > *kcap) {
+        *kcap = nk;
+        *klist = (uint64_t *) realloc(*klist, *kcap * sizeof(uint64_t));
+        nk = mko_profile_kmer_list(g->p, i, kmerMatchScore, *klist, *kcap);
+    }
+    *listLen += nk;
+    return nk;
+}
+
+int mko_prefilter_profile(const mko_prefilter_ctx *ctx, const mko_profile *p, mko_hit *out, mko_prefilter_stats *st) {
+    const int L = p->L;
+    int8_t *profile = (int8_t *) calloc((size_t) (L > 0 ? L : 1) * 21, 1);
+    for (int pos = 0; pos < L; pos++)
+        for (int a = 0; a < 20; a++) profile[pos * 21 + a] = p->aln[(size_t) a * L + pos];
+    prof_gen_t g = {ctx, p};
+    int rc = prefilter_core(ctx, p->query, L, profile, prof_kmer_gen, &g, out, st);
+    free(profile);
+    return rc;
+}
+
+static int prefilter_core(const mko_prefilter_ctx *ctx, const uint8_t *q, int L, const int8_t *profile, kmer_gen_fn gen, void *user,
+                          mko_hit *out, mko_prefilter_stats *st) {
     const mko_index *ix = ctx->index;
     const int B = ctx->bin_count;
     int shift = 0;
@@ -104,10 +179,6 @@ int mko_prefilter_query(const mko_prefilter_ctx *ctx, const uint8_t *q, int L, m
     const size_t maxDbMatches = (dbSize > 1000000 ? dbSize : 1000000) * 2;
     const size_t foundDiagonalsSize = dbSize > 1000000 ? dbSize : 1000000;
     int maxHits = ctx->max_hits < (int) dbSize ? ctx->max_hits : (int) dbSize;
-    float *bias = (float *) malloc((size_t) (L > 0 ? L : 1) * sizeof(float));
-    int8_t *profile = (int8_t *) malloc((size_t) (L > 0 ? L : 1) * 21);
-    mko_comp_bias(ctx->kmer_mat, q, L, ctx->bias_scale, bias);               /* QueryMatcher.cpp:91-99 */
-    mko_ungapped_profile(ctx->ungapped_mat, q, L, bias, profile);            /* :100-102 */
 
     /* ---- match() (:213-346): gather index entries in (i, k-mer list, index list) order ---- */
     size_t cap = 1 << 16, n = 0;
@@ -117,25 +188,8 @@ int mko_prefilter_query(const mko_prefilter_ctx *ctx, const uint8_t *q, int L, m
     uint64_t kmerListLen = 0;
     int rc = 0;
     for (int i = 0; i + 10 <= L; i++) {
-        uint8_t kmer[6];
-        int hasX = 0;
-        float biasCorrection = 0;
-        for (int p = 0; p < 6; p++) {
-            kmer[p] = q[i + SPACED6[p]];
-            hasX |= (kmer[p] == MKO_X);
-            biasCorrection += bias[i + SPACED6[p]];
-        }
-        if (hasX) continue;
-        short b = (short) ((biasCorrection < 0.0) ? (double) biasCorrection - 0.5 : (double) biasCorrection + 0.5);
-        int kms = ctx->kmer_thr - b;
-        short kmerMatchScore = (short) (kms > 0 ? kms : 0);
-        size_t nk = mko_kmer_list6(ctx->three, kmer, kmerMatchScore, klist, kcap);
-        if (nk > kcap) {
-            kcap = nk;
-            klist = (uint64_t *) realloc(klist, kcap * sizeof(uint64_t));
-            nk = mko_kmer_list6(ctx->three, kmer, kmerMatchScore, klist, kcap);
-        }
-        kmerListLen += nk;
+        const size_t nk = gen(user, i, &klist, &kcap, &kmerListLen);
+        if (nk == (size_t) -1) continue;
         for (size_t k = 0; k < nk; k++) {
             const uint64_t o0 = ix->offsets[klist[k]], o1 = ix->offsets[klist[k] + 1];
             const size_t sz = (size_t) (o1 - o0);
@@ -281,7 +335,7 @@ int mko_prefilter_query(const mko_prefilter_ctx *ctx, const uint8_t *q, int L, m
         free(binned); free(bs); free(dup); free(cand); free(tmp);
     }
 done:
-    free(hits); free(klist); free(bias); free(profile);
+    free(hits); free(klist);
     return rc;
 }
 

@@ -1,6 +1,7 @@
 """CPU tests: the C oracle against the golden fixtures produced by the reference's own code, and
 (when the harness is present) against a live run of the reference harness."""
 import gzip
+import json
 import os
 import subprocess
 
@@ -94,6 +95,42 @@ def test_oracle_matches_the_real_process(tmp_path):
     subprocess.check_call([oracle.CLI, "pipeline", str(tmp_path / "t.txt"), str(tmp_path / "q.txt"), str(tmp_path / "out"), "--l2", "2097152"], stdout=subprocess.DEVNULL)
     assert open(tmp_path / "out" / "pref.txt").read() == _text("e2e_process_pref.txt.gz")
     assert open(tmp_path / "out" / "aln.txt").read() == _text("e2e_process_aln.txt.gz")
+
+
+def _profile_inputs(tmp_path):
+    """the fixtures of the profile-target path as files: the profile DB, the fragments in the order of their data offsets in the
+    fragment DB (= the prefilter's target numbering) and their DB keys"""
+    import gzip
+    (tmp_path / "prof.bin").write_bytes(gzip.open(os.path.join(GOLD, "prof_db.bin.gz"), "rb").read())
+    frags = [l.rsplit("\t", 1)[1] for l in _text("e2e_process_orfs.txt.gz").splitlines()]
+    order = [int(x) for x in _text("prof_frag_order.txt.gz").split()]
+    (tmp_path / "frags.txt").write_text("\n".join(frags[k] for k in order) + "\n")
+    (tmp_path / "keys.txt").write_text("\n".join(str(k) for k in order) + "\n")
+    return os.path.join(GOLD, "prof_db.index")
+
+
+def test_oracle_profile_search_matches_the_real_process(tmp_path):
+    """Profile targets (BASELINE config 4): what the REAL `metaeuk predictexons contigsDB profileDB` left behind
+    (tests/golden/make_profile_golden.sh: searchslicedtargetprofile.sh = prefilter with profile queries, align, swapresults, then the
+    exon stage) against the oracle's restatement of Sequence::mapProfile, the profile k-mer lists, the PROFILE_SEQ Smith-Waterman
+    and swapResult -- every stage byte for byte."""
+    oracle.build()
+    index = _profile_inputs(tmp_path)
+    out = subprocess.check_output([oracle.CLI, "profilesearch", str(tmp_path / "prof.bin"), index, str(tmp_path / "frags.txt"),
+                                   str(tmp_path / "out"), "--l2", "2097152", "--keys", str(tmp_path / "keys.txt")])
+    info = json.loads(out)
+    assert info["kmer_thr"] == 109 and info["eval_thr"] == 24084 and info["masked_residues"] == 23422   # the values the real run logged
+    assert open(tmp_path / "out" / "pref.txt").read() == _text("prof_pref.txt.gz")
+    assert open(tmp_path / "out" / "aln.txt").read() == _text("prof_aln.txt.gz")
+    assert open(tmp_path / "out" / "swapped.txt").read() == _text("prof_search_res.txt.gz")
+    # the exon stage on the swapped lists; collectoptimalset's e-values use the profile DB's column count
+    (tmp_path / "c.txt").write_text(_text("e2e_contigs.txt.gz"))
+    subprocess.check_call([oracle.CLI, "orfs", str(tmp_path / "c.txt"), str(tmp_path / "orfs.txt")], stdout=subprocess.DEVNULL)
+    (tmp_path / "t.txt").write_text("")
+    subprocess.check_call([oracle.CLI, "exons", str(tmp_path / "t.txt"), str(tmp_path / "c.txt"), str(tmp_path / "orfs.txt"),
+                           str(tmp_path / "out" / "swapped.txt"), str(tmp_path / "exons.txt"), "--dbres", str(info["profile_db_residues"])],
+                          stdout=subprocess.DEVNULL)
+    assert (tmp_path / "exons.txt").read_text() == _text("prof_calls.txt.gz")
 
 
 @pytest.mark.skipif(not os.path.exists(oracle.REF) or not os.path.isdir("/root/reference"), reason="reference harness not built here")
