@@ -76,6 +76,10 @@ typedef struct {
     int simd_lanes_word;      /* 16 = AVX2,  8 = SSE4.1 */
     int simd_lanes_double;    /*  4 = AVX2,  2 = SSE4.1  (tantan partial sums) */
     uint64_t host_l2_bytes;   /* Util::getL2CacheSize() of the host being reproduced (tie order at --max-seqs) */
+    int profile_search;       /* 1: the queries are profiles (mk_profiles_create) and the targets sequences -- the inverted search of
+                                 searchslicedtargetprofile.sh.  Changes what the reference changes: k-mer threshold 134.35 - 6.15 s
+                                 (Prefiltering.cpp:1038-1040), no self-score filter in the target index (:525-527), the background of
+                                 the target masking from --sub-mat x8 instead of the seed matrix (:72-76) */
 } mk_params;
 
 /* ---- process-wide ---- */
@@ -129,6 +133,32 @@ void mk_queries_destroy(mk_queries *q);
  * (QueryMatcher.cpp:225-244; -1 = no k-mer / contains X), int8 diagonal correction (UngappedAlignment.cpp:391-396),
  * int8 SW composition bias (StripedSmithWaterman.cpp:1228-1235).  Each array has offsets[n_queries] entries. */
 int mk_queries_derived(const mk_queries *q, int16_t *kmer_thr, int8_t *diag_corr, int8_t *sw_bias8);
+
+/* ---- profile queries: `predictexons` against a PROFILE database runs the reference's sliced
+ * target-profile search (M/data/workflow/searchslicedtargetprofile.sh:108,130,181,190): the profiles are the QUERIES of prefilter and
+ * align, the ORF fragments the indexed targets (mk_targetdb_create with params->profile_search = 1), and swapresults turns the
+ * lists round (mk_swap_alignments).  columns = the profiles' 25-byte columns (Sequence::PROFILE_READIN_SIZE, M/src/commons/Sequence.h:
+ * 458-471: 20 int8 scores, query letter, consensus letter, neff, 2 gap bytes) concatenated WITHOUT the entries' trailing NUL;
+ * col_offsets[n+1] in columns.  Replaces Sequence::mapProfile (Sequence.cpp:241-292), the profile k-mer lists
+ * (KmerGenerator.cpp:30-39, Sequence.cpp:294-305), UngappedAlignment::createProfile's profile branch (UngappedAlignment.cpp:385-408)
+ * and ssw_init / ssw_align_private<PROFILE_SEQ> (StripedSmithWaterman.cpp:296-298,1243-1300).  The handle is a query batch:
+ * mk_prefilter, mk_align, mk_search and the result getters take it. */
+int mk_profiles_create(const uint8_t *columns, const uint64_t *col_offsets, uint32_t n_profiles, const mk_params *params, mk_queries **out);
+/* test hook: the derived per-column arrays -- query letters [cols], sorted scores + residue numbers [cols][40], alignment profile
+ * [cols][32], k-mer threshold per start [cols] */
+int mk_profiles_derived(const mk_queries *q, uint8_t *letters, int8_t *sorted40, int8_t *aln32, int16_t *kmer_thr);
+
+/* swapresults (M/src/util/swapresults.cpp:283-333 + Matcher::result_t::swapResult, Matcher.h:93-115) on arrays: alns[offsets[i] ..
+ * offsets[i+1]) = the accepted alignments of query i (db_key = target INDEX, as mk_align_result returns them); the result lists them
+ * per target: db_key = query_keys[i] (NULL: i), query and target columns exchanged, the e-value recomputed from the printed bit score
+ * for a search against `swapped_db_residues` (DBReader::getAminoAcidDBSize of the ORIGINAL target side = the profile DB: columns
+ * - per-entry rounding, DBReader.cpp:589-598), the identity as re-read from its 3-decimal text, every list sorted with
+ * Matcher::compareHits.  Host code, no GPU. */
+typedef struct mk_swapped mk_swapped;
+int mk_swap_alignments(const mk_alignment *alns, const uint64_t *offsets, uint32_t n_queries, const uint32_t *query_keys,
+                       uint32_t n_targets, uint64_t swapped_db_residues, const mk_params *params, mk_swapped **out);
+int mk_swapped_result(const mk_swapped *s, const mk_alignment **alns, const uint64_t **offsets /* n_targets + 1 */);
+void mk_swapped_destroy(mk_swapped *s);
 
 /* ---- prefilter: batch form of QueryMatcher::matchQuery (QueryMatcher.cpp:85-211).
  * Query i's hits are hits[offsets[i] .. offsets[i+1]), sorted like the reference (|score| desc,

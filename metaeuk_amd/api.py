@@ -18,7 +18,8 @@ class Params(C.Structure):
                 ("min_ungapped_score", C.c_int), ("comp_bias_corr", C.c_int), ("comp_bias_scale", C.c_float),
                 ("mask", C.c_int), ("mask_prob", C.c_float), ("gap_open", C.c_int), ("gap_extend", C.c_int),
                 ("evalue_thr", C.c_double), ("min_aln_len", C.c_int), ("simd_lanes_byte", C.c_int),
-                ("simd_lanes_word", C.c_int), ("simd_lanes_double", C.c_int), ("host_l2_bytes", C.c_uint64)]
+                ("simd_lanes_word", C.c_int), ("simd_lanes_double", C.c_int), ("host_l2_bytes", C.c_uint64),
+                ("profile_search", C.c_int)]
 
 
 class Hit(C.Structure):
@@ -44,7 +45,8 @@ EXPORTS = ["mk_init", "mk_last_error", "mk_default_params", "mk_device_name", "m
            "mk_queries_create", "mk_queries_destroy", "mk_queries_derived", "mk_prefilter", "mk_prefilter_result", "mk_prefilter_result_set",
            "mk_align", "mk_align_result", "mk_search", "mk_extract_orfs", "mk_orfs_result", "mk_queries_from_orfs",
            "mk_orfs_destroy", "mk_format_orf_header", "mk_sw_pairs", "mk_ungapped",
-           "mk_kernel_stats", "mk_kernel_stats_reset", "mk_format_hit", "mk_format_alignment", "mk_format_hits", "mk_format_alignments", "mk_targetdb_set_keys"]
+           "mk_kernel_stats", "mk_kernel_stats_reset", "mk_format_hit", "mk_format_alignment", "mk_format_hits", "mk_format_alignments", "mk_targetdb_set_keys",
+           "mk_profiles_create", "mk_profiles_derived", "mk_swap_alignments", "mk_swapped_result", "mk_swapped_destroy"]
 
 
 def lib():
@@ -221,6 +223,51 @@ class Queries:
             self.close()
         except Exception:
             pass
+
+
+class Profiles(Queries):
+    """a batch of profile queries (the reference's profile-target search makes the profiles the queries): `entries` = the profile DB's
+    entries as bytes, 25 bytes per column (a trailing NUL per entry is dropped).  Search it against a TargetDB whose params have
+    profile_search = 1."""
+
+    def __init__(self, entries, params=None):
+        self.params = params or default_params()
+        cols = [e[:len(e) - (len(e) % 25)] for e in entries]
+        self.off = np.zeros(len(cols) + 1, dtype=np.uint64)
+        self.off[1:] = np.cumsum([len(c) // 25 for c in cols], dtype=np.uint64)
+        self.columns = np.frombuffer(b"".join(cols), dtype=np.uint8).copy() if cols else np.zeros(0, dtype=np.uint8)
+        self.n = len(cols)
+        self.h = C.c_void_p()
+        _chk(lib().mk_profiles_create(_p(self.columns), _p(self.off), C.c_uint32(self.n), C.byref(self.params), C.byref(self.h)))
+
+    def derived(self):
+        """(query letters u8 [cols], sorted scores + residue numbers i8 [cols, 40], alignment profile i8 [cols, 32], k-mer threshold i16 [cols])"""
+        total = int(self.off[-1])
+        le = np.zeros(total, dtype=np.uint8); so = np.zeros((total, 40), dtype=np.int8); al = np.zeros((total, 32), dtype=np.int8)
+        kt = np.zeros(total, dtype=np.int16)
+        _chk(lib().mk_profiles_derived(self.h, _p(le), _p(so), _p(al), _p(kt)))
+        return le, so, al, kt
+
+
+def swap_alignments(alns, aln_off, n_targets, swapped_db_residues, query_keys=None, params=None):
+    """swapresults on the arrays of align_result(): -> (ctypes array of Alignment, offsets uint64[n_targets + 1]) per target index (copies)"""
+    p = params or default_params()
+    aln_off = np.ascontiguousarray(aln_off, dtype=np.uint64)
+    keys = None if query_keys is None else np.ascontiguousarray(query_keys, dtype=np.uint32)
+    h = C.c_void_p()
+    _chk(lib().mk_swap_alignments(alns, _p(aln_off), C.c_uint32(len(aln_off) - 1), None if keys is None else _p(keys), C.c_uint32(n_targets),
+                                  C.c_uint64(swapped_db_residues), C.byref(p), C.byref(h)))
+    try:
+        ap, op = C.c_void_p(), C.c_void_p()
+        _chk(lib().mk_swapped_result(h, C.byref(ap), C.byref(op)))
+        off = np.array(np.ctypeslib.as_array(C.cast(op, C.POINTER(C.c_uint64)), shape=(n_targets + 1,)))
+        total = int(off[-1])
+        out = (Alignment * total)()
+        if total:
+            C.memmove(out, ap, total * C.sizeof(Alignment))
+        return out, off
+    finally:
+        lib().mk_swapped_destroy(h)
 
 
 def prefilter(db, q, params=None):

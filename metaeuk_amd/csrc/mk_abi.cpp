@@ -10,6 +10,7 @@
 #include "mk_exons.hpp"
 #include "mk_indexfile.hpp"
 #include "mk_prefilter.hpp"
+#include "mk_profile.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -168,6 +169,8 @@ struct mk_targetdb {
     int histLo = 0, histRange = 0;
     DevBuf<int8_t> dMatAln, dMatUng;
     DevBuf<uint32_t> dKeys;          // device copy of `keys` (last tie-break of the alignment order)
+    DevBuf<uint16_t> dAddr3;         // 3-mer number -> address code of the table cells (profile k-mer lists)
+    bool profileSearch = false;      // built for profile queries (mk_params.profile_search)
     std::vector<int32_t> bitScoreTable;   // static_cast<int>(bitScore(score) + 0.5), score < 32768
 };
 
@@ -180,6 +183,9 @@ struct mk_queries {
     DevBuf<uint64_t> dOff;
     DevBuf<int16_t> dKmerThr;
     DevBuf<int8_t> dCorr, dBias8;
+    // profile queries (mk_profiles_create): res / dRes hold the profiles' query letters, off the column offsets
+    bool isProfile = false;
+    DevBuf<int8_t> dProfSorted, dProfAln;   // [column][40], [column][32] (mk_profile.hpp)
     // stage results (the reference hands these over through the pref_0 / search_res DBs)
     mk::HostBlock hits; size_t nHits = 0; std::vector<uint64_t> hitOff; bool havePref = false;
     mk::HostBlock alns; std::vector<uint64_t> alnOff; bool haveAln = false;
@@ -195,6 +201,7 @@ int ensure_ready() {
 mk::AlignView align_view(const mk_targetdb *db, const mk_queries *q) {
     mk::AlignView V;
     V.q_res = q->dRes.p; V.q_bias8 = q->dBias8.p; V.q_off = q->dOff.p; V.n_queries = q->n;
+    V.q_prof = q->isProfile ? q->dProfAln.p : nullptr;
     V.t_res = db->dRes.p; V.t_off = db->dOff.p; V.n_targets = db->n; V.mat_aln = db->dMatAln.p;
     V.max_q_len = q->maxLen; V.max_t_len = db->maxLen;
     return V;
@@ -224,7 +231,7 @@ int run_sw_jobs(const mk_targetdb *db, const mk_queries *q, const mk_params *P, 
         const uint32_t lo = bounds[c], hi = bounds[c + 1];
         if (hi == lo) continue;
         mk::SwLaunch L;
-        L.q_res = q->dRes.p; L.q_bias8 = q->dBias8.p; L.t_res = db->dRes.p; L.mat = db->dMatAln.p;
+        L.q_res = q->dRes.p; L.q_bias8 = q->dBias8.p; L.q_prof = q->isProfile ? q->dProfAln.p : nullptr; L.t_res = db->dRes.p; L.mat = db->dMatAln.p;
         L.jobs = dJobs.p + lo; L.out = dOut.p; L.n_jobs = hi - lo; L.order = nullptr;
         L.boundary = nullptr; L.boundary_stride = 0; L.boundary_job0 = 0;
         L.wave_start = nullptr; L.n_waves = 0; L.work_counter = nullptr; L.persistent_blocks = 0; L.units_per_block = 0; L.known_score = nullptr;
@@ -325,6 +332,7 @@ void mk_default_params(mk_params *p) {
     p->gap_open = 11; p->gap_extend = 1; p->evalue_thr = 100.0; p->min_aln_len = 11;
     p->simd_lanes_byte = 32; p->simd_lanes_word = 16; p->simd_lanes_double = 4;
     p->host_l2_bytes = 1048576;
+    p->profile_search = 0;
 }
 
 void mk_encode(const char *ascii, size_t len, uint8_t *codes) { mk::encode(ascii, len, codes); }
@@ -344,10 +352,14 @@ static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uin
         if (L >= MK_MAX_SEQ_LEN) { delete db; return fail(MK_ERR_UNSUPPORTED, "target %u has %llu residues: at most %u are supported (17-bit column field of the alignment kernels)", i, (unsigned long long) L, MK_MAX_SEQ_LEN - 1); }
         db->maxLen = std::max<uint32_t>(db->maxLen, (uint32_t) L);
     }
-    mk::build_submat(db->kmerMat, mk::MAT_VTML80, 8.0f, -0.2f);     // Prefiltering.cpp:68
+    db->profileSearch = P->profile_search != 0;
+    if (db->profileSearch && prebuilt) { delete db; return fail(MK_ERR_UNSUPPORTED, "a precomputed index cannot serve profile queries: it was masked with the seed matrix's background and filtered by the sequence threshold"); }
+    // profile queries: kmerSubMat is --sub-mat x8 (only the background of the masking uses it), Prefiltering.cpp:72-76
+    mk::build_submat(db->kmerMat, db->profileSearch ? mk::MAT_BLOSUM62 : mk::MAT_VTML80, 8.0f, -0.2f);     // Prefiltering.cpp:68
     mk::build_submat(db->ungMat, mk::MAT_BLOSUM62, 2.0f, -0.2f);    // Prefiltering.cpp:69
     mk::build_submat(db->alnMat, mk::MAT_BLOSUM62, 2.0f, 0.0f);     // Alignment.cpp:152
-    db->kmerThr = mk::kmer_threshold(P->sensitivity, P->kmer_score);
+    // ... and the index keeps every k-mer (localKmerThr = 0, Prefiltering.cpp:525-527)
+    db->kmerThr = db->profileSearch ? 0 : mk::kmer_threshold(P->sensitivity, P->kmer_score);
     db->evaluer.init(offsets[n]);
     db->bitScoreTable.resize(32768);
     for (int sc = 0; sc < 32768; sc++) db->bitScoreTable[sc] = static_cast<int>(db->evaluer.bitScore((double) sc) + 0.5);
@@ -391,6 +403,9 @@ static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uin
     db->histLo = sm.histLo; db->histRange = sm.histRange;
     ok(db->dMatAln.upload(matAln, 441));
     ok(db->dMatUng.upload(matUng, 441));
+    uint16_t addr3[8000];
+    mk::kmer3_address_table(addr3);
+    ok(db->dAddr3.upload(addr3, 8000));
     ok(hipStreamSynchronize(g_stream));
     if (e != hipSuccess) { delete db; return fail(MK_ERR_DEVICE, "target upload failed: %s", hipGetErrorString(e)); }
     *out = db;
@@ -568,6 +583,139 @@ static int queries_create(const uint8_t *residues, const uint8_t *devResidues, c
 int mk_queries_create(const uint8_t *residues, const uint64_t *offsets, uint32_t n, const mk_params *P, mk_queries **out) {
     return queries_create(residues, nullptr, offsets, n, P, out);
 }
+
+// ---- profile queries (mk_profile.hip): Sequence::mapProfile for the whole batch on the device ----
+int mk_profiles_create(const uint8_t *columns, const uint64_t *offsets, uint32_t n, const mk_params *P, mk_queries **out) {
+    int rc = ensure_ready();
+    if (rc) return rc;
+    if (!offsets || !P || !out || (!columns && offsets[n] > 0)) return fail(MK_ERR_ARG, "null argument");
+    if (offsets[n] >= 0xFFFFFFFFull / 64) return fail(MK_ERR_ARG, "profile batch too large: split it");
+    mk_queries *q = new mk_queries();
+    q->n = n;
+    q->isProfile = true;
+    q->off.assign(offsets, offsets + n + 1);
+    const uint64_t total = offsets[n];
+    for (uint32_t i = 0; i < n; i++) {
+        if (offsets[i + 1] < offsets[i]) { delete q; return fail(MK_ERR_ARG, "offsets are not ascending at profile %u", i); }
+        const uint64_t L = offsets[i + 1] - offsets[i];
+        if (L >= MK_MAX_SEQ_LEN) { delete q; return fail(MK_ERR_UNSUPPORTED, "profile %u has %llu columns: at most %u are supported", i, (unsigned long long) L, MK_MAX_SEQ_LEN - 1); }
+        q->maxLen = std::max<uint32_t>(q->maxLen, (uint32_t) L);
+    }
+    q->res.resize(total);
+#pragma omp parallel for schedule(static)
+    for (uint64_t c = 0; c < total; c++) q->res[c] = columns[c * mk::PROFILE_COL_BYTES + 20];      // the query letters (host copy: exact self score)
+    for (uint64_t c = 0; c < total; c++)
+        if (q->res[c] > 20) { delete q; return fail(MK_ERR_ARG, "column %llu: query letter %u is not a residue code", (unsigned long long) c, (unsigned) q->res[c]); }
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; };
+    DevBuf<uint8_t> dRaw;
+    const uint64_t pad = 512;                                   // the k-mer list kernels stage whole 256 + 9 column windows
+    ok(dRaw.alloc((total + pad) * mk::PROFILE_COL_BYTES));
+    if (e == hipSuccess) ok(hipMemsetAsync(dRaw.p, 0, (total + pad) * mk::PROFILE_COL_BYTES, g_stream));
+    if (e == hipSuccess && total) ok(hipMemcpyAsync(dRaw.p, columns, total * mk::PROFILE_COL_BYTES, hipMemcpyHostToDevice, g_stream));
+    ok(q->dOff.upload(offsets, n + 1));
+    ok(q->dRes.alloc(total + pad));
+    ok(q->dKmerThr.alloc(total + pad));
+    ok(q->dCorr.alloc(total + pad));
+    ok(q->dBias8.alloc(total + pad));
+    ok(q->dProfSorted.alloc((total + pad) * mk::PROFILE_SORTED_STRIDE));
+    ok(q->dProfAln.alloc((total + pad) * mk::PROFILE_ALN_STRIDE));
+    if (e == hipSuccess) {
+        ok(hipMemsetAsync(q->dCorr.p, 0, total + pad, g_stream));
+        ok(hipMemsetAsync(q->dBias8.p, 0, total + pad, g_stream));
+        ok(hipMemsetAsync(q->dKmerThr.p, 0xFF, (total + pad) * 2, g_stream));       // -1: no k-mer start
+        ok(hipMemsetAsync(q->dProfSorted.p, 0, (total + pad) * mk::PROFILE_SORTED_STRIDE, g_stream));
+        ok(hipMemsetAsync(q->dProfAln.p, 0, (total + pad) * mk::PROFILE_ALN_STRIDE, g_stream));
+        const int th = timed_begin("profile_derive", (double) total * (25.0 + 75.0), 0);
+        ok(mk::launch_profile_derive(dRaw.p, q->dOff.p, n, total, mk::kmer_threshold_profile(P->sensitivity), q->dRes.p, q->dProfSorted.p, q->dProfAln.p,
+                                     q->dKmerThr.p, g_stream));
+        timed_end(th);
+    }
+    ok(hipStreamSynchronize(g_stream));
+    timed_flush();
+    if (e != hipSuccess) { delete q; return fail(MK_ERR_DEVICE, "profile upload failed: %s", hipGetErrorString(e)); }
+    *out = q;
+    return MK_OK;
+}
+
+int mk_profiles_derived(const mk_queries *q, uint8_t *letters, int8_t *sorted40, int8_t *aln32, int16_t *kmerThr) {
+    int rc = ensure_ready();
+    if (rc) return rc;
+    if (!q || !letters || !sorted40 || !aln32 || !kmerThr) return fail(MK_ERR_ARG, "null argument");
+    if (!q->isProfile) return fail(MK_ERR_ARG, "not a profile batch");
+    const uint64_t total = q->off[q->n];
+    HIPCHK(hipMemcpy(letters, q->dRes.p, total, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(sorted40, q->dProfSorted.p, total * mk::PROFILE_SORTED_STRIDE, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(aln32, q->dProfAln.p, total * mk::PROFILE_ALN_STRIDE, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(kmerThr, q->dKmerThr.p, total * sizeof(int16_t), hipMemcpyDeviceToHost));
+    return MK_OK;
+}
+
+// ---- swapresults on arrays (host code) ----
+struct mk_swapped {
+    std::vector<mk_alignment> alns;
+    std::vector<uint64_t> off;
+};
+
+int mk_swap_alignments(const mk_alignment *alns, const uint64_t *offsets, uint32_t nq, const uint32_t *queryKeys, uint32_t nTargets,
+                       uint64_t swappedDbResidues, const mk_params *P, mk_swapped **out) {
+    if (!offsets || !P || !out || (!alns && offsets[nq] > 0)) return fail(MK_ERR_ARG, "null argument");
+    const uint64_t total = offsets[nq];
+    for (uint64_t k = 0; k < total; k++) if (alns[k].db_key >= nTargets) return fail(MK_ERR_ARG, "alignment %llu names target %u of %u", (unsigned long long) k, alns[k].db_key, nTargets);
+    mk_swapped *s = new mk_swapped();
+    s->off.assign((size_t) nTargets + 1, 0);
+    for (uint64_t k = 0; k < total; k++) s->off[(size_t) alns[k].db_key + 1]++;
+    for (uint32_t t = 0; t < nTargets; t++) s->off[t + 1] += s->off[t];
+    s->alns.resize(total);
+    std::vector<uint64_t> fill(s->off.begin(), s->off.end() - 1);
+    mk::Evaluer ev;
+    ev.init(swappedDbResidues);                        // swapresults.cpp:76-77,102
+    const double ln2 = std::log(2.0);
+    for (uint32_t i = 0; i < nq; i++) {
+        for (uint64_t k = offsets[i]; k < offsets[i + 1]; k++) {
+            mk_alignment a = alns[k];
+            // the record as swapresults re-reads it from its text (Matcher::parseAlignmentRecord, Matcher.cpp:203-239): the identity
+            // has three decimals there
+            char buf[192];
+            mk_format_alignment(buf, &a);
+            const char *p1 = strchr(buf, '\t'); p1 = p1 ? strchr(p1 + 1, '\t') : nullptr;
+            if (p1) a.seq_id = (float) strtod(p1 + 1, nullptr);
+            // Matcher::result_t::swapResult (Matcher.h:93-115)
+            const double rawScore = (ev.logK + (double) a.bit_score * ln2) / ev.lambda;        // EvalueComputation.h:22-24
+            a.evalue = ev.evalue(rawScore, (double) a.db_len);
+            const uint32_t target = a.db_key;
+            std::swap(a.q_start, a.db_start); std::swap(a.q_end, a.db_end); std::swap(a.q_len, a.db_len); std::swap(a.qcov, a.dbcov);
+            a.db_key = queryKeys ? queryKeys[i] : i;
+            if (a.evalue <= P->evalue_thr) s->alns[fill[target]++] = a;                      // swapresults.cpp:291-295 (-e)
+            else s->alns[fill[target]++].db_key = 0xFFFFFFFFu;
+        }
+    }
+    // lists with records beyond -e are compacted (the workflow passes DBL_MAX: none)
+    bool holes = false;
+    for (uint64_t k = 0; k < total && !holes; k++) holes = s->alns[k].db_key == 0xFFFFFFFFu && s->alns[k].q_len == 0 && s->alns[k].db_len == 0;
+    if (holes) {
+        std::vector<mk_alignment> kept; kept.reserve(total);
+        std::vector<uint64_t> noff((size_t) nTargets + 1, 0);
+        for (uint32_t t = 0; t < nTargets; t++) {
+            for (uint64_t k = s->off[t]; k < s->off[t + 1]; k++)
+                if (!(s->alns[k].db_key == 0xFFFFFFFFu && s->alns[k].q_len == 0 && s->alns[k].db_len == 0)) kept.push_back(s->alns[k]);
+            noff[t + 1] = kept.size();
+        }
+        s->alns.swap(kept); s->off.swap(noff);
+    }
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (uint32_t t = 0; t < nTargets; t++)
+        if (s->off[t + 1] - s->off[t] > 1) std::sort(s->alns.begin() + s->off[t], s->alns.begin() + s->off[t + 1], mk::alignment_less);
+    *out = s;
+    return MK_OK;
+}
+
+int mk_swapped_result(const mk_swapped *s, const mk_alignment **alns, const uint64_t **offsets) {
+    if (!s || !alns || !offsets) return fail(MK_ERR_ARG, "null argument");
+    *alns = s->alns.data(); *offsets = s->off.data();
+    return MK_OK;
+}
+void mk_swapped_destroy(mk_swapped *s) { delete s; }
 
 // ---- extractorfs --translate on the device (mk_orf.hip) ----
 struct mk_orfs {
@@ -748,6 +896,7 @@ int mk_ungapped(mk_targetdb *db, mk_queries *q, const uint32_t *qIdx, const uint
     int rc = ensure_ready();
     if (rc) return rc;
     if (!db || !q || !outScores) return fail(MK_ERR_ARG, "null argument");
+    if (q->isProfile) return fail(MK_ERR_UNSUPPORTED, "mk_ungapped takes sequence queries (the prefilter scores profile diagonals itself)");
     std::vector<mk::UngappedJob> jobs(n);
     double bytes = 0;
     for (uint64_t i = 0; i < n; i++) {
@@ -781,13 +930,23 @@ static mk::PrefilterDeviceView prefilter_view(const mk_targetdb *db, const mk_qu
     V.kmer_slot = db->dKmerSlot.p; V.kmer_bits = db->dKmerBits.p; V.entries = db->dEntries.p; V.score3 = db->dScore3.p; V.index3 = db->dIndex3.p;
     V.hist3 = db->dHist3.p; V.cum3 = db->dCum3.p; V.hist_lo = db->histLo; V.hist_range = db->histRange; V.n_entries = db->nEntries;
     V.mat_ung = db->dMatUng.p;
+    if (q->isProfile) { V.p_sorted = q->dProfSorted.p; V.p_aln = q->dProfAln.p; V.addr3 = db->dAddr3.p; }
     return V;
+}
+
+// a profile batch searches a target side built for it (and only that one)
+static int check_roles(const mk_targetdb *db, const mk_queries *q) {
+    if (q->isProfile != db->profileSearch)
+        return fail(MK_ERR_ARG, q->isProfile ? "profile queries need a target database created with params->profile_search = 1"
+                                             : "this target database was created for profile queries (params->profile_search = 1)");
+    return MK_OK;
 }
 
 int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     int rc = ensure_ready();
     if (rc) return rc;
     if (!db || !q || !P) return fail(MK_ERR_ARG, "null argument");
+    if ((rc = check_roles(db, q)) != MK_OK) return rc;
     std::string err;
     const int binCount = mk::bin_count_for(db->n, P->host_l2_bytes);
     {
@@ -926,6 +1085,7 @@ int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     if (rc) return rc;
     if (!db || !q || !P) return fail(MK_ERR_ARG, "null argument");
     if (!q->havePref) return fail(MK_ERR_ARG, "mk_align: the batch has no prefilter result");
+    if ((rc = check_roles(db, q)) != MK_OK) return rc;
     HostTimer htAll("host_align_total");
     std::vector<mk::GateEntry> gate;
     mk::AssembleTables tables;
@@ -952,6 +1112,11 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     int rc = ensure_ready();
     if (rc) return rc;
     if (!db || !q || !P) return fail(MK_ERR_ARG, "null argument");
+    if ((rc = check_roles(db, q)) != MK_OK) return rc;
+    if (q->isProfile) {          // profile queries: the two stages back to back (their kernels are not tuned to share the GPU)
+        if ((rc = mk_prefilter(db, q, P)) != MK_OK) return rc;
+        return mk_align(db, q, P);
+    }
     HostTimer htAll("host_search_total");
     std::vector<mk::GateEntry> gate;
     mk::AssembleTables tables;

@@ -361,7 +361,7 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
         const uint32_t lo = hb[c], hi = hb[c + 1];
         if (hi <= lo) continue;
         SwLaunch L;
-        L.q_res = V.q_res; L.q_bias8 = V.q_bias8; L.t_res = V.t_res; L.mat = V.mat_aln;
+        L.q_res = V.q_res; L.q_bias8 = V.q_bias8; L.q_prof = V.q_prof; L.t_res = V.t_res; L.mat = V.mat_aln;
         L.jobs = jobs; L.out = out; L.n_jobs = hi - lo; L.order = vb.Current() + lo;
         L.boundary = nullptr; L.boundary_stride = 0; L.boundary_job0 = 0;
         L.wave_start = nullptr; L.n_waves = 0; L.work_counter = nullptr; L.persistent_blocks = 0; L.units_per_block = 0; L.known_score = nullptr;
@@ -381,7 +381,7 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
         // 108 ms instead of 121 ms per config-2 pass).  Beside the prefilter of mk_search its 11-22 KB of profiles per wave cost the other
         // stage more LDS than the kernel saves (measured: 1.12 s per step against 1.10 s), so the int32 kernels stay there.  MK_SW_KNOWN=0/1 forces.
         static const int force = getenv("MK_SW_KNOWN") ? atoi(getenv("MK_SW_KNOWN")) : -1;
-        if (knownScore && sw_cfg_known(c) && (force >= 0 ? force != 0 : !V.co_resident)) {
+        if (knownScore && sw_cfg_known(c) && !V.q_prof && (force >= 0 ? force != 0 : !V.co_resident)) {
             static int cus = 0;
             if (!cus) { int dev = 0; (void) hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
             uint32_t *dWork = (uint32_t *) dev_scratch("align_knowncounters", 64 * sizeof(uint32_t));
@@ -466,7 +466,7 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const SwJob *j
         const uint32_t lo = hb[c], hi = hb[c + 1], wlo = hb[16 + c], whi = hb[16 + c + 1];
         if (hi <= lo || whi <= wlo) continue;
         SwLaunch L;
-        L.q_res = V.q_res; L.q_bias8 = V.q_bias8; L.t_res = V.t_res; L.mat = V.mat_aln;
+        L.q_res = V.q_res; L.q_bias8 = V.q_bias8; L.q_prof = V.q_prof; L.t_res = V.t_res; L.mat = V.mat_aln;
         L.jobs = jobs; L.out = out; L.n_jobs = hi - lo; L.order = vb.Current();      // wave_start holds absolute sorted positions
         L.boundary = nullptr; L.boundary_stride = 0; L.boundary_job0 = lo;
         L.wave_start = dWave + wlo; L.n_waves = whi - wlo;

@@ -14,6 +14,7 @@ namespace mk {
 
 struct AlignView {
     const uint8_t *q_res; const int8_t *q_bias8; const uint64_t *q_off; uint32_t n_queries;
+    const int8_t *q_prof = nullptr;   // profile queries: [column][32] alignment profile
     const uint8_t *t_res; const uint64_t *t_off; uint32_t n_targets;
     const int8_t *mat_aln;
     uint32_t max_q_len, max_t_len;

@@ -89,6 +89,13 @@ int kmer_threshold(float sensitivity, int kmerScoreOverride) {
     return static_cast<int>(best);
 }
 
+// the same for a profile search without context pseudo counts (:1036-1040), k = 6
+int kmer_threshold_profile(float sensitivity) {
+    float base = 134.35;
+    float best = base - (sensitivity * 6.15);
+    return static_cast<int>(best);
+}
+
 // QueryMatcher::initDiagonalMatcher (M/src/prefiltering/QueryMatcher.cpp:422-450)
 int bin_count_for(uint64_t dbSize, uint64_t l2) {
     for (int b = 2; b <= 1024; b <<= 1) if (dbSize / static_cast<uint64_t>(b) < l2) return b;

@@ -31,6 +31,7 @@ void build_submat(SubMat &m, int which, float bitFactor, float scoreBias);
 void encode(const char *s, size_t n, uint8_t *codes);
 void comp_bias(const SubMat &m, const uint8_t *seq, int L, float scale, float *bias);
 int kmer_threshold(float sensitivity, int kmerScoreOverride);
+int kmer_threshold_profile(float sensitivity);
 int bin_count_for(uint64_t dbSize, uint64_t l2Bytes);
 
 // similar-3-mer table: row r (= 3-mer index) lists all 8000 3-mers by descending score

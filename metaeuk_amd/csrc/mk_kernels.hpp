@@ -23,6 +23,7 @@ struct SwOut { int32_t score; int32_t end_col; int32_t end_row; int32_t pad; };
 
 struct SwLaunch {
     const uint8_t *q_res; const int8_t *q_bias8;
+    const int8_t *q_prof = nullptr;   // profile queries: [column][32] alignment profile (mk_profile.hpp); the scores then come from it, not from mat + bias
     const uint8_t *t_res;
     const int8_t *mat;          // 21x21 int8 substitution scores, mat[t*21+q]
     const SwJob *jobs; SwOut *out; uint64_t n_jobs;
@@ -70,38 +71,48 @@ hipError_t launch_sw_known(const SwLaunch &L, int cfg, hipStream_t stream);
 // Otherwise the 16-bit diagonal is ambiguous and the reference takes the best of every real diagonal it can stand for
 // (computeLongScore, :312-329): -d * 65536 + diagonal for d = 1 .. 1 + tLen / 32768, and d * 65536 + diagonal for d = 0 .. qLen / 65536.
 // smat = 21 x 21 int8 scores [q * 21 + t]; corr = the query's int8 diagonal correction.  Same code on the device and on the host.
-template <typename MatT>
-__host__ __device__ inline int ungapped_on_diagonal(const MatT *smat, const uint8_t *q, const int8_t *corr, uint32_t qLen, const uint8_t *t, uint32_t tLen,
-                                                    int diagonal, uint32_t minDist) {      // computeSingelSequenceScores (:416-430)
+// score(query position, target residue) is the scorer: substitution matrix + int8 correction for a sequence query, the alignment profile
+// for a profile query (UngappedAlignment::createProfile, :385-414: queryProfile[pos][aa], X column 0).
+template <class ScoreFn>
+__host__ __device__ inline int ungapped_on_diagonal_fn(ScoreFn score_of, uint32_t qLen, const uint8_t *t, uint32_t tLen,
+                                                       int diagonal, uint32_t minDist) {      // computeSingelSequenceScores (:416-430)
     uint32_t len = 0, q0 = 0, t0 = 0;
     if (diagonal >= 0 && minDist < qLen) { len = tLen < qLen - minDist ? tLen : qLen - minDist; q0 = minDist; }
     else if (diagonal < 0 && minDist < tLen) { len = tLen - minDist < qLen ? tLen - minDist : qLen; t0 = minDist; }
     int score = 0, best = 0;
     for (uint32_t k = 0; k < len; k++) {
-        const int curr = (int) (int8_t) ((int8_t) smat[q[q0 + k] * 21 + t[t0 + k]] + corr[q0 + k]);
+        const int curr = score_of(q0 + k, (uint32_t) t[t0 + k]);
         score = score + curr > 0 ? score + curr : 0;
         best = best > score ? best : score;
     }
     return best;
 }
-template <typename MatT>
-__host__ __device__ inline int ungapped_score(const MatT *smat, const uint8_t *q, const int8_t *corr, uint32_t qLen, const uint8_t *t, uint32_t tLen, uint32_t d16) {
+template <class ScoreFn>
+__host__ __device__ inline int ungapped_score_fn(ScoreFn score_of, uint32_t qLen, const uint8_t *t, uint32_t tLen, uint32_t d16) {
     if (qLen >= 32768u || tLen >= 32768u) {
         int best = 0;
         for (uint32_t d = 1; d <= 1u + tLen / 32768u; d++) {
             const int real = (int) (0u - d * 65536u + d16);                   // unsigned wrap, then int: as the reference computes it
-            const int m = ungapped_on_diagonal(smat, q, corr, qLen, t, tLen, real, (uint32_t) (real < 0 ? -real : real));
+            const int m = ungapped_on_diagonal_fn(score_of, qLen, t, tLen, real, (uint32_t) (real < 0 ? -real : real));
             best = best > m ? best : m;
         }
         for (uint32_t d = 0; d <= qLen / 65536u; d++) {
             const int real = (int) (d * 65536u + d16);
-            const int m = ungapped_on_diagonal(smat, q, corr, qLen, t, tLen, real, (uint32_t) (real < 0 ? -real : real));
+            const int m = ungapped_on_diagonal_fn(score_of, qLen, t, tLen, real, (uint32_t) (real < 0 ? -real : real));
             best = best > m ? best : m;
         }
         return best;
     }
     const uint32_t dist = ((0x10000u - d16) & 0xFFFFu) < d16 ? ((0x10000u - d16) & 0xFFFFu) : d16;      // distanceFromDiagonal (:364-369)
-    return ungapped_on_diagonal(smat, q, corr, qLen, t, tLen, (int) (short) (uint16_t) d16, dist);
+    return ungapped_on_diagonal_fn(score_of, qLen, t, tLen, (int) (short) (uint16_t) d16, dist);
+}
+template <typename MatT>
+__host__ __device__ inline int ungapped_score(const MatT *smat, const uint8_t *q, const int8_t *corr, uint32_t qLen, const uint8_t *t, uint32_t tLen, uint32_t d16) {
+    return ungapped_score_fn([=](uint32_t i, uint32_t tr) -> int { return (int) (int8_t) ((int8_t) smat[q[i] * 21 + tr] + corr[i]); }, qLen, t, tLen, d16);
+}
+// profile query: aln = [column][32] alignment profile of the query (mk_profile.hpp)
+__host__ __device__ inline int ungapped_score_profile(const int8_t *aln, uint32_t qLen, const uint8_t *t, uint32_t tLen, uint32_t d16) {
+    return ungapped_score_fn([=](uint32_t i, uint32_t tr) -> int { return (int) aln[(size_t) i * 32 + tr]; }, qLen, t, tLen, d16);
 }
 
 struct UngappedJob { uint64_t t_start; uint32_t q_start; uint32_t q_len; uint32_t t_len; uint32_t diagonal; };

@@ -41,6 +41,7 @@
 #include "mk_host.hpp"
 #include "mk_kernels.hpp"
 #include "mk_enum.hpp"
+#include "mk_profile.hpp"
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <cstdlib>
@@ -142,7 +143,24 @@ __device__ __forceinline__ bool kmer_present(const uint32_t *bits, uint32_t kmer
 #endif
 constexpr int PROBE_U = MK_PROBE_U;        // 64-k-mer groups whose index probes are issued together (global path)
 
-template <bool GATHER>
+// the similar k-mers of a start read back from a list in HBM (profile queries), in windows of U * 64 like enumerate_position
+template <int U, class F>
+__device__ __forceinline__ uint32_t enumerate_list(const uint32_t *list, uint32_t count, int lane, F &&onBatch) {
+    for (uint32_t base = 0; base < count; base += U * WAVE) {
+        uint32_t kmer[U];
+        bool has[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t x = base + (uint32_t) (u * WAVE + lane);
+            has[u] = x < count;
+            kmer[u] = has[u] ? list[x] : 0u;
+        }
+        if (!onBatch(kmer, has)) break;
+    }
+    return count;
+}
+
+template <bool GATHER, bool LIST = false>
 __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
     __shared__ enumk::EnumLds<PROBE_U> sE[4];
     __shared__ uint8_t sMark[4][WAVE];
@@ -166,8 +184,7 @@ __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
         hitBase = A.hit_count[rel];
     }
     uint32_t hits = 0;
-    const uint32_t kmers = enumk::enumerate_position<PROBE_U>(A.V, A.V.q_res + p, thr, lane, sE[w],
-        [&](const uint32_t (&kmer)[PROBE_U], const bool (&has)[PROBE_U]) -> bool {
+    const auto onBatch = [&](const uint32_t (&kmer)[PROBE_U], const bool (&has)[PROBE_U]) -> bool {
             uint32_t size[PROBE_U], o0[PROBE_U];
             uint64_t ent0[PROBE_U];
             bool inl[PROBE_U];
@@ -205,7 +222,14 @@ __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
                 }
             }
             return true;
-        });
+        };
+    uint32_t kmers;
+    if constexpr (LIST) {
+        const uint64_t l0 = A.V.klist_off[p - A.V.klist_pos0], l1 = A.V.klist_off[p - A.V.klist_pos0 + 1];
+        kmers = enumerate_list<PROBE_U>(A.V.klist + l0, (uint32_t) (l1 - l0), lane, onBatch);
+    } else {
+        kmers = enumk::enumerate_position<PROBE_U>(A.V, A.V.q_res + p, thr, lane, sE[w], onBatch);
+    }
     if (!GATHER) {
         hits = wave_sum(hits);
         if (lane == 0) { A.hit_count[rel] = hits; A.kmer_count[rel] = kmers; }
@@ -791,7 +815,8 @@ __global__ __launch_bounds__(256) void diag_score_kernel(PrefilterDeviceView V, 
     const uint32_t d16 = (uint32_t) C.diag[c];
     const uint64_t qs = V.q_off[q], ts = V.t_off[id];
     const uint32_t qLen = (uint32_t) (V.q_off[q + 1] - qs), tLen = (uint32_t) (V.t_off[id + 1] - ts);
-    const int best = ungapped_score(smat, V.q_res + qs, V.q_corr + qs, qLen, V.t_masked + ts, tLen, d16);
+    const int best = V.p_aln ? ungapped_score_profile(V.p_aln + qs * PROFILE_ALN_STRIDE, qLen, V.t_masked + ts, tLen, d16)
+                             : ungapped_score(smat, V.q_res + qs, V.q_corr + qs, qLen, V.t_masked + ts, tLen, d16);
     C.score[c] = best;
 }
 
@@ -931,8 +956,9 @@ struct Ctx {
 
 // B. global path over the view queries [a, b): appends their candidates at C[nCand...]; qMap/qAdd translate the view's
 // query index into the chunk-local one.  Splits the range so that the index hits of one piece fit HIT_CAP.
-int global_candidates(Ctx &X, const PrefilterDeviceView &V, const uint64_t *hOff /* host offsets of the view */, uint32_t a, uint32_t b,
+int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff /* host offsets of the view */, uint32_t a, uint32_t b,
                       const uint32_t *qMap, uint32_t qAddBase, uint32_t &nCand, double &hitsPerPos) {
+    PrefilterDeviceView V = Vin;                      // (the k-mer lists of a piece are attached to the copy)
     std::string &err = *X.err;
     hipStream_t stream = X.stream;
     const size_t HIT_CAP = 768u << 20;                // index hits per piece kept in HBM: 17 B each (record double buffered + high diagonal byte)
@@ -964,12 +990,44 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &V, const uint64_t *hOff
             dKmer = (uint32_t *) dev_scratch("pf_kmer", (nPos + 1) * 4);
             uint32_t *dLast = (uint32_t *) dev_scratch("pf_last", 16);
             PNULL(dHit); PNULL(dKmer); PNULL(dLast);
+            if (V.p_sorted) {
+                // profile queries: the similar k-mers of the piece as lists in HBM (count, scan, fill), walked by both probe passes
+                const size_t KLIST_CAP = (size_t) 1 << 30;                 // k-mers per piece (4 GB)
+                uint32_t *dCnt = (uint32_t *) dev_scratch("pf_klcount", (nPos + 1) * 4);
+                uint64_t *dKOff = (uint64_t *) dev_scratch("pf_kloff", (nPos + 2) * 8);
+                unsigned long long *hKTot = (unsigned long long *) pinned_scratch("pf_kltot_h", 16);
+                PNULL(dCnt); PNULL(dKOff); PNULL(hKTot);
+                int th = X.tb("profile_kmer_count", 46.0 * (double) nPos, 0);
+                PCHK(launch_profile_kmer_count(V.p_sorted, V.q_kmer_thr, hOff[q0], hOff[q1], dCnt, stream));
+                X.te(th);
+                PCHK(hipMemsetAsync(dCnt + nPos, 0, 4, stream));           // one more element: the scan then ends with the total
+                hipcub::TransformInputIterator<unsigned long long, hipcub::CastOp<unsigned long long>, uint32_t *> cit(dCnt, hipcub::CastOp<unsigned long long>());
+                size_t tk = 0;
+                hipcub::DeviceScan::ExclusiveSum(nullptr, tk, cit, (unsigned long long *) dKOff, (int) (nPos + 1), stream);
+                void *tempK = dev_scratch("pf_temp", tk);
+                PNULL(tempK);
+                PCHK(hipcub::DeviceScan::ExclusiveSum(tempK, tk, cit, (unsigned long long *) dKOff, (int) (nPos + 1), stream));
+                PCHK(hipMemcpyAsync(hKTot, dKOff + nPos, 8, hipMemcpyDeviceToHost, stream));
+                PCHK(sync_wait(stream, "wait_prefilter"));
+                const size_t nK = (size_t) hKTot[0];
+                if (nK > KLIST_CAP) {
+                    if (q1 - q0 > 1) { q1 = q0 + (q1 - q0) / 2; continue; }
+                    err = "one profile has more than 2^30 similar k-mers"; return MK_ERR_UNSUPPORTED;
+                }
+                uint32_t *dKList = (uint32_t *) dev_scratch("pf_klist", std::max<size_t>(nK, 1) * 4);
+                PNULL(dKList);
+                th = X.tb("profile_kmer_fill", 46.0 * (double) nPos + 4.0 * (double) nK, (double) nK);
+                PCHK(launch_profile_kmer_fill(V.p_sorted, V.q_kmer_thr, V.addr3, hOff[q0], hOff[q1], dKOff, dKList, stream));
+                X.te(th);
+                V.klist = dKList; V.klist_off = dKOff; V.klist_pos0 = hOff[q0];
+            }
             ProbeArgs A;
             A.V = V; A.pos_begin = hOff[q0]; A.pos_end = hOff[q1]; A.q_first = q0; A.seq_bits = X.seqBits; A.hit_bits = 0;
             A.hit_count = dHit; A.kmer_count = dKmer; A.keys = nullptr; A.diag_hi = nullptr;
             const unsigned blocks = (unsigned) ((nPos + 3) / 4);
             const int thCount = X.tb("kmer_probe_count", 0, 0);
-            hipLaunchKernelGGL(probe_kernel<false>, dim3(blocks), dim3(256), 0, stream, A);
+            if (V.p_sorted) hipLaunchKernelGGL((probe_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, A);
+            else hipLaunchKernelGGL(probe_kernel<false>, dim3(blocks), dim3(256), 0, stream, A);
             X.te(thCount);
             PCHK(hipGetLastError());
             // totals: k-mers (reduce), hits (scan); the count of the last position is saved before the in-place scan
@@ -1019,7 +1077,8 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &V, const uint64_t *hOff
             const unsigned blocks = (unsigned) ((nPos + 3) / 4);
             // gather pass: slots again + 8 B per index entry read + 9 B (record, high diagonal byte) written per entry
             int th = X.tb("kmer_probe_gather", 4.0 * (double) X.hTotals[2] + 25.0 * (double) totalHits + 1280.0 * (double) nPos, (double) X.hTotals[2]);
-            hipLaunchKernelGGL(probe_kernel<true>, dim3(blocks), dim3(256), 0, stream, A);
+            if (V.p_sorted) hipLaunchKernelGGL((probe_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, A);
+            else hipLaunchKernelGGL(probe_kernel<true>, dim3(blocks), dim3(256), 0, stream, A);
             X.te(th);
             PCHK(hipGetLastError());
             // sort by (query, target): only those bits are sorted, the records of a pair stay in arrival order.  The gather pass wrote the
@@ -1115,7 +1174,8 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     uint32_t seqBits = 1; while ((1ull << seqBits) < dbSize) seqBits++;
     // front end: the per-query kernels keep the target id in a 22-bit field of their hit records
     bool useFused = seqBits <= REC_T_BITS;
-    if (const char *e = getenv("MK_PREFILTER_PATH")) {
+    if (V.p_sorted) useFused = false;                  // profile queries: k-mer lists in HBM + the global path (the per-query kernels enumerate 3-mer rows)
+    else if (const char *e = getenv("MK_PREFILTER_PATH")) {
         if (!strcmp(e, "global")) useFused = false;
         else if (strcmp(e, "fused") && strcmp(e, "auto")) { err = "MK_PREFILTER_PATH must be auto, fused or global"; return MK_ERR_ARG; }
     }
@@ -1488,7 +1548,16 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                         int n255 = 0;
                         for (const Cand &c : perQuery) n255 += c.score >= 255;
                         int self = 0;
-                        if (n255 >= maxHits) {                     // threshold saturates: QueryMatcher.cpp:525-531 needs the exact self score
+                        if (n255 >= maxHits && V.p_sorted) {       // ... of the profile's query letters against the profile itself
+                            const uint32_t L = (uint32_t) (qOff[q + 1] - qOff[q]);
+                            std::vector<int8_t> aln((size_t) L * PROFILE_ALN_STRIDE);
+                            if (qCorrHost) std::memcpy(aln.data(), qCorrHost + qOff[q] * PROFILE_ALN_STRIDE, aln.size());
+                            else {
+#pragma omp critical(mk_pf_corr)
+                                if (hipMemcpy(aln.data(), V.p_aln + qOff[q] * PROFILE_ALN_STRIDE, aln.size(), hipMemcpyDeviceToHost) != hipSuccess) failed = 1;
+                            }
+                            self = ungapped_score_profile(aln.data(), L, qRes.data() + qOff[q], L, 0u);
+                        } else if (n255 >= maxHits) {              // threshold saturates: QueryMatcher.cpp:525-531 needs the exact self score
                             const int L = (int) (qOff[q + 1] - qOff[q]);
                             std::vector<int8_t> corr((size_t) L);
                             if (qCorrHost) std::memcpy(corr.data(), qCorrHost + qOff[q], (size_t) L);

@@ -23,6 +23,12 @@ struct PrefilterDeviceView {
     const uint16_t *hist3; const uint16_t *cum3; int hist_lo, hist_range;   // per-row score histograms (sizing)
     uint64_t n_entries;
     const int8_t *mat_ung;
+    // profile queries (mk_profile.hpp; null for sequence queries): q_res = the profiles' query letters, q_kmer_thr as usual, q_corr unused
+    const int8_t *p_sorted = nullptr;     // [column][40]: the 20 scores descending + their residue numbers
+    const int8_t *p_aln = nullptr;        // [column][32]: the alignment profile (score / 4), what the diagonal scoring reads
+    const uint16_t *addr3 = nullptr;      // 3-mer number -> address code of the index table (kmer3_address_table)
+    // the similar k-mers of the k-mer starts [klist_pos0, ...) as lists in HBM (filled per piece by the global path for profile queries)
+    const uint32_t *klist = nullptr; const uint64_t *klist_off = nullptr; uint64_t klist_pos0 = 0;
 };
 
 typedef int (*timed_begin_fn)(const char *name, double bytes, double cells);
@@ -41,7 +47,7 @@ struct PrefilterHooks {
 
 // Runs the whole prefilter for the batch.  q_off_host / t_off_host mirror the device offset arrays.
 int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &q_off_host, const std::vector<uint8_t> &q_res_host,
-                  const int8_t *q_corr_host,
+                  const int8_t *q_corr_host /* sequence queries: the int8 diagonal correction; profile queries: the alignment profile [column][32] */,
                   const std::vector<uint64_t> &t_off_host, const mk_params &P, int binCount, hipStream_t stream,
                   struct HostBlock &outHits, size_t &nOutHits, std::vector<uint64_t> &outOff, std::string &err, timed_begin_fn tb, timed_end_fn te, timed_set_fn ts,
                   const PrefilterHooks &hooks);

@@ -112,7 +112,18 @@ __device__ __forceinline__ void sw_unit(const SwLaunch &L, const uint32_t unit, 
         // ---- LDS query profile for this row tile: prof[t][row] = mat[t][q_row] + bias8[q_row]; row 21 = zeros ----
         // (residues and bias of the tile's rows are staged in LDS first, the matrix sits there too: two global loads per row instead of a
         //  dependent pair per profile entry -- these kernels must not stall when the prefilter of the other stream saturates HBM)
-        {
+        if (L.q_prof) {
+            // profile query (ssw_init with Sequence::getAlignmentProfile, StripedSmithWaterman.cpp:1243-1247): the scores of a row are the
+            // query's own column [row][32] (score / 4 per residue, X and "no column" 0), read as dwords: one 32-byte line per row
+            for (int i = SHARED ? (int) threadIdx.x : lane; i < ROWS * 6; i += SHARED ? BLOCK : G) {
+                const int row = i / 6, w = i - row * 6;
+                const int q = row0 + row;
+                uint32_t v = 0;
+                if (q < qLen) v = *reinterpret_cast<const uint32_t *>(L.q_prof + ((int64_t) profQStart + (int64_t) q * profQStep) * 32 + w * 4);
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (4 * w + k < 22) prof[(4 * w + k) * ROWS + row] = (int8_t) (v >> (8 * k));
+            }
+        } else {
             uint8_t *sQ = reinterpret_cast<uint8_t *>(prof) + 22 * ROWS;           // behind the group's / wave's profile
             int8_t *sB = reinterpret_cast<int8_t *>(sQ) + ROWS;
             for (int row = SHARED ? (int) threadIdx.x : lane; row < ROWS; row += SHARED ? BLOCK : G) {
@@ -283,6 +294,18 @@ __global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
         const SwJob jobB = L.jobs[L.order[(uint64_t) w0 + (haveB ? 2 * grp + 1 : 0)]];
         const int qLen = (int) jobA.q_len;                          // every job of the wave has this query
         const int tLenA = haveA ? (int) jobA.t_len : 0, tLenB = haveB ? (int) jobB.t_len : 0;
+        if (L.q_prof) {
+            // profile query: the row's scores are its own column of the alignment profile (see sw_unit)
+            for (int i = (int) threadIdx.x; i < ROWS * 6; i += 64) {
+                const int slot = i / 6, w = i - slot * 6;
+                const int row = RP == R ? slot : (slot / RP) * R + slot % RP;
+                const bool real = row < qLen && (RP == R || slot % RP < R);
+                uint32_t v = 0;
+                if (real) v = *reinterpret_cast<const uint32_t *>(L.q_prof + ((int64_t) jobA.q_start + (int64_t) row * jobA.q_step) * 32 + w * 4);
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (4 * w + k < 22) prof[(4 * w + k) * ROWS + slot] = (int16_t) (int8_t) (v >> (8 * k));
+            }
+        } else {
         for (int slot = (int) threadIdx.x; slot < ROWS; slot += 64) {
             const int row = RP == R ? slot : (slot / RP) * R + slot % RP;    // lane-major: lane * R + r
             const bool real = row < qLen && (RP == R || slot % RP < R);
@@ -296,6 +319,7 @@ __global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
             const int t = idx / ROWS, slot = idx - t * ROWS;
             const uint32_t qc = sQ[slot];
             prof[idx] = (t < 21 && qc != 255u) ? (int16_t) ((int) sMat[t * 21 + (int) qc] + (int) sB[slot]) : (int16_t) 0;
+        }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();

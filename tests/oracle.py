@@ -77,6 +77,25 @@ def sw(q, t, lanes_byte=32, lanes_word=16, gap_open=11, gap_extend=1, with_start
     return (r.score, r.q_end, r.t_end, r.q_start, r.t_start, r.rev_mismatch)
 
 
+class Profile(C.Structure):
+    _fields_ = [("L", C.c_int), ("query", C.POINTER(C.c_uint8)), ("consensus", C.POINTER(C.c_uint8)), ("aln", C.POINTER(C.c_int8)),
+                ("sorted_score", C.POINTER(C.c_short)), ("sorted_idx", C.POINTER(C.c_uint8))]
+
+
+def profile_arrays(entry, n_cols):
+    """Sequence::mapProfile by the oracle -> (sorted scores [n, 20] i8, residue numbers [n, 20] i8, alignment profile [n, 21] i8, query letters [n] u8)"""
+    L = lib()
+    L.mko_profile_map.restype = C.POINTER(Profile)
+    p = L.mko_profile_map(C.c_char_p(entry), C.c_int(n_cols))
+    pr = p.contents
+    scores = np.ctypeslib.as_array(pr.sorted_score, shape=(n_cols, 20)).astype(np.int8)
+    idx = np.ctypeslib.as_array(pr.sorted_idx, shape=(n_cols, 20)).astype(np.int8)
+    aln = np.ctypeslib.as_array(pr.aln, shape=(21, n_cols)).T.copy()
+    query = np.ctypeslib.as_array(pr.query, shape=(n_cols,)).copy()
+    L.mko_profile_free(p)
+    return scores, idx, aln, query
+
+
 def run_pipeline(targets, queries, outdir, extra=()):
     """oracle CLI over sequence lists -> (pref dict, aln dict) keyed by query index"""
     build()

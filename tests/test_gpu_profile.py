@@ -1,0 +1,188 @@
+"""GPU parity tests of the profile-target path: profiles as the QUERIES of prefilter / align, fragments as the
+indexed targets, swapresults -- through the C ABI, against the fixtures the REAL reference binary left behind
+(tests/golden/make_profile_golden.sh) and against the oracle on synthetic profiles."""
+import ctypes as C
+import gzip
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+AA = "ACDEFGHIKLMNPQRSTVWY"
+
+
+def _text(name):
+    with gzip.open(os.path.join(GOLD, name), "rt") as f:
+        return f.read()
+
+
+def _golden_inputs():
+    data = gzip.open(os.path.join(GOLD, "prof_db.bin.gz"), "rb").read()
+    index = sorted((int(k), int(o), int(l)) for k, o, l in (ln.split() for ln in open(os.path.join(GOLD, "prof_db.index"))))
+    keys = [k for k, _, _ in index]
+    entries = [data[o:o + l] for _, o, l in index]
+    frags = [l.rsplit("\t", 1)[1] for l in _text("e2e_process_orfs.txt.gz").splitlines()]
+    order = [int(x) for x in _text("prof_frag_order.txt.gz").split()]        # fragment keys in the order the prefilter numbers them
+    residues = sum(len(e) for e in entries) // 25 - len(entries)             # DBReader::getAminoAcidDBSize of the profile DB
+    return keys, entries, frags, order, residues
+
+
+def _blocks(keys, texts):
+    return "".join(">%d\n%s" % (k, t) for k, t in zip(keys, texts))
+
+
+def _keyed_alignment_text(api, alns, lo, hi, key_of):
+    out = []
+    buf = C.create_string_buffer(256)
+    for i in range(lo, hi):
+        a = api.Alignment.from_buffer_copy(alns[i])
+        a.db_key = key_of(int(a.db_key))
+        n = api.lib().mk_format_alignment(buf, C.byref(a))
+        out.append(buf.raw[:n].decode())
+    return "".join(out)
+
+
+def _profile_params(api, n_frag, n_prof, sens=4.0, evalue=100.0):
+    p = api.default_params()
+    p.sensitivity = sens
+    p.profile_search = 1
+    p.max_seqs = max(300, n_frag)                                            # Search.cpp:372
+    p.evalue_thr = float("%g" % (evalue * (np.float32(n_frag) / np.float32(n_prof))))   # Search.cpp:366-368 + the parameter string round trip
+    p.host_l2_bytes = 2097152
+    return p
+
+
+def test_profile_search_matches_the_real_process(gpu_api):
+    """prefilter / align / swapresults of 100 profiles x 24084 fragments: byte-identical to the DBs of the real
+    `metaeuk predictexons contigsDB profileDB` run"""
+    api = gpu_api
+    keys, entries, frags, order, prof_residues = _golden_inputs()
+    params = _profile_params(api, len(frags), len(entries))
+    assert params.evalue_thr == 24084
+    db = api.TargetDB([frags[k] for k in order], params)
+    frag_keys = np.array(order, dtype=np.uint32)
+    api._chk(api.lib().mk_targetdb_set_keys(db.h, api._p(frag_keys), C.c_uint32(len(order))))
+    q = api.Profiles(entries, params)
+    hits, hoff = api.prefilter(db, q, params)
+    pref = _blocks(keys, [api.format_hits(hits, int(hoff[i]), int(hoff[i + 1]), key_of=lambda t: order[t]) for i in range(q.n)])
+    assert pref == _text("prof_pref.txt.gz")
+    alns, aoff = api.align(db, q, params)
+    aln = _blocks(keys, [_keyed_alignment_text(api, alns, int(aoff[i]), int(aoff[i + 1]), lambda t: order[t]) for i in range(q.n)])
+    assert aln == _text("prof_aln.txt.gz")
+    swap_params = api.default_params()
+    swap_params.evalue_thr = 1.7976931348623157e308                          # swapresults -e DBL_MAX (Search.cpp:378-381)
+    sw, soff = api.swap_alignments(alns, aoff, len(order), prof_residues, query_keys=keys, params=swap_params)
+    by_key = {}
+    for t in range(len(order)):
+        by_key[order[t]] = api.format_alignments(sw, int(soff[t]), int(soff[t + 1]))
+    assert _blocks(sorted(by_key), [by_key[k] for k in sorted(by_key)]) == _text("prof_search_res.txt.gz")
+    # the search as one call gives the same two results
+    q2 = api.Profiles(entries, params)
+    (h2, ho2), (a2, ao2) = api.search(db, q2, params)
+    assert np.array_equal(ho2, hoff) and np.array_equal(h2, hits) and np.array_equal(ao2, aoff)
+    assert api.format_alignments_bulk(a2, 0, int(ao2[-1])) == api.format_alignments_bulk(alns, 0, int(aoff[-1]))
+
+
+def test_profile_arrays_match_the_oracle(gpu_api):
+    """Sequence::mapProfile on the device: sorted columns (the exchange network's tie order), alignment profile, k-mer thresholds"""
+    api = gpu_api
+    keys, entries, frags, order, _ = _golden_inputs()
+    params = _profile_params(api, len(frags), len(entries))
+    q = api.Profiles(entries[:20], params)
+    letters, sorted40, aln32, kthr = q.derived()
+    L = oracle.lib()
+    at = 0
+    for e in entries[:20]:
+        n = (len(e) - 1) // 25
+        scores, idx, aln, query = oracle.profile_arrays(e, n)
+        assert np.array_equal(sorted40[at:at + n, :20], scores) and np.array_equal(sorted40[at:at + n, 20:], idx)
+        assert np.array_equal(aln32[at:at + n, :21], aln) and not aln32[at:at + n, 21:].any()
+        assert np.array_equal(letters[at:at + n], query)
+        exp = np.full(n, -1, dtype=np.int16)
+        for i in range(0, n - 9):
+            if not any(query[i + d] == 20 for d in (0, 1, 3, 5, 8, 9)):
+                exp[i] = 109
+        assert np.array_equal(kthr[at:at + n], exp)
+        at += n
+    assert L is not None
+
+
+def _synthetic_profile(rng, length, x_rate=0.0):
+    """a profile entry with random integer scores in the range result2profile produces; some query letters X"""
+    out = bytearray()
+    for _ in range(length):
+        fav = rng.randrange(20)
+        col = [rng.randint(-24, 6) for _ in range(20)]
+        col[fav] = rng.randint(12, 40)
+        for _ in range(rng.randrange(3)):
+            col[rng.randrange(20)] = rng.randint(0, 20)
+        letter = 20 if rng.random() < x_rate else fav
+        out += bytes((v & 0xFF) for v in col) + bytes([letter, fav, 10, 0, 0])
+    return bytes(out) + b"\0", "".join(AA[max(range(20), key=lambda a: ((out[25 * i + a] + 128) % 256))] for i in range(length))
+
+
+def test_profile_search_synthetic_vs_oracle(gpu_api, tmp_path):
+    """synthetic profiles (ties inside columns, X query letters, lengths 12 .. 1500: every SW tile shape incl. row tiles) against
+    fragments derived from their consensus: the oracle's stages on the same files"""
+    api = gpu_api
+    rng = random.Random(5)
+    entries, cons = [], []
+    for L in [12, 31, 64, 100, 129, 200, 260, 390, 520, 800, 1100, 1500] + [rng.randint(20, 400) for _ in range(28)]:
+        e, c = _synthetic_profile(rng, L, x_rate=0.01 if L > 100 else 0.0)
+        entries.append(e); cons.append(c)
+    frags = []
+    for c in cons:
+        for _ in range(12):
+            a = rng.randrange(0, max(1, len(c) - 15)); b = min(len(c), a + rng.randint(15, 160))
+            s = "".join(rng.choice(AA) if rng.random() < 0.15 else ch for ch in c[a:b])
+            frags.append(_rand(rng, rng.randint(0, 20)) + s + _rand(rng, rng.randint(0, 20)))
+    frags += [_rand(rng, rng.randint(15, 120)) for _ in range(600)]
+    frags += ["A" * 40, "XXXXXXXXXXXXXXXXXXXX", cons[5][:50] + "X" * 5 + cons[5][55:100]]
+    rng.shuffle(frags)
+    keys = list(range(len(entries)))
+    data = b"".join(entries)
+    (tmp_path / "prof.bin").write_bytes(data)
+    off, lines = 0, []
+    for k, e in enumerate(entries):
+        lines.append("%d\t%d\t%d\n" % (k, off, len(e))); off += len(e)
+    (tmp_path / "prof.index").write_text("".join(lines))
+    (tmp_path / "frags.txt").write_text("\n".join(frags) + "\n")
+    subprocess.check_call([oracle.CLI, "profilesearch", str(tmp_path / "prof.bin"), str(tmp_path / "prof.index"), str(tmp_path / "frags.txt"),
+                           str(tmp_path / "out"), "--l2", "2097152", "-s", "5"], stdout=subprocess.DEVNULL)
+    params = _profile_params(api, len(frags), len(entries), sens=5.0)
+    db = api.TargetDB(frags, params)
+    q = api.Profiles(entries, params)
+    (hits, hoff), (alns, aoff) = api.search(db, q, params)
+    assert int(hoff[-1]) > 500 and int(aoff[-1]) > 300
+    pref = _blocks(keys, [api.format_hits(hits, int(hoff[i]), int(hoff[i + 1])) for i in range(q.n)])
+    assert pref == open(tmp_path / "out" / "pref.txt").read()
+    aln = _blocks(keys, [api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1])) for i in range(q.n)])
+    assert aln == open(tmp_path / "out" / "aln.txt").read()
+    residues = sum(len(e) for e in entries) // 25 - len(entries)
+    swap_params = api.default_params()
+    swap_params.evalue_thr = 1.7976931348623157e308
+    sw, soff = api.swap_alignments(alns, aoff, len(frags), residues, params=swap_params)
+    swapped = _blocks(range(len(frags)), [api.format_alignments(sw, int(soff[t]), int(soff[t + 1])) for t in range(len(frags))])
+    assert swapped == open(tmp_path / "out" / "swapped.txt").read()
+
+
+def _rand(rng, n):
+    return "".join(rng.choice(AA) for _ in range(n))
+
+
+def test_profile_and_sequence_roles_are_checked(gpu_api):
+    api = gpu_api
+    keys, entries, frags, order, _ = _golden_inputs()
+    params = api.default_params()
+    db = api.TargetDB(frags[:200], params)                                   # built for sequence queries
+    pp = _profile_params(api, 200, 5)
+    q = api.Profiles(entries[:5], pp)
+    with pytest.raises(api.MkError):
+        api.prefilter(db, q, pp)
