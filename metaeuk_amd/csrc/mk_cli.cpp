@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <string>
 #include <vector>
@@ -46,7 +47,7 @@ const Flag FLAGS[] = {
     {"--add-self-matches", "0", false}, {"--spaced-kmer-mode", "1", false}, {"--spaced-kmer-pattern", "", false},
     {"--local-tmp", "", false}, {"--db-load-mode", "0", false}, {"--pca", "", false}, {"--pcb", "", false},
     {"--taxon-list", "", false}, {"--threads", "", true}, {"--compressed", "0", false}, {"-v", "3", true},
-    {"-a", "0", false}, {"--alignment-mode", "2", false}, {"--alignment-output-mode", "0", false}, {"--wrapped-scoring", "0", false},
+    {"-a", "0", false}, {"--alignment-mode", "2", false}, {"--alignment-output-mode", "0", true}, {"--wrapped-scoring", "0", false},
     {"-e", "100", true}, {"--min-seq-id", "0", false}, {"--min-aln-len", "0", true}, {"--seq-id-mode", "0", false},
     {"--alt-ali", "0", false}, {"--max-rejected", "2147483647", false}, {"--max-accept", "2147483647", false},
     {"--score-bias", "0", false}, {"--realign", "0", false}, {"--realign-score-bias", "-0.2", false}, {"--realign-max-seqs", "2147483647", false},
@@ -120,6 +121,7 @@ int parse(int argc, char **argv, Args &a) {
             std::string(k.name) == "--threads" || std::string(k.name) == "--remove-tmp-files" || std::string(k.name) == "--reuse-latest" ||
             std::string(k.name) == "--force-reuse" || std::string(k.name) == "--disk-space-limit" || std::string(k.name) == "--mpi-runner") continue;    // no effect on this path
         if (std::string(k.name) == "--start-sens") continue;          // only read when --sens-steps > 1, which is refused below
+        if (std::string(k.name) == "--exhaustive-search") continue;   // predictexons turns it on by itself for profile targets (PredictExons.cpp:22-26); checked there
         if (std::string(k.name) == "--max-seq-len") {                 // sequences are never cut here: the value must admit everything the reference admits
             if (atol(v.c_str()) < 65535) { fprintf(stderr, "--max-seq-len %s: shorter limits than the default 65535 (sequence splitting) are not implemented\n", v.c_str()); return EXIT_FAILURE; }
             continue;
@@ -181,6 +183,30 @@ void encodeDb(const mk::Database &db, std::vector<uint8_t> &res, std::vector<uin
     for (size_t i = 0; i < db.entries.size(); i++) mk_encode(db.entry(i), db.seqLen(i), res.data() + off[i]);
 }
 
+// profile DB (type 2) -> the 25-byte columns of its entries without the trailing NULs + column offsets (DBReader::getSeqLen for
+// profiles: (length - 1) / 25, DBReader.h:224-227), in the order of db.entries
+constexpr int DBTYPE_HMM_PROFILE = 2;
+void profileColumns(const mk::Database &db, std::vector<uint8_t> &cols, std::vector<uint64_t> &off) {
+    off.assign(db.entries.size() + 1, 0);
+    for (size_t i = 0; i < db.entries.size(); i++) off[i + 1] = off[i] + (std::max<uint64_t>(db.entries[i].length, 1) - 1) / 25;
+    cols.assign(off.back() * 25 + 1, 0);
+    for (size_t i = 0; i < db.entries.size(); i++) std::memcpy(cols.data() + off[i] * 25, db.entry(i), (size_t) (off[i + 1] - off[i]) * 25);
+}
+// DBReader::getAminoAcidDBSize of a profile DB (DBReader.cpp:589-598): dataSize / 25 - entries
+uint64_t profileDbResidues(const mk::Database &db) {
+    uint64_t dataSize = 0;
+    for (const mk::DbEntry &e : db.entries) dataSize += e.length;
+    return dataSize / 25 - db.entries.size();
+}
+// the e-value threshold of the inverted search: scaled by #queries / #targets of the ORIGINAL search (Search.cpp:366-368, float division)
+// and handed to the modules as text (Parameters::createParameterString streams the double with 6 significant digits)
+double invertedEvalue(double evalThr, size_t nFragments, size_t nProfiles) {
+    evalThr *= ((float) nFragments) / nProfiles;
+    char txt[64];
+    snprintf(txt, sizeof(txt), "%g", evalThr);
+    return strtod(txt, nullptr);
+}
+
 // target side of a command: from the precomputed index DB when there is one (the path itself is an index DB, or <path>.idx exists and
 // MMSEQS_IGNORE_INDEX is unset -- PrefilteringIndexReader::searchForIndex, PrefilteringIndexReader.cpp:568-579), else built from the
 // sequence DB.  keys[i] = DB key of target i.
@@ -192,7 +218,8 @@ int openTarget(const std::string &path, const mk_params &P, TargetSide &ts) {
         int32_t t = -1;
         if (f) { if (fread(&t, 4, 1, f) != 1) t = -1; fclose(f); }
         if (t >= 0 && (t & 0xFFFF) == 9) idx = path;
-        else if (!getenv("MMSEQS_IGNORE_INDEX") && mk::Database::exists(path + ".idx.dbtype")) idx = path + ".idx";
+        else if (!P.profile_search && !getenv("MMSEQS_IGNORE_INDEX") && mk::Database::exists(path + ".idx.dbtype")) idx = path + ".idx";
+        // (profile queries need their own masking background and an unfiltered index: a sequence-search .idx next to the DB is not used)
     }
     if (!idx.empty()) {
         if (mk_targetdb_open_index(idx.c_str(), &P, &ts.T) != MK_OK) return die("%s", mk_last_error());
@@ -319,11 +346,18 @@ int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
     if (isAlign && a.opt.find("--alignment-mode") == a.opt.end())
         return die("%s needs --alignment-mode 2 (the module default, 0 = score only, is not implemented)", isSearch ? "search" : "align");
     if (int rc = fillParams(a, P, gpu)) return rc;
+    // --alignment-output-mode 1 (the per-slice `align` of the sliced profile workflow): the accepted targets' keys only
+    const bool keyListOut = isAlign && a.opt.count("--alignment-output-mode") && a.opt["--alignment-output-mode"] == "1";
+    if (a.opt.count("--alignment-output-mode") && a.opt["--alignment-output-mode"] != "0" && !keyListOut)
+        return die("--alignment-output-mode %s: only 0 (alignment records) and 1 (key lists) are implemented", a.opt["--alignment-output-mode"]);
     const double t0 = now();
     mk::Database qdb;
     std::string e = qdb.open(a.pos[0]);
     if (!e.empty()) return die("%s", e);
-    if ((qdb.dbtype & 0xFFFF) != mk::DBTYPE_AMINO_ACIDS) return die("only amino-acid query databases are implemented%s");
+    const bool profileQueries = (qdb.dbtype & 0xFFFF) == DBTYPE_HMM_PROFILE;      // the modules as searchslicedtargetprofile.sh calls them
+    if (!profileQueries && (qdb.dbtype & 0xFFFF) != mk::DBTYPE_AMINO_ACIDS) return die("only amino-acid and profile query databases are implemented%s");
+    if (profileQueries && isSearch) return die("search with a profile query DB is not a workflow of the reference: use predictexons with a profile target DB, or prefilter / align / swapresults%s");
+    if (profileQueries) P.profile_search = 1;
     Shard sh;
     if (int rc = shardOf(a, sh, argc, argv)) return rc;
     beginShard(a.pos[isAlign && !isSearch ? 3 : 2], sh);
@@ -338,13 +372,14 @@ int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
     if (mk_init(gpu) != MK_OK) return die("%s", mk_last_error());
     std::vector<uint8_t> qres;
     std::vector<uint64_t> qoff;
-    encodeDb(qdb, qres, qoff);
+    if (profileQueries) profileColumns(qdb, qres, qoff); else encodeDb(qdb, qres, qoff);
     TargetSide ts;
     if (int rc = openTarget(a.pos[1], P, ts)) return rc;
     mk_targetdb *T = ts.T;
     const std::vector<uint32_t> &tkeys = ts.keys;
     mk_queries *Q = nullptr;
-    if (mk_queries_create(qres.data(), qoff.data(), (uint32_t) qdb.entries.size(), &P, &Q) != MK_OK) return die("%s", mk_last_error());
+    if ((profileQueries ? mk_profiles_create(qres.data(), qoff.data(), (uint32_t) qdb.entries.size(), &P, &Q)
+                        : mk_queries_create(qres.data(), qoff.data(), (uint32_t) qdb.entries.size(), &P, &Q)) != MK_OK) return die("%s", mk_last_error());
     const size_t nq = qdb.entries.size();
     char line[512];
     std::string buf;
@@ -391,8 +426,16 @@ int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
                 char *q;
                 mk_hit h;
                 const uint32_t key = (uint32_t) strtoul(p, &q, 10);
-                h.pref_score = (int32_t) strtol(q, &q, 10);
-                h.diagonal = (uint16_t) (short) strtol(q, &q, 10);
+                // a line with the key alone (the key lists of --alignment-output-mode 1 that the sliced workflow re-aligns) or with other
+                // columns than a prefilter hit's three: diagonal 0 (Alignment.cpp:352-361)
+                h.pref_score = 0; h.diagonal = 0;
+                if (*q == '\t') {
+                    h.pref_score = (int32_t) strtol(q, &q, 10);
+                    if (*q == '\t') {
+                        h.diagonal = (uint16_t) (short) strtol(q, &q, 10);
+                        if (*q == '\t') { h.pref_score = 0; h.diagonal = 0; }      // more than three columns: not a prefilter hit
+                    }
+                }
                 h.pad_ = 0;
                 auto ti = tKeyToIdx.find(key);
                 if (ti == tKeyToIdx.end()) return die("Sequence %s is required in the prefiltering, but is not contained in the target sequence database", std::to_string(key));
@@ -409,7 +452,7 @@ int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
         }
         const mk_alignment *alns; const uint64_t *aoff;
         mk_align_result(Q, &alns, &aoff);
-        mk::DatabaseWriter w(outPath, mk::DBTYPE_ALIGNMENT_RES);
+        mk::DatabaseWriter w(outPath, keyListOut ? 6 /* DBTYPE_CLUSTER_RES, Alignment.cpp:250-252 */ : mk::DBTYPE_ALIGNMENT_RES);
         e = w.open();
         if (!e.empty()) return die("%s", e);
         for (size_t i = 0; i < nq; i++) {
@@ -417,6 +460,7 @@ int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
             for (uint64_t k = aoff[i]; k < aoff[i + 1]; k++) {
                 mk_alignment al = alns[k];
                 al.db_key = tkeys[al.db_key];
+                if (keyListOut) { buf.append(line, (size_t) snprintf(line, sizeof(line), "%u\n", al.db_key)); continue; }   // Alignment.cpp:499-503
                 buf.append(line, mk_format_alignment(line, &al));
             }
             w.write(qdb.entries[i].key, buf.data(), buf.size());
@@ -427,7 +471,74 @@ int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
     }
     mk_queries_destroy(Q);
     mk_targetdb_destroy(T);
-    return finishShards(outBase, sh, isAlign ? mk::DBTYPE_ALIGNMENT_RES : mk::DBTYPE_PREFILTER_RES);
+    return finishShards(outBase, sh, isAlign ? (keyListOut ? 6 : mk::DBTYPE_ALIGNMENT_RES) : mk::DBTYPE_PREFILTER_RES);
+}
+
+// swapresults <i:queryDB> <i:targetDB> <i:resultDB> <o:resultDB> [-e]      M/src/util/swapresults.cpp:356-360 (doswap, alignment results)
+//   queryDB / targetDB = the two sides of the search that produced resultDB (in the sliced workflow: the PROFILE DB and the fragments);
+//   the output lists, per target key, the queries that hit it, e-values recomputed for the search the other way round.  Host code.
+int cmdSwapResults(int argc, char **argv) {
+    Args a;
+    if (int rc = parse(argc, argv, a)) return rc;
+    if (a.pos.size() != 4) return die("usage: metaeuk-amd swapresults <i:queryDB> <i:targetDB> <i:resultDB> <o:resultDB> [-e EVAL]%s");
+    mk_params P;
+    int gpu = 0;
+    if (int rc = fillParams(a, P, gpu)) return rc;
+    if (a.opt.find("-e") == a.opt.end()) P.evalue_thr = 0.001;              // Parameters.cpp:2414
+    mk::Database qdb, tdb, rdb;
+    std::string e = qdb.open(a.pos[0]);
+    if (e.empty()) e = tdb.open(a.pos[1]);
+    if (e.empty()) e = rdb.open(a.pos[2]);
+    if (!e.empty()) return die("%s", e);
+    if ((rdb.dbtype & 0xFFFF) != mk::DBTYPE_ALIGNMENT_RES) return die("swapresults: only alignment result DBs (type 5) are implemented%s");
+    uint64_t aaResSize = 0;                                                  // query.sequenceReader->getAminoAcidDBSize(), swapresults.cpp:76-77
+    if ((qdb.dbtype & 0xFFFF) == DBTYPE_HMM_PROFILE) aaResSize = profileDbResidues(qdb);
+    else for (size_t i = 0; i < qdb.entries.size(); i++) aaResSize += qdb.seqLen(i);
+    // targets by key: the output has one entry per key of the target DB (targetElementExists, :84-91,337-339)
+    std::vector<size_t> tord = tdb.keyOrder();
+    std::map<uint32_t, uint32_t> tKeyToIdx;
+    for (size_t i = 0; i < tord.size(); i++) tKeyToIdx[tdb.entries[tord[i]].key] = (uint32_t) i;
+    std::vector<mk_alignment> alns;
+    std::vector<uint64_t> off(1, 0);
+    std::vector<uint32_t> qkeys;
+    for (size_t i = 0; i < rdb.entries.size(); i++) {
+        const char *p = rdb.entry(i);
+        while (*p != '\0') {                                                 // Matcher::parseAlignmentRecord (Matcher.cpp:203-239), 10 columns
+            mk_alignment x;
+            std::memset(&x, 0, sizeof(x));
+            unsigned key = 0; char sid[64], ev[64];
+            if (sscanf(p, "%u\t%d\t%63s\t%63s\t%d\t%d\t%d\t%d\t%d\t%d", &key, &x.bit_score, sid, ev, &x.q_start, &x.q_end, &x.q_len, &x.db_start, &x.db_end, &x.db_len) != 10)
+                return die("Invalid alignment result record in %s", a.pos[2]);
+            auto ti = tKeyToIdx.find(key);
+            if (ti == tKeyToIdx.end()) return die("swapresults: key %s of the result DB is not in the target DB", std::to_string(key));
+            x.db_key = ti->second;
+            x.seq_id = (float) strtod(sid, nullptr); x.evalue = strtod(ev, nullptr);
+            alns.push_back(x);
+            while (*p != '\n' && *p != '\0') p++;
+            if (*p == '\n') p++;
+        }
+        off.push_back(alns.size());
+        qkeys.push_back(rdb.entries[i].key);
+    }
+    mk_swapped *S = nullptr;
+    if (mk_swap_alignments(alns.data(), off.data(), (uint32_t) qkeys.size(), qkeys.data(), (uint32_t) tord.size(), aaResSize, &P, &S) != MK_OK) return die("%s", mk_last_error());
+    const mk_alignment *sw; const uint64_t *soff;
+    mk_swapped_result(S, &sw, &soff);
+    mk::DatabaseWriter w(a.pos[3], mk::DBTYPE_ALIGNMENT_RES);
+    e = w.open();
+    if (!e.empty()) return die("%s", e);
+    std::string buf;
+    char line[512];
+    for (size_t t = 0; t < tord.size(); t++) {
+        buf.clear();
+        for (uint64_t k = soff[t]; k < soff[t + 1]; k++) buf.append(line, mk_format_alignment(line, &sw[k]));
+        w.write(tdb.entries[tord[t]].key, buf.data(), buf.size());
+    }
+    e = w.close();
+    if (!e.empty()) return die("%s", e);
+    fprintf(stderr, "swapresults: %zu result lists -> %zu target entries, %llu records\n", qkeys.size(), tord.size(), (unsigned long long) soff[tord.size()]);
+    mk_swapped_destroy(S);
+    return EXIT_SUCCESS;
 }
 
 // end of the batch of contigs (positions in `ord`) that starts at c0: as many as fit the per-call nucleotide budget (MK_CLI_BATCH_NT,
@@ -546,6 +657,111 @@ int cmdExtractOrfs(int argc, char **argv) {
     return EXIT_SUCCESS;
 }
 
+// predictexons against a PROFILE database (BASELINE config 4): Search.cpp:357-399 + searchslicedtargetprofile.sh in one
+// process.  The fragments of ALL contigs become the indexed target side (the reference indexes the whole aa_6f DB as well: its numbers --
+// fragments, residues -- enter the e-value threshold, the e-values and --max-seqs), the profiles go through prefilter + align in slices
+// bounded by their columns, swapresults turns the lists round, the exon stage runs on them.  The workflow's second `align` (the merged key
+// lists again, to "keep the top hits") accepts exactly the pairs of the first with --max-accept / --max-rejected at their defaults, so one
+// pass is the result.  Not sharded: a worker would need the other workers' fragment counts before it can score anything.
+int predictExonsProfileTargets(const Args &a, mk_params P, const mk_exon_params &X, int minLength, const mk::Database &contigs, const std::vector<size_t> &ord,
+                               const Shard &sh, const std::string &outPath, double t0) {
+    if (sh.world > 1) return die("predictexons with a profile target database is not sharded: run it as one process%s");
+    static const char none = 0;
+    if (!ord.empty() && contigBatchEnd(contigs, ord, 0) != ord.size())
+        return die("predictexons with a profile target database takes all contigs in one batch: raise MK_CLI_BATCH_NT (now %s nucleotides per batch)",
+                   getenv("MK_CLI_BATCH_NT") ? getenv("MK_CLI_BATCH_NT") : "2^29");
+    mk::Database pdb;
+    std::string e = pdb.open(a.pos[1]);
+    if (!e.empty()) return die("%s", e);
+    std::vector<char> nucl;
+    std::vector<uint64_t> off(1, 0);
+    for (size_t i = 0; i < ord.size(); i++) {
+        nucl.insert(nucl.end(), contigs.entry(ord[i]), contigs.entry(ord[i]) + contigs.seqLen(ord[i]));
+        off.push_back(nucl.size());
+    }
+    mk_orfs *O = nullptr;
+    if (mk_extract_orfs(nucl.empty() ? &none : nucl.data(), off.data(), (uint32_t) ord.size(), minLength, &O) != MK_OK) return die("%s", mk_last_error());
+    const mk_orf *orfs; const uint64_t *aaOff; const char *aa; uint64_t nFrag = 0;
+    mk_orfs_result(O, &orfs, &aaOff, &aa, &nFrag);
+    const size_t nProf = pdb.entries.size();
+    // the fragments as the target side of a profile search
+    std::vector<uint8_t> fres(aaOff[nFrag] + 1);
+    mk_encode(aa, aaOff[nFrag], fres.data());
+    const double evalThrUser = P.evalue_thr;
+    P.profile_search = 1;
+    P.max_seqs = (int) std::max<uint64_t>(300, nFrag);                       // Search.cpp:372
+    P.evalue_thr = nProf ? invertedEvalue(evalThrUser, (size_t) nFrag, nProf) : evalThrUser;
+    mk_targetdb *F = nullptr;
+    if (mk_targetdb_create(fres.data(), aaOff, (uint32_t) nFrag, &P, &F) != MK_OK) return die("%s", mk_last_error());
+    const double t1 = now();
+    // profiles by key, in slices of at most MK_CLI_PROFILE_COLS columns (default 2^24)
+    std::vector<size_t> pord = pdb.keyOrder();
+    const uint64_t sliceCols = getenv("MK_CLI_PROFILE_COLS") ? strtoull(getenv("MK_CLI_PROFILE_COLS"), nullptr, 10) : (1ull << 24);
+    std::vector<mk_alignment> alnAll;
+    std::vector<uint64_t> alnOff(1, 0);
+    std::vector<uint32_t> pkeys;
+    uint64_t nHits = 0;
+    for (size_t p0 = 0; p0 < nProf; ) {
+        size_t p1 = p0;
+        uint64_t cols = 0;
+        std::vector<uint64_t> coff(1, 0);
+        while (p1 < nProf && (p1 == p0 || cols + (std::max<uint64_t>(pdb.entries[pord[p1]].length, 1) - 1) / 25 <= sliceCols)) {
+            cols += (std::max<uint64_t>(pdb.entries[pord[p1]].length, 1) - 1) / 25;
+            coff.push_back(cols);
+            p1++;
+        }
+        std::vector<uint8_t> colBytes(cols * 25 + 1);
+        for (size_t i = p0; i < p1; i++) std::memcpy(colBytes.data() + coff[i - p0] * 25, pdb.entry(pord[i]), (size_t) (coff[i - p0 + 1] - coff[i - p0]) * 25);
+        mk_queries *Q = nullptr;
+        if (mk_profiles_create(colBytes.data(), coff.data(), (uint32_t) (p1 - p0), &P, &Q) != MK_OK) return die("%s", mk_last_error());
+        if (mk_search(F, Q, &P) != MK_OK) return die("%s", mk_last_error());
+        const mk_hit *hp; const uint64_t *ho;
+        mk_prefilter_result(Q, &hp, &ho);
+        nHits += ho[p1 - p0];
+        const mk_alignment *alns; const uint64_t *aoff;
+        mk_align_result(Q, &alns, &aoff);
+        alnAll.insert(alnAll.end(), alns, alns + aoff[p1 - p0]);
+        for (size_t i = p0; i < p1; i++) { alnOff.push_back(alnOff[p0] + aoff[i - p0 + 1]); pkeys.push_back(pdb.entries[pord[i]].key); }
+        mk_queries_destroy(Q);
+        p0 = p1;
+    }
+    const double t2 = now();
+    // swapresults -e DBL_MAX (Search.cpp:378-381), then the exon stage on the fragments' lists: target = profile key, the e-values of a set
+    // use the profile DB's column count (collectoptimalset opens the target DB: DBReader::getAminoAcidDBSize)
+    const uint64_t profRes = profileDbResidues(pdb);
+    mk_params SP = P;
+    SP.evalue_thr = std::numeric_limits<double>::max();
+    mk_swapped *S = nullptr;
+    if (mk_swap_alignments(alnAll.data(), alnOff.data(), (uint32_t) nProf, pkeys.data(), (uint32_t) nFrag, profRes, &SP, &S) != MK_OK) return die("%s", mk_last_error());
+    const mk_alignment *sw; const uint64_t *soff;
+    mk_swapped_result(S, &sw, &soff);
+    mk_predictions *R = nullptr;
+    if (mk_predict_exons_arrays(orfs, nFrag, (uint32_t) ord.size(), sw, soff, profRes, &X, nullptr, &R) != MK_OK) return die("%s", mk_last_error());
+    const mk_prediction *preds; const uint64_t *coffs; const mk_exon *exons; uint64_t np = 0;
+    mk_predictions_result(R, &preds, &coffs, &exons, &np);
+    mk::DatabaseWriter w(outPath, 12 /* DBTYPE_GENERIC_DB, collectoptimalset.cpp:244 */);
+    e = w.open();
+    if (!e.empty()) return die("%s", e);
+    std::string buf;
+    char line[512];
+    for (size_t c = 0; c < ord.size(); c++) {
+        buf.clear();
+        for (uint64_t k = coffs[c]; k < coffs[c + 1]; k++)
+            for (uint64_t x = preds[k].first_exon; x < preds[k].first_exon + preds[k].n_exons; x++) buf.append(line, mk_format_prediction_exon(line, &preds[k], &exons[x]));
+        w.write(contigs.entries[ord[c]].key, buf.data(), buf.size());
+    }
+    e = w.close();
+    if (!e.empty()) return die("%s", e);
+    fprintf(stderr, "predictexons (profile targets): %zu contigs -> %llu fragments x %zu profiles -> %llu prefilter hits, %llu alignments -> %llu predictions; "
+            "%.2f s (fragment index %.2f s, search %.2f s, swap + exon sets %.2f s)\n", ord.size(), (unsigned long long) nFrag, nProf, (unsigned long long) nHits,
+            (unsigned long long) alnOff.back(), (unsigned long long) np, now() - t0, t1 - t0, t2 - t1, now() - t2);
+    mk_predictions_destroy(R);
+    mk_swapped_destroy(S);
+    mk_targetdb_destroy(F);
+    mk_orfs_destroy(O);
+    return finishShards(a.pos[2], sh, 12);
+}
+
 // predictexons <i:contigsDB> <i:targetsDB> <o:calledExonsDB> <tmpDir> [flags]   src/workflow/PredictExons.cpp:18-57, data/predictexons.sh
 //   the whole workflow in one process: extractorfs + translatenucs + search (prefilter, align) + resultspercontig +
 //   collectoptimalset, with nothing written between the stages.  Output = the dp_predictions DB the script moves to <o> (:96): one
@@ -593,6 +809,13 @@ int cmdPredictExons(int argc, char **argv) {
         ord = std::vector<size_t>(ord.begin() + (std::ptrdiff_t) first, ord.begin() + (std::ptrdiff_t) (first + count));
     }
     const std::string outPath = sh.world > 1 ? a.pos[2] + "_" + std::to_string(sh.rank) : a.pos[2];
+    {   // a PROFILE target database: the inverted search of searchslicedtargetprofile.sh (PredictExons.cpp:22-26 forces it)
+        FILE *f = fopen((a.pos[1] + ".dbtype").c_str(), "rb");
+        int32_t t = -1;
+        if (f) { if (fread(&t, 4, 1, f) != 1) t = -1; fclose(f); }
+        if (t >= 0 && (t & 0xFFFF) == DBTYPE_HMM_PROFILE) return predictExonsProfileTargets(a, P, X, minLength, contigs, ord, sh, outPath, t0);
+        if (get("--exhaustive-search") && *get("--exhaustive-search") != "0") return die("--exhaustive-search 1 with a sequence target database is not implemented%s");
+    }
     TargetSide ts;
     if (int rc = openTarget(a.pos[1], P, ts)) return rc;
     mk_targetdb *T = ts.T;
@@ -748,6 +971,7 @@ int main(int argc, char **argv) {
     if (cmd == "extractorfs") return cmdExtractOrfs(argc, argv);
     if (cmd == "predictexons") return cmdPredictExons(argc, argv);
     if (cmd == "createindex" || cmd == "indexdb") return cmdCreateIndex(argc, argv);
+    if (cmd == "swapresults") return cmdSwapResults(argc, argv);
     fprintf(stderr, "Invalid Command: %s\n", cmd.c_str());
     return EXIT_FAILURE;
 }

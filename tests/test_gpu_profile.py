@@ -186,3 +186,58 @@ def test_profile_and_sequence_roles_are_checked(gpu_api):
     q = api.Profiles(entries[:5], pp)
     with pytest.raises(api.MkError):
         api.prefilter(db, q, pp)
+
+
+def _read_result_db(base):
+    data = open(base, "rb").read()
+    out = {}
+    for line in open(base + ".index"):
+        k, o, l = line.split("\t")
+        out[int(k)] = data[int(o):int(o) + int(l) - 1].decode()
+    return out
+
+
+def test_cli_profile_workflow_equals_the_real_process(gpu_api, tmp_path):
+    """the commands of searchslicedtargetprofile.sh -- prefilter, align (key lists), align (the merged lists again), swapresults -- with
+    the parameter strings the real workflow printed, on the profile DB it used and a fragment DB laid out in its data order; then
+    `predictexons contigsDB profileDB` as one command against the real run's dp_predictions"""
+    from metaeuk_amd import api as A, build
+    keys, entries, frags, order, _ = _golden_inputs()
+    (tmp_path / "profDB").write_bytes(gzip.open(os.path.join(GOLD, "prof_db.bin.gz"), "rb").read())
+    (tmp_path / "profDB.index").write_text(open(os.path.join(GOLD, "prof_db.index")).read())
+    (tmp_path / "profDB.dbtype").write_bytes((2).to_bytes(4, "little"))
+    A.write_seq_db(str(tmp_path / "aa_6f"), A.seq_db_image(frags, order=order))
+    run = lambda *a: subprocess.check_call([build.BIN] + [str(x) for x in a], stderr=subprocess.DEVNULL)
+    common = ["--threads", "4", "--compressed", "0", "-v", "3"]
+    run("prefilter", tmp_path / "profDB", tmp_path / "aa_6f", tmp_path / "pref", "--sub-mat", "aa:blosum62.out,nucl:nucleotide.out",
+        "--seed-sub-mat", "aa:VTML80.out,nucl:nucleotide.out", "-s", "4", "-k", "0", "--target-search-mode", "0", "--k-score", "seq:2147483647,prof:2147483647",
+        "--alph-size", "aa:21,nucl:5", "--max-seq-len", "65535", "--max-seqs", "24084", "--split", "0", "--split-mode", "2", "--split-memory-limit", "0",
+        "-c", "0", "--cov-mode", "0", "--comp-bias-corr", "1", "--comp-bias-corr-scale", "1", "--diag-score", "1", "--exact-kmer-matching", "0",
+        "--mask", "1", "--mask-prob", "0.9", "--mask-lower-case", "0", "--mask-n-repeat", "0", "--min-ungapped-score", "15", "--add-self-matches", "0",
+        "--spaced-kmer-mode", "1", "--db-load-mode", "0", "--pca", "substitution:1.100,context:1.400", "--pcb", "substitution:4.100,context:5.800",
+        "--ref-l2-bytes", "2097152", *common)
+    blocks = lambda d: "".join(">%d\n%s" % (k, d[k]) for k in sorted(d))
+    assert blocks(_read_result_db(str(tmp_path / "pref"))) == _text("prof_pref.txt.gz")
+    aln_flags = ["--sub-mat", "aa:blosum62.out,nucl:nucleotide.out", "-a", "0", "--alignment-mode", "2", "--wrapped-scoring", "0", "-e", "24084", "--min-seq-id", "0",
+                 "--min-aln-len", "11", "--seq-id-mode", "0", "--alt-ali", "0", "-c", "0", "--cov-mode", "0", "--max-seq-len", "65535", "--comp-bias-corr", "1",
+                 "--comp-bias-corr-scale", "1", "--max-rejected", "2147483647", "--max-accept", "2147483647", "--add-self-matches", "0", "--db-load-mode", "0",
+                 "--pca", "substitution:1.100,context:1.400", "--pcb", "substitution:4.100,context:5.800", "--score-bias", "0", "--realign", "0",
+                 "--realign-score-bias", "-0.2", "--realign-max-seqs", "2147483647", "--corr-score-weight", "0", "--gap-open", "aa:11,nucl:5",
+                 "--gap-extend", "aa:1,nucl:2", "--zdrop", "40", *common]
+    run("align", tmp_path / "profDB", tmp_path / "aa_6f", tmp_path / "pref", tmp_path / "aln_it", "--alignment-output-mode", "1", *aln_flags)
+    it = _read_result_db(str(tmp_path / "aln_it"))
+    expected = {}
+    for blk in _text("prof_aln.txt.gz").split(">")[1:]:
+        head, _, body = blk.partition("\n")
+        expected[int(head)] = "".join(l.split("\t")[0] + "\n" for l in body.splitlines())
+    assert it == expected                                                    # the key lists = the first column of the final records
+    run("align", tmp_path / "profDB", tmp_path / "aa_6f", tmp_path / "aln_it", tmp_path / "aln", "--alignment-output-mode", "0", *aln_flags)
+    assert blocks(_read_result_db(str(tmp_path / "aln"))) == _text("prof_aln.txt.gz")
+    run("swapresults", tmp_path / "profDB", tmp_path / "aa_6f", tmp_path / "aln", tmp_path / "search_res", "--sub-mat", "aa:blosum62.out,nucl:nucleotide.out",
+        "-e", "1.79769e+308", "--split-memory-limit", "0", "--gap-open", "aa:11,nucl:5", "--gap-extend", "aa:1,nucl:2", "--db-load-mode", "0", *common)
+    assert blocks(_read_result_db(str(tmp_path / "search_res"))) == _text("prof_search_res.txt.gz")
+    # the whole workflow as one command (default -s 4, -e 100 scaled by 24084 fragments / 100 profiles)
+    contigs = _text("e2e_contigs.txt.gz").splitlines()
+    A.write_seq_db(str(tmp_path / "contigs"), A.seq_db_image(contigs), dbtype=1)
+    run("predictexons", tmp_path / "contigs", tmp_path / "profDB", tmp_path / "calls", tmp_path / "tmp", "--threads", "4", "--ref-l2-bytes", "2097152")
+    assert blocks(_read_result_db(str(tmp_path / "calls"))) == _text("prof_calls.txt.gz")
