@@ -40,7 +40,7 @@ VALU_PEAK_TOPS = 256 * 4 * 64 * 2.4e9 / 4 / 1e12   # = 39.3 T lane-ops/s
 # lane-ops per DP cell: the int32 kernels (position / reverse pass, large tiles) spend 10 (add, min, max3, lshl_or, max, sub, sub, max3, sub,
 # max3), the packed int16 score pass 10 per PAIR of cells (perm, add, max, max, max, sub, sub, max, sub, max) = 5 per cell
 SW_OPS_PER_CELL_INT32, SW_OPS_PER_CELL_PACKED = 10, 5
-PACKED_ROWS_MAX = 512     # tiles of at most 512 rows run the packed score pass (mk_kernels.hpp: sw_cfg_packed)
+PACKED_ROWS_MAX = 768     # tiles of at most 768 rows run the packed score pass (mk_kernels.hpp: sw_cfg_packed)
 
 
 def pmc_traffic(kernel_name):

@@ -662,46 +662,42 @@ int mk_swap_alignments(const mk_alignment *alns, const uint64_t *offsets, uint32
     if (!offsets || !P || !out || (!alns && offsets[nq] > 0)) return fail(MK_ERR_ARG, "null argument");
     const uint64_t total = offsets[nq];
     for (uint64_t k = 0; k < total; k++) if (alns[k].db_key >= nTargets) return fail(MK_ERR_ARG, "alignment %llu names target %u of %u", (unsigned long long) k, alns[k].db_key, nTargets);
-    mk_swapped *s = new mk_swapped();
-    s->off.assign((size_t) nTargets + 1, 0);
-    for (uint64_t k = 0; k < total; k++) s->off[(size_t) alns[k].db_key + 1]++;
-    for (uint32_t t = 0; t < nTargets; t++) s->off[t + 1] += s->off[t];
-    s->alns.resize(total);
-    std::vector<uint64_t> fill(s->off.begin(), s->off.end() - 1);
+    HostTimer ht("host_swap_total");
     mk::Evaluer ev;
     ev.init(swappedDbResidues);                        // swapresults.cpp:76-77,102
     const double ln2 = std::log(2.0);
+    // 1. every record swapped in place of a copy (parallel over the queries); a record beyond -e is marked (the workflow passes DBL_MAX)
+    std::vector<mk_alignment> tmp(total);
+    std::vector<uint32_t> target(total);
+    std::vector<uint64_t> cnt((size_t) nTargets + 1, 0);
+#pragma omp parallel for schedule(dynamic, 64)
     for (uint32_t i = 0; i < nq; i++) {
         for (uint64_t k = offsets[i]; k < offsets[i + 1]; k++) {
             mk_alignment a = alns[k];
-            // the record as swapresults re-reads it from its text (Matcher::parseAlignmentRecord, Matcher.cpp:203-239): the identity
-            // has three decimals there
-            char buf[192];
-            mk_format_alignment(buf, &a);
-            const char *p1 = strchr(buf, '\t'); p1 = p1 ? strchr(p1 + 1, '\t') : nullptr;
-            if (p1) a.seq_id = (float) strtod(p1 + 1, nullptr);
+            // the record as swapresults re-reads it from its text (Matcher::parseAlignmentRecord, Matcher.cpp:203-239): the identity has
+            // three decimals there -- "0.xyz" with xyz = (int)(seqId * 1000) (Util::fastSeqIdToBuffer), "1.00" for 1.0 -- and the nearest
+            // double of that decimal is the correctly rounded quotient xyz / 1000
+            if (!(a.seq_id == 1.0f)) a.seq_id = (float) ((double) (int) (a.seq_id * 1000) / 1000.0);
             // Matcher::result_t::swapResult (Matcher.h:93-115)
             const double rawScore = (ev.logK + (double) a.bit_score * ln2) / ev.lambda;        // EvalueComputation.h:22-24
             a.evalue = ev.evalue(rawScore, (double) a.db_len);
-            const uint32_t target = a.db_key;
+            target[k] = a.db_key;
             std::swap(a.q_start, a.db_start); std::swap(a.q_end, a.db_end); std::swap(a.q_len, a.db_len); std::swap(a.qcov, a.dbcov);
             a.db_key = queryKeys ? queryKeys[i] : i;
-            if (a.evalue <= P->evalue_thr) s->alns[fill[target]++] = a;                      // swapresults.cpp:291-295 (-e)
-            else s->alns[fill[target]++].db_key = 0xFFFFFFFFu;
+            if (!(a.evalue <= P->evalue_thr)) target[k] = 0xFFFFFFFFu;                       // swapresults.cpp:291-295 (-e)
+            tmp[k] = a;
         }
     }
-    // lists with records beyond -e are compacted (the workflow passes DBL_MAX: none)
-    bool holes = false;
-    for (uint64_t k = 0; k < total && !holes; k++) holes = s->alns[k].db_key == 0xFFFFFFFFu && s->alns[k].q_len == 0 && s->alns[k].db_len == 0;
-    if (holes) {
-        std::vector<mk_alignment> kept; kept.reserve(total);
-        std::vector<uint64_t> noff((size_t) nTargets + 1, 0);
-        for (uint32_t t = 0; t < nTargets; t++) {
-            for (uint64_t k = s->off[t]; k < s->off[t + 1]; k++)
-                if (!(s->alns[k].db_key == 0xFFFFFFFFu && s->alns[k].q_len == 0 && s->alns[k].db_len == 0)) kept.push_back(s->alns[k]);
-            noff[t + 1] = kept.size();
-        }
-        s->alns.swap(kept); s->off.swap(noff);
+    // 2. lists per target: counts, offsets, scatter (the order inside a list is settled by the sort: compareHits is a total order here,
+    //    its last key -- the query's DB key -- is unique within a list)
+    for (uint64_t k = 0; k < total; k++) if (target[k] != 0xFFFFFFFFu) cnt[(size_t) target[k] + 1]++;
+    for (uint32_t t = 0; t < nTargets; t++) cnt[t + 1] += cnt[t];
+    mk_swapped *s = new mk_swapped();
+    s->off = cnt;
+    s->alns.resize(cnt[nTargets]);
+    {
+        std::vector<uint64_t> fill(cnt.begin(), cnt.end() - 1);
+        for (uint64_t k = 0; k < total; k++) if (target[k] != 0xFFFFFFFFu) s->alns[fill[target[k]]++] = tmp[k];
     }
 #pragma omp parallel for schedule(dynamic, 1024)
     for (uint32_t t = 0; t < nTargets; t++)

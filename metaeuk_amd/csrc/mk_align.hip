@@ -239,43 +239,48 @@ __global__ __launch_bounds__(256) void assemble_kernel(AssembleView A) {
     A.pass[i] = (a.evalue <= A.evalThr && a.aln_len >= A.minAlnLen) ? 1 : 0;
 }
 
-__device__ __forceinline__ bool aln_less(const mk_alignment &a, uint32_t ka, const mk_alignment &b, uint32_t kb) {   // Matcher::compareHits (Matcher.h:157-168)
-    if (a.evalue != b.evalue) return a.evalue < b.evalue;
-    if (a.bit_score != b.bit_score) return a.bit_score > b.bit_score;
-    if (a.db_len != b.db_len) return a.db_len < b.db_len;
-    return ka < kb;
-}
 
-// one lane per query: its records are raw[first .. next) (raw is ordered by pair = by query); COUNT: how many pass; else: insertion
-// sort of the passing ones into out[off[q] ...] (a query has a handful of alignments, at most --max-seqs)
-template <bool COUNT>
-__global__ __launch_bounds__(256) void assemble_finish_kernel(AssembleView A, uint32_t *cnt, const uint32_t *off, mk_alignment *out) {
+// one lane per query: its records are raw[first .. next) (raw is ordered by pair = by query): how many pass
+__global__ __launch_bounds__(256) void assemble_count_kernel(AssembleView A, uint32_t *cnt) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= A.nq) return;
     const auto first_at = [&](uint64_t want) { uint32_t lo = 0, hi = A.n; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t) A.raw[mid].pair < want) lo = mid + 1; else hi = mid; } return lo; };
     const uint32_t b = first_at(A.hitOff[q]), e = first_at(A.hitOff[q + 1]);
-    if (COUNT) {
-        uint32_t c = 0;
-        for (uint32_t k = b; k < e; k++) c += A.pass[k];
-        cnt[q] = c;
-        return;
-    }
-    mk_alignment *dst = out + off[q];
-    uint32_t m = 0;
-    for (uint32_t k = b; k < e; k++) {
-        if (!A.pass[k]) continue;
-        const mk_alignment a = A.tmp[k];
-        const uint32_t ka = A.sortKey ? A.sortKey[a.db_key] : a.db_key;
-        uint32_t j = m;
-        while (j > 0) {
-            const mk_alignment p = dst[j - 1];
-            if (!aln_less(a, ka, p, A.sortKey ? A.sortKey[p.db_key] : p.db_key)) break;
-            dst[j] = p;
-            j--;
+    uint32_t c = 0;
+    for (uint32_t k = b; k < e; k++) c += A.pass[k];
+    cnt[q] = c;
+}
+
+// The per-query order (Alignment.cpp:403-405, Matcher::compareHits), one lane per passing record: its place in the query's list is the
+// number of the query's passing records that sort before it.  compareHits is a total order inside a list (the last key, the target's DB
+// key, is unique there), so the ranks are a permutation.  A fragment has a handful of alignments; a profile query has hundreds to
+// thousands, and the n^2 comparisons of a list spread over its n lanes.
+__global__ __launch_bounds__(256) void assemble_rank_kernel(AssembleView A, const uint32_t *off, mk_alignment *out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.n || !A.pass[k]) return;
+    const uint64_t pair = A.raw[k].pair;
+    uint32_t q;
+    { uint32_t lo = 0, hi = A.nq; while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (A.hitOff[mid] <= pair) lo = mid; else hi = mid; } q = lo; }
+    const auto first_at = [&](uint64_t want) { uint32_t lo = 0, hi = A.n; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t) A.raw[mid].pair < want) lo = mid + 1; else hi = mid; } return lo; };
+    const uint32_t b = first_at(A.hitOff[q]), e = first_at(A.hitOff[q + 1]);
+    const mk_alignment a = A.tmp[k];
+    const uint32_t ka = A.sortKey ? A.sortKey[a.db_key] : a.db_key;
+    uint32_t rank = 0;
+    for (uint32_t j = b; j < e; j++) {
+        if (j == k || !A.pass[j]) continue;
+        const mk_alignment &p = A.tmp[j];
+        const double pe = p.evalue;
+        bool before;
+        if (pe != a.evalue) before = pe < a.evalue;
+        else if (p.bit_score != a.bit_score) before = p.bit_score > a.bit_score;
+        else if (p.db_len != a.db_len) before = p.db_len < a.db_len;
+        else {
+            const uint32_t kp = A.sortKey ? A.sortKey[p.db_key] : p.db_key;
+            before = kp != ka ? kp < ka : j < k;        // (a caller-installed list may name a target twice: the input order then decides)
         }
-        dst[j] = a;
-        m++;
+        rank += before ? 1u : 0u;
     }
+    out[off[q] + rank] = a;
 }
 
 }  // namespace
@@ -627,13 +632,13 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hi
         AV.evalThr = P.evalue_thr; AV.minAlnLen = P.min_aln_len; AV.tmp = dTmp; AV.pass = dPass; AV.flags = dFlags;
         th = tb("align_assemble", (double) nRev * (sizeof(AlnRaw) + 2.0 * sizeof(mk_alignment)), 0);
         hipLaunchKernelGGL(assemble_kernel, dim3((nRev + 255) / 256), dim3(256), 0, stream, AV);
-        hipLaunchKernelGGL((assemble_finish_kernel<true>), dim3((V.n_queries + 255) / 256), dim3(256), 0, stream, AV, dCnt, (const uint32_t *) nullptr, (mk_alignment *) nullptr);
+        hipLaunchKernelGGL(assemble_count_kernel, dim3((V.n_queries + 255) / 256), dim3(256), 0, stream, AV, dCnt);
         size_t tS = 0;
         hipcub::DeviceScan::ExclusiveSum(nullptr, tS, dCnt, dOff, (int) V.n_queries + 1, stream);
         void *tempS = dev_scratch("align_sort_temp", tS);
         ANULL(tempS);
         ACHK(hipcub::DeviceScan::ExclusiveSum(tempS, tS, dCnt, dOff, (int) V.n_queries + 1, stream));
-        hipLaunchKernelGGL((assemble_finish_kernel<false>), dim3((V.n_queries + 255) / 256), dim3(256), 0, stream, AV, dCnt, (const uint32_t *) dOff, dFinal);
+        hipLaunchKernelGGL(assemble_rank_kernel, dim3((nRev + 255) / 256), dim3(256), 0, stream, AV, (const uint32_t *) dOff, dFinal);
         te(th);
         ACHK(hipGetLastError());
         ACHK(hipMemcpyAsync(hFlags, dFlags, 8, hipMemcpyDeviceToHost, stream));

@@ -49,10 +49,10 @@ __host__ __device__ inline int sw_cfg_rows(int c) {
     const int rows[SW_NCFG] = {32, 48, 64, 96, 128, 192, 256, 384, 512, 768, 1024};
     return rows[c];
 }
-// forward pass of the pipeline: tiles of at most 512 rows run in packed int16, two targets per lane group (16 lanes up to 256
+// forward pass of the pipeline: tiles of at most 768 rows run in packed int16, two targets per lane group (16 lanes up to 256
 // rows: 8 jobs per wave; 32 lanes: 4 jobs per wave); larger tiles in int32 on 64 lanes (1 job per wave)
-__host__ __device__ inline bool sw_cfg_packed(int c) { return sw_cfg_rows(c) <= 512; }
-__host__ __device__ inline uint32_t sw_cfg_jobs_per_wave(int c) { return sw_cfg_rows(c) <= 256 ? 8u : (sw_cfg_rows(c) <= 512 ? 4u : 1u); }
+__host__ __device__ inline bool sw_cfg_packed(int c) { return sw_cfg_rows(c) <= 768; }
+__host__ __device__ inline uint32_t sw_cfg_jobs_per_wave(int c) { return sw_cfg_rows(c) <= 256 ? 8u : (sw_cfg_rows(c) <= 768 ? 4u : 1u); }
 __host__ __device__ inline int sw_cfg_of(uint32_t qLen) {
     int c = 0;
     while (c < SW_NCFG - 1 && (uint32_t) sw_cfg_rows(c) < qLen) c++;

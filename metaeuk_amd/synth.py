@@ -147,3 +147,29 @@ if __name__ == "__main__":
     with open(sys.argv[5] if len(sys.argv) > 5 else "queries.txt", "w") as f:
         f.write("\n".join(q) + "\n")
     print(len(t), len(q), sum(map(len, q)) / max(1, len(q)))
+
+
+def make_profiles(proteins, seed=11):
+    """Synthetic profile DB entries (25 bytes per column + a trailing NUL, Sequence.h:458-471) for a list of uint8 code arrays: every
+    column scores its own residue with the top value of a template, the other residues get the remaining values in a fixed per-residue
+    similarity order, plus Gaussian noise (sigma 5).  The template is the mean sorted column of result2profile's output on the e2e fixture
+    (tests/golden/prof_db.bin.gz) with ranks 2-5 raised by 2: ~160 similar k-mers per start at -s 4, like the real profiles' 171.  For timing the profile path."""
+    rs = np.random.RandomState(seed + 77)
+    template = np.array([21.6, 10.5, 5.9, 2.8, 0.4, -3.5, -5.0, -6.0, -6.9, -7.7, -8.4, -9.1, -9.6, -10.2, -10.8, -11.3, -11.9, -12.4, -13.1, -14.1])
+    rank_of = np.zeros((20, 20), dtype=np.int64)            # rank_of[c][a] = position of residue a in c's similarity order (c itself first)
+    for c in range(20):
+        others = [a for a in rs.permutation(20) if a != c]
+        rank_of[c, c] = 0
+        for r, a in enumerate(others):
+            rank_of[c, a] = r + 1
+    out = []
+    for p in proteins:
+        c = np.asarray(p, dtype=np.int64)
+        col = np.rint(template[rank_of[c]] + rs.normal(0.0, 5.0, size=(len(c), 20)))
+        cols = np.zeros((len(c), 25), dtype=np.uint8)
+        cols[:, :20] = np.clip(col, -128, 127).astype(np.int8).view(np.uint8)
+        cols[:, 20] = c
+        cols[:, 21] = c
+        cols[:, 22] = 10
+        out.append(cols.tobytes() + b"\0")
+    return out
