@@ -49,14 +49,20 @@ void mko_scoremat_free(mko_scoremat *s);
 
 /* similar k-mer list for k=6 (M/src/prefiltering/KmerGenerator.cpp:107-216) */
 size_t mko_kmer_list6(const mko_scoremat *three, const uint8_t *kmer, short threshold, uint64_t *out, size_t cap);
+/* ... and for k=7: divide strategy {2,2,3} (setDivideStrategy :41-86, kmerSize % 3 == 1, reversed), three steps */
+size_t mko_kmer_list7(const mko_scoremat *two, const mko_scoremat *three, const uint8_t *kmer, short threshold, uint64_t *out, size_t cap);
+/* spaced seeds of Sequence.h:23,25 */
+int mko_spaced_pattern(int k, const int **offsets);   /* returns the span (10 for k=6, 11 for k=7) */
 
 /* ---- tantan masking + k-mer index (M/lib/tantan, Masker.cpp, IndexBuilder.cpp, IndexTable.h) ---- */
 int mko_tantan_mask(const mko_submat *kmer_mat, uint8_t *seq, int L, double min_mask_prob, int simd_lanes);
 
 typedef struct {
-    int k;                   /* 6 */
+    int k;                   /* 6 or 7 */
     uint64_t table_size;     /* 20^k */
-    uint64_t *offsets;       /* table_size+1 */
+    uint64_t *offsets;       /* k = 6: table_size+1 (dense).  k = 7: n_kmers+1 over `kmers` (the oracle keeps the 1.28e9-cell table sparse) */
+    uint64_t *kmers;         /* k = 7: the distinct k-mers with a list, ascending; NULL for k = 6 */
+    uint64_t n_kmers;
     uint32_t *seq_id;        /* entries, sorted by (seq_id,pos) inside each k-mer list */
     uint16_t *pos;
     uint64_t n_entries;
@@ -67,6 +73,10 @@ typedef struct {
 } mko_index;
 mko_index *mko_index_build(const mko_submat *kmer_mat, const uint8_t *residues, const uint64_t *seq_off,
                            uint32_t n_seq, int kmer_thr, int mask, int simd_lanes);
+mko_index *mko_index_build_k(const mko_submat *kmer_mat, const uint8_t *residues, const uint64_t *seq_off,
+                             uint32_t n_seq, int kmer_thr, int mask, int simd_lanes, int k);
+/* index list of a k-mer: entries [*o0, *o1) of seq_id / pos */
+void mko_index_list(const mko_index *ix, uint64_t kmer, uint64_t *o0, uint64_t *o1);
 void mko_index_free(mko_index *ix);
 
 /* ---- prefilter for one query (M/src/prefiltering/QueryMatcher.cpp) ---- */
@@ -75,7 +85,8 @@ typedef struct {
     const mko_submat *kmer_mat;      /* VTML80 x8, bias -0.2 */
     const mko_submat *ungapped_mat;  /* BLOSUM62 x2, bias -0.2 */
     const mko_scoremat *three;
-    const mko_index *index;
+    const mko_scoremat *two;         /* k = 7 only */
+    const mko_index *index;          /* its k decides the spaced seed and the list generator */
     int kmer_thr;
     int max_hits;                    /* min(--max-seqs, n_targets) */
     int min_diag_score;              /* 15 */

@@ -64,7 +64,7 @@ static int kmer_threshold(float sensitivity) {   /* Prefiltering.cpp:1051-1053, 
 static int cmd_pipeline(int argc, char **argv) {
     lines_t T = read_lines(argv[2]), Q = read_lines(argv[3]);
     const char *outdir = argv[4];
-    float sens = 5.7f; int dump = 0, lb = 32, lw = 16, tl = 4, maxSeqs = 300;
+    float sens = 5.7f; int dump = 0, lb = 32, lw = 16, tl = 4, maxSeqs = 300, kmerSize = 6;
     long l2 = sysconf(_SC_LEVEL2_CACHE_SIZE);
     if (l2 <= 0) l2 = 262144;   /* Util::getL2CacheSize, Util.cpp:317-332 */
     for (int a = 5; a < argc; a++) {
@@ -75,7 +75,9 @@ static int cmd_pipeline(int argc, char **argv) {
         else if (!strcmp(argv[a], "--tantan-lanes")) tl = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--l2")) l2 = atol(argv[++a]);
         else if (!strcmp(argv[a], "--max-seqs")) maxSeqs = atoi(argv[++a]);
+        else if (!strcmp(argv[a], "-k")) kmerSize = atoi(argv[++a]);
     }
+    if (kmerSize != 6 && kmerSize != 7) { fprintf(stderr, "-k 6 or 7\n"); return 2; }
     mkdir(outdir, 0755);
     uint8_t *tres, *qres; uint64_t *toff, *qoff;
     encode(&T, &tres, &toff);
@@ -84,11 +86,17 @@ static int cmd_pipeline(int argc, char **argv) {
     mko_submat_init(&kmerMat, MKO_MAT_VTML80, 8.0f, -0.2f);      /* Prefiltering.cpp:68 */
     mko_submat_init(&ungMat, MKO_MAT_BLOSUM62, 2.0f, -0.2f);     /* :69 */
     mko_submat_init(&alnMat, MKO_MAT_BLOSUM62, 2.0f, 0.0f);      /* Alignment.cpp:152 */
-    const int kmerThr = kmer_threshold(sens);
+    int kmerThr = kmer_threshold(sens);
+    if (kmerSize == 7) {                                        /* Prefiltering.cpp:1057-1059 */
+        float base = 186.15;
+        float best = base - (sens * 11.22);
+        kmerThr = (int) best;
+    }
     double t0 = now();
     mko_scoremat *three = mko_scoremat_build(&kmerMat, 3);
+    mko_scoremat *two = kmerSize == 7 ? mko_scoremat_build(&kmerMat, 2) : NULL;
     double tExt = now() - t0; t0 = now();
-    mko_index *ix = mko_index_build(&kmerMat, tres, toff, (uint32_t) T.n, kmerThr, 1, tl);
+    mko_index *ix = mko_index_build_k(&kmerMat, tres, toff, (uint32_t) T.n, kmerThr, 1, tl, kmerSize);
     double tIdx = now() - t0;
     char path[4096];
     if (dump) {
@@ -102,7 +110,7 @@ static int cmd_pipeline(int argc, char **argv) {
         fclose(f);
         snprintf(path, sizeof(path), "%s/index.txt", outdir);
         f = fopen(path, "w");
-        for (uint64_t k = 0; k < ix->table_size; k++) {
+        for (uint64_t k = 0; k < ix->table_size && !ix->kmers; k++) {
             if (ix->offsets[k + 1] == ix->offsets[k]) continue;
             fprintf(f, "%llu", (unsigned long long) k);
             for (uint64_t e = ix->offsets[k]; e < ix->offsets[k + 1]; e++) fprintf(f, " %u:%u", ix->seq_id[e], (unsigned) ix->pos[e]);
@@ -111,7 +119,7 @@ static int cmd_pipeline(int argc, char **argv) {
         fclose(f);
     }
     mko_prefilter_ctx pc;
-    pc.kmer_mat = &kmerMat; pc.ungapped_mat = &ungMat; pc.three = three; pc.index = ix; pc.kmer_thr = kmerThr;
+    pc.kmer_mat = &kmerMat; pc.ungapped_mat = &ungMat; pc.three = three; pc.two = two; pc.index = ix; pc.kmer_thr = kmerThr;
     pc.max_hits = maxSeqs; pc.min_diag_score = 15; pc.bin_count = mko_bin_count_for(T.n, (uint64_t) l2); pc.bias_scale = 1.0f;
     mko_evaluer ev;
     mko_evaluer_init(&ev, toff[T.n]);
@@ -402,7 +410,7 @@ static int cmd_profilesearch(int argc, char **argv) {
     const int kmerThr = (int) kmerThrBest;
     mko_index *ix = mko_index_build(&kmerMat, tres, toff, (uint32_t) T.n, 0 /* Prefiltering.cpp:525-527 */, 1, tl);
     mko_prefilter_ctx pc;
-    pc.kmer_mat = &kmerMat; pc.ungapped_mat = &ungMat; pc.three = NULL; pc.index = ix; pc.kmer_thr = kmerThr;
+    pc.kmer_mat = &kmerMat; pc.ungapped_mat = &ungMat; pc.three = NULL; pc.two = NULL; pc.index = ix; pc.kmer_thr = kmerThr;
     pc.max_hits = (int) (T.n > 300 ? T.n : 300);                              /* Search.cpp:372 */
     pc.min_diag_score = 15; pc.bin_count = mko_bin_count_for(T.n, (uint64_t) l2); pc.bias_scale = 1.0f;
     {   /* Search.cpp:366-368 and the text round trip of the parameter string */

@@ -131,9 +131,96 @@ static const int SPACED6[6] = {0, 1, 3, 5, 8, 9};   /* spaced_seed_6 = 110101001
  * k-mers with an X or with self-score < kmer_thr are skipped. */
 mko_index *mko_index_build(const mko_submat *km, const uint8_t *residues, const uint64_t *seq_off,
                            uint32_t n_seq, int kmer_thr, int mask, int simd_lanes) {
+    return mko_index_build_k(km, residues, seq_off, n_seq, kmer_thr, mask, simd_lanes, 6);
+}
+
+void mko_index_list(const mko_index *ix, uint64_t kmer, uint64_t *o0, uint64_t *o1) {
+    if (!ix->kmers) { *o0 = ix->offsets[kmer]; *o1 = ix->offsets[kmer + 1]; return; }
+    uint64_t lo = 0, hi = ix->n_kmers;
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (ix->kmers[mid] < kmer) lo = mid + 1; else hi = mid; }
+    if (lo < ix->n_kmers && ix->kmers[lo] == kmer) { *o0 = ix->offsets[lo]; *o1 = ix->offsets[lo + 1]; }
+    else { *o0 = 0; *o1 = 0; }
+}
+
+typedef struct { uint64_t kmer; uint32_t seq; uint16_t pos; } ksp_t;
+static int ksp_cmp(const void *a, const void *b) {
+    const ksp_t *x = (const ksp_t *) a, *y = (const ksp_t *) b;
+    if (x->kmer != y->kmer) return x->kmer < y->kmer ? -1 : 1;
+    if (x->seq != y->seq) return x->seq < y->seq ? -1 : 1;
+    return 0;
+}
+
+/* k = 7: the same table (20^7 cells) kept sparse -- the distinct k-mers in ascending order with their lists; same entries in the same
+ * order as the dense build (per sequence the smallest position of a k-mer, lists by sequence). */
+static void build_sparse(mko_index *ix, const mko_submat *km, int kmer_thr) {
+    const int *sp; const int span = mko_spaced_pattern(ix->k, &sp);
+    char idScore[MKO_ALPH];
+    for (int a = 0; a < MKO_ALPH; a++) idScore[a] = (char) km->sub[a][a];
+    size_t cap = 1 << 20, n = 0;
+    ksp_t *all = (ksp_t *) malloc(cap * sizeof(ksp_t));
+    for (uint32_t s = 0; s < ix->n_seq; s++) {
+        const uint8_t *seq = ix->masked + ix->seq_off[s];
+        const int L = (int) (ix->seq_off[s + 1] - ix->seq_off[s]);
+        const size_t first = n;
+        for (int i = 0; i + span <= L; i++) {
+            int hasX = 0, score = 0;
+            uint64_t idx = 0, pw = 1;
+            for (int p = 0; p < ix->k; p++) { uint8_t c = seq[i + sp[p]]; hasX |= (c == MKO_X); score += idScore[c]; idx += c * pw; pw *= 20; }
+            if (hasX || (kmer_thr > 0 && score < kmer_thr)) continue;
+            if (n == cap) { cap *= 2; all = (ksp_t *) realloc(all, cap * sizeof(ksp_t)); }
+            all[n].kmer = idx; all[n].seq = s; all[n].pos = (uint16_t) i; n++;
+        }
+        /* per (k-mer, sequence) only the smallest position: positions ascend, so keep the first of equal k-mers after a stable grouping */
+        if (n - first > 1) {
+            qsort(all + first, n - first, sizeof(ksp_t), ksp_cmp);   /* ties (same k-mer, same seq): any order, the minimum is taken below */
+            size_t w = first;
+            for (size_t r = first; r < n; ) {
+                size_t e = r; uint16_t mn = all[r].pos;
+                while (e < n && all[e].kmer == all[r].kmer) { if (all[e].pos < mn) mn = all[e].pos; e++; }
+                all[w] = all[r]; all[w].pos = mn; w++;
+                r = e;
+            }
+            n = w;
+        }
+    }
+    if (n > 1) qsort(all, n, sizeof(ksp_t), ksp_cmp);
+    ix->n_entries = n;
+    ix->seq_id = (uint32_t *) malloc((n + 1) * sizeof(uint32_t));
+    ix->pos = (uint16_t *) malloc((n + 1) * sizeof(uint16_t));
+    ix->kmers = (uint64_t *) malloc((n + 1) * sizeof(uint64_t));
+    ix->offsets = (uint64_t *) malloc((n + 2) * sizeof(uint64_t));
+    uint64_t nk = 0;
+    for (size_t j = 0; j < n; j++) {
+        if (j == 0 || all[j].kmer != all[j - 1].kmer) { ix->kmers[nk] = all[j].kmer; ix->offsets[nk] = j; nk++; }
+        ix->seq_id[j] = all[j].seq; ix->pos[j] = all[j].pos;
+    }
+    ix->offsets[nk] = n;
+    ix->n_kmers = nk;
+    free(all);
+}
+
+mko_index *mko_index_build_k(const mko_submat *km, const uint8_t *residues, const uint64_t *seq_off,
+                             uint32_t n_seq, int kmer_thr, int mask, int simd_lanes, int k) {
     mko_index *ix = (mko_index *) calloc(1, sizeof(*ix));
-    ix->k = 6;
-    ix->table_size = 64000000ull;
+    ix->k = k;
+    ix->table_size = k == 7 ? 1280000000ull : 64000000ull;
+    if (k == 7) {
+        ix->n_seq = n_seq;
+        const uint64_t total7 = seq_off[n_seq];
+        ix->masked = (uint8_t *) malloc(total7 + 1);
+        ix->seq_off = (uint64_t *) malloc((n_seq + 1) * sizeof(uint64_t));
+        memcpy(ix->masked, residues, total7);
+        memcpy(ix->seq_off, seq_off, (n_seq + 1) * sizeof(uint64_t));
+        uint64_t maskedRes7 = 0;
+        if (mask) {
+#pragma omp parallel for schedule(dynamic, 100) reduction(+: maskedRes7)
+            for (uint32_t s = 0; s < n_seq; s++)
+                maskedRes7 += (uint64_t) mko_tantan_mask(km, ix->masked + seq_off[s], (int) (seq_off[s + 1] - seq_off[s]), (double) 0.9f, simd_lanes);
+        }
+        ix->masked_residues = maskedRes7;
+        build_sparse(ix, km, kmer_thr);
+        return ix;
+    }
     ix->n_seq = n_seq;
     const uint64_t total = seq_off[n_seq];
     ix->masked = (uint8_t *) malloc(total + 1);
@@ -209,6 +296,6 @@ mko_index *mko_index_build(const mko_submat *km, const uint8_t *residues, const 
 
 void mko_index_free(mko_index *ix) {
     if (!ix) return;
-    free(ix->offsets); free(ix->seq_id); free(ix->pos); free(ix->masked); free(ix->seq_off);
+    free(ix->offsets); free(ix->kmers); free(ix->seq_id); free(ix->pos); free(ix->masked); free(ix->seq_off);
     free(ix);
 }

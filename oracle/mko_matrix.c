@@ -186,3 +186,53 @@ size_t mko_kmer_list6(const mko_scoremat *three, const uint8_t *kmer, short thre
     }
     return counter;
 }
+
+/* k = 7: KmerGenerator::setDivideStrategy (KmerGenerator.cpp:41-86) gives the steps {3,2,2} and reverses them: a 2-mer, a 2-mer and a
+ * 3-mer row (positions 0-1, 2-3, 4-6 of the window; multipliers 20^0, 20^2, 20^4).  generateKmerList (:107-187) multiplies the first two
+ * rows (the first one cut at threshold - best of the others), then the partial list -- walked whole, cutoff1 = -1000 -- with the third. */
+size_t mko_kmer_list7(const mko_scoremat *two, const mko_scoremat *three, const uint8_t *kmer, short threshold, uint64_t *out, size_t cap) {
+    const size_t MAX_KMER_RESULT_SIZE = 262144 * 32;
+    const uint32_t index0 = kmer[0] + 20u * kmer[1], index1 = kmer[2] + 20u * kmer[3], index2 = kmer[4] + 20u * kmer[5] + 400u * kmer[6];
+    const short *s0 = two->score + (size_t) index0 * two->row_size, *s1 = two->score + (size_t) index1 * two->row_size;
+    const short *s2 = three->score + (size_t) index2 * three->row_size;
+    const uint32_t *i0 = two->index + (size_t) index0 * two->row_size, *i1 = two->index + (size_t) index1 * two->row_size;
+    const uint32_t *i2 = three->index + (size_t) index2 * three->row_size;
+    const short rest1 = s2[0], rest0 = (short) (s1[0] + rest1);
+    short cutoff1 = (short) (threshold - rest0);
+    size_t capA = 4096, nA = 0;
+    short *scA = (short *) malloc(capA * sizeof(short));
+    uint64_t *kmA = (uint64_t *) malloc(capA * sizeof(uint64_t));
+    for (int a = 0; a < two->element_size; a++) {
+        const short score_i = s0[a];
+        if (score_i < cutoff1) break;
+        const short cutoff2 = (short) (threshold - score_i - rest1);
+        for (int b = 0; b < two->element_size && (nA + 1 < MAX_KMER_RESULT_SIZE) && s1[b] >= cutoff2; b++) {
+            if (nA == capA) { capA *= 2; scA = (short *) realloc(scA, capA * sizeof(short)); kmA = (uint64_t *) realloc(kmA, capA * sizeof(uint64_t)); }
+            scA[nA] = (short) (score_i + s1[b]);
+            kmA[nA] = (uint64_t) i0[a] + (uint64_t) i1[b] * 400u;
+            nA++;
+        }
+        if (nA + 1 >= MAX_KMER_RESULT_SIZE) break;
+    }
+    cutoff1 = -1000;
+    size_t counter = 0;
+    for (size_t e = 0; e < nA; e++) {
+        const short score_i = scA[e];
+        if (score_i < cutoff1) break;
+        const short cutoff2 = (short) (threshold - score_i - 0);
+        for (int c = 0; c < three->element_size && (counter + 1 < MAX_KMER_RESULT_SIZE) && s2[c] >= cutoff2; c++) {
+            if (counter < cap) out[counter] = kmA[e] + (uint64_t) i2[c] * 160000u;
+            counter++;
+        }
+        if (counter + 1 >= MAX_KMER_RESULT_SIZE) break;
+    }
+    free(scA); free(kmA);
+    return counter;
+}
+
+int mko_spaced_pattern(int k, const int **offsets) {
+    static const int P6[6] = {0, 1, 3, 5, 8, 9};          /* spaced_seed_6 = 1101010011 */
+    static const int P7[7] = {0, 1, 3, 5, 6, 9, 10};      /* spaced_seed_7 = 11010110011 */
+    *offsets = k == 7 ? P7 : P6;
+    return k == 7 ? 11 : 10;
+}

@@ -106,23 +106,27 @@ typedef struct { const mko_prefilter_ctx *ctx; const uint8_t *q; const float *bi
 
 static size_t seq_kmer_gen(void *user, int i, uint64_t **klist, size_t *kcap, uint64_t *listLen) {
     const seq_gen_t *g = (const seq_gen_t *) user;
-    uint8_t kmer[6];
+    const int k = g->ctx->index->k;
+    const int *sp; mko_spaced_pattern(k, &sp);
+    uint8_t kmer[8];
     int hasX = 0;
     float biasCorrection = 0;
-    for (int p = 0; p < 6; p++) {
-        kmer[p] = g->q[i + SPACED6[p]];
+    for (int p = 0; p < k; p++) {
+        kmer[p] = g->q[i + sp[p]];
         hasX |= (kmer[p] == MKO_X);
-        biasCorrection += g->bias[i + SPACED6[p]];
+        biasCorrection += g->bias[i + sp[p]];
     }
     if (hasX) return (size_t) -1;
     short b = (short) ((biasCorrection < 0.0) ? (double) biasCorrection - 0.5 : (double) biasCorrection + 0.5);
     int kms = g->ctx->kmer_thr - b;
     short kmerMatchScore = (short) (kms > 0 ? kms : 0);
-    size_t nk = mko_kmer_list6(g->ctx->three, kmer, kmerMatchScore, *klist, *kcap);
+    size_t nk = k == 7 ? mko_kmer_list7(g->ctx->two, g->ctx->three, kmer, kmerMatchScore, *klist, *kcap)
+                       : mko_kmer_list6(g->ctx->three, kmer, kmerMatchScore, *klist, *kcap);
     if (nk > *kcap) {
         *kcap = nk;
         *klist = (uint64_t *) realloc(*klist, *kcap * sizeof(uint64_t));
-        nk = mko_kmer_list6(g->ctx->three, kmer, kmerMatchScore, *klist, *kcap);
+        nk = k == 7 ? mko_kmer_list7(g->ctx->two, g->ctx->three, kmer, kmerMatchScore, *klist, *kcap)
+                    : mko_kmer_list6(g->ctx->three, kmer, kmerMatchScore, *klist, *kcap);
     }
     *listLen += nk;
     return nk;
@@ -187,11 +191,13 @@ static int prefilter_core(const mko_prefilter_ctx *ctx, const uint8_t *q, int L,
     uint64_t *klist = (uint64_t *) malloc(kcap * sizeof(uint64_t));
     uint64_t kmerListLen = 0;
     int rc = 0;
-    for (int i = 0; i + 10 <= L; i++) {
+    const int *spUnused; const int span = mko_spaced_pattern(ix->k, &spUnused);
+    for (int i = 0; i + span <= L; i++) {
         const size_t nk = gen(user, i, &klist, &kcap, &kmerListLen);
         if (nk == (size_t) -1) continue;
         for (size_t k = 0; k < nk; k++) {
-            const uint64_t o0 = ix->offsets[klist[k]], o1 = ix->offsets[klist[k] + 1];
+            uint64_t o0, o1;
+            mko_index_list(ix, klist[k], &o0, &o1);
             const size_t sz = (size_t) (o1 - o0);
             if (n + sz >= maxDbMatches) { rc = -1; goto done; }   /* overflow path (:281-316) not restated */
             if (n + sz > cap) { while (n + sz > cap) cap *= 2; hits = (cres_t *) realloc(hits, cap * sizeof(cres_t)); }

@@ -97,6 +97,22 @@ def test_oracle_matches_the_real_process(tmp_path):
     assert open(tmp_path / "out" / "aln.txt").read() == _text("e2e_process_aln.txt.gz")
 
 
+def test_oracle_k7_matches_the_real_process(tmp_path):
+    """k = 7 (the k-mer size of databases from 3.35e9 residues on, IndexTable.h:439-449; forced with -k 7): the 2-mer x 2-mer x 3-mer
+    list generator, the spaced seed 11010110011, the threshold 186.15 - 11.22 s and a 20^7-cell index against the real binary's
+    `prefilter -k 7` on the e2e fixture (first 5 000 fragments here; the GPU suite compares all of them)"""
+    oracle.build()
+    (tmp_path / "t.txt").write_text(_text("e2e_targets.txt.gz"))
+    frags = [l.rsplit("\t", 1)[1] for l in _text("e2e_process_orfs.txt.gz").splitlines()][:5000]
+    (tmp_path / "q.txt").write_text("\n".join(frags) + "\n")
+    out = subprocess.check_output([oracle.CLI, "pipeline", str(tmp_path / "t.txt"), str(tmp_path / "q.txt"), str(tmp_path / "out"), "-s", "5.7", "-k", "7",
+                                   "--l2", "2097152"])
+    assert json.loads(out)["kmer_thr"] == 122
+    expected = _text("e2e_process_pref_k7.txt.gz")
+    expected = expected[:expected.index(">5000\n")]
+    assert open(tmp_path / "out" / "pref.txt").read() == expected
+
+
 def _profile_inputs(tmp_path):
     """the fixtures of the profile-target path as files: the profile DB, the fragments in the order of their data offsets in the
     fragment DB (= the prefilter's target numbering) and their DB keys"""
