@@ -80,6 +80,10 @@ typedef struct {
                                  searchslicedtargetprofile.sh.  Changes what the reference changes: k-mer threshold 134.35 - 6.15 s
                                  (Prefiltering.cpp:1038-1040), no self-score filter in the target index (:525-527), the background of
                                  the target masking from --sub-mat x8 instead of the seed matrix (:72-76) */
+    int kmer_size;            /* -k: 0 = automatic = 6 below 3.35e9 target residues, else 7 (IndexTable::computeKmerSize, IndexTable.h:439-449);
+                                 6 or 7 force it.  k = 7: spaced seed 11010110011 (Sequence.h:25), threshold 186.15 - 11.22 s
+                                 (Prefiltering.cpp:1057-1059), 2-mer x 2-mer x 3-mer k-mer lists (KmerGenerator.cpp:41-86), a 20^7-cell
+                                 table (10 GB of HBM).  The target side decides; a query batch follows the database it is searched against */
 } mk_params;
 
 /* ---- process-wide ---- */

@@ -19,7 +19,7 @@ class Params(C.Structure):
                 ("mask", C.c_int), ("mask_prob", C.c_float), ("gap_open", C.c_int), ("gap_extend", C.c_int),
                 ("evalue_thr", C.c_double), ("min_aln_len", C.c_int), ("simd_lanes_byte", C.c_int),
                 ("simd_lanes_word", C.c_int), ("simd_lanes_double", C.c_int), ("host_l2_bytes", C.c_uint64),
-                ("profile_search", C.c_int)]
+                ("profile_search", C.c_int), ("kmer_size", C.c_int)]
 
 
 class Hit(C.Structure):

@@ -170,6 +170,9 @@ struct mk_targetdb {
     DevBuf<int8_t> dMatAln, dMatUng;
     DevBuf<uint32_t> dKeys;          // device copy of `keys` (last tie-break of the alignment order)
     DevBuf<uint16_t> dAddr3;         // 3-mer number -> address code of the table cells (profile k-mer lists)
+    int kmerSize = 6;                // 6 or 7 (mk_params.kmer_size / IndexTable::computeKmerSize)
+    DevBuf<int16_t> dScore2;         // k = 7: similar 2-mers [400][400]
+    DevBuf<uint16_t> dIndex2, dNum3; // ... their numbers; address code -> 3-mer number
     bool profileSearch = false;      // built for profile queries (mk_params.profile_search)
     std::vector<int32_t> bitScoreTable;   // static_cast<int>(bitScore(score) + 0.5), score < 32768
 };
@@ -186,6 +189,8 @@ struct mk_queries {
     // profile queries (mk_profiles_create): res / dRes hold the profiles' query letters, off the column offsets
     bool isProfile = false;
     DevBuf<int8_t> dProfSorted, dProfAln;   // [column][40], [column][32] (mk_profile.hpp)
+    int kmerSize = 6;                // the k the k-mer thresholds were derived for (re-derived when the database uses the other one)
+    mk_params derivedWith;           // the parameters of that derivation
     // stage results (the reference hands these over through the pref_0 / search_res DBs)
     mk::HostBlock hits; size_t nHits = 0; std::vector<uint64_t> hitOff; bool havePref = false;
     mk::HostBlock alns; std::vector<uint64_t> alnOff; bool haveAln = false;
@@ -333,6 +338,7 @@ void mk_default_params(mk_params *p) {
     p->simd_lanes_byte = 32; p->simd_lanes_word = 16; p->simd_lanes_double = 4;
     p->host_l2_bytes = 1048576;
     p->profile_search = 0;
+    p->kmer_size = 0;
 }
 
 void mk_encode(const char *ascii, size_t len, uint8_t *codes) { mk::encode(ascii, len, codes); }
@@ -343,8 +349,12 @@ static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uin
     if (rc) return rc;
     if (!residues || !offsets || !P || !out) return fail(MK_ERR_ARG, "null argument");
     // IndexTable::computeKmerSize (IndexTable.h:439-449): from 3.35e9 target residues on the reference searches with k = 7
-    if (offsets[n] >= 3350000000ull) return fail(MK_ERR_UNSUPPORTED, "the target database has %llu residues: the reference switches to k = 7 at 3.35e9, only k = 6 is implemented", (unsigned long long) offsets[n]);
+    if (P->kmer_size != 0 && P->kmer_size != 6 && P->kmer_size != 7) return fail(MK_ERR_UNSUPPORTED, "-k %d: k-mer sizes 6 and 7 are implemented", P->kmer_size);
+    const int kmerSize = P->kmer_size ? P->kmer_size : (offsets[n] < 3350000000ull ? 6 : 7);
+    if (kmerSize == 7 && P->profile_search) return fail(MK_ERR_UNSUPPORTED, "profile queries with k = 7 (a fragment set of 3.35e9 residues or more, or -k 7) are not implemented");
+    if (kmerSize == 7 && prebuilt) return fail(MK_ERR_UNSUPPORTED, "index DBs with k = 7 are not implemented");
     mk_targetdb *db = new mk_targetdb();
+    db->kmerSize = kmerSize;
     db->n = n;
     db->off.assign(offsets, offsets + n + 1);
     for (uint32_t i = 0; i < n; i++) {
@@ -359,12 +369,12 @@ static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uin
     mk::build_submat(db->ungMat, mk::MAT_BLOSUM62, 2.0f, -0.2f);    // Prefiltering.cpp:69
     mk::build_submat(db->alnMat, mk::MAT_BLOSUM62, 2.0f, 0.0f);     // Alignment.cpp:152
     // ... and the index keeps every k-mer (localKmerThr = 0, Prefiltering.cpp:525-527)
-    db->kmerThr = db->profileSearch ? 0 : mk::kmer_threshold(P->sensitivity, P->kmer_score);
+    db->kmerThr = db->profileSearch ? 0 : (kmerSize == 7 ? mk::kmer_threshold_k7(P->sensitivity, P->kmer_score) : mk::kmer_threshold(P->sensitivity, P->kmer_score));
     db->evaluer.init(offsets[n]);
     db->bitScoreTable.resize(32768);
     for (int sc = 0; sc < 32768; sc++) db->bitScoreTable[sc] = static_cast<int>(db->evaluer.bitScore((double) sc) + 0.5);
     mk::TargetIndex built;
-    if (!prebuilt) mk::build_index(db->kmerMat, residues, offsets, n, db->kmerThr, P->mask != 0, P->mask_prob, P->simd_lanes_double, built);
+    if (!prebuilt) mk::build_index(db->kmerMat, residues, offsets, n, db->kmerThr, P->mask != 0, P->mask_prob, P->simd_lanes_double, built, true, kmerSize);
     mk::TargetIndex &ix = prebuilt ? *prebuilt : built;
     if (ix.entries.size() >= 0xFFFFFFFFull) { delete db; return fail(MK_ERR_UNSUPPORTED, "index has >= 2^32 entries"); }
     db->nEntries = ix.entries.size();
@@ -406,6 +416,16 @@ static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uin
     uint16_t addr3[8000];
     mk::kmer3_address_table(addr3);
     ok(db->dAddr3.upload(addr3, 8000));
+    std::vector<int16_t> score2;
+    std::vector<uint16_t> index2;
+    uint16_t num3[8000];
+    if (kmerSize == 7) {
+        mk::build_scoremat2(db->kmerMat, score2, index2);
+        mk::kmer3_number_of_address(num3);
+        ok(db->dScore2.upload(score2.data(), score2.size()));
+        ok(db->dIndex2.upload(index2.data(), index2.size()));
+        ok(db->dNum3.upload(num3, 8000));
+    }
     ok(hipStreamSynchronize(g_stream));
     if (e != hipSuccess) { delete db; return fail(MK_ERR_DEVICE, "target upload failed: %s", hipGetErrorString(e)); }
     *out = db;
@@ -569,8 +589,11 @@ static int queries_create(const uint8_t *residues, const uint8_t *devResidues, c
     ok(q->dBias8.alloc(total));
     if (e == hipSuccess) {
         const int th = timed_begin("query_derive", (double) total * 9.0, 0);
-        ok(mk::launch_derive(q->dRes.p, q->dOff.p, n, total, kmerMat, alnMat, mk::kmer_threshold(P->sensitivity, P->kmer_score),
-                             P->comp_bias_corr != 0, P->comp_bias_scale, q->dKmerThr.p, q->dCorr.p, q->dBias8.p, g_stream));
+        q->kmerSize = P->kmer_size == 7 ? 7 : 6;
+        q->derivedWith = *P;
+        ok(mk::launch_derive(q->dRes.p, q->dOff.p, n, total, kmerMat, alnMat,
+                             q->kmerSize == 7 ? mk::kmer_threshold_k7(P->sensitivity, P->kmer_score) : mk::kmer_threshold(P->sensitivity, P->kmer_score),
+                             P->comp_bias_corr != 0, P->comp_bias_scale, q->dKmerThr.p, q->dCorr.p, q->dBias8.p, g_stream, q->kmerSize));
         timed_end(th);
     }
     ok(hipStreamSynchronize(g_stream));
@@ -927,7 +950,26 @@ static mk::PrefilterDeviceView prefilter_view(const mk_targetdb *db, const mk_qu
     V.hist3 = db->dHist3.p; V.cum3 = db->dCum3.p; V.hist_lo = db->histLo; V.hist_range = db->histRange; V.n_entries = db->nEntries;
     V.mat_ung = db->dMatUng.p;
     if (q->isProfile) { V.p_sorted = q->dProfSorted.p; V.p_aln = q->dProfAln.p; V.addr3 = db->dAddr3.p; }
+    V.kmer_size = db->kmerSize;
+    if (db->kmerSize == 7) { V.score2 = db->dScore2.p; V.index2 = db->dIndex2.p; V.num3 = db->dNum3.p; }
     return V;
+}
+
+// the k-mer thresholds of a sequence batch belong to one k-mer size (seed pattern, threshold formula): a batch that meets a database of
+// the other size (k chosen from the database's residue count, IndexTable.h:439-449) has them derived again
+static int match_kmer_size(const mk_targetdb *db, mk_queries *q) {
+    if (q->isProfile || q->kmerSize == db->kmerSize) return MK_OK;
+    const mk_params &P = q->derivedWith;
+    mk::SubMat kmerMat, alnMat;
+    mk::build_submat(kmerMat, mk::MAT_VTML80, 8.0f, -0.2f);
+    mk::build_submat(alnMat, mk::MAT_BLOSUM62, 2.0f, 0.0f);
+    const uint64_t total = q->off[q->n];
+    HIPCHK(mk::launch_derive(q->dRes.p, q->dOff.p, q->n, total, kmerMat, alnMat,
+                             db->kmerSize == 7 ? mk::kmer_threshold_k7(P.sensitivity, P.kmer_score) : mk::kmer_threshold(P.sensitivity, P.kmer_score),
+                             P.comp_bias_corr != 0, P.comp_bias_scale, q->dKmerThr.p, q->dCorr.p, q->dBias8.p, g_stream, db->kmerSize));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    q->kmerSize = db->kmerSize;
+    return MK_OK;
 }
 
 // a profile batch searches a target side built for it (and only that one)
@@ -943,6 +985,7 @@ int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     if (rc) return rc;
     if (!db || !q || !P) return fail(MK_ERR_ARG, "null argument");
     if ((rc = check_roles(db, q)) != MK_OK) return rc;
+    if ((rc = match_kmer_size(db, q)) != MK_OK) return rc;
     std::string err;
     const int binCount = mk::bin_count_for(db->n, P->host_l2_bytes);
     {
@@ -1109,6 +1152,7 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     if (rc) return rc;
     if (!db || !q || !P) return fail(MK_ERR_ARG, "null argument");
     if ((rc = check_roles(db, q)) != MK_OK) return rc;
+    if ((rc = match_kmer_size(db, q)) != MK_OK) return rc;
     if (q->isProfile) {          // profile queries: the two stages back to back (their kernels are not tuned to share the GPU)
         if ((rc = mk_prefilter(db, q, P)) != MK_OK) return rc;
         return mk_align(db, q, P);

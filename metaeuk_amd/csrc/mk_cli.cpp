@@ -126,8 +126,8 @@ int parse(int argc, char **argv, Args &a) {
             if (atol(v.c_str()) < 65535) { fprintf(stderr, "--max-seq-len %s: shorter limits than the default 65535 (sequence splitting) are not implemented\n", v.c_str()); return EXIT_FAILURE; }
             continue;
         }
-        if (std::string(k.name) == "-k") {                    // 0 = automatic = 6 below 3.35e9 target residues (IndexTable.h:439-449)
-            if (v != "0" && v != "6") { fprintf(stderr, "-k %s: only k = 6 (or 0 = auto) is implemented\n", v.c_str()); return EXIT_FAILURE; }
+        if (std::string(k.name) == "-k") {                    // 0 = automatic: 6 below 3.35e9 target residues, else 7 (IndexTable.h:439-449)
+            if (v != "0" && v != "6" && v != "7") { fprintf(stderr, "-k %s: k-mer sizes 6 and 7 (or 0 = auto) are implemented\n", v.c_str()); return EXIT_FAILURE; }
             continue;
         }
         if (!sameValue(v, d.c_str())) {
@@ -150,6 +150,7 @@ int fillParams(const Args &a, mk_params &P, int &gpu) {
         if (p != std::string::npos) s = s.substr(p + 4);
         P.kmer_score = atoi(s.c_str());
     }
+    if (auto v = get("-k")) P.kmer_size = atoi(v->c_str());
     if (auto v = get("--max-seqs")) P.max_seqs = atoi(v->c_str());
     if (auto v = get("--min-ungapped-score")) P.min_ungapped_score = atoi(v->c_str());
     if (auto v = get("--comp-bias-corr")) P.comp_bias_corr = atoi(v->c_str());

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void derive_kernel(const uint8_t *res, const u
     sw8[p] = (int8_t) ((b2 < 0.0) ? (double) b2 - 0.5 : (double) b2 + 0.5);
 }
 
+template <int K>
 __global__ __launch_bounds__(256) void kthr_kernel(const uint8_t *res, const uint64_t *off, uint32_t nq, uint64_t total, const float *bias1,
                                                    int kmerThr, int16_t *kthr) {
     const uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -63,11 +64,12 @@ __global__ __launch_bounds__(256) void kthr_kernel(const uint8_t *res, const uin
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (off[mid] <= p) lo = mid; else hi = mid; }
     const uint64_t qe = off[lo + 1];
     int16_t out = -1;
-    if (p + 10 <= qe) {                             // Sequence::hasNextKmer: i + span <= L
-        const int sp[6] = {0, 1, 3, 5, 8, 9};
+    constexpr int SPANK = K == 7 ? 11 : 10;         // spaced seeds 1101010011 / 11010110011 (Sequence.h:23,25)
+    if (p + SPANK <= qe) {                          // Sequence::hasNextKmer: i + span <= L
+        const int sp[7] = {0, 1, 3, 5, K == 7 ? 6 : 8, 9, 10};
         float acc = 0;
         bool hasX = false;
-        for (int k = 0; k < 6; k++) { acc += bias1[p + sp[k]]; hasX |= (res[p + sp[k]] == 20); }
+        for (int k = 0; k < K; k++) { acc += bias1[p + sp[k]]; hasX |= (res[p + sp[k]] == 20); }
         if (!hasX) {
             const short r = (short) ((acc < 0.0) ? (double) acc - 0.5 : (double) acc + 0.5);
             out = (int16_t) max(kmerThr - (int) r, 0);
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void kthr_kernel(const uint8_t *res, const uin
 }  // namespace
 
 hipError_t launch_derive(const uint8_t *dRes, const uint64_t *dOff, uint32_t nq, uint64_t total, const SubMat &kmerMat, const SubMat &alnMat,
-                         int kmerThr, bool compBias, float scale, int16_t *dKthr, int8_t *dCorr, int8_t *dSw8, hipStream_t stream) {
+                         int kmerThr, bool compBias, float scale, int16_t *dKthr, int8_t *dCorr, int8_t *dSw8, hipStream_t stream, int kmerSize) {
     if (total == 0) return hipSuccess;
     DeriveMats hm;
     for (int i = 0; i < 21; i++) {
@@ -95,7 +97,8 @@ hipError_t launch_derive(const uint8_t *dRes, const uint64_t *dOff, uint32_t nq,
     if (e != hipSuccess) return e;
     const unsigned blocks = (unsigned) ((total + 255) / 256);
     hipLaunchKernelGGL(derive_kernel, dim3(blocks), dim3(256), 0, stream, dRes, dOff, nq, total, dM, compBias ? 1 : 0, scale, dBias, dCorr, dSw8);
-    hipLaunchKernelGGL(kthr_kernel, dim3(blocks), dim3(256), 0, stream, dRes, dOff, nq, total, dBias, kmerThr, dKthr);
+    if (kmerSize == 7) hipLaunchKernelGGL(kthr_kernel<7>, dim3(blocks), dim3(256), 0, stream, dRes, dOff, nq, total, dBias, kmerThr, dKthr);
+    else hipLaunchKernelGGL(kthr_kernel<6>, dim3(blocks), dim3(256), 0, stream, dRes, dOff, nq, total, dBias, kmerThr, dKthr);
     return hipGetLastError();
 }
 

@@ -14,6 +14,7 @@ namespace mk {
 #include "../data/matrices.inc"
 
 const int SPACED6[6] = {0, 1, 3, 5, 8, 9};   // positions of the ones in 1101010011 (M/src/commons/Sequence.h:23)
+const int SPACED7[7] = {0, 1, 3, 5, 6, 9, 10};
 
 // SubstitutionMatrix::SubstitutionMatrix -> readProbMatrix (M/src/commons/SubstitutionMatrix.cpp:12-57,
 // 326-404) and BaseMatrix::generateSubMatrix (M/src/commons/BaseMatrix.cpp:110-159).
@@ -86,6 +87,13 @@ int kmer_threshold(float sensitivity, int kmerScoreOverride) {
     if (kmerScoreOverride != INT_MAX) return kmerScoreOverride;
     float base = 163.2;
     float best = base - (sensitivity * 8.917);
+    return static_cast<int>(best);
+}
+
+int kmer_threshold_k7(float sensitivity, int kmerScoreOverride) {
+    if (kmerScoreOverride != INT_MAX) return kmerScoreOverride;
+    float base = 186.15;
+    float best = base - (sensitivity * 11.22);
     return static_cast<int>(best);
 }
 
@@ -295,9 +303,35 @@ void index_to_address_order(TargetIndex &ix) {
     ix.entries.swap(entries);
 }
 
+void kmer3_number_of_address(uint16_t numOf[8000]) {
+    uint16_t addr[8000];
+    kmer3_address_table(addr);
+    for (int k = 0; k < 8000; k++) numOf[addr[k]] = static_cast<uint16_t>(k);
+}
+
+void build_scoremat2(const SubMat &km, std::vector<int16_t> &score, std::vector<uint16_t> &index) {
+    const int N = 400;
+    score.assign(static_cast<size_t>(N) * N, 0);
+    index.assign(static_cast<size_t>(N) * N, 0);
+    for (int e = 0; e < N; e++) {                          // enumeration order: first letter slowest; row of the query 2-mer a0 + 20 a1
+        const int a0 = e / 20, a1 = e % 20;
+        std::vector<std::pair<int, int>> cand(N);          // (score, enumeration rank)
+        for (int f = 0; f < N; f++) cand[f] = {static_cast<short>(km.sub[a0][f / 20] + km.sub[a1][f % 20]), f};
+        std::stable_sort(cand.begin(), cand.end(), [](const std::pair<int, int> &x, const std::pair<int, int> &y) { return x.first > y.first; });
+        const size_t row = static_cast<size_t>(a0 + 20 * a1) * N;
+        for (int r = 0; r < N; r++) {
+            score[row + r] = static_cast<int16_t>(cand[r].first);
+            index[row + r] = static_cast<uint16_t>(cand[r].second / 20 + 20 * (cand[r].second % 20));
+        }
+    }
+}
+
 void build_index(const SubMat &km, const uint8_t *residues, const uint64_t *seqOff, uint32_t nSeq,
-                 int kmerThr, bool mask, float maskProb, int tantanLanes, TargetIndex &out, bool addressOrder) {
-    const uint64_t TABLE = 64000000ull;
+                 int kmerThr, bool mask, float maskProb, int tantanLanes, TargetIndex &out, bool addressOrder, int kmerSize) {
+    const uint64_t TABLE = kmerSize == 7 ? 1280000000ull : 64000000ull;
+    const int K = kmerSize == 7 ? 7 : 6, SPANK = kmerSize == 7 ? 11 : SPAN;
+    const int *SP = kmerSize == 7 ? SPACED7 : SPACED6;
+    if (kmerSize == 7) addressOrder = false;              // k = 7 cells are the reference's numbering (no tiling)
     const uint64_t total = seqOff[nSeq];
     out.masked.assign(residues, residues + total);
     uint64_t maskedCount = 0;
@@ -320,13 +354,13 @@ void build_index(const SubMat &km, const uint8_t *residues, const uint64_t *seqO
             const uint8_t *seq = out.masked.data() + seqOff[s];
             const int L = static_cast<int>(seqOff[s + 1] - seqOff[s]);
             buf.clear();
-            for (int i = 0; i + SPAN <= L; i++) {
+            for (int i = 0; i + SPANK <= L; i++) {
                 uint32_t idx = 0, pw = 1;
                 int score = 0;
                 bool hasX = false;
-                uint8_t let[KMER];
-                for (int p = 0; p < KMER; p++) {
-                    const uint8_t c = seq[i + SPACED6[p]];
+                uint8_t let[7];
+                for (int p = 0; p < K; p++) {
+                    const uint8_t c = seq[i + SP[p]];
                     hasX |= (c == XCODE);
                     score += self[c];
                     let[p] = c < 20 ? c : 0;

@@ -18,6 +18,7 @@ constexpr int XCODE = 20;
 constexpr int KMER = 6;
 constexpr int SPAN = 10;       // spaced seed 1101010011
 extern const int SPACED6[6];
+extern const int SPACED7[7];   // spaced seed 11010110011 (k = 7, Sequence.h:25), span 11
 
 struct SubMat {
     short sub[ALPH][ALPH];
@@ -32,6 +33,7 @@ void encode(const char *s, size_t n, uint8_t *codes);
 void comp_bias(const SubMat &m, const uint8_t *seq, int L, float scale, float *bias);
 int kmer_threshold(float sensitivity, int kmerScoreOverride);
 int kmer_threshold_profile(float sensitivity);
+int kmer_threshold_k7(float sensitivity, int kmerScoreOverride);     // sequence search, k = 7 (Prefiltering.cpp:1057-1059)
 int bin_count_for(uint64_t dbSize, uint64_t l2Bytes);
 
 // similar-3-mer table: row r (= 3-mer index) lists all 8000 3-mers by descending score
@@ -56,7 +58,11 @@ struct TargetIndex {
 // addressOrder: lists ordered by the k-mers' device table address (mk_host.cpp, KMER_ADDR_LETTER); false = the reference's
 // Indexer numbering (what an index file holds)
 void build_index(const SubMat &kmerMat, const uint8_t *residues, const uint64_t *seqOff, uint32_t nSeq,
-                 int kmerThr, bool mask, float maskProb, int tantanLanes, TargetIndex &out, bool addressOrder = true);
+                 int kmerThr, bool mask, float maskProb, int tantanLanes, TargetIndex &out, bool addressOrder = true, int kmerSize = 6);
+// k = 7 (databases from 3.35e9 residues on, IndexTable.h:439-449): the similar 2-mers of every 2-mer, like build_scoremat3 (rows of 400,
+// descending score, stable over the cartesian order with the first letter slowest); index = the 2-mer's number a0 + 20 a1
+void build_scoremat2(const SubMat &kmerMat, std::vector<int16_t> &score, std::vector<uint16_t> &index);
+void kmer3_number_of_address(uint16_t numOf[8000]);   // inverse of kmer3_address_table
 void index_to_address_order(TargetIndex &ix);
 void kmer3_address_table(uint16_t addrOf[8000]);   // reference 3-mer number -> address code (tile << 6 | in-quad positions), a permutation of 0..7999
 uint32_t kmer_cell(uint32_t addrFirst, uint32_t addrSecond);   // table cell of the k-mer made of two 3-mers (their address codes)

@@ -127,7 +127,7 @@ hipError_t launch_ungapped(const UngappedLaunch &L, hipStream_t stream);
 // per-residue query-side inputs (k-mer thresholds, int8 diagonal correction, int8 SW composition bias), mk_derive.hip
 struct SubMat;
 hipError_t launch_derive(const uint8_t *dRes, const uint64_t *dOff, uint32_t nq, uint64_t total, const SubMat &kmerMat, const SubMat &alnMat,
-                         int kmerThr, bool compBias, float scale, int16_t *dKthr, int8_t *dCorr, int8_t *dSw8, hipStream_t stream);
+                         int kmerThr, bool compBias, float scale, int16_t *dKthr, int8_t *dCorr, int8_t *dSw8, hipStream_t stream, int kmerSize = 6);
 
 // wall-clock accounting of host-side phases (shows up in mk_kernel_stats with launches == 0)
 void host_stat(const char *name, double ms);

@@ -42,6 +42,7 @@
 #include "mk_kernels.hpp"
 #include "mk_enum.hpp"
 #include "mk_profile.hpp"
+#include "mk_kmer7.hpp"
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <cstdlib>
@@ -990,15 +991,20 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
             dKmer = (uint32_t *) dev_scratch("pf_kmer", (nPos + 1) * 4);
             uint32_t *dLast = (uint32_t *) dev_scratch("pf_last", 16);
             PNULL(dHit); PNULL(dKmer); PNULL(dLast);
-            if (V.p_sorted) {
-                // profile queries: the similar k-mers of the piece as lists in HBM (count, scan, fill), walked by both probe passes
+            const bool listed = V.p_sorted || V.kmer_size == 7;
+            Kmer7Tables T7;
+            T7.score2 = V.score2; T7.index2 = V.index2; T7.score3 = V.score3; T7.index3 = V.index3; T7.num3 = V.num3; T7.cum3 = V.cum3;
+            T7.hist_lo = V.hist_lo; T7.hist_range = V.hist_range;
+            if (listed) {
+                // profile queries / k = 7: the similar k-mers of the piece as lists in HBM (count, scan, fill), walked by both probe passes
                 const size_t KLIST_CAP = (size_t) 1 << 30;                 // k-mers per piece (4 GB)
                 uint32_t *dCnt = (uint32_t *) dev_scratch("pf_klcount", (nPos + 1) * 4);
                 uint64_t *dKOff = (uint64_t *) dev_scratch("pf_kloff", (nPos + 2) * 8);
                 unsigned long long *hKTot = (unsigned long long *) pinned_scratch("pf_kltot_h", 16);
                 PNULL(dCnt); PNULL(dKOff); PNULL(hKTot);
-                int th = X.tb("profile_kmer_count", 46.0 * (double) nPos, 0);
-                PCHK(launch_profile_kmer_count(V.p_sorted, V.q_kmer_thr, hOff[q0], hOff[q1], dCnt, stream));
+                int th = X.tb(V.p_sorted ? "profile_kmer_count" : "kmer7_count", 46.0 * (double) nPos, 0);
+                if (V.p_sorted) PCHK(launch_profile_kmer_count(V.p_sorted, V.q_kmer_thr, hOff[q0], hOff[q1], dCnt, stream));
+                else PCHK(launch_kmer7_count(T7, V.q_res, V.q_kmer_thr, hOff[q0], hOff[q1], dCnt, stream));
                 X.te(th);
                 PCHK(hipMemsetAsync(dCnt + nPos, 0, 4, stream));           // one more element: the scan then ends with the total
                 hipcub::TransformInputIterator<unsigned long long, hipcub::CastOp<unsigned long long>, uint32_t *> cit(dCnt, hipcub::CastOp<unsigned long long>());
@@ -1012,12 +1018,13 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
                 const size_t nK = (size_t) hKTot[0];
                 if (nK > KLIST_CAP) {
                     if (q1 - q0 > 1) { q1 = q0 + (q1 - q0) / 2; continue; }
-                    err = "one profile has more than 2^30 similar k-mers"; return MK_ERR_UNSUPPORTED;
+                    err = "one query has more than 2^30 similar k-mers"; return MK_ERR_UNSUPPORTED;
                 }
                 uint32_t *dKList = (uint32_t *) dev_scratch("pf_klist", std::max<size_t>(nK, 1) * 4);
                 PNULL(dKList);
-                th = X.tb("profile_kmer_fill", 46.0 * (double) nPos + 4.0 * (double) nK, (double) nK);
-                PCHK(launch_profile_kmer_fill(V.p_sorted, V.q_kmer_thr, V.addr3, hOff[q0], hOff[q1], dKOff, dKList, stream));
+                th = X.tb(V.p_sorted ? "profile_kmer_fill" : "kmer7_fill", 46.0 * (double) nPos + 4.0 * (double) nK, (double) nK);
+                if (V.p_sorted) PCHK(launch_profile_kmer_fill(V.p_sorted, V.q_kmer_thr, V.addr3, hOff[q0], hOff[q1], dKOff, dKList, stream));
+                else PCHK(launch_kmer7_fill(T7, V.q_res, V.q_kmer_thr, hOff[q0], hOff[q1], dKOff, dKList, stream));
                 X.te(th);
                 V.klist = dKList; V.klist_off = dKOff; V.klist_pos0 = hOff[q0];
             }
@@ -1026,7 +1033,7 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
             A.hit_count = dHit; A.kmer_count = dKmer; A.keys = nullptr; A.diag_hi = nullptr;
             const unsigned blocks = (unsigned) ((nPos + 3) / 4);
             const int thCount = X.tb("kmer_probe_count", 0, 0);
-            if (V.p_sorted) hipLaunchKernelGGL((probe_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, A);
+            if (listed) hipLaunchKernelGGL((probe_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, A);
             else hipLaunchKernelGGL(probe_kernel<false>, dim3(blocks), dim3(256), 0, stream, A);
             X.te(thCount);
             PCHK(hipGetLastError());
@@ -1077,7 +1084,7 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
             const unsigned blocks = (unsigned) ((nPos + 3) / 4);
             // gather pass: slots again + 8 B per index entry read + 9 B (record, high diagonal byte) written per entry
             int th = X.tb("kmer_probe_gather", 4.0 * (double) X.hTotals[2] + 25.0 * (double) totalHits + 1280.0 * (double) nPos, (double) X.hTotals[2]);
-            if (V.p_sorted) hipLaunchKernelGGL((probe_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, A);
+            if (V.klist) hipLaunchKernelGGL((probe_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, A);
             else hipLaunchKernelGGL(probe_kernel<true>, dim3(blocks), dim3(256), 0, stream, A);
             X.te(th);
             PCHK(hipGetLastError());
@@ -1174,7 +1181,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     uint32_t seqBits = 1; while ((1ull << seqBits) < dbSize) seqBits++;
     // front end: the per-query kernels keep the target id in a 22-bit field of their hit records
     bool useFused = seqBits <= REC_T_BITS;
-    if (V.p_sorted) useFused = false;                  // profile queries: k-mer lists in HBM + the global path (the per-query kernels enumerate 3-mer rows)
+    if (V.p_sorted || V.kmer_size == 7) useFused = false;   // profile queries, k = 7: k-mer lists in HBM + the global path (the per-query kernels enumerate two 3-mer rows)
     else if (const char *e = getenv("MK_PREFILTER_PATH")) {
         if (!strcmp(e, "global")) useFused = false;
         else if (strcmp(e, "fused") && strcmp(e, "auto")) { err = "MK_PREFILTER_PATH must be auto, fused or global"; return MK_ERR_ARG; }

@@ -27,6 +27,10 @@ struct PrefilterDeviceView {
     const int8_t *p_sorted = nullptr;     // [column][40]: the 20 scores descending + their residue numbers
     const int8_t *p_aln = nullptr;        // [column][32]: the alignment profile (score / 4), what the diagonal scoring reads
     const uint16_t *addr3 = nullptr;      // 3-mer number -> address code of the index table (kmer3_address_table)
+    // k = 7 (sequence queries against a database of 3.35e9 residues or more, or -k 7): 2-mer rows and the code -> 3-mer number map; the
+    // k-mer table then has 20^7 cells in the reference's numbering and the similar k-mers come as lists too (mk_kmer7.hpp)
+    int kmer_size = 6;
+    const int16_t *score2 = nullptr; const uint16_t *index2 = nullptr; const uint16_t *num3 = nullptr;
     // the similar k-mers of the k-mer starts [klist_pos0, ...) as lists in HBM (filled per piece by the global path for profile queries)
     const uint32_t *klist = nullptr; const uint64_t *klist_off = nullptr; uint64_t klist_pos0 = 0;
 };

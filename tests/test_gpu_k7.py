@@ -1,0 +1,54 @@
+"""GPU parity test of k = 7 -- the k-mer size the reference switches to for target databases of 3.35e9 residues or more
+(IndexTable.h:439-449), forced with -k 7 on the e2e fixture: 2-mer x 2-mer x 3-mer k-mer lists in the reference's order, the spaced
+seed 11010110011, the threshold 186.15 - 11.22 s and a 20^7-cell table, against the REAL binary's `prefilter -k 7`
+(tests/golden/e2e_process_pref_k7.txt.gz, make_process_golden.sh) and, for the alignments, against the oracle."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _text(name):
+    with gzip.open(os.path.join(GOLD, name), "rt") as f:
+        return f.read()
+
+
+def test_k7_prefilter_matches_the_real_process(gpu_api, tmp_path):
+    api = gpu_api
+    targets = _text("e2e_targets.txt.gz").splitlines()
+    frags = [l.rsplit("\t", 1)[1] for l in _text("e2e_process_orfs.txt.gz").splitlines()]
+    params = api.default_params()
+    params.sensitivity = 5.7
+    params.kmer_size = 7
+    params.host_l2_bytes = 2097152
+    db = api.TargetDB(targets, params)
+    q = api.Queries(frags, api.default_params())          # derived for k = 6: the batch follows the database it meets
+    (hits, hoff), (alns, aoff) = api.search(db, q, params)
+    pref = "".join(">%d\n%s" % (i, api.format_hits_bulk(hits, int(hoff[i]), int(hoff[i + 1])).decode()) for i in range(q.n))
+    assert pref == _text("e2e_process_pref_k7.txt.gz")
+    st = api.kernel_stats()
+    assert "kmer7_fill" in st and st["kmer7_fill"]["cells"] > 1e9     # ~2 119 similar k-mers per start
+    # the alignments of those hits: the oracle on a prefix (its k = 7 run takes seconds per thousand fragments)
+    n = 3000
+    (tmp_path / "t.txt").write_text("\n".join(targets) + "\n")
+    (tmp_path / "q.txt").write_text("\n".join(frags[:n]) + "\n")
+    subprocess.check_call([oracle.CLI, "pipeline", str(tmp_path / "t.txt"), str(tmp_path / "q.txt"), str(tmp_path / "out"), "-s", "5.7", "-k", "7",
+                           "--l2", "2097152"], stdout=subprocess.DEVNULL)
+    aln = "".join(">%d\n%s" % (i, api.format_alignments_bulk(alns, int(aoff[i]), int(aoff[i + 1])).decode()) for i in range(n))
+    assert aln == open(tmp_path / "out" / "aln.txt").read()
+    # a k = 6 search of the same batch afterwards: the thresholds are derived back
+    p6 = api.default_params()
+    p6.sensitivity = 5.7
+    p6.host_l2_bytes = 2097152
+    db6 = api.TargetDB(targets, p6)
+    hits6, hoff6 = api.prefilter(db6, q, p6)
+    pref6 = "".join(">%d\n%s" % (i, api.format_hits_bulk(hits6, int(hoff6[i]), int(hoff6[i + 1])).decode()) for i in range(q.n))
+    assert pref6 == _text("e2e_process_pref.txt.gz")
