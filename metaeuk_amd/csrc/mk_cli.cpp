@@ -23,6 +23,7 @@
 
 #include <chrono>
 #include <climits>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -108,6 +109,12 @@ int parse(int argc, char **argv, Args &a) {
         } else {
             a.pos.push_back(s);
         }
+    }
+    {   // target splits change the prefilter's results; only the prefilter command restates them (cmdPrefilterOrAlign)
+        auto sp = a.opt.find("--split"), sm = a.opt.find("--split-mode");
+        const std::string cmd = argc > 1 ? argv[1] : "";
+        if (sp != a.opt.end() && sm != a.opt.end() && sm->second == "0" && atoi(sp->second.c_str()) > 1 && cmd != "prefilter" && cmd != "align")
+            return die("--split %s --split-mode 0 (target splits) is implemented by the prefilter command only", sp->second);
     }
     for (const Flag &k : FLAGS) {
         auto it = a.opt.find(k.name);
@@ -374,8 +381,17 @@ int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
     std::vector<uint8_t> qres;
     std::vector<uint64_t> qoff;
     if (profileQueries) profileColumns(qdb, qres, qoff); else encodeDb(qdb, qres, qoff);
+    // TARGET_DB_SPLIT with N > 1 changes the prefilter's results (per-split --max-seqs, BINSIZE, merge order): honoured by `prefilter`,
+    // refused where the stages run as one pass.  Query splits (--split-mode 1) and the automatic mode leave the results alone.
+    int targetSplits = 1;
+    if (a.opt.count("--split") && a.opt.count("--split-mode") && a.opt["--split-mode"] == "0" && atoi(a.opt["--split"].c_str()) > 1) {
+        targetSplits = atoi(a.opt["--split"].c_str());
+        if (isSearch) return die("search with --split %s --split-mode 0: target splits are implemented by the prefilter command", a.opt["--split"]);
+        if (profileQueries) return die("--split-mode 0 with profile queries is not implemented%s");
+        if (isAlign) targetSplits = 1;                                   // (align has no such flag in the reference; tolerated)
+    }
     TargetSide ts;
-    if (int rc = openTarget(a.pos[1], P, ts)) return rc;
+    if (targetSplits == 1) { if (int rc = openTarget(a.pos[1], P, ts)) return rc; }
     mk_targetdb *T = ts.T;
     const std::vector<uint32_t> &tkeys = ts.keys;
     mk_queries *Q = nullptr;
@@ -384,7 +400,63 @@ int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
     const size_t nq = qdb.entries.size();
     char line[512];
     std::string buf;
-    if (!isAlign) {
+    if (!isAlign && targetSplits > 1) {
+        // --split N --split-mode 0 (TARGET_DB_SPLIT, Prefiltering.cpp:352-361,379-496): the targets are cut into N residue-balanced ranges
+        // (Util::decomposeDomainByAminoAcid over the DB's data order), every range is indexed and searched on its own -- with its own BINSIZE
+        // and a reduced --max-seqs -- and the N hit lists of a query are joined and sorted by (score, key); the joined list is NOT cut again
+        mk::Database tdb;
+        e = tdb.open(a.pos[1]);
+        if (!e.empty()) return die("%s", e);
+        if ((tdb.dbtype & 0xFFFF) != mk::DBTYPE_AMINO_ACIDS) return die("--split with --split-mode 0 needs an amino-acid sequence DB as the target (index DBs hold one split)%s");
+        const size_t nT = tdb.entries.size();
+        if ((size_t) targetSplits > nT) return die("split was set to %s but the db to split has fewer sequences", std::to_string(targetSplits));
+        uint64_t aaSize = 0;
+        for (size_t i = 0; i < nT; i++) aaSize += tdb.seqLen(i);
+        mk_params PS = P;
+        if (!PS.kmer_size) PS.kmer_size = aaSize / (uint64_t) targetSplits < 3350000000ull ? 6 : 7;      // Prefiltering.cpp:352-355
+        {
+            const size_t maxRes = std::min<size_t>(nT, (size_t) P.max_seqs);                              // Prefiltering.cpp:169, then :359-362
+            const size_t fourTimesStdDeviation = (size_t) (4 * sqrt(static_cast<double>(maxRes) / static_cast<double>(targetSplits)));
+            PS.max_seqs = (int) std::max<size_t>(1, (maxRes / (size_t) targetSplits) + fourTimesStdDeviation);
+        }
+        struct KeyHit { uint32_t key; int32_t score; uint16_t diag; };
+        std::vector<std::vector<KeyHit>> merged(nq);
+        for (int sp = 0; sp < targetSplits; sp++) {
+            size_t first = 0, count = 0;
+            mk::decomposeByLength(tdb.entries, sp, targetSplits, first, count);
+            std::vector<uint64_t> toff(count + 1, 0);
+            for (size_t i = 0; i < count; i++) toff[i + 1] = toff[i] + tdb.seqLen(first + i);
+            std::vector<uint8_t> tres(toff.back() + 1, 0);
+            for (size_t i = 0; i < count; i++) mk_encode(tdb.entry(first + i), tdb.seqLen(first + i), tres.data() + toff[i]);
+            mk_targetdb *TS = nullptr;
+            if (mk_targetdb_create(tres.data(), toff.data(), (uint32_t) count, &PS, &TS) != MK_OK) return die("%s", mk_last_error());
+            if (mk_prefilter(TS, Q, &PS) != MK_OK) return die("%s", mk_last_error());
+            const mk_hit *hits; const uint64_t *hoff;
+            mk_prefilter_result(Q, &hits, &hoff);
+            for (size_t i = 0; i < nq; i++)
+                for (uint64_t h = hoff[i]; h < hoff[i + 1]; h++) merged[i].push_back(KeyHit{tdb.entries[first + hits[h].seq_id].key, hits[h].pref_score, hits[h].diagonal});
+            mk_targetdb_destroy(TS);
+        }
+        mk::DatabaseWriter w(outPath, mk::DBTYPE_PREFILTER_RES);
+        e = w.open();
+        if (!e.empty()) return die("%s", e);
+        uint64_t total = 0;
+        for (size_t i = 0; i < nq; i++) {
+            std::vector<KeyHit> &v = merged[i];
+            std::sort(v.begin(), v.end(), [](const KeyHit &x, const KeyHit &y) {          // hit_t::compareHitsByScoreAndId on the parsed lines (seqId = key)
+                if (std::abs(x.score) != std::abs(y.score)) return std::abs(x.score) > std::abs(y.score);
+                return x.key < y.key;
+            });
+            buf.clear();
+            for (const KeyHit &h : v) buf.append(line, mk_format_hit(line, h.key, h.score, h.diag));
+            w.write(qdb.entries[i].key, buf.data(), buf.size());
+            total += v.size();
+        }
+        e = w.close();
+        if (!e.empty()) return die("%s", e);
+        fprintf(stderr, "prefilter: %zu queries x %zu targets in %d target splits (--max-seqs %d per split, k = %d), %llu hits, %.2f s\n", nq, nT, targetSplits, PS.max_seqs,
+                PS.kmer_size, (unsigned long long) total, now() - t0);
+    } else if (!isAlign) {
         if (mk_prefilter(T, Q, &P) != MK_OK) return die("%s", mk_last_error());
         const mk_hit *hits; const uint64_t *hoff;
         mk_prefilter_result(Q, &hits, &hoff);
@@ -471,7 +543,7 @@ int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
         fprintf(stderr, "%s: %llu alignments calculated, %llu passed, %.2f s\n", isSearch ? "search" : "align", (unsigned long long) hits.size(), (unsigned long long) aoff[nq], now() - t0);
     }
     mk_queries_destroy(Q);
-    mk_targetdb_destroy(T);
+    if (T) mk_targetdb_destroy(T);
     return finishShards(outBase, sh, isAlign ? (keyListOut ? 6 : mk::DBTYPE_ALIGNMENT_RES) : mk::DBTYPE_PREFILTER_RES);
 }
 

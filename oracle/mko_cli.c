@@ -8,6 +8,7 @@
  */
 #include "mko.h"
 #include <limits.h>
+#include <math.h>
 #include <float.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -61,10 +62,18 @@ static int kmer_threshold(float sensitivity) {   /* Prefiltering.cpp:1051-1053, 
     return (int) best;
 }
 
+static int merged_hit_cmp(const void *a, const void *b) {   /* hit_t::compareHitsByScoreAndId on the joined lists */
+    const mko_hit *x = (const mko_hit *) a, *y = (const mko_hit *) b;
+    int ax = abs(x->score), ay = abs(y->score);
+    if (ax != ay) return ax > ay ? -1 : 1;
+    if (x->seq_id != y->seq_id) return x->seq_id < y->seq_id ? -1 : 1;
+    return 0;
+}
+
 static int cmd_pipeline(int argc, char **argv) {
     lines_t T = read_lines(argv[2]), Q = read_lines(argv[3]);
     const char *outdir = argv[4];
-    float sens = 5.7f; int dump = 0, lb = 32, lw = 16, tl = 4, maxSeqs = 300, kmerSize = 6;
+    float sens = 5.7f; int dump = 0, lb = 32, lw = 16, tl = 4, maxSeqs = 300, kmerSize = 6, splits = 1;
     long l2 = sysconf(_SC_LEVEL2_CACHE_SIZE);
     if (l2 <= 0) l2 = 262144;   /* Util::getL2CacheSize, Util.cpp:317-332 */
     for (int a = 5; a < argc; a++) {
@@ -76,7 +85,9 @@ static int cmd_pipeline(int argc, char **argv) {
         else if (!strcmp(argv[a], "--l2")) l2 = atol(argv[++a]);
         else if (!strcmp(argv[a], "--max-seqs")) maxSeqs = atoi(argv[++a]);
         else if (!strcmp(argv[a], "-k")) kmerSize = atoi(argv[++a]);
+        else if (!strcmp(argv[a], "--split")) splits = atoi(argv[++a]);      /* target splits: --split N --split-mode 0 */
     }
+    if (splits < 1 || (splits > 1 && dump)) { fprintf(stderr, "--split N >= 1 (and no --dump with splits)\n"); return 2; }
     if (kmerSize != 6 && kmerSize != 7) { fprintf(stderr, "-k 6 or 7\n"); return 2; }
     mkdir(outdir, 0755);
     uint8_t *tres, *qres; uint64_t *toff, *qoff;
@@ -96,7 +107,32 @@ static int cmd_pipeline(int argc, char **argv) {
     mko_scoremat *three = mko_scoremat_build(&kmerMat, 3);
     mko_scoremat *two = kmerSize == 7 ? mko_scoremat_build(&kmerMat, 2) : NULL;
     double tExt = now() - t0; t0 = now();
-    mko_index *ix = mko_index_build_k(&kmerMat, tres, toff, (uint32_t) T.n, kmerThr, 1, tl, kmerSize);
+    /* TARGET_DB_SPLIT (Prefiltering.cpp:352-362,733-750): residue-balanced target ranges (DBReader::decomposeDomainByAminoAcid over the
+     * index lengths = residues + 2), an index per range, --max-seqs reduced to maxRes / N + 4 sqrt(maxRes / N) */
+    uint32_t *splitFirst = (uint32_t *) calloc((size_t) splits + 1, sizeof(uint32_t));
+    if (splits > 1) {
+        uint64_t total = 0;
+        for (size_t i = 0; i < T.n; i++) total += (uint64_t) T.len[i] + 2;
+        const uint64_t chunk = (total + (uint64_t) splits - 1) / (uint64_t) splits;
+        uint64_t acc = 0; int w = 0;
+        uint32_t *per = (uint32_t *) calloc((size_t) splits, sizeof(uint32_t));
+        for (size_t i = 0; i < T.n; i++) { if (acc >= chunk) { acc = 0; w++; } acc += (uint64_t) T.len[i] + 2; per[w]++; }
+        for (int r = 0; r < splits; r++) splitFirst[r + 1] = splitFirst[r] + per[r];
+        free(per);
+        size_t maxRes = (size_t) maxSeqs < T.n ? (size_t) maxSeqs : T.n;
+        size_t four = (size_t) (4 * sqrt((double) maxRes / (double) splits));
+        maxSeqs = (int) (maxRes / (size_t) splits + four);
+        if (maxSeqs < 1) maxSeqs = 1;
+    } else splitFirst[1] = (uint32_t) T.n;
+    mko_index **ixs = (mko_index **) calloc((size_t) splits, sizeof(mko_index *));
+    for (int r = 0; r < splits; r++) {
+        const uint32_t f = splitFirst[r], n = splitFirst[r + 1] - splitFirst[r];
+        uint64_t *so = (uint64_t *) malloc(((size_t) n + 1) * sizeof(uint64_t));
+        for (uint32_t i = 0; i <= n; i++) so[i] = toff[f + i] - toff[f];
+        ixs[r] = mko_index_build_k(&kmerMat, tres + toff[f], so, n, kmerThr, 1, tl, kmerSize);
+        free(so);
+    }
+    mko_index *ix = ixs[0];
     double tIdx = now() - t0;
     char path[4096];
     if (dump) {
@@ -134,15 +170,32 @@ static int cmd_pipeline(int argc, char **argv) {
     t0 = now();
 #pragma omp parallel
     {
-        mko_hit *hits = (mko_hit *) malloc((size_t) (maxSeqs + 1) * sizeof(mko_hit));
-        mko_aln_result *res = (mko_aln_result *) malloc((size_t) (maxSeqs + 1) * sizeof(mko_aln_result));
+        mko_hit *hits = (mko_hit *) malloc(((size_t) maxSeqs * (size_t) splits + 1) * sizeof(mko_hit));
+        mko_aln_result *res = (mko_aln_result *) malloc(((size_t) maxSeqs * (size_t) splits + 1) * sizeof(mko_aln_result));
         char buf[512];
 #pragma omp for schedule(dynamic, 1) reduction(+: totalHits, alignments, passed, dbMatches, kmersPerPos, cells)
         for (size_t id = 0; id < Q.n; id++) {
             const uint8_t *q = qres + qoff[id];
             const int L = (int) (qoff[id + 1] - qoff[id]);
             mko_prefilter_stats st;
-            int nh = mko_prefilter_query(&pc, q, L, hits, &st);
+            int nh = 0;
+            if (splits == 1) nh = mko_prefilter_query(&pc, q, L, hits, &st);
+            else {
+                /* every split on its own (own BINSIZE), the lists joined and sorted by (score, key) without another cut (mergeTargetSplits, :379-496) */
+                mko_prefilter_stats one;
+                memset(&st, 0, sizeof(st));
+                for (int r = 0; r < splits && nh >= 0; r++) {
+                    mko_prefilter_ctx ps = pc;
+                    ps.index = ixs[r];
+                    ps.bin_count = mko_bin_count_for(ixs[r]->n_seq, (uint64_t) l2);
+                    int k = mko_prefilter_query(&ps, q, L, hits + nh, &one);
+                    if (k < 0) { nh = -1; break; }
+                    for (int h = 0; h < k; h++) hits[nh + h].seq_id += splitFirst[r];
+                    nh += k;
+                    st.kmer_list_len += one.kmer_list_len; st.db_matches += one.db_matches;
+                }
+                if (nh > 1) qsort(hits, (size_t) nh, sizeof(mko_hit), merged_hit_cmp);
+            }
             if (nh < 0) { fprintf(stderr, "query %zu: unsupported overflow path\n", id); nh = 0; }
             totalHits += (unsigned long long) nh;
             dbMatches += st.db_matches;

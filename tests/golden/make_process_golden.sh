@@ -10,6 +10,8 @@
 #   e2e_process_calls_default_s4.txt.gz   dp_predictions of a run WITHOUT -s: predictexons passes its own default -s 4 to search
 #   e2e_process_pref_k7.txt.gz       `prefilter aa_6f targetsDB -k 7 -s 5.7`: the k-mer size the reference switches to from 3.35e9 target
 #                                    residues on (IndexTable.h:439-449), forced on the small fixture (threshold 122, 2119 k-mers per position)
+#   e2e_process_pref_split3_maxseqs20.txt.gz   `prefilter ... --split 3 --split-mode 0 --max-seqs 20 -s 5.7`: TARGET_DB_SPLIT -- three target ranges
+#                                    (68 / 60 / 72 proteins) searched one by one with --max-seqs 6 + 10 each, the lists joined and sorted
 # Inputs: tests/golden/e2e_targets.txt.gz, e2e_contigs.txt.gz (createdb --shuffle 0, so keys = line numbers).  Host L2 = 2097152.
 set -e
 R=$(cd $(dirname $0)/../.. && pwd)
@@ -32,6 +34,7 @@ mkdir tmp tmp2
 $M predictexons contigsDB targetsDB calls tmp --remove-tmp-files 0 --threads 4 -s 5.7 > run.log 2>&1
 $M predictexons contigsDB targetsDB calls4 tmp2 --threads 4 > run4.log 2>&1
 $M prefilter tmp/latest/aa_6f targetsDB pref_k7 -k 7 -s 5.7 --threads 4 > k7.log 2>&1      # ~1.5 min: the reference initialises a 21^7 table
+$M prefilter tmp/latest/aa_6f targetsDB pref_sp3 --split 3 --split-mode 0 -s 5.7 --max-seqs 20 --threads 4 > sp3.log 2>&1
 python3 - <<PY
 import glob, gzip, os
 def read_db(base):
@@ -50,6 +53,7 @@ write("e2e_process_pref.txt.gz", blocks(read_db(glob.glob(T + 'tmp_search/*/pref
 write("e2e_process_aln.txt.gz", blocks(read_db(T + 'search_res')))
 write("e2e_process_calls_default_s4.txt.gz", blocks(read_db('$W/calls4')))
 write("e2e_process_pref_k7.txt.gz", blocks(read_db('$W/pref_k7')))
+write("e2e_process_pref_split3_maxseqs20.txt.gz", blocks(read_db('$W/pref_sp3')))
 assert blocks(read_db('$W/calls')) == gzip.open(G + 'e2e_exons_expected.txt.gz', 'rt').read(), "the real predictexons differs from the harness-made exon sets"
 print("real metaeuk predictexons -s 5.7 == harness-made e2e_exons_expected: OK")
 PY

@@ -52,3 +52,41 @@ def test_k7_prefilter_matches_the_real_process(gpu_api, tmp_path):
     hits6, hoff6 = api.prefilter(db6, q, p6)
     pref6 = "".join(">%d\n%s" % (i, api.format_hits_bulk(hits6, int(hoff6[i]), int(hoff6[i + 1])).decode()) for i in range(q.n))
     assert pref6 == _text("e2e_process_pref.txt.gz")
+
+
+def _write_seq_db(base, seqs):
+    from metaeuk_amd import api as A
+    A.write_seq_db(base, A.seq_db_image(seqs))
+
+
+def _read_result_db(base):
+    data = open(base, "rb").read()
+    out = {}
+    for line in open(base + ".index"):
+        k, o, l = line.split("\t")
+        out[int(k)] = data[int(o):int(o) + int(l) - 1].decode()
+    return out
+
+
+def test_cli_target_splits_and_k7_match_the_real_process(gpu_api, tmp_path):
+    """`prefilter --split 3 --split-mode 0 --max-seqs 20` (TARGET_DB_SPLIT: per-range index, BINSIZE and reduced --max-seqs, joined lists)
+    and `prefilter -k 7` as commands, against the real binary's DBs; where target splits are not restated they are refused"""
+    from metaeuk_amd import build
+    targets = _text("e2e_targets.txt.gz").splitlines()
+    frags = [l.rsplit("\t", 1)[1] for l in _text("e2e_process_orfs.txt.gz").splitlines()]
+    _write_seq_db(str(tmp_path / "targets"), targets)
+    _write_seq_db(str(tmp_path / "frags"), frags)
+    blocks = lambda d: "".join(">%d\n%s" % (k, d[k]) for k in sorted(d))
+    run = lambda *a: subprocess.run([build.BIN] + [str(x) for x in a], stderr=subprocess.PIPE)
+    r = run("prefilter", tmp_path / "frags", tmp_path / "targets", tmp_path / "pref_sp3", "--split", "3", "--split-mode", "0", "-s", "5.7", "--max-seqs", "20",
+            "--ref-l2-bytes", "2097152")
+    assert r.returncode == 0, r.stderr.decode()
+    assert blocks(_read_result_db(str(tmp_path / "pref_sp3"))) == _text("e2e_process_pref_split3_maxseqs20.txt.gz")
+    # 2 000 fragments through the command with -k 7
+    _write_seq_db(str(tmp_path / "frags2k"), frags[:2000])
+    r = run("prefilter", tmp_path / "frags2k", tmp_path / "targets", tmp_path / "pref_k7", "-k", "7", "-s", "5.7", "--ref-l2-bytes", "2097152")
+    assert r.returncode == 0, r.stderr.decode()
+    expected = _text("e2e_process_pref_k7.txt.gz")
+    assert blocks(_read_result_db(str(tmp_path / "pref_k7"))) == expected[:expected.index(">2000\n")]
+    r = run("search", tmp_path / "frags2k", tmp_path / "targets", tmp_path / "aln", tmp_path / "tmp", "--alignment-mode", "2", "--split", "3", "--split-mode", "0")
+    assert r.returncode != 0 and b"target splits" in r.stderr

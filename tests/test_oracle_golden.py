@@ -113,6 +113,16 @@ def test_oracle_k7_matches_the_real_process(tmp_path):
     assert open(tmp_path / "out" / "pref.txt").read() == expected
 
 
+def test_oracle_target_splits_match_the_real_process(tmp_path):
+    """TARGET_DB_SPLIT (--split 3 --split-mode 0 --max-seqs 20): per-range index, BINSIZE and reduced --max-seqs, joined lists"""
+    oracle.build()
+    (tmp_path / "t.txt").write_text(_text("e2e_targets.txt.gz"))
+    (tmp_path / "q.txt").write_text("".join(l.rsplit("\t", 1)[1] + "\n" for l in _text("e2e_process_orfs.txt.gz").splitlines()))
+    subprocess.check_call([oracle.CLI, "pipeline", str(tmp_path / "t.txt"), str(tmp_path / "q.txt"), str(tmp_path / "out"), "-s", "5.7", "--split", "3",
+                           "--max-seqs", "20", "--l2", "2097152"], stdout=subprocess.DEVNULL)
+    assert open(tmp_path / "out" / "pref.txt").read() == _text("e2e_process_pref_split3_maxseqs20.txt.gz")
+
+
 def _profile_inputs(tmp_path):
     """the fixtures of the profile-target path as files: the profile DB, the fragments in the order of their data offsets in the
     fragment DB (= the prefilter's target numbering) and their DB keys"""
