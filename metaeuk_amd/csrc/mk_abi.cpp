@@ -171,6 +171,7 @@ struct mk_targetdb {
     DevBuf<uint32_t> dKeys;          // device copy of `keys` (last tie-break of the alignment order)
     DevBuf<uint16_t> dAddr3;         // 3-mer number -> address code of the table cells (profile k-mer lists)
     int kmerSize = 6;                // 6 or 7 (mk_params.kmer_size / IndexTable::computeKmerSize)
+    uint64_t entryShift = 0;         // MK_TEST_ENTRY_BASE: the slots' list starts are shifted by this much, the entries pointer of the views back
     DevBuf<int16_t> dScore2;         // k = 7: similar 2-mers [400][400]
     DevBuf<uint16_t> dIndex2, dNum3; // ... their numbers; address code -> 3-mer number
     bool profileSearch = false;      // built for profile queries (mk_params.profile_search)
@@ -376,12 +377,18 @@ static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uin
     mk::TargetIndex built;
     if (!prebuilt) mk::build_index(db->kmerMat, residues, offsets, n, db->kmerThr, P->mask != 0, P->mask_prob, P->simd_lanes_double, built, true, kmerSize);
     mk::TargetIndex &ix = prebuilt ? *prebuilt : built;
-    if (ix.entries.size() >= 0xFFFFFFFFull) { delete db; return fail(MK_ERR_UNSUPPORTED, "index has >= 2^32 entries"); }
+    if (ix.entries.size() >= (1ull << 40)) { delete db; return fail(MK_ERR_UNSUPPORTED, "index has >= 2^40 entries"); }
+    // test hook: shift every list start by this many entries (and the device pointer back by as many), so that the slots' 40-bit starts
+    // are exercised beyond 2^32 without a database of that size
+    const uint64_t entryShift = getenv("MK_TEST_ENTRY_BASE") ? strtoull(getenv("MK_TEST_ENTRY_BASE"), nullptr, 10) : 0;
+    if (ix.entries.size() + entryShift >= (1ull << 40)) { delete db; return fail(MK_ERR_ARG, "MK_TEST_ENTRY_BASE too large"); }
+    db->entryShift = entryShift;
     db->nEntries = ix.entries.size();
     db->maskedHost = ix.masked;
     const size_t nKmers = ix.offsets.size() - 1;
     std::vector<uint64_t> slots(nKmers);
     std::vector<uint32_t> bits((nKmers + 31) / 32, 0u);
+    int tooLong = 0;
 #pragma omp parallel for schedule(static)
     for (size_t wd = 0; wd < bits.size(); wd++) {
         uint32_t m = 0;
@@ -389,10 +396,12 @@ static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uin
         for (size_t k = k0; k < k1; k++) {
             const uint64_t first = ix.offsets[k], len = ix.offsets[k + 1] - first;
             if (len) m |= 1u << (k - k0);
-            slots[k] = len == 1 ? ((1ull << 63) | ix.entries[first]) : (first | (len << 32));
+            if (len >= (1ull << 23)) tooLong = 1;
+            slots[k] = len == 1 ? ((1ull << 63) | ix.entries[first]) : ((first + entryShift) | (len << 40));
         }
         bits[wd] = m;
     }
+    if (tooLong) { delete db; return fail(MK_ERR_UNSUPPORTED, "a k-mer occurs in 2^23 or more targets: the slot's length field holds 23 bits"); }
     mk::ScoreMat3 sm;
     mk::build_scoremat3(db->kmerMat, sm);
     int8_t matAln[441], matUng[441];
@@ -946,7 +955,7 @@ static mk::PrefilterDeviceView prefilter_view(const mk_targetdb *db, const mk_qu
     mk::PrefilterDeviceView V;
     V.q_res = q->dRes.p; V.q_off = q->dOff.p; V.q_kmer_thr = q->dKmerThr.p; V.q_corr = q->dCorr.p; V.n_queries = q->n;
     V.t_masked = db->dMasked.p; V.t_off = db->dOff.p; V.n_targets = db->n;
-    V.kmer_slot = db->dKmerSlot.p; V.kmer_bits = db->dKmerBits.p; V.entries = db->dEntries.p; V.score3 = db->dScore3.p; V.index3 = db->dIndex3.p;
+    V.kmer_slot = db->dKmerSlot.p; V.kmer_bits = db->dKmerBits.p; V.entries = db->dEntries.p - db->entryShift; V.score3 = db->dScore3.p; V.index3 = db->dIndex3.p;
     V.hist3 = db->dHist3.p; V.cum3 = db->dCum3.p; V.hist_lo = db->histLo; V.hist_range = db->histRange; V.n_entries = db->nEntries;
     V.mat_ung = db->dMatUng.p;
     if (q->isProfile) { V.p_sorted = q->dProfSorted.p; V.p_aln = q->dProfAln.p; V.addr3 = db->dAddr3.p; }

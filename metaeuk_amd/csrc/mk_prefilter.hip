@@ -127,15 +127,19 @@ __device__ __forceinline__ uint64_t ld_probe(const uint64_t *p) {
 #endif
 }
 // index list of a k-mer from its slot: length, first entry index, and the first entry itself when the slot holds it
-struct KmerList { uint32_t size, first; uint64_t ent0; bool isInline; };
+// (slot of a longer list: first entry index in bits 0..39, length in bits 40..62 -- 2^40 entries per index, 2^23 per list)
+struct KmerList { uint32_t size; uint64_t first; uint64_t ent0; bool isInline; };
 __device__ __forceinline__ KmerList load_kmer_list(const uint64_t *slots, uint32_t kmer) {
     const uint64_t s = ld_probe(slots + kmer);
     KmerList l;
     l.isInline = (s >> 63) != 0;
-    l.size = l.isInline ? 1u : (uint32_t) (s >> 32);
-    l.first = (uint32_t) s;
+    l.size = l.isInline ? 1u : (uint32_t) (s >> 40) & 0x7FFFFFu;
+    l.first = s & 0xFFFFFFFFFFull;
     l.ent0 = s & 0x0000FFFFFFFFFFFFull;
     return l;
+}
+__device__ __forceinline__ uint64_t wave_read_lane64(uint64_t v, uint32_t srcLane) {
+    return (uint64_t) enumk::wave_read_lane((uint32_t) v, srcLane) | ((uint64_t) enumk::wave_read_lane((uint32_t) (v >> 32), srcLane) << 32);
 }
 __device__ __forceinline__ bool kmer_present(const uint32_t *bits, uint32_t kmer) { return (bits[kmer >> 5] >> (kmer & 31u)) & 1u; }
 
@@ -186,7 +190,8 @@ __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
     }
     uint32_t hits = 0;
     const auto onBatch = [&](const uint32_t (&kmer)[PROBE_U], const bool (&has)[PROBE_U]) -> bool {
-            uint32_t size[PROBE_U], o0[PROBE_U];
+            uint32_t size[PROBE_U];
+            uint64_t o0[PROBE_U];
             uint64_t ent0[PROBE_U];
             bool inl[PROBE_U];
 #pragma unroll
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
                     if (size[u]) put(ent0[u], dst);
                     // the rest of the longer lists, one entry per lane
                     enumk::wave_deal_tail(size[u] > 1 ? size[u] - 1 : 0u, lane, sMark[w], [&](uint32_t owner, uint32_t e, bool valid) {
-                        const uint32_t oFirst = enumk::wave_read_lane(o0[u], owner);
+                        const uint64_t oFirst = wave_read_lane64(o0[u], owner);
                         const uint32_t oLo = enumk::wave_read_lane((uint32_t) dst, owner), oHi = enumk::wave_read_lane((uint32_t) (dst >> 32), owner);
                         if (valid) put(A.V.entries[oFirst + e], (((uint64_t) oHi << 32) | oLo) + e);
                     });
@@ -534,7 +539,8 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
             kmers += enumk::enumerate_position<U>(A.V, A.V.q_res + p, thr, lane, P1.e[w],
                 [&](const uint32_t (&kmer)[U], const bool (&has)[U]) -> bool {
                     PROF_LAP(pEnum);
-                    uint32_t size[U], o0[U], ex[U];
+                    uint32_t size[U], ex[U];
+                    uint64_t o0[U];
                     uint64_t ent0[U];
                     bool inl[U];
 #pragma unroll
@@ -584,7 +590,8 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
                         const uint32_t r0 = ex[u];
                         if (size[u]) put(ent0[u], r0);
                         enumk::wave_deal_tail(size[u] > 1 ? size[u] - 1 : 0u, lane, P1.mark[w], [&](uint32_t owner, uint32_t e, bool valid) {
-                            const uint32_t oFirst = enumk::wave_read_lane(o0[u], owner), oR0 = enumk::wave_read_lane(r0, owner);
+                            const uint64_t oFirst = wave_read_lane64(o0[u], owner);
+                            const uint32_t oR0 = enumk::wave_read_lane(r0, owner);
                             if (valid) put(ld_probe(A.V.entries + oFirst + e), oR0 + e);
                         });
                     }

@@ -204,6 +204,23 @@ def test_pipeline_vs_golden(gpu_api, tag, pf_path):
         assert api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1])) == galn[i], ("aln", i)
 
 
+def test_index_list_starts_beyond_32_bits(gpu_api, pf_path, monkeypatch):
+    """An index of more than 2^32 entries (UniRef50-scale databases): the slots hold 40-bit list starts.  MK_TEST_ENTRY_BASE shifts every
+    start by 6e9 entries (and the device pointer back), so the wide arithmetic of every prefilter front end runs on the small fixture."""
+    monkeypatch.setenv("MK_TEST_ENTRY_BASE", "6000000000")
+    api = gpu_api
+    targets, queries = _lines("small_targets.txt.gz"), _lines("small_queries.txt.gz")
+    params = api.default_params()
+    params.host_l2_bytes = 2097152
+    db = api.TargetDB(targets, params)
+    q = api.Queries(queries, params)
+    (hits, hoff), (alns, aoff) = api.search(db, q)
+    gpref, galn = _blocks("small_pref.txt.gz"), _blocks("small_aln.txt.gz")
+    for i in range(len(queries)):
+        assert api.format_hits(hits, int(hoff[i]), int(hoff[i + 1])) == gpref[i], ("pref", i)
+        assert api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1])) == galn[i], ("aln", i)
+
+
 def test_sw_vs_golden(gpu_api):
     """400 adversarial pairs (gap next to gap, poly-residue inserts, long related pairs): coordinates and bit
     scores printed by the reference (AVX2 == SSE4.1) vs the kernel's integers"""
