@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--two-calls", action="store_true", help="mk_prefilter then mk_align instead of the pipelined mk_search")
     ap.add_argument("--cpu-sample", type=int, default=400000, help="queries in the CPU baseline sample (0 = skip)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default=None, help="multi-GPU mode (default: strong when --gpus > 1)")
+    ap.add_argument("--config4-profiles", type=int, default=50000, help="BASELINE config 4 beside the headline number (N = 1 only): this many synthetic "
+                    "profiles searched against the same fragments, profiles as queries (0 = skip)")
     args = ap.parse_args()
 
     # the one JSON line goes to the real stdout; whatever libraries print there (RCCL's version banner at communicator creation) is
@@ -278,6 +280,50 @@ def main():
                           "frac": (sw_lane_ops / max(sw_ms * 1e-3, 1e-12) / 1e12 / VALU_PEAK_TOPS) if sw_ms else None,
                           "note": "peak = one integer / packed-int16 wave-instruction per 4 cycles per SIMD (measured, profiles/r02_valu_issue_rates.txt)"},
     }
+    if rank == 0 and world == 1 and args.config4_profiles > 0:
+        # BASELINE config 4 (profile targets: the reference's inverted search -- profiles as queries, the fragments as the indexed side,
+        # swapresults), reported beside the headline metric and outside its timed region.  DESIGN.md 4.7; parity: tests/test_gpu_profile.py.
+        try:
+            from metaeuk_amd import synth
+            import numpy as np
+            t1 = time.time()
+            proteins, _ = synth.make_targets(args.config4_profiles, args.seed)
+            entries = synth.make_profiles(proteins, args.seed)
+            pp = api.default_params()
+            pp.sensitivity = 4.0                                   # predictexons' own default
+            pp.profile_search = 1
+            pp.max_seqs = max(300, nq)
+            pp.evalue_thr = float("%g" % (100.0 * (np.float32(nq) / np.float32(len(entries)))))
+            pp.host_l2_bytes = params.host_l2_bytes
+            t_gen4 = time.time() - t1
+            t1 = time.time()
+            fdb = api.TargetDB.from_codes(q_res, q_off, pp)         # the fragments of the headline workload as the indexed side
+            t_idx4 = time.time() - t1
+            residues = sum(len(e) for e in entries) // 25 - len(entries)
+            times = []
+            for it in range(2):
+                api.kernel_stats(reset=True)
+                t1 = time.time()
+                pq = api.Profiles(entries, pp)
+                (ph, pho), (pa, pao) = api.search(fdb, pq, pp)
+                sp = api.default_params()
+                sp.evalue_thr = 1.7976931348623157e308
+                sw, soff = api.swap_alignments(pa, pao, nq, residues, params=sp)
+                times.append(time.time() - t1)
+                st4 = api.kernel_stats()
+                counts = (int(pho[-1]), int(pao[-1]), int(soff[-1]))
+                del pq, sw
+            cells4 = sum(v["cells"] for k, v in st4.items() if k.startswith("sw_fwd"))
+            line["config4_profile_targets"] = {
+                "workload": "%d synthetic profiles (%d columns) as queries x the %d fragments above as the indexed side, -s 4; prefilter + align + swapresults" % (
+                    len(entries), sum(len(e) // 25 for e in entries), nq),
+                "s_per_pass": round(times[-1], 3), "profiles_per_s": round(len(entries) / times[-1], 1), "first_pass_s": round(times[0], 3),
+                "prefilter_hits": counts[0], "alignments": counts[1], "swapped_records": counts[2], "sw_fwd_cells": cells4,
+                "setup_s": {"generate_profiles": round(t_gen4, 2), "fragment_index_build_upload": round(t_idx4, 2)},
+                "kernels_ms": {k: round(v["ms"], 2) for k, v in sorted(st4.items()) if v["ms"] >= 1.0}}
+            fdb.close()
+        except Exception as e:      # reported beside the headline number, never required for it
+            line["config4_profile_targets"] = {"error": repr(e)}
     if rank == 0:
         if world == 1 and args.cpu_sample > 0:
             n_s = min(args.cpu_sample, nq)

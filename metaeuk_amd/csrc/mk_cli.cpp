@@ -733,33 +733,53 @@ int cmdExtractOrfs(int argc, char **argv) {
 // predictexons against a PROFILE database (BASELINE config 4): Search.cpp:357-399 + searchslicedtargetprofile.sh in one
 // process.  The fragments of ALL contigs become the indexed target side (the reference indexes the whole aa_6f DB as well: its numbers --
 // fragments, residues -- enter the e-value threshold, the e-values and --max-seqs), the profiles go through prefilter + align in slices
-// bounded by their columns, swapresults turns the lists round, the exon stage runs on them.  The workflow's second `align` (the merged key
+// bounded by their columns, swapresults turns the lists round, the exon stage runs on them.  The contigs are translated in
+// nucleotide-bounded batches; their fragments are collected on the host because they form ONE target side.  The workflow's second `align` (the merged key
 // lists again, to "keep the top hits") accepts exactly the pairs of the first with --max-accept / --max-rejected at their defaults, so one
 // pass is the result.  Not sharded: a worker would need the other workers' fragment counts before it can score anything.
 int predictExonsProfileTargets(const Args &a, mk_params P, const mk_exon_params &X, int minLength, const mk::Database &contigs, const std::vector<size_t> &ord,
                                const Shard &sh, const std::string &outPath, double t0) {
     if (sh.world > 1) return die("predictexons with a profile target database is not sharded: run it as one process%s");
     static const char none = 0;
-    if (!ord.empty() && contigBatchEnd(contigs, ord, 0) != ord.size())
-        return die("predictexons with a profile target database takes all contigs in one batch: raise MK_CLI_BATCH_NT (now %s nucleotides per batch)",
-                   getenv("MK_CLI_BATCH_NT") ? getenv("MK_CLI_BATCH_NT") : "2^29");
     mk::Database pdb;
     std::string e = pdb.open(a.pos[1]);
     if (!e.empty()) return die("%s", e);
-    std::vector<char> nucl;
-    std::vector<uint64_t> off(1, 0);
-    for (size_t i = 0; i < ord.size(); i++) {
-        nucl.insert(nucl.end(), contigs.entry(ord[i]), contigs.entry(ord[i]) + contigs.seqLen(ord[i]));
-        off.push_back(nucl.size());
+    // the fragments of all contigs (ORF extraction in nucleotide-bounded batches, like the sequence path): records, offsets, residue codes
+    std::vector<mk_orf> orfAll;
+    std::vector<uint64_t> aaOffAll(1, 0);
+    std::vector<uint8_t> fres;
+    {
+        std::vector<char> nucl;
+        std::vector<uint64_t> off;
+        for (size_t c0 = 0; c0 < ord.size(); ) {
+            const size_t c1 = contigBatchEnd(contigs, ord, c0);
+            nucl.clear(); off.assign(1, 0);
+            for (size_t i = c0; i < c1; i++) {
+                nucl.insert(nucl.end(), contigs.entry(ord[i]), contigs.entry(ord[i]) + contigs.seqLen(ord[i]));
+                off.push_back(nucl.size());
+            }
+            mk_orfs *O = nullptr;
+            if (mk_extract_orfs(nucl.empty() ? &none : nucl.data(), off.data(), (uint32_t) (c1 - c0), minLength, &O) != MK_OK) return die("%s", mk_last_error());
+            const mk_orf *ob; const uint64_t *ao; const char *aab; uint64_t nb = 0;
+            mk_orfs_result(O, &ob, &ao, &aab, &nb);
+            const uint64_t base = aaOffAll.back();
+            fres.resize(base + ao[nb] + 1);
+            mk_encode(aab, ao[nb], fres.data() + base);
+            for (uint64_t k = 0; k < nb; k++) {
+                mk_orf o = ob[k];
+                o.contig += (uint32_t) c0;                                    // position in `ord`, over all batches
+                orfAll.push_back(o);
+                aaOffAll.push_back(base + ao[k + 1]);
+            }
+            mk_orfs_destroy(O);
+            c0 = c1;
+        }
+        if (fres.empty()) fres.push_back(0);
     }
-    mk_orfs *O = nullptr;
-    if (mk_extract_orfs(nucl.empty() ? &none : nucl.data(), off.data(), (uint32_t) ord.size(), minLength, &O) != MK_OK) return die("%s", mk_last_error());
-    const mk_orf *orfs; const uint64_t *aaOff; const char *aa; uint64_t nFrag = 0;
-    mk_orfs_result(O, &orfs, &aaOff, &aa, &nFrag);
+    const mk_orf *orfs = orfAll.data();
+    const uint64_t *aaOff = aaOffAll.data();
+    const uint64_t nFrag = orfAll.size();
     const size_t nProf = pdb.entries.size();
-    // the fragments as the target side of a profile search
-    std::vector<uint8_t> fres(aaOff[nFrag] + 1);
-    mk_encode(aa, aaOff[nFrag], fres.data());
     const double evalThrUser = P.evalue_thr;
     P.profile_search = 1;
     P.max_seqs = (int) std::max<uint64_t>(300, nFrag);                       // Search.cpp:372
@@ -831,7 +851,6 @@ int predictExonsProfileTargets(const Args &a, mk_params P, const mk_exon_params 
     mk_predictions_destroy(R);
     mk_swapped_destroy(S);
     mk_targetdb_destroy(F);
-    mk_orfs_destroy(O);
     return finishShards(a.pos[2], sh, 12);
 }
 

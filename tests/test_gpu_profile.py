@@ -241,3 +241,9 @@ def test_cli_profile_workflow_equals_the_real_process(gpu_api, tmp_path):
     A.write_seq_db(str(tmp_path / "contigs"), A.seq_db_image(contigs), dbtype=1)
     run("predictexons", tmp_path / "contigs", tmp_path / "profDB", tmp_path / "calls", tmp_path / "tmp", "--threads", "4", "--ref-l2-bytes", "2097152")
     assert blocks(_read_result_db(str(tmp_path / "calls"))) == _text("prof_calls.txt.gz")
+    # the contigs translated in batches of at most 50 000 nucleotides (their fragments still form one indexed side), the profiles in slices of
+    # at most 5 000 columns
+    env = dict(os.environ, MK_CLI_BATCH_NT="50000", MK_CLI_PROFILE_COLS="5000")
+    subprocess.check_call([build.BIN, "predictexons", str(tmp_path / "contigs"), str(tmp_path / "profDB"), str(tmp_path / "calls_b"), str(tmp_path / "tmp"),
+                           "--ref-l2-bytes", "2097152"], stderr=subprocess.DEVNULL, env=env)
+    assert blocks(_read_result_db(str(tmp_path / "calls_b"))) == _text("prof_calls.txt.gz")

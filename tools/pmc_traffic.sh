@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/pmc
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 1 --warmup 1 --cpu-sample 0"
+BENCH="python $R/bench.py --steps 1 --warmup 1 --cpu-sample 0 --config4-profiles 0"
 rm -rf $OUT/rd $OUT/wr
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace --output-format csv -d $OUT/rd -- $BENCH > $OUT/rd.log 2>&1
 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d $OUT/wr -- $BENCH > $OUT/wr.log 2>&1
@@ -42,7 +42,7 @@ for k, v in agg.items():
     wr, w64 = v.get("TCC_EA0_WRREQ_sum", 0), v.get("TCC_EA0_WRREQ_64B_sum", 0)
     kern[k] = {"launches": n[k], "fetch_bytes": 128 * r128 + 32 * r32 + 64 * max(rd - r128 - r32, 0), "write_bytes": 64 * w64 + 32 * max(wr - w64, 0),
                "read_requests": rd, "read_requests_128B": r128}
-art = {"build": h.hexdigest()[:16], "command": "rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum (pass 1) / TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum (pass 2) --kernel-trace -- python bench.py --steps 1 --warmup 1 --cpu-sample 0",
+art = {"build": h.hexdigest()[:16], "command": "rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum (pass 1) / TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum (pass 2) --kernel-trace -- python bench.py --steps 1 --warmup 1 --cpu-sample 0 --config4-profiles 0",
        "note": "sums over all dispatches of both passes of the run (warm-up + 1 step); bench.py divides by launches", "kernels": kern}
 json.dump(art, open(out + "/${TAG}_pmc_hbm_traffic.json", "w"), indent=1)
 for k, v in sorted(kern.items(), key=lambda x: -x[1]["fetch_bytes"])[:12]:
