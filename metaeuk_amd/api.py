@@ -230,15 +230,24 @@ class Profiles(Queries):
     entries as bytes, 25 bytes per column (a trailing NUL per entry is dropped).  Search it against a TargetDB whose params have
     profile_search = 1."""
 
-    def __init__(self, entries, params=None):
+    def __init__(self, entries, params=None, _columns=None):
         self.params = params or default_params()
-        cols = [e[:len(e) - (len(e) % 25)] for e in entries]
-        self.off = np.zeros(len(cols) + 1, dtype=np.uint64)
-        self.off[1:] = np.cumsum([len(c) // 25 for c in cols], dtype=np.uint64)
-        self.columns = np.frombuffer(b"".join(cols), dtype=np.uint8).copy() if cols else np.zeros(0, dtype=np.uint8)
-        self.n = len(cols)
+        self.columns, self.off = _columns if _columns is not None else self.pack(entries)
+        self.n = len(self.off) - 1
         self.h = C.c_void_p()
         _chk(lib().mk_profiles_create(_p(self.columns), _p(self.off), C.c_uint32(self.n), C.byref(self.params), C.byref(self.h)))
+
+    @staticmethod
+    def pack(entries):
+        """(columns uint8 [25 * total], col_offsets uint64 [n + 1]) of a list of profile DB entries: what mk_profiles_create takes"""
+        cols = [e[:len(e) - (len(e) % 25)] for e in entries]
+        off = np.zeros(len(cols) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(c) // 25 for c in cols], dtype=np.uint64)
+        return (np.frombuffer(b"".join(cols), dtype=np.uint8).copy() if cols else np.zeros(0, dtype=np.uint8)), off
+
+    @classmethod
+    def from_columns(cls, columns, off, params=None):
+        return cls(None, params, _columns=(np.ascontiguousarray(columns, dtype=np.uint8), np.ascontiguousarray(off, dtype=np.uint64)))
 
     def derived(self):
         """(query letters u8 [cols], sorted scores + residue numbers i8 [cols, 40], alignment profile i8 [cols, 32], k-mer threshold i16 [cols])"""

@@ -722,14 +722,17 @@ int mk_swap_alignments(const mk_alignment *alns, const uint64_t *offsets, uint32
     }
     // 2. lists per target: counts, offsets, scatter (the order inside a list is settled by the sort: compareHits is a total order here,
     //    its last key -- the query's DB key -- is unique within a list)
-    for (uint64_t k = 0; k < total; k++) if (target[k] != 0xFFFFFFFFu) cnt[(size_t) target[k] + 1]++;
+#pragma omp parallel for schedule(static)
+    for (uint64_t k = 0; k < total; k++) if (target[k] != 0xFFFFFFFFu) __atomic_fetch_add(&cnt[(size_t) target[k] + 1], 1ull, __ATOMIC_RELAXED);
     for (uint32_t t = 0; t < nTargets; t++) cnt[t + 1] += cnt[t];
     mk_swapped *s = new mk_swapped();
     s->off = cnt;
     s->alns.resize(cnt[nTargets]);
     {
         std::vector<uint64_t> fill(cnt.begin(), cnt.end() - 1);
-        for (uint64_t k = 0; k < total; k++) if (target[k] != 0xFFFFFFFFu) s->alns[fill[target[k]]++] = tmp[k];
+#pragma omp parallel for schedule(static)
+        for (uint64_t k = 0; k < total; k++)
+            if (target[k] != 0xFFFFFFFFu) s->alns[__atomic_fetch_add(&fill[target[k]], 1ull, __ATOMIC_RELAXED)] = tmp[k];
     }
 #pragma omp parallel for schedule(dynamic, 1024)
     for (uint32_t t = 0; t < nTargets; t++)

