@@ -76,11 +76,11 @@ __global__ __launch_bounds__(256) void seg_mark_kernel(const uint64_t *sortedKey
     head[i] = (i > 0 && (sortedKeys[i] >> 12) != (sortedKeys[i - 1] >> 12)) ? i : 0u;
 }
 // a wave starts at every (64/G)-th job of a segment
-__global__ __launch_bounds__(256) void wave_flag_kernel(const uint64_t *sortedKeys, const uint32_t *head, uint32_t n, uint8_t *flag) {
+__global__ __launch_bounds__(256) void wave_flag_kernel(const uint64_t *sortedKeys, const uint32_t *head, uint32_t n, uint8_t *flag, bool narrow) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int cfg = (int) (sortedKeys[i] >> 44);
-    const uint32_t dpw = sw_cfg_jobs_per_wave(cfg);                // packed score kernel: 2 per 16-lane group; else 64 / G
+    const uint32_t dpw = sw_cfg_jobs_per_wave(cfg, narrow);        // packed score kernel: 2 per 16-lane group; else 64 / G
     flag[i] = ((i - head[i]) % dpw) == 0 ? 1 : 0;
 }
 // job and wave ranges of every configuration; closes the wave list with n
@@ -460,7 +460,9 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const SwJob *j
     th = tb("align_waves", 30.0 * n, 0);
     hipLaunchKernelGGL(seg_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, kb.Current(), n, dHead);
     ACHK(hipcub::DeviceScan::InclusiveScan(temp, t2, dHead, dHead, hipcub::Max(), (int) n, stream));
-    hipLaunchKernelGGL(wave_flag_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, kb.Current(), dHead, n, dFlag);
+    static const int narrowEnv = getenv("MK_SW_NARROW") ? atoi(getenv("MK_SW_NARROW")) : -1;
+    const bool narrow = narrowEnv >= 0 ? narrowEnv != 0 : V.q_prof != nullptr;      // profile queries meet short targets (ORF fragments)
+    hipLaunchKernelGGL(wave_flag_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, kb.Current(), dHead, n, dFlag, narrow);
     ACHK(hipcub::DeviceSelect::Flagged(temp, t3, iota, dFlag, dWave, dNum, (int) n, stream));
     hipLaunchKernelGGL(shared_bounds_kernel, dim3(1), dim3(64), 0, stream, kb.Current(), n, dWave, dNum, dBounds);
     te(th);
@@ -477,6 +479,7 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const SwJob *j
         L.wave_start = dWave + wlo; L.n_waves = whi - wlo;
         L.work_counter = dWork + c; L.persistent_blocks = persistentBlocks[c]; L.units_per_block = unitsPerBlock;
         L.gap_open = P.gap_open; L.gap_extend = P.gap_extend;
+        L.narrow = narrow;
         if (c == SW_NCFG - 1 && V.max_q_len > (uint32_t) sw_cfg_rows(c)) {
             // queries beyond the largest tile run in row tiles with an HBM border per job; the border is as long as the
             // longest target of the bucket (the first key only bounds its own query)

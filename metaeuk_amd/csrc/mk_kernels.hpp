@@ -40,6 +40,7 @@ struct SwLaunch {
     uint32_t units_per_block;   // a workgroup retires after this many waves of jobs (0: runs until the counter is exhausted)
     uint64_t boundary_job0;     // job index that owns the first boundary_stride entries of `boundary`
     const int32_t *known_score; // position / reverse pass of the small tiles (launch_sw_known): the maximum score of job j is known_score[jobs[j].slot]
+    bool narrow = false;        // score pass: the 16-lane variant of the 384-row tile (the waves were cut with sw_cfg_jobs_per_wave(c, true))
 };
 
 // tile configurations: G lanes per DP x R rows per lane; a job uses the smallest one whose G*R >= q_len
@@ -52,7 +53,13 @@ __host__ __device__ inline int sw_cfg_rows(int c) {
 // forward pass of the pipeline: tiles of at most 768 rows run in packed int16, two targets per lane group (16 lanes up to 256
 // rows: 8 jobs per wave; 32 lanes: 4 jobs per wave); larger tiles in int32 on 64 lanes (1 job per wave)
 __host__ __device__ inline bool sw_cfg_packed(int c) { return sw_cfg_rows(c) <= 768; }
-__host__ __device__ inline uint32_t sw_cfg_jobs_per_wave(int c) { return sw_cfg_rows(c) <= 256 ? 8u : (sw_cfg_rows(c) <= 768 ? 4u : 1u); }
+// narrow: the score pass of the 384-row tile on 16 lanes x 24 rows (8 jobs per wave) instead of 32 lanes x 12 rows -- fewer ramp steps per
+// DP when the targets are short (profile queries against ORF fragments, ~40 columns: 87 -> 65 ms at config-4 scale; the same for the
+// 512-row tile, 32 rows per lane and 133 VGPRs, was slower: 166 -> 225 ms)
+__host__ __device__ inline uint32_t sw_cfg_jobs_per_wave(int c, bool narrow = false) {
+    const int rows = sw_cfg_rows(c);
+    return rows <= 256 ? 8u : (rows <= 768 ? ((narrow && rows == 384) ? 8u : 4u) : 1u);
+}
 __host__ __device__ inline int sw_cfg_of(uint32_t qLen) {
     int c = 0;
     while (c < SW_NCFG - 1 && (uint32_t) sw_cfg_rows(c) < qLen) c++;

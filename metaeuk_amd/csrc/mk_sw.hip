@@ -586,7 +586,9 @@ hipError_t launch_sw_score(const SwLaunch &L, int cfg, hipStream_t stream) {
         case 128: hipLaunchKernelGGL((swp_kernel<8>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
         case 192: hipLaunchKernelGGL((swp_kernel<12>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
         case 256: hipLaunchKernelGGL((swp_kernel<16>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
-        case 384: hipLaunchKernelGGL((swp_kernel<12, 12, 32>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
+        case 384: if (L.narrow) hipLaunchKernelGGL((swp_kernel<24, 24, 16>), dim3((unsigned) grid), dim3(64), lds, stream, L);
+                  else hipLaunchKernelGGL((swp_kernel<12, 12, 32>), dim3((unsigned) grid), dim3(64), lds, stream, L);
+                  break;
         case 512: hipLaunchKernelGGL((swp_kernel<16, 16, 32>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
         case 768: hipLaunchKernelGGL((swp_kernel<24, 24, 32>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;   // (profile queries: 513 .. 768 columns)
         default: return hipErrorInvalidValue;
