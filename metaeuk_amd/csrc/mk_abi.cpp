@@ -470,7 +470,11 @@ int mk_index_write(const char *indexDb, const char *seqData, uint64_t seqDataSiz
     }
     std::vector<uint8_t> res;
     encode_seq_db(c.seqs, res, c.seqOffsets);
-    if (c.seqOffsets[n] >= 3350000000ull) return fail(MK_ERR_UNSUPPORTED, "the database has %llu residues: the reference indexes with k = 7 from 3.35e9 on, only k = 6 is implemented", (unsigned long long) c.seqOffsets[n]);
+    if (P->kmer_size == 7 || (P->kmer_size == 0 && c.seqOffsets[n] >= 3350000000ull))
+        return fail(MK_ERR_UNSUPPORTED, "index DBs with k = 7 (-k 7, or %llu residues: the reference indexes with k = 7 from 3.35e9 on) are not implemented: search the sequence DB directly",
+                    (unsigned long long) c.seqOffsets[n]);
+    if (P->kmer_size != 0 && P->kmer_size != 6) return fail(MK_ERR_UNSUPPORTED, "-k %d: index DBs are written with k = 6", P->kmer_size);
+    if (P->profile_search) return fail(MK_ERR_UNSUPPORTED, "index DBs for profile queries are not implemented (they need their own masking background and an unfiltered index)");
     mk::SubMat km;
     mk::build_submat(km, mk::MAT_VTML80, 8.0f, -0.2f);
     c.meta.kmerThr = mk::kmer_threshold(P->sensitivity, P->kmer_score);
