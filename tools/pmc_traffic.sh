@@ -21,8 +21,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = colle
 def name_of(k):
     m = re.search(r"stream_kernel<(\d+),", k)
     if m: return "prefilter_query_cap" + m.group(1)
-    if "probe_kernel<true>" in k: return "kmer_probe_gather"
-    if "probe_kernel<false>" in k: return "kmer_probe_count"
+    if "probe_kernel<true" in k: return "kmer_probe_gather"
+    if "probe_kernel<false" in k: return "kmer_probe_count"
     if "kmer_count_kernel" in k: return "kmer_count"
     if "diag_score_kernel" in k: return "diag_score"
     m = re.search(r"swp_kernel<(\d+), (\d+), (\d+)>", k)
