@@ -405,7 +405,7 @@ static int pindex_cmp(const void *a, const void *b) { unsigned int x = ((const p
 
 static int cmd_profilesearch(int argc, char **argv) {
     const char *outdir = argv[5];
-    float sens = 4.0f; double evalThr = 100.0; int lb = 32, lw = 16, tl = 4;
+    float sens = 4.0f; double evalThr = 100.0, evalAbs = -1.0; int lb = 32, lw = 16, tl = 4;
     const char *keysPath = NULL;   /* line i = DB key of fragment i; fragments.txt is in the order of the data offsets of the fragment DB
                                       (the prefilter's target numbering, DBReader LINEAR_ACCCESS: Prefiltering.cpp:163) */
     long l2 = sysconf(_SC_LEVEL2_CACHE_SIZE);
@@ -418,6 +418,7 @@ static int cmd_profilesearch(int argc, char **argv) {
         else if (!strcmp(argv[a], "--tantan-lanes")) tl = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--l2")) l2 = atol(argv[++a]);
         else if (!strcmp(argv[a], "--keys")) keysPath = argv[++a];
+        else if (!strcmp(argv[a], "--eval-abs")) evalAbs = atof(argv[++a]);   /* the alignment threshold as given (a sample of a larger profile set) */
     }
     mkdir(outdir, 0755);
     /* profile DB */
@@ -471,6 +472,7 @@ static int cmd_profilesearch(int argc, char **argv) {
         char txt[64];
         snprintf(txt, sizeof(txt), "%g", evalThr);
         evalThr = strtod(txt, NULL);
+        if (evalAbs >= 0) evalThr = evalAbs;
     }
     mko_evaluer ev, evSwap;
     mko_evaluer_init(&ev, toff[T.n]);                                         /* Alignment.cpp:262: the target DB = the fragments */

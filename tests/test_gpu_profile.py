@@ -137,8 +137,17 @@ def test_profile_search_synthetic_vs_oracle(gpu_api, tmp_path):
     for L in [12, 31, 64, 100, 129, 200, 260, 390, 520, 800, 1100, 1500] + [rng.randint(20, 400) for _ in range(28)]:
         e, c = _synthetic_profile(rng, L, x_rate=0.01 if L > 100 else 0.0)
         entries.append(e); cons.append(c)
+    # edge profiles: no column at all, fewer columns than the seed spans (no k-mer start), exactly one start, every query letter X
+    for L in (0, 1, 9, 10):
+        e, c = _synthetic_profile(rng, L)
+        entries.append(e); cons.append(c)
+    e, c = _synthetic_profile(rng, 60, x_rate=1.0)
+    entries.append(e); cons.append(c)
     frags = []
     for c in cons:
+        if len(c) < 20:
+            frags.append(c + _rand(rng, 30))
+            continue
         for _ in range(12):
             a = rng.randrange(0, max(1, len(c) - 15)); b = min(len(c), a + rng.randint(15, 160))
             s = "".join(rng.choice(AA) if rng.random() < 0.15 else ch for ch in c[a:b])

@@ -66,3 +66,45 @@ def test_headline_scale_parity(gpu_api, tmp_path):
     assert k_big + k_glob > k_small, "most similar k-mers should belong to queries with more than 8 K index hits (%g + %g vs %g)" % (k_big, k_glob, k_small)
     assert k_glob > 0, "the global path should see the largest queries"
     assert int(aoff[-1]) > 100000 and int(hoff[-1]) > 1000000
+
+
+def test_profile_path_scale_parity(gpu_api, tmp_path):
+    """BASELINE config 4 at a tenth of its size: 5 000 synthetic profiles as queries against the ~400 000 fragments of 2 000 contigs
+    (what the small fixtures cannot reach: pieces of hundreds of millions of listed k-mers, ~18 000 index hits per profile, every
+    Smith-Waterman tile up to 768 rows incl. the 16-lane variant, thousands of accepted alignments per profile in the rank-count order),
+    against the C oracle's restatement of the reference path on a sample of the profiles."""
+    import subprocess
+    from metaeuk_amd import synth
+    api = gpu_api
+    n_prof, sample = 5000, 160
+    proteins, founders = synth.make_targets(n_prof, seed=11)
+    entries = synth.make_profiles(proteins, seed=11)
+    frags = [synth.codes_to_str(c) for c in synth.make_queries(2000, founders, seed=11)]
+    assert len(frags) > 300000
+    p = api.default_params()
+    p.sensitivity = 4.0
+    p.profile_search = 1
+    p.max_seqs = max(300, len(frags))
+    p.evalue_thr = float("%g" % (100.0 * (np.float32(len(frags)) / np.float32(n_prof))))
+    p.host_l2_bytes = 2097152
+    db = api.TargetDB(frags, p)
+    q = api.Profiles(entries, p)
+    api.kernel_stats(reset=True)
+    (hits, hoff), (alns, aoff) = api.search(db, q, p)
+    st = api.kernel_stats()
+    assert int(hoff[-1]) > 500000 and int(aoff[-1]) > 200000
+    assert st["profile_kmer_fill"]["cells"] > 2e8 and "sw_fwd_rows768" in st and "sw_fwd_rows384" in st
+    # the oracle on the first `sample` profiles: same fragments, same thresholds (-s 4, the e-value threshold of the whole search)
+    (tmp_path / "p.bin").write_bytes(b"".join(entries[:sample]))
+    off, lines = 0, []
+    for k, e in enumerate(entries[:sample]):
+        lines.append("%d\t%d\t%d\n" % (k, off, len(e))); off += len(e)
+    (tmp_path / "p.index").write_text("".join(lines))
+    (tmp_path / "f.txt").write_text("\n".join(frags) + "\n")
+    subprocess.check_call([oracle.CLI, "profilesearch", str(tmp_path / "p.bin"), str(tmp_path / "p.index"), str(tmp_path / "f.txt"), str(tmp_path / "out"),
+                           "-s", "4", "--eval-abs", repr(float(p.evalue_thr)), "--l2", "2097152"], stdout=subprocess.DEVNULL)
+    pref = "".join(">%d\n%s" % (i, api.format_hits_bulk(hits, int(hoff[i]), int(hoff[i + 1])).decode()) for i in range(sample))
+    aln = "".join(">%d\n%s" % (i, api.format_alignments_bulk(alns, int(aoff[i]), int(aoff[i + 1])).decode()) for i in range(sample))
+    assert pref == open(tmp_path / "out" / "pref.txt").read()
+    assert aln == open(tmp_path / "out" / "aln.txt").read()
+    assert max(int(aoff[i + 1] - aoff[i]) for i in range(sample)) > 200
