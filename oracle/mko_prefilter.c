@@ -192,14 +192,111 @@ static int prefilter_core(const mko_prefilter_ctx *ctx, const uint8_t *q, int L,
     uint64_t kmerListLen = 0;
     int rc = 0;
     const int *spUnused; const int span = mko_spaced_pattern(ix->k, &spUnused);
-    for (int i = 0; i + span <= L; i++) {
+    /* the diagonal matcher's working state (CacheFriendlyOperations): bins, duplicateBitArray, tmpElementBuffer */
+    uint8_t *dup = (uint8_t *) calloc((dbSize >> shift) + 2, 1);
+    size_t *bs = (size_t *) malloc(((size_t) B + 1) * sizeof(size_t));
+    size_t wcap = 1 << 16, tcap = 1 << 16;
+    cres_t *binned = (cres_t *) malloc(wcap * sizeof(cres_t)), *tmp = (cres_t *) malloc(tcap * sizeof(cres_t));
+    /* foundDiagonals: [0, overflowHitCount) = what earlier overflow segments left, behind it the current segment's diagonals */
+    size_t fcap = 1 << 16, overflowHitCount = 0, hitCount = 0;
+    cres_t *found = (cres_t *) malloc(fcap * sizeof(cres_t));
+    uint64_t dbMatchesAll = 0;
+    int stopped = 0;
+#define GROW(ptr, capv, need) do { if ((need) > (capv)) { while ((need) > (capv)) (capv) *= 2; (ptr) = (cres_t *) realloc((ptr), (capv) * sizeof(cres_t)); } } while (0)
+    /* findDuplicates of the gathered segment hits[0..n) into found[overflowHitCount..] (CacheFriendlyOperations.cpp:38-49,185-274, computeTotalScore == false) */
+#define FIND_DUPLICATES(result) do { \
+        GROW(binned, wcap, n + 1); GROW(tmp, tcap, n + 1); GROW(found, fcap, overflowHitCount + n + 1); \
+        bin_partition(hits, n, B, binned, bs); \
+        cres_t *cand_ = found + overflowHitCount; \
+        const size_t outSize_ = foundDiagonalsSize - overflowHitCount; \
+        size_t nc_ = 0; \
+        for (int bin = 0; bin < B; bin++) { \
+            const cres_t *bp = binned + bs[bin]; \
+            const size_t cur = bs[bin + 1] - bs[bin]; \
+            size_t ec = 0; \
+            for (size_t k = 0; k < cur; k++) { \
+                const uint32_t h = bp[k].id >> shift; \
+                const uint8_t currDiagonal = (uint8_t) bp[k].diagonal; \
+                const uint8_t prevDiagonal = dup[h]; \
+                tmp[ec] = bp[k]; \
+                ec += (currDiagonal == prevDiagonal) ? 1 : 0; \
+                dup[h] = currDiagonal; \
+            } \
+            if (nc_ + (ec < cur / 2 ? ec : cur / 2) >= outSize_) break;   /* :214-216 */ \
+            for (size_t k = ec; k-- > 0;) dup[tmp[k].id >> shift] = (uint8_t) ((uint8_t) tmp[k].diagonal + 1); \
+            for (size_t k = 0; k < ec; k++) { \
+                const uint32_t h = tmp[k].id >> shift; \
+                cand_[nc_].id = tmp[k].id; \
+                cand_[nc_].count = 0; \
+                cand_[nc_].diagonal = tmp[k].diagonal; \
+                nc_ += (dup[h] != (uint8_t) tmp[k].diagonal) ? 1 : 0; \
+                dup[h] = (uint8_t) tmp[k].diagonal; \
+            } \
+            for (size_t k = 0; k < cur; k++) dup[bp[k].id >> shift] = 0; \
+        } \
+        (result) = nc_; \
+    } while (0)
+    for (int i = 0; i + span <= L && !stopped; i++) {
         const size_t nk = gen(user, i, &klist, &kcap, &kmerListLen);
         if (nk == (size_t) -1) continue;
         for (size_t k = 0; k < nk; k++) {
             uint64_t o0, o1;
             mko_index_list(ix, klist[k], &o0, &o1);
             const size_t sz = (size_t) (o1 - o0);
-            if (n + sz >= maxDbMatches) { rc = -1; goto done; }   /* overflow path (:281-316) not restated */
+            if (n + sz >= maxDbMatches) {
+                /* the overflow path (:281-316): the hits gathered so far are one segment with a double-diagonal rule of its own; from the
+                 * second overflow on the kept diagonals are merged (the later one of equal neighbours stays, order reversed), scored, and
+                 * only the best one per target survives */
+                size_t hc;
+                FIND_DUPLICATES(hc);
+                if (overflowHitCount != 0) {
+                    size_t N = hc + overflowHitCount;
+                    /* mergeDiagonalKeepScoredHitsDuplicates (CacheFriendlyOperations.cpp:118-150) */
+                    GROW(binned, wcap, N + 1);
+                    bin_partition(found, N, B, binned, bs);
+                    size_t m = 0;
+                    for (int bin = 0; bin < B; bin++) {
+                        const cres_t *bp = binned + bs[bin];
+                        const size_t cur = bs[bin + 1] - bs[bin];
+                        for (size_t x = 0; x < cur; x++) dup[bp[x].id >> shift] = (uint8_t) ((uint8_t) bp[x].diagonal + 1);
+                        for (size_t x = cur; x-- > 0;) {
+                            const uint32_t h = bp[x].id >> shift;
+                            found[m] = bp[x];
+                            m += (found[m].count != 0 || dup[h] != (uint8_t) bp[x].diagonal) ? 1 : 0;
+                            dup[h] = (uint8_t) bp[x].diagonal;
+                        }
+                    }
+                    /* ungappedAlignment->align (:295) */
+                    for (size_t x = 0; x < m; x++) {
+                        const uint32_t id = found[x].id;
+                        int sc = mko_ungapped_score(profile, L, ix->masked + ix->seq_off[id], (int) (ix->seq_off[id + 1] - ix->seq_off[id]), found[x].diagonal);
+                        found[x].count = (uint8_t) (sc < 255 ? sc : 255);
+                    }
+                    /* keepMaxScoreElementOnly (:297; CacheFriendlyOperations.cpp:350-380) */
+                    GROW(binned, wcap, m + 1);
+                    bin_partition(found, m, B, binned, bs);
+                    memset(dup, 0, (dbSize >> shift) + 2);
+                    size_t r = 0;
+                    for (int bin = 0; bin < B; bin++) {
+                        const cres_t *bp = binned + bs[bin];
+                        const size_t cur = bs[bin + 1] - bs[bin];
+                        for (size_t x = 0; x < cur; x++) { const uint32_t h = bp[x].id >> shift; if (bp[x].count > dup[h]) dup[h] = bp[x].count; }
+                        for (size_t x = 0; x < cur; x++) {
+                            const uint32_t h = bp[x].id >> shift;
+                            found[r] = bp[x];
+                            int fnd = (dup[h] == bp[x].count) ? 1 : 0;
+                            r += (size_t) fnd;
+                            dup[h] = (uint8_t) (dup[h] * (1 - fnd));
+                        }
+                    }
+                    overflowHitCount = r;
+                } else {
+                    overflowHitCount = hc;
+                }
+                dbMatchesAll += n;
+                n = 0;
+                if (n + sz >= maxDbMatches) { stopped = 1; break; }      /* :313-315: one list alone fills the buffer -> everything is dropped below */
+            }
             if (n + sz > cap) { while (n + sz > cap) cap *= 2; hits = (cres_t *) realloc(hits, cap * sizeof(cres_t)); }
             for (size_t e = 0; e < sz; e++) {
                 hits[n].id = ix->seq_id[o0 + e];
@@ -209,42 +306,37 @@ static int prefilter_core(const mko_prefilter_ctx *ctx, const uint8_t *q, int L,
             }
         }
     }
-    if (st) { st->kmer_list_len = kmerListLen; st->db_matches = n; st->diagonals = 0; }
-    {
-        /* ---- findDuplicates (CacheFriendlyOperations.cpp:38-49,185-274), computeTotalScore == false ---- */
-        cres_t *binned = (cres_t *) malloc((n + 1) * sizeof(cres_t));
-        size_t *bs = (size_t *) malloc(((size_t) B + 1) * sizeof(size_t));
-        bin_partition(hits, n, B, binned, bs);
-        uint8_t *dup = (uint8_t *) calloc((dbSize >> shift) + 2, 1);
-        cres_t *cand = (cres_t *) malloc((n + 1) * sizeof(cres_t));
-        cres_t *tmp = (cres_t *) malloc((n + 1) * sizeof(cres_t));
-        size_t nc = 0;
-        for (int bin = 0; bin < B; bin++) {
-            const cres_t *bp = binned + bs[bin];
-            const size_t cur = bs[bin + 1] - bs[bin];
-            size_t ec = 0;
-            for (size_t k = 0; k < cur; k++) {
-                const uint32_t h = bp[k].id >> shift;
-                const uint8_t currDiagonal = (uint8_t) bp[k].diagonal;
-                const uint8_t prevDiagonal = dup[h];
-                tmp[ec] = bp[k];
-                ec += (currDiagonal == prevDiagonal) ? 1 : 0;
-                dup[h] = currDiagonal;
+    /* :318-334: the last segment; nothing at all when it is empty */
+    if (n > 0) {
+        FIND_DUPLICATES(hitCount);
+        if (overflowHitCount != 0) {
+            /* mergeDiagonalDuplicates (CacheFriendlyOperations.cpp:80-115): of equal neighbours the earlier one stays */
+            const size_t N = overflowHitCount + hitCount;
+            GROW(binned, wcap, N + 1);
+            bin_partition(found, N, B, binned, bs);
+            size_t m = 0;
+            for (int bin = 0; bin < B; bin++) {
+                const cres_t *bp = binned + bs[bin];
+                const size_t cur = bs[bin + 1] - bs[bin];
+                for (size_t x = cur; x-- > 0;) dup[bp[x].id >> shift] = (uint8_t) ((uint8_t) bp[x].diagonal + 1);
+                for (size_t x = 0; x < cur; x++) {
+                    const uint32_t h = bp[x].id >> shift;
+                    found[m] = bp[x];
+                    m += (dup[h] != (uint8_t) bp[x].diagonal) ? 1 : 0;
+                    dup[h] = (uint8_t) bp[x].diagonal;
+                }
             }
-            if (nc + (ec < cur / 2 ? ec : cur / 2) >= foundDiagonalsSize) break;   /* :214-216 */
-            for (size_t k = ec; k-- > 0;) dup[tmp[k].id >> shift] = (uint8_t) ((uint8_t) tmp[k].diagonal + 1);
-            for (size_t k = 0; k < ec; k++) {
-                const uint32_t h = tmp[k].id >> shift;
-                cand[nc].id = tmp[k].id;
-                cand[nc].count = 0;
-                cand[nc].diagonal = tmp[k].diagonal;
-                nc += (dup[h] != (uint8_t) tmp[k].diagonal) ? 1 : 0;
-                dup[h] = (uint8_t) tmp[k].diagonal;
-            }
-            for (size_t k = 0; k < cur; k++) dup[bp[k].id >> shift] = 0;
+            hitCount = m;
         }
+    }
+    dbMatchesAll += n;
+    if (st) { st->kmer_list_len = kmerListLen; st->db_matches = dbMatchesAll; st->diagonals = 0; }
+    {
+        cres_t *cand = found;
+        size_t nc = hitCount;
+        GROW(binned, wcap, nc + 1);
         if (st) st->diagonals = nc;
-        if (nc >= foundDiagonalsSize / 2) { rc = -1; free(binned); free(bs); free(dup); free(cand); free(tmp); goto done; }
+        if (nc >= foundDiagonalsSize / 2) { rc = -1; free(binned); free(bs); free(dup); free(found); free(tmp); goto done; }
 
         /* ---- UngappedAlignment::align / computeScores (:331-362): count = min(255, score) ---- */
         for (size_t k = 0; k < nc; k++) {
@@ -254,6 +346,7 @@ static int prefilter_core(const mko_prefilter_ctx *ctx, const uint8_t *q, int L,
         }
         /* ---- keepMaxScoreElementOnly (CacheFriendlyOperations.cpp:70-78,350-380) ---- */
         bin_partition(cand, nc, B, binned, bs);
+        memset(dup, 0, (dbSize >> shift) + 2);                    /* keepMaxElement starts from a cleared array (:353) */
         size_t nr = 0;
         for (int bin = 0; bin < B; bin++) {
             const cres_t *bp = binned + bs[bin];
@@ -338,7 +431,7 @@ static int prefilter_core(const mko_prefilter_ctx *ctx, const uint8_t *q, int L,
         }
         if (nout > 1) qsort(out, (size_t) nout, sizeof(mko_hit), hit_cmp);   /* :203-209 */
         rc = nout;
-        free(binned); free(bs); free(dup); free(cand); free(tmp);
+        free(binned); free(bs); free(dup); free(found); free(tmp);
     }
 done:
     free(hits); free(klist);

@@ -198,6 +198,26 @@ def test_oracle_matches_live_reference_on_long_sequences(tmp_path):
     assert len(rpref[3].splitlines()) >= 2, "the long query should have hits"
 
 
+@pytest.mark.skipif(not os.path.exists(oracle.REF) or not os.path.isdir("/root/reference"), reason="reference harness not built here")
+def test_oracle_matches_live_reference_on_the_database_hits_overflow_path(tmp_path):
+    """QueryMatcher::match's overflow path (QueryMatcher.cpp:281-334): a query that gathers >= 2 * max(1e6, #targets) index entries is cut
+    into segments with a double-diagonal rule each; from the second overflow on the kept diagonals are merged (later one of equal
+    neighbours, order reversed), scored and reduced to the best per target.  70 000 near-copies of one protein: three of the four queries
+    overflow 4 ... 13 times.  The device path still refuses such a query; this pins the restatement it will be held to."""
+    import random
+    oracle.build()
+    rng = random.Random(3)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    base = "".join(rng.choice(aa) for _ in range(400))
+    mut = lambda s, r: "".join(rng.choice(aa) if rng.random() < r else c for c in s)
+    targets = [mut(base, 0.02) for _ in range(70000)]
+    queries = [base, mut(base, 0.05), base[:150], "".join(rng.choice(aa) for _ in range(300))]
+    rpref, raln = oracle.run_ref_pipeline(targets, queries, str(tmp_path), extra=["--threads", "8"])
+    opref, oaln = oracle.run_pipeline(targets, queries, str(tmp_path))      # (both take BINSIZE from this host's L2)
+    assert opref == rpref and oaln == raln
+    assert sum(len(b.splitlines()) for b in opref) >= 900
+
+
 def test_matrix_tables_reproduce_reference_matrices(tmp_path):
     """the .out text regenerated from the repository's matrix table parses back to identical numbers"""
     d = oracle.write_matrix_files(str(tmp_path / "mat"))
