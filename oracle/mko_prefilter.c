@@ -173,6 +173,153 @@ int mko_prefilter_profile(const mko_prefilter_ctx *ctx, const mko_profile *p, mk
     return rc;
 }
 
+/* ---- A model of the DEVICE algorithm for the overflow path (MKO_OVERFLOW_MODEL=1): what the GPU kernels will compute, written
+ * the way they will compute it, so that the plan is checked against the literal restatement above before any kernel exists.
+ *   1. all hits of the query in arrival order (no buffer), with the arrival index of every k-mer list's first hit;
+ *   2. segment boundaries from the list sizes (the buffer arithmetic of :281-316), `stopped` when one list alone fills the buffer;
+ *   3. hits sorted by target (stable); the double-diagonal rule per (target, segment) run -- kept: low diagonal byte equals the previous
+ *      hit's of the run (0 for the first); emitted: kept and the nearest earlier kept hit of the run has another byte;
+ *   4. per target the merges of the overflow events replayed on its emitted candidates (scores from the exact ungapped score). */
+typedef struct { uint32_t id; uint16_t diagonal; uint32_t arrival; } mhit_t;
+typedef struct { uint64_t k; size_t i; } kp2_t;
+static int kp2_cmp(const void *pa, const void *pb) { const kp2_t *a = (const kp2_t *) pa, *b = (const kp2_t *) pb; return a->k < b->k ? -1 : a->k > b->k; }
+static int mhit_cmp(const void *a, const void *b) {
+    const mhit_t *x = (const mhit_t *) a, *y = (const mhit_t *) b;
+    if (x->id != y->id) return x->id < y->id ? -1 : 1;
+    if (x->arrival != y->arrival) return x->arrival < y->arrival ? -1 : 1;
+    return 0;
+}
+static size_t overflow_device_model(const mko_index *ix, const int8_t *profile, int L, const mhit_t *hitsIn, size_t nAll,
+                                    const uint32_t *listStart, size_t nLists, size_t maxDbMatches, cres_t **foundOut) {
+    /* 2. segments */
+    size_t segCap = nAll / (maxDbMatches / 2 + 1) + 8, nSeg = 1;
+    uint32_t *segStart = (uint32_t *) malloc(segCap * sizeof(uint32_t));
+    segStart[0] = 0;
+    size_t n = 0, stopAt = nAll;
+    int stopped = 0;
+    for (size_t l = 0; l < nLists; l++) {
+        const size_t sz = (l + 1 < nLists ? listStart[l + 1] : nAll) - listStart[l];
+        if (n + sz >= maxDbMatches) {
+            segStart[nSeg++] = listStart[l];
+            n = 0;
+            if (sz >= maxDbMatches) { stopped = 1; stopAt = listStart[l]; break; }
+        }
+        n += sz;
+    }
+    const size_t events = nSeg - 1;                      /* overflow events; segment `events` is the last one */
+    cres_t *found = (cres_t *) malloc((nAll + 1) * sizeof(cres_t));
+    size_t nf = 0;
+    if (!stopped) {
+        /* 3. sort by (target, arrival), rule per (target, segment) */
+        mhit_t *h = (mhit_t *) malloc((stopAt + 1) * sizeof(mhit_t));
+        memcpy(h, hitsIn, stopAt * sizeof(mhit_t));
+        qsort(h, stopAt, sizeof(mhit_t), mhit_cmp);
+        uint8_t *segOf = (uint8_t *) malloc(stopAt + 1);   /* (fewer than 256 segments in the cases modelled here) */
+        uint8_t *emit = (uint8_t *) calloc(stopAt + 1, 1);
+        for (size_t t = 0; t < stopAt; t++) { size_t s = 0; while (s + 1 < nSeg && segStart[s + 1] <= h[t].arrival) s++; segOf[t] = (uint8_t) s; }
+        for (size_t t = 0; t < stopAt; t++) {
+            const int samePrev = t > 0 && h[t - 1].id == h[t].id && segOf[t - 1] == segOf[t];
+            const uint8_t lo = (uint8_t) h[t].diagonal, prevLo = samePrev ? (uint8_t) h[t - 1].diagonal : 0;
+            if (lo != prevLo) continue;
+            int e = 1;
+            if (samePrev) {
+                size_t u = t - 1;
+                for (;;) {
+                    const uint8_t ulo = (uint8_t) h[u].diagonal;
+                    const int uSame = u > 0 && h[u - 1].id == h[u].id && segOf[u - 1] == segOf[u];
+                    const uint8_t uprev = uSame ? (uint8_t) h[u - 1].diagonal : 0;
+                    if (ulo == uprev) { e = ulo != lo; break; }
+                    if (!uSame) break;
+                    u--;
+                }
+            }
+            emit[t] = (uint8_t) e;
+        }
+        /* 4. per target: replay.  Every element remembers the segment and arrival number it came from: the reference's array order -- which
+         * decides ties at the --max-seqs cut -- follows from them.  An overflow event e >= 1 reverses the whole array: after it the order is
+         * [C_e descending] ++ reverse(order before), so with m = events - 1:  order_m = [C_m desc] ++ reverse(order_(m-1)),  order_0 = [C_0 asc];
+         * the last segment's candidates follow in arrival order. */
+        typedef struct { cres_t c; uint32_t seg, arrival; } mel_t;
+        mel_t *A = (mel_t *) malloc((stopAt + 1) * sizeof(mel_t)), *F = (mel_t *) malloc((stopAt + 1) * sizeof(mel_t));
+        mel_t *surv = (mel_t *) malloc((stopAt + 1) * sizeof(mel_t));
+        size_t ns = 0;
+        for (size_t r0 = 0; r0 < stopAt; ) {
+            size_t r1 = r0;
+            while (r1 < stopAt && h[r1].id == h[r0].id) r1++;
+            const uint32_t id = h[r0].id;
+            size_t nF = 0;
+            size_t t = r0;
+            for (size_t e = 0; e <= events; e++) {
+                size_t nA = 0;
+                for (size_t x = 0; x < nF; x++) A[nA++] = F[x];
+                for (; t < r1 && segOf[t] == e; t++)
+                    if (emit[t]) { A[nA].c.id = id; A[nA].c.diagonal = h[t].diagonal; A[nA].c.count = 0; A[nA].seg = (uint32_t) e; A[nA].arrival = h[t].arrival; nA++; }
+                if (e == events) {
+                    nF = 0;
+                    if (events == 0) { for (size_t x = 0; x < nA; x++) F[nF++] = A[x]; }
+                    else if (nA > 0) {       /* mergeDiagonalDuplicates */
+                        uint8_t d = (uint8_t) ((uint8_t) A[0].c.diagonal + 1);
+                        for (size_t x = 0; x < nA; x++) { if (d != (uint8_t) A[x].c.diagonal) F[nF++] = A[x]; d = (uint8_t) A[x].c.diagonal; }
+                    }
+                } else if (e == 0) {
+                    nF = 0;
+                    for (size_t x = 0; x < nA; x++) F[nF++] = A[x];
+                } else if (nA > 0) {         /* keep-scored merge (backwards, output reversed), score, per-target maximum */
+                    uint8_t d = (uint8_t) ((uint8_t) A[nA - 1].c.diagonal + 1);
+                    nF = 0;
+                    for (size_t x = nA; x-- > 0;) { if (A[x].c.count != 0 || d != (uint8_t) A[x].c.diagonal) F[nF++] = A[x]; d = (uint8_t) A[x].c.diagonal; }
+                    uint8_t mx = 0;
+                    for (size_t x = 0; x < nF; x++) {
+                        int sc = mko_ungapped_score(profile, L, ix->masked + ix->seq_off[id], (int) (ix->seq_off[id + 1] - ix->seq_off[id]), F[x].c.diagonal);
+                        F[x].c.count = (uint8_t) (sc < 255 ? sc : 255);
+                        if (F[x].c.count > mx) mx = F[x].c.count;
+                    }
+                    size_t w = 0;
+                    for (size_t x = 0; x < nF; x++) { const int fnd = mx == F[x].c.count; if (fnd) { F[w++] = F[x]; mx = 0; } }
+                    nF = w;
+                } else nF = 0;
+            }
+            for (size_t x = 0; x < nF; x++) surv[ns++] = F[x];
+            r0 = r1;
+        }
+        /* the array order: rank and direction of every segment */
+        {
+            int32_t *rank = (int32_t *) malloc((events + 2) * sizeof(int32_t));
+            uint8_t *desc = (uint8_t *) calloc(events + 2, 1);
+            /* order_e as a list of (segment, descending) */
+            uint32_t *os = (uint32_t *) malloc((events + 2) * sizeof(uint32_t)), *ot = (uint32_t *) malloc((events + 2) * sizeof(uint32_t));
+            uint8_t *od = (uint8_t *) malloc(events + 2), *odt = (uint8_t *) malloc(events + 2);
+            size_t no = 1;
+            os[0] = 0; od[0] = 0;
+            for (size_t e = 1; e + 1 <= events; e++) {
+                ot[0] = (uint32_t) e; odt[0] = 1;
+                for (size_t x = 0; x < no; x++) { ot[1 + x] = os[no - 1 - x]; odt[1 + x] = (uint8_t) !od[no - 1 - x]; }
+                no++;
+                memcpy(os, ot, no * sizeof(uint32_t)); memcpy(od, odt, no);
+            }
+            if (events > 0) { os[no] = (uint32_t) events; od[no] = 0; no++; }
+            for (size_t x = 0; x < no; x++) { rank[os[x]] = (int32_t) x; desc[os[x]] = od[x]; }
+            /* counting sort of the survivors by (rank, +-arrival): simple insertion into per-rank buckets via qsort on a key */
+            uint64_t *key = (uint64_t *) malloc((ns + 1) * sizeof(uint64_t));
+            for (size_t x = 0; x < ns; x++) {
+                const uint32_t a = surv[x].arrival;
+                key[x] = ((uint64_t) rank[surv[x].seg] << 40) | ((uint64_t) (desc[surv[x].seg] ? 0xFFFFFFFFu - a : a) << 8);
+            }
+            /* (keys are unique: arrival numbers are) */
+            kp2_t *kp = (kp2_t *) malloc((ns + 1) * sizeof(kp2_t));
+            for (size_t x = 0; x < ns; x++) { kp[x].k = key[x]; kp[x].i = x; }
+            qsort(kp, ns, sizeof(kp2_t), kp2_cmp);
+            for (size_t x = 0; x < ns; x++) found[nf++] = surv[kp[x].i].c;
+            free(rank); free(desc); free(os); free(ot); free(od); free(odt); free(key); free(kp);
+        }
+        free(surv);
+        free(h); free(segOf); free(emit); free(A); free(F);
+    }
+    free(segStart);
+    *foundOut = found;
+    return nf;
+}
+
 static int prefilter_core(const mko_prefilter_ctx *ctx, const uint8_t *q, int L, const int8_t *profile, kmer_gen_fn gen, void *user,
                           mko_hit *out, mko_prefilter_stats *st) {
     const mko_index *ix = ctx->index;
@@ -236,6 +383,39 @@ static int prefilter_core(const mko_prefilter_ctx *ctx, const uint8_t *q, int L,
         } \
         (result) = nc_; \
     } while (0)
+    if (getenv("MKO_OVERFLOW_MODEL")) {
+        /* the device model instead of the literal buffer logic below (tests compare the two) */
+        size_t mcap = 1 << 20, nAll = 0, lcap = 1 << 16, nLists = 0;
+        mhit_t *mh = (mhit_t *) malloc(mcap * sizeof(mhit_t));
+        uint32_t *ls = (uint32_t *) malloc(lcap * sizeof(uint32_t));
+        for (int i = 0; i + span <= L; i++) {
+            const size_t nk = gen(user, i, &klist, &kcap, &kmerListLen);
+            if (nk == (size_t) -1) continue;
+            for (size_t k = 0; k < nk; k++) {
+                uint64_t o0, o1;
+                mko_index_list(ix, klist[k], &o0, &o1);
+                const size_t sz = (size_t) (o1 - o0);
+                if (sz == 0) continue;
+                if (nLists == lcap) { lcap *= 2; ls = (uint32_t *) realloc(ls, lcap * sizeof(uint32_t)); }
+                ls[nLists++] = (uint32_t) nAll;
+                if (nAll + sz > mcap) { while (nAll + sz > mcap) mcap *= 2; mh = (mhit_t *) realloc(mh, mcap * sizeof(mhit_t)); }
+                for (size_t e = 0; e < sz; e++) {
+                    mh[nAll].id = ix->seq_id[o0 + e];
+                    mh[nAll].diagonal = (uint16_t) (i - (int) ix->pos[o0 + e]);
+                    mh[nAll].arrival = (uint32_t) nAll;
+                    nAll++;
+                }
+            }
+        }
+        cres_t *mf = NULL;
+        hitCount = overflow_device_model(ix, profile, L, mh, nAll, ls, nLists, maxDbMatches, &mf);
+        GROW(found, fcap, hitCount + 1);
+        memcpy(found, mf, hitCount * sizeof(cres_t));
+        free(mf); free(mh); free(ls);
+        dbMatchesAll = nAll;
+        n = 0;
+        goto tail;
+    }
     for (int i = 0; i + span <= L && !stopped; i++) {
         const size_t nk = gen(user, i, &klist, &kcap, &kmerListLen);
         if (nk == (size_t) -1) continue;
@@ -330,6 +510,7 @@ static int prefilter_core(const mko_prefilter_ctx *ctx, const uint8_t *q, int L,
         }
     }
     dbMatchesAll += n;
+tail:
     if (st) { st->kmer_list_len = kmerListLen; st->db_matches = dbMatchesAll; st->diagonals = 0; }
     {
         cres_t *cand = found;

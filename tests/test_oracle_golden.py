@@ -216,6 +216,14 @@ def test_oracle_matches_live_reference_on_the_database_hits_overflow_path(tmp_pa
     opref, oaln = oracle.run_pipeline(targets, queries, str(tmp_path))      # (both take BINSIZE from this host's L2)
     assert opref == rpref and oaln == raln
     assert sum(len(b.splitlines()) for b in opref) >= 900
+    # the model of the device algorithm for this path (segments from list sizes, rule per (target, segment), merges replayed per target,
+    # the reference's array order rebuilt from segment and arrival number): the same output
+    os.environ["MKO_OVERFLOW_MODEL"] = "1"
+    try:
+        mpref, maln = oracle.run_pipeline(targets, queries, str(tmp_path / "model"))
+    finally:
+        del os.environ["MKO_OVERFLOW_MODEL"]
+    assert mpref == rpref and maln == raln
 
 
 def test_matrix_tables_reproduce_reference_matrices(tmp_path):
