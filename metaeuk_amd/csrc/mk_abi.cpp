@@ -1006,8 +1006,10 @@ int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     const int binCount = mk::bin_count_for(db->n, P->host_l2_bytes);
     {
         HostTimer ht("host_prefilter_total");
+        mk::PrefilterHooks hooks;
+        hooks.t_masked_host = db->maskedHost.data();
         rc = mk::run_prefilter(prefilter_view(db, q), q->off, q->res, nullptr, db->off, *P, binCount, g_stream, q->hits, q->nHits, q->hitOff, err,
-                               timed_begin, timed_end, timed_set, mk::PrefilterHooks());
+                               timed_begin, timed_end, timed_set, hooks);
     }
     timed_flush();
     if (rc != MK_OK) return fail(rc, "%s", err.c_str());
@@ -1224,6 +1226,7 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     mk::PrefilterHooks hooks;
     hooks.max_chunk_queries = 1u << 17;
     hooks.co_resident = true;
+    hooks.t_masked_host = db->maskedHost.data();
     if (const char *e = getenv("MK_SEARCH_CHUNK_QUERIES")) hooks.max_chunk_queries = (uint32_t) std::max(1024L, atol(e));
     hooks.on_chunk = [&](uint32_t a, uint32_t b) {
         { std::lock_guard<std::mutex> lk(pipe.m); pipe.items.emplace_back(a, b); }

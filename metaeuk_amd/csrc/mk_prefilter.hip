@@ -112,6 +112,8 @@ struct ProbeArgs {
     uint32_t *hit_count;              // [pos] (COUNT: written; GATHER: exclusive prefix, read)
     uint32_t *kmer_count;             // [pos] statistics
     uint64_t *keys; uint8_t *diag_hi; // GATHER outputs: one 8-byte record per index hit + the diagonal's high byte
+    uint8_t *list_start = nullptr;    // GATHER, overflow path only: 1 at the first hit of every k-mer's index list (the buffer arithmetic of
+                                      // QueryMatcher::match works on whole lists)
 };
 
 // slot and entry reads are one-touch random probes of tables far larger than L2; MK_NT_LOADS=1 marks them non-temporal so that
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
                 for (int u = 0; u < PROBE_U; u++) {
                     const uint32_t incl = enumk::wave_incl_scan(size[u]);
                     const uint64_t dst = (uint64_t) hitBase + hits + (incl - size[u]);
-                    if (size[u]) put(ent0[u], dst);
+                    if (size[u]) { put(ent0[u], dst); if (A.list_start) A.list_start[dst] = 1; }
                     // the rest of the longer lists, one entry per lane
                     enumk::wave_deal_tail(size[u] > 1 ? size[u] - 1 : 0u, lane, sMark[w], [&](uint32_t owner, uint32_t e, bool valid) {
                         const uint64_t oFirst = wave_read_lane64(o0[u], owner);
@@ -270,22 +272,41 @@ __global__ __launch_bounds__(256) void segment_offsets_kernel(const uint64_t *qO
 //   kept(t)    : low 8 bits of the diagonal equal those of the previous hit of the same (query,target);
 //                the first hit of a target is compared with 0 (duplicateBitArray starts zeroed)
 //   emitted(t) : kept(t) and the nearest earlier kept hit of the run has a different low byte (or none exists)
-__device__ __forceinline__ bool double_hit_emits(const uint64_t *rec, uint32_t hitBits, uint32_t t) {
+// The overflow path of QueryMatcher::match (QueryMatcher.cpp:281-316) cuts the hits of a query into segments (by arrival number) and runs
+// findDuplicates on every segment with a cleared state: Segments makes a run end at a segment boundary as well.  start == nullptr: one segment.
+struct Segments { const uint32_t *start; uint32_t n; uint32_t stop; /* hits from this arrival number on are dropped */ };
+__device__ __forceinline__ uint32_t segment_of(const Segments &S, uint32_t arrival) {      // largest s with start[s] <= arrival
+    uint32_t lo = 0, hi = S.n;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (S.start[mid] <= arrival) lo = mid; else hi = mid; }
+    return lo;
+}
+template <bool OVF = false>
+__device__ __forceinline__ bool double_hit_emits(const uint64_t *rec, uint32_t hitBits, uint32_t t, const Segments S = Segments{nullptr, 1, 0xFFFFFFFFu}) {
+    const uint64_t ordMask = (1ull << hitBits) - 1;
     const uint64_t r = rec[t] >> hitBits;
     const uint64_t group = r >> 8;
     const uint32_t lo = (uint32_t) r & 0xFFu;
-    const uint64_t rp = t > 0 ? rec[t - 1] >> hitBits : 0;
-    const bool samePrev = t > 0 && (rp >> 8) == group;
-    const uint32_t prevLo = samePrev ? ((uint32_t) rp & 0xFFu) : 0u;
+    uint32_t seg = 0;
+    if (OVF) {
+        const uint32_t ord = (uint32_t) (rec[t] & ordMask);
+        if (ord >= S.stop) return false;
+        seg = segment_of(S, ord);
+    }
+    const auto same_run = [&](uint32_t u) -> bool {        // hit u - 1 belongs to the run of hit u (u > 0)
+        if ((rec[u - 1] >> (hitBits + 8)) != group) return false;
+        if (OVF) return segment_of(S, (uint32_t) (rec[u - 1] & ordMask)) == seg;
+        return true;
+    };
+    const bool samePrev = t > 0 && same_run(t);
+    const uint32_t prevLo = samePrev ? ((uint32_t) (rec[t - 1] >> hitBits) & 0xFFu) : 0u;
     if (lo != prevLo) return false;
     bool emit = true;
     if (samePrev) {
         uint32_t u = t - 1;
         while (true) {
             const uint32_t ulo = (uint32_t) (rec[u] >> hitBits) & 0xFFu;
-            const uint64_t rq = u > 0 ? rec[u - 1] >> hitBits : 0;
-            const bool uSame = u > 0 && (rq >> 8) == group;
-            const uint32_t uprev = uSame ? ((uint32_t) rq & 0xFFu) : 0u;
+            const bool uSame = u > 0 && same_run(u);
+            const uint32_t uprev = uSame ? ((uint32_t) (rec[u - 1] >> hitBits) & 0xFFu) : 0u;
             if (ulo == uprev) { emit = ulo != lo; break; }
             if (!uSame) break;
             u--;
@@ -294,23 +315,46 @@ __device__ __forceinline__ bool double_hit_emits(const uint64_t *rec, uint32_t h
     return emit;
 }
 
+// segment boundaries of an overflowing query from the arrival numbers of its k-mer lists' first hits (ascending): the buffer arithmetic of
+// QueryMatcher::match (:281-316) -- a list that does not fit (n + size >= cap) closes the segment before it; a list that alone fills the
+// buffer stops the query (everything is dropped, :313-315,318-334).  One lane: a few hundred thousand lists, once per such query.
+__global__ void overflow_segments_kernel(const uint32_t *listPos, uint32_t nLists, uint32_t nHits, uint64_t cap, uint32_t maxSeg, uint32_t *segStart,
+                                         uint32_t *out /* [0] segments [1] stop (arrival number) [2] stopped [3] more segments than maxSeg */) {
+    uint32_t nSeg = 1, stop = nHits, stopped = 0, tooMany = 0;
+    uint64_t n = 0;
+    segStart[0] = 0;
+    for (uint32_t l = 0; l < nLists; l++) {
+        const uint64_t sz = (uint64_t) (l + 1 < nLists ? listPos[l + 1] : nHits) - listPos[l];
+        if (n + sz >= cap) {
+            if (nSeg >= maxSeg) { tooMany = 1; break; }
+            segStart[nSeg++] = listPos[l];
+            n = 0;
+            if (sz >= cap) { stopped = 1; stop = listPos[l]; break; }
+        }
+        n += sz;
+    }
+    out[0] = nSeg; out[1] = stop; out[2] = stopped; out[3] = tooMany;
+}
+
 // ordered compaction of the emitted records in two sweeps: candidates per 256-record block, (scan), then every block writes its
 // candidates behind those of the blocks before it -- runs of one (query, target) stay contiguous and in arrival order
-__global__ __launch_bounds__(256) void double_hit_count_kernel(const uint64_t *rec, uint32_t hitBits, uint32_t n, uint32_t *blockCount) {
+template <bool OVF = false>
+__global__ __launch_bounds__(256) void double_hit_count_kernel(const uint64_t *rec, uint32_t hitBits, uint32_t n, uint32_t *blockCount, Segments S) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = __syncthreads_count(t < n && double_hit_emits(rec, hitBits, t));
+    const int c = __syncthreads_count(t < n && double_hit_emits<OVF>(rec, hitBits, t, S));
     if (threadIdx.x == 0) blockCount[blockIdx.x] = (uint32_t) c;
 }
 
 // second sweep: emitted records -> candidate arrays (appended at `base`); qMap translates the range-local query index into the
 // chunk-local one (null: qLocal + qAdd)
+template <bool OVF = false>
 __global__ __launch_bounds__(256) void double_hit_emit_kernel(const uint64_t *rec, const uint8_t *diagHi, const uint32_t *blockStart, uint32_t n, uint32_t seqBits,
                                                               uint32_t hitBits, const uint64_t *qOff, uint32_t qFirst, uint64_t posBegin, const uint32_t *hitScan,
-                                                              const uint32_t *qMap, uint32_t qAdd, CandArrays C, uint32_t base) {
+                                                              const uint32_t *qMap, uint32_t qAdd, CandArrays C, uint32_t base, Segments S) {
     __shared__ uint32_t sWave[4];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const int w = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
-    const bool emit = t < n && double_hit_emits(rec, hitBits, t);
+    const bool emit = t < n && double_hit_emits<OVF>(rec, hitBits, t, S);
     const unsigned long long m = __ballot(emit);
     if (lane == 0) sWave[w] = (uint32_t) __popcll(m);
     __syncthreads();
@@ -960,7 +1004,83 @@ struct Ctx {
     int lastHitBits = 16;
     CandArrays C; uint32_t candCap;
     unsigned long long *dTotals, *hTotals;
+    // host side of the batch, for the overflow path's replay (the rare query that fills the reference's databaseHits buffer)
+    const std::vector<uint64_t> *qOffHost = nullptr; const std::vector<uint8_t> *qResHost = nullptr; const int8_t *qCorrHost = nullptr;
+    const uint8_t *tMaskedHost = nullptr; const std::vector<uint64_t> *tOffHost = nullptr; const SubMat *ungMat = nullptr;
+    uint32_t chunkQ0 = 0;              // batch index of the chunk's first query (candidates carry chunk-local indices)
 };
+
+// ---- the overflow path of QueryMatcher::match, host part (QueryMatcher.cpp:281-334; oracle/mko_prefilter.c: overflow_device_model) ----
+// cands = the diagonals the per-segment double-diagonal rule kept, ordered by (target, arrival number).  Per target the merges of the
+// overflow events are replayed: after event 0 the list is segment 0's; at every later event the list + the event's segment goes through
+// mergeDiagonalKeepScoredHitsDuplicates (backwards: an element stays when it is scored or its low diagonal byte differs from the element
+// behind it; the output is reversed), is scored, and keepMaxElement leaves the first maximum (and zero-score elements behind it); the
+// last segment is appended and mergeDiagonalDuplicates drops an element whose low byte equals its predecessor's.  The reference's ARRAY
+// order -- ties at the --max-seqs cut follow it -- is rebuilt from (segment, arrival): an event reverses the array, so after event e it
+// reads [C_e descending] ++ reverse(order before); the last segment follows ascending.  Survivors come back ordered by (target, that
+// order) with `ordinal` = their rank in that order.
+struct OvfCand { uint32_t id, ordinal; uint16_t diag; };
+template <class ScoreFn>
+void replay_overflow(const std::vector<OvfCand> &cands, const std::vector<uint32_t> &segStart, ScoreFn score_of, std::vector<OvfCand> &out) {
+    struct El { uint32_t arrival, seg; uint16_t diag; uint8_t count; };
+    const size_t events = segStart.size() - 1;
+    const auto seg_of = [&](uint32_t arrival) { size_t lo = 0, hi = segStart.size(); while (hi - lo > 1) { const size_t mid = (lo + hi) >> 1; if (segStart[mid] <= arrival) lo = mid; else hi = mid; } return (uint32_t) lo; };
+    // rank and direction of every segment in the final array
+    std::vector<uint32_t> os(1, 0u);
+    std::vector<uint8_t> od(1, (uint8_t) 0);
+    for (size_t e = 1; e + 1 <= events; e++) {
+        std::vector<uint32_t> ns(1, (uint32_t) e);
+        std::vector<uint8_t> nd(1, (uint8_t) 1);
+        for (size_t x = os.size(); x-- > 0;) { ns.push_back(os[x]); nd.push_back((uint8_t) !od[x]); }
+        os.swap(ns); od.swap(nd);
+    }
+    if (events > 0) { os.push_back((uint32_t) events); od.push_back(0); }
+    std::vector<uint32_t> rank(events + 1, 0u);
+    std::vector<uint8_t> desc(events + 1, (uint8_t) 0);
+    for (size_t x = 0; x < os.size(); x++) { rank[os[x]] = (uint32_t) x; desc[os[x]] = od[x]; }
+    struct Surv { uint32_t id; uint16_t diag; uint64_t key; };
+    std::vector<Surv> surv;
+    std::vector<El> A, F, T;
+    for (size_t r0 = 0; r0 < cands.size(); ) {
+        size_t r1 = r0;
+        while (r1 < cands.size() && cands[r1].id == cands[r0].id) r1++;
+        const uint32_t id = cands[r0].id;
+        F.clear();
+        size_t t = r0;
+        for (size_t e = 0; e <= events; e++) {
+            A = F;
+            for (; t < r1 && seg_of(cands[t].ordinal) == e; t++) A.push_back(El{cands[t].ordinal, (uint32_t) e, cands[t].diag, 0});
+            F.clear();
+            if (e == events) {
+                if (events == 0) F = A;
+                else if (!A.empty()) {                                   // mergeDiagonalDuplicates (CacheFriendlyOperations.cpp:80-115)
+                    uint8_t d = (uint8_t) ((uint8_t) A[0].diag + 1);
+                    for (const El &x : A) { if (d != (uint8_t) x.diag) F.push_back(x); d = (uint8_t) x.diag; }
+                }
+            } else if (e == 0) {
+                F = A;
+            } else if (!A.empty()) {                                     // mergeDiagonalKeepScoredHitsDuplicates (:118-150), align, keepMaxElement (:350-380)
+                uint8_t d = (uint8_t) ((uint8_t) A.back().diag + 1);
+                T.clear();
+                for (size_t x = A.size(); x-- > 0;) { if (A[x].count != 0 || d != (uint8_t) A[x].diag) T.push_back(A[x]); d = (uint8_t) A[x].diag; }
+                uint8_t mx = 0;
+                for (El &x : T) { const int sc = score_of(id, x.diag); x.count = (uint8_t) (sc < 255 ? sc : 255); if (x.count > mx) mx = x.count; }
+                for (const El &x : T) if (mx == x.count) { F.push_back(x); mx = 0; }
+            }
+        }
+        for (const El &x : F) surv.push_back(Surv{id, x.diag, ((uint64_t) rank[x.seg] << 32) | (uint64_t) (desc[x.seg] ? 0xFFFFFFFFu - x.arrival : x.arrival)});
+        r0 = r1;
+    }
+    // ordinal = rank of the key among all survivors; output by (target, key): the per-target lists above are already in key order
+    std::vector<uint32_t> idx(surv.size());
+    std::iota(idx.begin(), idx.end(), 0u);
+    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return surv[a].key < surv[b].key; });
+    std::vector<uint32_t> rnk(surv.size());
+    for (size_t x = 0; x < idx.size(); x++) rnk[idx[x]] = (uint32_t) x;
+    out.clear();
+    out.reserve(surv.size());
+    for (size_t x = 0; x < surv.size(); x++) out.push_back(OvfCand{surv[x].id, rnk[x], surv[x].diag});
+}
 
 // B. global path over the view queries [a, b): appends their candidates at C[nCand...]; qMap/qAdd translate the view's
 // query index into the chunk-local one.  Splits the range so that the index hits of one piece fit HIT_CAP.
@@ -991,6 +1111,7 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
         uint64_t totalHits = 0, nPos = 0;
         uint32_t *dHit = nullptr, *dKmer = nullptr;
         int qBits = 1, hitBits = 1;
+        bool ovf = false;
         for (;;) {
             nPos = hOff[q1] - hOff[q0];
             if (nPos == 0) break;
@@ -1065,7 +1186,9 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
             PCHK(hipMemcpyAsync(X.hTotals, X.dTotals, 32, hipMemcpyDeviceToHost, stream));
             PCHK(sync_wait(stream, "wait_prefilter"));
             totalHits = X.hTotals[0];
-            if (X.hTotals[1] != 0) { err = "a query overflows the reference's databaseHits buffer (QueryMatcher.cpp:281-316 is not restated)"; return MK_ERR_UNSUPPORTED; }
+            ovf = X.hTotals[1] != 0;               // a query of the piece fills the reference's databaseHits buffer: it is processed alone, in segments
+            if (ovf && q1 - q0 > 1) { q1 = q0 + (q1 - q0) / 2; continue; }
+            if (ovf && (V.p_sorted || !X.tMaskedHost)) { err = "a profile query overflows the reference's databaseHits buffer (QueryMatcher.cpp:281-316): not restated for profile queries"; return MK_ERR_UNSUPPORTED; }
             X.ts(thCount, 4.0 * (double) X.hTotals[2] + 8.0 * (double) totalHits + 1280.0 * (double) nPos, (double) X.hTotals[2]);   // bitmap word per k-mer, slot per non-empty k-mer, row heads per start
             hitsPerPos = std::max(1.0, (double) totalHits / (double) nPos);
             if (totalHits > HIT_CAP && q1 - q0 > 1) { q1 = q0 + (q1 - q0) / 2; continue; }
@@ -1088,6 +1211,13 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
             ProbeArgs A;
             A.V = V; A.pos_begin = hOff[q0]; A.pos_end = hOff[q1]; A.q_first = q0; A.seq_bits = X.seqBits; A.hit_bits = (uint32_t) hitBits;
             A.hit_count = dHit; A.kmer_count = dKmer; A.keys = dKeys; A.diag_hi = dDiagHi;
+            uint8_t *dListStart = nullptr;
+            if (ovf) {
+                dListStart = (uint8_t *) dev_scratch("pf_liststart", (size_t) nHits);
+                PNULL(dListStart);
+                PCHK(hipMemsetAsync(dListStart, 0, (size_t) nHits, stream));
+                A.list_start = dListStart;
+            }
             const unsigned blocks = (unsigned) ((nPos + 3) / 4);
             // gather pass: slots again + 8 B per index entry read + 9 B (record, high diagonal byte) written per entry
             int th = X.tb("kmer_probe_gather", 4.0 * (double) X.hTotals[2] + 25.0 * (double) totalHits + 1280.0 * (double) nPos, (double) X.hTotals[2]);
@@ -1095,6 +1225,40 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
             else hipLaunchKernelGGL(probe_kernel<true>, dim3(blocks), dim3(256), 0, stream, A);
             X.te(th);
             PCHK(hipGetLastError());
+            Segments S{nullptr, 1, 0xFFFFFFFFu};
+            std::vector<uint32_t> hSegStart;
+            bool ovfStopped = false;
+            if (ovf) {
+                // segment boundaries from the list starts (arrival numbers, ascending)
+                uint32_t *dListPos = (uint32_t *) dev_scratch("pf_listpos", (size_t) nHits * 4);
+                uint32_t *dNumL = (uint32_t *) dev_scratch("pf_num", 64);
+                const uint32_t maxSeg = (uint32_t) std::min<uint64_t>(1u << 20, 2 * (uint64_t) nHits / X.maxDbMatches + 8);
+                uint32_t *dSegStart = (uint32_t *) dev_scratch("pf_segstart", (size_t) maxSeg * 4);
+                uint32_t *dSegOut = (uint32_t *) dev_scratch("pf_segout", 64);
+                uint32_t *hSegOut = (uint32_t *) pinned_scratch("pf_segout_h", 64);
+                PNULL(dListPos); PNULL(dNumL); PNULL(dSegStart); PNULL(dSegOut); PNULL(hSegOut);
+                hipcub::CountingInputIterator<uint32_t> iota(0);
+                size_t tl = 0;
+                hipcub::DeviceSelect::Flagged(nullptr, tl, iota, dListStart, dListPos, dNumL, (int) nHits, stream);
+                void *tempL = dev_scratch("pf_temp", tl);
+                PNULL(tempL);
+                PCHK(hipcub::DeviceSelect::Flagged(tempL, tl, iota, dListStart, dListPos, dNumL, (int) nHits, stream));
+                PCHK(hipMemcpyAsync(hSegOut + 8, dNumL, 4, hipMemcpyDeviceToHost, stream));
+                PCHK(sync_wait(stream, "wait_prefilter"));
+                const uint32_t nLists = hSegOut[8];
+                hipLaunchKernelGGL(overflow_segments_kernel, dim3(1), dim3(1), 0, stream, dListPos, nLists, nHits, (uint64_t) X.maxDbMatches, maxSeg, dSegStart, dSegOut);
+                PCHK(hipGetLastError());
+                PCHK(hipMemcpyAsync(hSegOut, dSegOut, 16, hipMemcpyDeviceToHost, stream));
+                PCHK(sync_wait(stream, "wait_prefilter"));
+                if (hSegOut[3]) { err = "internal: more overflow segments than expected"; return MK_ERR_DEVICE; }
+                ovfStopped = hSegOut[2] != 0;
+                hSegStart.resize(hSegOut[0]);
+                PCHK(hipMemcpy(hSegStart.data(), dSegStart, (size_t) hSegOut[0] * 4, hipMemcpyDeviceToHost));
+                S.start = dSegStart; S.n = hSegOut[0]; S.stop = hSegOut[1];
+                if (getenv("MK_PREFILTER_DEBUG")) fprintf(stderr, "[prefilter] a query overflows the databaseHits buffer: %u index hits in %u lists, %u segments%s\n",
+                                                          nHits, nLists, hSegOut[0], ovfStopped ? ", one list alone fills the buffer: dropped" : "");
+            }
+            if (ovfStopped) { q0 = q1; continue; }                        // (:313-315,318-334: nothing is reported for this query)
             // sort by (query, target): only those bits are sorted, the records of a pair stay in arrival order.  The gather pass wrote the
             // records query by query, so the sort is per query over the target bits alone (segments of ~20 K records stay in L2)
             hipcub::DoubleBuffer<uint64_t> kb(dKeys, dKeys2);
@@ -1131,7 +1295,8 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
             uint32_t *dLastBlk = (uint32_t *) dev_scratch("pf_num", 64);
             PNULL(dBlk); PNULL(dLastBlk);
             th = X.tb("double_hit", 16.0 * nHits, 0);
-            hipLaunchKernelGGL(double_hit_count_kernel, dim3(nBlocks), dim3(256), 0, stream, kb.Current(), (uint32_t) hitBits, nHits, dBlk);
+            if (ovf) hipLaunchKernelGGL(double_hit_count_kernel<true>, dim3(nBlocks), dim3(256), 0, stream, kb.Current(), (uint32_t) hitBits, nHits, dBlk, S);
+            else hipLaunchKernelGGL(double_hit_count_kernel<false>, dim3(nBlocks), dim3(256), 0, stream, kb.Current(), (uint32_t) hitBits, nHits, dBlk, S);
             PCHK(hipGetLastError());
             PCHK(hipMemcpyAsync(dLastBlk, dBlk + (nBlocks - 1), 4, hipMemcpyDeviceToDevice, stream));
             {
@@ -1148,13 +1313,55 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
             PCHK(sync_wait(stream, "wait_prefilter"));
             const uint32_t nSel = hNum[0] + hNum[1];
             if ((uint64_t) nCand + nSel > X.candCap) { X.te(th); return RC_CAND_OVERFLOW; }
-            if (nSel > 0) {
-                hipLaunchKernelGGL(double_hit_emit_kernel, dim3(nBlocks), dim3(256), 0, stream, kb.Current(), dDiagHi, dBlk, nHits, X.seqBits,
-                                   (uint32_t) hitBits, V.q_off, q0, hOff[q0], dHit, qMap ? qMap + q0 : nullptr, qAddBase + q0, X.C, nCand);
+            if (nSel > 0 && !ovf) {
+                hipLaunchKernelGGL(double_hit_emit_kernel<false>, dim3(nBlocks), dim3(256), 0, stream, kb.Current(), dDiagHi, dBlk, nHits, X.seqBits,
+                                   (uint32_t) hitBits, V.q_off, q0, hOff[q0], dHit, qMap ? qMap + q0 : nullptr, qAddBase + q0, X.C, nCand, S);
                 PCHK(hipGetLastError());
                 nCand += nSel;
             }
             X.te(th);
+            if (nSel > 0 && ovf) {
+                // the per-segment diagonals of the one query: emitted, brought to the host, merged as the overflow events merged them, the
+                // survivors written back in the reference's array order
+                hipLaunchKernelGGL(double_hit_emit_kernel<true>, dim3(nBlocks), dim3(256), 0, stream, kb.Current(), dDiagHi, dBlk, nHits, X.seqBits,
+                                   (uint32_t) hitBits, V.q_off, q0, hOff[q0], dHit, qMap ? qMap + q0 : nullptr, qAddBase + q0, X.C, nCand, S);
+                PCHK(hipGetLastError());
+                ScopedHost sh("host_prefilter_overflow");
+                std::vector<uint32_t> hId(nSel), hOrd(nSel), hQ(1);
+                std::vector<uint16_t> hDiag(nSel);
+                PCHK(hipMemcpyAsync(hId.data(), X.C.id + nCand, (size_t) nSel * 4, hipMemcpyDeviceToHost, stream));
+                PCHK(hipMemcpyAsync(hOrd.data(), X.C.ordinal + nCand, (size_t) nSel * 4, hipMemcpyDeviceToHost, stream));
+                PCHK(hipMemcpyAsync(hDiag.data(), X.C.diag + nCand, (size_t) nSel * 2, hipMemcpyDeviceToHost, stream));
+                PCHK(hipMemcpyAsync(hQ.data(), X.C.q + nCand, 4, hipMemcpyDeviceToHost, stream));
+                PCHK(sync_wait(stream, "wait_prefilter"));
+                std::vector<OvfCand> cands(nSel), surv;
+                for (uint32_t k = 0; k < nSel; k++) cands[k] = OvfCand{hId[k], hOrd[k], hDiag[k]};
+                // (emitted in (target, arrival) order: the records were sorted by target, stably)
+                const size_t qg = (size_t) X.chunkQ0 + hQ[0];
+                const uint64_t qs = (*X.qOffHost)[qg];
+                const uint32_t L = (uint32_t) ((*X.qOffHost)[qg + 1] - qs);
+                std::vector<int8_t> corr(L);
+                if (X.qCorrHost) std::memcpy(corr.data(), X.qCorrHost + qs, L);
+                else PCHK(hipMemcpy(corr.data(), V.q_corr + hOff[q0], L, hipMemcpyDeviceToHost));
+                int8_t m8[21 * 21];
+                for (int a = 0; a < 21; a++) for (int b = 0; b < 21; b++) m8[a * 21 + b] = (int8_t) X.ungMat->sub[a][b];
+                const uint8_t *qr = X.qResHost->data() + qs;
+                replay_overflow(cands, hSegStart, [&](uint32_t id, uint16_t diag) -> int {
+                    const uint64_t ts = (*X.tOffHost)[id];
+                    return ungapped_score(m8, qr, corr.data(), L, X.tMaskedHost + ts, (uint32_t) ((*X.tOffHost)[id + 1] - ts), (uint32_t) diag);
+                }, surv);
+                const uint32_t nSurv = (uint32_t) surv.size();
+                for (uint32_t k = 0; k < nSurv; k++) { hId[k] = surv[k].id; hOrd[k] = surv[k].ordinal; hDiag[k] = surv[k].diag; }
+                std::vector<uint32_t> hQs(nSurv, hQ[0]);
+                if (nSurv) {
+                    PCHK(hipMemcpyAsync(X.C.id + nCand, hId.data(), (size_t) nSurv * 4, hipMemcpyHostToDevice, stream));
+                    PCHK(hipMemcpyAsync(X.C.ordinal + nCand, hOrd.data(), (size_t) nSurv * 4, hipMemcpyHostToDevice, stream));
+                    PCHK(hipMemcpyAsync(X.C.diag + nCand, hDiag.data(), (size_t) nSurv * 2, hipMemcpyHostToDevice, stream));
+                    PCHK(hipMemcpyAsync(X.C.q + nCand, hQs.data(), (size_t) nSurv * 4, hipMemcpyHostToDevice, stream));
+                    PCHK(sync_wait(stream, "wait_prefilter"));              // the vectors die with this scope
+                }
+                nCand += nSurv;
+            }
         }
         q0 = q1;
     }
@@ -1214,6 +1421,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     X.stream = stream; X.err = &err; X.tb = tb; X.te = te; X.ts = ts; X.seqBits = seqBits;
     X.maxDbMatches = std::max<uint64_t>(1000000, dbSize) * 2;   // QueryMatcher.cpp:43
     X.candCap = CAND_CAP;
+    X.qOffHost = &qOff; X.qResHost = &qRes; X.qCorrHost = V.p_sorted ? nullptr : qCorrHost; X.tMaskedHost = hooks.t_masked_host; X.tOffHost = &tOff; X.ungMat = &ungMat;
     X.dTotals = (unsigned long long *) dev_scratch("pf_totals", 64);
     X.hTotals = (unsigned long long *) pinned_scratch("pf_totals_h", 64);
     PNULL(X.dTotals); PNULL(X.hTotals);
@@ -1239,6 +1447,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
         const uint32_t q1 = (uint32_t) std::min<uint64_t>(nq, (uint64_t) q0 + std::max<uint32_t>(want, 1));
         const uint32_t nqc = q1 - q0;
         uint32_t nCand = 0;
+        X.chunkQ0 = q0;
         std::vector<uint32_t> fallback;                                     // chunk-local ids for the global path
         int rc = MK_OK;
         if (useFused) {

@@ -221,6 +221,31 @@ def test_index_list_starts_beyond_32_bits(gpu_api, pf_path, monkeypatch):
         assert api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1])) == galn[i], ("aln", i)
 
 
+def test_database_hits_overflow_path(gpu_api, tmp_path):
+    """QueryMatcher::match's overflow path (QueryMatcher.cpp:281-334): 70 000 near-copies of one protein make three of four queries gather
+    10 ... 27 million index entries where the reference's buffer holds 2 million -- segments with a double-diagonal rule each, merged as
+    the overflow events merge them, ties at the --max-seqs cut in the reference's array order.  Against the oracle's literal restatement
+    (itself equal to the reference harness: tests/test_oracle_golden.py)."""
+    rng = random.Random(3)
+    base = "".join(rng.choice(AA) for _ in range(400))
+    mut = lambda s, r: "".join(rng.choice(AA) if rng.random() < r else c for c in s)
+    targets = [mut(base, 0.02) for _ in range(70000)]
+    queries = [base, mut(base, 0.05), base[:150], "".join(rng.choice(AA) for _ in range(300))]
+    api = gpu_api
+    params = api.default_params()
+    params.host_l2_bytes = 2097152
+    db = api.TargetDB(targets, params)
+    # (the overflowing queries between ordinary ones: they are isolated piece by piece)
+    batch = queries + [mut(base, 0.4), queries[0]]
+    q = api.Queries(batch, params)
+    (hits, hoff), (alns, aoff) = api.search(db, q)
+    opref, oaln = oracle.run_pipeline(targets, batch, str(tmp_path), extra=["--l2", "2097152"])
+    for i in range(len(batch)):
+        assert api.format_hits(hits, int(hoff[i]), int(hoff[i + 1])) == opref[i], ("pref", i)
+        assert api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1])) == oaln[i], ("aln", i)
+    assert "host_prefilter_overflow" in api.kernel_stats()
+
+
 def test_sw_vs_golden(gpu_api):
     """400 adversarial pairs (gap next to gap, poly-residue inserts, long related pairs): coordinates and bit
     scores printed by the reference (AVX2 == SSE4.1) vs the kernel's integers"""
