@@ -258,25 +258,37 @@ class Profiles(Queries):
         return le, so, al, kt
 
 
+class _SwappedHandle:
+    def __init__(self, h):
+        self.h = h
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().mk_swapped_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 def swap_alignments(alns, aln_off, n_targets, swapped_db_residues, query_keys=None, params=None):
-    """swapresults on the arrays of align_result(): -> (ctypes array of Alignment, offsets uint64[n_targets + 1]) per target index (copies)"""
+    """swapresults on the arrays of align_result(): -> (ctypes array of Alignment, offsets uint64[n_targets + 1]) per target index"""
     p = params or default_params()
     aln_off = np.ascontiguousarray(aln_off, dtype=np.uint64)
     keys = None if query_keys is None else np.ascontiguousarray(query_keys, dtype=np.uint32)
     h = C.c_void_p()
     _chk(lib().mk_swap_alignments(alns, _p(aln_off), C.c_uint32(len(aln_off) - 1), None if keys is None else _p(keys), C.c_uint32(n_targets),
                                   C.c_uint64(swapped_db_residues), C.byref(p), C.byref(h)))
-    try:
-        ap, op = C.c_void_p(), C.c_void_p()
-        _chk(lib().mk_swapped_result(h, C.byref(ap), C.byref(op)))
-        off = np.array(np.ctypeslib.as_array(C.cast(op, C.POINTER(C.c_uint64)), shape=(n_targets + 1,)))
-        total = int(off[-1])
-        out = (Alignment * total)()
-        if total:
-            C.memmove(out, ap, total * C.sizeof(Alignment))
-        return out, off
-    finally:
-        lib().mk_swapped_destroy(h)
+    owner = _SwappedHandle(h)
+    ap, op = C.c_void_p(), C.c_void_p()
+    _chk(lib().mk_swapped_result(h, C.byref(ap), C.byref(op)))
+    off = np.array(np.ctypeslib.as_array(C.cast(op, C.POINTER(C.c_uint64)), shape=(n_targets + 1,)))
+    total = int(off[-1])
+    if total == 0 or not ap.value:
+        return (Alignment * 0)(), off
+    out = (Alignment * total).from_address(ap.value)          # a view into the handle's memory: it lives as long as the array does
+    out._owner = owner
+    return out, off
 
 
 def prefilter(db, q, params=None):
