@@ -333,6 +333,52 @@ int finishShards(const std::string &out, const Shard &sh, int dbtype) {
 
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+int invertedProfileSearch(const mk::Database &pdb, mk_targetdb *F, uint64_t nFrag, const mk_params &P, mk_swapped **S, uint64_t &nHits, uint64_t &nAln);
+
+// search <i:fragmentDB> <i:profileDB> <o:alignmentDB> <tmpDir>: what Search.cpp:357-399 + searchslicedtargetprofile.sh compute -- the profiles
+// against the fragments, swapped: one record per fragment key with the profiles that hit it.  Fragment numbering = the DB's data order, like
+// the reference's prefilter numbers its targets.
+int searchProfileTargets(const Args &a, mk_params P, const mk::Database &qdb, const std::string &outPath, double t0) {
+    mk::Database pdb;
+    std::string e = pdb.open(a.pos[1]);
+    if (!e.empty()) return die("%s", e);
+    const size_t nFrag = qdb.entries.size(), nProf = pdb.entries.size();
+    std::vector<uint8_t> fres;
+    std::vector<uint64_t> foff;
+    encodeDb(qdb, fres, foff);
+    const double evalThrUser = P.evalue_thr;
+    P.profile_search = 1;
+    P.max_seqs = (int) std::max<uint64_t>(300, nFrag);                       // Search.cpp:372
+    P.evalue_thr = nProf ? invertedEvalue(evalThrUser, nFrag, nProf) : evalThrUser;
+    mk_targetdb *F = nullptr;
+    if (mk_targetdb_create(fres.data(), foff.data(), (uint32_t) nFrag, &P, &F) != MK_OK) return die("%s", mk_last_error());
+    std::vector<uint32_t> fkeys(nFrag);
+    for (size_t i = 0; i < nFrag; i++) fkeys[i] = qdb.entries[i].key;
+    if (mk_targetdb_set_keys(F, fkeys.data(), (uint32_t) nFrag) != MK_OK) return die("%s", mk_last_error());
+    uint64_t nHits = 0, nAln = 0;
+    mk_swapped *S = nullptr;
+    if (int rc = invertedProfileSearch(pdb, F, nFrag, P, &S, nHits, nAln)) return rc;
+    const mk_alignment *sw; const uint64_t *soff;
+    mk_swapped_result(S, &sw, &soff);
+    mk::DatabaseWriter w(outPath, mk::DBTYPE_ALIGNMENT_RES);
+    e = w.open();
+    if (!e.empty()) return die("%s", e);
+    std::string buf;
+    char line[512];
+    for (size_t i = 0; i < nFrag; i++) {
+        buf.clear();
+        for (uint64_t k = soff[i]; k < soff[i + 1]; k++) buf.append(line, mk_format_alignment(line, &sw[k]));
+        w.write(qdb.entries[i].key, buf.data(), buf.size());
+    }
+    e = w.close();
+    if (!e.empty()) return die("%s", e);
+    fprintf(stderr, "search (profile targets): %zu profiles x %zu fragments, %llu prefilter hits, %llu alignments, %.2f s\n", nProf, nFrag, (unsigned long long) nHits,
+            (unsigned long long) nAln, now() - t0);
+    mk_swapped_destroy(S);
+    mk_targetdb_destroy(F);
+    return EXIT_SUCCESS;
+}
+
 // mode: 0 = prefilter, 1 = align, 2 = search (the `search` workflow's two modules as one pipelined pass: <queryDB> <targetDB> <alignmentDB>
 // <tmpDir>, nothing written in between -- blastp.sh:70,85 without the pref_0 round trip)
 int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
@@ -389,6 +435,16 @@ int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
         if (isSearch) return die("search with --split %s --split-mode 0: target splits are implemented by the prefilter command", a.opt["--split"]);
         if (profileQueries) return die("--split-mode 0 with profile queries is not implemented%s");
         if (isAlign) targetSplits = 1;                                   // (align has no such flag in the reference; tolerated)
+    }
+    {   // `search <fragmentDB> <profileDB>`: Search.cpp:357-399 turns a profile TARGET database into the inverted sliced search
+        FILE *f = fopen((a.pos[1] + ".dbtype").c_str(), "rb");
+        int32_t t = -1;
+        if (f) { if (fread(&t, 4, 1, f) != 1) t = -1; fclose(f); }
+        if (t >= 0 && (t & 0xFFFF) == DBTYPE_HMM_PROFILE) {
+            if (!isSearch || profileQueries) return die("a profile target database is searched by `search` / `predictexons` (the inverted sliced search), not by %s", isAlign ? "align" : "prefilter");
+            if (sh.world > 1) return die("search with a profile target database is not sharded: run it as one process%s");
+            return searchProfileTargets(a, P, qdb, outPath, t0);
+        }
     }
     TargetSide ts;
     if (targetSplits == 1) { if (int rc = openTarget(a.pos[1], P, ts)) return rc; }
@@ -730,6 +786,49 @@ int cmdExtractOrfs(int argc, char **argv) {
     return EXIT_SUCCESS;
 }
 
+// The inverted search of searchslicedtargetprofile.sh on handles: the profiles of pdb (by key, in slices of at most MK_CLI_PROFILE_COLS
+// columns, default 2^24) as queries against the fragment side F (built with profile_search = 1; P already carries the inverted e-value
+// threshold and --max-seqs), then swapresults -e DBL_MAX (Search.cpp:378-381): *S lists, per fragment index, the profiles that hit it.
+int invertedProfileSearch(const mk::Database &pdb, mk_targetdb *F, uint64_t nFrag, const mk_params &P, mk_swapped **S, uint64_t &nHits, uint64_t &nAln) {
+    const size_t nProf = pdb.entries.size();
+    std::vector<size_t> pord = pdb.keyOrder();
+    const uint64_t sliceCols = getenv("MK_CLI_PROFILE_COLS") ? strtoull(getenv("MK_CLI_PROFILE_COLS"), nullptr, 10) : (1ull << 24);
+    std::vector<mk_alignment> alnAll;
+    std::vector<uint64_t> alnOff(1, 0);
+    std::vector<uint32_t> pkeys;
+    nHits = 0;
+    for (size_t p0 = 0; p0 < nProf; ) {
+        size_t p1 = p0;
+        uint64_t cols = 0;
+        std::vector<uint64_t> coff(1, 0);
+        while (p1 < nProf && (p1 == p0 || cols + (std::max<uint64_t>(pdb.entries[pord[p1]].length, 1) - 1) / 25 <= sliceCols)) {
+            cols += (std::max<uint64_t>(pdb.entries[pord[p1]].length, 1) - 1) / 25;
+            coff.push_back(cols);
+            p1++;
+        }
+        std::vector<uint8_t> colBytes(cols * 25 + 1);
+        for (size_t i = p0; i < p1; i++) std::memcpy(colBytes.data() + coff[i - p0] * 25, pdb.entry(pord[i]), (size_t) (coff[i - p0 + 1] - coff[i - p0]) * 25);
+        mk_queries *Q = nullptr;
+        if (mk_profiles_create(colBytes.data(), coff.data(), (uint32_t) (p1 - p0), &P, &Q) != MK_OK) return die("%s", mk_last_error());
+        if (mk_search(F, Q, &P) != MK_OK) return die("%s", mk_last_error());
+        const mk_hit *hp; const uint64_t *ho;
+        mk_prefilter_result(Q, &hp, &ho);
+        nHits += ho[p1 - p0];
+        const mk_alignment *alns; const uint64_t *aoff;
+        mk_align_result(Q, &alns, &aoff);
+        alnAll.insert(alnAll.end(), alns, alns + aoff[p1 - p0]);
+        for (size_t i = p0; i < p1; i++) { alnOff.push_back(alnOff[p0] + aoff[i - p0 + 1]); pkeys.push_back(pdb.entries[pord[i]].key); }
+        mk_queries_destroy(Q);
+        p0 = p1;
+    }
+    nAln = alnOff.back();
+    // the e-values of the swapped lists use the profile DB's column count (swapresults.cpp:76-77: the original target side)
+    mk_params SP = P;
+    SP.evalue_thr = std::numeric_limits<double>::max();
+    if (mk_swap_alignments(alnAll.data(), alnOff.data(), (uint32_t) nProf, pkeys.data(), (uint32_t) nFrag, profileDbResidues(pdb), &SP, S) != MK_OK) return die("%s", mk_last_error());
+    return 0;
+}
+
 // predictexons against a PROFILE database (BASELINE config 4): Search.cpp:357-399 + searchslicedtargetprofile.sh in one
 // process.  The fragments of ALL contigs become the indexed target side (the reference indexes the whole aa_6f DB as well: its numbers --
 // fragments, residues -- enter the e-value threshold, the e-values and --max-seqs), the profiles go through prefilter + align in slices
@@ -787,45 +886,11 @@ int predictExonsProfileTargets(const Args &a, mk_params P, const mk_exon_params 
     mk_targetdb *F = nullptr;
     if (mk_targetdb_create(fres.data(), aaOff, (uint32_t) nFrag, &P, &F) != MK_OK) return die("%s", mk_last_error());
     const double t1 = now();
-    // profiles by key, in slices of at most MK_CLI_PROFILE_COLS columns (default 2^24)
-    std::vector<size_t> pord = pdb.keyOrder();
-    const uint64_t sliceCols = getenv("MK_CLI_PROFILE_COLS") ? strtoull(getenv("MK_CLI_PROFILE_COLS"), nullptr, 10) : (1ull << 24);
-    std::vector<mk_alignment> alnAll;
-    std::vector<uint64_t> alnOff(1, 0);
-    std::vector<uint32_t> pkeys;
-    uint64_t nHits = 0;
-    for (size_t p0 = 0; p0 < nProf; ) {
-        size_t p1 = p0;
-        uint64_t cols = 0;
-        std::vector<uint64_t> coff(1, 0);
-        while (p1 < nProf && (p1 == p0 || cols + (std::max<uint64_t>(pdb.entries[pord[p1]].length, 1) - 1) / 25 <= sliceCols)) {
-            cols += (std::max<uint64_t>(pdb.entries[pord[p1]].length, 1) - 1) / 25;
-            coff.push_back(cols);
-            p1++;
-        }
-        std::vector<uint8_t> colBytes(cols * 25 + 1);
-        for (size_t i = p0; i < p1; i++) std::memcpy(colBytes.data() + coff[i - p0] * 25, pdb.entry(pord[i]), (size_t) (coff[i - p0 + 1] - coff[i - p0]) * 25);
-        mk_queries *Q = nullptr;
-        if (mk_profiles_create(colBytes.data(), coff.data(), (uint32_t) (p1 - p0), &P, &Q) != MK_OK) return die("%s", mk_last_error());
-        if (mk_search(F, Q, &P) != MK_OK) return die("%s", mk_last_error());
-        const mk_hit *hp; const uint64_t *ho;
-        mk_prefilter_result(Q, &hp, &ho);
-        nHits += ho[p1 - p0];
-        const mk_alignment *alns; const uint64_t *aoff;
-        mk_align_result(Q, &alns, &aoff);
-        alnAll.insert(alnAll.end(), alns, alns + aoff[p1 - p0]);
-        for (size_t i = p0; i < p1; i++) { alnOff.push_back(alnOff[p0] + aoff[i - p0 + 1]); pkeys.push_back(pdb.entries[pord[i]].key); }
-        mk_queries_destroy(Q);
-        p0 = p1;
-    }
-    const double t2 = now();
-    // swapresults -e DBL_MAX (Search.cpp:378-381), then the exon stage on the fragments' lists: target = profile key, the e-values of a set
-    // use the profile DB's column count (collectoptimalset opens the target DB: DBReader::getAminoAcidDBSize)
-    const uint64_t profRes = profileDbResidues(pdb);
-    mk_params SP = P;
-    SP.evalue_thr = std::numeric_limits<double>::max();
+    uint64_t nHits = 0, nAlnTotal = 0;
     mk_swapped *S = nullptr;
-    if (mk_swap_alignments(alnAll.data(), alnOff.data(), (uint32_t) nProf, pkeys.data(), (uint32_t) nFrag, profRes, &SP, &S) != MK_OK) return die("%s", mk_last_error());
+    if (int rc = invertedProfileSearch(pdb, F, nFrag, P, &S, nHits, nAlnTotal)) return rc;
+    const double t2 = now();
+    const uint64_t profRes = profileDbResidues(pdb);
     const mk_alignment *sw; const uint64_t *soff;
     mk_swapped_result(S, &sw, &soff);
     mk_predictions *R = nullptr;
@@ -847,7 +912,7 @@ int predictExonsProfileTargets(const Args &a, mk_params P, const mk_exon_params 
     if (!e.empty()) return die("%s", e);
     fprintf(stderr, "predictexons (profile targets): %zu contigs -> %llu fragments x %zu profiles -> %llu prefilter hits, %llu alignments -> %llu predictions; "
             "%.2f s (fragment index %.2f s, search %.2f s, swap + exon sets %.2f s)\n", ord.size(), (unsigned long long) nFrag, nProf, (unsigned long long) nHits,
-            (unsigned long long) alnOff.back(), (unsigned long long) np, now() - t0, t1 - t0, t2 - t1, now() - t2);
+            (unsigned long long) nAlnTotal, (unsigned long long) np, now() - t0, t1 - t0, t2 - t1, now() - t2);
     mk_predictions_destroy(R);
     mk_swapped_destroy(S);
     mk_targetdb_destroy(F);

@@ -245,6 +245,10 @@ def test_cli_profile_workflow_equals_the_real_process(gpu_api, tmp_path):
     run("swapresults", tmp_path / "profDB", tmp_path / "aa_6f", tmp_path / "aln", tmp_path / "search_res", "--sub-mat", "aa:blosum62.out,nucl:nucleotide.out",
         "-e", "1.79769e+308", "--split-memory-limit", "0", "--gap-open", "aa:11,nucl:5", "--gap-extend", "aa:1,nucl:2", "--db-load-mode", "0", *common)
     assert blocks(_read_result_db(str(tmp_path / "search_res"))) == _text("prof_search_res.txt.gz")
+    # `search <fragmentDB> <profileDB>`: what the search workflow (Search.cpp:357-399) makes of a profile target -- the same swapped lists
+    run("search", tmp_path / "aa_6f", tmp_path / "profDB", tmp_path / "search_res_1", tmp_path / "tmp", "--alignment-mode", "2", "-s", "4", "-e", "100",
+        "--min-aln-len", "11", "--ref-l2-bytes", "2097152")
+    assert blocks(_read_result_db(str(tmp_path / "search_res_1"))) == _text("prof_search_res.txt.gz")
     # the whole workflow as one command (default -s 4, -e 100 scaled by 24084 fragments / 100 profiles)
     contigs = _text("e2e_contigs.txt.gz").splitlines()
     A.write_seq_db(str(tmp_path / "contigs"), A.seq_db_image(contigs), dbtype=1)
