@@ -108,11 +108,22 @@ uint64_t mk_targetdb_index_entries(const mk_targetdb *db);
 /* copies of host-built artefacts, for tests */
 int mk_targetdb_masked(const mk_targetdb *db, uint8_t *out /* residues */);
 
+/* masking and indexing run on the device (mk_index.hip); these report what came out.  MK_INDEX_BUILD=host in the environment selects
+ * the host builder (the check of the device one).  mk_targetdb_index_compare is a test hook: the number of differing slot words,
+ * presence words, entries and masked residues between two databases (all ~0 when their sizes differ). */
+uint64_t mk_targetdb_masked_residues(const mk_targetdb *db);
+int mk_targetdb_kmer_size(const mk_targetdb *db);          /* 6 or 7 */
+uint32_t mk_targetdb_longest_list(const mk_targetdb *db);  /* most targets one k-mer occurs in */
+int mk_targetdb_index_compare(const mk_targetdb *a, const mk_targetdb *b, uint64_t diff[4]);
+
 /* ---- precomputed index: the index DB of `createindex` / `indexdb` (type 9,
  * M/src/prefiltering/PrefilteringIndexReader.cpp:54-326): sequence DB + masked sequences + k-mer lists, so that a database is
- * masked and indexed once.  Both directions are interchangeable with the reference: it reads what mk_index_write writes and
- * mk_targetdb_open_index reads what its createindex writes (amino-acid targets, k = 6, one split).
- * mk_index_write needs no GPU.  The sequence DB is passed as it lies on disk: the data file(s) and the rows of its .index
+ * masked and indexed once and every rank of a node loads the same file.  Both directions are interchangeable with the reference: it
+ * reads what mk_index_write writes and mk_targetdb_open_index reads what its createindex writes (amino-acid targets, k = 6 and
+ * k = 7, one split).  mk_index_write builds the lists in HBM and streams them into the file when mk_init was called (any size;
+ * k = 7 from 3.35e9 residues on, IndexTable.h:439-449); without a GPU the host builder writes k = 6 index DBs.  A k = 7 index DB is
+ * not materialised on the host when it is opened: offsets and 6-byte entries go from the mapped file to HBM in pieces.
+ * The sequence DB is passed as it lies on disk: the data file(s) and the rows of its .index
  * (key, offset, length incl. "\n\0") in file order; target ids of the index = positions in that order (DBReader NOSORT,
  * util/indexdb.cpp:67-68).  Writes <index_db>, <index_db>.index, <index_db>.dbtype. */
 int mk_index_write(const char *index_db, const char *seq_data, uint64_t seq_data_size, const uint32_t *keys, const uint64_t *offsets,
@@ -255,6 +266,19 @@ int mk_ungapped(mk_targetdb *db, mk_queries *q, const uint32_t *q_idx, const uin
 typedef struct { const char *name; double ms; uint64_t launches; double alg_bytes; double cells; } mk_kernel_stat;
 int mk_kernel_stats(mk_kernel_stat *out, int cap);
 void mk_kernel_stats_reset(void);
+
+/* ---- test and bench support (host code): the seeded generator of the synthetic workload of SURVEY.md 8(d) at database sizes the Python
+ * generator cannot reach.  Families of ten proteins (founder of 150 .. 600 residues from the Robinson background, member j = the founder
+ * with every residue redrawn with probability 0.05 (1 + j)); residues = NULL: only offsets[n + 1] and *total are filled. */
+int mk_synth_targets(uint64_t n_targets, uint64_t seed, uint8_t *residues, uint64_t cap, uint64_t *offsets, uint64_t *total);
+/* query fragments cut out of the targets ("planted homologs"): fragment k = min_len .. max_len residues of a random target, every residue
+ * redrawn with probability mutation_rate; every random_every-th fragment is pure background (0: none).  source[k] = the target it came
+ * from (0xFFFFFFFF: background).  residues = NULL: only offsets, source and *total. */
+int mk_synth_fragments(uint64_t n_fragments, uint64_t seed, const uint8_t *target_residues, const uint64_t *target_offsets, uint64_t n_targets,
+                       double mutation_rate, uint32_t min_len, uint32_t max_len, uint64_t random_every, uint8_t *residues, uint64_t cap,
+                       uint64_t *offsets, uint32_t *source, uint64_t *total);
+/* residue codes -> an MMseqs2 sequence DB in memory: data[total + 2 n] = "SEQ\n\0" entries, rows of its .index (key = position) */
+int mk_synth_seqdb(const uint8_t *residues, const uint64_t *offsets, uint64_t n, char *data, uint32_t *keys, uint64_t *data_offsets, uint32_t *lengths);
 
 /* ---- formatting: QueryMatcher::prefilterHitToBuffer (QueryMatcher.h:118-130),
  * Matcher::resultToBuffer (Matcher.cpp:280-327) ---- */

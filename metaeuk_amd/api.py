@@ -46,7 +46,9 @@ EXPORTS = ["mk_init", "mk_last_error", "mk_default_params", "mk_device_name", "m
            "mk_align", "mk_align_result", "mk_search", "mk_extract_orfs", "mk_orfs_result", "mk_queries_from_orfs",
            "mk_orfs_destroy", "mk_format_orf_header", "mk_sw_pairs", "mk_ungapped",
            "mk_kernel_stats", "mk_kernel_stats_reset", "mk_format_hit", "mk_format_alignment", "mk_format_hits", "mk_format_alignments", "mk_targetdb_set_keys",
-           "mk_profiles_create", "mk_profiles_derived", "mk_swap_alignments", "mk_swapped_result", "mk_swapped_destroy"]
+           "mk_profiles_create", "mk_profiles_derived", "mk_swap_alignments", "mk_swapped_result", "mk_swapped_destroy",
+           "mk_targetdb_masked_residues", "mk_targetdb_kmer_size", "mk_targetdb_longest_list", "mk_targetdb_index_compare",
+           "mk_synth_targets", "mk_synth_fragments", "mk_synth_seqdb"]
 
 
 def lib():
@@ -59,6 +61,8 @@ def lib():
         L.mk_last_error.restype = C.c_char_p
         L.mk_targetdb_residues.restype = C.c_uint64
         L.mk_targetdb_index_entries.restype = C.c_uint64
+        L.mk_targetdb_masked_residues.restype = C.c_uint64
+        L.mk_targetdb_longest_list.restype = C.c_uint32
         L.mk_format_hit.restype = C.c_size_t
         L.mk_format_alignment.restype = C.c_size_t
         L.mk_format_hits.restype = C.c_size_t
@@ -142,6 +146,21 @@ class TargetDB:
     def index_entries(self):
         return int(lib().mk_targetdb_index_entries(self.h))
 
+    def masked_residues(self):
+        return int(lib().mk_targetdb_masked_residues(self.h))
+
+    def kmer_size(self):
+        return int(lib().mk_targetdb_kmer_size(self.h))
+
+    def longest_list(self):
+        return int(lib().mk_targetdb_longest_list(self.h))
+
+    def index_compare(self, other):
+        """test hook: (differing slot words, presence words, entries, masked residues) between the device tables of two databases"""
+        d = (C.c_uint64 * 4)()
+        _chk(lib().mk_targetdb_index_compare(self.h, other.h, d))
+        return tuple(int(x) for x in d)
+
     def close(self):
         if self.h:
             lib().mk_targetdb_destroy(self.h)
@@ -152,6 +171,39 @@ class TargetDB:
             self.close()
         except Exception:
             pass
+
+
+def synth_targets(n_targets, seed=11):
+    """native seeded generator (mk_synth.cpp): protein families of ten -> (uint8 codes, uint64 offsets[n + 1])"""
+    off = np.zeros(n_targets + 1, dtype=np.uint64)
+    total = C.c_uint64()
+    _chk(lib().mk_synth_targets(C.c_uint64(n_targets), C.c_uint64(seed), None, C.c_uint64(0), _p(off), C.byref(total)))
+    res = np.empty(max(1, int(total.value)), dtype=np.uint8)
+    _chk(lib().mk_synth_targets(C.c_uint64(n_targets), C.c_uint64(seed), _p(res), C.c_uint64(res.size), _p(off), C.byref(total)))
+    return res, off
+
+
+def synth_fragments(n_fragments, t_res, t_off, seed=11, mutation_rate=0.15, min_len=20, max_len=80, random_every=0):
+    """planted homologs: fragments cut out of the targets and mutated -> (uint8 codes, uint64 offsets, uint32 source target)"""
+    n_t = len(t_off) - 1
+    off = np.zeros(n_fragments + 1, dtype=np.uint64)
+    src = np.zeros(n_fragments, dtype=np.uint32)
+    total = C.c_uint64()
+    args = (C.c_uint64(n_fragments), C.c_uint64(seed), _p(t_res), _p(t_off), C.c_uint64(n_t), C.c_double(mutation_rate), C.c_uint32(min_len),
+            C.c_uint32(max_len), C.c_uint64(random_every))
+    _chk(lib().mk_synth_fragments(*args, None, C.c_uint64(0), _p(off), _p(src), C.byref(total)))
+    res = np.empty(max(1, int(total.value)), dtype=np.uint8)
+    _chk(lib().mk_synth_fragments(*args, _p(res), C.c_uint64(res.size), _p(off), _p(src), C.byref(total)))
+    return res, off, src
+
+
+def synth_seqdb(res, off):
+    """residue codes -> the image of an MMseqs2 sequence DB (data bytes as a numpy array, keys, offsets, lengths) for index_write / write_seq_db"""
+    n = len(off) - 1
+    data = np.empty(int(off[-1]) + 2 * n, dtype=np.uint8)
+    keys = np.zeros(n, dtype=np.uint32); offs = np.zeros(n, dtype=np.uint64); lens = np.zeros(n, dtype=np.uint32)
+    _chk(lib().mk_synth_seqdb(_p(res), _p(off), C.c_uint64(n), _p(data), _p(keys), _p(offs), _p(lens)))
+    return data, keys, offs, lens
 
 
 def seq_db_image(seqs, keys=None, order=None):
@@ -174,7 +226,7 @@ def seq_db_image(seqs, keys=None, order=None):
 def write_seq_db(base, image, dbtype=0):
     data, keys, offs, lens = image
     with open(base, "wb") as f:
-        f.write(data)
+        f.write(data if not isinstance(data, np.ndarray) else data.tobytes())
     with open(base + ".index", "w") as f:
         for k, o, l in zip(keys, offs, lens):
             f.write("%d\t%d\t%d\n" % (k, o, l))
@@ -186,7 +238,8 @@ def index_write(index_db, image, params=None, dbtype=0):
     """createindex: <index_db>, .index, .dbtype in the reference's format (no GPU needed)"""
     data, keys, offs, lens = image
     p = params or default_params()
-    _chk(lib().mk_index_write(C.c_char_p(index_db.encode()), C.c_char_p(data), C.c_uint64(len(data)), _p(keys), _p(offs), _p(lens), C.c_uint32(len(keys)),
+    dptr = _p(data) if isinstance(data, np.ndarray) else C.c_char_p(data)
+    _chk(lib().mk_index_write(C.c_char_p(index_db.encode()), dptr, C.c_uint64(len(data)), _p(keys), _p(offs), _p(lens), C.c_uint32(len(keys)),
                               C.c_int(dbtype), C.byref(p)))
 
 
@@ -484,8 +537,8 @@ def ungapped(db, q, q_idx, t_idx, diag):
 
 
 def kernel_stats(reset=False):
-    arr = (KernelStat * 64)()
-    n = lib().mk_kernel_stats(arr, 64)
+    arr = (KernelStat * 160)()
+    n = lib().mk_kernel_stats(arr, 160)
     res = {arr[i].name.decode(): dict(ms=arr[i].ms, launches=int(arr[i].launches), alg_bytes=arr[i].alg_bytes, cells=arr[i].cells)
            for i in range(n)}
     if reset:
@@ -493,13 +546,14 @@ def kernel_stats(reset=False):
     return res
 
 
-def format_hits_bulk(hits, lo, hi):
-    """bytes of the prefilter lines of hits[lo:hi] (key = target index), formatted by the library in one call"""
+def format_hits_bulk(hits, lo, hi, target_keys=None):
+    """bytes of the prefilter lines of hits[lo:hi] (key = target index, or target_keys[index]), formatted by the library in one call"""
     n = hi - lo
     if n <= 0:
         return b""
     buf = np.empty(32 * n, dtype=np.uint8)
-    w = lib().mk_format_hits(_p(buf), C.c_size_t(buf.size), C.c_void_p(hits.ctypes.data + lo * HIT_DTYPE.itemsize), C.c_uint64(n), None)
+    tk = None if target_keys is None else np.ascontiguousarray(target_keys, dtype=np.uint32)
+    w = lib().mk_format_hits(_p(buf), C.c_size_t(buf.size), C.c_void_p(hits.ctypes.data + lo * HIT_DTYPE.itemsize), C.c_uint64(n), None if tk is None else _p(tk))
     return buf[:w].tobytes()
 
 

@@ -9,6 +9,7 @@
 #include "mk_orf.hpp"
 #include "mk_exons.hpp"
 #include "mk_indexfile.hpp"
+#include "mk_index.hpp"
 #include "mk_prefilter.hpp"
 #include "mk_profile.hpp"
 
@@ -152,7 +153,11 @@ int effective_cpus() {
 struct mk_targetdb {
     uint32_t n = 0;
     std::vector<uint64_t> off;
-    std::vector<uint8_t> maskedHost;
+    std::vector<uint8_t> maskedHost;       // host copy of the masked residues: fetched from HBM when somebody asks (masked_host)
+    bool maskedHostReady = false;
+    uint64_t cells = 0;                    // cells of the k-mer table (20^6 or 20^7)
+    uint64_t maskedResidues = 0;
+    uint32_t maxList = 0;
     std::vector<uint32_t> keys;      // DB keys of the targets when the database came from an index file
     mk::SubMat kmerMat, ungMat, alnMat;
     mk::Evaluer evaluer;
@@ -344,16 +349,42 @@ void mk_default_params(mk_params *p) {
 
 void mk_encode(const char *ascii, size_t len, uint8_t *codes) { mk::encode(ascii, len, codes); }
 
-// target side, given the k-mer lists (built here or read from an index file): matrices, tables, upload
-static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uint32_t n, const mk_params *P, mk::TargetIndex *prebuilt, mk_targetdb **out) {
+// k-mer lists that exist already (an index DB)
+struct PrebuiltIndex {
+    mk::TargetIndex *host = nullptr;             // k = 6: lists in the tiled address order + masked residues, in host memory
+    // k = 7: views into the mapped index DB (reference numbering = the device's numbering), streamed to the device
+    const uint64_t *fileOffsets = nullptr; const unsigned char *fileEntries6 = nullptr; uint64_t nEntries = 0; const uint8_t *masked = nullptr;
+    int kmerSize = 6;
+};
+
+static const uint8_t *masked_host(mk_targetdb *db) {
+    if (!db->maskedHostReady) {
+        db->maskedHost.resize(db->off[db->n]);
+        if (db->off[db->n] && hipMemcpy(db->maskedHost.data(), db->dMasked.p, db->off[db->n], hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+        db->maskedHostReady = true;
+    }
+    return db->maskedHost.data();
+}
+
+static void adopt_index(mk_targetdb *db, mk::DeviceIndex &ix, uint64_t total) {
+    db->dMasked.p = ix.masked; db->dMasked.n = total;
+    db->dKmerSlot.p = ix.slots; db->dKmerSlot.n = ix.cells;
+    db->dKmerBits.p = ix.bits; db->dKmerBits.n = (ix.cells + 31) / 32;
+    db->dEntries.p = ix.entries; db->dEntries.n = ix.n_entries;
+    db->nEntries = ix.n_entries; db->cells = ix.cells; db->maskedResidues = ix.masked_residues; db->maxList = ix.max_list;
+    ix = mk::DeviceIndex();
+}
+
+// target side: matrices, tables, masking + k-mer index (built in HBM, or taken from an index DB), upload
+static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uint32_t n, const mk_params *P, const PrebuiltIndex *prebuilt, mk_targetdb **out) {
     int rc = ensure_ready();
     if (rc) return rc;
     if (!residues || !offsets || !P || !out) return fail(MK_ERR_ARG, "null argument");
     // IndexTable::computeKmerSize (IndexTable.h:439-449): from 3.35e9 target residues on the reference searches with k = 7
     if (P->kmer_size != 0 && P->kmer_size != 6 && P->kmer_size != 7) return fail(MK_ERR_UNSUPPORTED, "-k %d: k-mer sizes 6 and 7 are implemented", P->kmer_size);
-    const int kmerSize = P->kmer_size ? P->kmer_size : (offsets[n] < 3350000000ull ? 6 : 7);
+    const int kmerSize = prebuilt ? prebuilt->kmerSize : (P->kmer_size ? P->kmer_size : (offsets[n] < 3350000000ull ? 6 : 7));
+    if (prebuilt && P->kmer_size && P->kmer_size != kmerSize) return fail(MK_ERR_ARG, "-k %d, but the index DB was built with k = %d", P->kmer_size, kmerSize);
     if (kmerSize == 7 && P->profile_search) return fail(MK_ERR_UNSUPPORTED, "profile queries with k = 7 (a fragment set of 3.35e9 residues or more, or -k 7) are not implemented");
-    if (kmerSize == 7 && prebuilt) return fail(MK_ERR_UNSUPPORTED, "index DBs with k = 7 are not implemented");
     mk_targetdb *db = new mk_targetdb();
     db->kmerSize = kmerSize;
     db->n = n;
@@ -374,47 +405,79 @@ static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uin
     db->evaluer.init(offsets[n]);
     db->bitScoreTable.resize(32768);
     for (int sc = 0; sc < 32768; sc++) db->bitScoreTable[sc] = static_cast<int>(db->evaluer.bitScore((double) sc) + 0.5);
-    mk::TargetIndex built;
-    if (!prebuilt) mk::build_index(db->kmerMat, residues, offsets, n, db->kmerThr, P->mask != 0, P->mask_prob, P->simd_lanes_double, built, true, kmerSize);
-    mk::TargetIndex &ix = prebuilt ? *prebuilt : built;
-    if (ix.entries.size() >= (1ull << 40)) { delete db; return fail(MK_ERR_UNSUPPORTED, "index has >= 2^40 entries"); }
     // test hook: shift every list start by this many entries (and the device pointer back by as many), so that the slots' 40-bit starts
     // are exercised beyond 2^32 without a database of that size
     const uint64_t entryShift = getenv("MK_TEST_ENTRY_BASE") ? strtoull(getenv("MK_TEST_ENTRY_BASE"), nullptr, 10) : 0;
-    if (ix.entries.size() + entryShift >= (1ull << 40)) { delete db; return fail(MK_ERR_ARG, "MK_TEST_ENTRY_BASE too large"); }
+    if (entryShift >= (1ull << 39)) { delete db; return fail(MK_ERR_ARG, "MK_TEST_ENTRY_BASE too large"); }
     db->entryShift = entryShift;
-    db->nEntries = ix.entries.size();
-    db->maskedHost = ix.masked;
-    const size_t nKmers = ix.offsets.size() - 1;
-    std::vector<uint64_t> slots(nKmers);
-    std::vector<uint32_t> bits((nKmers + 31) / 32, 0u);
-    int tooLong = 0;
-#pragma omp parallel for schedule(static)
-    for (size_t wd = 0; wd < bits.size(); wd++) {
-        uint32_t m = 0;
-        const size_t k0 = wd * 32, k1 = std::min(k0 + 32, nKmers);
-        for (size_t k = k0; k < k1; k++) {
-            const uint64_t first = ix.offsets[k], len = ix.offsets[k + 1] - first;
-            if (len) m |= 1u << (k - k0);
-            if (len >= (1ull << 23)) tooLong = 1;
-            slots[k] = len == 1 ? ((1ull << 63) | ix.entries[first]) : ((first + entryShift) | (len << 40));
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; };
+    ok(db->dRes.upload(residues, offsets[n]));
+    ok(db->dOff.upload(offsets, n + 1));
+    if (e != hipSuccess) { delete db; return fail(MK_ERR_DEVICE, "target upload failed: %s", hipGetErrorString(e)); }
+    // MK_INDEX_BUILD=host: mask and index on the host (mk::build_index, the reference of the device builder)
+    const char *ib = getenv("MK_INDEX_BUILD");
+    const bool hostBuild = !prebuilt && ib && strcmp(ib, "host") == 0;
+    if ((prebuilt && prebuilt->host) || hostBuild) {
+        mk::TargetIndex built;
+        if (!prebuilt) mk::build_index(db->kmerMat, residues, offsets, n, db->kmerThr, P->mask != 0, P->mask_prob, P->simd_lanes_double, built, true, kmerSize);
+        mk::TargetIndex &ix = prebuilt ? *prebuilt->host : built;
+        if (ix.entries.size() + entryShift >= (1ull << 40)) { delete db; return fail(MK_ERR_UNSUPPORTED, "index has >= 2^40 entries"); }
+        db->nEntries = ix.entries.size();
+        db->maskedResidues = ix.maskedResidues;
+        const size_t nKmers = ix.offsets.size() - 1;
+        db->cells = nKmers;
+        std::vector<uint64_t> slots(nKmers);
+        std::vector<uint32_t> bits((nKmers + 31) / 32, 0u);
+        int tooLong = 0;
+        uint32_t maxList = 0;
+#pragma omp parallel for schedule(static) reduction(| : tooLong) reduction(max : maxList)
+        for (size_t wd = 0; wd < bits.size(); wd++) {
+            uint32_t m = 0;
+            const size_t k0 = wd * 32, k1 = std::min(k0 + 32, nKmers);
+            for (size_t k = k0; k < k1; k++) {
+                const uint64_t first = ix.offsets[k], len = ix.offsets[k + 1] - first;
+                if (len) m |= 1u << (k - k0);
+                if (len >= (1ull << 23)) tooLong |= 1;
+                maxList = std::max<uint32_t>(maxList, (uint32_t) std::min<uint64_t>(len, 0xFFFFFFFFull));
+                slots[k] = len == 1 ? ((1ull << 63) | ix.entries[first]) : ((first + entryShift) | (len << 40));
+            }
+            bits[wd] = m;
         }
-        bits[wd] = m;
+        if (tooLong) { delete db; return fail(MK_ERR_UNSUPPORTED, "a k-mer occurs in 2^23 or more targets: the slot's length field holds 23 bits"); }
+        db->maxList = maxList;
+        ok(db->dMasked.upload(ix.masked.data(), ix.masked.size()));
+        ok(db->dKmerSlot.upload(slots.data(), slots.size()));
+        ok(db->dKmerBits.upload(bits.data(), bits.size()));
+        ok(db->dEntries.upload(ix.entries.data(), ix.entries.size()));
+        ok(hipStreamSynchronize(g_stream));
+    } else {
+        mk::DeviceIndex ix;
+        std::string err;
+        if (prebuilt) {
+            ok(hipMalloc(reinterpret_cast<void **>(&ix.masked), std::max<uint64_t>(offsets[n], 1)));
+            if (e == hipSuccess && offsets[n]) ok(hipMemcpy(ix.masked, prebuilt->masked, offsets[n], hipMemcpyHostToDevice));
+            if (e == hipSuccess) rc = mk::device_index_from_file(prebuilt->fileOffsets, prebuilt->fileEntries6, prebuilt->nEntries, kmerSize, entryShift, g_stream, ix, err);
+        } else {
+            HostTimer ht("host_index_build_total");
+            mk::IndexBuildParams B;
+            B.kmer_size = kmerSize; B.kmer_thr = db->kmerThr; B.mask = P->mask != 0; B.mask_prob = static_cast<double>(P->mask_prob);
+            B.tantan_lanes = P->simd_lanes_double; B.reference_order = false; B.entry_shift = entryShift;
+            rc = mk::device_build_index(db->dRes.p, db->dOff.p, db->off, n, db->kmerMat, B, g_stream, ix, err, timed_begin, timed_end);
+            timed_flush();
+        }
+        if (e != hipSuccess || rc != MK_OK) {
+            ix.release();
+            delete db;
+            return e != hipSuccess ? fail(MK_ERR_DEVICE, "target upload failed: %s", hipGetErrorString(e)) : fail(rc, "%s", err.c_str());
+        }
+        adopt_index(db, ix, offsets[n]);
     }
-    if (tooLong) { delete db; return fail(MK_ERR_UNSUPPORTED, "a k-mer occurs in 2^23 or more targets: the slot's length field holds 23 bits"); }
     mk::ScoreMat3 sm;
     mk::build_scoremat3(db->kmerMat, sm);
     int8_t matAln[441], matUng[441];
     for (int i = 0; i < 21; i++)
         for (int j = 0; j < 21; j++) { matAln[i * 21 + j] = (int8_t) db->alnMat.sub[i][j]; matUng[i * 21 + j] = (int8_t) db->ungMat.sub[i][j]; }
-    hipError_t e = hipSuccess;
-    auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; };
-    ok(db->dRes.upload(residues, offsets[n]));
-    ok(db->dMasked.upload(ix.masked.data(), ix.masked.size()));
-    ok(db->dOff.upload(offsets, n + 1));
-    ok(db->dKmerSlot.upload(slots.data(), slots.size()));
-    ok(db->dKmerBits.upload(bits.data(), bits.size()));
-    ok(db->dEntries.upload(ix.entries.data(), ix.entries.size()));
     ok(db->dScore3.upload(sm.score.data(), sm.score.size()));
     ok(db->dIndex3.upload(sm.index.data(), sm.index.size()));
     ok(db->dHist3.upload(sm.hist.data(), sm.hist.size()));
@@ -456,6 +519,8 @@ static void encode_seq_db(const mk::SeqDbImage &db, std::vector<uint8_t> &res, s
     for (size_t i = 0; i < n; i++) mk::encode(db.data.data() + db.offsets[i], off[i + 1] - off[i], res.data() + off[i]);
 }
 
+// createindex: mask + index the sequence DB and write the reference's index DB.  With a GPU (mk_init was called) the lists are built
+// in HBM (mk_index.hip) and streamed into the file -- any size, k = 6 or 7; without one the host builder does it (k = 6, no GPU needed).
 int mk_index_write(const char *indexDb, const char *seqData, uint64_t seqDataSize, const uint32_t *keys, const uint64_t *offsets,
                    const uint32_t *lengths, uint32_t n, int seqDbtype, const mk_params *P) {
     if (!indexDb || !keys || !offsets || !lengths || !P || (!seqData && seqDataSize)) return fail(MK_ERR_ARG, "null argument");
@@ -470,17 +535,45 @@ int mk_index_write(const char *indexDb, const char *seqData, uint64_t seqDataSiz
     }
     std::vector<uint8_t> res;
     encode_seq_db(c.seqs, res, c.seqOffsets);
-    if (P->kmer_size == 7 || (P->kmer_size == 0 && c.seqOffsets[n] >= 3350000000ull))
-        return fail(MK_ERR_UNSUPPORTED, "index DBs with k = 7 (-k 7, or %llu residues: the reference indexes with k = 7 from 3.35e9 on) are not implemented: search the sequence DB directly",
-                    (unsigned long long) c.seqOffsets[n]);
-    if (P->kmer_size != 0 && P->kmer_size != 6) return fail(MK_ERR_UNSUPPORTED, "-k %d: index DBs are written with k = 6", P->kmer_size);
+    if (P->kmer_size != 0 && P->kmer_size != 6 && P->kmer_size != 7) return fail(MK_ERR_UNSUPPORTED, "-k %d: index DBs are written with k = 6 or 7", P->kmer_size);
+    const int kmerSize = P->kmer_size ? P->kmer_size : (c.seqOffsets[n] < 3350000000ull ? 6 : 7);     // IndexTable::computeKmerSize
     if (P->profile_search) return fail(MK_ERR_UNSUPPORTED, "index DBs for profile queries are not implemented (they need their own masking background and an unfiltered index)");
     mk::SubMat km;
     mk::build_submat(km, mk::MAT_VTML80, 8.0f, -0.2f);
-    c.meta.kmerThr = mk::kmer_threshold(P->sensitivity, P->kmer_score);
+    c.meta.kmerSize = kmerSize;
+    c.meta.kmerThr = kmerSize == 7 ? mk::kmer_threshold_k7(P->sensitivity, P->kmer_score) : mk::kmer_threshold(P->sensitivity, P->kmer_score);
     c.meta.mask = P->mask != 0; c.meta.compBiasCorr = P->comp_bias_corr != 0; c.meta.seqType = seqDbtype; c.meta.srcSeqType = seqDbtype;
-    mk::build_index(km, res.data(), c.seqOffsets.data(), n, c.meta.kmerThr, P->mask != 0, P->mask_prob, P->simd_lanes_double, c.index, false);
-    const std::string e = mk::write_index_file(indexDb, km, c);
+    const char *ib = getenv("MK_INDEX_BUILD");
+    if (!g_ready || (ib && strcmp(ib, "host") == 0)) {
+        mk::build_index(km, res.data(), c.seqOffsets.data(), n, c.meta.kmerThr, P->mask != 0, P->mask_prob, P->simd_lanes_double, c.index, false, kmerSize);
+        const std::string e = mk::write_index_file(indexDb, km, c);
+        if (!e.empty()) return fail(MK_ERR_ARG, "%s", e.c_str());
+        return MK_OK;
+    }
+    // device build, cells in the reference's numbering; the file is written while the lists stream out of HBM
+    DevBuf<uint8_t> dRes;
+    DevBuf<uint64_t> dOff;
+    HIPCHK(dRes.upload(res.data(), c.seqOffsets[n]));
+    HIPCHK(dOff.upload(c.seqOffsets.data(), n + 1));
+    mk::IndexBuildParams B;
+    B.kmer_size = kmerSize; B.kmer_thr = c.meta.kmerThr; B.mask = P->mask != 0; B.mask_prob = static_cast<double>(P->mask_prob);
+    B.tantan_lanes = P->simd_lanes_double; B.reference_order = true; B.entry_shift = 0;
+    mk::DeviceIndex ix;
+    std::string err;
+    int rc = mk::device_build_index(dRes.p, dOff.p, c.seqOffsets, n, km, B, g_stream, ix, err, nullptr, nullptr);
+    if (rc != MK_OK) { ix.release(); return fail(rc, "%s", err.c_str()); }
+    std::vector<uint8_t> masked(c.seqOffsets[n]);
+    if (c.seqOffsets[n] && hipMemcpy(masked.data(), ix.masked, c.seqOffsets[n], hipMemcpyDeviceToHost) != hipSuccess) { ix.release(); return fail(MK_ERR_DEVICE, "cannot fetch the masked residues"); }
+    std::vector<uint64_t> listOff;
+    mk::IndexListSource src;
+    src.cells = ix.cells; src.nEntries = ix.n_entries;
+    src.masked = masked.data(); src.maskedSize = masked.size();
+    int rcStream = MK_OK;
+    src.entries6 = [&](const std::function<bool(const void *, size_t)> &sink) { rcStream = mk::device_index_entries6(ix, g_stream, sink, err); return rcStream == MK_OK; };
+    src.offsets = [&]() -> const uint64_t * { rcStream = mk::device_index_offsets(ix, g_stream, listOff, err); return rcStream == MK_OK ? listOff.data() : nullptr; };
+    const std::string e = mk::write_index_file(indexDb, km, c, src);
+    ix.release();
+    if (rcStream != MK_OK) return fail(rcStream, "%s", err.c_str());
     if (!e.empty()) return fail(MK_ERR_ARG, "%s", e.c_str());
     return MK_OK;
 }
@@ -490,15 +583,26 @@ int mk_targetdb_open_index(const char *indexDb, const mk_params *P, mk_targetdb 
     if (rc) return rc;
     if (!indexDb || !P || !out) return fail(MK_ERR_ARG, "null argument");
     mk::IndexFileContent c;
-    const std::string e = mk::read_index_file(indexDb, c);
+    const std::string e = mk::read_index_file(indexDb, c, true);
     if (!e.empty()) return fail(MK_ERR_UNSUPPORTED, "%s", e.c_str());
     std::vector<uint8_t> res;
     std::vector<uint64_t> off;
     encode_seq_db(c.seqs, res, off);
     if (off != c.seqOffsets) return fail(MK_ERR_ARG, "%s: the masked sequences do not line up with the sequence database", indexDb);
-    mk::index_to_address_order(c.index);
-    rc = targetdb_create(res.data(), off.data(), (uint32_t) c.seqs.keys.size(), P, &c.index, out);
-    if (rc == MK_OK) rc = mk_targetdb_set_keys(*out, c.seqs.keys.data(), (uint32_t) c.seqs.keys.size());
+    const std::vector<uint32_t> keys = c.seqs.keys;
+    { std::vector<char>().swap(c.seqs.data); }                           // the ASCII sequences are encoded: drop the copy
+    PrebuiltIndex pre;
+    pre.kmerSize = c.meta.kmerSize;
+    if (c.meta.kmerSize == 7) {
+        // cells of the device table = the reference's k-mer numbers: offsets and 6-byte entries go from the mapped file to HBM in pieces
+        pre.fileOffsets = c.listOffsets; pre.fileEntries6 = c.listEntries6; pre.nEntries = c.nEntries; pre.masked = c.maskedView;
+    } else {
+        mk::materialize_lists(c);
+        mk::index_to_address_order(c.index);
+        pre.host = &c.index;
+    }
+    rc = targetdb_create(res.data(), off.data(), (uint32_t) keys.size(), P, &pre, out);
+    if (rc == MK_OK) rc = mk_targetdb_set_keys(*out, keys.data(), (uint32_t) keys.size());
     return rc;
 }
 
@@ -564,7 +668,28 @@ uint64_t mk_targetdb_residues(const mk_targetdb *db) { return db ? db->off[db->n
 uint64_t mk_targetdb_index_entries(const mk_targetdb *db) { return db ? db->nEntries : 0; }
 int mk_targetdb_masked(const mk_targetdb *db, uint8_t *out) {
     if (!db || !out) return fail(MK_ERR_ARG, "null argument");
-    std::memcpy(out, db->maskedHost.data(), db->maskedHost.size());
+    const uint8_t *m = masked_host(const_cast<mk_targetdb *>(db));
+    if (!m) return fail(MK_ERR_DEVICE, "cannot fetch the masked residues from the device");
+    std::memcpy(out, m, db->off[db->n]);
+    return MK_OK;
+}
+uint64_t mk_targetdb_masked_residues(const mk_targetdb *db) { return db ? db->maskedResidues : 0; }
+int mk_targetdb_kmer_size(const mk_targetdb *db) { return db ? db->kmerSize : 0; }
+uint32_t mk_targetdb_longest_list(const mk_targetdb *db) { return db ? db->maxList : 0; }
+
+// test hook: words / entries / residues in which the tables of two databases differ (slot table, presence bits, entries, masked residues);
+// all ~0 when the sizes differ
+int mk_targetdb_index_compare(const mk_targetdb *a, const mk_targetdb *b, uint64_t diff[4]) {
+    int rc = ensure_ready();
+    if (rc) return rc;
+    if (!a || !b || !diff) return fail(MK_ERR_ARG, "null argument");
+    mk::DeviceIndex x, y;
+    x.masked = a->dMasked.p; x.slots = a->dKmerSlot.p; x.bits = a->dKmerBits.p; x.entries = a->dEntries.p; x.cells = a->cells; x.n_entries = a->nEntries;
+    y.masked = b->dMasked.p; y.slots = b->dKmerSlot.p; y.bits = b->dKmerBits.p; y.entries = b->dEntries.p; y.cells = b->cells; y.n_entries = b->nEntries;
+    std::string err;
+    if (a->off[a->n] != b->off[b->n]) { diff[0] = diff[1] = diff[2] = diff[3] = ~0ull; return MK_OK; }
+    rc = mk::device_index_compare(x, y, a->off[a->n], g_stream, diff, err);
+    if (rc != MK_OK) return fail(rc, "%s", err.c_str());
     return MK_OK;
 }
 
@@ -1007,7 +1132,7 @@ int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     {
         HostTimer ht("host_prefilter_total");
         mk::PrefilterHooks hooks;
-        hooks.t_masked_host = db->maskedHost.data();
+        hooks.t_masked_host = [db]() { return masked_host(db); };
         rc = mk::run_prefilter(prefilter_view(db, q), q->off, q->res, nullptr, db->off, *P, binCount, g_stream, q->hits, q->nHits, q->hitOff, err,
                                timed_begin, timed_end, timed_set, hooks);
     }
@@ -1226,7 +1351,7 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     mk::PrefilterHooks hooks;
     hooks.max_chunk_queries = 1u << 17;
     hooks.co_resident = true;
-    hooks.t_masked_host = db->maskedHost.data();
+    hooks.t_masked_host = [db]() { return masked_host(db); };
     if (const char *e = getenv("MK_SEARCH_CHUNK_QUERIES")) hooks.max_chunk_queries = (uint32_t) std::max(1024L, atol(e));
     hooks.on_chunk = [&](uint32_t a, uint32_t b) {
         { std::lock_guard<std::mutex> lk(pipe.m); pipe.items.emplace_back(a, b); }

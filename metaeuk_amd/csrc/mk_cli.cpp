@@ -1070,8 +1070,9 @@ int cmdPredictExons(int argc, char **argv) {
 }
 
 // createindex <i:sequenceDB> <tmpDir> [-s 7.5 ...]   M/src/workflow/CreateIndex.cpp:108-175 -> indexdb (util/indexdb.cpp:42-186)
-//   masks the targets, builds the k-mer lists and writes <sequenceDB>.idx in the reference's index DB format (type 9); no GPU is
-//   involved.  The reference's `prefilter` / `search` pick the file up like one of their own; so do the commands above.
+//   masks the targets, builds the k-mer lists and writes <sequenceDB>.idx in the reference's index DB format (type 9).  With a GPU the
+//   lists are built in HBM and streamed into the file (k = 6, and k = 7 from 3.35e9 residues on or with -k 7); without one the host
+//   builder writes a k = 6 index.  The reference's `prefilter` / `search` pick the file up like one of their own; so do the commands above.
 int cmdCreateIndex(int argc, char **argv) {
     Args a;
     if (int rc = parse(argc, argv, a)) return rc;
@@ -1089,9 +1090,10 @@ int cmdCreateIndex(int argc, char **argv) {
     std::vector<uint64_t> offs(ord.size());
     for (size_t i = 0; i < ord.size(); i++) { keys[i] = db.entries[ord[i]].key; offs[i] = db.entries[ord[i]].offset; lens[i] = (uint32_t) db.entries[ord[i]].length; }
     const std::string out = a.pos[0] + ".idx";
+    const bool onGpu = mk_init(gpu) == MK_OK;                          // (no device: mk_index_write builds on the host)
     if (mk_index_write(out.c_str(), db.data.data(), db.data.size(), keys.data(), offs.data(), lens.data(), (uint32_t) ord.size(), db.dbtype, &P) != MK_OK)
         return die("%s", mk_last_error());
-    fprintf(stderr, "createindex: %zu sequences -> %s, %.2f s\n", ord.size(), out.c_str(), now() - t0);
+    fprintf(stderr, "createindex: %zu sequences -> %s, %.2f s (%s)\n", ord.size(), out.c_str(), now() - t0, onGpu ? "lists built on the GPU" : "lists built on the host");
     return EXIT_SUCCESS;
 }
 

@@ -121,6 +121,7 @@ int bin_count_for(uint64_t dbSize, uint64_t l2) {
 static const uint8_t KMER_ADDR_LETTER[20] = {
     /* A */ 16, /* C */ 19, /* D */ 12, /* E */ 11, /* F */ 4, /* G */ 17, /* H */ 7, /* I */ 1, /* K */ 9, /* L */ 2,
     /* M */ 3, /* N */ 13, /* P */ 18, /* Q */ 10, /* R */ 8, /* S */ 14, /* T */ 15, /* V */ 0, /* W */ 6, /* Y */ 5};
+const uint8_t *kmer_addr_letters() { return KMER_ADDR_LETTER; }
 static inline uint16_t addr3_of_letters(int l0, int l1, int l2) {
     const int d0 = KMER_ADDR_LETTER[l0], d1 = KMER_ADDR_LETTER[l1], d2 = KMER_ADDR_LETTER[l2];
     return static_cast<uint16_t>((((d0 >> 2) + 5 * (d1 >> 2) + 25 * (d2 >> 2)) << 6) | ((d0 & 3) + 4 * (d1 & 3) + 16 * (d2 & 3)));

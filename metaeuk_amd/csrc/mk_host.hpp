@@ -65,6 +65,7 @@ void build_scoremat2(const SubMat &kmerMat, std::vector<int16_t> &score, std::ve
 void kmer3_number_of_address(uint16_t numOf[8000]);   // inverse of kmer3_address_table
 void index_to_address_order(TargetIndex &ix);
 void kmer3_address_table(uint16_t addrOf[8000]);   // reference 3-mer number -> address code (tile << 6 | in-quad positions), a permutation of 0..7999
+const uint8_t *kmer_addr_letters();                 // [20]: residue -> quad << 2 | position in the quad (the tiled address order)
 uint32_t kmer_cell(uint32_t addrFirst, uint32_t addrSecond);   // table cell of the k-mer made of two 3-mers (their address codes)
 
 struct Evaluer {

@@ -26,7 +26,6 @@ enum : uint32_t {   // PrefilteringIndexReader.cpp:10-34
 const char INDEX_VERSION[] = "16";       // MMSEQS_CURRENT_INDEX_VERSION (M/src/MMseqsBase.cpp:6)
 const int DBTYPE_INDEX_DB = 9;           // Parameters.h:77
 const size_t PAGE = 4096;
-const size_t TABLE = 64000000;           // 20^6
 const size_t ROW3 = (8000 / 64 + 1) * 64, ROW2 = (400 / 64 + 1) * 64;   // ScoreMatrix rows, MAX_ALIGN_INT = 64 (ScoreMatrix.h:45-47)
 
 // DBReader<unsigned int>::Index (DBReader.h:58-62) as the compiler lays it out: id, pad, offset, length, pad
@@ -70,6 +69,9 @@ void scorematrix2(const SubMat &km, std::vector<int16_t> &score, std::vector<uin
 
 struct Mapped {
     char *p = nullptr; size_t n = 0;
+    Mapped() = default;
+    Mapped(const Mapped &) = delete;
+    Mapped &operator=(const Mapped &) = delete;
     ~Mapped() { if (p) munmap(p, n); }
     std::string open(const std::string &path) {
         const int fd = ::open(path.c_str(), O_RDONLY);
@@ -88,6 +90,8 @@ struct Mapped {
 };
 
 }  // namespace
+
+uint64_t kmer_table_cells(int kmerSize) { return kmerSize == 7 ? 1280000000ull : 64000000ull; }
 
 std::string matrix_text(int which) {
     const bool bl = which == MAT_BLOSUM62;
@@ -112,8 +116,35 @@ std::string matrix_text(int which) {
 }
 
 std::string write_index_file(const std::string &base, const SubMat &km, const IndexFileContent &c) {
+    IndexListSource src;
+    src.cells = kmer_table_cells(c.meta.kmerSize);
+    if (c.index.offsets.size() != src.cells + 1) return "index content is inconsistent";
+    src.nEntries = c.index.entries.size();
+    src.offsets = [&c]() { return c.index.offsets.data(); };
+    src.entries6 = [&c](const std::function<bool(const void *, size_t)> &sink) {
+        const size_t ne = c.index.entries.size();
+        std::vector<unsigned char> buf;
+        const size_t CH = 1u << 20;
+        for (size_t b = 0; b < ne; b += CH) {
+            const size_t e = std::min(ne, b + CH);
+            buf.resize((e - b) * 6);
+            for (size_t k = b; k < e; k++) {
+                const uint32_t seq = static_cast<uint32_t>(c.index.entries[k]);
+                const uint16_t pos = static_cast<uint16_t>(c.index.entries[k] >> 32);
+                std::memcpy(buf.data() + (k - b) * 6, &seq, 4); std::memcpy(buf.data() + (k - b) * 6 + 4, &pos, 2);
+            }
+            if (!sink(buf.data(), buf.size())) return false;
+        }
+        return true;
+    };
+    src.masked = c.index.masked.data(); src.maskedSize = c.index.masked.size();
+    return write_index_file(base, km, c, src);
+}
+
+std::string write_index_file(const std::string &base, const SubMat &km, const IndexFileContent &c, const IndexListSource &src) {
     const size_t n = c.seqs.keys.size();
-    if (c.index.offsets.size() != TABLE + 1 || c.seqOffsets.size() != n + 1) return "index content is inconsistent";
+    const size_t TABLE = src.cells;
+    if (TABLE != kmer_table_cells(c.meta.kmerSize) || c.seqOffsets.size() != n + 1) return "index content is inconsistent";
     remove((base + ".dbtype").c_str());
     Writer w;
     w.f = fopen(base.c_str(), "wb");
@@ -175,34 +206,26 @@ std::string write_index_file(const std::string &base, const SubMat &km, const In
         w.raw(s2.data(), s2.size() * 2); w.raw(i2.data(), i2.size() * 4);
         w.end(K_SCOREMATRIX2MER, t);
     }
-    {   // IndexEntryLocal{u32 seqId; u16 position_j} packed (IndexTable.h:25-27), offsets size_t[20^6 + 1]
+    {   // IndexEntryLocal{u32 seqId; u16 position_j} packed (IndexTable.h:25-27), offsets size_t[cells + 1]
         const uint64_t s = w.begin();
-        const size_t ne = c.index.entries.size();
-        std::vector<unsigned char> buf;
-        const size_t CH = 1u << 20;
-        for (size_t b = 0; b < ne; b += CH) {
-            const size_t e = std::min(ne, b + CH);
-            buf.resize((e - b) * 6);
-            for (size_t k = b; k < e; k++) {
-                const uint32_t seq = static_cast<uint32_t>(c.index.entries[k]);
-                const uint16_t pos = static_cast<uint16_t>(c.index.entries[k] >> 32);
-                std::memcpy(buf.data() + (k - b) * 6, &seq, 4); std::memcpy(buf.data() + (k - b) * 6 + 4, &pos, 2);
-            }
-            w.raw(buf.data(), buf.size());
-        }
+        uint64_t written = 0;
+        if (!src.entries6([&](const void *p, size_t bytes) { w.raw(p, bytes); written += bytes; return w.ok; })) { fclose(w.f); return "write to " + base + " failed"; }
+        if (written != src.nEntries * 6) { fclose(w.f); return "index content is inconsistent (entries)"; }
         w.end(K_ENTRIES, s);
-        w.put(K_ENTRIESOFFSETS, c.index.offsets.data(), (TABLE + 1) * 8);
-        const uint64_t num = ne;
+        const uint64_t *off = src.offsets();
+        if (!off || off[TABLE] != src.nEntries) { fclose(w.f); return "index content is inconsistent (offsets)"; }
+        w.put(K_ENTRIESOFFSETS, off, (TABLE + 1) * 8);
+        const uint64_t num = src.nEntries;
         w.put(K_ENTRIESNUM, &num, 8);
     }
     {
         const uint64_t count = n;
         w.put(K_SEQCOUNT, &count, 8);
-        const int64_t dataSize = static_cast<int64_t>(c.index.masked.size());
+        const int64_t dataSize = static_cast<int64_t>(src.maskedSize);
         w.put(K_SEQINDEXDATASIZE, &dataSize, 8);
         w.put(K_SEQINDEXSEQOFFSET, c.seqOffsets.data(), (n + 1) * 8);
         const uint64_t s = w.begin();
-        w.raw(c.index.masked.data(), c.index.masked.size());
+        w.raw(src.masked, src.maskedSize);
         const char z = 0;
         w.raw(&z, 1);                                                  // getDataSize() + 1 bytes (:303)
         w.end(K_SEQINDEXDATA, s);
@@ -211,7 +234,9 @@ std::string write_index_file(const std::string &base, const SubMat &km, const In
     std::stable_sort(w.recs.begin(), w.recs.end(), [](const Writer::Rec &a, const Writer::Rec &b) { return a.key < b.key; });
     FILE *i = fopen((base + ".index").c_str(), "wb");
     if (!i) return "cannot create " + base + ".index";
-    for (const Writer::Rec &r : w.recs) fprintf(i, "%u\t%llu\t%llu\n", r.key, (unsigned long long) r.offset, (unsigned long long) r.length);
+    // lengths modulo 2^32, as the reference's own index files hold them (DBReader::Index::length is an unsigned int and DBWriter::sortIndex
+    // writes the final .index through it): the 10 GB of k = 7 list offsets read 1650065417
+    for (const Writer::Rec &r : w.recs) fprintf(i, "%u\t%llu\t%llu\n", r.key, (unsigned long long) r.offset, (unsigned long long) (r.length & 0xFFFFFFFFull));
     if (fclose(i) != 0) return "cannot close " + base + ".index";
     FILE *t = fopen((base + ".dbtype").c_str(), "wb");
     if (!t) return "cannot create " + base + ".dbtype";
@@ -221,7 +246,7 @@ std::string write_index_file(const std::string &base, const SubMat &km, const In
     return "";
 }
 
-std::string read_index_file(const std::string &base, IndexFileContent &c) {
+std::string read_index_file(const std::string &base, IndexFileContent &c, bool viewLists) {
     struct stat st;
     std::string dataPath = base;
     if (stat(dataPath.c_str(), &st) != 0) {
@@ -229,7 +254,9 @@ std::string read_index_file(const std::string &base, IndexFileContent &c) {
         if (stat(dataPath.c_str(), &st) != 0) return "index database " + base + " has no data file";
         if (stat((base + ".1").c_str(), &st) == 0) return "index databases in several data files (--split > 1) are not implemented";
     }
-    Mapped idx, dat;
+    Mapped idx;
+    std::shared_ptr<Mapped> datp = std::make_shared<Mapped>();
+    Mapped &dat = *datp;
     std::string e = idx.open(base + ".index");
     if (!e.empty()) return e;
     e = dat.open(dataPath);
@@ -243,11 +270,24 @@ std::string read_index_file(const std::string &base, IndexFileContent &c) {
         Ent x;
         x.offset = strtoull(q, &q, 10);
         x.length = strtoull(q, &q, 10);
-        if (x.offset + x.length > dat.n || x.length == 0) return "index of " + base + " points outside the data file";
+        if (x.offset >= dat.n || x.length == 0) return "index of " + base + " points outside the data file";
         ent[key] = x;
         p = q;
         while (p < end && *p != '\n') p++;
         if (p < end) p++;
+    }
+    {   // the reference keeps an entry's length in 32 bits (DBReader::Index::length; DBWriter::sortIndex re-writes the .index through it), so an
+        // entry of 4 GB or more -- the 10 GB of k = 7 list offsets, the entries of a large database -- is recorded modulo 2^32: its true length
+        // is the value of that residue class that fills the room up to the next entry (entries are padded to pages only)
+        std::vector<uint64_t> starts;
+        for (const auto &kv : ent) starts.push_back(kv.second.offset);
+        starts.push_back(dat.n);
+        std::sort(starts.begin(), starts.end());
+        for (auto &kv : ent) {
+            const uint64_t room = *std::upper_bound(starts.begin(), starts.end(), kv.second.offset) - kv.second.offset;
+            if (kv.second.length <= 0xFFFFFFFFull && room > kv.second.length) kv.second.length += ((room - kv.second.length) >> 32) << 32;
+            if (kv.second.offset + kv.second.length > dat.n) return "index of " + base + " points outside the data file";
+        }
     }
     auto need = [&](uint32_t key, const char *&p, uint64_t &len) -> bool {
         auto it = ent.find(key);
@@ -264,12 +304,13 @@ std::string read_index_file(const std::string &base, IndexFileContent &c) {
     c.meta.maxSeqLen = meta[0]; c.meta.kmerSize = meta[1]; c.meta.compBiasCorr = meta[2]; c.meta.alphabetSize = meta[3]; c.meta.mask = meta[4];
     c.meta.spacedKmer = meta[5]; c.meta.kmerThr = meta[6]; c.meta.seqType = meta[7]; c.meta.srcSeqType = meta[8]; c.meta.headers1 = meta[9];
     c.meta.headers2 = meta[10]; c.meta.splits = meta[11] == 0 ? 1 : meta[11];
-    if (c.meta.kmerSize != KMER) return "the index was built with -k " + std::to_string(c.meta.kmerSize) + ": only k = 6 is implemented";
+    if (c.meta.kmerSize != 6 && c.meta.kmerSize != 7) return "the index was built with -k " + std::to_string(c.meta.kmerSize) + ": k = 6 and 7 are implemented";
+    const size_t TABLE = kmer_table_cells(c.meta.kmerSize);
     if (c.meta.alphabetSize != ALPH) return "the index was built with --alph-size " + std::to_string(c.meta.alphabetSize) + ": only 21 is implemented";
     if ((c.meta.seqType & 0xFFFF) != 0) return "only amino-acid target indices are implemented (profile targets: SURVEY 8f-4)";
     if (c.meta.splits != 1) return "index databases with --split > 1 are not implemented";
     if (c.meta.spacedKmer != 1) return "the index was built without spaced k-mers: not implemented";
-    if (need(K_SPACEDPATTERN, p, len) && len > 0 && std::string(p, len) != "1101010011") return "the index uses a custom spaced k-mer pattern: not implemented";
+    if (need(K_SPACEDPATTERN, p, len) && len > 0 && std::string(p, len) != (c.meta.kmerSize == 7 ? "11010110011" : "1101010011")) return "the index uses a custom spaced k-mer pattern: not implemented";
     if (!need(K_SCOREMATRIXNAME, p, len)) return base + ": no SCOREMATRIXNAME entry";
     {
         const std::string s(p, strnlen(p, len));
@@ -292,6 +333,7 @@ std::string read_index_file(const std::string &base, IndexFileContent &c) {
     }
     if (!need(K_DBR1DATA, p, len)) return base + ": the index holds no sequence data";
     c.seqs.data.assign(p, p + len);
+    if (viewLists) madvise(dat.p, dat.n, MADV_SEQUENTIAL);
     for (size_t i = 0; i < c.seqs.keys.size(); i++)
         if (c.seqs.offsets[i] + c.seqs.lengths[i] > c.seqs.data.size()) return base + ": sequence index points outside the sequence data";
     const size_t n = c.seqs.keys.size();
@@ -303,16 +345,21 @@ std::string read_index_file(const std::string &base, IndexFileContent &c) {
     std::memcpy(&seqCount, p, 8);
     if (seqCount != n) return base + ": SEQCOUNT does not match the sequence index";
     if (!need(K_ENTRIESOFFSETS, p, len) || len < (TABLE + 1) * 8) return base + ": no ENTRIESOFFSETS entry";
-    c.index.offsets.resize(TABLE + 1);
-    std::memcpy(c.index.offsets.data(), p, (TABLE + 1) * 8);
-    if (c.index.offsets[TABLE] != nEntries) return base + ": ENTRIESOFFSETS does not end at ENTRIESNUM";
+    const uint64_t *offView = reinterpret_cast<const uint64_t *>(p);             // (entries are page-aligned in the file)
+    if (offView[TABLE] != nEntries) return base + ": ENTRIESOFFSETS does not end at ENTRIESNUM";
     if (!need(K_ENTRIES, p, len) || len < nEntries * 6) return base + ": no ENTRIES entry";
-    c.index.entries.resize(nEntries);
+    const unsigned char *entView = reinterpret_cast<const unsigned char *>(p);
+    if (viewLists) {
+        c.listOffsets = offView; c.listEntries6 = entView; c.nEntries = nEntries; c.mapping = datp;
+    } else {
+        c.index.offsets.assign(offView, offView + TABLE + 1);
+        c.index.entries.resize(nEntries);
 #pragma omp parallel for schedule(static)
-    for (uint64_t k = 0; k < nEntries; k++) {
-        uint32_t seq; uint16_t pos;
-        std::memcpy(&seq, p + k * 6, 4); std::memcpy(&pos, p + k * 6 + 4, 2);
-        c.index.entries[k] = static_cast<uint64_t>(seq) | (static_cast<uint64_t>(pos) << 32);
+        for (uint64_t k = 0; k < nEntries; k++) {
+            uint32_t seq; uint16_t pos;
+            std::memcpy(&seq, entView + k * 6, 4); std::memcpy(&pos, entView + k * 6 + 4, 2);
+            c.index.entries[k] = static_cast<uint64_t>(seq) | (static_cast<uint64_t>(pos) << 32);
+        }
     }
     if (!need(K_SEQINDEXDATASIZE, p, len) || len < 8) return base + ": no SEQINDEXDATASIZE entry";
     std::memcpy(&maskedSize, p, 8);
@@ -321,9 +368,27 @@ std::string read_index_file(const std::string &base, IndexFileContent &c) {
     std::memcpy(c.seqOffsets.data(), p, (n + 1) * 8);
     if (c.seqOffsets[n] != static_cast<uint64_t>(maskedSize)) return base + ": SEQINDEXSEQOFFSET does not end at SEQINDEXDATASIZE";
     if (!need(K_SEQINDEXDATA, p, len) || len < static_cast<uint64_t>(maskedSize)) return base + ": no SEQINDEXDATA entry";
-    c.index.masked.assign(p, p + maskedSize);
+    if (viewLists) c.maskedView = reinterpret_cast<const uint8_t *>(p);
+    else c.index.masked.assign(p, p + maskedSize);
     c.index.maskedResidues = 0;
     return "";
+}
+
+// the lists of a content read with viewLists = true -> host vectors (c.index), the mapping is released
+void materialize_lists(IndexFileContent &c) {
+    if (!c.listOffsets) return;
+    const size_t TABLE = kmer_table_cells(c.meta.kmerSize);
+    c.index.offsets.assign(c.listOffsets, c.listOffsets + TABLE + 1);
+    c.index.entries.resize(c.nEntries);
+    const unsigned char *entView = c.listEntries6;
+#pragma omp parallel for schedule(static)
+    for (uint64_t k = 0; k < c.nEntries; k++) {
+        uint32_t seq; uint16_t pos;
+        std::memcpy(&seq, entView + k * 6, 4); std::memcpy(&pos, entView + k * 6 + 4, 2);
+        c.index.entries[k] = static_cast<uint64_t>(seq) | (static_cast<uint64_t>(pos) << 32);
+    }
+    c.index.masked.assign(c.maskedView, c.maskedView + c.seqOffsets.back());
+    c.listOffsets = nullptr; c.listEntries6 = nullptr; c.maskedView = nullptr; c.mapping.reset();
 }
 
 }  // namespace mk

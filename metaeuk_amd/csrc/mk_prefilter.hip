@@ -1006,7 +1006,7 @@ struct Ctx {
     unsigned long long *dTotals, *hTotals;
     // host side of the batch, for the overflow path's replay (the rare query that fills the reference's databaseHits buffer)
     const std::vector<uint64_t> *qOffHost = nullptr; const std::vector<uint8_t> *qResHost = nullptr; const int8_t *qCorrHost = nullptr;
-    const uint8_t *tMaskedHost = nullptr; const std::vector<uint64_t> *tOffHost = nullptr; const SubMat *ungMat = nullptr;
+    std::function<const uint8_t *()> tMaskedHost; const std::vector<uint64_t> *tOffHost = nullptr; const SubMat *ungMat = nullptr;
     uint32_t chunkQ0 = 0;              // batch index of the chunk's first query (candidates carry chunk-local indices)
 };
 
@@ -1188,7 +1188,8 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
             totalHits = X.hTotals[0];
             ovf = X.hTotals[1] != 0;               // a query of the piece fills the reference's databaseHits buffer: it is processed alone, in segments
             if (ovf && q1 - q0 > 1) { q1 = q0 + (q1 - q0) / 2; continue; }
-            if (ovf && (V.p_sorted || !X.tMaskedHost)) { err = "a profile query overflows the reference's databaseHits buffer (QueryMatcher.cpp:281-316): not restated for profile queries"; return MK_ERR_UNSUPPORTED; }
+            if (ovf && V.p_sorted) { err = "a profile query overflows the reference's databaseHits buffer (QueryMatcher.cpp:281-316): not restated for profile queries"; return MK_ERR_UNSUPPORTED; }
+            if (ovf && !X.tMaskedHost) { err = "a query overflows the reference's databaseHits buffer (QueryMatcher.cpp:281-316) and the caller gave no access to the masked target residues"; return MK_ERR_UNSUPPORTED; }
             X.ts(thCount, 4.0 * (double) X.hTotals[2] + 8.0 * (double) totalHits + 1280.0 * (double) nPos, (double) X.hTotals[2]);   // bitmap word per k-mer, slot per non-empty k-mer, row heads per start
             hitsPerPos = std::max(1.0, (double) totalHits / (double) nPos);
             if (totalHits > HIT_CAP && q1 - q0 > 1) { q1 = q0 + (q1 - q0) / 2; continue; }
@@ -1346,9 +1347,11 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
                 int8_t m8[21 * 21];
                 for (int a = 0; a < 21; a++) for (int b = 0; b < 21; b++) m8[a * 21 + b] = (int8_t) X.ungMat->sub[a][b];
                 const uint8_t *qr = X.qResHost->data() + qs;
+                const uint8_t *tMasked = X.tMaskedHost();
+                if (!tMasked) { err = "cannot fetch the masked target residues from the device"; return MK_ERR_DEVICE; }
                 replay_overflow(cands, hSegStart, [&](uint32_t id, uint16_t diag) -> int {
                     const uint64_t ts = (*X.tOffHost)[id];
-                    return ungapped_score(m8, qr, corr.data(), L, X.tMaskedHost + ts, (uint32_t) ((*X.tOffHost)[id + 1] - ts), (uint32_t) diag);
+                    return ungapped_score(m8, qr, corr.data(), L, tMasked + ts, (uint32_t) ((*X.tOffHost)[id + 1] - ts), (uint32_t) diag);
                 }, surv);
                 const uint32_t nSurv = (uint32_t) surv.size();
                 for (uint32_t k = 0; k < nSurv; k++) { hId[k] = surv[k].id; hOrd[k] = surv[k].ordinal; hDiag[k] = surv[k].diag; }

@@ -45,8 +45,8 @@ struct PrefilterHooks {
     int max_tiers = 0;                                               // > 0: use only the first tiers of the per-query front end
     bool co_resident = false;                                        // another stage (the Smith-Waterman waves of mk_search) shares the CUs: the
                                                                      // persistent prefilter workgroups take about half of the wave slots
-    const uint8_t *t_masked_host = nullptr;                          // host copy of the masked target residues: the overflow path of a query
-                                                                     // that fills the reference's databaseHits buffer scores a few diagonals on the host
+    std::function<const uint8_t *()> t_masked_host;                  // host copy of the masked target residues (fetched on demand): the overflow path of a
+                                                                     // query that fills the reference's databaseHits buffer scores a few diagonals on the host
     std::function<void(uint32_t q0, uint32_t q1)> on_chunk;          // hits and offsets of [q0, q1) are final and in host memory
     std::function<void()> before_grow;                               // the result block is about to be re-allocated
 };

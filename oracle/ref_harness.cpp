@@ -17,10 +17,10 @@
 // compiled code.
 //
 // Modes:
-//   ref_harness pipeline <matdir> <targets.txt> <queries.txt> <outdir> [-s 5.7] [--threads N] [--dump] [--index <indexDB>]
+//   ref_harness pipeline <matdir> <targets.txt> <queries.txt> <outdir> [-s 5.7] [-k 7] [--threads N] [--dump] [--index <indexDB>]
 //     --index: the target side comes from a precomputed index DB through the reference's PrefilteringIndexReader (sequence DB,
 //     SequenceLookup, IndexTable, score matrices, seed matrix), the way Prefiltering.cpp:84-160,530-545 uses it; targets.txt is ignored
-//   ref_harness createindex <matdir> <seqDB> [-s 5.7]
+//   ref_harness createindex <matdir> <seqDB> [-s 5.7] [-k 7]
 //     = indexdb (util/indexdb.cpp:67-186): PrefilteringIndexReader::createIndexFile over the sequence DB on disk -> <seqDB>.idx
 //   ref_harness sw       <matdir> <targets.txt> <queries.txt> <pairs.txt> <out.txt> [--dbres N]
 //   ref_harness submat   <matfile.out> <bitFactor> <bias>
@@ -139,9 +139,11 @@ static int cmdPipeline(int argc, char **argv) {
     bool doAlign = true;
     size_t maxResListLen = 300;
     std::string indexDb;
+    int forcedK = 0;
     for (int a = 6; a < argc; a++) {
         std::string s = argv[a];
         if (s == "-s") sensitivity = atof(argv[++a]);
+        else if (s == "-k") forcedK = atoi(argv[++a]);
         else if (s == "--threads") threads = atoi(argv[++a]);
         else if (s == "--dump") dump = true;
         else if (s == "--no-align") doAlign = false;
@@ -177,7 +179,7 @@ static int cmdPipeline(int argc, char **argv) {
     BaseMatrix *kmerSubMat = new SubstitutionMatrix(vtml.c_str(), 8.0, -0.2f);
     BaseMatrix *ungappedSubMat = new SubstitutionMatrix(blosum.c_str(), 2.0, -0.2f);
     const int alphabetSize = kmerSubMat->alphabetSize;
-    int kmerSize = IndexTable::computeKmerSize(tdbr.getAminoAcidDBSize());
+    int kmerSize = forcedK ? forcedK : IndexTable::computeKmerSize(tdbr.getAminoAcidDBSize());      // -k (Prefiltering.cpp:98-99,181)
     if (tidxdbr) kmerSize = PrefilteringIndexReader::getMetadata(tidxdbr).kmerSize;
     const int kmerThr = kmerThreshold(sensitivity, kmerSize);
     maxResListLen = std::min(tdbr.getSize(), maxResListLen);
@@ -362,12 +364,16 @@ static int cmdCreateIndex(int argc, char **argv) {
     if (argc < 4) return 2;
     std::string matdir = argv[2], db = argv[3];
     float sensitivity = 5.7f;
-    for (int a = 4; a < argc; a++) if (std::string(argv[a]) == "-s") sensitivity = atof(argv[++a]);
+    int forcedK = 0;
+    for (int a = 4; a < argc; a++) {
+        if (std::string(argv[a]) == "-s") sensitivity = atof(argv[++a]);
+        else if (std::string(argv[a]) == "-k") forcedK = atoi(argv[++a]);
+    }
     DBReader<unsigned int> dbr(db.c_str(), (db + ".index").c_str(), 1, DBReader<unsigned int>::USE_INDEX | DBReader<unsigned int>::USE_DATA);
     dbr.open(DBReader<unsigned int>::NOSORT);
     std::string vtml = matdir + "/VTML80.out";
     BaseMatrix *seedSubMat = new SubstitutionMatrix(vtml.c_str(), 8.0, -0.2f);
-    const int kmerSize = IndexTable::computeKmerSize(dbr.getAminoAcidDBSize());
+    const int kmerSize = forcedK ? forcedK : IndexTable::computeKmerSize(dbr.getAminoAcidDBSize());     // indexdb.cpp:71-75
     const int kmerThr = kmerThreshold(sensitivity, kmerSize);
     PrefilteringIndexReader::createIndexFile(PrefilteringIndexReader::indexName(db), &dbr, NULL, NULL, NULL, NULL, seedSubMat, 65535,
                                              true, "", true, seedSubMat->alphabetSize, kmerSize, 1 /*maskMode*/, 0 /*maskLowerCase*/, 0.9f,

@@ -108,3 +108,100 @@ def test_profile_path_scale_parity(gpu_api, tmp_path):
     assert pref == open(tmp_path / "out" / "pref.txt").read()
     assert aln == open(tmp_path / "out" / "aln.txt").read()
     assert max(int(aoff[i + 1] - aoff[i]) for i in range(sample)) > 200
+
+
+def _config5_case(api, tmp_path, n_targets, forced_k, n_queries=20000, index_db=True):
+    """A database shaped like BASELINE config 5's (native generator: families of ten, 375 residues on average), masked and indexed ON THE
+    DEVICE, searched with planted fragments; the same database through a k = 7 index DB (written while the lists stream out of HBM, read
+    back from the mapped file in pieces) must give the same tables and the same bytes; the digest of the result against the reference's
+    own run over the same seeded input (tests/golden/config5_digest_<n>.json, tools/config5_digest.py)."""
+    import json
+    import sys
+    import time
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import config5_digest as c5
+    t0 = time.time()
+    res, off = api.synth_targets(n_targets, seed=c5.TARGET_SEED)
+    fr, foff, src = api.synth_fragments(n_queries, res, off, **c5.FRAGMENTS)
+    t_gen = time.time() - t0
+    gold_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config5_digest_%d.json" % n_targets)
+    gold = json.load(open(gold_path)) if os.path.exists(gold_path) else None
+    p = api.default_params()
+    p.kmer_size = forced_k
+    if gold:
+        assert gold["target_residues"] == int(off[-1]) and gold["n_queries"] == n_queries and gold["fragments"] == c5.FRAGMENTS
+        p.host_l2_bytes = gold["host_l2_bytes"]
+    api.kernel_stats(reset=True)
+    t0 = time.time()
+    db = api.TargetDB.from_codes(res, off, p)
+    t_build = time.time() - t0
+    st = api.kernel_stats()
+    assert db.kmer_size() == 7
+    q = api.Queries.from_codes(fr, foff, p)
+    t0 = time.time()
+    (hits, hoff), (alns, aoff) = api.search(db, q, p)
+    t_search = time.time() - t0
+    hbody = api.format_hits_bulk(hits, 0, int(hoff[-1]))
+    abody = api.format_alignments_bulk(alns, 0, int(aoff[-1]))
+    report = dict(n_targets=n_targets, target_residues=int(off[-1]), index_entries=db.index_entries(), masked_residues=db.masked_residues(),
+                  longest_list=db.longest_list(), t_generate_s=round(t_gen, 2), t_targetdb_s=round(t_build, 2), t_search_s=round(t_search, 2),
+                  index_kernels_ms={k: round(v["ms"], 1) for k, v in st.items() if k.startswith("index_") or k.startswith("host_index")},
+                  pref_hits=int(hoff[-1]), alignments=int(aoff[-1]))
+    # planted homologs: the fragment's source (or a member of its family) is among its alignments
+    alns_np = np.frombuffer(alns, dtype=np.dtype([("db_key", "<u4"), ("rest", "V68")])) if int(aoff[-1]) else None
+    planted = np.flatnonzero(src != 0xFFFFFFFF)
+    found = 0
+    for k in planted[:4000]:
+        keys = alns_np["db_key"][int(aoff[k]):int(aoff[k + 1])] if alns_np is not None else []
+        found += int(np.any(keys // 10 == src[k] // 10))
+    recall = found / float(min(len(planted), 4000))
+    report["planted_recall"] = round(recall, 4)
+    background = np.flatnonzero(src == 0xFFFFFFFF)
+    report["alignments_per_background_fragment"] = float(np.mean([int(aoff[k + 1] - aoff[k]) for k in background[:2000]]))
+    assert recall > 0.97, report
+    d_pref = oracle.digest_arrays(hoff, hbody, n_queries)
+    d_aln = oracle.digest_arrays(aoff, abody, n_queries)
+    if gold:
+        report["reference"] = gold["reference"]
+        assert (int(hoff[-1]), d_pref) == (gold["reference"]["pref_hits"], gold["sha256_pref"]), report
+        assert d_aln == gold["sha256_aln"], report
+    if index_db:
+        image = api.synth_seqdb(res, off)
+        t0 = time.time()
+        api.index_write(str(tmp_path / "T.idx"), image, p)
+        report["t_index_db_write_s"] = round(time.time() - t0, 2)
+        report["index_db_bytes"] = os.path.getsize(str(tmp_path / "T.idx"))
+        del image
+        t0 = time.time()
+        db2 = api.TargetDB.from_index(str(tmp_path / "T.idx"), p)
+        report["t_index_db_open_s"] = round(time.time() - t0, 2)
+        assert db2.kmer_size() == 7 and db2.index_entries() == db.index_entries()
+        assert db.index_compare(db2) == (0, 0, 0, 0)
+        db.close()
+        q2 = api.Queries.from_codes(fr, foff, p)
+        (hits2, hoff2), (alns2, aoff2) = api.search(db2, q2, p)
+        assert oracle.digest_arrays(hoff2, api.format_hits_bulk(hits2, 0, int(hoff2[-1])), n_queries) == d_pref
+        assert oracle.digest_arrays(aoff2, api.format_alignments_bulk(alns2, 0, int(aoff2[-1])), n_queries) == d_aln
+        db2.close()
+        for ext in ("", ".index", ".dbtype"):
+            os.remove(str(tmp_path / "T.idx") + ext)
+    print("config-5-shaped case:", json.dumps(report))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "config5_case_%d.json" % n_targets), "w") as f:
+            json.dump(report, f, indent=1)
+    return report
+
+
+def test_config5_shape_1e9_residues_pinned_to_the_reference(gpu_api, tmp_path):
+    """2.7 M proteins = 1.0e9 residues, -k 7: device-built index, planted homologs, and the result digest of 20 000 fragments equal to the
+    reference's own run over the same input (the largest size its index build fits the build container: 62 GB of host memory)"""
+    r = _config5_case(gpu_api, tmp_path, 2700000, 7, index_db=False)
+    assert r["index_entries"] > 9e8
+
+
+def test_config5_scale_4e9_residues_index_beyond_2_32_entries(gpu_api, tmp_path):
+    """11.8 M proteins = 4.4e9 residues: k = 7 chosen automatically (IndexTable::computeKmerSize, from 3.35e9 residues on), a real index of
+    more than 2^32 entries (40-bit list starts without MK_TEST_ENTRY_BASE), built in HBM, written as an index DB and loaded back"""
+    r = _config5_case(gpu_api, tmp_path, int(os.environ.get("MK_TEST_CONFIG5_TARGETS", "11800000")), 0)
+    assert r["target_residues"] >= 4.4e9 and r["index_entries"] > 2 ** 32

@@ -98,5 +98,4 @@ def test_cli_createindex_without_a_gpu(tmp_path):
                                "--index", str(tmp_path / name / "T.idx")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         out[name] = (open(os.path.join(d, "pref.txt")).read(), open(os.path.join(d, "aln.txt")).read())
     assert out["own"] == out["ref"] and out["own"][0].count("\n") > len(qstr) + 50
-    # an index DB with k = 7 (what the reference writes from 3.35e9 residues on) is refused, not written with k = 6
-    assert subprocess.call([build.BIN, "createindex", str(tmp_path / "own" / "T"), str(tmp_path / "tmp"), "-k", "7"], stderr=subprocess.DEVNULL) != 0
+    # (k = 7 index DBs -- 10 GB of list offsets each -- are written and read back in tests/test_gpu_index.py, on the GPU box's disk)
