@@ -148,7 +148,7 @@ def _config5_case(api, tmp_path, n_targets, forced_k, n_queries=20000, index_db=
                   index_kernels_ms={k: round(v["ms"], 1) for k, v in st.items() if k.startswith("index_") or k.startswith("host_index")},
                   pref_hits=int(hoff[-1]), alignments=int(aoff[-1]))
     # planted homologs: the fragment's source (or a member of its family) is among its alignments
-    alns_np = np.frombuffer(alns, dtype=np.dtype([("db_key", "<u4"), ("rest", "V68")])) if int(aoff[-1]) else None
+    alns_np = np.frombuffer(alns, dtype=np.dtype([("db_key", "<u4"), ("rest", "V60")])) if int(aoff[-1]) else None
     planted = np.flatnonzero(src != 0xFFFFFFFF)
     found = 0
     for k in planted[:4000]:
