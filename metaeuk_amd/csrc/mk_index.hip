@@ -255,15 +255,30 @@ __global__ __launch_bounds__(CT) void index_count_kernel(CountArgs A) {
         const int i = i0 + tid;
         const uint32_t mine = i < nStart ? cell_of<K>(seq + i, A.G) : INVALID_CELL;
         bool dup = false;
-        for (int j0 = 0; j0 < i0 + CT && j0 < nStart; j0 += TJ) {
-            __syncthreads();
-            for (int t = tid; t < TJ; t += CT) { const int j = j0 + t; sCell[t] = j < nStart ? cell_of<K>(seq + j, A.G) : INVALID_CELL; }
-            __syncthreads();
-            const int lim = min(TJ, i - j0);                                    // tile cells that lie before start i
-            const int wlim = min(TJ, i0 + w * WAVE + WAVE - 1 - j0);            // ... before the wave's last start
-            for (int t = 0; t < wlim; t += 4) {
-                const uint4 c = *reinterpret_cast<const uint4 *>(&sCell[t]);
-                dup |= (t < lim && c.x == mine) | (t + 1 < lim && c.y == mine) | (t + 2 < lim && c.z == mine) | (t + 3 < lim && c.w == mine);
+        if (nStart <= 65536) {
+            for (int j0 = 0; j0 < i0 + CT && j0 < nStart; j0 += TJ) {
+                __syncthreads();
+                for (int t = tid; t < TJ; t += CT) { const int j = j0 + t; sCell[t] = j < nStart ? cell_of<K>(seq + j, A.G) : INVALID_CELL; }
+                __syncthreads();
+                const int lim = min(TJ, i - j0);                                    // tile cells that lie before start i
+                const int wlim = min(TJ, i0 + w * WAVE + WAVE - 1 - j0);            // ... before the wave's last start
+                for (int t = 0; t < wlim; t += 4) {
+                    const uint4 c = *reinterpret_cast<const uint4 *>(&sCell[t]);
+                    dup |= (t < lim && c.x == mine) | (t + 1 < lim && c.y == mine) | (t + 2 < lim && c.z == mine) | (t + 3 < lim && c.w == mine);
+                }
+            }
+        } else {
+            // index positions are 16 bits wide (IndexEntryLocal::position_j): the reference sorts a sequence's k-mers by (k-mer, position as
+            // stored) and keeps the first, so beyond 65536 residues "first" means the smallest WRAPPED position -- every start is compared
+            const uint32_t key = (((uint32_t) i & 0xFFFFu) << 16) | ((uint32_t) i >> 16);
+            for (int j0 = 0; j0 < nStart; j0 += TJ) {
+                __syncthreads();
+                for (int t = tid; t < TJ; t += CT) { const int j = j0 + t; sCell[t] = j < nStart ? cell_of<K>(seq + j, A.G) : INVALID_CELL; }
+                __syncthreads();
+                for (int t = 0; t < TJ; t++) {
+                    const uint32_t j = (uint32_t) (j0 + t);
+                    dup |= sCell[t] == mine && (((j & 0xFFFFu) << 16) | (j >> 16)) < key;
+                }
             }
         }
         const bool first = mine != INVALID_CELL && !dup;

@@ -192,4 +192,4 @@ def test_k7_index_db_both_directions_against_the_reference(gpu_api, tmp_path):
     subprocess.check_call([oracle.REF, "pipeline", mat, str(tmp_path / "t_unused.txt"), str(tmp_path / "q.txt"), str(tmp_path / "pipe"), "-s", "5.7", "--threads", "8",
                            "--no-align", "--index", str(tmp_path / "own.idx")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     ref_pref = "".join(oracle.read_blocks(str(tmp_path / "pipe" / "pref.txt")))
-    assert ref_pref == first[0].decode() and ref_pref.count("\n") > 2000
+    assert ref_pref == first[0].decode() and ref_pref.count("\n") > 200
