@@ -20,6 +20,17 @@
 //   ref_harness pipeline <matdir> <targets.txt> <queries.txt> <outdir> [-s 5.7] [-k 7] [--threads N] [--dump] [--index <indexDB>]
 //     --index: the target side comes from a precomputed index DB through the reference's PrefilteringIndexReader (sequence DB,
 //     SequenceLookup, IndexTable, score matrices, seed matrix), the way Prefiltering.cpp:84-160,530-545 uses it; targets.txt is ignored
+//     --split N: TARGET_DB_SPLIT (Prefiltering.cpp:352-362,725-750,957-1003): N residue-balanced target ranges, each with its own
+//     index, k from the residues of the range, --max-seqs reduced to max/N + 4 sqrt(max/N), the N prefilter DBs joined by the
+//     reference's own Prefiltering::mergeTargetSplits (Prefiltering.cpp:379-496, compiled in place)
+//   ref_harness profilesearch <matdir> <profile DB data file> <its .index> <fragments.txt> <outdir> [-s 4] [-e 100] [--eval-abs X]
+//                [--keys keys.txt] [--threads N]
+//     = the sliced target-profile search of `predictexons contigsDB profileDB` (searchslicedtargetprofile.sh; Search.cpp:357-399) for one
+//       slice: prefilter with the PROFILES as queries (Sequence::mapProfile, profile k-mer lists, QueryMatcher with setProfileMatrix)
+//       against the fragments, align (Matcher with a profile query), swapresults (Matcher::result_t::swapResult + compareHits).
+//       Same arguments and output files as `mko_cli profilesearch`: pref.txt / aln.txt ('>profile key' blocks in key order) and
+//       swapped.txt ('>fragment key' blocks, every fragment).  The loops are restated from Prefiltering.cpp:790-887, Alignment.cpp:
+//       279-514 and util/swapresults.cpp:254-318; every class they drive is the reference's compiled code.
 //   ref_harness createindex <matdir> <seqDB> [-s 5.7] [-k 7]
 //     = indexdb (util/indexdb.cpp:67-186): PrefilteringIndexReader::createIndexFile over the sequence DB on disk -> <seqDB>.idx
 //   ref_harness sw       <matdir> <targets.txt> <queries.txt> <pairs.txt> <out.txt> [--dbres N]
@@ -51,6 +62,8 @@
 #include "TranslateNucl.h"
 #include "PredictionParser.h"
 #include "PrefilteringIndexReader.h"
+#include "Prefiltering.h"
+#include "DBWriter.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -85,14 +98,14 @@ static std::vector<std::string> readLines(const char *path) {
 
 // Write a sequence DB in the MMseqs2 on-disk format
 // (DBWriter.cpp:401-428 index lines, :193-213 dbtype; entries are "SEQ\n\0").
-static void writeSeqDb(const std::string &base, const std::vector<std::string> &seqs) {
+static void writeSeqDb(const std::string &base, const std::vector<std::string> &seqs, const std::vector<unsigned int> *keys = NULL) {
     FILE *d = fopen(base.c_str(), "wb");
     FILE *i = fopen((base + ".index").c_str(), "wb");
     size_t off = 0;
     for (size_t k = 0; k < seqs.size(); k++) {
         fwrite(seqs[k].data(), 1, seqs[k].size(), d);
         fputc('\n', d); fputc('\0', d);
-        fprintf(i, "%zu\t%zu\t%zu\n", k, off, seqs[k].size() + 2);
+        fprintf(i, "%zu\t%zu\t%zu\n", keys ? (size_t) (*keys)[k] : k, off, seqs[k].size() + 2);
         off += seqs[k].size() + 2;
     }
     fclose(d); fclose(i);
@@ -140,10 +153,12 @@ static int cmdPipeline(int argc, char **argv) {
     size_t maxResListLen = 300;
     std::string indexDb;
     int forcedK = 0;
+    int splits = 1;
     for (int a = 6; a < argc; a++) {
         std::string s = argv[a];
         if (s == "-s") sensitivity = atof(argv[++a]);
         else if (s == "-k") forcedK = atoi(argv[++a]);
+        else if (s == "--split") splits = std::max(1, atoi(argv[++a]));
         else if (s == "--threads") threads = atoi(argv[++a]);
         else if (s == "--dump") dump = true;
         else if (s == "--no-align") doAlign = false;
@@ -179,10 +194,16 @@ static int cmdPipeline(int argc, char **argv) {
     BaseMatrix *kmerSubMat = new SubstitutionMatrix(vtml.c_str(), 8.0, -0.2f);
     BaseMatrix *ungappedSubMat = new SubstitutionMatrix(blosum.c_str(), 2.0, -0.2f);
     const int alphabetSize = kmerSubMat->alphabetSize;
-    int kmerSize = forcedK ? forcedK : IndexTable::computeKmerSize(tdbr.getAminoAcidDBSize());      // -k (Prefiltering.cpp:98-99,181)
+    // Prefiltering::setupSplit (Prefiltering.cpp:352-362): k from the residues per split, --max-seqs reduced for TARGET_DB_SPLIT
+    int kmerSize = forcedK ? forcedK : IndexTable::computeKmerSize(tdbr.getAminoAcidDBSize() / std::max(splits, 1));      // -k (Prefiltering.cpp:98-99,181)
     if (tidxdbr) kmerSize = PrefilteringIndexReader::getMetadata(tidxdbr).kmerSize;
     const int kmerThr = kmerThreshold(sensitivity, kmerSize);
     maxResListLen = std::min(tdbr.getSize(), maxResListLen);
+    if (splits > 1) {
+        if (tidxdbr) { fprintf(stderr, "--split with --index is not part of this harness\n"); return 2; }
+        size_t fourTimesStdDeviation = 4 * sqrt(static_cast<double>(maxResListLen) / static_cast<double>(splits));
+        maxResListLen = std::max(static_cast<size_t>(1), (maxResListLen / splits) + fourTimesStdDeviation);
+    }
     double t0 = now();
     // Prefiltering.cpp:208-213
     ScoreMatrix _2mer, _3mer;
@@ -196,6 +217,20 @@ static int cmdPipeline(int argc, char **argv) {
         kmerSubMat->alphabetSize = alphabetSize;
     }
     double tExt = now() - t0;
+    const size_t nq = qdbr.getSize();
+    std::vector<std::string> prefOut(nq), alnOut(nq);
+    std::vector<std::string> statOut(nq);
+    size_t totalHits = 0;
+    double kmersPerPos = 0; size_t dbMatches = 0;
+    double tIndex = 0, tPrefAcc = 0;
+    std::vector<std::pair<std::string, std::string>> splitFiles;
+    for (int split = 0; split < splits; split++) {
+    // Prefiltering::runSplit, TARGET_DB_SPLIT (Prefiltering.cpp:733-750): the split's target range
+    size_t dbFrom = 0, dbSize = tdbr.getSize();
+    if (splits > 1) {
+        tdbr.decomposeDomainByAminoAcid(split, splits, &dbFrom, &dbSize);
+        if (dbSize == 0) continue;
+    }
     // Prefiltering.cpp:514-553
     t0 = now();
     SequenceLookup *sequenceLookup = NULL;
@@ -206,14 +241,14 @@ static int cmdPipeline(int argc, char **argv) {
     } else {
         Sequence tseq(maxSeqLen, targetSeqType, kmerSubMat, kmerSize, true, true, true, "");
         indexTable = new IndexTable(alphabetSize - 1, kmerSize, false);
-        IndexBuilder::fillDatabase(indexTable, &sequenceLookup, *kmerSubMat, _3mer, _2mer, &tseq, &tdbr, 0, tdbr.getSize(),
+        IndexBuilder::fillDatabase(indexTable, &sequenceLookup, *kmerSubMat, _3mer, _2mer, &tseq, &tdbr, dbFrom, dbFrom + dbSize,
                                    kmerThr, true /*mask*/, false /*maskLowerCase*/, 0.9f /*maskProb*/, 0 /*maskNrepeats*/, 0 /*targetSearchMode*/);
     }
-    double tIndex = now() - t0;
+    tIndex += now() - t0;
 
     if (dump) {
         FILE *f = fopen((outdir + "/masked_targets.txt").c_str(), "w");
-        for (size_t id = 0; id < tdbr.getSize(); id++) {
+        for (size_t id = 0; id < dbSize; id++) {
             std::pair<const unsigned char *, const unsigned int> s = sequenceLookup->getSequence(id);
             for (unsigned int p = 0; p < s.second; p++) fputc(kmerSubMat->num2aa[s.first[p]], f);
             fputc('\n', f);
@@ -231,17 +266,13 @@ static int cmdPipeline(int argc, char **argv) {
         fclose(f);
     }
 
-    const size_t nq = qdbr.getSize();
-    std::vector<std::string> prefOut(nq), alnOut(nq);
-    std::vector<std::string> statOut(nq);
-    size_t totalHits = 0;
-    double kmersPerPos = 0; size_t dbMatches = 0;
+    std::vector<std::string> splitOut(splits > 1 ? nq : 0);
     t0 = now();
 #pragma omp parallel num_threads(threads)
     {
         unsigned int thread_idx = (unsigned int) omp_get_thread_num();
         Sequence seq(qdbr.getMaxSeqLen(), querySeqType, kmerSubMat, kmerSize, true, true, true, "");
-        QueryMatcher matcher(indexTable, sequenceLookup, kmerSubMat, ungappedSubMat, kmerThr, kmerSize, tdbr.getSize(),
+        QueryMatcher matcher(indexTable, sequenceLookup, kmerSubMat, ungappedSubMat, kmerThr, kmerSize, dbSize,
                              std::max(tdbr.getMaxSeqLen(), qdbr.getMaxSeqLen()), maxResListLen, true, 1.0f,
                              true, 15, false, false);
         matcher.setSubstitutionMatrix(&_3mer, &_2mer);
@@ -252,10 +283,10 @@ static int cmdPipeline(int argc, char **argv) {
             unsigned int qKey = qdbr.getDbKey(id);
             seq.mapSequence(id, qKey, seqData, qdbr.getSeqLen(id));
             std::pair<hit_t *, size_t> res = matcher.matchQuery(&seq, UINT_MAX, false);
-            std::string &out = prefOut[id];
+            std::string &out = splits > 1 ? splitOut[id] : prefOut[id];
             for (size_t i = 0; i < res.second; i++) {
                 hit_t *h = res.first + i;
-                h->seqId = tdbr.getDbKey(h->seqId);
+                h->seqId = tdbr.getDbKey(h->seqId + dbFrom);
                 int len = QueryMatcher::prefilterHitToBuffer(buffer, *h);
                 out.append(buffer, len);
             }
@@ -269,7 +300,45 @@ static int cmdPipeline(int argc, char **argv) {
             }
         }
     }
-    double tPref = now() - t0;
+    tPrefAcc += now() - t0;
+    if (splits > 1) {
+        // the split's prefilter DB, entries in id order (what runSplit leaves after sortDatafileByIdOrder, Prefiltering.cpp:920-937)
+        const std::string base = outdir + "/_pref_split_" + std::to_string(split);
+        FILE *d = fopen(base.c_str(), "wb"), *ix = fopen((base + ".index").c_str(), "wb");
+        size_t off = 0;
+        for (size_t id = 0; id < nq; id++) {
+            fwrite(splitOut[id].data(), 1, splitOut[id].size(), d);
+            fputc('\0', d);
+            fprintf(ix, "%u\t%zu\t%zu\n", qdbr.getDbKey(id), off, splitOut[id].size() + 1);
+            off += splitOut[id].size() + 1;
+        }
+        fclose(d); fclose(ix);
+        FILE *t = fopen((base + ".dbtype").c_str(), "wb");
+        int dbtype = Parameters::DBTYPE_PREFILTER_RES;
+        fwrite(&dbtype, 4, 1, t);
+        fclose(t);
+        splitFiles.push_back(std::make_pair(base, base + ".index"));
+        delete indexTable;
+        delete sequenceLookup;
+    }
+    }   // splits
+    t0 = now();
+    if (splits > 1) {
+        // the reference's own merge (Prefiltering.cpp:379-496), then the merged DB back into memory
+        const std::string merged = outdir + "/_pref_merged";
+        Prefiltering::mergeTargetSplits(merged, merged + ".index", splitFiles, threads);
+        DBReader<unsigned int> mdbr(merged.c_str(), (merged + ".index").c_str(), 1, DBReader<unsigned int>::USE_INDEX | DBReader<unsigned int>::USE_DATA);
+        mdbr.open(DBReader<unsigned int>::NOSORT);
+        totalHits = 0;
+        for (size_t id = 0; id < nq; id++) {
+            const size_t mid = mdbr.getId(qdbr.getDbKey(id));
+            prefOut[id] = mid == UINT_MAX ? std::string() : std::string(mdbr.getData(mid, 0));
+            for (char ch : prefOut[id]) totalHits += ch == '\n';
+        }
+        mdbr.close();
+    }
+    tPrefAcc += now() - t0;
+    const double tPref = tPrefAcc;
 
     // ---------------- align (Alignment.cpp) ----------------
     size_t alignmentsNum = 0, totalPassed = 0;
@@ -603,12 +672,193 @@ static int cmdExons(int argc, char **argv) {
     return 0;
 }
 
+// The sliced target-profile search of `predictexons contigsDB profileDB` for one slice (see the header of this file).
+static int cmdProfileSearch(int argc, char **argv) {
+    if (argc < 7) return 2;
+    const std::string matdir = argv[2], profData = argv[3], profIndex = argv[4], outdir = argv[6];
+    std::vector<std::string> frags = readLines(argv[5]);
+    float sensitivity = 4.0f;
+    double evalThr = 100.0, evalAbs = -1.0;
+    int threads = 1;
+    std::string keysPath;
+    for (int a = 7; a < argc; a++) {
+        std::string s = argv[a];
+        if (s == "-s") sensitivity = atof(argv[++a]);
+        else if (s == "-e") evalThr = atof(argv[++a]);
+        else if (s == "--eval-abs") evalAbs = atof(argv[++a]);
+        else if (s == "--keys") keysPath = argv[++a];
+        else if (s == "--threads") threads = atoi(argv[++a]);
+    }
+    mkdir(outdir.c_str(), 0755);
+    omp_set_num_threads(threads);
+    // the fragment DB: data in the order of fragments.txt (= the prefilter's target numbering, LINEAR_ACCCESS), keys from --keys
+    std::vector<unsigned int> fragKeys(frags.size());
+    for (size_t i = 0; i < frags.size(); i++) fragKeys[i] = (unsigned int) i;
+    if (!keysPath.empty()) {
+        std::vector<std::string> k = readLines(keysPath.c_str());
+        if (k.size() != frags.size()) { fprintf(stderr, "--keys: %zu keys for %zu fragments\n", k.size(), frags.size()); return 2; }
+        for (size_t i = 0; i < frags.size(); i++) fragKeys[i] = (unsigned int) strtoul(k[i].c_str(), NULL, 10);
+    }
+    const std::string tdb = outdir + "/_tdb", qdb = outdir + "/_qdb";
+    writeSeqDb(tdb, frags, &fragKeys);
+    {   // the profile DB as a DB triple: data file linked, index copied, dbtype = profile
+        unlink(qdb.c_str());
+        char *real = realpath(profData.c_str(), NULL);
+        if (!real || symlink(real, qdb.c_str()) != 0) { fprintf(stderr, "cannot link %s\n", profData.c_str()); return 2; }
+        free(real);
+        std::ifstream in(profIndex.c_str(), std::ios::binary);
+        std::ofstream out((qdb + ".index").c_str(), std::ios::binary);
+        out << in.rdbuf();
+        FILE *t = fopen((qdb + ".dbtype").c_str(), "wb");
+        int dbtype = Parameters::DBTYPE_HMM_PROFILE;
+        fwrite(&dbtype, 4, 1, t);
+        fclose(t);
+    }
+    DBReader<unsigned int> tdbr(tdb.c_str(), (tdb + ".index").c_str(), threads, DBReader<unsigned int>::USE_INDEX | DBReader<unsigned int>::USE_DATA);
+    tdbr.open(DBReader<unsigned int>::LINEAR_ACCCESS);
+    DBReader<unsigned int> qdbr(qdb.c_str(), (qdb + ".index").c_str(), threads, DBReader<unsigned int>::USE_INDEX | DBReader<unsigned int>::USE_DATA);
+    qdbr.open(DBReader<unsigned int>::LINEAR_ACCCESS);
+    const int querySeqType = qdbr.getDbtype(), targetSeqType = tdbr.getDbtype();
+    if (!Parameters::isEqualDbtype(querySeqType, Parameters::DBTYPE_HMM_PROFILE)) { fprintf(stderr, "not a profile DB\n"); return 2; }
+    const size_t maxSeqLen = 65535;
+    const std::string blosum = matdir + "/blosum62.out";
+    // Prefiltering.cpp:72-76: profile queries take --sub-mat for both matrices
+    BaseMatrix *kmerSubMat = new SubstitutionMatrix(blosum.c_str(), 8.0, -0.2f);
+    BaseMatrix *ungappedSubMat = new SubstitutionMatrix(blosum.c_str(), 2.0, -0.2f);
+    const int alphabetSize = kmerSubMat->alphabetSize;
+    const int kmerSize = IndexTable::computeKmerSize(tdbr.getAminoAcidDBSize());
+    float kmerThrBest = FLT_MAX;                                   // Prefiltering.cpp:1033-1046 (profile search, no context pseudo counts)
+    if (kmerSize == 5) { float base = 108.8; kmerThrBest = base - (sensitivity * 4.7); }
+    else if (kmerSize == 6) { float base = 134.35; kmerThrBest = base - (sensitivity * 6.15); }
+    else if (kmerSize == 7) { float base = 149.15; kmerThrBest = base - (sensitivity * 6.85); }
+    const int kmerThr = static_cast<int>(kmerThrBest);
+    const size_t nFrag = tdbr.getSize(), nProf = qdbr.getSize();
+    // Search.cpp:366-372: the e-value threshold scaled by #fragments / #profiles, passed on as text; --max-seqs = max(300, #fragments)
+    {
+        evalThr *= ((float) nFrag) / nProf;
+        char txt[64];
+        snprintf(txt, sizeof(txt), "%g", evalThr);
+        evalThr = strtod(txt, NULL);
+        if (evalAbs >= 0) evalThr = evalAbs;
+    }
+    size_t maxResListLen = std::max((size_t) 300, nFrag);
+    maxResListLen = std::min(tdbr.getSize(), maxResListLen);
+    ScoreMatrix _2mer, _3mer;                                      // not computed for profile queries (Prefiltering.cpp:208-213)
+    SequenceLookup *sequenceLookup = NULL;
+    Sequence tseq(maxSeqLen, targetSeqType, kmerSubMat, kmerSize, true, true, true, "");
+    IndexTable *indexTable = new IndexTable(alphabetSize - 1, kmerSize, false);
+    IndexBuilder::fillDatabase(indexTable, &sequenceLookup, *kmerSubMat, _3mer, _2mer, &tseq, &tdbr, 0, tdbr.getSize(),
+                               0 /* localKmerThr, Prefiltering.cpp:525-527 */, true, false, 0.9f, 0, 0);
+    std::vector<std::string> prefOut(nProf), alnOut(nProf);
+    size_t totalHits = 0, passed = 0;
+#pragma omp parallel num_threads(threads)
+    {
+        unsigned int thread_idx = (unsigned int) omp_get_thread_num();
+        Sequence seq(qdbr.getMaxSeqLen(), querySeqType, kmerSubMat, kmerSize, true, true, true, "");
+        QueryMatcher matcher(indexTable, sequenceLookup, kmerSubMat, ungappedSubMat, kmerThr, kmerSize, tdbr.getSize(),
+                             std::max(tdbr.getMaxSeqLen(), qdbr.getMaxSeqLen()), maxResListLen, true, 1.0f, true, 15, false, false);
+        matcher.setProfileMatrix(seq.profile_matrix);
+        char buffer[128];
+#pragma omp for schedule(dynamic, 1) reduction(+: totalHits)
+        for (size_t id = 0; id < nProf; id++) {
+            seq.mapSequence(id, qdbr.getDbKey(id), qdbr.getData(id, thread_idx), qdbr.getSeqLen(id));
+            std::pair<hit_t *, size_t> res = matcher.matchQuery(&seq, UINT_MAX, false);
+            for (size_t i = 0; i < res.second; i++) {
+                hit_t *h = res.first + i;
+                h->seqId = tdbr.getDbKey(h->seqId);
+                prefOut[id].append(buffer, QueryMatcher::prefilterHitToBuffer(buffer, *h));
+            }
+            totalHits += res.second;
+        }
+    }
+    // ---- align (Alignment.cpp:152-154,263,279-514)
+    BaseMatrix *m = new SubstitutionMatrix(blosum.c_str(), 2.0, 0.0);
+    const int gapOpen = 11, gapExtend = 1;
+    EvalueComputation evaluer(tdbr.getAminoAcidDBSize(), m, gapOpen, gapExtend);
+    std::vector<std::vector<Matcher::result_t>> kept(nProf);
+#pragma omp parallel num_threads(threads)
+    {
+        unsigned int thread_idx = (unsigned int) omp_get_thread_num();
+        char buffer[1024 + 32768 * 4];
+        Sequence qSeq(maxSeqLen, querySeqType, m, 0, false, true);
+        Sequence dbSeq(maxSeqLen, targetSeqType, m, 0, false, true);
+        Matcher matcher(querySeqType, targetSeqType, std::max(tdbr.getMaxSeqLen(), qdbr.getMaxSeqLen()), m, &evaluer, true, 1.0f, gapOpen, gapExtend, 0.0f, 40);
+#pragma omp for schedule(dynamic, 1) reduction(+: passed)
+        for (size_t id = 0; id < nProf; id++) {
+            char *data = (char *) prefOut[id].c_str();
+            if (*data != '\0') {
+                qSeq.mapSequence(id, qdbr.getDbKey(id), qdbr.getData(id, thread_idx), qdbr.getSeqLen(id));
+                matcher.initQuery(&qSeq);
+            }
+            std::vector<Matcher::result_t> &swResults = kept[id];
+            while (*data != '\0') {
+                hit_t hit = QueryMatcher::parsePrefilterHit(data);
+                data = Util::skipLine(data);
+                const size_t dbId = tdbr.getId(hit.seqId);
+                dbSeq.mapSequence(dbId, hit.seqId, tdbr.getData(dbId, thread_idx), tdbr.getSeqLen(dbId));
+                Matcher::result_t res = matcher.getSWResult(&dbSeq, static_cast<int>(static_cast<short>(hit.diagonal)), false, 0, 0.0f, evalThr, Matcher::SCORE_COV, 0, false, false);
+                if (res.eval <= evalThr && res.seqId >= 0.0 && Util::hasCoverage(0.0f, 0, res.qcov, res.dbcov) && Util::hasAlignmentLength(11, res.alnLength)) {
+                    swResults.emplace_back(res);
+                    passed++;
+                }
+            }
+            if (swResults.size() > 1) SORT_SERIAL(swResults.begin(), swResults.end(), Matcher::compareHits);
+            for (size_t r = 0; r < swResults.size(); r++) alnOut[id].append(buffer, Matcher::resultToBuffer(buffer, swResults[r], false));
+        }
+    }
+    // '>profile key' blocks in key order
+    std::vector<size_t> byKey(nProf);
+    for (size_t i = 0; i < nProf; i++) byKey[i] = i;
+    std::sort(byKey.begin(), byKey.end(), [&](size_t a, size_t b) { return qdbr.getDbKey(a) < qdbr.getDbKey(b); });
+    {
+        FILE *f = fopen((outdir + "/pref.txt").c_str(), "w");
+        for (size_t k = 0; k < nProf; k++) { fprintf(f, ">%u\n", qdbr.getDbKey(byKey[k])); fputs(prefOut[byKey[k]].c_str(), f); }
+        fclose(f);
+        f = fopen((outdir + "/aln.txt").c_str(), "w");
+        for (size_t k = 0; k < nProf; k++) { fprintf(f, ">%u\n", qdbr.getDbKey(byKey[k])); fputs(alnOut[byKey[k]].c_str(), f); }
+        fclose(f);
+    }
+    // ---- swapresults (util/swapresults.cpp:74-103,254-318): every printed record parsed back, swapped with the e-value of a search
+    // against the profile DB, lists sorted with compareHits; every fragment gets an entry
+    EvalueComputation swapEvaluer(qdbr.getAminoAcidDBSize(), m, gapOpen, gapExtend);
+    unsigned int maxKey = 0;
+    for (size_t i = 0; i < nFrag; i++) maxKey = std::max(maxKey, tdbr.getDbKey(i));
+    std::vector<std::vector<Matcher::result_t>> swapped(static_cast<size_t>(maxKey) + 1);
+    for (size_t k = 0; k < nProf; k++) {
+        const size_t id = byKey[k];
+        char *data = (char *) alnOut[id].c_str();
+        while (*data != '\0') {
+            Matcher::result_t res = Matcher::parseAlignmentRecord(data, true);
+            const unsigned int fragKey = res.dbKey;
+            res.dbKey = qdbr.getDbKey(id);                          // swapresults.cpp: the record moves to the target's list under the query's key
+            Matcher::result_t::swapResult(res, swapEvaluer, false);
+            swapped[fragKey].emplace_back(res);
+            data = Util::skipLine(data);
+        }
+    }
+    {
+        FILE *f = fopen((outdir + "/swapped.txt").c_str(), "w");
+        char buffer[1024 + 32768 * 4];
+        for (size_t key = 0; key <= maxKey; key++) {
+            fprintf(f, ">%zu\n", key);
+            std::vector<Matcher::result_t> &v = swapped[key];
+            if (v.size() > 1) SORT_SERIAL(v.begin(), v.end(), Matcher::compareHits);
+            for (size_t j = 0; j < v.size(); j++) fwrite(buffer, 1, Matcher::resultToBuffer(buffer, v[j], false, false), f);
+        }
+        fclose(f);
+    }
+    printf("{\"profiles\": %zu, \"fragments\": %zu, \"k\": %d, \"kmer_thr\": %d, \"eval_thr\": %.17g, \"profile_db_residues\": %zu, \"pref_hits\": %zu, \"passed\": %zu}\n",
+           nProf, nFrag, kmerSize, kmerThr, evalThr, (size_t) qdbr.getAminoAcidDBSize(), totalHits, passed);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc >= 2 && std::string(argv[1]) == "createindex") return cmdCreateIndex(argc, argv);
     if (argc < 2) { fprintf(stderr, "usage: ref_harness pipeline|sw|submat ...\n"); return 2; }
     std::string cmd = argv[1];
     if (cmd == "submat") return cmdSubmat(argc, argv);
     if (cmd == "pipeline") return cmdPipeline(argc, argv);
+    if (cmd == "profilesearch") return cmdProfileSearch(argc, argv);
     if (cmd == "sw") return cmdSw(argc, argv);
     if (cmd == "orfs") return cmdOrfs(argc, argv);
     if (cmd == "exons") return cmdExons(argc, argv);

@@ -8,6 +8,13 @@ sources, AVX2 and SSE4.1 builds must agree):
           SSE4.1 build return different garbage (no end position, uninitialised e-value) -- sw_saturation() checks that and
           keeps such pairs out of the fixture.
 
+  round 3: the fixtures of the profile-target path (prof_pref / prof_aln / prof_search_res), of k = 7 (e2e_process_pref_k7) and of the
+  target splits (e2e_process_pref_split3_maxseqs20) regenerated from `ref_harness profilesearch`, `pipeline -k 7` and `pipeline --split 3`
+  -- the reference's translation units compiled by oracle/Makefile.ref (Sequence::mapProfile, KmerGenerator's profile and k = 7 divide
+  strategies, Matcher PROFILE_SEQ, result_t::swapResult, Prefiltering::mergeTargetSplits) -- and REQUIRED to equal, byte for byte, the
+  files the real binary wrote (make_process_golden.sh / make_profile_golden.sh): harness_regenerated() raises otherwise.  tests/
+  test_oracle_golden.py repeats the comparison on every CPU run in the build container.
+
   python tests/golden/make_golden_r2.py
 """
 import gzip
@@ -67,8 +74,52 @@ def sw_saturation(tmp):
     return [targets[k] for k in keep], [queries[k] for k in keep], "\n".join(rows) + "\n"
 
 
+def read_gz(name):
+    with gzip.open(os.path.join(HERE, name), "rt") as f:
+        return f.read()
+
+
+def harness_regenerated(tmp, ref=REF_AVX2, threads=8, k7_fragments=None):
+    """{fixture name: text} of the profile / k = 7 / target-split fixtures as the reference harness produces them"""
+    out = {}
+    frags = [l.rsplit("\t", 1)[1] for l in read_gz("e2e_process_orfs.txt.gz").splitlines()]
+    order = [int(x) for x in read_gz("prof_frag_order.txt.gz").split()]
+    with open(os.path.join(tmp, "prof.bin"), "wb") as f:
+        f.write(gzip.open(os.path.join(HERE, "prof_db.bin.gz"), "rb").read())
+    with open(os.path.join(tmp, "frags.txt"), "w") as f:
+        f.write("\n".join(frags[k] for k in order) + "\n")
+    with open(os.path.join(tmp, "keys.txt"), "w") as f:
+        f.write("\n".join(str(k) for k in order) + "\n")
+    quiet = dict(stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([ref, "profilesearch", MATDIR, os.path.join(tmp, "prof.bin"), os.path.join(HERE, "prof_db.index"), os.path.join(tmp, "frags.txt"),
+                           os.path.join(tmp, "prof"), "--keys", os.path.join(tmp, "keys.txt"), "--threads", str(threads)], **quiet)
+    for f, name in (("pref.txt", "prof_pref.txt.gz"), ("aln.txt", "prof_aln.txt.gz"), ("swapped.txt", "prof_search_res.txt.gz")):
+        out[name] = open(os.path.join(tmp, "prof", f)).read()
+    with open(os.path.join(tmp, "t.txt"), "w") as f:
+        f.write(read_gz("e2e_targets.txt.gz"))
+    with open(os.path.join(tmp, "q.txt"), "w") as f:
+        f.write("".join(x + "\n" for x in frags))
+    subprocess.check_call([ref, "pipeline", MATDIR, os.path.join(tmp, "t.txt"), os.path.join(tmp, "q.txt"), os.path.join(tmp, "split"), "-s", "5.7", "--split", "3",
+                           "--max-seqs", "20", "--threads", str(threads), "--no-align"], **quiet)
+    out["e2e_process_pref_split3_maxseqs20.txt.gz"] = open(os.path.join(tmp, "split", "pref.txt")).read()
+    if k7_fragments:                     # (a prefix: the k = 7 index table costs the reference ~1 minute to set up and ~10 ms per fragment)
+        with open(os.path.join(tmp, "q.txt"), "w") as f:
+            f.write("".join(x + "\n" for x in frags[:k7_fragments]))
+    subprocess.check_call([ref, "pipeline", MATDIR, os.path.join(tmp, "t.txt"), os.path.join(tmp, "q.txt"), os.path.join(tmp, "k7"), "-s", "5.7", "-k", "7",
+                           "--threads", str(threads), "--no-align"], **quiet)
+    out["e2e_process_pref_k7.txt.gz"] = open(os.path.join(tmp, "k7", "pref.txt")).read()
+    return out
+
+
 def main():
     with tempfile.TemporaryDirectory() as tmp:
+        for ref in (REF_AVX2, REF_SSE):
+            if not os.path.exists(ref):
+                continue
+            for name, text in harness_regenerated(tmp, ref).items():
+                if text != read_gz(name):
+                    raise SystemExit("%s: %s differs from the real binary's file" % (ref, name))
+                print("%s == %s" % (name, os.path.relpath(ref, ROOT)))
         t, q, sw = sw_saturation(tmp)
         write("sw2_targets.txt.gz", "\n".join(t) + "\n")
         write("sw2_queries.txt.gz", "\n".join(q) + "\n")

@@ -123,6 +123,25 @@ def test_oracle_target_splits_match_the_real_process(tmp_path):
     assert open(tmp_path / "out" / "pref.txt").read() == _text("e2e_process_pref_split3_maxseqs20.txt.gz")
 
 
+@pytest.mark.skipif(not os.path.exists(oracle.REF) or not os.path.isdir("/root/reference"), reason="reference harness not built here")
+def test_reference_harness_reproduces_the_real_process_fixtures(tmp_path):
+    """The fixtures that only the real binary had written (profile-target path, k = 7, target splits) come out of oracle/_ref/ref_harness
+    as well: the reference's own translation units, compiled in place by oracle/Makefile.ref (no cmake, no stand-in files), driven by
+    `profilesearch`, `pipeline -k 7` and `pipeline --split 3`.  With this the oracle's restatement of Sequence::mapProfile, the profile and
+    k = 7 k-mer lists, PROFILE_SEQ Smith-Waterman, swapResult and mergeTargetSplits is pinned to reference code compiled HERE."""
+    import sys
+    sys.path.insert(0, GOLD)
+    import make_golden_r2 as mg
+    got = mg.harness_regenerated(str(tmp_path), threads=4, k7_fragments=2500)      # (make_golden_r2.py itself compares all 24 084 fragments)
+    assert sorted(got) == ["e2e_process_pref_k7.txt.gz", "e2e_process_pref_split3_maxseqs20.txt.gz", "prof_aln.txt.gz", "prof_pref.txt.gz", "prof_search_res.txt.gz"]
+    for name, text in got.items():
+        expected = _text(name)
+        if name == "e2e_process_pref_k7.txt.gz":
+            expected = expected[:expected.index(">2500\n")]
+        assert text == expected, name
+        assert text.count("\n") > 1000, name
+
+
 def _profile_inputs(tmp_path):
     """the fixtures of the profile-target path as files: the profile DB, the fragments in the order of their data offsets in the
     fragment DB (= the prefilter's target numbering) and their DB keys"""
