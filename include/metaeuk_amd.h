@@ -180,6 +180,18 @@ void mk_swapped_destroy(mk_swapped *s);
  * seq_id asc); seq_id = target index.  The arrays are owned by the batch handle. */
 int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *params);
 int mk_prefilter_result(const mk_queries *q, const mk_hit **hits, const uint64_t **offsets /* n+1 */);
+/* what the reference's prefilter logs about a run (Prefiltering.cpp:889-904, printStatistics :953-975), from the counters of the last
+ * mk_prefilter / mk_search over the batch: mean over the queries of (similar k-mers / query length), index entries gathered per
+ * query, queries that took the databaseHits overflow path, hits per query, median list length, queries without a hit */
+typedef struct {
+    double kmers_per_pos;
+    uint64_t db_matches_per_seq, overflows, results_per_seq, empty_results, n_queries;
+    uint32_t median_result_len, pad_;
+} mk_prefilter_stats;
+int mk_prefilter_statistics(const mk_queries *q, mk_prefilter_stats *out);
+/* the six lines as the reference prints them ("246.638184 k-mers per position\n12 DB matches per sequence\n...") */
+size_t mk_format_prefilter_statistics(char *buf, size_t cap, const mk_prefilter_stats *s, uint64_t max_results);
+
 /* install a prefilter result produced elsewhere (the `align` command reading a pref_0 DB,
  * Alignment.cpp:312-358) */
 int mk_prefilter_result_set(mk_queries *q, const mk_hit *hits, const uint64_t *offsets);

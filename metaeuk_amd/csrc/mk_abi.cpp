@@ -199,6 +199,7 @@ struct mk_queries {
     mk_params derivedWith;           // the parameters of that derivation
     // stage results (the reference hands these over through the pref_0 / search_res DBs)
     mk::HostBlock hits; size_t nHits = 0; std::vector<uint64_t> hitOff; bool havePref = false;
+    mk::PrefilterStats pfStats;      // run statistics of the prefilter over this batch (Prefiltering.cpp:889-904)
     mk::HostBlock alns; std::vector<uint64_t> alnOff; bool haveAln = false;
 };
 
@@ -1133,6 +1134,8 @@ int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *P) {
         HostTimer ht("host_prefilter_total");
         mk::PrefilterHooks hooks;
         hooks.t_masked_host = [db]() { return masked_host(db); };
+        q->pfStats = mk::PrefilterStats();
+        hooks.stats = &q->pfStats;
         rc = mk::run_prefilter(prefilter_view(db, q), q->off, q->res, nullptr, db->off, *P, binCount, g_stream, q->hits, q->nHits, q->hitOff, err,
                                timed_begin, timed_end, timed_set, hooks);
     }
@@ -1140,6 +1143,37 @@ int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     if (rc != MK_OK) return fail(rc, "%s", err.c_str());
     q->havePref = true;
     return MK_OK;
+}
+
+// the reference's prefilter statistics (Prefiltering.cpp:889-904 -> printStatistics :953-975) of the last mk_prefilter / mk_search over the batch
+int mk_prefilter_statistics(const mk_queries *q, mk_prefilter_stats *out) {
+    if (!q || !out) return fail(MK_ERR_ARG, "null argument");
+    if (!q->havePref) return fail(MK_ERR_ARG, "no prefilter result in this batch");
+    const uint64_t n = q->n;
+    std::memset(out, 0, sizeof(*out));
+    out->n_queries = n;
+    if (n == 0) return MK_OK;
+    out->kmers_per_pos = q->pfStats.kmers_per_pos / static_cast<double>(n);
+    out->db_matches_per_seq = q->pfStats.db_matches / n;
+    out->overflows = q->pfStats.overflows;
+    out->results_per_seq = q->hitOff[n] / n;
+    std::vector<uint32_t> lens(n);
+    uint64_t empty = 0;
+    for (uint64_t i = 0; i < n; i++) { lens[i] = (uint32_t) (q->hitOff[i + 1] - q->hitOff[i]); empty += lens[i] == 0; }
+    std::nth_element(lens.begin(), lens.begin() + n / 2, lens.end());
+    out->median_result_len = lens[n / 2];
+    out->empty_results = empty;
+    return MK_OK;
+}
+// "246.638184 k-mers per position\n12 DB matches per sequence\n..." as Prefiltering::printStatistics writes it
+size_t mk_format_prefilter_statistics(char *buf, size_t cap, const mk_prefilter_stats *s, uint64_t max_results) {
+    if (!buf || !s) return 0;
+    const int n = snprintf(buf, cap, "\n%f k-mers per position\n%llu DB matches per sequence\n%llu overflows\n%llu sequences passed prefiltering per query sequence%s\n"
+                                     "%u median result list length\n%llu sequences with 0 size result lists\n",
+                           s->kmers_per_pos, (unsigned long long) s->db_matches_per_seq, (unsigned long long) s->overflows, (unsigned long long) s->results_per_seq,
+                           s->results_per_seq > max_results ? " (ATTENTION: max. results were written to the output prefiltering database)" : "",
+                           s->median_result_len, (unsigned long long) s->empty_results);
+    return n < 0 || (size_t) n >= cap ? 0 : (size_t) n;
 }
 
 int mk_prefilter_result(const mk_queries *q, const mk_hit **hits, const uint64_t **offsets) {
@@ -1352,6 +1386,8 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     hooks.max_chunk_queries = 1u << 17;
     hooks.co_resident = true;
     hooks.t_masked_host = [db]() { return masked_host(db); };
+    q->pfStats = mk::PrefilterStats();
+    hooks.stats = &q->pfStats;
     if (const char *e = getenv("MK_SEARCH_CHUNK_QUERIES")) hooks.max_chunk_queries = (uint32_t) std::max(1024L, atol(e));
     hooks.on_chunk = [&](uint32_t a, uint32_t b) {
         { std::lock_guard<std::mutex> lk(pipe.m); pipe.items.emplace_back(a, b); }

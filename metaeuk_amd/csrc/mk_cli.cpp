@@ -25,6 +25,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <sys/stat.h>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -97,6 +98,15 @@ struct Args {
     std::map<std::string, std::string> opt;
 };
 
+// the run statistics the reference's prefilter logs (Prefiltering::printStatistics, Prefiltering.cpp:953-975), same six lines, on stderr
+void printPrefilterStatistics(const mk_queries *Q, const mk_params &P) {
+    mk_prefilter_stats st;
+    char buf[512];
+    if (mk_prefilter_statistics(Q, &st) != MK_OK) return;
+    const size_t n = mk_format_prefilter_statistics(buf, sizeof(buf), &st, (uint64_t) P.max_seqs);
+    fwrite(buf, 1, n, stderr);
+}
+
 int parse(int argc, char **argv, Args &a) {
     for (int i = 2; i < argc; i++) {
         const std::string s = argv[i];
@@ -121,7 +131,7 @@ int parse(int argc, char **argv, Args &a) {
         if (it == a.opt.end() || k.honoured) continue;
         std::string v = it->second, d = k.def;
         if (std::string(k.name) == "--alph-size" || std::string(k.name) == "--sub-mat" || std::string(k.name) == "--seed-sub-mat") { v = aaPart(v); d = aaPart(d); }
-        if (std::string(k.name) == "--max-seq-len" || std::string(k.name) == "--split-memory-limit" || std::string(k.name) == "--local-tmp" ||
+        if (std::string(k.name) == "--split-memory-limit" || std::string(k.name) == "--local-tmp" ||
             std::string(k.name) == "--db-load-mode" || std::string(k.name) == "--split" || std::string(k.name) == "--split-mode" ||
             std::string(k.name) == "--pca" || std::string(k.name) == "--pcb" || std::string(k.name) == "--zdrop" || std::string(k.name) == "--realign-score-bias" ||
             std::string(k.name) == "--realign-max-seqs" || std::string(k.name) == "--seq-id-mode" || std::string(k.name) == "--mask-lower-case" ||
@@ -263,16 +273,28 @@ int openTarget(const std::string &path, const mk_params &P, TargetSide &ts) {
 // collective: the workers only meet in the file system.  --shard r/N, else RANK / WORLD_SIZE of the launcher (torch.distributed.run,
 // the RUNNER hook of blastp.sh:70,85).
 struct Shard { int rank = 0, world = 1; std::string token; };
-// what identifies ONE launch of the workers: the launcher's run id, else a hash of the command line (without the per-worker flags).
-// A shard left behind by an earlier, crashed launch carries another token (or none) and is never merged.
+// what identifies ONE launch of the workers: the launcher's run id, else a hash of the command line (without the per-worker flags) AND of
+// the size and modification time of every input the command line names.  A shard left behind by an earlier, crashed launch carries
+// another token (or none) and is never merged -- unless it was made by the very same command over the very same input files, in which
+// case it holds what this launch would write (the commands are deterministic; a shard's .dbtype appears last, when it is complete).
 std::string launchToken(int argc, char **argv) {
     if (const char *id = getenv("TORCHELASTIC_RUN_ID")) if (*id && strcmp(id, "none") != 0) return std::string("run-") + id;
     if (const char *id = getenv("MK_LAUNCH_ID")) if (*id) return std::string("id-") + id;
     uint64_t h = 1469598103934665603ull;
+    int positional = 0;                                     // the first positional argument after the command is always an input DB, the second one
+    const int inputs = argc > 1 && !strcmp(argv[1], "extractorfs") ? 1 : 2;     // too except for extractorfs; outputs are not looked at (they change while the workers run)
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--shard") || !strcmp(argv[i], "--gpu")) { i++; continue; }
         for (const char *c = argv[i]; *c; c++) { h ^= (unsigned char) *c; h *= 1099511628211ull; }
         h ^= 0xFF; h *= 1099511628211ull;
+        if (argv[i][0] == '-' && !(argv[i][1] >= '0' && argv[i][1] <= '9')) { i++; if (i < argc) { for (const char *c = argv[i]; *c; c++) { h ^= (unsigned char) *c; h *= 1099511628211ull; } h ^= 0xFE; h *= 1099511628211ull; } continue; }
+        if (i > 1 && positional++ < inputs)
+            for (const char *ext : {"", ".index"}) {
+                struct stat st;
+                if (stat((std::string(argv[i]) + ext).c_str(), &st) != 0 || !S_ISREG(st.st_mode)) continue;
+                const uint64_t v[3] = {(uint64_t) st.st_size, (uint64_t) st.st_mtim.tv_sec, (uint64_t) st.st_mtim.tv_nsec};
+                for (uint64_t x : v) for (int b = 0; b < 8; b++) { h ^= (x >> (8 * b)) & 0xFF; h *= 1099511628211ull; }
+            }
     }
     char buf[32];
     snprintf(buf, sizeof(buf), "argv-%016llx", (unsigned long long) h);
@@ -442,9 +464,20 @@ int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
         if (f) { if (fread(&t, 4, 1, f) != 1) t = -1; fclose(f); }
         if (t >= 0 && (t & 0xFFFF) == DBTYPE_HMM_PROFILE) {
             if (!isSearch || profileQueries) return die("a profile target database is searched by `search` / `predictexons` (the inverted sliced search), not by %s", isAlign ? "align" : "prefilter");
+            // Search.cpp:357-399 takes the inverted sliced search only with --exhaustive-search 1 (predictexons sets it itself for profile targets,
+            // PredictExons.cpp:22-26); without it the reference runs the target-side k-mer search of searchtargetprofile.sh (:251-257), which is not built
+            {
+                auto ex = a.opt.find("--exhaustive-search");
+                if (ex == a.opt.end() || ex->second == "0")
+                    return die("search against a profile target database without --exhaustive-search 1 (the target-side k-mer profile search, Search.cpp:251-257) is not implemented: pass --exhaustive-search 1%s");
+            }
             if (sh.world > 1) return die("search with a profile target database is not sharded: run it as one process%s");
             return searchProfileTargets(a, P, qdb, outPath, t0);
         }
+    }
+    if (isSearch) {
+        auto ex = a.opt.find("--exhaustive-search");
+        if (ex != a.opt.end() && ex->second != "0") return die("--exhaustive-search 1 with a sequence target database is not implemented%s");
     }
     TargetSide ts;
     if (targetSplits == 1) { if (int rc = openTarget(a.pos[1], P, ts)) return rc; }
@@ -527,6 +560,7 @@ int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
         }
         e = w.close();
         if (!e.empty()) return die("%s", e);
+        printPrefilterStatistics(Q, P);
         fprintf(stderr, "prefilter: %zu queries x %zu targets%s, %llu hits, %.2f s\n", nq, tkeys.size(), ts.fromIndex ? " (precomputed index)" : "", (unsigned long long) hoff[nq], now() - t0);
     } else {
         std::vector<mk_hit> hits;
@@ -535,6 +569,7 @@ int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
             const mk_hit *hp; const uint64_t *ho;
             mk_prefilter_result(Q, &hp, &ho);
             hits.resize(ho[nq]);                                     // (only their number is reported)
+            printPrefilterStatistics(Q, P);
         } else {
         // read the prefilter DB: key \t score \t diagonal lines (QueryMatcher::parsePrefilterHit, QueryMatcher.h:87-102)
         mk::Database pdb;

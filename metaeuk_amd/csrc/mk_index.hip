@@ -240,62 +240,83 @@ struct CountArgs {
 constexpr int CT = 256;                 // threads per sequence
 constexpr int TJ = 1024;                // cells per comparison tile
 
+constexpr int LONG_STARTS = 4096;       // sequences with more k-mer starts are cut into 256-start work items of their own (index_count_long_kernel)
+
+// the kept starts among i0 .. i0 + 255 of sequence s (whole workgroup): table cell, first-position test against the other starts, counter + bit
+template <int K>
+__device__ __forceinline__ void count_round(const CountArgs &A, uint32_t s, uint64_t begin, const uint8_t *seq, int nStart, int i0, uint32_t *sCell) {
+    const int tid = threadIdx.x, w = tid / WAVE, lane = tid & (WAVE - 1);
+    const int i = i0 + tid;
+    const uint32_t mine = i < nStart ? cell_of<K>(seq + i, A.G) : INVALID_CELL;
+    bool dup = false;
+    if (nStart <= 65536) {
+        for (int j0 = 0; j0 < i0 + CT && j0 < nStart; j0 += TJ) {
+            __syncthreads();
+            for (int t = tid; t < TJ; t += CT) { const int j = j0 + t; sCell[t] = j < nStart ? cell_of<K>(seq + j, A.G) : INVALID_CELL; }
+            __syncthreads();
+            const int lim = min(TJ, i - j0);                                    // tile cells that lie before start i
+            const int wlim = min(TJ, i0 + w * WAVE + WAVE - 1 - j0);            // ... before the wave's last start
+            for (int t = 0; t < wlim; t += 4) {
+                const uint4 c = *reinterpret_cast<const uint4 *>(&sCell[t]);
+                dup |= (t < lim && c.x == mine) | (t + 1 < lim && c.y == mine) | (t + 2 < lim && c.z == mine) | (t + 3 < lim && c.w == mine);
+            }
+        }
+    } else {
+        // index positions are 16 bits wide (IndexEntryLocal::position_j): the reference sorts a sequence's k-mers by (k-mer, position as
+        // stored) and keeps the first, so beyond 65536 residues "first" means the smallest WRAPPED position -- every start is compared
+        const uint32_t key = (((uint32_t) i & 0xFFFFu) << 16) | ((uint32_t) i >> 16);
+        for (int j0 = 0; j0 < nStart; j0 += TJ) {
+            __syncthreads();
+            for (int t = tid; t < TJ; t += CT) { const int j = j0 + t; sCell[t] = j < nStart ? cell_of<K>(seq + j, A.G) : INVALID_CELL; }
+            __syncthreads();
+            for (int t = 0; t < TJ; t += 4) {
+                const uint4 c = *reinterpret_cast<const uint4 *>(&sCell[t]);
+                const uint32_t j = (uint32_t) (j0 + t);
+                dup |= (c.x == mine && (((j & 0xFFFFu) << 16) | (j >> 16)) < key) | (c.y == mine && ((((j + 1u) & 0xFFFFu) << 16) | ((j + 1u) >> 16)) < key) |
+                       (c.z == mine && ((((j + 2u) & 0xFFFFu) << 16) | ((j + 2u) >> 16)) < key) | (c.w == mine && ((((j + 3u) & 0xFFFFu) << 16) | ((j + 3u) >> 16)) < key);
+            }
+        }
+    }
+    const bool first = mine != INVALID_CELL && !dup;
+    if (first) atomicAdd(&A.count[mine], 1u);
+    const unsigned long long m = __ballot(first);
+    if (m) {                                                                // (wave-uniform)
+        const uint64_t p0 = begin + (uint64_t) (i0 + w * WAVE);
+        const uint64_t word = p0 >> 5;
+        const uint32_t sh = (uint32_t) (p0 & 31u);
+        const uint32_t w0 = (uint32_t) (m << sh);
+        const uint32_t w1 = sh ? (uint32_t) (m >> (32u - sh)) : (uint32_t) (m >> 32);
+        const uint32_t w2 = sh ? (uint32_t) (m >> (64u - sh)) : 0u;
+        if (lane == 0 && w0) atomicOr(&A.first_bits[word], w0);
+        if (lane == 1 && w1) atomicOr(&A.first_bits[word + 1], w1);
+        if (lane == 2 && w2) atomicOr(&A.first_bits[word + 2], w2);
+    }
+    (void) s;
+}
+
 template <int K>
 __global__ __launch_bounds__(CT) void index_count_kernel(CountArgs A) {
     constexpr int SPAN = K == 7 ? 11 : 10;
     __shared__ __attribute__((aligned(16))) uint32_t sCell[TJ];
     const uint32_t s = A.seq0 + blockIdx.x;
     if (s >= A.n_seq) return;
-    const int tid = threadIdx.x, w = tid / WAVE, lane = tid & (WAVE - 1);
     const uint64_t begin = A.off[s];
     const int L = (int) (A.off[s + 1] - begin);
     const int nStart = L >= SPAN ? L - SPAN + 1 : 0;
-    const uint8_t *seq = A.masked + begin;
-    for (int i0 = 0; i0 < nStart; i0 += CT) {
-        const int i = i0 + tid;
-        const uint32_t mine = i < nStart ? cell_of<K>(seq + i, A.G) : INVALID_CELL;
-        bool dup = false;
-        if (nStart <= 65536) {
-            for (int j0 = 0; j0 < i0 + CT && j0 < nStart; j0 += TJ) {
-                __syncthreads();
-                for (int t = tid; t < TJ; t += CT) { const int j = j0 + t; sCell[t] = j < nStart ? cell_of<K>(seq + j, A.G) : INVALID_CELL; }
-                __syncthreads();
-                const int lim = min(TJ, i - j0);                                    // tile cells that lie before start i
-                const int wlim = min(TJ, i0 + w * WAVE + WAVE - 1 - j0);            // ... before the wave's last start
-                for (int t = 0; t < wlim; t += 4) {
-                    const uint4 c = *reinterpret_cast<const uint4 *>(&sCell[t]);
-                    dup |= (t < lim && c.x == mine) | (t + 1 < lim && c.y == mine) | (t + 2 < lim && c.z == mine) | (t + 3 < lim && c.w == mine);
-                }
-            }
-        } else {
-            // index positions are 16 bits wide (IndexEntryLocal::position_j): the reference sorts a sequence's k-mers by (k-mer, position as
-            // stored) and keeps the first, so beyond 65536 residues "first" means the smallest WRAPPED position -- every start is compared
-            const uint32_t key = (((uint32_t) i & 0xFFFFu) << 16) | ((uint32_t) i >> 16);
-            for (int j0 = 0; j0 < nStart; j0 += TJ) {
-                __syncthreads();
-                for (int t = tid; t < TJ; t += CT) { const int j = j0 + t; sCell[t] = j < nStart ? cell_of<K>(seq + j, A.G) : INVALID_CELL; }
-                __syncthreads();
-                for (int t = 0; t < TJ; t++) {
-                    const uint32_t j = (uint32_t) (j0 + t);
-                    dup |= sCell[t] == mine && (((j & 0xFFFFu) << 16) | (j >> 16)) < key;
-                }
-            }
-        }
-        const bool first = mine != INVALID_CELL && !dup;
-        if (first) atomicAdd(&A.count[mine], 1u);
-        const unsigned long long m = __ballot(first);
-        if (m) {                                                                // (wave-uniform)
-            const uint64_t p0 = begin + (uint64_t) (i0 + w * WAVE);
-            const uint64_t word = p0 >> 5;
-            const uint32_t sh = (uint32_t) (p0 & 31u);
-            const uint32_t w0 = (uint32_t) (m << sh);
-            const uint32_t w1 = sh ? (uint32_t) (m >> (32u - sh)) : (uint32_t) (m >> 32);
-            const uint32_t w2 = sh ? (uint32_t) (m >> (64u - sh)) : 0u;
-            if (lane == 0 && w0) atomicOr(&A.first_bits[word], w0);
-            if (lane == 1 && w1) atomicOr(&A.first_bits[word + 1], w1);
-            if (lane == 2 && w2) atomicOr(&A.first_bits[word + 2], w2);
-        }
-    }
+    if (nStart > LONG_STARTS) return;                                       // index_count_long_kernel
+    for (int i0 = 0; i0 < nStart; i0 += CT) count_round<K>(A, s, begin, A.masked + begin, nStart, i0, sCell);
+}
+
+// long sequences: one workgroup per 256 starts (a titin-sized target alone would keep one workgroup busy for seconds)
+template <int K>
+__global__ __launch_bounds__(CT) void index_count_long_kernel(CountArgs A, const uint2 *items /* (sequence, first start) */, uint32_t nItems) {
+    constexpr int SPAN = K == 7 ? 11 : 10;
+    __shared__ __attribute__((aligned(16))) uint32_t sCell[TJ];
+    if (blockIdx.x >= nItems) return;
+    const uint32_t s = items[blockIdx.x].x;
+    const uint64_t begin = A.off[s];
+    const int L = (int) (A.off[s + 1] - begin);
+    count_round<K>(A, s, begin, A.masked + begin, L - SPAN + 1, (int) items[blockIdx.x].y, sCell);
 }
 
 template <int K>
@@ -730,6 +751,24 @@ int device_build_index(const uint8_t *dRes, const uint64_t *dOff, const std::vec
             const unsigned grid = (unsigned) std::min<uint64_t>(GRID_MAX, (uint64_t) nSeq - s0);
             if (K == 7) hipLaunchKernelGGL(index_count_kernel<7>, dim3(grid), dim3(CT), 0, stream, C);
             else hipLaunchKernelGGL(index_count_kernel<6>, dim3(grid), dim3(CT), 0, stream, C);
+        }
+        std::vector<uint2> items;
+        const uint64_t span = K == 7 ? 11 : 10;
+        for (uint32_t s2 = 0; s2 < nSeq; s2++) {
+            const uint64_t L = offHost[s2 + 1] - offHost[s2];
+            if (L < span + LONG_STARTS) continue;
+            for (uint64_t i0 = 0; i0 < L - span + 1; i0 += CT) items.push_back(make_uint2(s2, (uint32_t) i0));
+        }
+        Tmp<uint2> dItems;
+        if (!items.empty()) {
+            ICHK(dItems.alloc(items.size()));
+            ICHK(hipMemcpyAsync(dItems.p, items.data(), items.size() * sizeof(uint2), hipMemcpyHostToDevice, stream));
+            for (size_t b0 = 0; b0 < items.size(); b0 += GRID_MAX) {
+                const uint32_t nb = (uint32_t) std::min<size_t>(GRID_MAX, items.size() - b0);
+                if (K == 7) hipLaunchKernelGGL(index_count_long_kernel<7>, dim3(nb), dim3(CT), 0, stream, C, dItems.p + b0, nb);
+                else hipLaunchKernelGGL(index_count_long_kernel<6>, dim3(nb), dim3(CT), 0, stream, C, dItems.p + b0, nb);
+            }
+            ICHK(hipStreamSynchronize(stream));                    // (the item list lives on the host stack)
         }
         if (te) te(th);
         ICHK(hipGetLastError());

@@ -259,6 +259,24 @@ __global__ __launch_bounds__(256) void chunk_totals_kernel(const uint64_t *qOff,
     atomicMax(&totals[3], (unsigned long long) (endv - scan[b]));
 }
 
+// statistics: sum over the queries of a piece of (similar k-mers of the query) / (its length), in double, one atomic per wave
+__global__ __launch_bounds__(256) void kmers_per_pos_kernel(const uint64_t *qOff, uint32_t qFirst, uint32_t nq, uint64_t posBegin, const uint32_t *kmerCount, double *out) {
+    const uint32_t ql = blockIdx.x * blockDim.x + threadIdx.x;
+    double v = 0.0;
+    if (ql < nq) {
+        const uint64_t b = qOff[qFirst + ql], e = qOff[qFirst + ql + 1];
+        unsigned long long sum = 0;
+        for (uint64_t p = b; p < e; p++) sum += kmerCount[p - posBegin];
+        if (e > b) v = (double) sum / (double) (e - b);
+    }
+#pragma unroll
+    for (int d = WAVE / 2; d >= 1; d >>= 1) {
+        const uint32_t lo = (uint32_t) __shfl_xor((int) (uint32_t) __double_as_longlong(v), d, WAVE), hi = (uint32_t) __shfl_xor((int) (uint32_t) (__double_as_longlong(v) >> 32), d, WAVE);
+        v += __longlong_as_double((long long) (((uint64_t) hi << 32) | lo));
+    }
+    if ((threadIdx.x & (WAVE - 1)) == 0 && v != 0.0) atomicAdd(out, v);
+}
+
 // first record of every query of a piece (+ the end): the exclusive hit scan at the query's first position
 __global__ __launch_bounds__(256) void segment_offsets_kernel(const uint64_t *qOff, uint32_t qFirst, uint32_t nq, uint64_t posBegin, uint64_t nPos,
                                                              const uint32_t *hitScan, uint32_t nHits, uint32_t *seg) {
@@ -1008,6 +1026,8 @@ struct Ctx {
     const std::vector<uint64_t> *qOffHost = nullptr; const std::vector<uint8_t> *qResHost = nullptr; const int8_t *qCorrHost = nullptr;
     std::function<const uint8_t *()> tMaskedHost; const std::vector<uint64_t> *tOffHost = nullptr; const SubMat *ungMat = nullptr;
     uint32_t chunkQ0 = 0;              // batch index of the chunk's first query (candidates carry chunk-local indices)
+    PrefilterStats *stats = nullptr;   // run statistics (Prefiltering.cpp:889-904)
+    bool statsKmers = false;           // ... the global path adds the similar k-mers per query too (no per-query count exists yet)
 };
 
 // ---- the overflow path of QueryMatcher::match, host part (QueryMatcher.cpp:281-334; oracle/mko_prefilter.c: overflow_device_model) ----
@@ -1202,6 +1222,20 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
                 err = "a single query produces more index hits than the 64-bit hit record can number"; return MK_ERR_UNSUPPORTED;
             }
             break;
+        }
+        if (X.stats && nPos > 0) {                 // the piece is final: its share of the run statistics
+            X.stats->db_matches += totalHits;
+            if (ovf) X.stats->overflows += 1;
+            if (X.statsKmers) {
+                double *dSum = (double *) dev_scratch("pf_kpp", 16);
+                PNULL(dSum);
+                double hSum = 0;
+                PCHK(hipMemsetAsync(dSum, 0, 8, stream));
+                hipLaunchKernelGGL(kmers_per_pos_kernel, dim3((q1 - q0 + 255) / 256), dim3(256), 0, stream, V.q_off, q0, q1 - q0, hOff[q0], dKmer, dSum);
+                PCHK(hipMemcpyAsync(&hSum, dSum, 8, hipMemcpyDeviceToHost, stream));
+                PCHK(sync_wait(stream, "wait_prefilter"));
+                X.stats->kmers_per_pos += hSum;
+            }
         }
         if (nPos > 0 && totalHits > 0) {
             if (totalHits >= 0x7FFFFFFFull) { err = "a single query produces >= 2^31 index hits"; return MK_ERR_UNSUPPORTED; }
@@ -1424,6 +1458,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     X.stream = stream; X.err = &err; X.tb = tb; X.te = te; X.ts = ts; X.seqBits = seqBits;
     X.maxDbMatches = std::max<uint64_t>(1000000, dbSize) * 2;   // QueryMatcher.cpp:43
     X.candCap = CAND_CAP;
+    X.statsKmers = hooks.stats && !useFused;
     X.qOffHost = &qOff; X.qResHost = &qRes; X.qCorrHost = V.p_sorted ? nullptr : qCorrHost; X.tMaskedHost = hooks.t_masked_host; X.tOffHost = &tOff; X.ungMat = &ungMat;
     X.dTotals = (unsigned long long *) dev_scratch("pf_totals", 64);
     X.hTotals = (unsigned long long *) pinned_scratch("pf_totals_h", 64);
@@ -1451,6 +1486,8 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
         const uint32_t nqc = q1 - q0;
         uint32_t nCand = 0;
         X.chunkQ0 = q0;
+        PrefilterStats cs;                                                 // this attempt at the chunk; committed when it is final
+        X.stats = hooks.stats ? &cs : nullptr;
         std::vector<uint32_t> fallback;                                     // chunk-local ids for the global path
         int rc = MK_OK;
         if (useFused) {
@@ -1475,6 +1512,14 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                 }
                 PCHK(hipMemcpyAsync(hQK, dQK, (size_t) nqc * 4, hipMemcpyDeviceToHost, stream));
                 PCHK(sync_wait(stream, "wait_prefilter"));
+            }
+            if (hooks.stats) {
+                double sum = 0;
+                for (uint32_t ql = 0; ql < nqc; ql++) {
+                    const uint64_t L = qOff[(size_t) q0 + ql + 1] - qOff[(size_t) q0 + ql];
+                    if (L) sum += (double) hQK[ql] / (double) L;
+                }
+                cs.kmers_per_pos += sum;
             }
             {
                 ScopedHost sh("host_prefilter_tiers");
@@ -1552,6 +1597,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             PCHK(hipMemcpyAsync(hFTotals + 16, dFTotals, 16 * 8 * N_TIERS, hipMemcpyDeviceToHost, stream));
             PCHK(sync_wait(stream, "wait_prefilter"));
             for (int k = 0; k < 16; k++) { hFTotals[k] = 0; for (int t = 0; t < N_TIERS; t++) hFTotals[k] += hFTotals[16 * (t + 1) + k]; }
+            cs.db_matches += hFTotals[1];
             if (getenv("MK_PREFILTER_DEBUG"))
                 for (int t = 0; t < N_TIERS; t++) {
                     const unsigned long long *T = hFTotals + 16 * (t + 1);
@@ -1638,6 +1684,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             continue;                                                      // same q0, smaller chunk
         }
         if (rc != MK_OK) return rc;
+        if (hooks.stats) { hooks.stats->kmers_per_pos += cs.kmers_per_pos; hooks.stats->db_matches += cs.db_matches; hooks.stats->overflows += cs.overflows; }
         chunkLimit = QCAP;
         candPerQuery = std::max(1.0, (double) nCand / (double) nqc);
 

@@ -39,6 +39,13 @@ typedef int (*timed_begin_fn)(const char *name, double bytes, double cells);
 typedef void (*timed_end_fn)(int handle);
 typedef void (*timed_set_fn)(int handle, double bytes, double cells);
 
+// what the reference's prefilter logs about a run (Prefiltering.cpp:889-904,953-975), accumulated over the calls of a batch
+struct PrefilterStats {
+    double kmers_per_pos = 0;        // sum over the queries of (similar k-mers of the query / its length)
+    uint64_t db_matches = 0;         // index entries gathered
+    uint64_t overflows = 0;          // queries that filled the reference's databaseHits buffer (QueryMatcher.cpp:281-334)
+};
+
 // optional hooks for a caller that consumes the result chunk by chunk while the prefilter is still running (mk_search)
 struct PrefilterHooks {
     uint32_t max_chunk_queries = 0;                                  // 0: no limit beyond the device buffers
@@ -47,6 +54,7 @@ struct PrefilterHooks {
                                                                      // persistent prefilter workgroups take about half of the wave slots
     std::function<const uint8_t *()> t_masked_host;                  // host copy of the masked target residues (fetched on demand): the overflow path of a
                                                                      // query that fills the reference's databaseHits buffer scores a few diagonals on the host
+    PrefilterStats *stats = nullptr;                                 // accumulates the run statistics when set
     std::function<void(uint32_t q0, uint32_t q1)> on_chunk;          // hits and offsets of [q0, q1) are final and in host memory
     std::function<void()> before_grow;                               // the result block is about to be re-allocated
 };

@@ -12,6 +12,7 @@
 #                                    residues on (IndexTable.h:439-449), forced on the small fixture (threshold 122, 2119 k-mers per position)
 #   e2e_process_pref_split3_maxseqs20.txt.gz   `prefilter ... --split 3 --split-mode 0 --max-seqs 20 -s 5.7`: TARGET_DB_SPLIT -- three target ranges
 #                                    (68 / 60 / 72 proteins) searched one by one with --max-seqs 6 + 10 each, the lists joined and sorted
+#   e2e_process_prefilter_stats.txt  the six statistics lines of that prefilter run's log ("246.638184 k-mers per position" ...)
 # Inputs: tests/golden/e2e_targets.txt.gz, e2e_contigs.txt.gz (createdb --shuffle 0, so keys = line numbers).  Host L2 = 2097152.
 set -e
 R=$(cd $(dirname $0)/../.. && pwd)
@@ -32,6 +33,7 @@ $M createdb targets.faa targetsDB --shuffle 0 > /dev/null
 $M createdb contigs.fna contigsDB --shuffle 0 > /dev/null
 mkdir tmp tmp2
 $M predictexons contigsDB targetsDB calls tmp --remove-tmp-files 0 --threads 4 -s 5.7 > run.log 2>&1
+grep -A5 "k-mers per position" run.log > $R/tests/golden/e2e_process_prefilter_stats.txt     # the prefilter's run statistics (Prefiltering.cpp:953-975)
 $M predictexons contigsDB targetsDB calls4 tmp2 --threads 4 > run4.log 2>&1
 $M prefilter tmp/latest/aa_6f targetsDB pref_k7 -k 7 -s 5.7 --threads 4 > k7.log 2>&1      # ~1.5 min: the reference initialises a 21^7 table
 $M prefilter tmp/latest/aa_6f targetsDB pref_sp3 --split 3 --split-mode 0 -s 5.7 --max-seqs 20 --threads 4 > sp3.log 2>&1

@@ -873,6 +873,12 @@ def test_cli_equals_the_real_process(gpu_api, tmp_path):
         "--threads", "4", "--compressed", "0", "-v", "3", "-s", "5.7", "--ref-l2-bytes", "2097152")
     blocks = lambda d: "".join(">%d\n%s" % (k, d[k]) for k in sorted(d))
     assert blocks(_read_result_db(str(tmp_path / "pref_0"))) == _text("e2e_process_pref.txt.gz")
+    # the run statistics the reference's prefilter logs (Prefiltering::printStatistics): the same six lines, from the device counters
+    r = subprocess.run([build.BIN, "prefilter", str(tmp_path / "aa_6f"), str(tmp_path / "targets"), str(tmp_path / "pref_stats"), "-s", "5.7", "--ref-l2-bytes", "2097152"],
+                       stderr=subprocess.PIPE)
+    assert r.returncode == 0
+    expected_stats = open(os.path.join(GOLD, "e2e_process_prefilter_stats.txt")).read()
+    assert expected_stats.startswith("246.638184 k-mers per position\n12 DB matches per sequence\n") and expected_stats in r.stderr.decode(), r.stderr.decode()[-600:]
     run("align", tmp_path / "aa_6f", tmp_path / "targets", tmp_path / "pref_0", tmp_path / "search_res", "--sub-mat", "aa:blosum62.out,nucl:nucleotide.out",
         "-a", "0", "--alignment-mode", "2", "--alignment-output-mode", "0", "--wrapped-scoring", "0", "-e", "100", "--min-seq-id", "0", "--min-aln-len", "11",
         "--seq-id-mode", "0", "--alt-ali", "0", "-c", "0", "--cov-mode", "0", "--max-seq-len", "65535", "--comp-bias-corr", "1", "--comp-bias-corr-scale", "1",

@@ -247,8 +247,16 @@ def test_cli_profile_workflow_equals_the_real_process(gpu_api, tmp_path):
     assert blocks(_read_result_db(str(tmp_path / "search_res"))) == _text("prof_search_res.txt.gz")
     # `search <fragmentDB> <profileDB>`: what the search workflow (Search.cpp:357-399) makes of a profile target -- the same swapped lists
     run("search", tmp_path / "aa_6f", tmp_path / "profDB", tmp_path / "search_res_1", tmp_path / "tmp", "--alignment-mode", "2", "-s", "4", "-e", "100",
-        "--min-aln-len", "11", "--ref-l2-bytes", "2097152")
+        "--min-aln-len", "11", "--ref-l2-bytes", "2097152", "--exhaustive-search", "1")
     assert blocks(_read_result_db(str(tmp_path / "search_res_1"))) == _text("prof_search_res.txt.gz")
+    # without --exhaustive-search 1 the reference runs the target-side k-mer search (Search.cpp:251-257): refused, not silently replaced
+    r = subprocess.run([build.BIN, "search", str(tmp_path / "aa_6f"), str(tmp_path / "profDB"), str(tmp_path / "search_res_x"), str(tmp_path / "tmp"),
+                        "--alignment-mode", "2"], stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"--exhaustive-search 1" in r.stderr
+    # ... and --exhaustive-search 1 against a sequence DB is refused as well
+    r = subprocess.run([build.BIN, "search", str(tmp_path / "aa_6f"), str(tmp_path / "aa_6f"), str(tmp_path / "search_res_y"), str(tmp_path / "tmp"),
+                        "--alignment-mode", "2", "--exhaustive-search", "1"], stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"sequence target" in r.stderr
     # the whole workflow as one command (default -s 4, -e 100 scaled by 24084 fragments / 100 profiles)
     contigs = _text("e2e_contigs.txt.gz").splitlines()
     A.write_seq_db(str(tmp_path / "contigs"), A.seq_db_image(contigs), dbtype=1)
