@@ -1145,6 +1145,18 @@ int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     return MK_OK;
 }
 
+// experiment hook (not part of the documented ABI): see mk::debug_probe_order
+int mk_debug_probe_order(mk_targetdb *db, mk_queries *q, uint32_t nq, int tileOrder, double out[4]) {
+    int rc = ensure_ready();
+    if (rc) return rc;
+    if (!db || !q || !out || nq > q->n) return fail(MK_ERR_ARG, "bad argument");
+    if ((rc = match_kmer_size(db, q)) != MK_OK) return rc;
+    std::string err;
+    rc = mk::debug_probe_order(prefilter_view(db, q), q->off, nq, tileOrder, g_stream, out, err);
+    if (rc != MK_OK) return fail(rc, "%s", err.c_str());
+    return MK_OK;
+}
+
 // the reference's prefilter statistics (Prefiltering.cpp:889-904 -> printStatistics :953-975) of the last mk_prefilter / mk_search over the batch
 int mk_prefilter_statistics(const mk_queries *q, mk_prefilter_stats *out) {
     if (!q || !out) return fail(MK_ERR_ARG, "null argument");

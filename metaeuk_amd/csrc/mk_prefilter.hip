@@ -114,6 +114,8 @@ struct ProbeArgs {
     uint64_t *keys; uint8_t *diag_hi; // GATHER outputs: one 8-byte record per index hit + the diagonal's high byte
     uint8_t *list_start = nullptr;    // GATHER, overflow path only: 1 at the first hit of every k-mer's index list (the buffer arithmetic of
                                       // QueryMatcher::match works on whole lists)
+    const uint32_t *order = nullptr;  // the launch's i-th wave takes k-mer start pos_begin + order[i] (null: pos_begin + i); n_order of them
+    uint64_t n_order = 0;
 };
 
 // slot and entry reads are one-touch random probes of tables far larger than L2; MK_NT_LOADS=1 marks them non-temporal so that
@@ -173,7 +175,9 @@ __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
     __shared__ uint8_t sMark[4][WAVE];
     __builtin_amdgcn_s_setprio(3);                    // latency-bound waves issue ahead of the ALU-bound ones of the other stream
     const int w = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
-    const uint64_t p = A.pos_begin + (uint64_t) blockIdx.x * 4 + w;
+    const uint64_t item = (uint64_t) blockIdx.x * 4 + w;
+    if (A.order && item >= A.n_order) return;
+    const uint64_t p = A.pos_begin + (A.order ? (uint64_t) A.order[item] : item);
     if (p >= A.pos_end) return;
     const uint64_t rel = p - A.pos_begin;
     const int thr = (int) A.V.q_kmer_thr[p];
@@ -442,6 +446,23 @@ __global__ __launch_bounds__(256) void kmer_count_kernel(PrefilterDeviceView V, 
         acc += total;
     }
     if (acc && lane == 0) atomicAdd(&perQuery[q - qFirst], acc);
+}
+
+// home tile of the k-mer that starts at a residue position (k = 6): the quads of its six letters, base 5 -- the 4096-cell tile of the
+// index table its in-quad variants share (mk_host.cpp: KMER_ADDR_LETTER).  Similar k-mers are substitutions of similar residues, so the
+// probes of starts with the same home tile fall into the same few hundred bitmap / slot lines.
+struct QuadOf { uint8_t q[20]; };
+__global__ __launch_bounds__(256) void tile_key_kernel(PrefilterDeviceView V, uint64_t posBegin, uint64_t nPos, QuadOf Q, uint16_t *key, uint32_t *idx) {
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nPos) return;
+    const uint64_t p = posBegin + i;
+    uint32_t k = 0xFFFFu;
+    if ((int) V.q_kmer_thr[p] >= 0) {
+        const uint8_t *r = V.q_res + p;
+        k = (uint32_t) Q.q[r[0]] + 5u * Q.q[r[1]] + 25u * Q.q[r[3]] + 125u * ((uint32_t) Q.q[r[5]] + 5u * Q.q[r[8]] + 25u * Q.q[r[9]]);
+    }
+    key[i] = (uint16_t) k;
+    idx[i] = (uint32_t) i;
 }
 
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
@@ -1906,6 +1927,57 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     g_memo.candPerQuery = candPerQuery;
     (void) tOff;
     PCHK(sync_wait(stream, "wait_prefilter"));         // the last DMA into the result block
+    return MK_OK;
+}
+
+// experiment hook (tools/probe_order_experiment.py): the index probes of the k-mer starts of queries [0, nq) -- enumeration, bitmap, slot --
+// in natural order or ordered by home tile; out = {ms, similar k-mers, index hits, starts}
+int debug_probe_order(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOff, uint32_t nq, int tileOrder, hipStream_t stream, double out[4], std::string &err) {
+    const uint64_t nPos = qOff[nq] - qOff[0];
+    if (nPos == 0 || nPos >= 0xFFFFFFFFull) { err = "empty or too large"; return MK_ERR_ARG; }
+    uint32_t *dHit = (uint32_t *) dev_scratch("dbg_hit", (nPos + 1) * 4), *dKmer = (uint32_t *) dev_scratch("dbg_kmer", (nPos + 1) * 4);
+    uint16_t *dKey = (uint16_t *) dev_scratch("dbg_key", nPos * 2), *dKey2 = (uint16_t *) dev_scratch("dbg_key2", nPos * 2);
+    uint32_t *dIdx = (uint32_t *) dev_scratch("dbg_idx", nPos * 4), *dIdx2 = (uint32_t *) dev_scratch("dbg_idx2", nPos * 4);
+    PNULL(dHit); PNULL(dKmer); PNULL(dKey); PNULL(dKey2); PNULL(dIdx); PNULL(dIdx2);
+    ProbeArgs A;
+    A.V = V; A.pos_begin = qOff[0]; A.pos_end = qOff[nq]; A.q_first = 0; A.seq_bits = 0; A.hit_bits = 0;
+    A.hit_count = dHit; A.kmer_count = dKmer; A.keys = nullptr; A.diag_hi = nullptr;
+    uint64_t nItems = nPos;
+    if (tileOrder) {
+        QuadOf Q;
+        const uint8_t *addr = kmer_addr_letters();
+        for (int a = 0; a < 20; a++) Q.q[a] = addr[a] >> 2;
+        hipLaunchKernelGGL(tile_key_kernel, dim3((unsigned) ((nPos + 255) / 256)), dim3(256), 0, stream, V, A.pos_begin, nPos, Q, dKey, dIdx);
+        hipcub::DoubleBuffer<uint16_t> kb(dKey, dKey2);
+        hipcub::DoubleBuffer<uint32_t> ib(dIdx, dIdx2);
+        size_t tb = 0;
+        hipcub::DeviceRadixSort::SortPairs(nullptr, tb, kb, ib, (int) nPos, 0, 16, stream);
+        void *temp = dev_scratch("dbg_temp", tb);
+        PNULL(temp);
+        PCHK(hipcub::DeviceRadixSort::SortPairs(temp, tb, kb, ib, (int) nPos, 0, 16, stream));
+        A.order = ib.Current(); A.n_order = nPos;
+        PCHK(hipMemsetAsync(dHit, 0, (nPos + 1) * 4, stream));
+        PCHK(hipMemsetAsync(dKmer, 0, (nPos + 1) * 4, stream));
+    }
+    hipEvent_t e0, e1;
+    PCHK(hipEventCreate(&e0)); PCHK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {
+        PCHK(hipEventRecord(e0, stream));
+        hipLaunchKernelGGL(probe_kernel<false>, dim3((unsigned) ((nItems + 3) / 4)), dim3(256), 0, stream, A);
+        PCHK(hipEventRecord(e1, stream));
+        PCHK(hipStreamSynchronize(stream));
+        float ms = 0;
+        PCHK(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, ms);
+    }
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    std::vector<uint32_t> hHit(nPos), hKmer(nPos);
+    PCHK(hipMemcpy(hHit.data(), dHit, nPos * 4, hipMemcpyDeviceToHost));
+    PCHK(hipMemcpy(hKmer.data(), dKmer, nPos * 4, hipMemcpyDeviceToHost));
+    double kmers = 0, hits = 0, starts = 0;
+    for (uint64_t i = 0; i < nPos; i++) { kmers += hKmer[i]; hits += hHit[i]; starts += hKmer[i] != 0; }
+    out[0] = best; out[1] = kmers; out[2] = hits; out[3] = starts;
     return MK_OK;
 }
 
