@@ -14,6 +14,6 @@ for f in mk_prefilter.hip mk_sw.hip mk_align.hip; do
 done
 for p in $pids; do wait $p; done
 objs=""
-for f in mk_host.cpp mk_exons.cpp mk_indexfile.cpp mk_abi.cpp mk_derive.hip mk_orf.hip; do objs="$objs $R/metaeuk_amd/lib/obj/$f.o"; done
+for f in mk_host.cpp mk_exons.cpp mk_indexfile.cpp mk_abi.cpp mk_derive.hip mk_orf.hip mk_profile.hip mk_kmer7.hip mk_index.hip mk_synth.cpp; do objs="$objs $R/metaeuk_amd/lib/obj/$f.o"; done
 /opt/rocm/bin/hipcc $FLAGS -shared $objs $O/mk_prefilter.hip.o $O/mk_sw.hip.o $O/mk_align.hip.o -o $R/metaeuk_amd/lib/variants/lib$name.so
 echo $R/metaeuk_amd/lib/variants/lib$name.so
