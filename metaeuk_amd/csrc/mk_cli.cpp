@@ -355,12 +355,15 @@ int finishShards(const std::string &out, const Shard &sh, int dbtype) {
 
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-int invertedProfileSearch(const mk::Database &pdb, mk_targetdb *F, uint64_t nFrag, const mk_params &P, mk_swapped **S, uint64_t &nHits, uint64_t &nAln);
+// returns 0 and *S = nullptr on a worker other than 0 of a sharded launch (its share went to worker 0)
+int invertedProfileSearch(const mk::Database &pdb, mk_targetdb *F, uint64_t nFrag, const mk_params &P, mk_swapped **S, uint64_t &nHits, uint64_t &nAln,
+                          const Shard &sh, const std::string &outBase);
 
 // search <i:fragmentDB> <i:profileDB> <o:alignmentDB> <tmpDir>: what Search.cpp:357-399 + searchslicedtargetprofile.sh compute -- the profiles
 // against the fragments, swapped: one record per fragment key with the profiles that hit it.  Fragment numbering = the DB's data order, like
 // the reference's prefilter numbers its targets.
-int searchProfileTargets(const Args &a, mk_params P, const mk::Database &qdb, const std::string &outPath, double t0) {
+int searchProfileTargets(const Args &a, mk_params P, const mk::Database &qdb, const std::string &outBase, const Shard &sh, double t0) {
+    const std::string outPath = outBase;                                        // (worker 0 writes the whole result: the shards are the profiles)
     mk::Database pdb;
     std::string e = pdb.open(a.pos[1]);
     if (!e.empty()) return die("%s", e);
@@ -379,7 +382,8 @@ int searchProfileTargets(const Args &a, mk_params P, const mk::Database &qdb, co
     if (mk_targetdb_set_keys(F, fkeys.data(), (uint32_t) nFrag) != MK_OK) return die("%s", mk_last_error());
     uint64_t nHits = 0, nAln = 0;
     mk_swapped *S = nullptr;
-    if (int rc = invertedProfileSearch(pdb, F, nFrag, P, &S, nHits, nAln)) return rc;
+    if (int rc = invertedProfileSearch(pdb, F, nFrag, P, &S, nHits, nAln, sh, outBase)) return rc;
+    if (!S) { mk_targetdb_destroy(F); return EXIT_SUCCESS; }                    // a worker whose alignments went to worker 0
     const mk_alignment *sw; const uint64_t *soff;
     mk_swapped_result(S, &sw, &soff);
     mk::DatabaseWriter w(outPath, mk::DBTYPE_ALIGNMENT_RES);
@@ -398,6 +402,7 @@ int searchProfileTargets(const Args &a, mk_params P, const mk::Database &qdb, co
             (unsigned long long) nAln, now() - t0);
     mk_swapped_destroy(S);
     mk_targetdb_destroy(F);
+    for (int r = 0; r < sh.world && sh.world > 1; r++) remove((outBase + "_" + std::to_string(r) + ".token").c_str());
     return EXIT_SUCCESS;
 }
 
@@ -471,8 +476,11 @@ int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
                 if (ex == a.opt.end() || ex->second == "0")
                     return die("search against a profile target database without --exhaustive-search 1 (the target-side k-mer profile search, Search.cpp:251-257) is not implemented: pass --exhaustive-search 1%s");
             }
-            if (sh.world > 1) return die("search with a profile target database is not sharded: run it as one process%s");
-            return searchProfileTargets(a, P, qdb, outPath, t0);
+            // sharded: the workers split the PROFILES (every worker indexes all fragments: their number enters the e-value threshold,
+            // the e-values and --max-seqs); qdb was cut to this worker's queries above -- the fragments are needed whole
+            mk::Database fdb;
+            if (sh.world > 1) { e = fdb.open(a.pos[0]); if (!e.empty()) return die("%s", e); }
+            return searchProfileTargets(a, P, sh.world > 1 ? fdb : qdb, outBase, sh, t0);
         }
     }
     if (isSearch) {
@@ -824,19 +832,31 @@ int cmdExtractOrfs(int argc, char **argv) {
 // The inverted search of searchslicedtargetprofile.sh on handles: the profiles of pdb (by key, in slices of at most MK_CLI_PROFILE_COLS
 // columns, default 2^24) as queries against the fragment side F (built with profile_search = 1; P already carries the inverted e-value
 // threshold and --max-seqs), then swapresults -e DBL_MAX (Search.cpp:378-381): *S lists, per fragment index, the profiles that hit it.
-int invertedProfileSearch(const mk::Database &pdb, mk_targetdb *F, uint64_t nFrag, const mk_params &P, mk_swapped **S, uint64_t &nHits, uint64_t &nAln) {
-    const size_t nProf = pdb.entries.size();
+// The profiles against the indexed fragments, swapped.  Sharded (sh.world > 1): the workers split the profiles by columns (contiguous ranges in
+// key order, DBReader::decomposeDomainByAminoAcid's rule), every worker holds the whole fragment index; a worker's accepted alignments travel
+// to worker 0 as they are in memory (<out>_<r>.alnbin: full-precision e-values -- the order of a swapped list is decided by them, a text
+// round trip would not do), worker 0 strings the shares together in key order and swaps once: from there on the unsharded computation.
+int invertedProfileSearch(const mk::Database &pdb, mk_targetdb *F, uint64_t nFrag, const mk_params &P, mk_swapped **S, uint64_t &nHits, uint64_t &nAln,
+                          const Shard &sh, const std::string &outBase) {
+    const size_t nProfAll = pdb.entries.size();
     std::vector<size_t> pord = pdb.keyOrder();
+    size_t first = 0, count = nProfAll;
+    if (sh.world > 1) {
+        std::vector<mk::DbEntry> inKeyOrder(nProfAll);
+        for (size_t i = 0; i < nProfAll; i++) inKeyOrder[i] = pdb.entries[pord[i]];
+        mk::decomposeByLength(inKeyOrder, sh.rank, sh.world, first, count);
+    }
     const uint64_t sliceCols = getenv("MK_CLI_PROFILE_COLS") ? strtoull(getenv("MK_CLI_PROFILE_COLS"), nullptr, 10) : (1ull << 24);
     std::vector<mk_alignment> alnAll;
     std::vector<uint64_t> alnOff(1, 0);
     std::vector<uint32_t> pkeys;
     nHits = 0;
-    for (size_t p0 = 0; p0 < nProf; ) {
+    *S = nullptr;
+    for (size_t p0 = first; p0 < first + count; ) {
         size_t p1 = p0;
         uint64_t cols = 0;
         std::vector<uint64_t> coff(1, 0);
-        while (p1 < nProf && (p1 == p0 || cols + (std::max<uint64_t>(pdb.entries[pord[p1]].length, 1) - 1) / 25 <= sliceCols)) {
+        while (p1 < first + count && (p1 == p0 || cols + (std::max<uint64_t>(pdb.entries[pord[p1]].length, 1) - 1) / 25 <= sliceCols)) {
             cols += (std::max<uint64_t>(pdb.entries[pord[p1]].length, 1) - 1) / 25;
             coff.push_back(cols);
             p1++;
@@ -851,16 +871,53 @@ int invertedProfileSearch(const mk::Database &pdb, mk_targetdb *F, uint64_t nFra
         nHits += ho[p1 - p0];
         const mk_alignment *alns; const uint64_t *aoff;
         mk_align_result(Q, &alns, &aoff);
+        const uint64_t before = alnOff.back();
         alnAll.insert(alnAll.end(), alns, alns + aoff[p1 - p0]);
-        for (size_t i = p0; i < p1; i++) { alnOff.push_back(alnOff[p0] + aoff[i - p0 + 1]); pkeys.push_back(pdb.entries[pord[i]].key); }
+        for (size_t i = p0; i < p1; i++) { alnOff.push_back(before + aoff[i - p0 + 1]); pkeys.push_back(pdb.entries[pord[i]].key); }
         mk_queries_destroy(Q);
         p0 = p1;
+    }
+    if (sh.world > 1) {
+        const std::string mine = outBase + "_" + std::to_string(sh.rank) + ".alnbin";
+        if (sh.rank != 0) {
+            FILE *f = fopen((mine + ".tmp").c_str(), "wb");
+            if (!f) return die("cannot write %s", mine);
+            const uint64_t head[3] = {(uint64_t) count, alnOff.back(), nHits};
+            bool ok = fwrite(head, 8, 3, f) == 3 && fwrite(alnOff.data(), 8, alnOff.size(), f) == alnOff.size() &&
+                      (pkeys.empty() || fwrite(pkeys.data(), 4, pkeys.size(), f) == pkeys.size()) &&
+                      (alnAll.empty() || fwrite(alnAll.data(), sizeof(mk_alignment), alnAll.size(), f) == alnAll.size());
+            ok = fclose(f) == 0 && ok;
+            if (!ok || rename((mine + ".tmp").c_str(), mine.c_str()) != 0) return die("cannot write %s", mine);
+            nAln = alnOff.back();
+            return 0;
+        }
+        for (int r = 1; r < sh.world; r++) {
+            const std::string theirs = outBase + "_" + std::to_string(r) + ".alnbin";
+            if (!waitForPeer(outBase, r, theirs, sh.token)) return EXIT_FAILURE;
+            FILE *f = fopen(theirs.c_str(), "rb");
+            uint64_t head[3] = {0, 0, 0};
+            if (!f || fread(head, 8, 3, f) != 3) return die("cannot read %s", theirs);
+            std::vector<uint64_t> off(head[0] + 1);
+            std::vector<uint32_t> keys(head[0]);
+            std::vector<mk_alignment> al(head[1]);
+            bool ok = fread(off.data(), 8, off.size(), f) == off.size() && (keys.empty() || fread(keys.data(), 4, keys.size(), f) == keys.size()) &&
+                      (al.empty() || fread(al.data(), sizeof(mk_alignment), al.size(), f) == al.size());
+            fclose(f);
+            if (!ok || off.back() != head[1]) return die("%s is truncated", theirs);
+            const uint64_t before = alnOff.back();
+            for (uint64_t i = 0; i < head[0]; i++) alnOff.push_back(before + off[i + 1]);
+            pkeys.insert(pkeys.end(), keys.begin(), keys.end());
+            alnAll.insert(alnAll.end(), al.begin(), al.end());
+            nHits += head[2];
+            remove(theirs.c_str());
+        }
+        if (pkeys.size() != nProfAll) return die("the workers' profile ranges do not add up%s");
     }
     nAln = alnOff.back();
     // the e-values of the swapped lists use the profile DB's column count (swapresults.cpp:76-77: the original target side)
     mk_params SP = P;
     SP.evalue_thr = std::numeric_limits<double>::max();
-    if (mk_swap_alignments(alnAll.data(), alnOff.data(), (uint32_t) nProf, pkeys.data(), (uint32_t) nFrag, profileDbResidues(pdb), &SP, S) != MK_OK) return die("%s", mk_last_error());
+    if (mk_swap_alignments(alnAll.data(), alnOff.data(), (uint32_t) nProfAll, pkeys.data(), (uint32_t) nFrag, profileDbResidues(pdb), &SP, S) != MK_OK) return die("%s", mk_last_error());
     return 0;
 }
 
@@ -870,10 +927,10 @@ int invertedProfileSearch(const mk::Database &pdb, mk_targetdb *F, uint64_t nFra
 // bounded by their columns, swapresults turns the lists round, the exon stage runs on them.  The contigs are translated in
 // nucleotide-bounded batches; their fragments are collected on the host because they form ONE target side.  The workflow's second `align` (the merged key
 // lists again, to "keep the top hits") accepts exactly the pairs of the first with --max-accept / --max-rejected at their defaults, so one
-// pass is the result.  Not sharded: a worker would need the other workers' fragment counts before it can score anything.
+// pass is the result.  Sharded launches split the PROFILES: every worker translates all contigs and indexes all fragments (their number
+// enters the e-value threshold, the e-values and --max-seqs), worker 0 gathers the alignments, swaps and predicts (invertedProfileSearch).
 int predictExonsProfileTargets(const Args &a, mk_params P, const mk_exon_params &X, int minLength, const mk::Database &contigs, const std::vector<size_t> &ord,
                                const Shard &sh, const std::string &outPath, double t0) {
-    if (sh.world > 1) return die("predictexons with a profile target database is not sharded: run it as one process%s");
     static const char none = 0;
     mk::Database pdb;
     std::string e = pdb.open(a.pos[1]);
@@ -923,7 +980,8 @@ int predictExonsProfileTargets(const Args &a, mk_params P, const mk_exon_params 
     const double t1 = now();
     uint64_t nHits = 0, nAlnTotal = 0;
     mk_swapped *S = nullptr;
-    if (int rc = invertedProfileSearch(pdb, F, nFrag, P, &S, nHits, nAlnTotal)) return rc;
+    if (int rc = invertedProfileSearch(pdb, F, nFrag, P, &S, nHits, nAlnTotal, sh, a.pos[2])) return rc;
+    if (!S) { mk_targetdb_destroy(F); return EXIT_SUCCESS; }                    // a worker whose alignments went to worker 0: it is done
     const double t2 = now();
     const uint64_t profRes = profileDbResidues(pdb);
     const mk_alignment *sw; const uint64_t *soff;
@@ -951,7 +1009,8 @@ int predictExonsProfileTargets(const Args &a, mk_params P, const mk_exon_params 
     mk_predictions_destroy(R);
     mk_swapped_destroy(S);
     mk_targetdb_destroy(F);
-    return finishShards(a.pos[2], sh, 12);
+    for (int r = 0; r < sh.world && sh.world > 1; r++) remove((a.pos[2] + "_" + std::to_string(r) + ".token").c_str());
+    return EXIT_SUCCESS;
 }
 
 // predictexons <i:contigsDB> <i:targetsDB> <o:calledExonsDB> <tmpDir> [flags]   src/workflow/PredictExons.cpp:18-57, data/predictexons.sh
@@ -993,6 +1052,14 @@ int cmdPredictExons(int argc, char **argv) {
     Shard sh;
     if (int rc = shardOf(a, sh, argc, argv)) return rc;
     beginShard(a.pos[2], sh);
+    {   // a PROFILE target database: the inverted search of searchslicedtargetprofile.sh (PredictExons.cpp:22-26 forces it).  Its shards are
+        // the profiles, not the contigs: every worker sees all contigs
+        FILE *f = fopen((a.pos[1] + ".dbtype").c_str(), "rb");
+        int32_t t = -1;
+        if (f) { if (fread(&t, 4, 1, f) != 1) t = -1; fclose(f); }
+        if (t >= 0 && (t & 0xFFFF) == DBTYPE_HMM_PROFILE) return predictExonsProfileTargets(a, P, X, minLength, contigs, ord, sh, a.pos[2], t0);
+        if (get("--exhaustive-search") && *get("--exhaustive-search") != "0") return die("--exhaustive-search 1 with a sequence target database is not implemented%s");
+    }
     if (sh.world > 1) {                                           // this worker's contigs (a contiguous range of the key order)
         std::vector<mk::DbEntry> inOrder(ord.size());
         for (size_t i = 0; i < ord.size(); i++) inOrder[i] = contigs.entries[ord[i]];
@@ -1001,13 +1068,6 @@ int cmdPredictExons(int argc, char **argv) {
         ord = std::vector<size_t>(ord.begin() + (std::ptrdiff_t) first, ord.begin() + (std::ptrdiff_t) (first + count));
     }
     const std::string outPath = sh.world > 1 ? a.pos[2] + "_" + std::to_string(sh.rank) : a.pos[2];
-    {   // a PROFILE target database: the inverted search of searchslicedtargetprofile.sh (PredictExons.cpp:22-26 forces it)
-        FILE *f = fopen((a.pos[1] + ".dbtype").c_str(), "rb");
-        int32_t t = -1;
-        if (f) { if (fread(&t, 4, 1, f) != 1) t = -1; fclose(f); }
-        if (t >= 0 && (t & 0xFFFF) == DBTYPE_HMM_PROFILE) return predictExonsProfileTargets(a, P, X, minLength, contigs, ord, sh, outPath, t0);
-        if (get("--exhaustive-search") && *get("--exhaustive-search") != "0") return die("--exhaustive-search 1 with a sequence target database is not implemented%s");
-    }
     TargetSide ts;
     if (int rc = openTarget(a.pos[1], P, ts)) return rc;
     mk_targetdb *T = ts.T;

@@ -262,6 +262,20 @@ def test_cli_profile_workflow_equals_the_real_process(gpu_api, tmp_path):
     A.write_seq_db(str(tmp_path / "contigs"), A.seq_db_image(contigs), dbtype=1)
     run("predictexons", tmp_path / "contigs", tmp_path / "profDB", tmp_path / "calls", tmp_path / "tmp", "--threads", "4", "--ref-l2-bytes", "2097152")
     assert blocks(_read_result_db(str(tmp_path / "calls"))) == _text("prof_calls.txt.gz")
+    # the same two commands as THREE workers (RANK / WORLD_SIZE of a launcher, all on this GPU): the workers split the profiles, every one
+    # indexes all fragments, worker 0 gathers the alignments (full-precision e-values), swaps and writes -- byte-identical results
+    def run_workers(cmd, world):
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MK_SHARD_TIMEOUT_S="300")
+            procs.append(subprocess.Popen([build.BIN] + [str(x) for x in cmd], env=env, stderr=subprocess.DEVNULL))
+        assert all(p.wait() == 0 for p in procs)
+    run_workers(["search", tmp_path / "aa_6f", tmp_path / "profDB", tmp_path / "search_res_w3", tmp_path / "tmp", "--alignment-mode", "2", "-s", "4", "-e", "100",
+                 "--min-aln-len", "11", "--ref-l2-bytes", "2097152", "--exhaustive-search", "1", "--gpu", "0"], 3)
+    assert blocks(_read_result_db(str(tmp_path / "search_res_w3"))) == _text("prof_search_res.txt.gz")
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("search_res_w3_")], "shard files left behind"
+    run_workers(["predictexons", tmp_path / "contigs", tmp_path / "profDB", tmp_path / "calls_w2", tmp_path / "tmp", "--threads", "4", "--ref-l2-bytes", "2097152", "--gpu", "0"], 2)
+    assert blocks(_read_result_db(str(tmp_path / "calls_w2"))) == _text("prof_calls.txt.gz")
     # the contigs translated in batches of at most 50 000 nucleotides (their fragments still form one indexed side), the profiles in slices of
     # at most 5 000 columns
     env = dict(os.environ, MK_CLI_BATCH_NT="50000", MK_CLI_PROFILE_COLS="5000")
