@@ -91,6 +91,7 @@ int mk_init(int device_ordinal);            /* binds the calling process to one 
 const char *mk_last_error(void);
 void mk_default_params(mk_params *p);       /* defaults of `metaeuk predictexons` (SURVEY.md 3.2 argv) */
 int mk_device_name(char *buf, size_t cap);
+int mk_device_memory(uint64_t *free_bytes, uint64_t *total_bytes);   /* HBM of the bound GPU (the split planner of the commands sizes the target side with it) */
 int mk_host_threads(void);                  /* CPUs usable by this process (affinity and cgroup quota) */
 
 /* ---- encoding: Sequence::mapSequence + SubstitutionMatrix::aa2num (Sequence.cpp:307-324) ---- */
@@ -102,6 +103,11 @@ void mk_encode(const char *ascii, size_t len, uint8_t *codes);
  * residues: encoded 0..20, concatenated; offsets[n+1].  Everything ends up resident in HBM. */
 int mk_targetdb_create(const uint8_t *residues, const uint64_t *offsets, uint32_t n_targets,
                        const mk_params *params, mk_targetdb **out);
+/* the target side as the ALIGNMENT stage needs it (Alignment.cpp opens the sequence DB, not the index): residues and offsets in HBM, the
+ * alignment matrix, the e-value parameters of the whole database -- no masking, no k-mer index.  mk_align takes it (with a prefilter
+ * result installed by mk_prefilter_result_set: the `align` command, the one-pass commands after a target-split prefilter); mk_prefilter /
+ * mk_search refuse it. */
+int mk_targetdb_create_sequences(const uint8_t *residues, const uint64_t *offsets, uint32_t n_targets, const mk_params *params, mk_targetdb **out);
 void mk_targetdb_destroy(mk_targetdb *db);
 uint64_t mk_targetdb_residues(const mk_targetdb *db);
 uint64_t mk_targetdb_index_entries(const mk_targetdb *db);

@@ -48,7 +48,8 @@ EXPORTS = ["mk_init", "mk_last_error", "mk_default_params", "mk_device_name", "m
            "mk_kernel_stats", "mk_kernel_stats_reset", "mk_format_hit", "mk_format_alignment", "mk_format_hits", "mk_format_alignments", "mk_targetdb_set_keys",
            "mk_profiles_create", "mk_profiles_derived", "mk_swap_alignments", "mk_swapped_result", "mk_swapped_destroy",
            "mk_targetdb_masked_residues", "mk_targetdb_kmer_size", "mk_targetdb_longest_list", "mk_targetdb_index_compare",
-           "mk_synth_targets", "mk_synth_fragments", "mk_synth_seqdb"]
+           "mk_synth_targets", "mk_synth_fragments", "mk_synth_seqdb", "mk_targetdb_create_sequences", "mk_prefilter_statistics",
+           "mk_format_prefilter_statistics", "mk_device_memory"]
 
 
 def lib():

@@ -180,6 +180,7 @@ struct mk_targetdb {
     DevBuf<int16_t> dScore2;         // k = 7: similar 2-mers [400][400]
     DevBuf<uint16_t> dIndex2, dNum3; // ... their numbers; address code -> 3-mer number
     bool profileSearch = false;      // built for profile queries (mk_params.profile_search)
+    bool unindexed = false;          // mk_targetdb_create_sequences: residues only, what mk_align needs (no masking, no k-mer index)
     std::vector<int32_t> bitScoreTable;   // static_cast<int>(bitScore(score) + 0.5), score < 32768
 };
 
@@ -338,6 +339,16 @@ int mk_device_name(char *buf, size_t cap) {
     return MK_OK;
 }
 
+int mk_device_memory(uint64_t *freeBytes, uint64_t *totalBytes) {
+    int rc = ensure_ready();
+    if (rc) return rc;
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (freeBytes) *freeBytes = f;
+    if (totalBytes) *totalBytes = t;
+    return MK_OK;
+}
+
 void mk_default_params(mk_params *p) {
     p->sensitivity = 5.7f; p->kmer_score = INT_MAX; p->max_seqs = 300; p->min_ungapped_score = 15;
     p->comp_bias_corr = 1; p->comp_bias_scale = 1.0f; p->mask = 1; p->mask_prob = 0.9f;
@@ -377,7 +388,8 @@ static void adopt_index(mk_targetdb *db, mk::DeviceIndex &ix, uint64_t total) {
 }
 
 // target side: matrices, tables, masking + k-mer index (built in HBM, or taken from an index DB), upload
-static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uint32_t n, const mk_params *P, const PrebuiltIndex *prebuilt, mk_targetdb **out) {
+static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uint32_t n, const mk_params *P, const PrebuiltIndex *prebuilt, mk_targetdb **out,
+                           bool noIndex = false) {
     int rc = ensure_ready();
     if (rc) return rc;
     if (!residues || !offsets || !P || !out) return fail(MK_ERR_ARG, "null argument");
@@ -416,6 +428,19 @@ static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uin
     ok(db->dRes.upload(residues, offsets[n]));
     ok(db->dOff.upload(offsets, n + 1));
     if (e != hipSuccess) { delete db; return fail(MK_ERR_DEVICE, "target upload failed: %s", hipGetErrorString(e)); }
+    if (noIndex) {
+        // the alignment stage's view of the targets (Alignment.cpp opens the sequence DB alone): residues, offsets, matrices, e-values
+        db->unindexed = true;
+        int8_t mA[441], mU[441];
+        for (int i = 0; i < 21; i++)
+            for (int j = 0; j < 21; j++) { mA[i * 21 + j] = (int8_t) db->alnMat.sub[i][j]; mU[i * 21 + j] = (int8_t) db->ungMat.sub[i][j]; }
+        ok(db->dMatAln.upload(mA, 441));
+        ok(db->dMatUng.upload(mU, 441));
+        ok(hipStreamSynchronize(g_stream));
+        if (e != hipSuccess) { delete db; return fail(MK_ERR_DEVICE, "target upload failed: %s", hipGetErrorString(e)); }
+        *out = db;
+        return MK_OK;
+    }
     // MK_INDEX_BUILD=host: mask and index on the host (mk::build_index, the reference of the device builder)
     const char *ib = getenv("MK_INDEX_BUILD");
     const bool hostBuild = !prebuilt && ib && strcmp(ib, "host") == 0;
@@ -508,6 +533,9 @@ static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uin
 void mk_targetdb_destroy(mk_targetdb *db) { delete db; }
 int mk_targetdb_create(const uint8_t *residues, const uint64_t *offsets, uint32_t n, const mk_params *P, mk_targetdb **out) {
     return targetdb_create(residues, offsets, n, P, nullptr, out);
+}
+int mk_targetdb_create_sequences(const uint8_t *residues, const uint64_t *offsets, uint32_t n, const mk_params *P, mk_targetdb **out) {
+    return targetdb_create(residues, offsets, n, P, nullptr, out, true);
 }
 
 // ---- createindex's precomputed index DB (mk_indexfile.cpp) ----
@@ -669,6 +697,7 @@ uint64_t mk_targetdb_residues(const mk_targetdb *db) { return db ? db->off[db->n
 uint64_t mk_targetdb_index_entries(const mk_targetdb *db) { return db ? db->nEntries : 0; }
 int mk_targetdb_masked(const mk_targetdb *db, uint8_t *out) {
     if (!db || !out) return fail(MK_ERR_ARG, "null argument");
+    if (db->unindexed) return fail(MK_ERR_ARG, "this target database holds no masked residues (mk_targetdb_create_sequences)");
     const uint8_t *m = masked_host(const_cast<mk_targetdb *>(db));
     if (!m) return fail(MK_ERR_DEVICE, "cannot fetch the masked residues from the device");
     std::memcpy(out, m, db->off[db->n]);
@@ -1057,6 +1086,7 @@ int mk_ungapped(mk_targetdb *db, mk_queries *q, const uint32_t *qIdx, const uint
     int rc = ensure_ready();
     if (rc) return rc;
     if (!db || !q || !outScores) return fail(MK_ERR_ARG, "null argument");
+    if (db->unindexed) return fail(MK_ERR_ARG, "mk_ungapped needs a target database with masked residues (this one was made by mk_targetdb_create_sequences)");
     if (q->isProfile) return fail(MK_ERR_UNSUPPORTED, "mk_ungapped takes sequence queries (the prefilter scores profile diagonals itself)");
     std::vector<mk::UngappedJob> jobs(n);
     double bytes = 0;
@@ -1115,7 +1145,12 @@ static int match_kmer_size(const mk_targetdb *db, mk_queries *q) {
 }
 
 // a profile batch searches a target side built for it (and only that one)
+static int check_indexed(const mk_targetdb *db, const char *what) {
+    if (db->unindexed) return fail(MK_ERR_ARG, "%s needs a target database with a k-mer index: this one was made by mk_targetdb_create_sequences (residues only, for mk_align)", what);
+    return MK_OK;
+}
 static int check_roles(const mk_targetdb *db, const mk_queries *q) {
+    if (db->unindexed) return MK_OK;                    // (residues serve either kind of query)
     if (q->isProfile != db->profileSearch)
         return fail(MK_ERR_ARG, q->isProfile ? "profile queries need a target database created with params->profile_search = 1"
                                              : "this target database was created for profile queries (params->profile_search = 1)");
@@ -1126,6 +1161,7 @@ int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     int rc = ensure_ready();
     if (rc) return rc;
     if (!db || !q || !P) return fail(MK_ERR_ARG, "null argument");
+    if ((rc = check_indexed(db, "mk_prefilter")) != MK_OK) return rc;
     if ((rc = check_roles(db, q)) != MK_OK) return rc;
     if ((rc = match_kmer_size(db, q)) != MK_OK) return rc;
     std::string err;
@@ -1340,6 +1376,7 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     int rc = ensure_ready();
     if (rc) return rc;
     if (!db || !q || !P) return fail(MK_ERR_ARG, "null argument");
+    if ((rc = check_indexed(db, "mk_search")) != MK_OK) return rc;
     if ((rc = check_roles(db, q)) != MK_OK) return rc;
     if ((rc = match_kmer_size(db, q)) != MK_OK) return rc;
     if (q->isProfile) {          // profile queries: the two stages back to back (their kernels are not tuned to share the GPU)

@@ -120,12 +120,6 @@ int parse(int argc, char **argv, Args &a) {
             a.pos.push_back(s);
         }
     }
-    {   // target splits change the prefilter's results; only the prefilter command restates them (cmdPrefilterOrAlign)
-        auto sp = a.opt.find("--split"), sm = a.opt.find("--split-mode");
-        const std::string cmd = argc > 1 ? argv[1] : "";
-        if (sp != a.opt.end() && sm != a.opt.end() && sm->second == "0" && atoi(sp->second.c_str()) > 1 && cmd != "prefilter" && cmd != "align")
-            return die("--split %s --split-mode 0 (target splits) is implemented by the prefilter command only", sp->second);
-    }
     for (const Flag &k : FLAGS) {
         auto it = a.opt.find(k.name);
         if (it == a.opt.end() || k.honoured) continue;
@@ -229,6 +223,7 @@ double invertedEvalue(double evalThr, size_t nFragments, size_t nProfiles) {
 // MMSEQS_IGNORE_INDEX is unset -- PrefilteringIndexReader::searchForIndex, PrefilteringIndexReader.cpp:568-579), else built from the
 // sequence DB.  keys[i] = DB key of target i.
 struct TargetSide { mk_targetdb *T = nullptr; std::vector<uint32_t> keys; bool fromIndex = false; };
+int openTargetDb(const mk::Database &tdb, const mk_params &P, TargetSide &ts);
 int openTarget(const std::string &path, const mk_params &P, TargetSide &ts) {
     std::string idx;
     {
@@ -250,6 +245,9 @@ int openTarget(const std::string &path, const mk_params &P, TargetSide &ts) {
     mk::Database tdb;
     const std::string e = tdb.open(path);
     if (!e.empty()) return die("%s", e);
+    return openTargetDb(tdb, P, ts);
+}
+int openTargetDb(const mk::Database &tdb, const mk_params &P, TargetSide &ts) {
     if ((tdb.dbtype & 0xFFFF) != mk::DBTYPE_AMINO_ACIDS) return die("only amino-acid target databases are implemented (profile targets: SURVEY 8f-4)%s");
     std::vector<uint8_t> tres;
     std::vector<uint64_t> toff;
@@ -406,6 +404,149 @@ int searchProfileTargets(const Args &a, mk_params P, const mk::Database &qdb, co
     return EXIT_SUCCESS;
 }
 
+
+// ---- target splits (TARGET_DB_SPLIT) -------------------------------------------------------------------------------------------------
+// Prefiltering::estimateMemoryConsumption (Prefiltering.cpp:1067-1104): what the REFERENCE needs in host memory for one split
+uint64_t refMemoryConsumption(int split, uint64_t dbSize, uint64_t resSize, uint64_t maxResListLen, int alphabetSize, int kmerSize, int threads) {
+    const uint64_t dbSizeSplit = dbSize / (uint64_t) split;
+    const uint64_t residueSize = resSize / (uint64_t) split * 7;
+    const uint64_t indexTableSize = static_cast<uint64_t>(pow(alphabetSize, kmerSize)) * 8;
+    const uint64_t threadSize = (uint64_t) ((double) threads * ((double) (dbSizeSplit * 2 * 6) + (double) dbSizeSplit * 1.5 * 7.0 + (double) (maxResListLen * 12) + (double) (dbSizeSplit * 2 * 7 * 2)));
+    const uint64_t dbReaderSize = dbSize * (24 + 4);
+    const uint64_t extendedMatrix = 8 * static_cast<uint64_t>(pow(pow(alphabetSize, 3), 2)) + (uint64_t) (8 * pow(pow(alphabetSize, 2), 2));
+    const uint64_t background = dbSize * 22;
+    return residueSize + indexTableSize + threadSize + background + extendedMatrix + dbReaderSize;
+}
+// ByteParser::parse (commons/ByteParser.h:11-60): digits + B / K / M / G / T, no unit = M
+uint64_t parseBytes(const std::string &v) {
+    if (v.empty()) return 0;
+    uint64_t unit = 1ull << 20;
+    std::string digits = v;
+    const char last = v[v.size() - 1];
+    if (!(last >= '0' && last <= '9')) {
+        digits = v.substr(0, v.size() - 1);
+        switch (last) { case 't': case 'T': unit = 1ull << 40; break; case 'g': case 'G': unit = 1ull << 30; break; case 'm': case 'M': unit = 1ull << 20; break;
+                        case 'k': case 'K': unit = 1ull << 10; break; case 'b': case 'B': unit = 1; break; default: return ~0ull; }
+    }
+    return strtoull(digits.c_str(), nullptr, 10) * unit;
+}
+// What Prefiltering::setupSplit (Prefiltering.cpp:273-377) makes of --split / --split-mode / --split-memory-limit:
+//   --split N --split-mode 0         N target splits, as given;
+//   --split 0 (the default), mode 0 or 2, --split-memory-limit L > 0: the smallest N (and, with -k 0, the k) whose estimated need fits 0.9 L --
+//                                    the reference's own estimate and search order (optimizeSplit, :1143-1176), L less what its DB readers hold
+//                                    (MemoryTracker: ~32 bytes per entry of the two sequence DBs, an approximation);
+//   no limit given:                  the limit is this GPU's memory -- one split unless masked residues + index of the whole database cannot
+//                                    live in HBM next to the search's scratch (then the smallest N that can).
+// N > 1 changes the result the way it changes the reference's: k from the residues per split, --max-seqs cut per split, BINSIZE per split.
+struct SplitPlan { int splits = 1; int kmerSize = 0; int maxSeqs = 300; bool chosen = false; };
+int planTargetSplits(const Args &a, const mk_params &P, size_t nT, uint64_t aaSize, size_t nQ, SplitPlan &plan) {
+    auto get = [&](const char *k) -> const std::string * { auto it = a.opt.find(k); return it == a.opt.end() ? nullptr : &it->second; };
+    const int splitArg = get("--split") ? atoi(get("--split")->c_str()) : 0;
+    const int modeArg = get("--split-mode") ? atoi(get("--split-mode")->c_str()) : 2;
+    const uint64_t limitArg = get("--split-memory-limit") ? parseBytes(*get("--split-memory-limit")) : 0;
+    if (limitArg == ~0ull) return die("--split-memory-limit %s: not a size", *get("--split-memory-limit"));
+    const int threads = get("--threads") ? std::max(1, atoi(get("--threads")->c_str())) : mk_host_threads();
+    const size_t maxRes = std::min<size_t>(nT, (size_t) P.max_seqs);                                      // Prefiltering.cpp:169
+    plan.splits = 1; plan.kmerSize = P.kmer_size; plan.maxSeqs = P.max_seqs;
+    if (modeArg == 1) return 0;                                                                            // query splits leave the results alone
+    if (splitArg > 1 && modeArg == 0) plan.splits = splitArg;
+    else if (splitArg == 0) {
+        if (limitArg > 0) {
+            const uint64_t tracker = 32ull * ((uint64_t) nT + (uint64_t) nQ);
+            const uint64_t limit = limitArg > tracker ? limitArg - tracker : 0;
+            const int kAll = P.kmer_size ? P.kmer_size : (aaSize < 3350000000ull ? 6 : 7);
+            if ((double) refMemoryConsumption(1, nT, aaSize, maxRes, 20, kAll, threads) > 0.9 * (double) limit) {
+                int found = -1, foundK = 0;
+                for (int k = P.kmer_size ? P.kmer_size : 7; k >= (P.kmer_size ? P.kmer_size : 6) && found < 0; k--)
+                    for (int sp = 1; sp < 1000; sp++) {
+                        if (!P.kmer_size && k == 6 && aaSize / (uint64_t) sp >= 3350000000ull) continue;          // getUpperBoundAACountForKmerSize
+                        if ((double) refMemoryConsumption(sp, nT, aaSize, 0, 20, k, threads) < 0.9 * (double) limit) { found = sp; foundK = k; break; }
+                    }
+                if (found < 0) return die("Cannot fit databases into %s. Please use a computer with more main memory.", *get("--split-memory-limit"));
+                plan.splits = (int) std::min<size_t>(nT, (size_t) found);
+                if (!P.kmer_size) plan.kmerSize = foundK;
+                plan.chosen = true;
+            }
+        } else {
+            // this GPU: masked + unmasked residues, 8-byte entries (one per residue at most), slots + bits of the k-mer table, ~24 GB of search scratch
+            uint64_t freeB = 0, totalB = 0;
+            if (mk_device_memory(&freeB, &totalB) != MK_OK) totalB = 288ull << 30;
+            for (int sp = 1; sp < 1000; sp++) {
+                const uint64_t per = aaSize / (uint64_t) sp;
+                const int k = P.kmer_size ? P.kmer_size : (per < 3350000000ull ? 6 : 7);
+                const double need = 2.0 * (double) aaSize + 9.0 * (double) per + (k == 7 ? 1.28e9 : 6.4e7) * 12.2 + 24.0 * 1073741824.0;
+                if (need < 0.9 * (double) totalB) { plan.splits = sp; plan.chosen = sp > 1; break; }
+                if (sp == 999) return die("the target database does not fit this GPU even in 999 splits%s");
+            }
+        }
+    }
+    if ((size_t) plan.splits > nT) return die("split was set to %s but the db to split has fewer sequences", std::to_string(plan.splits));
+    if (plan.splits > 1) {
+        if (!plan.kmerSize) plan.kmerSize = aaSize / (uint64_t) plan.splits < 3350000000ull ? 6 : 7;               // Prefiltering.cpp:352-355
+        const size_t fourTimesStdDeviation = (size_t) (4 * sqrt(static_cast<double>(maxRes) / static_cast<double>(plan.splits)));
+        plan.maxSeqs = (int) std::max<size_t>(1, (maxRes / (size_t) plan.splits) + fourTimesStdDeviation);         // :359-362
+    }
+    return 0;
+}
+
+// Prefilter of batch Q against the targets in `plan.splits` residue-balanced ranges (Prefiltering::runSplit with TARGET_DB_SPLIT, :733-750): every
+// range is masked, indexed and searched on its own -- its own BINSIZE, the reduced --max-seqs -- and a query's lists are joined and sorted by
+// (score, key) like Prefiltering::mergeTargetSplits (:379-496) does; the joined list is NOT cut again.  The result is installed in Q with
+// seq_id = position in tdb (mk_prefilter_result_set), so that mk_align / the writers go on as after a one-piece prefilter.
+int splitPrefilter(mk_queries *Q, size_t nq, const mk::Database &tdb, const mk_params &P, const SplitPlan &plan, uint64_t &total) {
+    mk_params PS = P;
+    PS.kmer_size = plan.kmerSize;
+    PS.max_seqs = plan.maxSeqs;
+    std::vector<std::vector<mk_hit>> merged(nq);
+    for (int sp = 0; sp < plan.splits; sp++) {
+        size_t first = 0, count = 0;
+        mk::decomposeByLength(tdb.entries, sp, plan.splits, first, count);
+        if (count == 0) continue;
+        std::vector<uint64_t> toff(count + 1, 0);
+        for (size_t i = 0; i < count; i++) toff[i + 1] = toff[i] + tdb.seqLen(first + i);
+        std::vector<uint8_t> tres(toff.back() + 1, 0);
+#pragma omp parallel for schedule(dynamic, 256)
+        for (size_t i = 0; i < count; i++) mk_encode(tdb.entry(first + i), tdb.seqLen(first + i), tres.data() + toff[i]);
+        mk_targetdb *TS = nullptr;
+        if (mk_targetdb_create(tres.data(), toff.data(), (uint32_t) count, &PS, &TS) != MK_OK) return die("%s", mk_last_error());
+        if (mk_prefilter(TS, Q, &PS) != MK_OK) return die("%s", mk_last_error());
+        const mk_hit *hits; const uint64_t *hoff;
+        mk_prefilter_result(Q, &hits, &hoff);
+        for (size_t i = 0; i < nq; i++)
+            for (uint64_t h = hoff[i]; h < hoff[i + 1]; h++) { mk_hit x = hits[h]; x.seq_id += (uint32_t) first; merged[i].push_back(x); }
+        mk_targetdb_destroy(TS);
+    }
+    std::vector<uint64_t> off(nq + 1, 0);
+    for (size_t i = 0; i < nq; i++) off[i + 1] = off[i] + merged[i].size();
+    std::vector<mk_hit> all(off[nq] + 1);
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (size_t i = 0; i < nq; i++) {
+        std::vector<mk_hit> &v = merged[i];
+        std::sort(v.begin(), v.end(), [&](const mk_hit &x, const mk_hit &y) {          // hit_t::compareHitsByScoreAndId on the parsed lines (seqId = key)
+            if (std::abs(x.pref_score) != std::abs(y.pref_score)) return std::abs(x.pref_score) > std::abs(y.pref_score);
+            return tdb.entries[x.seq_id].key < tdb.entries[y.seq_id].key;
+        });
+        std::copy(v.begin(), v.end(), all.begin() + (std::ptrdiff_t) off[i]);
+    }
+    total = off[nq];
+    if (mk_prefilter_result_set(Q, all.data(), off.data()) != MK_OK) return die("%s", mk_last_error());
+    return 0;
+}
+
+// the targets as the alignment stage needs them: residues in HBM, no index (mk_targetdb_create_sequences)
+int openTargetSequences(const mk::Database &tdb, const mk_params &P, TargetSide &ts) {
+    std::vector<uint64_t> toff(tdb.entries.size() + 1, 0);
+    for (size_t i = 0; i < tdb.entries.size(); i++) toff[i + 1] = toff[i] + tdb.seqLen(i);
+    std::vector<uint8_t> tres(toff.back() + 1, 0);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (size_t i = 0; i < tdb.entries.size(); i++) mk_encode(tdb.entry(i), tdb.seqLen(i), tres.data() + toff[i]);
+    if (mk_targetdb_create_sequences(tres.data(), toff.data(), (uint32_t) tdb.entries.size(), &P, &ts.T) != MK_OK) return die("%s", mk_last_error());
+    ts.keys.resize(tdb.entries.size());
+    for (size_t i = 0; i < ts.keys.size(); i++) ts.keys[i] = tdb.entries[i].key;
+    if (mk_targetdb_set_keys(ts.T, ts.keys.data(), (uint32_t) ts.keys.size()) != MK_OK) return die("%s", mk_last_error());
+    return 0;
+}
+
 // mode: 0 = prefilter, 1 = align, 2 = search (the `search` workflow's two modules as one pipelined pass: <queryDB> <targetDB> <alignmentDB>
 // <tmpDir>, nothing written in between -- blastp.sh:70,85 without the pref_0 round trip)
 int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
@@ -454,15 +595,10 @@ int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
     std::vector<uint8_t> qres;
     std::vector<uint64_t> qoff;
     if (profileQueries) profileColumns(qdb, qres, qoff); else encodeDb(qdb, qres, qoff);
-    // TARGET_DB_SPLIT with N > 1 changes the prefilter's results (per-split --max-seqs, BINSIZE, merge order): honoured by `prefilter`,
-    // refused where the stages run as one pass.  Query splits (--split-mode 1) and the automatic mode leave the results alone.
-    int targetSplits = 1;
-    if (a.opt.count("--split") && a.opt.count("--split-mode") && a.opt["--split-mode"] == "0" && atoi(a.opt["--split"].c_str()) > 1) {
-        targetSplits = atoi(a.opt["--split"].c_str());
-        if (isSearch) return die("search with --split %s --split-mode 0: target splits are implemented by the prefilter command", a.opt["--split"]);
-        if (profileQueries) return die("--split-mode 0 with profile queries is not implemented%s");
-        if (isAlign) targetSplits = 1;                                   // (align has no such flag in the reference; tolerated)
-    }
+    // TARGET_DB_SPLIT (explicit, or chosen from --split-memory-limit / this GPU's memory: planTargetSplits) changes the prefilter's results
+    // (per-split --max-seqs, BINSIZE, merge order); `prefilter` and `search` honour it, `align` reads whatever prefilter DB it is given
+    if (profileQueries && a.opt.count("--split") && a.opt.count("--split-mode") && a.opt["--split-mode"] == "0" && atoi(a.opt["--split"].c_str()) > 1)
+        return die("--split-mode 0 with profile queries is not implemented%s");
     {   // `search <fragmentDB> <profileDB>`: Search.cpp:357-399 turns a profile TARGET database into the inverted sliced search
         FILE *f = fopen((a.pos[1] + ".dbtype").c_str(), "rb");
         int32_t t = -1;
@@ -487,8 +623,34 @@ int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
         auto ex = a.opt.find("--exhaustive-search");
         if (ex != a.opt.end() && ex->second != "0") return die("--exhaustive-search 1 with a sequence target database is not implemented%s");
     }
+    // the target side: a sequence DB is looked at first (its size decides about target splits); an index DB holds one split
     TargetSide ts;
-    if (targetSplits == 1) { if (int rc = openTarget(a.pos[1], P, ts)) return rc; }
+    SplitPlan plan;
+    plan.kmerSize = P.kmer_size; plan.maxSeqs = P.max_seqs;
+    mk::Database tdbSeq;
+    bool haveSeqDb = false;
+    {
+        FILE *f = fopen((a.pos[1] + ".dbtype").c_str(), "rb");
+        int32_t t = -1;
+        if (f) { if (fread(&t, 4, 1, f) != 1) t = -1; fclose(f); }
+        const bool explicitSplit = a.opt.count("--split") && atoi(a.opt["--split"].c_str()) > 1 && a.opt.count("--split-mode") && a.opt["--split-mode"] == "0";
+        const bool hasIdx = (t >= 0 && (t & 0xFFFF) == 9) || (!P.profile_search && !getenv("MMSEQS_IGNORE_INDEX") && mk::Database::exists(a.pos[1] + ".idx.dbtype"));
+        if (explicitSplit && t >= 0 && (t & 0xFFFF) == 9) return die("--split with --split-mode 0 needs an amino-acid sequence DB as the target (index DBs hold one split)%s");
+        if (t >= 0 && (t & 0xFFFF) == mk::DBTYPE_AMINO_ACIDS && (isAlign && !isSearch ? true : (explicitSplit || !hasIdx))) {
+            e = tdbSeq.open(a.pos[1]);
+            if (!e.empty()) return die("%s", e);
+            haveSeqDb = true;
+            if (!isAlign || isSearch) {
+                uint64_t aaSize = 0;
+                for (size_t i = 0; i < tdbSeq.entries.size(); i++) aaSize += tdbSeq.seqLen(i);
+                if (!profileQueries) { if (int rc = planTargetSplits(a, P, tdbSeq.entries.size(), aaSize, qdb.entries.size(), plan)) return rc; }
+            }
+        }
+    }
+    const int targetSplits = plan.splits;
+    if (isAlign && !isSearch && haveSeqDb) { if (int rc = openTargetSequences(tdbSeq, P, ts)) return rc; }      // align: residues only, no index is built
+    else if (targetSplits == 1) { if (int rc = haveSeqDb ? openTargetDb(tdbSeq, P, ts) : openTarget(a.pos[1], P, ts)) return rc; }
+    else if (isSearch) { if (int rc = openTargetSequences(tdbSeq, P, ts)) return rc; }                          // the alignment half of a split search
     mk_targetdb *T = ts.T;
     const std::vector<uint32_t> &tkeys = ts.keys;
     mk_queries *Q = nullptr;
@@ -498,61 +660,23 @@ int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
     char line[512];
     std::string buf;
     if (!isAlign && targetSplits > 1) {
-        // --split N --split-mode 0 (TARGET_DB_SPLIT, Prefiltering.cpp:352-361,379-496): the targets are cut into N residue-balanced ranges
-        // (Util::decomposeDomainByAminoAcid over the DB's data order), every range is indexed and searched on its own -- with its own BINSIZE
-        // and a reduced --max-seqs -- and the N hit lists of a query are joined and sorted by (score, key); the joined list is NOT cut again
-        mk::Database tdb;
-        e = tdb.open(a.pos[1]);
-        if (!e.empty()) return die("%s", e);
-        if ((tdb.dbtype & 0xFFFF) != mk::DBTYPE_AMINO_ACIDS) return die("--split with --split-mode 0 needs an amino-acid sequence DB as the target (index DBs hold one split)%s");
-        const size_t nT = tdb.entries.size();
-        if ((size_t) targetSplits > nT) return die("split was set to %s but the db to split has fewer sequences", std::to_string(targetSplits));
-        uint64_t aaSize = 0;
-        for (size_t i = 0; i < nT; i++) aaSize += tdb.seqLen(i);
-        mk_params PS = P;
-        if (!PS.kmer_size) PS.kmer_size = aaSize / (uint64_t) targetSplits < 3350000000ull ? 6 : 7;      // Prefiltering.cpp:352-355
-        {
-            const size_t maxRes = std::min<size_t>(nT, (size_t) P.max_seqs);                              // Prefiltering.cpp:169, then :359-362
-            const size_t fourTimesStdDeviation = (size_t) (4 * sqrt(static_cast<double>(maxRes) / static_cast<double>(targetSplits)));
-            PS.max_seqs = (int) std::max<size_t>(1, (maxRes / (size_t) targetSplits) + fourTimesStdDeviation);
-        }
-        struct KeyHit { uint32_t key; int32_t score; uint16_t diag; };
-        std::vector<std::vector<KeyHit>> merged(nq);
-        for (int sp = 0; sp < targetSplits; sp++) {
-            size_t first = 0, count = 0;
-            mk::decomposeByLength(tdb.entries, sp, targetSplits, first, count);
-            std::vector<uint64_t> toff(count + 1, 0);
-            for (size_t i = 0; i < count; i++) toff[i + 1] = toff[i] + tdb.seqLen(first + i);
-            std::vector<uint8_t> tres(toff.back() + 1, 0);
-            for (size_t i = 0; i < count; i++) mk_encode(tdb.entry(first + i), tdb.seqLen(first + i), tres.data() + toff[i]);
-            mk_targetdb *TS = nullptr;
-            if (mk_targetdb_create(tres.data(), toff.data(), (uint32_t) count, &PS, &TS) != MK_OK) return die("%s", mk_last_error());
-            if (mk_prefilter(TS, Q, &PS) != MK_OK) return die("%s", mk_last_error());
-            const mk_hit *hits; const uint64_t *hoff;
-            mk_prefilter_result(Q, &hits, &hoff);
-            for (size_t i = 0; i < nq; i++)
-                for (uint64_t h = hoff[i]; h < hoff[i + 1]; h++) merged[i].push_back(KeyHit{tdb.entries[first + hits[h].seq_id].key, hits[h].pref_score, hits[h].diagonal});
-            mk_targetdb_destroy(TS);
-        }
+        // TARGET_DB_SPLIT (Prefiltering.cpp:352-361,379-496): splitPrefilter
+        uint64_t total = 0;
+        if (int rc = splitPrefilter(Q, nq, tdbSeq, P, plan, total)) return rc;
+        const mk_hit *hits; const uint64_t *hoff;
+        mk_prefilter_result(Q, &hits, &hoff);
         mk::DatabaseWriter w(outPath, mk::DBTYPE_PREFILTER_RES);
         e = w.open();
         if (!e.empty()) return die("%s", e);
-        uint64_t total = 0;
         for (size_t i = 0; i < nq; i++) {
-            std::vector<KeyHit> &v = merged[i];
-            std::sort(v.begin(), v.end(), [](const KeyHit &x, const KeyHit &y) {          // hit_t::compareHitsByScoreAndId on the parsed lines (seqId = key)
-                if (std::abs(x.score) != std::abs(y.score)) return std::abs(x.score) > std::abs(y.score);
-                return x.key < y.key;
-            });
             buf.clear();
-            for (const KeyHit &h : v) buf.append(line, mk_format_hit(line, h.key, h.score, h.diag));
+            for (uint64_t h = hoff[i]; h < hoff[i + 1]; h++) buf.append(line, mk_format_hit(line, tdbSeq.entries[hits[h].seq_id].key, hits[h].pref_score, hits[h].diagonal));
             w.write(qdb.entries[i].key, buf.data(), buf.size());
-            total += v.size();
         }
         e = w.close();
         if (!e.empty()) return die("%s", e);
-        fprintf(stderr, "prefilter: %zu queries x %zu targets in %d target splits (--max-seqs %d per split, k = %d), %llu hits, %.2f s\n", nq, nT, targetSplits, PS.max_seqs,
-                PS.kmer_size, (unsigned long long) total, now() - t0);
+        fprintf(stderr, "prefilter: %zu queries x %zu targets in %d target splits%s (--max-seqs %d per split, k = %d), %llu hits, %.2f s\n", nq, tdbSeq.entries.size(), targetSplits,
+                plan.chosen ? " [chosen from the memory limit]" : "", plan.maxSeqs, plan.kmerSize, (unsigned long long) total, now() - t0);
     } else if (!isAlign) {
         if (mk_prefilter(T, Q, &P) != MK_OK) return die("%s", mk_last_error());
         const mk_hit *hits; const uint64_t *hoff;
@@ -572,7 +696,14 @@ int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
         fprintf(stderr, "prefilter: %zu queries x %zu targets%s, %llu hits, %.2f s\n", nq, tkeys.size(), ts.fromIndex ? " (precomputed index)" : "", (unsigned long long) hoff[nq], now() - t0);
     } else {
         std::vector<mk_hit> hits;
-        if (isSearch) {
+        if (isSearch && targetSplits > 1) {
+            // search over target splits: the prefilter of every split, the joined lists, then the alignment against the whole database
+            uint64_t total = 0;
+            if (int rc = splitPrefilter(Q, nq, tdbSeq, P, plan, total)) return rc;
+            if (mk_align(T, Q, &P) != MK_OK) return die("%s", mk_last_error());
+            hits.resize(total);
+            fprintf(stderr, "search: %d target splits%s (--max-seqs %d per split, k = %d)\n", targetSplits, plan.chosen ? " [chosen from the memory limit]" : "", plan.maxSeqs, plan.kmerSize);
+        } else if (isSearch) {
             if (mk_search(T, Q, &P) != MK_OK) return die("%s", mk_last_error());
             const mk_hit *hp; const uint64_t *ho;
             mk_prefilter_result(Q, &hp, &ho);
@@ -1068,8 +1199,30 @@ int cmdPredictExons(int argc, char **argv) {
         ord = std::vector<size_t>(ord.begin() + (std::ptrdiff_t) first, ord.begin() + (std::ptrdiff_t) (first + count));
     }
     const std::string outPath = sh.world > 1 ? a.pos[2] + "_" + std::to_string(sh.rank) : a.pos[2];
+    // the target side; a sequence DB that needs (or is told to use) target splits keeps only its residues resident: every contig batch then
+    // runs the prefilter split by split and aligns against the whole database (splitPrefilter)
     TargetSide ts;
-    if (int rc = openTarget(a.pos[1], P, ts)) return rc;
+    SplitPlan plan;
+    plan.kmerSize = P.kmer_size; plan.maxSeqs = P.max_seqs;
+    mk::Database tdbSeq;
+    {
+        FILE *f = fopen((a.pos[1] + ".dbtype").c_str(), "rb");
+        int32_t t = -1;
+        if (f) { if (fread(&t, 4, 1, f) != 1) t = -1; fclose(f); }
+        const bool explicitSplit = get("--split") && atoi(get("--split")->c_str()) > 1 && get("--split-mode") && *get("--split-mode") == "0";
+        const bool hasIdx = (t >= 0 && (t & 0xFFFF) == 9) || (!getenv("MMSEQS_IGNORE_INDEX") && mk::Database::exists(a.pos[1] + ".idx.dbtype"));
+        if (explicitSplit && t >= 0 && (t & 0xFFFF) == 9) return die("--split with --split-mode 0 needs an amino-acid sequence DB as the target (index DBs hold one split)%s");
+        if (t >= 0 && (t & 0xFFFF) == mk::DBTYPE_AMINO_ACIDS && (explicitSplit || !hasIdx)) {
+            e = tdbSeq.open(a.pos[1]);
+            if (!e.empty()) return die("%s", e);
+            uint64_t aaSize = 0, nucl = 0;
+            for (size_t i = 0; i < tdbSeq.entries.size(); i++) aaSize += tdbSeq.seqLen(i);
+            for (size_t i = 0; i < contigs.entries.size(); i++) nucl += contigs.seqLen(i);
+            // (the fragment DB the reference would have open is not written here: ~1 fragment per 25 nucleotides stands in for its size)
+            if (int rc = planTargetSplits(a, P, tdbSeq.entries.size(), aaSize, (size_t) (nucl / 25), plan)) return rc;
+            if (int rc = plan.splits > 1 ? openTargetSequences(tdbSeq, P, ts) : openTargetDb(tdbSeq, P, ts)) return rc;
+        } else if (int rc = openTarget(a.pos[1], P, ts)) return rc;
+    }
     mk_targetdb *T = ts.T;
     const std::vector<uint32_t> &tkeys = ts.keys;
     const double t1 = now();
@@ -1132,7 +1285,11 @@ int cmdPredictExons(int argc, char **argv) {
         const mk_orf *orfs; const uint64_t *aaOff; const char *aa; uint64_t nb = 0;
         mk_orfs_result(O, &orfs, &aaOff, &aa, &nb);
         if (mk_queries_from_orfs(O, &P, &Q) != MK_OK) return die("%s", mk_last_error());
-        if (mk_search(T, Q, &P) != MK_OK) return die("%s", mk_last_error());
+        if (plan.splits > 1) {
+            uint64_t total = 0;
+            if (int rc = splitPrefilter(Q, (size_t) nb, tdbSeq, P, plan, total)) return rc;
+            if (mk_align(T, Q, &P) != MK_OK) return die("%s", mk_last_error());
+        } else if (mk_search(T, Q, &P) != MK_OK) return die("%s", mk_last_error());
         if (mk_predict_exons(T, O, Q, &X, tkeys.data(), &R) != MK_OK) return die("%s", mk_last_error());
         const mk_prediction *preds; const uint64_t *coff; const mk_exon *exons; uint64_t npb = 0;
         mk_predictions_result(R, &preds, &coff, &exons, &npb);
@@ -1156,6 +1313,7 @@ int cmdPredictExons(int argc, char **argv) {
     const double t2 = now();
     e = w.close();
     if (!e.empty()) return die("%s", e);
+    if (plan.splits > 1) fprintf(stderr, "predictexons: %d target splits%s (--max-seqs %d per split, k = %d)\n", plan.splits, plan.chosen ? " [chosen from the memory limit]" : "", plan.maxSeqs, plan.kmerSize);
     fprintf(stderr, "predictexons: %zu contigs -> %llu fragments x %zu targets -> %llu predictions; %.2f s (target index %.2f s, fragments to exon sets %.2f s)\n",
             ord.size(), (unsigned long long) nOrfs, tkeys.size(), (unsigned long long) np, now() - t0, t1 - t0, t2 - t1);
     mk_targetdb_destroy(T);

@@ -88,5 +88,59 @@ def test_cli_target_splits_and_k7_match_the_real_process(gpu_api, tmp_path):
     assert r.returncode == 0, r.stderr.decode()
     expected = _text("e2e_process_pref_k7.txt.gz")
     assert blocks(_read_result_db(str(tmp_path / "pref_k7"))) == expected[:expected.index(">2000\n")]
-    r = run("search", tmp_path / "frags2k", tmp_path / "targets", tmp_path / "aln", tmp_path / "tmp", "--alignment-mode", "2", "--split", "3", "--split-mode", "0")
-    assert r.returncode != 0 and b"target splits" in r.stderr
+    # target splits inside the one-pass commands: `search --split 3 --split-mode 0` = the split prefilter + the alignment of the joined lists
+    # against the whole database (the oracle's pipeline with --split 3 -- pinned to the reference harness's mergeTargetSplits run in
+    # tests/test_oracle_golden.py)
+    (tmp_path / "t.txt").write_text("\n".join(targets) + "\n")
+    (tmp_path / "q.txt").write_text("\n".join(frags[:2000]) + "\n")
+    subprocess.check_call([oracle.CLI, "pipeline", str(tmp_path / "t.txt"), str(tmp_path / "q.txt"), str(tmp_path / "osplit"), "-s", "5.7", "--split", "3",
+                           "--max-seqs", "20", "--l2", "2097152"], stdout=subprocess.DEVNULL)
+    r = run("search", tmp_path / "frags2k", tmp_path / "targets", tmp_path / "aln_sp3", tmp_path / "tmp", "--alignment-mode", "2", "--split", "3", "--split-mode", "0",
+            "-s", "5.7", "--max-seqs", "20", "-e", "100", "--min-aln-len", "11", "--ref-l2-bytes", "2097152")
+    assert r.returncode == 0, r.stderr.decode()
+    assert b"3 target splits" in r.stderr
+    got = blocks(_read_result_db(str(tmp_path / "aln_sp3")))
+    assert got == open(tmp_path / "osplit" / "aln.txt").read() and got.count("\n") > 2100
+    # `align` keeps no index: its target side is the residues alone
+    r = run("prefilter", tmp_path / "frags2k", tmp_path / "targets", tmp_path / "pref_sp3b", "--split", "3", "--split-mode", "0", "-s", "5.7", "--max-seqs", "20",
+            "--ref-l2-bytes", "2097152")
+    assert r.returncode == 0
+    r = run("align", tmp_path / "frags2k", tmp_path / "targets", tmp_path / "pref_sp3b", tmp_path / "aln_sp3b", "--alignment-mode", "2", "-e", "100", "--min-aln-len", "11")
+    assert r.returncode == 0, r.stderr.decode()
+    assert blocks(_read_result_db(str(tmp_path / "aln_sp3b"))) == got
+
+
+def test_cli_split_chosen_from_the_memory_limit(gpu_api, tmp_path):
+    """--split 0 (the default) with --split-memory-limit: the number of target splits follows the reference's own estimate
+    (Prefiltering::setupSplit / optimizeSplit / estimateMemoryConsumption, Prefiltering.cpp:273-377,1067-1176) -- for the 100 000-protein
+    database of config 2 and 16 threads a limit of 1450 M asks for two splits -- and the result is the reference's two-split result;
+    `predictexons` takes the same path, and a limit nothing fits is an error, as in the reference"""
+    from metaeuk_amd import api as A, build, synth
+    targets, queries = synth.make_workload(12, 100000, seed=11)
+    targets, queries = list(targets), list(queries)[:1500]
+    A.write_seq_db(str(tmp_path / "T"), A.seq_db_image(targets))
+    A.write_seq_db(str(tmp_path / "Q"), A.seq_db_image(queries))
+    blocks = lambda d: "".join(">%d\n%s" % (k, d[k]) for k in sorted(d))
+    flags = ["-s", "5.7", "--alignment-mode", "2", "-e", "100", "--min-aln-len", "11", "--threads", "16"]
+    r = subprocess.run([build.BIN, "search", str(tmp_path / "Q"), str(tmp_path / "T"), str(tmp_path / "res"), str(tmp_path / "tmp"), "--split-memory-limit", "1450M"] + flags,
+                       stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    assert b"2 target splits [chosen from the memory limit]" in r.stderr, r.stderr.decode()[-400:]
+    (tmp_path / "t.txt").write_text("\n".join(targets) + "\n")
+    (tmp_path / "q.txt").write_text("\n".join(queries) + "\n")
+    if os.path.exists(oracle.REF):
+        mat = oracle.write_matrix_files(str(tmp_path / "mat"))
+        subprocess.check_call([oracle.REF, "pipeline", mat, str(tmp_path / "t.txt"), str(tmp_path / "q.txt"), str(tmp_path / "o"), "-s", "5.7", "--split", "2", "--threads", "16"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    else:
+        subprocess.check_call([oracle.CLI, "pipeline", str(tmp_path / "t.txt"), str(tmp_path / "q.txt"), str(tmp_path / "o"), "-s", "5.7", "--split", "2"], stdout=subprocess.DEVNULL)
+    got = blocks(_read_result_db(str(tmp_path / "res")))
+    assert got == open(tmp_path / "o" / "aln.txt").read() and got.count("\n") > 3000
+    # a generous limit: one split, the ordinary result (differs from the split run: --max-seqs is cut per split there)
+    r = subprocess.run([build.BIN, "search", str(tmp_path / "Q"), str(tmp_path / "T"), str(tmp_path / "res1"), str(tmp_path / "tmp"), "--split-memory-limit", "100G"] + flags,
+                       stderr=subprocess.PIPE)
+    assert r.returncode == 0 and b"target splits" not in r.stderr
+    # nothing fits 800 M (the 20^6 table and the 3-mer matrix alone need a gigabyte in the reference)
+    r = subprocess.run([build.BIN, "search", str(tmp_path / "Q"), str(tmp_path / "T"), str(tmp_path / "res2"), str(tmp_path / "tmp"), "--split-memory-limit", "800M"] + flags,
+                       stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"Cannot fit databases" in r.stderr
