@@ -216,6 +216,8 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default=None, help="multi-GPU mode (default: strong when --gpus > 1)")
     ap.add_argument("--config4-profiles", type=int, default=50000, help="BASELINE config 4 beside the headline number (N = 1 only): this many synthetic "
                     "profiles searched against the same fragments, profiles as queries (0 = skip)")
+    ap.add_argument("--target-index", default=None, help="path of a createindex DB: rank 0 writes it when it is missing, EVERY rank then loads the target side "
+                    "from that one file (mk_targetdb_open_index) instead of masking and indexing its own replica")
     ap.add_argument("--config4-sample", type=int, default=192, help="profiles of the config-4 leg whose hits and alignments are compared with the reference")
     args = ap.parse_args()
 
@@ -264,7 +266,14 @@ def main():
     q_res, q_off = pack(queries)
     t_gen = time.time() - t0
     t0 = time.time()
-    db = api.TargetDB.from_codes(t_res, t_off, params)
+    if args.target_index:
+        if rank == 0 and not os.path.exists(args.target_index + ".dbtype"):
+            api.index_write(args.target_index, api.synth_seqdb(t_res, t_off), params)
+        if dist is not None:
+            dist.barrier()
+        db = api.TargetDB.from_index(args.target_index, params)
+    else:
+        db = api.TargetDB.from_codes(t_res, t_off, params)
     t_index = time.time() - t0
 
     def barrier():
@@ -344,7 +353,9 @@ def main():
         "gcups_sw": gcups_total,
         "gcups_sw_kernel_only": (cells_sw / max(sw_ms * 1e-3, 1e-12) / 1e9) if sw_ms else None,
         "prefilter_hits": nhits, "alignments_passed": npass,
-        "setup_s": {"generate": round(t_gen, 2), "target_index_build_upload": round(t_index, 2)},
+        "setup_s": {"generate": round(t_gen, 2), "target_index_build_upload": round(t_index, 2), "target_from_index_db": bool(args.target_index)},
+        "host": {"threads": int(api.lib().mk_host_threads()) if not os.environ.get("OMP_NUM_THREADS") else int(os.environ["OMP_NUM_THREADS"]),
+                 "max_rss_mb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1024.0, 1)},
         "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(stats.items())},
         # dominant kernel against HBM; `traffic` (PMC FETCH_SIZE + WRITE_SIZE per launch) comes from the rocprofv3 passes kept
         # under profiles/ -- bench.py cannot read PMC counters itself

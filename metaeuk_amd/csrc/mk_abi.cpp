@@ -26,6 +26,7 @@
 #include <mutex>
 #include <omp.h>
 #include <thread>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -182,6 +183,13 @@ struct mk_targetdb {
     bool profileSearch = false;      // built for profile queries (mk_params.profile_search)
     bool unindexed = false;          // mk_targetdb_create_sequences: residues only, what mk_align needs (no masking, no k-mer index)
     std::vector<int32_t> bitScoreTable;   // static_cast<int>(bitScore(score) + 0.5), score < 32768
+    // score tables of the alignment stage, kept from call to call: the e-value row of a query length depends on the database alone, and
+    // consecutive batches of ORF fragments bring the same lengths (a batch of other lengths adds its rows; the device copy follows the id)
+    std::unordered_map<uint32_t, std::vector<double>> evalueRows;
+    std::vector<uint32_t> tableLens;       // the distinct query lengths the cached tables were assembled for
+    double gateThr = -1.0;
+    mk::AssembleTables tables;
+    std::vector<mk::GateEntry> gate;
 };
 
 struct mk_queries {
@@ -203,6 +211,28 @@ struct mk_queries {
     mk::PrefilterStats pfStats;      // run statistics of the prefilter over this batch (Prefiltering.cpp:889-904)
     mk::HostBlock alns; std::vector<uint64_t> alnOff; bool haveAln = false;
 };
+
+// the alignment stage's score tables for batch q (e-value per query length and score, the gate), from the database's cache
+static void score_tables(mk_targetdb *db, const mk_queries *q, double evalThr, const mk::AssembleTables *&tables, const std::vector<mk::GateEntry> *&gate) {
+    std::vector<uint32_t> lens;
+    {
+        uint32_t maxLen = 0;
+        for (uint32_t i = 0; i < q->n; i++) maxLen = std::max<uint32_t>(maxLen, (uint32_t) (q->off[i + 1] - q->off[i]));
+        std::vector<uint8_t> present((size_t) maxLen + 1, 0);
+        for (uint32_t i = 0; i < q->n; i++) present[q->off[i + 1] - q->off[i]] = 1;
+        for (uint32_t L = 0; L <= maxLen; L++) if (present[L] && (L > 0 || q->n > 0)) lens.push_back(L);
+    }
+    if (!(lens == db->tableLens && evalThr == db->gateThr && !db->tables.evalue.empty())) {
+        db->tables.bitScore = db->bitScoreTable;
+        mk::build_assemble_tables(db->evaluer, q->off, db->tables, &db->evalueRows);
+        mk::build_gate_table(db->evaluer, evalThr, q->off, db->gate, &db->tables);
+        db->tableLens = lens; db->gateThr = evalThr;
+        if (db->evalueRows.size() > 8192) db->evalueRows.clear();           // (bounded: 32 KB per length)
+    }
+    tables = &db->tables; gate = &db->gate;
+}
+
+
 
 namespace {
 
@@ -1351,17 +1381,15 @@ int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     if (!q->havePref) return fail(MK_ERR_ARG, "mk_align: the batch has no prefilter result");
     if ((rc = check_roles(db, q)) != MK_OK) return rc;
     HostTimer htAll("host_align_total");
-    std::vector<mk::GateEntry> gate;
-    mk::AssembleTables tables;
+    const std::vector<mk::GateEntry> *gatep = nullptr;
+    const mk::AssembleTables *tablesp = nullptr;
     {
         HostTimer ht("host_gate_table");
-        tables.bitScore = db->bitScoreTable;
-        mk::build_assemble_tables(db->evaluer, q->off, tables);
-        mk::build_gate_table(db->evaluer, P->evalue_thr, q->off, gate, &tables);
+        score_tables(db, q, P->evalue_thr, tablesp, gatep);
     }
     q->alnOff.assign((size_t) q->n + 1, 0);
     size_t nAln = 0;
-    rc = align_range(db, q, P, 0, q->n, gate, &tables, g_stream, nAln);
+    rc = align_range(db, q, P, 0, q->n, *gatep, tablesp, g_stream, nAln);
     if (rc != MK_OK) return rc;
     q->haveAln = true;
     return MK_OK;
@@ -1384,8 +1412,8 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
         return mk_align(db, q, P);
     }
     HostTimer htAll("host_search_total");
-    std::vector<mk::GateEntry> gate;
-    mk::AssembleTables tables;
+    const std::vector<mk::GateEntry> *gatep = nullptr;
+    const mk::AssembleTables *tablesp = nullptr;
     q->alnOff.assign((size_t) q->n + 1, 0);
     q->havePref = false; q->haveAln = false;
 
@@ -1405,9 +1433,7 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
         omp_set_num_threads(half);
         {   // the per-length score tables of the batch, while the prefilter works on its first chunk
             HostTimer ht("host_gate_table");
-            tables.bitScore = db->bitScoreTable;
-            mk::build_assemble_tables(db->evaluer, q->off, tables);
-            mk::build_gate_table(db->evaluer, P->evalue_thr, q->off, gate, &tables);
+            score_tables(db, q, P->evalue_thr, tablesp, gatep);
         }
         for (;;) {
             std::pair<uint32_t, uint32_t> it;
@@ -1421,7 +1447,7 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
             int r = MK_OK;
             if (pipe.rc == MK_OK) {
                 HostTimer ht("host_align_total");
-                r = align_range(db, q, P, it.first, it.second, gate, &tables, g_stream2, nAln);
+                r = align_range(db, q, P, it.first, it.second, *gatep, tablesp, g_stream2, nAln);
             }
             {
                 std::lock_guard<std::mutex> lk(pipe.m);

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void assemble_rank_kernel(AssembleView A, cons
 
 }  // namespace
 
-void build_assemble_tables(const Evaluer &ev, const std::vector<uint64_t> &qOff, AssembleTables &t) {
+void build_assemble_tables(const Evaluer &ev, const std::vector<uint64_t> &qOff, AssembleTables &t, std::unordered_map<uint32_t, std::vector<double>> *rowCache) {
     uint32_t maxLen = 0;
     const size_t n = qOff.size() - 1;
     for (size_t i = 0; i < n; i++) maxLen = std::max<uint32_t>(maxLen, (uint32_t) (qOff[i + 1] - qOff[i]));
@@ -298,9 +298,19 @@ void build_assemble_tables(const Evaluer &ev, const std::vector<uint64_t> &qOff,
     std::sort(lens.begin(), lens.end());
     for (size_t k = 0; k < lens.size(); k++) t.lenIdx[lens[k]] = (int32_t) k;
     t.evalue.assign(lens.size() * (size_t) t.smax, 0.0);
+    std::vector<uint8_t> cached(lens.size(), 0);
+    if (rowCache)
+        for (size_t k = 0; k < lens.size(); k++) {
+            auto it = rowCache->find(lens[k]);
+            if (it != rowCache->end() && it->second.size() == t.smax) { std::memcpy(&t.evalue[k * t.smax], it->second.data(), t.smax * sizeof(double)); cached[k] = 1; }
+        }
 #pragma omp parallel for schedule(dynamic, 4)
     for (size_t k = 0; k < lens.size(); k++)
-        for (uint32_t s = 0; s < t.smax; s++) t.evalue[k * t.smax + s] = ev.evalue((double) s, (double) lens[k]);
+        if (!cached[k])
+            for (uint32_t s = 0; s < t.smax; s++) t.evalue[k * t.smax + s] = ev.evalue((double) s, (double) lens[k]);
+    if (rowCache)
+        for (size_t k = 0; k < lens.size(); k++)
+            if (!cached[k]) (*rowCache)[lens[k]].assign(&t.evalue[k * t.smax], &t.evalue[k * t.smax] + t.smax);
     if (t.bitScore.empty()) {
         t.bitScore.resize(32768);
         for (int s = 0; s < 32768; s++) t.bitScore[s] = static_cast<int>(ev.bitScore((double) s) + 0.5);

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <functional>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include "../../include/metaeuk_amd.h"
 #include "mk_host.hpp"
@@ -40,7 +41,9 @@ struct AssembleTables {
     uint32_t smax = 0;
     uint64_t id = 0;                 // changes with every build (the device copy is refreshed when it differs)
 };
-void build_assemble_tables(const Evaluer &ev, const std::vector<uint64_t> &qOff, AssembleTables &t);
+// rowCache (optional): e-value rows by query length that were computed before for the same database; missing ones are added
+void build_assemble_tables(const Evaluer &ev, const std::vector<uint64_t> &qOff, AssembleTables &t,
+                           std::unordered_map<uint32_t, std::vector<double>> *rowCache = nullptr);
 struct AssembleArgs {
     const AssembleTables *tables = nullptr;      // null: no device assembly (the caller gets AlnRaw records)
     const uint32_t *dSortKey = nullptr;          // device array: DB key of every target for the last tie-break of the sort (null: the target index)
