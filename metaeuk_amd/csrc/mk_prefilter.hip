@@ -1229,7 +1229,6 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
             totalHits = X.hTotals[0];
             ovf = X.hTotals[1] != 0;               // a query of the piece fills the reference's databaseHits buffer: it is processed alone, in segments
             if (ovf && q1 - q0 > 1) { q1 = q0 + (q1 - q0) / 2; continue; }
-            if (ovf && V.p_sorted) { err = "a profile query overflows the reference's databaseHits buffer (QueryMatcher.cpp:281-316): not restated for profile queries"; return MK_ERR_UNSUPPORTED; }
             if (ovf && !X.tMaskedHost) { err = "a query overflows the reference's databaseHits buffer (QueryMatcher.cpp:281-316) and the caller gave no access to the masked target residues"; return MK_ERR_UNSUPPORTED; }
             X.ts(thCount, 4.0 * (double) X.hTotals[2] + 8.0 * (double) totalHits + 1280.0 * (double) nPos, (double) X.hTotals[2]);   // bitmap word per k-mer, slot per non-empty k-mer, row heads per start
             hitsPerPos = std::max(1.0, (double) totalHits / (double) nPos);
@@ -1396,18 +1395,28 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
                 const size_t qg = (size_t) X.chunkQ0 + hQ[0];
                 const uint64_t qs = (*X.qOffHost)[qg];
                 const uint32_t L = (uint32_t) ((*X.qOffHost)[qg + 1] - qs);
-                std::vector<int8_t> corr(L);
-                if (X.qCorrHost) std::memcpy(corr.data(), X.qCorrHost + qs, L);
-                else PCHK(hipMemcpy(corr.data(), V.q_corr + hOff[q0], L, hipMemcpyDeviceToHost));
-                int8_t m8[21 * 21];
-                for (int a = 0; a < 21; a++) for (int b = 0; b < 21; b++) m8[a * 21 + b] = (int8_t) X.ungMat->sub[a][b];
-                const uint8_t *qr = X.qResHost->data() + qs;
                 const uint8_t *tMasked = X.tMaskedHost();
                 if (!tMasked) { err = "cannot fetch the masked target residues from the device"; return MK_ERR_DEVICE; }
-                replay_overflow(cands, hSegStart, [&](uint32_t id, uint16_t diag) -> int {
-                    const uint64_t ts = (*X.tOffHost)[id];
-                    return ungapped_score(m8, qr, corr.data(), L, tMasked + ts, (uint32_t) ((*X.tOffHost)[id + 1] - ts), (uint32_t) diag);
-                }, surv);
+                if (V.p_sorted) {
+                    // a profile query: its alignment profile rows [column][32] (what diag_score_kernel reads) come from the device
+                    std::vector<int8_t> aln((size_t) L * PROFILE_ALN_STRIDE);
+                    PCHK(hipMemcpy(aln.data(), V.p_aln + hOff[q0] * PROFILE_ALN_STRIDE, aln.size(), hipMemcpyDeviceToHost));
+                    replay_overflow(cands, hSegStart, [&](uint32_t id, uint16_t diag) -> int {
+                        const uint64_t ts = (*X.tOffHost)[id];
+                        return ungapped_score_profile(aln.data(), L, tMasked + ts, (uint32_t) ((*X.tOffHost)[id + 1] - ts), (uint32_t) diag);
+                    }, surv);
+                } else {
+                    std::vector<int8_t> corr(L);
+                    if (X.qCorrHost) std::memcpy(corr.data(), X.qCorrHost + qs, L);
+                    else PCHK(hipMemcpy(corr.data(), V.q_corr + hOff[q0], L, hipMemcpyDeviceToHost));
+                    int8_t m8[21 * 21];
+                    for (int a = 0; a < 21; a++) for (int b = 0; b < 21; b++) m8[a * 21 + b] = (int8_t) X.ungMat->sub[a][b];
+                    const uint8_t *qr = X.qResHost->data() + qs;
+                    replay_overflow(cands, hSegStart, [&](uint32_t id, uint16_t diag) -> int {
+                        const uint64_t ts = (*X.tOffHost)[id];
+                        return ungapped_score(m8, qr, corr.data(), L, tMasked + ts, (uint32_t) ((*X.tOffHost)[id + 1] - ts), (uint32_t) diag);
+                    }, surv);
+                }
                 const uint32_t nSurv = (uint32_t) surv.size();
                 for (uint32_t k = 0; k < nSurv; k++) { hId[k] = surv[k].id; hOrd[k] = surv[k].ordinal; hDiag[k] = surv[k].diag; }
                 std::vector<uint32_t> hQs(nSurv, hQ[0]);

@@ -282,3 +282,47 @@ def test_cli_profile_workflow_equals_the_real_process(gpu_api, tmp_path):
     subprocess.check_call([build.BIN, "predictexons", str(tmp_path / "contigs"), str(tmp_path / "profDB"), str(tmp_path / "calls_b"), str(tmp_path / "tmp"),
                            "--ref-l2-bytes", "2097152"], stderr=subprocess.DEVNULL, env=env)
     assert blocks(_read_result_db(str(tmp_path / "calls_b"))) == _text("prof_calls.txt.gz")
+
+
+@pytest.mark.skipif(not os.path.exists(oracle.REF), reason="reference harness not on this box")
+def test_profile_query_fills_the_database_hits_buffer(gpu_api, tmp_path):
+    """QueryMatcher::match's overflow path (QueryMatcher.cpp:281-334) with PROFILE queries: profiles of a protein that 70 000 fragments are
+    near-copies of gather tens of millions of index entries where the reference's buffer holds two million -- segments, merges and the
+    array order as for sequence queries (tests/test_gpu_parity.py::test_database_hits_overflow_path), the diagonals scored with the
+    profile's own columns.  Against the reference's own code (oracle/_ref/ref_harness profilesearch)."""
+    import ctypes
+    from metaeuk_amd import synth
+    api = gpu_api
+    rng = random.Random(3)
+    AA = synth.AA
+    base = "".join(rng.choice(AA) for _ in range(400))
+    mut = lambda s, r: "".join(rng.choice(AA) if rng.random() < r else c for c in s)
+    frags = [mut(base, 0.02) for _ in range(70000)]
+    prots = [base, mut(base, 0.05), "".join(rng.choice(AA) for _ in range(300)), base[:150]]
+    entries = synth.make_profiles([np.array([AA.index(c) for c in s], dtype=np.uint8) for s in prots], seed=5)
+    p = api.default_params()
+    p.sensitivity = 4.0
+    p.profile_search = 1
+    p.max_seqs = max(300, len(frags))
+    p.evalue_thr = 1000.0
+    l2 = ctypes.CDLL(None).sysconf(191)
+    p.host_l2_bytes = l2 if l2 and l2 > 0 else 262144
+    db = api.TargetDB(frags, p)
+    q = api.Profiles(entries, p)
+    api.kernel_stats(reset=True)
+    (hits, hoff), (alns, aoff) = api.search(db, q, p)
+    assert "host_prefilter_overflow" in api.kernel_stats()
+    (tmp_path / "p.bin").write_bytes(b"".join(entries))
+    off, lines = 0, []
+    for k, e in enumerate(entries):
+        lines.append("%d\t%d\t%d\n" % (k, off, len(e))); off += len(e)
+    (tmp_path / "p.index").write_text("".join(lines))
+    (tmp_path / "f.txt").write_text("\n".join(frags) + "\n")
+    mat = oracle.write_matrix_files(str(tmp_path / "mat"))
+    subprocess.check_call([oracle.REF, "profilesearch", mat, str(tmp_path / "p.bin"), str(tmp_path / "p.index"), str(tmp_path / "f.txt"), str(tmp_path / "o"),
+                           "-s", "4", "--eval-abs", "1000", "--threads", "16"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    pref = "".join(">%d\n%s" % (i, api.format_hits_bulk(hits, int(hoff[i]), int(hoff[i + 1])).decode()) for i in range(q.n))
+    aln = "".join(">%d\n%s" % (i, api.format_alignments_bulk(alns, int(aoff[i]), int(aoff[i + 1])).decode()) for i in range(q.n))
+    assert pref == open(tmp_path / "o" / "pref.txt").read()
+    assert aln == open(tmp_path / "o" / "aln.txt").read()
+    assert int(hoff[-1]) > 100000
