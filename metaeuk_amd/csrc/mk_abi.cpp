@@ -1458,12 +1458,18 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
         }
     });
     mk::PrefilterHooks hooks;
-    hooks.max_chunk_queries = 1u << 17;
+    // chunks of 262 144 queries, the first ones smaller (65 536, 131 072: the alignment stage starts when the first chunk is done).  Measured on
+    // config 2 (profiles/r03_search_tuning.txt): 131 072-query chunks 1.095 s per step, 262 144 with the ramp 0.99 s -- the position and reverse
+    // passes are one launch per tile configuration and chunk, and short launches beside the persistent prefilter workgroups run at a third of
+    // their speed
+    hooks.max_chunk_queries = 1u << 18;
+    hooks.chunk_ramp = true;
     hooks.co_resident = true;
     hooks.t_masked_host = [db]() { return masked_host(db); };
     q->pfStats = mk::PrefilterStats();
     hooks.stats = &q->pfStats;
     if (const char *e = getenv("MK_SEARCH_CHUNK_QUERIES")) hooks.max_chunk_queries = (uint32_t) std::max(1024L, atol(e));
+    if (const char *e = getenv("MK_SEARCH_CHUNK_RAMP")) hooks.chunk_ramp = atoi(e) != 0;
     hooks.on_chunk = [&](uint32_t a, uint32_t b) {
         { std::lock_guard<std::mutex> lk(pipe.m); pipe.items.emplace_back(a, b); }
         pipe.cv.notify_all();

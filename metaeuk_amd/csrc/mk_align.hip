@@ -443,7 +443,7 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const SwJob *j
         int dev = 0, cus = 256;
         (void) hipGetDevice(&dev);
         (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        int perCu[SW_NCFG] = {16, 16, 16, 12, 12, 8, 8, 6, 6, 8, 8};
+        int perCu[SW_NCFG] = {12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12};     // (round 2: 16 for the small tiles, 6-8 for the large ones; profiles/r03_search_tuning.txt)
         if (const char *e = getenv("MK_SW_WAVES_PER_CU")) {
             int k = 0, last = 16;
             for (const char *p = e; *p && k < SW_NCFG; k++) {

@@ -1509,7 +1509,13 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     while (q0 < nq) {
         // ---- chunk size: bounded by the query field of the sort key and by the candidate buffers
         uint32_t want = chunkLimit;
-        if (hooks.max_chunk_queries) want = std::min(want, hooks.max_chunk_queries);
+        if (hooks.max_chunk_queries) {
+            // the consumer of the chunks (the alignment stage of mk_search) starts when the FIRST chunk is done: the first chunks are small
+            // (1/4, then 1/2 of the limit), the later ones large enough to keep the launches of both stages long
+            uint32_t lim = hooks.max_chunk_queries;
+            if (hooks.chunk_ramp) lim = q0 == 0 ? std::max(1024u, lim / 4) : (q0 < lim ? std::max(1024u, lim / 2) : lim);
+            want = std::min(want, lim);
+        }
         if (candPerQuery > 0) want = (uint32_t) std::min<double>(want, std::max(1.0, 0.6 * (double) CAND_CAP / candPerQuery));
         else want = std::min<uint32_t>(want, 1u << 16);                    // nothing known yet: a small probe chunk
         const uint32_t q1 = (uint32_t) std::min<uint64_t>(nq, (uint64_t) q0 + std::max<uint32_t>(want, 1));

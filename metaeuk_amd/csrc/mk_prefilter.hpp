@@ -49,6 +49,7 @@ struct PrefilterStats {
 // optional hooks for a caller that consumes the result chunk by chunk while the prefilter is still running (mk_search)
 struct PrefilterHooks {
     uint32_t max_chunk_queries = 0;                                  // 0: no limit beyond the device buffers
+    bool chunk_ramp = false;                                         // the first chunks are smaller (1/4, 1/2 of the limit): the consumer starts sooner
     int max_tiers = 0;                                               // > 0: use only the first tiers of the per-query front end
     bool co_resident = false;                                        // another stage (the Smith-Waterman waves of mk_search) shares the CUs: the
                                                                      // persistent prefilter workgroups take about half of the wave slots

@@ -623,17 +623,21 @@ static hipError_t launch_one(const SwLaunch &L, hipStream_t stream) {
 hipError_t launch_sw(const SwLaunch &L, int cfg, hipStream_t stream) {
     if (cfg < 0 || cfg >= SW_NCFG) return hipErrorInvalidValue;
     switch (sw_cfg_rows(cfg)) {
-        case 32: return launch_one<16, 2, 256>(L, stream);
+#ifndef MK_SW_POS_BLOCK_S
+#define MK_SW_POS_BLOCK_S 256
+#define MK_SW_POS_BLOCK_L 128
+#endif
+        case 32: return launch_one<16, 2, MK_SW_POS_BLOCK_S>(L, stream);
         case 48:                                              // tiles the int32 kernel has no lane shape for run in the next one, padded
-        case 64: return launch_one<16, 4, 256>(L, stream);
+        case 64: return launch_one<16, 4, MK_SW_POS_BLOCK_S>(L, stream);
         case 96:
-        case 128: return launch_one<16, 8, 256>(L, stream);
+        case 128: return launch_one<16, 8, MK_SW_POS_BLOCK_S>(L, stream);
         case 192:
-        case 256: return launch_one<16, 16, 128>(L, stream);
-        case 384: return launch_one<32, 12, 128>(L, stream);
-        case 512: return launch_one<32, 16, 128>(L, stream);
-        case 768: return launch_one<64, 12, 128>(L, stream);
-        case 1024: return launch_one<64, 16, 128>(L, stream);
+        case 256: return launch_one<16, 16, MK_SW_POS_BLOCK_L>(L, stream);
+        case 384: return launch_one<32, 12, MK_SW_POS_BLOCK_L>(L, stream);
+        case 512: return launch_one<32, 16, MK_SW_POS_BLOCK_L>(L, stream);
+        case 768: return launch_one<64, 12, MK_SW_POS_BLOCK_L>(L, stream);
+        case 1024: return launch_one<64, 16, MK_SW_POS_BLOCK_L>(L, stream);
         default: return hipErrorInvalidValue;
     }
 }
