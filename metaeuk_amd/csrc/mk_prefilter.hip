@@ -1513,7 +1513,11 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             // the consumer of the chunks (the alignment stage of mk_search) starts when the FIRST chunk is done: the first chunks are small
             // (1/4, then 1/2 of the limit), the later ones large enough to keep the launches of both stages long
             uint32_t lim = hooks.max_chunk_queries;
-            if (hooks.chunk_ramp) lim = q0 == 0 ? std::max(1024u, lim / 4) : (q0 < lim ? std::max(1024u, lim / 2) : lim);
+            if (hooks.chunk_ramp) {
+                const uint32_t full = lim;
+                lim = q0 == 0 ? std::max(1024u, full / 4) : (q0 < full ? std::max(1024u, full / 2) : full);
+                // (shrinking the LAST chunks as well, to shorten the consumer's tail, was measured and costs more in short launches than it saves)
+            }
             want = std::min(want, lim);
         }
         if (candPerQuery > 0) want = (uint32_t) std::min<double>(want, std::max(1.0, 0.6 * (double) CAND_CAP / candPerQuery));
