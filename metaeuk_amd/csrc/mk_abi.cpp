@@ -427,7 +427,6 @@ static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uin
     if (P->kmer_size != 0 && P->kmer_size != 6 && P->kmer_size != 7) return fail(MK_ERR_UNSUPPORTED, "-k %d: k-mer sizes 6 and 7 are implemented", P->kmer_size);
     const int kmerSize = prebuilt ? prebuilt->kmerSize : (P->kmer_size ? P->kmer_size : (offsets[n] < 3350000000ull ? 6 : 7));
     if (prebuilt && P->kmer_size && P->kmer_size != kmerSize) return fail(MK_ERR_ARG, "-k %d, but the index DB was built with k = %d", P->kmer_size, kmerSize);
-    if (kmerSize == 7 && P->profile_search) return fail(MK_ERR_UNSUPPORTED, "profile queries with k = 7 (a fragment set of 3.35e9 residues or more, or -k 7) are not implemented");
     mk_targetdb *db = new mk_targetdb();
     db->kmerSize = kmerSize;
     db->n = n;
@@ -848,8 +847,10 @@ int mk_profiles_create(const uint8_t *columns, const uint64_t *offsets, uint32_t
         ok(hipMemsetAsync(q->dProfSorted.p, 0, (total + pad) * mk::PROFILE_SORTED_STRIDE, g_stream));
         ok(hipMemsetAsync(q->dProfAln.p, 0, (total + pad) * mk::PROFILE_ALN_STRIDE, g_stream));
         const int th = timed_begin("profile_derive", (double) total * (25.0 + 75.0), 0);
-        ok(mk::launch_profile_derive(dRaw.p, q->dOff.p, n, total, mk::kmer_threshold_profile(P->sensitivity), q->dRes.p, q->dProfSorted.p, q->dProfAln.p,
-                                     q->dKmerThr.p, g_stream));
+        q->kmerSize = P->kmer_size == 7 ? 7 : 6;
+        q->derivedWith = *P;
+        ok(mk::launch_profile_derive(dRaw.p, q->dOff.p, n, total, q->kmerSize == 7 ? mk::kmer_threshold_profile_k7(P->sensitivity) : mk::kmer_threshold_profile(P->sensitivity),
+                                     q->kmerSize, q->dRes.p, q->dProfSorted.p, q->dProfAln.p, q->dKmerThr.p, g_stream));
         timed_end(th);
     }
     ok(hipStreamSynchronize(g_stream));
@@ -1160,8 +1161,16 @@ static mk::PrefilterDeviceView prefilter_view(const mk_targetdb *db, const mk_qu
 // the k-mer thresholds of a sequence batch belong to one k-mer size (seed pattern, threshold formula): a batch that meets a database of
 // the other size (k chosen from the database's residue count, IndexTable.h:439-449) has them derived again
 static int match_kmer_size(const mk_targetdb *db, mk_queries *q) {
-    if (q->isProfile || q->kmerSize == db->kmerSize) return MK_OK;
+    if (q->kmerSize == db->kmerSize) return MK_OK;
     const mk_params &P = q->derivedWith;
+    if (q->isProfile) {          // the k-mer starts of a profile batch follow the seed pattern and threshold of the database's k
+        const uint64_t total = q->off[q->n];
+        HIPCHK(mk::launch_profile_kthr(q->dRes.p, q->dOff.p, q->n, total, db->kmerSize == 7 ? mk::kmer_threshold_profile_k7(P.sensitivity) : mk::kmer_threshold_profile(P.sensitivity),
+                                       db->kmerSize, q->dKmerThr.p, g_stream));
+        HIPCHK(hipStreamSynchronize(g_stream));
+        q->kmerSize = db->kmerSize;
+        return MK_OK;
+    }
     mk::SubMat kmerMat, alnMat;
     mk::build_submat(kmerMat, mk::MAT_VTML80, 8.0f, -0.2f);
     mk::build_submat(alnMat, mk::MAT_BLOSUM62, 2.0f, 0.0f);

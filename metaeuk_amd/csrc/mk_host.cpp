@@ -104,6 +104,13 @@ int kmer_threshold_profile(float sensitivity) {
     return static_cast<int>(best);
 }
 
+// ... and with k = 7 (:1041-1043)
+int kmer_threshold_profile_k7(float sensitivity) {
+    float base = 149.15;
+    float best = base - (sensitivity * 6.85);
+    return static_cast<int>(best);
+}
+
 // QueryMatcher::initDiagonalMatcher (M/src/prefiltering/QueryMatcher.cpp:422-450)
 int bin_count_for(uint64_t dbSize, uint64_t l2) {
     for (int b = 2; b <= 1024; b <<= 1) if (dbSize / static_cast<uint64_t>(b) < l2) return b;

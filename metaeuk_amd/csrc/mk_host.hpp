@@ -33,6 +33,7 @@ void encode(const char *s, size_t n, uint8_t *codes);
 void comp_bias(const SubMat &m, const uint8_t *seq, int L, float scale, float *bias);
 int kmer_threshold(float sensitivity, int kmerScoreOverride);
 int kmer_threshold_profile(float sensitivity);
+int kmer_threshold_profile_k7(float sensitivity);
 int kmer_threshold_k7(float sensitivity, int kmerScoreOverride);     // sequence search, k = 7 (Prefiltering.cpp:1057-1059)
 int bin_count_for(uint64_t dbSize, uint64_t l2Bytes);
 

@@ -1172,7 +1172,7 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
                 unsigned long long *hKTot = (unsigned long long *) pinned_scratch("pf_kltot_h", 16);
                 PNULL(dCnt); PNULL(dKOff); PNULL(hKTot);
                 int th = X.tb(V.p_sorted ? "profile_kmer_count" : "kmer7_count", 46.0 * (double) nPos, 0);
-                if (V.p_sorted) PCHK(launch_profile_kmer_count(V.p_sorted, V.q_kmer_thr, hOff[q0], hOff[q1], dCnt, stream));
+                if (V.p_sorted) PCHK(launch_profile_kmer_count(V.p_sorted, V.q_kmer_thr, hOff[q0], hOff[q1], dCnt, stream, V.kmer_size));
                 else PCHK(launch_kmer7_count(T7, V.q_res, V.q_kmer_thr, hOff[q0], hOff[q1], dCnt, stream));
                 X.te(th);
                 PCHK(hipMemsetAsync(dCnt + nPos, 0, 4, stream));           // one more element: the scan then ends with the total
@@ -1192,7 +1192,7 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
                 uint32_t *dKList = (uint32_t *) dev_scratch("pf_klist", std::max<size_t>(nK, 1) * 4);
                 PNULL(dKList);
                 th = X.tb(V.p_sorted ? "profile_kmer_fill" : "kmer7_fill", 46.0 * (double) nPos + 4.0 * (double) nK, (double) nK);
-                if (V.p_sorted) PCHK(launch_profile_kmer_fill(V.p_sorted, V.q_kmer_thr, V.addr3, hOff[q0], hOff[q1], dKOff, dKList, stream));
+                if (V.p_sorted) PCHK(launch_profile_kmer_fill(V.p_sorted, V.q_kmer_thr, V.addr3, hOff[q0], hOff[q1], dKOff, dKList, stream, V.kmer_size));
                 else PCHK(launch_kmer7_fill(T7, V.q_res, V.q_kmer_thr, hOff[q0], hOff[q1], dKOff, dKList, stream));
                 X.te(th);
                 V.klist = dKList; V.klist_off = dKOff; V.klist_pos0 = hOff[q0];

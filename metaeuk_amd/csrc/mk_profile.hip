@@ -16,6 +16,9 @@ namespace {
 
 constexpr int SPACED[6] = {0, 1, 3, 5, 8, 9};     // spaced seed 1101010011 (k = 6)
 constexpr int SPAN = 10;
+constexpr int SPACED7[7] = {0, 1, 3, 5, 6, 9, 10}; // spaced seed 11010110011 (k = 7, Sequence.h:25)
+constexpr int SPAN7 = 11;
+constexpr int SPAN_MAX = 11;
 
 __device__ __forceinline__ uint32_t find_profile(const uint64_t *off, uint32_t n, uint64_t p) {
     uint32_t lo = 0, hi = n;
@@ -43,7 +46,7 @@ __device__ __forceinline__ void ranked_desc_sort20(int (&val)[20], int (&idx)[20
 #undef MK_SWAP
 }
 
-__global__ __launch_bounds__(256) void profile_derive_kernel(const uint8_t *raw, const uint64_t *off, uint32_t n, uint64_t total, int kmerThr,
+__global__ __launch_bounds__(256) void profile_derive_kernel(const uint8_t *raw, const uint64_t *off, uint32_t n, uint64_t total, int kmerThr, int kmerSize,
                                                              uint8_t *letters, int8_t *sorted, int8_t *aln, int16_t *kthr) {
     const uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= total) return;
@@ -64,13 +67,100 @@ __global__ __launch_bounds__(256) void profile_derive_kernel(const uint8_t *raw,
     // k-mer start: Sequence::hasNextKmer (i + span <= L), kmerContainsX on the query letters
     const uint32_t q = find_profile(off, n, p);
     int16_t out = -1;
-    if (p + SPAN <= off[q + 1]) {
+    if (p + (kmerSize == 7 ? SPAN7 : SPAN) <= off[q + 1]) {
         bool hasX = false;
+        if (kmerSize == 7) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) hasX |= raw[(p + SPACED[k]) * PROFILE_COL_BYTES + 20] == 20;
+            for (int k = 0; k < 7; k++) hasX |= raw[(p + SPACED7[k]) * PROFILE_COL_BYTES + 20] == 20;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; k++) hasX |= raw[(p + SPACED[k]) * PROFILE_COL_BYTES + 20] == 20;
+        }
         if (!hasX) out = (int16_t) max(kmerThr, 0);
     }
     kthr[p] = out;
+}
+
+// the k-mer thresholds alone, from the query letters: a batch derived for one k-mer size that meets a database of the other
+__global__ __launch_bounds__(256) void profile_kthr_kernel(const uint8_t *letters, const uint64_t *off, uint32_t n, uint64_t total, int kmerThr, int kmerSize, int16_t *kthr) {
+    const uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    const uint32_t q = find_profile(off, n, p);
+    int16_t out = -1;
+    if (p + (kmerSize == 7 ? SPAN7 : SPAN) <= off[q + 1]) {
+        bool hasX = false;
+        for (int k = 0; k < kmerSize; k++) hasX |= letters[p + (kmerSize == 7 ? SPACED7[k] : SPACED[k])] == 20;
+        if (!hasX) out = (int16_t) max(kmerThr, 0);
+    }
+    kthr[p] = out;
+}
+
+// k = 7: seven one-column steps, cells in the reference's numbering (sum of residue * 20^step)
+template <bool FILL>
+__global__ __launch_bounds__(256) void profile_kmer7_kernel(const int8_t *sorted, const int16_t *kthr, uint64_t posBegin, uint64_t posEnd,
+                                                            uint32_t *counts, const uint64_t *listOff, uint32_t *list) {
+    __shared__ int8_t sCol[(256 + SPAN_MAX) * PROFILE_SORTED_STRIDE];
+    const uint64_t p0 = posBegin + (uint64_t) blockIdx.x * 256;
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(sorted + p0 * PROFILE_SORTED_STRIDE);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(sCol);
+        for (int k = threadIdx.x; k < (256 + SPAN_MAX) * PROFILE_SORTED_STRIDE / 4; k += 256) dst[k] = src[k];
+    }
+    __syncthreads();
+    const uint64_t p = p0 + threadIdx.x;
+    if (p >= posEnd) return;
+    const int thr = (int) kthr[p];
+    if (thr < 0) { if (!FILL) counts[p - posBegin] = 0; return; }
+    const int8_t *c[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) c[i] = sCol + (threadIdx.x + SPACED7[i]) * PROFILE_SORTED_STRIDE;
+    int rest[7];
+    rest[6] = 0;
+#pragma unroll
+    for (int i = 6; i >= 1; i--) rest[i - 1] = rest[i] + (int) c[i][0];
+    uint32_t n = 0;
+    uint32_t *out = FILL ? list + listOff[p - posBegin] : nullptr;
+    for (int j0 = 0; j0 < 20; j0++) {
+        const int s0 = (int) c[0][j0];
+        if (s0 < thr - rest[0]) break;
+        const uint32_t a0 = (uint32_t) c[0][20 + j0];
+        for (int j1 = 0; j1 < 20; j1++) {
+            const int v1 = (int) c[1][j1];
+            if (v1 < thr - s0 - rest[1]) break;
+            const int s1 = s0 + v1;
+            const uint32_t a1 = a0 + 20u * (uint32_t) c[1][20 + j1];
+            for (int j2 = 0; j2 < 20; j2++) {
+                const int v2 = (int) c[2][j2];
+                if (v2 < thr - s1 - rest[2]) break;
+                const int s2 = s1 + v2;
+                const uint32_t a2 = a1 + 400u * (uint32_t) c[2][20 + j2];
+                for (int j3 = 0; j3 < 20; j3++) {
+                    const int v3 = (int) c[3][j3];
+                    if (v3 < thr - s2 - rest[3]) break;
+                    const int s3 = s2 + v3;
+                    const uint32_t a3 = a2 + 8000u * (uint32_t) c[3][20 + j3];
+                    for (int j4 = 0; j4 < 20; j4++) {
+                        const int v4 = (int) c[4][j4];
+                        if (v4 < thr - s3 - rest[4]) break;
+                        const int s4 = s3 + v4;
+                        const uint32_t a4 = a3 + 160000u * (uint32_t) c[4][20 + j4];
+                        for (int j5 = 0; j5 < 20; j5++) {
+                            const int v5 = (int) c[5][j5];
+                            if (v5 < thr - s4 - rest[5]) break;
+                            const int s5 = s4 + v5;
+                            const uint32_t a5 = a4 + 3200000u * (uint32_t) c[5][20 + j5];
+                            for (int j6 = 0; j6 < 20; j6++) {
+                                if ((int) c[6][j6] < thr - s5) break;
+                                if (FILL) out[n] = a5 + 64000000u * (uint32_t) c[6][20 + j6];
+                                n++;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (!FILL) counts[p - posBegin] = n;
 }
 
 // Depth-first walk of one k-mer start.  rest[i] = best score of the columns behind step i (possibleRest, KmerGenerator.cpp:124-126).
@@ -80,7 +170,7 @@ __global__ __launch_bounds__(256) void profile_kmer_kernel(const int8_t *sorted,
                                                            uint32_t *counts, const uint64_t *listOff, uint32_t *list) {
     __shared__ int8_t sCol[(256 + SPAN) * PROFILE_SORTED_STRIDE];
     const uint64_t p0 = posBegin + (uint64_t) blockIdx.x * 256;
-    {   // the sorted columns of this workgroup's starts (the array is padded by SPAN columns behind the last profile)
+    {   // the sorted columns of this workgroup's starts (the array is padded by more than SPAN columns behind the last profile)
         const uint32_t *src = reinterpret_cast<const uint32_t *>(sorted + p0 * PROFILE_SORTED_STRIDE);
         uint32_t *dst = reinterpret_cast<uint32_t *>(sCol);
         for (int k = threadIdx.x; k < (256 + SPAN) * PROFILE_SORTED_STRIDE / 4; k += 256) dst[k] = src[k];
@@ -138,24 +228,40 @@ __global__ __launch_bounds__(256) void profile_kmer_kernel(const int8_t *sorted,
 
 }  // namespace
 
-hipError_t launch_profile_derive(const uint8_t *dRaw, const uint64_t *dOff, uint32_t nProfiles, uint64_t totalCols, int kmerThr,
+hipError_t launch_profile_derive(const uint8_t *dRaw, const uint64_t *dOff, uint32_t nProfiles, uint64_t totalCols, int kmerThr, int kmerSize,
                                  uint8_t *dLetters, int8_t *dSorted, int8_t *dAln, int16_t *dKthr, hipStream_t stream) {
     if (totalCols == 0) return hipSuccess;
-    hipLaunchKernelGGL(profile_derive_kernel, dim3((unsigned) ((totalCols + 255) / 256)), dim3(256), 0, stream, dRaw, dOff, nProfiles, totalCols, kmerThr,
+    hipLaunchKernelGGL(profile_derive_kernel, dim3((unsigned) ((totalCols + 255) / 256)), dim3(256), 0, stream, dRaw, dOff, nProfiles, totalCols, kmerThr, kmerSize,
                        dLetters, dSorted, dAln, dKthr);
     return hipGetLastError();
 }
 
-hipError_t launch_profile_kmer_count(const int8_t *dSorted, const int16_t *dKthr, uint64_t posBegin, uint64_t posEnd, uint32_t *dCounts, hipStream_t stream) {
+hipError_t launch_profile_kthr(const uint8_t *dLetters, const uint64_t *dOff, uint32_t nProfiles, uint64_t totalCols, int kmerThr, int kmerSize, int16_t *dKthr, hipStream_t stream) {
+    if (totalCols == 0) return hipSuccess;
+    hipLaunchKernelGGL(profile_kthr_kernel, dim3((unsigned) ((totalCols + 255) / 256)), dim3(256), 0, stream, dLetters, dOff, nProfiles, totalCols, kmerThr, kmerSize, dKthr);
+    return hipGetLastError();
+}
+
+hipError_t launch_profile_kmer_count(const int8_t *dSorted, const int16_t *dKthr, uint64_t posBegin, uint64_t posEnd, uint32_t *dCounts, hipStream_t stream, int kmerSize) {
     if (posEnd <= posBegin) return hipSuccess;
+    if (kmerSize == 7) {
+        hipLaunchKernelGGL(profile_kmer7_kernel<false>, dim3((unsigned) ((posEnd - posBegin + 255) / 256)), dim3(256), 0, stream, dSorted, dKthr, posBegin, posEnd, dCounts,
+                           (const uint64_t *) nullptr, (uint32_t *) nullptr);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(profile_kmer_kernel<false>, dim3((unsigned) ((posEnd - posBegin + 255) / 256)), dim3(256), 0, stream, dSorted, dKthr,
                        (const uint16_t *) nullptr, posBegin, posEnd, dCounts, (const uint64_t *) nullptr, (uint32_t *) nullptr);
     return hipGetLastError();
 }
 
 hipError_t launch_profile_kmer_fill(const int8_t *dSorted, const int16_t *dKthr, const uint16_t *dAddr3, uint64_t posBegin, uint64_t posEnd,
-                                    const uint64_t *dListOff, uint32_t *dList, hipStream_t stream) {
+                                    const uint64_t *dListOff, uint32_t *dList, hipStream_t stream, int kmerSize) {
     if (posEnd <= posBegin) return hipSuccess;
+    if (kmerSize == 7) {
+        hipLaunchKernelGGL(profile_kmer7_kernel<true>, dim3((unsigned) ((posEnd - posBegin + 255) / 256)), dim3(256), 0, stream, dSorted, dKthr, posBegin, posEnd,
+                           (uint32_t *) nullptr, dListOff, dList);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(profile_kmer_kernel<true>, dim3((unsigned) ((posEnd - posBegin + 255) / 256)), dim3(256), 0, stream, dSorted, dKthr, dAddr3,
                        posBegin, posEnd, (uint32_t *) nullptr, dListOff, dList);
     return hipGetLastError();

@@ -24,7 +24,7 @@
 //     index, k from the residues of the range, --max-seqs reduced to max/N + 4 sqrt(max/N), the N prefilter DBs joined by the
 //     reference's own Prefiltering::mergeTargetSplits (Prefiltering.cpp:379-496, compiled in place)
 //   ref_harness profilesearch <matdir> <profile DB data file> <its .index> <fragments.txt> <outdir> [-s 4] [-e 100] [--eval-abs X]
-//                [--keys keys.txt] [--threads N]
+//                [--keys keys.txt] [--threads N] [-k 7]
 //     = the sliced target-profile search of `predictexons contigsDB profileDB` (searchslicedtargetprofile.sh; Search.cpp:357-399) for one
 //       slice: prefilter with the PROFILES as queries (Sequence::mapProfile, profile k-mer lists, QueryMatcher with setProfileMatrix)
 //       against the fragments, align (Matcher with a profile query), swapresults (Matcher::result_t::swapResult + compareHits).
@@ -679,11 +679,12 @@ static int cmdProfileSearch(int argc, char **argv) {
     std::vector<std::string> frags = readLines(argv[5]);
     float sensitivity = 4.0f;
     double evalThr = 100.0, evalAbs = -1.0;
-    int threads = 1;
+    int threads = 1, forcedK = 0;
     std::string keysPath;
     for (int a = 7; a < argc; a++) {
         std::string s = argv[a];
         if (s == "-s") sensitivity = atof(argv[++a]);
+        else if (s == "-k") forcedK = atoi(argv[++a]);
         else if (s == "-e") evalThr = atof(argv[++a]);
         else if (s == "--eval-abs") evalAbs = atof(argv[++a]);
         else if (s == "--keys") keysPath = argv[++a];
@@ -726,7 +727,7 @@ static int cmdProfileSearch(int argc, char **argv) {
     BaseMatrix *kmerSubMat = new SubstitutionMatrix(blosum.c_str(), 8.0, -0.2f);
     BaseMatrix *ungappedSubMat = new SubstitutionMatrix(blosum.c_str(), 2.0, -0.2f);
     const int alphabetSize = kmerSubMat->alphabetSize;
-    const int kmerSize = IndexTable::computeKmerSize(tdbr.getAminoAcidDBSize());
+    const int kmerSize = forcedK ? forcedK : IndexTable::computeKmerSize(tdbr.getAminoAcidDBSize());
     float kmerThrBest = FLT_MAX;                                   // Prefiltering.cpp:1033-1046 (profile search, no context pseudo counts)
     if (kmerSize == 5) { float base = 108.8; kmerThrBest = base - (sensitivity * 4.7); }
     else if (kmerSize == 6) { float base = 134.35; kmerThrBest = base - (sensitivity * 6.15); }

@@ -326,3 +326,47 @@ def test_profile_query_fills_the_database_hits_buffer(gpu_api, tmp_path):
     assert pref == open(tmp_path / "o" / "pref.txt").read()
     assert aln == open(tmp_path / "o" / "aln.txt").read()
     assert int(hoff[-1]) > 100000
+
+
+@pytest.mark.skipif(not os.path.exists(oracle.REF), reason="reference harness not on this box")
+def test_profile_queries_with_k7(gpu_api, tmp_path):
+    """profile queries against a fragment set searched with k = 7 (what the reference does from 3.35e9 fragment residues on; forced with -k 7):
+    seven one-column steps under the seed 11010110011, threshold 149.15 - 6.85 s (Prefiltering.cpp:1041-1043), a 20^7-cell table.  The e2e
+    profile fixture against the reference's own code (ref_harness profilesearch -k 7); the batch is derived for k = 6 first and follows the
+    database it meets."""
+    import ctypes
+    api = gpu_api
+    _, entries, frags, _, _ = _golden_inputs()
+    frags = frags[:6000]
+    p = api.default_params()
+    p.sensitivity = 4.0
+    p.profile_search = 1
+    p.max_seqs = max(300, len(frags))
+    p.evalue_thr = 5000.0
+    l2 = ctypes.CDLL(None).sysconf(191)
+    p.host_l2_bytes = l2 if l2 and l2 > 0 else 262144
+    p6 = api.default_params()
+    for f in ("sensitivity", "profile_search", "max_seqs", "evalue_thr", "host_l2_bytes"):
+        setattr(p6, f, getattr(p, f))
+    p.kmer_size = 7
+    db = api.TargetDB(frags, p)
+    assert db.kmer_size() == 7
+    q = api.Profiles(entries, p6)                       # thresholds of k = 6: re-derived when the batch meets the k = 7 database
+    (hits, hoff), (alns, aoff) = api.search(db, q, p)
+    (tmp_path / "p.bin").write_bytes(b"".join(entries))
+    off, lines = 0, []
+    for k, e in enumerate(entries):
+        lines.append("%d\t%d\t%d\n" % (k, off, len(e))); off += len(e)
+    (tmp_path / "p.index").write_text("".join(lines))
+    (tmp_path / "f.txt").write_text("\n".join(frags) + "\n")
+    mat = oracle.write_matrix_files(str(tmp_path / "mat"))
+    out = subprocess.check_output([oracle.REF, "profilesearch", mat, str(tmp_path / "p.bin"), str(tmp_path / "p.index"), str(tmp_path / "f.txt"), str(tmp_path / "o"),
+                                   "-s", "4", "-k", "7", "--eval-abs", "5000", "--threads", "16"], stderr=subprocess.DEVNULL)
+    import json
+    info = json.loads(out.decode().strip().splitlines()[-1])
+    assert info["k"] == 7 and info["kmer_thr"] == 121
+    pref = "".join(">%d\n%s" % (i, api.format_hits_bulk(hits, int(hoff[i]), int(hoff[i + 1])).decode()) for i in range(q.n))
+    aln = "".join(">%d\n%s" % (i, api.format_alignments_bulk(alns, int(aoff[i]), int(aoff[i + 1])).decode()) for i in range(q.n))
+    assert pref == open(tmp_path / "o" / "pref.txt").read()
+    assert aln == open(tmp_path / "o" / "aln.txt").read()
+    assert int(hoff[-1]) > 300
