@@ -60,6 +60,8 @@ std::map<std::string, StatAcc> g_stats;
 std::mutex g_statsMutex;
 std::vector<std::string> g_statNames;
 hipStream_t g_stream2 = nullptr;                         // alignment stage of mk_search
+constexpr int MAX_ALIGN_WORKERS = 4;
+hipStream_t g_alignStreams[MAX_ALIGN_WORKERS] = {};      // [0] = g_stream2; the further workers of the alignment stage
 thread_local hipStream_t t_stream = nullptr;             // stream of the calling thread's stage (null: g_stream)
 hipStream_t cur_stream() { return t_stream ? t_stream : g_stream; }
 
@@ -354,6 +356,9 @@ int mk_init(int device) {
         const bool prio = pr && atoi(pr) != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
         if (!g_stream) HIPCHK(prio ? hipStreamCreateWithPriority(&g_stream, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
         if (!g_stream2) HIPCHK(prio ? hipStreamCreateWithPriority(&g_stream2, hipStreamNonBlocking, least) : hipStreamCreateWithFlags(&g_stream2, hipStreamNonBlocking));
+        g_alignStreams[0] = g_stream2;
+        for (int w = 1; w < MAX_ALIGN_WORKERS; w++)
+            if (!g_alignStreams[w]) HIPCHK(prio ? hipStreamCreateWithPriority(&g_alignStreams[w], hipStreamNonBlocking, least) : hipStreamCreateWithFlags(&g_alignStreams[w], hipStreamNonBlocking));
     }
     g_device = device;
     g_ready = true;
@@ -1285,8 +1290,9 @@ int mk_prefilter_result_set(mk_queries *q, const mk_hit *hits, const uint64_t *o
 // Alignment::run over the queries [q0, q1) (Alignment.cpp:312-514): SW on the device, then Matcher::getSWResult's
 // float/double tail (Matcher.cpp:60-142), Alignment::checkCriteria (:548-567) and the per-query sort (:403-405).
 // Appends the accepted alignments at alns[nAlnOut...] and fills alnOff[q0+1 .. q1].
+// (wait_turn: with several workers on one batch, called before anything of the batch's result block is touched -- chunks commit in order)
 static int align_range(mk_targetdb *db, mk_queries *q, const mk_params *P, uint32_t q0, uint32_t q1, const std::vector<mk::GateEntry> &gate,
-                       const mk::AssembleTables *tables, hipStream_t stream, size_t &nAlnOut) {
+                       const mk::AssembleTables *tables, hipStream_t stream, size_t &nAlnOut, const std::function<void()> &wait_turn = nullptr) {
     const uint32_t nqc = q1 - q0;
     const uint64_t h0 = q->hitOff[q0];
     const size_t n = (size_t) (q->hitOff[q1] - h0);
@@ -1295,7 +1301,7 @@ static int align_range(mk_targetdb *db, mk_queries *q, const mk_params *P, uint3
     for (uint32_t i = 0; i <= nqc; i++) hitOff[i] = q->hitOff[(size_t) q0 + i] - h0;
     mk::AlignView V = align_view(db, q);
     V.q_off = q->dOff.p + q0; V.n_queries = nqc;
-    V.co_resident = stream == g_stream2;            // the alignment stage of mk_search runs beside the prefilter
+    V.co_resident = stream != g_stream;             // the alignment stage of mk_search runs beside the prefilter
     const mk::AlnRaw *raw = nullptr;
     size_t m = 0;
     std::string err;
@@ -1307,13 +1313,17 @@ static int align_range(mk_targetdb *db, mk_queries *q, const mk_params *P, uint3
     asmArgs.dSortKey = db->dKeys.p;
     asmArgs.counts = (uint32_t *) mk::pinned_scratch(stream == g_stream2 ? "asm_counts_h2" : "asm_counts_h", std::max<size_t>(nqc, 1) * 4);
     if (!asmArgs.counts) return fail(MK_ERR_DEVICE, "pinned host allocation failed");
+    bool turned = false;
+    const auto turn = [&]() { if (!turned && wait_turn) wait_turn(); turned = true; };
     asmArgs.reserve = [&](size_t cnt) -> mk_alignment * {
+        turn();
         if (!q->alns.reserve(std::max<size_t>(nAlnOut + cnt, 1) * sizeof(mk_alignment), nAlnOut * sizeof(mk_alignment))) return nullptr;
         return (mk_alignment *) q->alns.p + nAlnOut;
     };
     int rc = mk::run_align_device(V, hitOff.data(), hits, n, gate, *P, stream, nullptr, &raw, &m, err, timed_begin, timed_end, timed_set, &asmArgs);
     timed_flush();
     if (rc != MK_OK) return fail(rc, "%s", err.c_str());
+    turn();
     if (asmArgs.done) {
         uint64_t o = 0;
         for (uint32_t i = 0; i < nqc; i++) { o += asmArgs.counts[i]; q->alnOff[(size_t) q0 + i + 1] = nAlnOut + o; }
@@ -1426,46 +1436,62 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     q->alnOff.assign((size_t) q->n + 1, 0);
     q->havePref = false; q->haveAln = false;
 
+    struct Item { uint32_t seq, q0, q1; };
     struct Pipe {
         std::mutex m; std::condition_variable cv;
-        std::deque<std::pair<uint32_t, uint32_t>> items;     // finished prefilter chunks [q0, q1)
-        bool done = false, busy = false;
+        std::deque<Item> items;                              // finished prefilter chunks [q0, q1), numbered
+        bool done = false;
+        int busy = 0;
+        uint32_t pushed = 0, turn = 0;                       // chunks handed over; the chunk whose alignments are appended next
         int rc = MK_OK; std::string err;
     } pipe;
     size_t nAln = 0;
     const int hostThreads = omp_get_max_threads();
-    const int half = std::max(1, hostThreads / 2);
-    std::thread consumer([&]() {
-        t_stream = g_stream2;
+    // the alignment stage: MK_ALIGN_WORKERS host threads, each with a stream and scratch buffers of its own, take the chunks in turn --
+    // the position and reverse passes of one chunk (short launches, slow beside persistent workgroups) then run beside the
+    // forward pass of the next one instead of in front of it.  Results are appended in chunk order.
+    static const int nWorkers = std::min(MAX_ALIGN_WORKERS, std::max(1, getenv("MK_ALIGN_WORKERS") ? atoi(getenv("MK_ALIGN_WORKERS")) : 2));
+    const int half = std::max(1, hostThreads / (1 + nWorkers));
+    {   // the per-length score tables of the batch (cached per database and query lengths)
+        HostTimer ht("host_gate_table");
+        score_tables(db, q, P->evalue_thr, tablesp, gatep);
+    }
+    const auto worker = [&](int w) {
+        t_stream = g_alignStreams[w];
+        mk::set_scratch_lane(w);
         (void) hipSetDevice(g_device);
         kmp_set_blocktime(0);
         omp_set_num_threads(half);
-        {   // the per-length score tables of the batch, while the prefilter works on its first chunk
-            HostTimer ht("host_gate_table");
-            score_tables(db, q, P->evalue_thr, tablesp, gatep);
-        }
         for (;;) {
-            std::pair<uint32_t, uint32_t> it;
+            Item it;
             {
                 std::unique_lock<std::mutex> lk(pipe.m);
                 pipe.cv.wait(lk, [&] { return !pipe.items.empty() || pipe.done; });
                 if (pipe.items.empty()) break;
                 it = pipe.items.front(); pipe.items.pop_front();
-                pipe.busy = true;
+                pipe.busy++;
             }
             int r = MK_OK;
+            const auto wait_turn = [&]() {
+                std::unique_lock<std::mutex> lk(pipe.m);
+                pipe.cv.wait(lk, [&] { return pipe.turn == it.seq; });
+            };
             if (pipe.rc == MK_OK) {
                 HostTimer ht("host_align_total");
-                r = align_range(db, q, P, it.first, it.second, *gatep, tablesp, g_stream2, nAln);
+                r = align_range(db, q, P, it.q0, it.q1, *gatep, tablesp, g_alignStreams[w], nAln, wait_turn);
             }
+            wait_turn();
             {
                 std::lock_guard<std::mutex> lk(pipe.m);
                 if (r != MK_OK && pipe.rc == MK_OK) { pipe.rc = r; pipe.err = g_err; }
-                pipe.busy = false;
+                pipe.busy--;
+                pipe.turn = it.seq + 1;
             }
             pipe.cv.notify_all();
         }
-    });
+    };
+    std::vector<std::thread> consumers;
+    for (int w = 0; w < nWorkers; w++) consumers.emplace_back(worker, w);
     mk::PrefilterHooks hooks;
     // chunks of 262 144 queries, the first ones smaller (65 536, 131 072: the alignment stage starts when the first chunk is done).  Measured on
     // config 2 (profiles/r03_search_tuning.txt): 131 072-query chunks 1.095 s per step, 262 144 with the ramp 0.99 s -- the position and reverse
@@ -1480,12 +1506,12 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     if (const char *e = getenv("MK_SEARCH_CHUNK_QUERIES")) hooks.max_chunk_queries = (uint32_t) std::max(1024L, atol(e));
     if (const char *e = getenv("MK_SEARCH_CHUNK_RAMP")) hooks.chunk_ramp = atoi(e) != 0;
     hooks.on_chunk = [&](uint32_t a, uint32_t b) {
-        { std::lock_guard<std::mutex> lk(pipe.m); pipe.items.emplace_back(a, b); }
+        { std::lock_guard<std::mutex> lk(pipe.m); pipe.items.push_back(Item{pipe.pushed++, a, b}); }
         pipe.cv.notify_all();
     };
     hooks.before_grow = [&]() {                                // the result block moves: nobody may be reading it
         std::unique_lock<std::mutex> lk(pipe.m);
-        pipe.cv.wait(lk, [&] { return pipe.items.empty() && !pipe.busy; });
+        pipe.cv.wait(lk, [&] { return pipe.items.empty() && pipe.busy == 0; });
     };
     std::string err;
     const int binCount = mk::bin_count_for(db->n, P->host_l2_bytes);
@@ -1499,7 +1525,7 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     timed_flush();
     { std::lock_guard<std::mutex> lk(pipe.m); pipe.done = true; if (rc != MK_OK && pipe.rc == MK_OK) { pipe.rc = rc; pipe.err = err; } }
     pipe.cv.notify_all();
-    consumer.join();
+    for (std::thread &t : consumers) t.join();
     if (pipe.rc != MK_OK) return fail(pipe.rc, "%s", pipe.err.c_str());
     q->havePref = true; q->haveAln = true;
     return MK_OK;

@@ -623,7 +623,7 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hi
         uint32_t *hFlags = (uint32_t *) pinned_scratch("asm_flags_h", 16);
         ANULL(dEval); ANULL(dLenIdx); ANULL(dBit); ANULL(dTmp); ANULL(dFinal); ANULL(dPass); ANULL(dCnt); ANULL(dOff); ANULL(dFlags); ANULL(hFlags);
         // the tables belong to the batch (same for every range of an mk_search): uploaded when they change
-        static uint64_t uploadedId = 0; static std::mutex upMutex;
+        static thread_local uint64_t uploadedId = 0; static std::mutex upMutex;     // (per host thread: a second worker of the stage has buffers of its own)
         {
             std::lock_guard<std::mutex> g(upMutex);
             if (uploadedId != T.id) {
@@ -717,10 +717,17 @@ std::map<std::string, Scratch> &scratch_map() { static std::map<std::string, Scr
 }
 
 static std::mutex &scratch_mutex() { static std::mutex m; return m; }
+static thread_local int t_lane = 0;
+void set_scratch_lane(int lane) { t_lane = lane; }
+static std::string scratch_key(const char *prefix, const char *name) {
+    std::string k = std::string(prefix) + name;
+    if (t_lane > 0) { k += '#'; k += std::to_string(t_lane); }
+    return k;
+}
 
 void *dev_scratch(const char *name, size_t bytes) {
     std::lock_guard<std::mutex> g(scratch_mutex());
-    Scratch &s = scratch_map()[std::string("d:") + name];
+    Scratch &s = scratch_map()[scratch_key("d:", name)];
     if (bytes <= s.cap && s.p) return s.p;
     if (s.p) (void) hipFree(s.p);
     s.p = nullptr; s.cap = 0;
@@ -732,7 +739,7 @@ void *dev_scratch(const char *name, size_t bytes) {
 
 void *pinned_scratch(const char *name, size_t bytes) {
     std::lock_guard<std::mutex> g(scratch_mutex());
-    Scratch &s = scratch_map()[std::string("h:") + name];
+    Scratch &s = scratch_map()[scratch_key("h:", name)];
     if (bytes <= s.cap && s.p) return s.p;
     if (s.p) (void) hipHostFree(s.p);
     s.p = nullptr; s.cap = 0;

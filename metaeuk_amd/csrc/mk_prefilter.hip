@@ -43,6 +43,7 @@
 #include "mk_enum.hpp"
 #include "mk_profile.hpp"
 #include "mk_kmer7.hpp"
+#include "mk_segsort.hpp"
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <cstdlib>
@@ -55,6 +56,12 @@ namespace {
 
 constexpr int WAVE = 64;
 constexpr int N3 = 8000;
+
+// short launches of this stage run beside the persistent workgroups of the other one, whose older waves win the CU's issue arbitration
+#ifndef MK_HELPER_PRIO
+#define MK_HELPER_PRIO 3         // (profiles/r03_search_tuning.txt: the helpers of a config-2 step 210 -> 95 ms)
+#endif
+__device__ __forceinline__ void helper_prio() { if (MK_HELPER_PRIO) __builtin_amdgcn_s_setprio(MK_HELPER_PRIO); }
 
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
     uint32_t x = v;
@@ -362,6 +369,7 @@ __global__ void overflow_segments_kernel(const uint32_t *listPos, uint32_t nList
 // candidates behind those of the blocks before it -- runs of one (query, target) stay contiguous and in arrival order
 template <bool OVF = false>
 __global__ __launch_bounds__(256) void double_hit_count_kernel(const uint64_t *rec, uint32_t hitBits, uint32_t n, uint32_t *blockCount, Segments S) {
+    helper_prio();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = __syncthreads_count(t < n && double_hit_emits<OVF>(rec, hitBits, t, S));
     if (threadIdx.x == 0) blockCount[blockIdx.x] = (uint32_t) c;
@@ -373,6 +381,7 @@ template <bool OVF = false>
 __global__ __launch_bounds__(256) void double_hit_emit_kernel(const uint64_t *rec, const uint8_t *diagHi, const uint32_t *blockStart, uint32_t n, uint32_t seqBits,
                                                               uint32_t hitBits, const uint64_t *qOff, uint32_t qFirst, uint64_t posBegin, const uint32_t *hitScan,
                                                               const uint32_t *qMap, uint32_t qAdd, CandArrays C, uint32_t base, Segments S) {
+    helper_prio();
     __shared__ uint32_t sWave[4];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const int w = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
@@ -412,6 +421,7 @@ __global__ __launch_bounds__(256) void gather_queries_kernel(PrefilterDeviceView
 // query leave the wave in one atomic.
 __global__ __launch_bounds__(256) void kmer_count_kernel(PrefilterDeviceView V, uint64_t posBegin, uint64_t posEnd, uint32_t qFirst, uint32_t *perQuery,
                                                         uint16_t *perPos /* [p - posBegin]: similar k-mers of the start / 4, saturated (work estimate) */) {
+    helper_prio();
     const int lane = threadIdx.x & (WAVE - 1);
     const uint64_t wave = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const uint64_t p0 = posBegin + wave * WAVE;
@@ -897,6 +907,7 @@ void launch_stream(int tier, const StreamArgs &A, unsigned grid, hipStream_t str
 // =====================================================================================================
 // exact ungapped diagonal score of every candidate
 __global__ __launch_bounds__(256) void diag_score_kernel(PrefilterDeviceView V, uint32_t qFirst, uint32_t n, CandArrays C) {
+    helper_prio();
     __shared__ int8_t smat[21 * 21 + 3];
     for (int i = threadIdx.x; i < 21 * 21; i += blockDim.x) smat[i] = V.mat_ung[i];
     __syncthreads();
@@ -914,8 +925,9 @@ __global__ __launch_bounds__(256) void diag_score_kernel(PrefilterDeviceView V, 
 // keepMaxScoreElementOnly on the candidates (per (query,target) contiguous, in arrival order): a candidate survives
 // when its clamped score is the maximum of its run and no earlier candidate of the run has the same clamped score.
 // Survivors below --min-ungapped-score can never be reported (diagonalThr >= minDiagScoreThr) and are dropped here.
-__global__ __launch_bounds__(256) void keep_kernel(CandArrays C, uint32_t n, int minDiag, uint8_t *kept, uint32_t *perQuery,
-                                                   uint32_t *perQuery255 /* survivors at the clamp value 255 (>= 2^30: the query goes to the host) */) {
+__global__ __launch_bounds__(256) void keep_kernel(CandArrays C, uint32_t n, int minDiag, uint32_t scoreMax, bool hostCut, uint8_t *kept, uint32_t *perQuery,
+                                                   uint32_t *perQuery255 /* survivors at the clamp value 255 | flags: the host finishes the query (P255_*) */) {
+    helper_prio();
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     const uint32_t q = C.q[c], id = C.id[c];
@@ -934,81 +946,201 @@ __global__ __launch_bounds__(256) void keep_kernel(CandArrays C, uint32_t n, int
     if (keep) {
         atomicAdd(&perQuery[q], 1u);
         if (s == 255) atomicAdd(&perQuery255[q], 1u);
-        if (C.ordinal[c] >= (1u << 26)) atomicOr(&perQuery255[q], 1u << 30);       // does not fit the selection key below
+        if (hostCut || C.ordinal[c] >= (1u << 26)) atomicOr(&perQuery255[q], 1u << 30);       // P255_HOST_IF_CUT: does not fit the cut key below
+        if ((uint32_t) C.score[c] > scoreMax) atomicOr(&perQuery255[q], 1u << 31);             // P255_HOST: does not fit the report key
     }
 }
 
+// ---- the tail of QueryMatcher::matchQuery per query (QueryMatcher.cpp:149-209 + getResult :117-125), without a device-wide sort
 // Queries with at least --max-seqs surviving targets: the reference keeps the first max-seqs of them in the order (clamped score
-// descending, hash bin of the target = id & (BINSIZE - 1), arrival) -- QueryMatcher.cpp:149-209, radixSortByScoreSize :498-523 over the
-// bin-major element order of CacheFriendlyOperations.  That order as ONE 64-bit key per surviving candidate: query | 255 - clamped |
-// bin | arrival; after a radix sort a candidate is selected when fewer than max-seqs keys of its query precede it.  Only the case in
-// which max-seqs survivors sit AT the clamp value (the threshold saturates and is rescaled by the self score, :163-170) stays on the host.
-__global__ __launch_bounds__(256) void maxseqs_key_kernel(CandArrays C, uint32_t n, const uint8_t *kept, const uint32_t *perQuery, const uint32_t *perQuery255,
-                                                          uint32_t maxHits, uint32_t binMask, uint64_t *key, uint32_t *idx) {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
-    const uint32_t q = C.q[c];
-    uint64_t k = ~0ull;
-    if (kept[c] && perQuery[q] >= maxHits && perQuery255[q] < maxHits)
-        k = ((uint64_t) q << 44) | ((uint64_t) (255u - (uint32_t) min(C.score[c], 255)) << 36) | ((uint64_t) (C.id[c] & binMask) << 26) | (uint64_t) C.ordinal[c];
-    key[c] = k;
-    idx[c] = c;
-}
-__global__ __launch_bounds__(256) void maxseqs_rank_kernel(const uint64_t *sortedKey, const uint32_t *sortedIdx, uint32_t n, uint32_t maxHits, uint8_t *selected) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t k = sortedKey[i];
-    if (k == ~0ull) { selected[sortedIdx[i]] = 0; return; }
-    const uint64_t q = k >> 44;
-    uint32_t lo = 0, hi = i;                          // first key of this query
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((sortedKey[mid] >> 44) < q) lo = mid + 1; else hi = mid; }
-    selected[sortedIdx[i]] = (i - lo) < maxHits ? 1 : 0;
-}
+// descending, hash bin of the target = id & (BINSIZE - 1), arrival) -- radixSortByScoreSize :498-523 over the bin-major element
+// order of CacheFriendlyOperations.  That order as ONE 64-bit key per survivor: 255 - clamped | bin | arrival (the "cut key").  The
+// reported order (score descending, target ascending) as another, which also carries the hit: inverted score | target | diagonal.
+// The survivors of a query are gathered into its segment (counting sort by query: counts from keep_kernel, offsets from a scan,
+// one atomic cursor per query); then whoever owns the segment -- a wave, a workgroup in LDS, a workgroup over HBM -- takes the
+// max-seqs smallest cut keys (if the query reaches the cut), sorts the report keys and writes the query's hits at their final
+// offset.  Only the case in which max-seqs survivors sit AT the clamp value (the threshold saturates and is rescaled by the self
+// score, :163-170), arrival numbers >= 2^26 and scores beyond the key's score field stay on the host (flags in perQuery255).
+constexpr uint32_t P255_HOST_IF_CUT = 1u << 30, P255_HOST = 1u << 31;
+constexpr uint32_t FIN_WAVE_MAX = 64, FIN_SMALL_MAX = 512, FIN_LDS_MAX = 4096, FIN_HUGE_TILE = 8192;
+__host__ __device__ __forceinline__ bool fin_to_host(uint32_t n, uint32_t p255, uint32_t maxHits) { return (p255 & P255_HOST) != 0u || (n >= maxHits && p255 >= maxHits); }
+__host__ __device__ __forceinline__ uint32_t fin_score_max(uint32_t seqBits) { return (1u << (48u - seqBits < 31u ? 48u - seqBits : 31u)) - 1u; }
 
-// sort key of a reportable hit: (query, score descending, target ascending); everything else sorts last
-__global__ __launch_bounds__(256) void outkey_kernel(CandArrays C, uint32_t n, const uint8_t *kept, const uint32_t *perQuery, const uint32_t *perQuery255,
-                                                     const uint8_t *selected, uint32_t maxHits,
-                                                     uint32_t seqBits, uint64_t *outKey, uint32_t *outIdx, uint8_t *hostFlag) {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
-    const uint32_t q = C.q[c];
-    const bool cut = perQuery[q] >= maxHits;           // --max-seqs reached: the first max-seqs in the reference's order (selected[]) ...
-    const bool toHost = cut && perQuery255[q] >= maxHits;   // ... or, with a saturated threshold, the host's restatement
-    hostFlag[c] = toHost ? 1 : 0;
-    uint64_t key = ~0ull;
-    if (kept[c] && !toHost && (!cut || selected[c])) {
-        // 20 bits query | (44 - seqBits) bits inverted score | seqBits bits target  (score field >= 17 bits)
-        const uint32_t smax = (1u << min(44u - seqBits, 31u)) - 1u;
-        const uint32_t sc = (uint32_t) min((uint32_t) C.score[c], smax);
-        key = ((uint64_t) q << 44) | ((uint64_t) (smax - sc) << seqBits) | (uint64_t) C.id[c];
+struct FinishArgs {
+    const uint32_t *perQ, *perQ255;      // survivors per query, survivors at the clamp value | flags
+    uint32_t nq, maxHits, seqBits;
+    uint32_t *segOff, *outOff;           // per query: first survivor in the segment arrays, first hit in the output
+    uint32_t *listW, *listS, *listB, *listH;     // queries by segment size: <= 64, <= 512, <= 4096, longer
+    uint32_t *hugeTmp;                   // per listH entry: offset of its scratch (cut queries)
+    uint32_t *blockSums;                 // [blocks][8]
+    uint32_t *totals;                    // [0] hits [1] survivors in segments [2..5] list sizes [6] scratch keys [8] candidates of host queries [9] export cursor
+};
+constexpr int FIN_NV = 7;
+__device__ __forceinline__ void fin_values(const FinishArgs &F, uint32_t q, uint32_t (&v)[FIN_NV]) {
+#pragma unroll
+    for (int k = 0; k < FIN_NV; k++) v[k] = 0;
+    if (q >= F.nq) return;
+    const uint32_t n = F.perQ[q];
+    if (n == 0 || fin_to_host(n, F.perQ255[q], F.maxHits)) return;
+    v[0] = min(n, F.maxHits);
+    v[1] = n;
+    v[2] = n <= FIN_WAVE_MAX ? 1u : 0u;
+    v[3] = (n > FIN_WAVE_MAX && n <= FIN_SMALL_MAX) ? 1u : 0u;
+    v[4] = (n > FIN_SMALL_MAX && n <= FIN_LDS_MAX) ? 1u : 0u;
+    v[5] = n > FIN_LDS_MAX ? 1u : 0u;
+    v[6] = (n > FIN_LDS_MAX && n >= F.maxHits) ? n : 0u;
+}
+// (small workgroups: these kernels run beside the persistent ones of both stages and must find room on a CU)
+constexpr uint32_t FIN_SCAN = 256;
+__global__ __launch_bounds__(FIN_SCAN) void finish_sums_kernel(FinishArgs F) {
+    helper_prio();
+    __shared__ uint32_t sm[FIN_NV * 16];
+    uint32_t v[FIN_NV], excl[FIN_NV], total[FIN_NV];
+    fin_values(F, blockIdx.x * FIN_SCAN + threadIdx.x, v);
+    segsort::block_scan<FIN_NV>(v, excl, total, sm);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < FIN_NV; k++) F.blockSums[blockIdx.x * 8u + k] = total[k];
+}
+__global__ __launch_bounds__(FIN_SCAN) void finish_offsets_kernel(FinishArgs F) {
+    helper_prio();
+    __shared__ uint32_t sm[FIN_NV * 16];
+    uint32_t v[FIN_NV], excl[FIN_NV], total[FIN_NV], base[FIN_NV];
+#pragma unroll
+    for (int k = 0; k < FIN_NV; k++) v[k] = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += FIN_SCAN)
+#pragma unroll
+        for (int k = 0; k < FIN_NV; k++) v[k] += F.blockSums[b * 8u + k];
+    segsort::block_scan<FIN_NV>(v, excl, base, sm);
+    const uint32_t q = blockIdx.x * FIN_SCAN + threadIdx.x;
+    fin_values(F, q, v);
+    segsort::block_scan<FIN_NV>(v, excl, total, sm);
+    if (q < F.nq) {
+        F.outOff[q] = base[0] + excl[0];
+        F.segOff[q] = base[1] + excl[1];
+        if (v[2]) F.listW[base[2] + excl[2]] = q;
+        if (v[3]) F.listS[base[3] + excl[3]] = q;
+        if (v[4]) F.listB[base[4] + excl[4]] = q;
+        if (v[5]) { F.listH[base[5] + excl[5]] = q; F.hugeTmp[base[5] + excl[5]] = base[6] + excl[6]; }
     }
-    outKey[c] = key;
-    outIdx[c] = c;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < FIN_NV; k++) F.totals[k] = base[k] + total[k];
 }
 
-__global__ __launch_bounds__(256) void emit_kernel(CandArrays C, const uint32_t *sortedIdx, uint32_t nValid, mk_hit *out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nValid) return;
-    const uint32_t c = sortedIdx[i];
+// survivors into the segments of their queries; candidates of host queries are counted
+__global__ __launch_bounds__(256) void finish_scatter_kernel(CandArrays C, uint32_t n, const uint8_t *kept, FinishArgs F, uint32_t binMask, uint32_t *cursor,
+                                                             uint64_t *cutKey, uint64_t *outKey) {
+    helper_prio();
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    bool host = false;
+    if (c < n) {
+        const uint32_t q = C.q[c], nQ = F.perQ[q];
+        if (nQ != 0 && fin_to_host(nQ, F.perQ255[q], F.maxHits)) host = true;
+        else if (kept[c]) {
+            const uint32_t pos = F.segOff[q] + atomicAdd(&cursor[q], 1u);
+            const uint32_t score = (uint32_t) C.score[c], id = C.id[c];
+            outKey[pos] = ((uint64_t) (fin_score_max(F.seqBits) - score) << (16u + F.seqBits)) | ((uint64_t) id << 16) | (uint64_t) C.diag[c];
+            if (nQ >= F.maxHits) cutKey[pos] = ((uint64_t) (255u - min(score, 255u)) << 36) | ((uint64_t) (id & binMask) << 26) | (uint64_t) C.ordinal[c];
+        }
+    }
+    const unsigned long long m = __ballot(host);
+    if (m != 0 && (threadIdx.x & 63u) == (uint32_t) (__ffsll((long long) m) - 1)) atomicAdd(&F.totals[8], (uint32_t) __popcll(m));
+}
+
+__device__ __forceinline__ mk_hit fin_hit(uint64_t key, uint32_t seqBits) {
     mk_hit h;
-    h.seq_id = C.id[c]; h.pref_score = C.score[c]; h.diagonal = C.diag[c]; h.pad_ = 0;
-    out[i] = h;
+    h.seq_id = (uint32_t) (key >> 16) & ((1u << seqBits) - 1u);
+    h.pref_score = (int32_t) (fin_score_max(seqBits) - (uint32_t) (key >> (16u + seqBits)));
+    h.diagonal = (uint16_t) key; h.pad_ = 0;
+    return h;
+}
+
+// segments of at most 64 survivors: one wave each, ranks by counting
+__global__ __launch_bounds__(256) void finish_wave_kernel(FinishArgs F, uint32_t nItems, const uint64_t *cutKey, const uint64_t *outKey, mk_hit *out) {
+    helper_prio();
+    const uint32_t item = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (item >= nItems) return;
+    const uint32_t q = F.listW[item], n = F.perQ[q], b = F.segOff[q];
+    uint64_t key = lane < n ? outKey[b + lane] : ~0ull;
+    if (n >= F.maxHits) {
+        const uint64_t k1 = lane < n ? cutKey[b + lane] : ~0ull;
+        if (segsort::wave_rank(k1, n) >= F.maxHits) key = ~0ull;
+    }
+    const uint32_t r = segsort::wave_rank(key, n);
+    if (key != ~0ull) out[F.outOff[q] + r] = fin_hit(key, F.seqBits);
+}
+
+// longer segments: one workgroup each; in LDS up to TILE survivors, over HBM beyond
+template <int THREADS, uint32_t TILE>
+__global__ __launch_bounds__(THREADS) void finish_block_kernel(FinishArgs F, const uint32_t *list, const uint64_t *cutKey, uint64_t *outKey, uint64_t *scratch, mk_hit *out) {
+    helper_prio();
+    __shared__ uint64_t sK[TILE];
+    __shared__ uint32_t sM;
+    const uint32_t q = list[blockIdx.x], n = F.perQ[q], b = F.segOff[q];
+    const bool cut = n >= F.maxHits;
+    const uint32_t m = cut ? F.maxHits : n;
+    mk_hit *dst = out + F.outOff[q];
+    if (n <= TILE) {
+        uint32_t P = segsort::pow2_at_least(n);
+        if (cut) {
+            for (uint32_t t = threadIdx.x; t < P; t += THREADS) sK[t] = t < n ? cutKey[b + t] : ~0ull;
+            if (threadIdx.x == 0) sM = 0;
+            __syncthreads();
+            segsort::lds_sort<THREADS>(sK, P);
+            const uint64_t last = sK[m - 1];
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < n; t += THREADS)
+                if (cutKey[b + t] <= last) sK[atomicAdd(&sM, 1u)] = outKey[b + t];
+            __syncthreads();
+            P = segsort::pow2_at_least(m);
+            for (uint32_t t = m + threadIdx.x; t < P; t += THREADS) sK[t] = ~0ull;
+        } else {
+            for (uint32_t t = threadIdx.x; t < P; t += THREADS) sK[t] = t < n ? outKey[b + t] : ~0ull;
+        }
+        __syncthreads();
+        segsort::lds_sort<THREADS>(sK, P);
+        for (uint32_t t = threadIdx.x; t < m; t += THREADS) dst[t] = fin_hit(sK[t], F.seqBits);
+        return;
+    }
+    uint64_t *work = outKey + b;
+    if (cut) {
+        work = scratch + F.hugeTmp[blockIdx.x];
+        for (uint32_t t = threadIdx.x; t < n; t += THREADS) work[t] = cutKey[b + t];
+        if (threadIdx.x == 0) sM = 0;
+        __syncthreads();
+        segsort::global_sort<THREADS, TILE>(work, n, sK);
+        const uint64_t last = work[m - 1];
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < n; t += THREADS)
+            if (cutKey[b + t] <= last) work[atomicAdd(&sM, 1u)] = outKey[b + t];
+        __syncthreads();
+    }
+    segsort::global_sort<THREADS, TILE>(work, m, sK);
+    for (uint32_t t = threadIdx.x; t < m; t += THREADS) dst[t] = fin_hit(work[t], F.seqBits);
 }
 
 struct HostCand { uint32_t q, id, ordinal; uint16_t diag; int32_t score; };
-__global__ __launch_bounds__(256) void export_flagged_kernel(CandArrays C, const uint32_t *sel, uint32_t n, HostCand *out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t c = sel[i];
+// every candidate of the queries the host finishes (any order: the host sorts a query's candidates by arrival)
+__global__ __launch_bounds__(256) void export_host_kernel(CandArrays C, uint32_t n, FinishArgs F, HostCand *out) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    bool host = false;
+    uint32_t q = 0;
+    if (c < n) {
+        q = C.q[c];
+        const uint32_t nQ = F.perQ[q];
+        host = nQ != 0 && fin_to_host(nQ, F.perQ255[q], F.maxHits);
+    }
+    const unsigned long long m = __ballot(host);
+    if (m == 0) return;
+    const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t) (__ffsll((long long) m) - 1);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&F.totals[9], (uint32_t) __popcll(m));
+    base = (uint32_t) __shfl((int) base, (int) leader, 64);
+    if (!host) return;
     HostCand h;
-    h.q = C.q[c]; h.id = C.id[c]; h.ordinal = C.ordinal[c]; h.diag = C.diag[c]; h.score = C.score[c];
-    out[i] = h;
-}
-
-__global__ void first_invalid_kernel(const uint64_t *sortedKeys, uint32_t n, uint32_t *out) {
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sortedKeys[mid] != ~0ull) lo = mid + 1; else hi = mid; }
-    out[0] = lo;
+    h.q = q; h.id = C.id[c]; h.ordinal = C.ordinal[c]; h.diag = C.diag[c]; h.score = C.score[c];
+    out[base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull))] = h;
 }
 
 // exact ungapped self score of a query on diagonal 0 (QueryMatcher::rescoreHits, QueryMatcher.cpp:525-531);
@@ -1736,68 +1868,58 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
         std::vector<std::vector<mk_hit>> hostHits;     // per flagged query
         std::vector<uint32_t> hostQ;
         if (nCand > 0) {
-            uint8_t *dKept = (uint8_t *) dev_scratch("pf_kept", nCand), *dHostFlag = (uint8_t *) dev_scratch("pf_hostflag", nCand);
-            uint32_t *dPerQ = (uint32_t *) dev_scratch("pf_perq", (size_t) nqc * 8), *dPerQ255 = dPerQ ? dPerQ + nqc : nullptr;
-            uint8_t *dSelected = (uint8_t *) dev_scratch("pf_selected", nCand);
-            PNULL(dSelected);
-            uint64_t *dOutKey = (uint64_t *) dev_scratch("pf_okey", (size_t) nCand * 8), *dOutKey2 = (uint64_t *) dev_scratch("pf_okey2", (size_t) nCand * 8);
-            uint32_t *dOutIdx = (uint32_t *) dev_scratch("pf_oidx", (size_t) nCand * 4), *dOutIdx2 = (uint32_t *) dev_scratch("pf_oidx2", (size_t) nCand * 4);
-            uint32_t *dFlagSel = (uint32_t *) dev_scratch("pf_flagsel", (size_t) nCand * 4);
+            if (seqBits > 28) { err = "more than 2^28 targets: the report key of the prefilter's tail has no room"; return MK_ERR_UNSUPPORTED; }
+            const uint32_t nb = (nqc + FIN_SCAN - 1u) / FIN_SCAN;
+            uint8_t *dKept = (uint8_t *) dev_scratch("pf_kept", nCand);
+            uint32_t *dPerQ = (uint32_t *) dev_scratch("pf_perq", (size_t) nqc * 12), *dPerQ255 = dPerQ ? dPerQ + nqc : nullptr, *dCursor = dPerQ ? dPerQ + 2 * (size_t) nqc : nullptr;
+            uint32_t *dFin = (uint32_t *) dev_scratch("pf_fin", ((size_t) nqc * 7 + (size_t) nb * 8) * 4);
+            uint64_t *dCutKey = (uint64_t *) dev_scratch("pf_cutkey", (size_t) nCand * 8), *dOutKey = (uint64_t *) dev_scratch("pf_okey", (size_t) nCand * 8);
             uint32_t *dNum = (uint32_t *) dev_scratch("pf_num", 64);
             uint32_t *hNum = (uint32_t *) pinned_scratch("pf_num_h", 64);
-            PNULL(dKept); PNULL(dHostFlag); PNULL(dPerQ); PNULL(dOutKey); PNULL(dOutKey2); PNULL(dOutIdx); PNULL(dOutIdx2); PNULL(dFlagSel); PNULL(dNum); PNULL(hNum);
+            PNULL(dKept); PNULL(dPerQ); PNULL(dFin); PNULL(dCutKey); PNULL(dOutKey); PNULL(dNum); PNULL(hNum);
             int th = tb("diag_score", 28.0 * nCand, 0);
             hipLaunchKernelGGL(diag_score_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, V, q0, nCand, C);
             te(th);
             PCHK(hipGetLastError());
-            PCHK(hipMemsetAsync(dPerQ, 0, (size_t) nqc * 8, stream));
-            th = tb("select_hits", 20.0 * nCand, 0);
-            hipLaunchKernelGGL(keep_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, C, nCand, P.min_ungapped_score, dKept, dPerQ, dPerQ255);
-            hipcub::DoubleBuffer<uint64_t> ob(dOutKey, dOutKey2);
-            hipcub::DoubleBuffer<uint32_t> ib(dOutIdx, dOutIdx2);
-            size_t t2 = 0;
-            hipcub::DeviceRadixSort::SortPairs(nullptr, t2, ob, ib, (int) nCand, 0, 64, stream);
-            void *temp = dev_scratch("pf_temp", t2);
-            PNULL(temp);
-            {   // the --max-seqs cut of the queries that reach it (the buffers of the output sort serve both sorts)
-                static const bool hostCut = getenv("MK_PREFILTER_HOST_MAXSEQS") && atoi(getenv("MK_PREFILTER_HOST_MAXSEQS")) != 0;
-                // (min-ungapped-score 0 keeps zero-score elements under rules of their own: left to the host's restatement)
-                const uint32_t deviceCut = (hostCut || P.min_ungapped_score <= 0) ? 0xFFFFFFFFu : (uint32_t) maxHits;
-                if (deviceCut != 0xFFFFFFFFu) {
-                    hipLaunchKernelGGL(maxseqs_key_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, C, nCand, dKept, dPerQ, dPerQ255, (uint32_t) maxHits, (uint32_t) (binCount - 1), dOutKey, dOutIdx);
-                    PCHK(hipcub::DeviceRadixSort::SortPairs(temp, t2, ob, ib, (int) nCand, 0, 64, stream));
-                    hipLaunchKernelGGL(maxseqs_rank_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, ob.Current(), ib.Current(), nCand, (uint32_t) maxHits, dSelected);
-                } else {
-                    PCHK(hipMemsetAsync(dSelected, 0, nCand, stream));
-                    PCHK(hipMemsetAsync(dPerQ255, 0x7F, (size_t) nqc * 4, stream));      // every query at the cut goes to the host
-                }
-            }
-            hipLaunchKernelGGL(outkey_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, C, nCand, dKept, dPerQ, dPerQ255, dSelected, (uint32_t) maxHits, seqBits, ob.Current(), ib.Current(), dHostFlag);
+            PCHK(hipMemsetAsync(dPerQ, 0, (size_t) nqc * 12, stream));
+            PCHK(hipMemsetAsync(dNum, 0, 64, stream));
+            th = tb("select_hits", 35.0 * nCand, 0);
+            // (min-ungapped-score 0 keeps zero-score elements under rules of their own: every query at the cut is left to the host's restatement)
+            static const bool hostCutEnv = getenv("MK_PREFILTER_HOST_MAXSEQS") && atoi(getenv("MK_PREFILTER_HOST_MAXSEQS")) != 0;
+            const bool hostCut = hostCutEnv || P.min_ungapped_score <= 0;
+            hipLaunchKernelGGL(keep_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, C, nCand, P.min_ungapped_score, fin_score_max(seqBits), hostCut, dKept, dPerQ, dPerQ255);
+            FinishArgs F;
+            F.perQ = dPerQ; F.perQ255 = dPerQ255; F.nq = nqc; F.maxHits = (uint32_t) maxHits; F.seqBits = seqBits;
+            F.segOff = dFin; F.outOff = dFin + nqc; F.listW = dFin + 2 * (size_t) nqc; F.listS = dFin + 3 * (size_t) nqc; F.listB = dFin + 4 * (size_t) nqc;
+            F.listH = dFin + 5 * (size_t) nqc; F.hugeTmp = dFin + 6 * (size_t) nqc; F.blockSums = dFin + 7 * (size_t) nqc; F.totals = dNum;
+            hipLaunchKernelGGL(finish_sums_kernel, dim3(nb), dim3(FIN_SCAN), 0, stream, F);
+            hipLaunchKernelGGL(finish_offsets_kernel, dim3(nb), dim3(FIN_SCAN), 0, stream, F);
+            hipLaunchKernelGGL(finish_scatter_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, C, nCand, dKept, F, (uint32_t) (binCount - 1), dCursor, dCutKey, dOutKey);
             PCHK(hipGetLastError());
-            PCHK(hipcub::DeviceRadixSort::SortPairs(temp, t2, ob, ib, (int) nCand, 0, 64, stream));
-            hipLaunchKernelGGL(first_invalid_kernel, dim3(1), dim3(1), 0, stream, ob.Current(), nCand, dNum + 1);
-            // candidates of flagged queries, per query contiguous and in (target, arrival) order, for the host
-            hipcub::CountingInputIterator<uint32_t> iota(0);
-            size_t t3 = 0;
-            hipcub::DeviceSelect::Flagged(nullptr, t3, iota, dHostFlag, dFlagSel, dNum + 2, (int) nCand, stream);
-            void *temp2 = dev_scratch("pf_temp2", t3);
-            PNULL(temp2);
-            PCHK(hipcub::DeviceSelect::Flagged(temp2, t3, iota, dHostFlag, dFlagSel, dNum + 2, (int) nCand, stream));
             te(th);
-            PCHK(hipMemcpyAsync(hNum, dNum, 12, hipMemcpyDeviceToHost, stream));
+            PCHK(hipMemcpyAsync(hNum, dNum, 40, hipMemcpyDeviceToHost, stream));
             uint32_t *hPerQ = (uint32_t *) pinned_scratch("pf_perq_h", (size_t) nqc * 8);
             PNULL(hPerQ);
             PCHK(hipMemcpyAsync(hPerQ, dPerQ, (size_t) nqc * 8, hipMemcpyDeviceToHost, stream));
             const uint32_t *hPerQ255 = hPerQ + nqc;
             // hits of a query in the device-final array: all survivors, or exactly max-seqs of them; 0 when the host selects
-            const auto dev_count = [&](uint32_t ql) -> uint32_t { return hPerQ[ql] < (uint32_t) maxHits ? hPerQ[ql] : (hPerQ255[ql] >= (uint32_t) maxHits ? 0u : (uint32_t) maxHits); };
+            const auto dev_count = [&](uint32_t ql) -> uint32_t { return fin_to_host(hPerQ[ql], hPerQ255[ql], (uint32_t) maxHits) ? 0u : std::min(hPerQ[ql], (uint32_t) maxHits); };
             PCHK(sync_wait(stream, "wait_prefilter"));
-            const uint32_t nValid = hNum[1], nFlagged = hNum[2];
+            const uint32_t nValid = hNum[0], nFlagged = hNum[8];
             mk_hit *dHitsOut = nullptr;
             if (nValid > 0) {
                 dHitsOut = (mk_hit *) dev_scratch("pf_hits_out", (size_t) nValid * sizeof(mk_hit));
                 PNULL(dHitsOut);
-                hipLaunchKernelGGL(emit_kernel, dim3((nValid + 255) / 256), dim3(256), 0, stream, C, ib.Current(), nValid, dHitsOut);
+                th = tb("sort_query_hits", 28.0 * hNum[1], 0);
+                if (hNum[2]) hipLaunchKernelGGL(finish_wave_kernel, dim3((hNum[2] + 3) / 4), dim3(256), 0, stream, F, hNum[2], dCutKey, dOutKey, dHitsOut);
+                if (hNum[3]) hipLaunchKernelGGL((finish_block_kernel<64, FIN_SMALL_MAX>), dim3(hNum[3]), dim3(64), 0, stream, F, F.listS, dCutKey, dOutKey, (uint64_t *) nullptr, dHitsOut);
+                if (hNum[4]) hipLaunchKernelGGL((finish_block_kernel<256, FIN_LDS_MAX>), dim3(hNum[4]), dim3(256), 0, stream, F, F.listB, dCutKey, dOutKey, (uint64_t *) nullptr, dHitsOut);
+                if (hNum[5]) {
+                    uint64_t *dHuge = (uint64_t *) dev_scratch("pf_hugekeys", ((size_t) hNum[6] + 1) * 8);
+                    PNULL(dHuge);
+                    hipLaunchKernelGGL((finish_block_kernel<1024, FIN_HUGE_TILE>), dim3(hNum[5]), dim3(1024), 0, stream, F, F.listH, dCutKey, dOutKey, dHuge, dHitsOut);
+                }
+                te(th);
                 PCHK(hipGetLastError());
             }
             if (nFlagged == 0) {
@@ -1821,7 +1943,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                 HostCand *dHC = (HostCand *) dev_scratch("pf_hostcand", (size_t) nFlagged * sizeof(HostCand));
                 HostCand *hHC = (HostCand *) pinned_scratch("pf_hostcand_h", (size_t) nFlagged * sizeof(HostCand));
                 PNULL(dHC); PNULL(hHC);
-                hipLaunchKernelGGL(export_flagged_kernel, dim3((nFlagged + 255) / 256), dim3(256), 0, stream, C, dFlagSel, nFlagged, dHC);
+                hipLaunchKernelGGL(export_host_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, C, nCand, F, dHC);
                 PCHK(hipGetLastError());
                 PCHK(hipMemcpyAsync(hHC, dHC, (size_t) nFlagged * sizeof(HostCand), hipMemcpyDeviceToHost, stream));
                 PCHK(sync_wait(stream, "wait_prefilter"));

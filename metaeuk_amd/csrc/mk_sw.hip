@@ -224,8 +224,12 @@ __device__ __forceinline__ void sw_unit(const SwLaunch &L, const uint32_t unit, 
 
 // Shared-query mode is a persistent launch: a fixed number of one-wave workgroups per CU pull units from a counter, which
 // leaves wave slots, registers and LDS on every CU for the (memory-latency-bound) prefilter kernels of the other stream.
+#ifndef MK_HELPER_PRIO
+#define MK_HELPER_PRIO 3         // older waves win the CU's issue arbitration: short launches beside persistent workgroups ask for priority
+#endif
 template <int G, int R, int BLOCK, bool SHARED>
 __global__ __launch_bounds__(BLOCK) void sw_kernel(SwLaunch L) {
+    if (!SHARED && MK_HELPER_PRIO) __builtin_amdgcn_s_setprio(MK_HELPER_PRIO);       // position / reverse passes: short launches beside the prefilter's persistent waves
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     __shared__ int8_t sMat[448];
     for (int k = (int) threadIdx.x; k < 441; k += BLOCK) sMat[k] = L.mat[k];
