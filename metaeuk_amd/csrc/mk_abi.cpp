@@ -1505,8 +1505,17 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     hooks.stats = &q->pfStats;
     if (const char *e = getenv("MK_SEARCH_CHUNK_QUERIES")) hooks.max_chunk_queries = (uint32_t) std::max(1024L, atol(e));
     if (const char *e = getenv("MK_SEARCH_CHUNK_RAMP")) hooks.chunk_ramp = atoi(e) != 0;
+    // the last chunk is dealt out in pieces: its alignment is the tail of the pass and every worker takes a share of it
+    static const int tailPieces = getenv("MK_ALIGN_TAIL_PIECES") ? std::max(1, atoi(getenv("MK_ALIGN_TAIL_PIECES"))) : 1;
     hooks.on_chunk = [&](uint32_t a, uint32_t b) {
-        { std::lock_guard<std::mutex> lk(pipe.m); pipe.items.push_back(Item{pipe.pushed++, a, b}); }
+        {
+            std::lock_guard<std::mutex> lk(pipe.m);
+            const uint32_t pieces = (b == q->n && b - a >= 4096u) ? (uint32_t) tailPieces : 1u;
+            for (uint32_t k = 0; k < pieces; k++) {
+                const uint32_t lo = a + (uint32_t) ((uint64_t) (b - a) * k / pieces), hi = a + (uint32_t) ((uint64_t) (b - a) * (k + 1) / pieces);
+                if (hi > lo) pipe.items.push_back(Item{pipe.pushed++, lo, hi});
+            }
+        }
         pipe.cv.notify_all();
     };
     hooks.before_grow = [&]() {                                // the result block moves: nobody may be reading it

@@ -525,6 +525,12 @@ struct StreamArgs {
 #define MK_STREAM_MBITS_B 131072
 #define MK_STREAM_WG_B 2
 #endif
+#ifndef MK_STREAM_CAP_B
+#define MK_STREAM_CAP_B 65536      // hits of a query held by the largest tier, and its k-mer starts: beyond, the query takes the global path
+#endif
+#ifndef MK_STREAM_MAXPOS_B
+#define MK_STREAM_MAXPOS_B 2048
+#endif
 #ifndef MK_STREAM_PROF
 #define MK_STREAM_PROF 0        // 1: per-phase cycle counters in totals[10..15] (costs ~10 %)
 #endif
@@ -885,7 +891,7 @@ constexpr int N_TIERS = 4;
 // production tiers, then a miniature set (MK_PREFILTER_TIERS=tiny) with which small test inputs exercise every
 // workgroup shape, the overflow hand-over, the class passes and the global path
 const FusedTier TIERS[2 * N_TIERS] = {{2048, 1, 64, 28}, {4096, 1, 128, 24},
-                                      {8192, MK_STREAM_NW_A, 512, MK_STREAM_WG_A}, {65536, MK_STREAM_NW_B, 2048, MK_STREAM_WG_B},
+                                      {8192, MK_STREAM_NW_A, 512, MK_STREAM_WG_A}, {MK_STREAM_CAP_B, MK_STREAM_NW_B, MK_STREAM_MAXPOS_B, MK_STREAM_WG_B},
                                       {256, 1, 32, 8}, {512, 1, 64, 8}, {1024, 4, 64, 4}, {4096, 8, 256, 4}};
 
 //                                    region (hits)  LDS sort  bitmap bits  k-mer starts  waves  probe groups
@@ -894,7 +900,7 @@ void launch_stream(int tier, const StreamArgs &A, unsigned grid, hipStream_t str
         case 0: hipLaunchKernelGGL((stream_kernel<2048, 256, 8192, 64, 1, MK_STREAM_U>), dim3(grid), dim3(64), 0, stream, A); break;
         case 1: hipLaunchKernelGGL((stream_kernel<4096, 256, 8192, 128, 1, MK_STREAM_U>), dim3(grid), dim3(64), 0, stream, A); break;
         case 2: hipLaunchKernelGGL((stream_kernel<8192, MK_STREAM_SURV_A, MK_STREAM_MBITS_A, 512, MK_STREAM_NW_A, MK_STREAM_U>), dim3(grid), dim3(64 * MK_STREAM_NW_A), 0, stream, A); break;
-        case 3: hipLaunchKernelGGL((stream_kernel<65536, MK_STREAM_SURV_B, MK_STREAM_MBITS_B, 2048, MK_STREAM_NW_B, MK_STREAM_U>), dim3(grid), dim3(64 * MK_STREAM_NW_B), 0, stream, A); break;
+        case 3: hipLaunchKernelGGL((stream_kernel<MK_STREAM_CAP_B, MK_STREAM_SURV_B, MK_STREAM_MBITS_B, MK_STREAM_MAXPOS_B, MK_STREAM_NW_B, MK_STREAM_U>), dim3(grid), dim3(64 * MK_STREAM_NW_B), 0, stream, A); break;
         case 4: hipLaunchKernelGGL((stream_kernel<256, 64, 1024, 32, 1, 2>), dim3(grid), dim3(64), 0, stream, A); break;
         case 5: hipLaunchKernelGGL((stream_kernel<512, 64, 1024, 64, 1, 2>), dim3(grid), dim3(64), 0, stream, A); break;
         case 6: hipLaunchKernelGGL((stream_kernel<1024, 128, 2048, 64, 4, 2>), dim3(grid), dim3(256), 0, stream, A); break;

@@ -284,6 +284,43 @@ def test_saturated_score_threshold(gpu_api, tmp_path, pf_path, max_seqs):
         assert max(sum(1 for h in hits[int(hoff[i]):int(hoff[i + 1])] if int(h["pref_score"]) >= 255) for i in range(3)) >= 100
 
 
+@pytest.mark.parametrize("max_seqs", [300, 20000])
+def test_hit_lists_of_every_size_class(gpu_api, tmp_path, max_seqs):
+    """the per-query tail of the prefilter (mk_prefilter.hip finish_*: one wave up to 64 survivors (the other tests), one wave with LDS up to 512, a workgroup
+    in LDS up to 4096, a workgroup over HBM beyond -- one tile, and several tiles with merge levels in HBM): queries whose motif sits in 40 ...
+    13 000 targets, below the clamp value so that nothing is left to the host; with --max-seqs 300 every list but the first is cut in the
+    reference's (score, bin, arrival) order, with 20 000 none is"""
+    rng = random.Random(17)
+    targets, queries = [], []
+    for n_copies in (40, 300, 2000, 5000, 13000):
+        motif = "".join(rng.choice(AA) for _ in range(26))
+        for _ in range(n_copies):
+            m = "".join(rng.choice(AA) if rng.random() < 0.12 else c for c in motif)
+            targets.append(_rand_seq(rng, rng.randint(5, 40)) + m + _rand_seq(rng, rng.randint(5, 40)))
+        queries.append(_rand_seq(rng, 20) + motif + _rand_seq(rng, 25))
+    order = list(range(len(targets)))
+    rng.shuffle(order)
+    targets = [targets[i] for i in order]
+    api = gpu_api
+    params = api.default_params()
+    params.max_seqs = max_seqs
+    db = api.TargetDB(targets, params)
+    q = api.Queries(queries, params)
+    api.kernel_stats(reset=True)
+    hits, hoff = api.prefilter(db, q, params)
+    alns, aoff = api.align(db, q, params)
+    opref, oaln = oracle.run_pipeline(targets, queries, str(tmp_path), extra=["--l2", str(params.host_l2_bytes), "--max-seqs", str(max_seqs)])
+    sizes = [int(hoff[i + 1] - hoff[i]) for i in range(len(queries))]
+    for i in range(len(queries)):
+        assert api.format_hits(hits, int(hoff[i]), int(hoff[i + 1])) == opref[i], ("pref", i, sizes)
+        assert api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1])) == oaln[i], ("aln", i)
+    assert "host_prefilter_maxseqs" not in api.kernel_stats(), "every list should be finished on the device"
+    if max_seqs == 300:
+        assert sizes[0] < 300 and sizes[1:] == [300] * 4, sizes
+    else:
+        assert 64 < sizes[0] < sizes[1] <= 512 < sizes[2] <= 4096 < sizes[3] <= 8192 < sizes[4], sizes
+
+
 _ORACLE_CACHE = {}
 
 
