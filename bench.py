@@ -351,7 +351,7 @@ def main():
             args.contigs, nq, int(q_off[-1]), args.targets, int(t_off[-1])), "parallelism": "query-shard x%d" % world,
             "seed": args.seed},
         "gcups_sw": gcups_total,
-        "gcups_sw_kernel_only": (cells_sw / max(sw_ms * 1e-3, 1e-12) / 1e9) if sw_ms else None,
+        "gcups_sw_kernel_only": (cells_sw / max(sw_ms * 1e-3, 1e-12) / 1e9) if sw_ms else None,      # (kernel durations summed: overlapping launches count twice)
         "prefilter_hits": nhits, "alignments_passed": npass,
         "setup_s": {"generate": round(t_gen, 2), "target_index_build_upload": round(t_index, 2), "target_from_index_db": bool(args.target_index)},
         "host": {"threads": int(api.lib().mk_host_threads()) if not os.environ.get("OMP_NUM_THREADS") else int(os.environ["OMP_NUM_THREADS"]),
@@ -368,10 +368,13 @@ def main():
                              "(~5 TB/s when they run alone); the Smith-Waterman kernels are vector-ALU bound (valu_roofline)"},
         # the Smith-Waterman kernels against the integer vector-ALU issue rate: the cell arithmetic alone (5 lane-ops per cell in the packed
         # score pass, 10 in the int32 passes), not counting the wavefront's hand-over instructions, padding rows or fill / drain steps
-        "valu_roofline": {"kernels": "sw_fwd_* + sw_pos_* + sw_rev_*", "achieved": (sw_lane_ops / max(sw_ms * 1e-3, 1e-12) / 1e12) if sw_ms else None,
+        # (denominator: the wall clock of the timed region -- the kernels of the two alignment workers overlap each other and the prefilter's,
+        # so the sum of their own durations counts the same seconds more than once)
+        "valu_roofline": {"kernels": "sw_fwd_* + sw_pos_* + sw_rev_*", "achieved": (sw_lane_ops / max(elapsed, 1e-12) / 1e12) if sw_ms else None,
                           "peak": VALU_PEAK_TOPS, "unit": "Tlane-op/s",
-                          "frac": (sw_lane_ops / max(sw_ms * 1e-3, 1e-12) / 1e12 / VALU_PEAK_TOPS) if sw_ms else None,
-                          "note": "peak = one integer / packed-int16 wave-instruction per 4 cycles per SIMD (measured, profiles/r02_valu_issue_rates.txt)"},
+                          "frac": (sw_lane_ops / max(elapsed, 1e-12) / 1e12 / VALU_PEAK_TOPS) if sw_ms else None,
+                          "note": "lane-ops of the DP cells per second of the whole step (the prefilter shares the GPU); peak = one integer / packed-int16 "
+                                  "wave-instruction per 4 cycles per SIMD (measured, profiles/r02_valu_issue_rates.txt)"},
     }
     if rank == 0 and world == 1 and args.config4_profiles > 0:
         # BASELINE config 4 (profile targets: the reference's inverted search -- profiles as queries, the fragments as the indexed side,

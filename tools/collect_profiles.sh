@@ -2,9 +2,9 @@
 # Round evidence on a GPU box: the default bench line, rocprofv3 kernel statistics of the same command, the HBM traffic artefact
 # (tools/pmc_traffic.sh), SQ counters, the two-stage timeline and the host-thread sensitivity.  Writes under gpurun_out/evidence/ ; copy
 # the files to be judged into profiles/.
-#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r02'
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r03'
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/evidence
 mkdir -p $OUT
@@ -24,7 +24,7 @@ out = "$OUT"
 f = sorted(glob.glob(out + "/prof_stats/**/*kernel_stats.csv", recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 with open(out + "/${TAG}_bench_kernel_stats.txt", "w") as w:
-    w.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-sample 0 --config4-profiles 0   (3 passes: warm-up + 2 steps, 16 chunks each)\n")
+    w.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-sample 0 --config4-profiles 0   (3 passes: warm-up + 2 steps, 10 chunks each)\n")
     w.write("%-96s %8s %12s %10s %7s\n" % ("kernel", "calls", "total_ms", "avg_ms", "pct"))
     for r in rows[:56]:
         w.write("%-96s %8d %12.2f %10.3f %7.2f\n" % (r["Name"].replace("(anonymous namespace)::", "")[:96], int(r["Calls"]), float(r["TotalDurationNs"]) / 1e6,
