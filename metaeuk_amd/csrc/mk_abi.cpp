@@ -1426,7 +1426,10 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     if ((rc = check_indexed(db, "mk_search")) != MK_OK) return rc;
     if ((rc = check_roles(db, q)) != MK_OK) return rc;
     if ((rc = match_kmer_size(db, q)) != MK_OK) return rc;
-    if (q->isProfile) {          // profile queries: the two stages back to back (their kernels are not tuned to share the GPU)
+    static const int profilePipe = getenv("MK_SEARCH_PROFILE_PIPELINE") ? atoi(getenv("MK_SEARCH_PROFILE_PIPELINE")) : 1;
+    // profile queries (the inverted search of BASELINE config 4) take the pipeline too since round 3: 1.34 -> 1.20 s per config-4 pass
+    // (MK_SEARCH_PROFILE_PIPELINE=0: the two stages back to back)
+    if (q->isProfile && !profilePipe) {
         if ((rc = mk_prefilter(db, q, P)) != MK_OK) return rc;
         return mk_align(db, q, P);
     }
@@ -1503,6 +1506,7 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     hooks.t_masked_host = [db]() { return masked_host(db); };
     q->pfStats = mk::PrefilterStats();
     hooks.stats = &q->pfStats;
+    if (q->isProfile) hooks.max_chunk_queries = (uint32_t) std::max(64, getenv("MK_SEARCH_PROFILE_CHUNK") ? atoi(getenv("MK_SEARCH_PROFILE_CHUNK")) : 8192);
     if (const char *e = getenv("MK_SEARCH_CHUNK_QUERIES")) hooks.max_chunk_queries = (uint32_t) std::max(1024L, atol(e));
     if (const char *e = getenv("MK_SEARCH_CHUNK_RAMP")) hooks.chunk_ramp = atoi(e) != 0;
     // the last chunk is dealt out in pieces: its alignment is the tail of the pass and every worker takes a share of it
