@@ -63,6 +63,21 @@ constexpr int N3 = 8000;
 #endif
 __device__ __forceinline__ void helper_prio() { if (MK_HELPER_PRIO) __builtin_amdgcn_s_setprio(MK_HELPER_PRIO); }
 
+// The lanes of a wave that hold the same key act as one group: fn(mask of the group, its first lane) runs in every member.  The candidates
+// of a query are neighbours, so a per-query counter sees one atomic per wave instead of 64 (which the L2 would serialise).
+template <typename F>
+__device__ __forceinline__ void wave_grouped(bool active, uint32_t key, F &&fn) {
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((long long) todo) - 1;
+        const uint32_t k = (uint32_t) __shfl((int) key, leader, 64);
+        const bool mine = active && key == k;
+        const unsigned long long grp = __ballot(mine);
+        if (mine) { fn(grp, leader); active = false; }
+        todo &= ~grp;
+    }
+}
+
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
     uint32_t x = v;
 #pragma unroll
@@ -935,26 +950,32 @@ __global__ __launch_bounds__(256) void keep_kernel(CandArrays C, uint32_t n, int
                                                    uint32_t *perQuery255 /* survivors at the clamp value 255 | flags: the host finishes the query (P255_*) */) {
     helper_prio();
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
-    const uint32_t q = C.q[c], id = C.id[c];
-    const int s = min(C.score[c], 255);
-    bool keep = s >= minDiag;
-    for (uint32_t u = c; keep && u > 0; ) {            // earlier candidates of the run: none may reach s
-        u--;
-        if (C.q[u] != q || C.id[u] != id) break;
-        if (min(C.score[u], 255) >= s) keep = false;
+    const int lane = (int) (threadIdx.x & 63u);
+    uint32_t q = 0;
+    int s = 0;
+    bool keep = false;
+    if (c < n) {
+        q = C.q[c];
+        const uint32_t id = C.id[c];
+        s = min(C.score[c], 255);
+        keep = s >= minDiag;
+        for (uint32_t u = c; keep && u > 0; ) {            // earlier candidates of the run: none may reach s
+            u--;
+            if (C.q[u] != q || C.id[u] != id) break;
+            if (min(C.score[u], 255) >= s) keep = false;
+        }
+        for (uint32_t u = c + 1; keep && u < n; u++) {    // later candidates: none may exceed s
+            if (C.q[u] != q || C.id[u] != id) break;
+            if (min(C.score[u], 255) > s) keep = false;
+        }
+        kept[c] = keep ? 1 : 0;
+        if (keep) {
+            if (hostCut || C.ordinal[c] >= (1u << 26)) atomicOr(&perQuery255[q], 1u << 30);       // P255_HOST_IF_CUT: does not fit the cut key below
+            if ((uint32_t) C.score[c] > scoreMax) atomicOr(&perQuery255[q], 1u << 31);             // P255_HOST: does not fit the report key
+        }
     }
-    for (uint32_t u = c + 1; keep && u < n; u++) {    // later candidates: none may exceed s
-        if (C.q[u] != q || C.id[u] != id) break;
-        if (min(C.score[u], 255) > s) keep = false;
-    }
-    kept[c] = keep ? 1 : 0;
-    if (keep) {
-        atomicAdd(&perQuery[q], 1u);
-        if (s == 255) atomicAdd(&perQuery255[q], 1u);
-        if (hostCut || C.ordinal[c] >= (1u << 26)) atomicOr(&perQuery255[q], 1u << 30);       // P255_HOST_IF_CUT: does not fit the cut key below
-        if ((uint32_t) C.score[c] > scoreMax) atomicOr(&perQuery255[q], 1u << 31);             // P255_HOST: does not fit the report key
-    }
+    wave_grouped(keep, q, [&](unsigned long long grp, int leader) { if (lane == leader) atomicAdd(&perQuery[q], (uint32_t) __popcll(grp)); });
+    wave_grouped(keep && s == 255, q, [&](unsigned long long grp, int leader) { if (lane == leader) atomicAdd(&perQuery255[q], (uint32_t) __popcll(grp)); });
 }
 
 // ---- the tail of QueryMatcher::matchQuery per query (QueryMatcher.cpp:149-209 + getResult :117-125), without a device-wide sort
@@ -1039,16 +1060,25 @@ __global__ __launch_bounds__(256) void finish_scatter_kernel(CandArrays C, uint3
                                                              uint64_t *cutKey, uint64_t *outKey) {
     helper_prio();
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    bool host = false;
+    const int lane = (int) (threadIdx.x & 63u);
+    bool host = false, put = false;
+    uint32_t qv = 0, nQv = 0;
     if (c < n) {
         const uint32_t q = C.q[c], nQ = F.perQ[q];
+        qv = q; nQv = nQ;
         if (nQ != 0 && fin_to_host(nQ, F.perQ255[q], F.maxHits)) host = true;
-        else if (kept[c]) {
-            const uint32_t pos = F.segOff[q] + atomicAdd(&cursor[q], 1u);
-            const uint32_t score = (uint32_t) C.score[c], id = C.id[c];
-            outKey[pos] = ((uint64_t) (fin_score_max(F.seqBits) - score) << (16u + F.seqBits)) | ((uint64_t) id << 16) | (uint64_t) C.diag[c];
-            if (nQ >= F.maxHits) cutKey[pos] = ((uint64_t) (255u - min(score, 255u)) << 36) | ((uint64_t) (id & binMask) << 26) | (uint64_t) C.ordinal[c];
-        }
+        else put = kept[c] != 0;
+    }
+    uint32_t pos = 0;
+    wave_grouped(put, qv, [&](unsigned long long grp, int leader) {
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&cursor[qv], (uint32_t) __popcll(grp));
+        pos = F.segOff[qv] + (uint32_t) __shfl((int) base, leader, 64) + (uint32_t) __popcll(grp & ((1ull << lane) - 1ull));
+    });
+    if (put) {
+        const uint32_t score = (uint32_t) C.score[c], id = C.id[c];
+        outKey[pos] = ((uint64_t) (fin_score_max(F.seqBits) - score) << (16u + F.seqBits)) | ((uint64_t) id << 16) | (uint64_t) C.diag[c];
+        if (nQv >= F.maxHits) cutKey[pos] = ((uint64_t) (255u - min(score, 255u)) << 36) | ((uint64_t) (id & binMask) << 26) | (uint64_t) C.ordinal[c];
     }
     const unsigned long long m = __ballot(host);
     if (m != 0 && (threadIdx.x & 63u) == (uint32_t) (__ffsll((long long) m) - 1)) atomicAdd(&F.totals[8], (uint32_t) __popcll(m));
