@@ -1312,7 +1312,11 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
             const int qBitsLeft = 64 - 8 - (int) X.seqBits - std::min(X.lastHitBits + 1, 31);
             // ... and what keeps the sorted (query, target) bits at a whole number of 8-bit radix passes, pieces of >= 8192 queries
             const int qBitsPass = (((int) X.seqBits + 13 + 7) / 8) * 8 - (int) X.seqBits;
-            static const bool wholeSort = getenv("MK_PREFILTER_SEGSORT") && atoi(getenv("MK_PREFILTER_SEGSORT")) == 0;   // (only matters for the one-sort variant)
+            // one sort per query (segmented, target bits only) or one over the piece's (query, target) bits: measured both ways
+            // (profiles/r03_experiments.txt) -- against 10^5 .. 2*10^6 targets the segmented sort is 2 x faster (configs 2 and 4), against
+            // 1.2*10^7 (config-5 scale: 2*10^5 hits per query, 24 target bits) the whole-piece sort is 1.7 x faster.  MK_PREFILTER_SEGSORT=0/1 forces.
+            static const int sortEnv = getenv("MK_PREFILTER_SEGSORT") ? atoi(getenv("MK_PREFILTER_SEGSORT")) : -1;
+            const bool wholeSort = sortEnv >= 0 ? sortEnv == 0 : X.seqBits >= 23;
             const int qBitsCap = wholeSort ? std::min(qBitsLeft, qBitsPass) : qBitsLeft;
             const uint32_t qCap = qBitsCap >= 20 ? QCAP : (qBitsCap < 1 ? 1u : (1u << qBitsCap));
             while (q1 < b && q1 - q0 < qCap && (hOff[q1 + 1] - hOff[q0] <= posBudget || q1 == q0)) q1++;
@@ -1485,7 +1489,8 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
             // sort by (query, target): only those bits are sorted, the records of a pair stay in arrival order.  The gather pass wrote the
             // records query by query, so the sort is per query over the target bits alone (segments of ~20 K records stay in L2)
             hipcub::DoubleBuffer<uint64_t> kb(dKeys, dKeys2);
-            static const bool segSort = !getenv("MK_PREFILTER_SEGSORT") || atoi(getenv("MK_PREFILTER_SEGSORT")) != 0;
+            static const int sortEnv2 = getenv("MK_PREFILTER_SEGSORT") ? atoi(getenv("MK_PREFILTER_SEGSORT")) : -1;
+            const bool segSort = sortEnv2 >= 0 ? sortEnv2 != 0 : X.seqBits < 23;
             void *temp = nullptr;
             if (segSort) {
                 const uint32_t nqc = q1 - q0;
