@@ -1479,7 +1479,9 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
                 std::unique_lock<std::mutex> lk(pipe.m);
                 pipe.cv.wait(lk, [&] { return pipe.turn == it.seq; });
             };
-            if (pipe.rc == MK_OK) {
+            bool healthy;
+            { std::lock_guard<std::mutex> lk(pipe.m); healthy = pipe.rc == MK_OK; }
+            if (healthy) {
                 HostTimer ht("host_align_total");
                 r = align_range(db, q, P, it.q0, it.q1, *gatep, tablesp, g_alignStreams[w], nAln, wait_turn);
             }
