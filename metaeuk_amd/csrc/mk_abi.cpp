@@ -337,9 +337,9 @@ const char *mk_last_error(void) { return g_err.c_str(); }
 int mk_host_threads(void) { return effective_cpus(); }
 
 int mk_init(int device) {
-    if (!getenv("OMP_NUM_THREADS")) {
+    if (!mk::launcher_env("OMP_NUM_THREADS")) {
         int share = 1;                                      // one process per GPU: the ranks of a node split its cores
-        if (const char *lw = getenv("LOCAL_WORLD_SIZE")) share = std::max(1, atoi(lw));
+        if (const char *lw = mk::launcher_env("LOCAL_WORLD_SIZE")) share = std::max(1, atoi(lw));
         omp_set_num_threads(std::max(1, effective_cpus() / share));
     }
     kmp_set_blocktime(0);                                   // idle team threads sleep: two stages share the host cores in mk_search
@@ -352,7 +352,7 @@ int mk_init(int device) {
         // two streams for the two stages of mk_search; MK_STREAM_PRIORITY=1: the prefilter's (latency-bound, few instructions) ahead
         // of the alignment's in the dispatcher
         int least = 0, greatest = 0;
-        const char *pr = getenv("MK_STREAM_PRIORITY");
+        const char *pr = mk::knob("MK_STREAM_PRIORITY");
         const bool prio = pr && atoi(pr) != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
         if (!g_stream) HIPCHK(prio ? hipStreamCreateWithPriority(&g_stream, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
         if (!g_stream2) HIPCHK(prio ? hipStreamCreateWithPriority(&g_stream2, hipStreamNonBlocking, least) : hipStreamCreateWithFlags(&g_stream2, hipStreamNonBlocking));
@@ -454,7 +454,7 @@ static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uin
     for (int sc = 0; sc < 32768; sc++) db->bitScoreTable[sc] = static_cast<int>(db->evaluer.bitScore((double) sc) + 0.5);
     // test hook: shift every list start by this many entries (and the device pointer back by as many), so that the slots' 40-bit starts
     // are exercised beyond 2^32 without a database of that size
-    const uint64_t entryShift = getenv("MK_TEST_ENTRY_BASE") ? strtoull(getenv("MK_TEST_ENTRY_BASE"), nullptr, 10) : 0;
+    const uint64_t entryShift = mk::knob("MK_TEST_ENTRY_BASE") ? strtoull(mk::knob("MK_TEST_ENTRY_BASE"), nullptr, 10) : 0;
     if (entryShift >= (1ull << 39)) { delete db; return fail(MK_ERR_ARG, "MK_TEST_ENTRY_BASE too large"); }
     db->entryShift = entryShift;
     hipError_t e = hipSuccess;
@@ -476,7 +476,7 @@ static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uin
         return MK_OK;
     }
     // MK_INDEX_BUILD=host: mask and index on the host (mk::build_index, the reference of the device builder)
-    const char *ib = getenv("MK_INDEX_BUILD");
+    const char *ib = mk::knob("MK_INDEX_BUILD");
     const bool hostBuild = !prebuilt && ib && strcmp(ib, "host") == 0;
     if ((prebuilt && prebuilt->host) || hostBuild) {
         mk::TargetIndex built;
@@ -606,7 +606,7 @@ int mk_index_write(const char *indexDb, const char *seqData, uint64_t seqDataSiz
     c.meta.kmerSize = kmerSize;
     c.meta.kmerThr = kmerSize == 7 ? mk::kmer_threshold_k7(P->sensitivity, P->kmer_score) : mk::kmer_threshold(P->sensitivity, P->kmer_score);
     c.meta.mask = P->mask != 0; c.meta.compBiasCorr = P->comp_bias_corr != 0; c.meta.seqType = seqDbtype; c.meta.srcSeqType = seqDbtype;
-    const char *ib = getenv("MK_INDEX_BUILD");
+    const char *ib = mk::knob("MK_INDEX_BUILD");
     if (!g_ready || (ib && strcmp(ib, "host") == 0)) {
         mk::build_index(km, res.data(), c.seqOffsets.data(), n, c.meta.kmerThr, P->mask != 0, P->mask_prob, P->simd_lanes_double, c.index, false, kmerSize);
         const std::string e = mk::write_index_file(indexDb, km, c);
@@ -1308,7 +1308,7 @@ static int align_range(mk_targetdb *db, mk_queries *q, const mk_params *P, uint3
     // the float/double tail of getSWResult, the criteria and the per-query order run on the device; the host path below only
     // serves a range in which a score lies beyond the e-value table
     mk::AssembleArgs asmArgs;
-    static const bool hostAssemble = getenv("MK_ALIGN_HOST_ASSEMBLE") && atoi(getenv("MK_ALIGN_HOST_ASSEMBLE")) != 0;
+    static const bool hostAssemble = mk::knob_long("MK_ALIGN_HOST_ASSEMBLE", 0) != 0;
     asmArgs.tables = hostAssemble ? nullptr : tables;
     asmArgs.dSortKey = db->dKeys.p;
     asmArgs.counts = (uint32_t *) mk::pinned_scratch(stream == g_stream2 ? "asm_counts_h2" : "asm_counts_h", std::max<size_t>(nqc, 1) * 4);
@@ -1426,7 +1426,7 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     if ((rc = check_indexed(db, "mk_search")) != MK_OK) return rc;
     if ((rc = check_roles(db, q)) != MK_OK) return rc;
     if ((rc = match_kmer_size(db, q)) != MK_OK) return rc;
-    static const int profilePipe = getenv("MK_SEARCH_PROFILE_PIPELINE") ? atoi(getenv("MK_SEARCH_PROFILE_PIPELINE")) : 1;
+    static const int profilePipe = (int) mk::knob_long("MK_SEARCH_PROFILE_PIPELINE", 1);
     // profile queries (the inverted search of BASELINE config 4) take the pipeline too since round 3: 1.34 -> 1.20 s per config-4 pass
     // (MK_SEARCH_PROFILE_PIPELINE=0: the two stages back to back)
     if (q->isProfile && !profilePipe) {
@@ -1453,7 +1453,7 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     // the alignment stage: MK_ALIGN_WORKERS host threads, each with a stream and scratch buffers of its own, take the chunks in turn --
     // the position and reverse passes of one chunk (short launches, slow beside persistent workgroups) then run beside the
     // forward pass of the next one instead of in front of it.  Results are appended in chunk order.
-    static const int nWorkers = std::min(MAX_ALIGN_WORKERS, std::max(1, getenv("MK_ALIGN_WORKERS") ? atoi(getenv("MK_ALIGN_WORKERS")) : 2));
+    static const int nWorkers = std::min(MAX_ALIGN_WORKERS, std::max(1, (int) mk::knob_long("MK_ALIGN_WORKERS", 2)));
     const int half = std::max(1, hostThreads / (1 + nWorkers));
     {   // the per-length score tables of the batch (cached per database and query lengths)
         HostTimer ht("host_gate_table");
@@ -1508,11 +1508,11 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     hooks.t_masked_host = [db]() { return masked_host(db); };
     q->pfStats = mk::PrefilterStats();
     hooks.stats = &q->pfStats;
-    if (q->isProfile) hooks.max_chunk_queries = (uint32_t) std::max(64, getenv("MK_SEARCH_PROFILE_CHUNK") ? atoi(getenv("MK_SEARCH_PROFILE_CHUNK")) : 8192);
-    if (const char *e = getenv("MK_SEARCH_CHUNK_QUERIES")) hooks.max_chunk_queries = (uint32_t) std::max(1024L, atol(e));
-    if (const char *e = getenv("MK_SEARCH_CHUNK_RAMP")) hooks.chunk_ramp = atoi(e) != 0;
+    if (q->isProfile) hooks.max_chunk_queries = (uint32_t) std::max(64L, mk::knob_long("MK_SEARCH_PROFILE_CHUNK", 8192));
+    if (const char *e = mk::knob("MK_SEARCH_CHUNK_QUERIES")) hooks.max_chunk_queries = (uint32_t) std::max(1024L, atol(e));
+    if (const char *e = mk::knob("MK_SEARCH_CHUNK_RAMP")) hooks.chunk_ramp = atoi(e) != 0;
     // the last chunk is dealt out in pieces: its alignment is the tail of the pass and every worker takes a share of it
-    static const int tailPieces = getenv("MK_ALIGN_TAIL_PIECES") ? std::max(1, atoi(getenv("MK_ALIGN_TAIL_PIECES"))) : 1;
+    static const int tailPieces = (int) std::max(1L, mk::knob_long("MK_ALIGN_TAIL_PIECES", 1));
     hooks.on_chunk = [&](uint32_t a, uint32_t b) {
         {
             std::lock_guard<std::mutex> lk(pipe.m);

@@ -1,20 +1,24 @@
 // metaeuk_amd/csrc/mk_align.hip -- the alignment stage as a device-resident pipeline.
 // Per batch (or per prefilter chunk, under mk_search): the prefilter hits go up once (12 B per pair) and only the accepted
 // pairs' integers come back (24 B each).
-//   expand_pairs_kernel      pair -> query (binary search in the per-query offsets), forward SwJob + 64-bit sort key
-//                            (tile configuration, query, target length descending)
-//   hipcub radix sort        the jobs of a query become adjacent and similar in length
-//   seg_mark / max-scan / wave_flag / select   cut every (configuration, query) segment into waves of jobs that share ONE
-//                            LDS query profile
-//   swp_kernel / sw_kernel   score pass (mk_sw.hip): packed int16, two targets per lane group, for tiles <= 256 rows;
+//   expand_pairs_kernel      pair -> query (binary search in the per-query offsets), forward SwJob
+//   job order (round 4: no device-wide radix sort)
+//                            the score pass wants the jobs grouped by (tile configuration, query) with the targets of a query by falling
+//                            length.  The pairs of a query are neighbours already, so: a scan over the QUERIES per tile configuration
+//                            (plan_sums / plan_offsets: first job and first wave of every query) and a sort of every query's own pairs
+//                            by target length -- one wave up to 64 pairs, a workgroup in LDS / over HBM beyond (order_wave / order_block,
+//                            mk_segsort.hpp).  The wave list falls out of the same scan: a wave = the next 64/G (x2 packed) jobs of one query.
+//   swp_kernel / sw_kernel   score pass (mk_sw.hip): packed int16, two targets per lane group, for tiles <= 768 rows;
 //                            persistent launch (a fixed number of one-wave workgroups per CU pull waves from a counter)
-//   gate_kernel              e-value gate on the score (table per query length) -> position jobs for the ~9 % survivors
+//   gate_count / gate_emit   e-value gate on the score (table per query length) -> position jobs for the ~9 % survivors, numbered in
+//                            pair order (block counts + scan: the collected records need no sort afterwards)
+//   bin_scan / bin_scatter   position and reverse jobs by (tile configuration, target length class): a counting sort over 11 x 4096 bins
 //   sw_kernel                position pass (end cell of the maximum), then rev_jobs_kernel + reverse pass on the reversed
 //                            prefixes (start cell)
 //   collect_kernel           AlnRaw records in pair order
 #include "mk_align.hpp"
 #include "mk_kernels.hpp"
-#include <hipcub/hipcub.hpp>
+#include "mk_segsort.hpp"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -28,130 +32,251 @@ namespace mk {
 
 namespace {
 
-constexpr uint32_t KEY_CLS = 4096;
-static_assert(SW_NCFG <= 16, "job sort keys keep 4 bits for the tile configuration");
+constexpr uint32_t KEY_CLS = 4096;                    // target-length classes (16 residues each), falling length = ascending class
+constexpr uint32_t N_BINS = (uint32_t) SW_NCFG * KEY_CLS;
+static_assert(SW_NCFG <= 16, "the bounds arrays keep 16 slots per kind");
 
-__device__ __forceinline__ uint32_t sort_key(uint32_t qLen, uint32_t tLen) {
-    return (uint32_t) sw_cfg_of(qLen) * KEY_CLS + (KEY_CLS - 1 - min(tLen >> 4, KEY_CLS - 1));
-}
+__device__ __forceinline__ uint32_t len_class(uint32_t tLen) { return KEY_CLS - 1 - min(tLen >> 4, KEY_CLS - 1); }
+__device__ __forceinline__ uint32_t sort_key(uint32_t qLen, uint32_t tLen) { return (uint32_t) sw_cfg_of(qLen) * KEY_CLS + len_class(tLen); }
 
-// forward jobs are ordered by (tile configuration, query, target length descending): the DPs of a wave share their query
-// (one LDS profile per wave) and have similar numbers of columns
+// short launches of this stage run beside the persistent workgroups of the prefilter (mk_search): they ask for issue priority
+__device__ __forceinline__ void helper_prio() { __builtin_amdgcn_s_setprio(3); }
+
+// pair -> forward job (the query of pair p is the one whose hit range holds p)
 __global__ __launch_bounds__(256) void expand_pairs_kernel(AlignView V, const uint64_t *hitOff, const mk_hit *hits, uint64_t n,
-                                                           SwJob *jobs, uint64_t *keys, uint32_t *idx, uint32_t *badTarget,
+                                                           SwJob *jobs, uint32_t *badTarget,
                                                            unsigned long long *work /* [2 * cfg]: bytes, [2 * cfg + 1]: cells of the forward pass (statistics) */) {
+    helper_prio();
     __shared__ unsigned long long sWork[2 * SW_NCFG];
     for (int k = threadIdx.x; k < 2 * SW_NCFG; k += blockDim.x) sWork[k] = 0;
     __syncthreads();
     const uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (p < n) {
-        uint32_t lo = 0, hi = V.n_queries;
+        uint32_t lo = 0, hi = V.n_queries;              // largest q with hitOff[q] <= p
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (hitOff[mid] <= p) lo = mid; else hi = mid; }
-        const uint32_t t = hits[p].seq_id;
-        const uint32_t qLen = (uint32_t) (V.q_off[lo + 1] - V.q_off[lo]), tLen = t < V.n_targets ? (uint32_t) (V.t_off[t + 1] - V.t_off[t]) : 0u;
-        const int c = sw_cfg_of(qLen);
-        atomicAdd(&sWork[2 * c], (unsigned long long) (tLen + 2u * qLen + (uint32_t) (sizeof(SwJob) + sizeof(SwOut))));
-        atomicAdd(&sWork[2 * c + 1], (unsigned long long) qLen * tLen);
+        const uint32_t q = lo, t = hits[p].seq_id;
+        SwJob j;
+        j.q_start = (uint32_t) V.q_off[q]; j.q_len = (uint32_t) (V.q_off[q + 1] - V.q_off[q]);
+        if (t < V.n_targets) { j.t_start = V.t_off[t]; j.t_len = (uint32_t) (V.t_off[t + 1] - V.t_off[t]); }
+        else { j.t_start = 0; j.t_len = 0; atomicMax(badTarget, (uint32_t) p + 1u); }     // reported to the caller, nothing is aligned
+        j.q_step = 1; j.t_step = 1; j.slot = (uint32_t) p;
+        jobs[p] = j;
+        const int c = sw_cfg_of(j.q_len);
+        atomicAdd(&sWork[2 * c], (unsigned long long) (j.t_len + 2u * j.q_len + (uint32_t) (sizeof(SwJob) + sizeof(SwOut))));
+        atomicAdd(&sWork[2 * c + 1], (unsigned long long) j.q_len * j.t_len);
     }
     __syncthreads();
     for (int k = threadIdx.x; k < 2 * SW_NCFG; k += blockDim.x) if (sWork[k]) atomicAdd(&work[k], sWork[k]);
-    if (p >= n) return;
-    uint32_t lo = 0, hi = V.n_queries;              // largest q with hitOff[q] <= p
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (hitOff[mid] <= p) lo = mid; else hi = mid; }
-    const uint32_t q = lo, t = hits[p].seq_id;
-    SwJob j;
-    j.q_start = (uint32_t) V.q_off[q]; j.q_len = (uint32_t) (V.q_off[q + 1] - V.q_off[q]);
-    if (t < V.n_targets) { j.t_start = V.t_off[t]; j.t_len = (uint32_t) (V.t_off[t + 1] - V.t_off[t]); }
-    else { j.t_start = 0; j.t_len = 0; atomicMax(badTarget, (uint32_t) p + 1u); }     // reported to the caller, nothing is aligned
-    j.q_step = 1; j.t_step = 1; j.slot = (uint32_t) p;
-    jobs[p] = j;
-    keys[p] = ((uint64_t) sw_cfg_of(j.q_len) << 44) | ((uint64_t) q << 12) | (uint64_t) (KEY_CLS - 1 - min(j.t_len >> 4, KEY_CLS - 1));
-    idx[p] = (uint32_t) p;
 }
 
-// segment = run of jobs with the same (configuration, query); value = own index at a segment head, 0 elsewhere (max-scan -> head)
-__global__ __launch_bounds__(256) void seg_mark_kernel(const uint64_t *sortedKeys, uint32_t n, uint32_t *head) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    head[i] = (i > 0 && (sortedKeys[i] >> 12) != (sortedKeys[i - 1] >> 12)) ? i : 0u;
+// ---- the score pass's job order, per query -------------------------------------------------------------------------------------
+// jobs grouped by tile configuration, inside it by query (ascending), inside a query by falling target length: the DPs of a wave share
+// their query (one LDS profile per wave) and have similar numbers of columns.  The order inside a query is a matter of speed only --
+// every job writes to its own slot -- so a query with more pairs than an LDS tile holds is ordered run by run (ORDER_TILE pairs each).
+constexpr uint32_t ORDER_WAVE_MAX = 64, ORDER_TILE = 2048;
+constexpr int PLAN_NV = 2 * SW_NCFG + 1;              // per tile configuration: pairs, waves; runs of the queries beyond a wave
+constexpr uint32_t PLAN_BLOCK = 256;
+struct PlanArgs {
+    const uint64_t *hitOff; const uint64_t *q_off; uint32_t nq, nPairs; bool narrow;
+    uint32_t *jobOff, *waveOff;          // per query: its first job / first wave in the ordered lists
+    uint32_t *runQuery, *runIndex;       // one entry per run of ORDER_TILE pairs of the queries with more than ORDER_WAVE_MAX pairs
+    uint32_t *blockSums;                 // [blocks][PLAN_NV + 1]
+    uint32_t *bounds;                    // [0..SW_NCFG] job bounds, [16..16+SW_NCFG] wave bounds, [33] runs
+    uint32_t *waveStart;
+};
+__device__ __forceinline__ void plan_values(const PlanArgs &A, uint32_t q, uint32_t (&v)[PLAN_NV], int &cfg, uint32_t &n) {
+#pragma unroll
+    for (int k = 0; k < PLAN_NV; k++) v[k] = 0;
+    cfg = 0; n = 0;
+    if (q >= A.nq) return;
+    n = (uint32_t) (A.hitOff[q + 1] - A.hitOff[q]);
+    if (n == 0) return;
+    cfg = sw_cfg_of((uint32_t) (A.q_off[q + 1] - A.q_off[q]));
+    const uint32_t dpw = sw_cfg_jobs_per_wave(cfg, A.narrow);
+#pragma unroll
+    for (int c = 0; c < SW_NCFG; c++) if (c == cfg) { v[2 * c] = n; v[2 * c + 1] = (n + dpw - 1u) / dpw; }
+    v[2 * SW_NCFG] = n > ORDER_WAVE_MAX ? (n + ORDER_TILE - 1u) / ORDER_TILE : 0u;
 }
-// a wave starts at every (64/G)-th job of a segment
-__global__ __launch_bounds__(256) void wave_flag_kernel(const uint64_t *sortedKeys, const uint32_t *head, uint32_t n, uint8_t *flag, bool narrow) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int cfg = (int) (sortedKeys[i] >> 44);
-    const uint32_t dpw = sw_cfg_jobs_per_wave(cfg, narrow);        // packed score kernel: 2 per 16-lane group; else 64 / G
-    flag[i] = ((i - head[i]) % dpw) == 0 ? 1 : 0;
+__global__ __launch_bounds__(PLAN_BLOCK) void plan_sums_kernel(PlanArgs A) {
+    helper_prio();
+    __shared__ uint32_t sm[PLAN_NV * 16];
+    uint32_t v[PLAN_NV], excl[PLAN_NV], total[PLAN_NV], n;
+    int cfg;
+    plan_values(A, blockIdx.x * PLAN_BLOCK + threadIdx.x, v, cfg, n);
+    segsort::block_scan<PLAN_NV>(v, excl, total, sm);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < PLAN_NV; k++) A.blockSums[blockIdx.x * (PLAN_NV + 1) + k] = total[k];
 }
-// job and wave ranges of every configuration; closes the wave list with n
-__global__ void shared_bounds_kernel(const uint64_t *sortedKeys, uint32_t n, uint32_t *waveStart, const uint32_t *nWaves,
-                                     uint32_t *out /* [0..SW_NCFG] job bounds, [16..16+SW_NCFG] wave bounds, [32..] first target-length class */) {
-    const uint32_t c = threadIdx.x;
-    const uint32_t nw = nWaves[0];
-    if (c == 0) waveStart[nw] = n;
-    if (c > SW_NCFG) return;
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t) (sortedKeys[mid] >> 44) < c) lo = mid + 1; else hi = mid; }
-    out[c] = lo;
-    const uint32_t jb = lo;
-    if (c < SW_NCFG) out[32 + c] = jb < n ? (uint32_t) (sortedKeys[jb] & (KEY_CLS - 1)) : 0u;
-    lo = 0; hi = nw;                                                 // first wave starting at or after the job bound
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (waveStart[mid] < jb) lo = mid + 1; else hi = mid; }
-    out[16 + c] = lo;
-}
-
-// first index whose key >= c*KEY_CLS, for c = 0..SW_NCFG; plus the key at that index
-__global__ void bounds_kernel(const uint32_t *sortedKeys, uint32_t n, uint32_t *bounds /* SW_NCFG+1 */, uint32_t *firstKey /* SW_NCFG */) {
-    const uint32_t c = threadIdx.x;
-    if (c > SW_NCFG) return;
-    const uint32_t want = c * KEY_CLS;
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sortedKeys[mid] < want) lo = mid + 1; else hi = mid; }
-    bounds[c] = lo;
-    if (c < SW_NCFG) firstKey[c] = lo < n ? sortedKeys[lo] : 0;
-}
-
-// e-value gate on the forward score (table per query length); survivors get a position job (the same DP again, this time
-// with end-position tracking)
-__global__ __launch_bounds__(256) void gate_kernel(const SwJob *fwdJobs, const SwOut *fwdOut, uint64_t n, const GateEntry *gate,
-                                                   uint32_t *posCount, uint32_t *posPair, SwJob *posJobs, uint32_t *posKeys, uint32_t *posIdx, int32_t *posScore,
-                                                   unsigned long long *work /* [2 * cfg]: bytes, [2 * cfg + 1]: cells of the position pass (statistics) */) {
-    __shared__ unsigned long long sWork[2 * SW_NCFG];
-    for (int k = threadIdx.x; k < 2 * SW_NCFG; k += blockDim.x) sWork[k] = 0;
-    __syncthreads();
-    const uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    bool pass = false;
-    SwJob j;
-    if (p < n) {
-        const int score = fwdOut[p].score;
-        if (score > 0) {
-            j = fwdJobs[p];
-            const GateEntry g = gate[j.q_len];
-            pass = score >= g.s0;
-            if (!pass && score < 256) pass = (g.mask[score >> 5] >> (score & 31)) & 1u;
-            if (pass) {
-                const int c = sw_cfg_of(j.q_len);
-                atomicAdd(&sWork[2 * c], (unsigned long long) (j.t_len + 2u * j.q_len + (uint32_t) (sizeof(SwJob) + sizeof(SwOut))));
-                atomicAdd(&sWork[2 * c + 1], (unsigned long long) j.q_len * j.t_len);
-            }
+__global__ __launch_bounds__(PLAN_BLOCK) void plan_offsets_kernel(PlanArgs A) {
+    helper_prio();
+    __shared__ uint32_t sm[PLAN_NV * 16];
+    uint32_t v[PLAN_NV], w[PLAN_NV], excl[PLAN_NV], base[PLAN_NV], all[PLAN_NV], total[PLAN_NV], n;
+#pragma unroll
+    for (int k = 0; k < PLAN_NV; k++) { v[k] = 0; w[k] = 0; }
+    for (uint32_t b = threadIdx.x; b < gridDim.x; b += PLAN_BLOCK)
+#pragma unroll
+        for (int k = 0; k < PLAN_NV; k++) {
+            const uint32_t x = A.blockSums[b * (PLAN_NV + 1) + k];
+            if (b < blockIdx.x) v[k] += x;
+            w[k] += x;
         }
+    segsort::block_scan<PLAN_NV>(v, excl, base, sm);          // base = sums of the blocks before this one
+    segsort::block_scan<PLAN_NV>(w, excl, all, sm);           // all = sums of every block
+    const uint32_t q = blockIdx.x * PLAN_BLOCK + threadIdx.x;
+    int cfg;
+    plan_values(A, q, v, cfg, n);
+    segsort::block_scan<PLAN_NV>(v, excl, total, sm);
+    uint32_t jobBase = 0, waveBase = 0;                       // first job / wave of this query's tile configuration
+#pragma unroll
+    for (int c = 0; c < SW_NCFG; c++) if (c < cfg) { jobBase += all[2 * c]; waveBase += all[2 * c + 1]; }
+    if (q < A.nq) {
+        uint32_t jo = jobBase, wo = waveBase;
+#pragma unroll
+        for (int c = 0; c < SW_NCFG; c++) if (c == cfg) { jo += base[2 * c] + excl[2 * c]; wo += base[2 * c + 1] + excl[2 * c + 1]; }
+        A.jobOff[q] = jo; A.waveOff[q] = wo;
+        const uint32_t runs = v[2 * SW_NCFG], r0 = base[2 * SW_NCFG] + excl[2 * SW_NCFG];
+        for (uint32_t r = 0; r < runs; r++) { A.runQuery[r0 + r] = q; A.runIndex[r0 + r] = r; }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        uint32_t jb = 0, wb = 0;
+        for (int c = 0; c < SW_NCFG; c++) { A.bounds[c] = jb; A.bounds[16 + c] = wb; jb += all[2 * c]; wb += all[2 * c + 1]; }
+        A.bounds[SW_NCFG] = jb; A.bounds[16 + SW_NCFG] = wb; A.bounds[33] = all[2 * SW_NCFG];
+        A.waveStart[wb] = A.nPairs;                           // closes the wave list
+    }
+}
+struct OrderArgs {
+    const uint64_t *hitOff; const uint64_t *q_off; const mk_hit *hits; const uint64_t *t_off; uint32_t nq, nTargets; bool narrow;
+    const uint32_t *jobOff, *waveOff, *runQuery, *runIndex;
+    uint32_t *order, *waveStart;
+};
+__device__ __forceinline__ uint64_t order_key(const OrderArgs &A, uint64_t p) {
+    const uint32_t t = A.hits[p].seq_id;
+    const uint32_t tLen = t < A.nTargets ? (uint32_t) (A.t_off[t + 1] - A.t_off[t]) : 0u;
+    return ((uint64_t) len_class(tLen) << 32) | (uint64_t) (uint32_t) p;
+}
+// queries of at most 64 pairs: one wave each, ranks by counting
+__global__ __launch_bounds__(256) void order_wave_kernel(OrderArgs A) {
+    helper_prio();
+    const uint32_t q = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (q >= A.nq) return;
+    const uint64_t p0 = A.hitOff[q];
+    const uint32_t n = (uint32_t) (A.hitOff[q + 1] - p0);
+    if (n == 0 || n > ORDER_WAVE_MAX) return;
+    const uint64_t key = lane < n ? order_key(A, p0 + lane) : ~0ull;
+    const uint32_t r = segsort::wave_rank(key, n);
+    const uint32_t jo = A.jobOff[q];
+    if (lane < n) A.order[jo + r] = (uint32_t) (p0 + lane);
+    const uint32_t dpw = sw_cfg_jobs_per_wave(sw_cfg_of((uint32_t) (A.q_off[q + 1] - A.q_off[q])), A.narrow);
+    const uint32_t nW = (n + dpw - 1u) / dpw;
+    if (lane < nW) A.waveStart[A.waveOff[q] + lane] = jo + lane * dpw;
+}
+// larger queries: one workgroup per run of ORDER_TILE pairs, sorted in LDS
+__global__ __launch_bounds__(256) void order_block_kernel(OrderArgs A) {
+    helper_prio();
+    __shared__ uint64_t sK[ORDER_TILE];
+    const uint32_t q = A.runQuery[blockIdx.x], run = A.runIndex[blockIdx.x];
+    const uint64_t p0 = A.hitOff[q];
+    const uint32_t n = (uint32_t) (A.hitOff[q + 1] - p0);
+    const uint32_t b = run * ORDER_TILE, m = min(ORDER_TILE, n - b);
+    const uint32_t P = segsort::pow2_at_least(m);
+    for (uint32_t t = threadIdx.x; t < P; t += 256) sK[t] = t < m ? order_key(A, p0 + b + t) : ~0ull;
+    __syncthreads();
+    segsort::lds_sort<256>(sK, P);
+    const uint32_t jo = A.jobOff[q] + b;
+    for (uint32_t t = threadIdx.x; t < m; t += 256) A.order[jo + t] = (uint32_t) sK[t];
+    const uint32_t dpw = sw_cfg_jobs_per_wave(sw_cfg_of((uint32_t) (A.q_off[q + 1] - A.q_off[q])), A.narrow);   // (divides ORDER_TILE)
+    const uint32_t w0 = b / dpw, nW = (m + dpw - 1u) / dpw;
+    for (uint32_t w = threadIdx.x; w < nW; w += 256) A.waveStart[A.waveOff[q] + w0 + w] = jo + w * dpw;
+}
+static_assert(ORDER_TILE % 8 == 0, "a run holds whole waves");
+
+// ---- exclusive prefix sums of a uint32 array in two sweeps (1024 elements per workgroup) ----
+constexpr uint32_t SCAN_TILE = 1024;
+__global__ __launch_bounds__(256) void scan_sums_kernel(const uint32_t *in, uint32_t n, uint32_t *blockSums) {
+    helper_prio();
+    __shared__ uint32_t sm[16];
+    const uint32_t i0 = blockIdx.x * SCAN_TILE + threadIdx.x * 4u;
+    uint32_t v[1] = {0}, excl[1], total[1];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) if (i0 + k < n) v[0] += in[i0 + k];
+    segsort::block_scan<1>(v, excl, total, sm);
+    if (threadIdx.x == 0) blockSums[blockIdx.x] = total[0];
+}
+__global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t *in, uint32_t n, uint32_t *out, const uint32_t *blockSums, uint32_t *grandTotal) {
+    helper_prio();
+    __shared__ uint32_t sm[16];
+    uint32_t v[1] = {0}, excl[1], base[1], total[1];
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256) v[0] += blockSums[b];
+    segsort::block_scan<1>(v, excl, base, sm);
+    const uint32_t i0 = blockIdx.x * SCAN_TILE + threadIdx.x * 4u;
+    uint32_t x[4];
+    v[0] = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) { x[k] = i0 + k < n ? in[i0 + k] : 0u; v[0] += x[k]; }
+    segsort::block_scan<1>(v, excl, total, sm);
+    uint32_t run = base[0] + excl[0];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) { if (i0 + k < n) out[i0 + k] = run; run += x[k]; }
+    if (grandTotal && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *grandTotal = base[0] + total[0];
+}
+
+// ---- e-value gate on the forward score (table per query length); survivors get a position job (the same DP again, this time
+// with end-position tracking).  Two sweeps: survivors per 256-pair block, (scan), then every survivor takes its number in pair
+// order -- the records collected at the end are ordered by pair without a sort.
+__device__ __forceinline__ bool gate_pass(const SwJob *fwdJobs, const SwOut *fwdOut, uint64_t n, const GateEntry *gate, uint64_t p, SwJob &j) {
+    if (p >= n) return false;
+    const int score = fwdOut[p].score;
+    if (score <= 0) return false;
+    j = fwdJobs[p];
+    const GateEntry g = gate[j.q_len];
+    bool pass = score >= g.s0;
+    if (!pass && score < 256) pass = (g.mask[score >> 5] >> (score & 31)) & 1u;
+    return pass;
+}
+__global__ __launch_bounds__(256) void gate_count_kernel(const SwJob *fwdJobs, const SwOut *fwdOut, uint64_t n, const GateEntry *gate, uint32_t *blockCount) {
+    helper_prio();
+    SwJob j;
+    const int c = __syncthreads_count(gate_pass(fwdJobs, fwdOut, n, gate, (uint64_t) blockIdx.x * blockDim.x + threadIdx.x, j));
+    if (threadIdx.x == 0) blockCount[blockIdx.x] = (uint32_t) c;
+}
+__global__ __launch_bounds__(256) void gate_emit_kernel(const SwJob *fwdJobs, const SwOut *fwdOut, uint64_t n, const GateEntry *gate, const uint32_t *blockStart,
+                                                        uint32_t *posPair, SwJob *posJobs, uint32_t *posKeys, int32_t *posScore, uint32_t *hist,
+                                                        unsigned long long *work /* [2 * cfg]: bytes, [2 * cfg + 1]: cells of the position pass (statistics) */) {
+    helper_prio();
+    __shared__ unsigned long long sWork[2 * SW_NCFG];
+    __shared__ uint32_t sWave[4];
+    for (int k = threadIdx.x; k < 2 * SW_NCFG; k += blockDim.x) sWork[k] = 0;
+    const uint64_t p = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    SwJob j;
+    const bool pass = gate_pass(fwdJobs, fwdOut, n, gate, p, j);
+    const unsigned long long m = __ballot(pass);
+    if (lane == 0) sWave[w] = (uint32_t) __popcll(m);
+    __syncthreads();
+    if (pass) {
+        uint32_t r = blockStart[blockIdx.x] + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+        for (int k = 0; k < w; k++) r += sWave[k];
+        const int c = sw_cfg_of(j.q_len);
+        atomicAdd(&sWork[2 * c], (unsigned long long) (j.t_len + 2u * j.q_len + (uint32_t) (sizeof(SwJob) + sizeof(SwOut))));
+        atomicAdd(&sWork[2 * c + 1], (unsigned long long) j.q_len * j.t_len);
+        posPair[r] = (uint32_t) p;
+        posScore[r] = fwdOut[p].score;
+        j.slot = r;
+        posJobs[r] = j;
+        const uint32_t key = sort_key(j.q_len, j.t_len);
+        posKeys[r] = key;
+        atomicAdd(&hist[key], 1u);
     }
     __syncthreads();
     for (int k = threadIdx.x; k < 2 * SW_NCFG; k += blockDim.x) if (sWork[k]) atomicAdd(&work[k], sWork[k]);
-    if (!pass) return;
-    const uint32_t r = atomicAdd(posCount, 1u);
-    posPair[r] = (uint32_t) p;
-    posScore[r] = fwdOut[p].score;
-    j.slot = r;
-    posJobs[r] = j;
-    posKeys[r] = sort_key(j.q_len, j.t_len);
-    posIdx[r] = r;
 }
 
 // reverse jobs (reversed prefixes ending at the forward end cell) of the survivors; the position pass must reproduce the
 // score the gate saw
 __global__ __launch_bounds__(256) void rev_jobs_kernel(const SwJob *posJobs, const SwOut *posOut, const uint32_t *posPair, const SwOut *fwdOut, uint32_t n,
-                                                       SwJob *revJobs, uint32_t *revKeys, uint32_t *revIdx, uint32_t *mismatch) {
+                                                       SwJob *revJobs, uint32_t *revKeys, uint32_t *hist, uint32_t *mismatch) {
+    helper_prio();
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     const SwOut o = posOut[r];
@@ -163,23 +288,55 @@ __global__ __launch_bounds__(256) void rev_jobs_kernel(const SwJob *posJobs, con
     j.t_start = f.t_start + (uint64_t) max(o.end_col, 0); j.t_step = -1;
     j.slot = r;
     revJobs[r] = j;
-    revKeys[r] = sort_key(j.q_len, j.t_len);
-    revIdx[r] = r;
+    const uint32_t key = sort_key(j.q_len, j.t_len);
+    revKeys[r] = key;
+    atomicAdd(&hist[key], 1u);
 }
 
-__global__ void iota_kernel(uint32_t *p, uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = i;
+// ---- position / reverse jobs by (tile configuration, target length class): a counting sort over the N_BINS keys ----
+// bin_scan: hist -> cursor (exclusive prefix), hist is cleared for the next use; bounds[c] = first job of tile configuration c,
+// bounds[32 + c] = its first occupied key
+constexpr uint32_t BIN_THREADS = 1024, BINS_PER_THREAD = N_BINS / BIN_THREADS;
+static_assert(N_BINS % BIN_THREADS == 0, "bins per thread");
+__global__ __launch_bounds__(BIN_THREADS) void bin_scan_kernel(uint32_t *hist, uint32_t *cursor, uint32_t *bounds) {
+    helper_prio();
+    __shared__ uint32_t sm[16];
+    __shared__ uint32_t sFirst[SW_NCFG];
+    if (threadIdx.x < SW_NCFG) sFirst[threadIdx.x] = 0xFFFFFFFFu;
+    __syncthreads();
+    const uint32_t k0 = threadIdx.x * BINS_PER_THREAD;
+    uint32_t v[1] = {0}, excl[1], total[1];
+    for (uint32_t k = 0; k < BINS_PER_THREAD; k++) {
+        const uint32_t h = hist[k0 + k];
+        v[0] += h;
+        if (h) atomicMin(&sFirst[(k0 + k) / KEY_CLS], k0 + k);
+    }
+    segsort::block_scan<1>(v, excl, total, sm);
+    uint32_t run = excl[0];
+    for (uint32_t k = 0; k < BINS_PER_THREAD; k++) {
+        const uint32_t h = hist[k0 + k];
+        cursor[k0 + k] = run;
+        if ((k0 + k) % KEY_CLS == 0) bounds[(k0 + k) / KEY_CLS] = run;
+        run += h;
+        hist[k0 + k] = 0;
+    }
+    if (threadIdx.x == 0) bounds[SW_NCFG] = total[0];
+    __syncthreads();
+    if (threadIdx.x < SW_NCFG) bounds[32 + threadIdx.x] = sFirst[threadIdx.x] == 0xFFFFFFFFu ? 0u : sFirst[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void bin_scatter_kernel(const uint32_t *keys, uint32_t n, uint32_t *cursor, uint32_t *order) {
+    helper_prio();
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) order[atomicAdd(&cursor[keys[r]], 1u)] = r;
 }
 
-__global__ __launch_bounds__(256) void collect_kernel(const uint32_t *sortedPair, const uint32_t *sortedRev, uint32_t n,
-                                                      const SwOut *fwdOut, const SwOut *revOut, AlnRaw *out) {
+__global__ __launch_bounds__(256) void collect_kernel(const uint32_t *posPair, uint32_t n, const SwOut *fwdOut, const SwOut *revOut, AlnRaw *out) {
+    helper_prio();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t p = sortedPair[i], r = sortedRev[i];
-    const SwOut f = fwdOut[r], b = revOut[r];          // both indexed by survivor number
+    const SwOut f = fwdOut[i], b = revOut[i];          // both indexed by survivor number = pair order
     AlnRaw a;
-    a.pair = p; a.score = f.score; a.q_end = f.end_row; a.t_end = f.end_col;
+    a.pair = posPair[i]; a.score = f.score; a.q_end = f.end_row; a.t_end = f.end_col;
     // reverse score kept in q_start when it disagrees (the reference EXITs on that, :466-473)
     if (b.score != f.score) { a.q_start = -2; a.t_start = b.score; }
     else { a.q_start = f.end_row - b.end_row; a.t_start = f.end_col - b.end_col; }
@@ -350,26 +507,73 @@ void build_gate_table(const Evaluer &ev, double evalThr, const std::vector<uint6
 #define ACHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); return MK_ERR_DEVICE; } } while (0)
 #define ANULL(p) do { if (!(p)) { err = "device scratch allocation failed (" #p ")"; return MK_ERR_DEVICE; } } while (0)
 
-static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jobs, SwOut *out, uint32_t *keys, uint32_t *idx,
-                         uint32_t *keys2, uint32_t *idx2, uint32_t n, const char *tag, hipStream_t stream, std::string &err,
+// exclusive prefix sums of n uint32 (in -> out, in == out allowed); the grand total goes to *total (device) when given
+static int device_scan(const uint32_t *in, uint32_t n, uint32_t *out, uint32_t *total, hipStream_t stream, std::string &err) {
+    if (n == 0) { if (total) ACHK(hipMemsetAsync(total, 0, 4, stream)); return MK_OK; }
+    const uint32_t nb = (n + SCAN_TILE - 1u) / SCAN_TILE;
+    uint32_t *sums = (uint32_t *) dev_scratch("align_scansums", (size_t) nb * 4);
+    ANULL(sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(nb), dim3(256), 0, stream, in, n, sums);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, stream, in, n, out, (const uint32_t *) sums, total);
+    ACHK(hipGetLastError());
+    return MK_OK;
+}
+
+// launch shapes of the stage, fixed at the first call (several alignment workers run this code at once)
+struct AlignShapes {
+    int cus = 256;
+    uint32_t persistentBlocks[SW_NCFG];      // persistent score pass: one-wave workgroups per tile configuration
+    uint32_t unitsPerBlock = 0;              // MK_SW_UNITS_PER_BLOCK: short-lived workgroups instead of the persistent launch
+    int knownForce = -1, knownWaves = 12, narrowForce = -1;
+};
+static const AlignShapes &align_shapes() {
+    static AlignShapes S;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        int dev = 0;
+        (void) hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&S.cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || S.cus <= 0) S.cus = 256;
+        // persistent forward launch: this many one-wave workgroups per CU and tile configuration (MK_SW_WAVES_PER_CU = one number or one per
+        // tile configuration, comma separated); 12 for every tile (round 2: 16 for the small tiles, 6-8 for the large ones; profiles/r03_search_tuning.txt)
+        int perCu[SW_NCFG];
+        for (int c = 0; c < SW_NCFG; c++) perCu[c] = 12;
+        if (const char *e = knob("MK_SW_WAVES_PER_CU")) {
+            int k = 0, last = 16;
+            for (const char *p = e; *p && k < SW_NCFG; k++) {
+                last = std::max(1, atoi(p));
+                perCu[k] = last;
+                while (*p && *p != ',') p++;
+                if (*p == ',') p++;
+            }
+            for (; k < SW_NCFG; k++) perCu[k] = last;
+        }
+        for (int c = 0; c < SW_NCFG; c++) S.persistentBlocks[c] = (uint32_t) (S.cus * perCu[c]);
+        S.unitsPerBlock = (uint32_t) std::max(0L, knob_long("MK_SW_UNITS_PER_BLOCK", 0));
+        S.knownForce = (int) knob_long("MK_SW_KNOWN", -1);
+        S.knownWaves = (int) std::max(1L, knob_long("MK_SW_KNOWN_WAVES", 12));
+        S.narrowForce = (int) knob_long("MK_SW_NARROW", -1);
+    });
+    return S;
+}
+
+// position / reverse pass: the jobs (their keys and the key histogram are filled by the producing kernel) ordered by
+// (tile configuration, target length class) with a counting sort, one launch per tile configuration
+static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jobs, SwOut *out, const uint32_t *keys, uint32_t *hist, uint32_t *order,
+                         uint32_t n, const char *tag, hipStream_t stream, std::string &err,
                          timed_begin_fn tb, timed_end_fn te, int *handles /* SW_NCFG, may be null */,
                          const int32_t *knownScore /* device, by job slot: the maximum every job will reach (null: unknown) */) {
     if (handles) for (int c = 0; c < SW_NCFG; c++) handles[c] = -1;
     if (n == 0) return MK_OK;
-    hipcub::DoubleBuffer<uint32_t> kb(keys, keys2), vb(idx, idx2);
-    size_t tempBytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, kb, vb, (int) n, 0, 16, stream);
-    void *temp = dev_scratch("align_sort_temp", tempBytes);
-    ANULL(temp);
-    int th = tb("align_sort", 16.0 * n, 0);
-    ACHK(hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, kb, vb, (int) n, 0, 16, stream));
-    te(th);
+    const AlignShapes &S = align_shapes();
+    uint32_t *dCursor = (uint32_t *) dev_scratch("align_bincursor", (size_t) N_BINS * 4);
     uint32_t *dBounds = (uint32_t *) dev_scratch("align_bounds", 64 * sizeof(uint32_t));
-    ANULL(dBounds);
-    hipLaunchKernelGGL(bounds_kernel, dim3(1), dim3(64), 0, stream, kb.Current(), n, dBounds, dBounds + 32);
-    ACHK(hipGetLastError());
     uint32_t *hb = (uint32_t *) pinned_scratch("align_bounds_h", 64 * sizeof(uint32_t));
-    ANULL(hb);
+    ANULL(dCursor); ANULL(dBounds); ANULL(hb);
+    int th = tb("align_sort", 12.0 * n, 0);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(BIN_THREADS), 0, stream, hist, dCursor, dBounds);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, keys, n, dCursor, order);
+    te(th);
+    ACHK(hipGetLastError());
     ACHK(hipMemcpyAsync(hb, dBounds, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     ACHK(sync_wait(stream, "wait_align"));
     for (int c = 0; c < SW_NCFG; c++) {
@@ -377,7 +581,7 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
         if (hi <= lo) continue;
         SwLaunch L;
         L.q_res = V.q_res; L.q_bias8 = V.q_bias8; L.q_prof = V.q_prof; L.t_res = V.t_res; L.mat = V.mat_aln;
-        L.jobs = jobs; L.out = out; L.n_jobs = hi - lo; L.order = vb.Current() + lo;
+        L.jobs = jobs; L.out = out; L.n_jobs = hi - lo; L.order = order + lo;
         L.boundary = nullptr; L.boundary_stride = 0; L.boundary_job0 = 0;
         L.wave_start = nullptr; L.n_waves = 0; L.work_counter = nullptr; L.persistent_blocks = 0; L.units_per_block = 0; L.known_score = nullptr;
         L.gap_open = P.gap_open; L.gap_extend = P.gap_extend;
@@ -395,19 +599,14 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
         // the score is known: packed int16, eight independent DPs per wave, persistent -- when the stage has the GPU to itself (mk_align:
         // 108 ms instead of 121 ms per config-2 pass).  Beside the prefilter of mk_search its 11-22 KB of profiles per wave cost the other
         // stage more LDS than the kernel saves (measured: 1.12 s per step against 1.10 s), so the int32 kernels stay there.  MK_SW_KNOWN=0/1 forces.
-        static const int force = getenv("MK_SW_KNOWN") ? atoi(getenv("MK_SW_KNOWN")) : -1;
-        if (knownScore && sw_cfg_known(c) && !V.q_prof && (force >= 0 ? force != 0 : !V.co_resident)) {
-            static int cus = 0;
-            if (!cus) { int dev = 0; (void) hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
-            uint32_t *dWork = (uint32_t *) dev_scratch("align_knowncounters", 64 * sizeof(uint32_t));
+        if (knownScore && sw_cfg_known(c) && !V.q_prof && (S.knownForce >= 0 ? S.knownForce != 0 : !V.co_resident)) {
+            uint32_t *dWork = (uint32_t *) dev_scratch("align_knowncounters", 64 * sizeof(uint32_t));     // (a buffer per scratch lane = per worker)
             ANULL(dWork);
-            static uint32_t slot = 0;
-            uint32_t *counter = dWork + (slot++ % 64);
+            uint32_t *counter = dWork + (strcmp(tag, "sw_rev") == 0 ? 16 : 0) + c;
             ACHK(hipMemsetAsync(counter, 0, sizeof(uint32_t), stream));
             L.known_score = knownScore; L.work_counter = counter;
             // 11 / 22.5 KB of profiles per wave: few waves per CU, the LDS is shared with the prefilter workgroups of the other stream
-            static const int perCuSmall = getenv("MK_SW_KNOWN_WAVES") ? std::max(1, atoi(getenv("MK_SW_KNOWN_WAVES"))) : 12;
-            L.persistent_blocks = (uint32_t) cus * (uint32_t) (sw_cfg_rows(c) <= 32 ? perCuSmall : std::max(1, perCuSmall / 2));
+            L.persistent_blocks = (uint32_t) S.cus * (uint32_t) (sw_cfg_rows(c) <= 32 ? S.knownWaves : std::max(1, S.knownWaves / 2));
             ACHK(launch_sw_known(L, c, stream));
         } else {
             ACHK(launch_sw(L, c, stream));
@@ -417,79 +616,56 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
     return MK_OK;
 }
 
-// forward pass: jobs sorted by (configuration, query, target length); one wave per (query, <= 64/G targets)
-static int run_shared_fwd(const AlignView &V, const mk_params &P, const SwJob *jobs, SwOut *out, uint64_t *keys, uint32_t *idx,
-                          uint64_t *keys2, uint32_t *idx2, uint32_t n, hipStream_t stream, std::string &err,
-                          timed_begin_fn tb, timed_end_fn te, int *handles /* SW_NCFG */) {
+// forward pass: jobs ordered by (configuration, query, target length); one wave per (query, <= 64/G targets)
+static int run_shared_fwd(const AlignView &V, const mk_params &P, const uint64_t *dHitOff, const mk_hit *dHits, const SwJob *jobs, SwOut *out,
+                          uint32_t n, hipStream_t stream, std::string &err, timed_begin_fn tb, timed_end_fn te, int *handles /* SW_NCFG */) {
     for (int c = 0; c < SW_NCFG; c++) handles[c] = -1;
     if (n == 0) return MK_OK;
-    hipcub::DoubleBuffer<uint64_t> kb(keys, keys2);
-    hipcub::DoubleBuffer<uint32_t> vb(idx, idx2);
-    uint32_t *dHead = (uint32_t *) dev_scratch("align_seghead", (size_t) n * 4);
-    uint8_t *dFlag = (uint8_t *) dev_scratch("align_waveflag", n);
+    const AlignShapes &S = align_shapes();
+    const uint32_t nq = V.n_queries;
+    const uint32_t nb = (nq + PLAN_BLOCK - 1u) / PLAN_BLOCK;
+    const uint32_t maxRuns = n / ORDER_TILE + nq + 1;                      // every query adds at most one partial run
+    uint32_t *dOrder = (uint32_t *) dev_scratch("align_order", (size_t) n * 4);
     uint32_t *dWave = (uint32_t *) dev_scratch("align_wavestart", ((size_t) n + 1) * 4);
-    uint32_t *dNum = (uint32_t *) dev_scratch("align_nwaves", 16);
+    uint32_t *dPlan = (uint32_t *) dev_scratch("align_plan", ((size_t) nq * 2 + (size_t) maxRuns * 2 + (size_t) nb * (PLAN_NV + 1)) * 4);
     uint32_t *dBounds = (uint32_t *) dev_scratch("align_bounds", 64 * sizeof(uint32_t));
     uint32_t *hb = (uint32_t *) pinned_scratch("align_bounds_h", 64 * sizeof(uint32_t));
     uint32_t *dWork = (uint32_t *) dev_scratch("align_workcounters", 64);
-    ANULL(dHead); ANULL(dFlag); ANULL(dWave); ANULL(dNum); ANULL(dBounds); ANULL(hb); ANULL(dWork);
+    ANULL(dOrder); ANULL(dWave); ANULL(dPlan); ANULL(dBounds); ANULL(hb); ANULL(dWork);
     ACHK(hipMemsetAsync(dWork, 0, 64, stream));
-    // persistent forward launch: this many one-wave workgroups per CU and tile configuration (MK_SW_WAVES_PER_CU = one number
-    // or one per tile configuration, comma separated).  Half the wave slots for the small tiles; fewer for the tiles whose profiles are large, so
-    // that the LDS-hungry prefilter workgroups of the other stream still find room on the CU.
-    static uint32_t persistentBlocks[SW_NCFG] = {};
-    static uint32_t unitsPerBlock = 0;              // MK_SW_UNITS_PER_BLOCK: short-lived workgroups instead of the persistent launch
-    if (!persistentBlocks[0]) {
-        int dev = 0, cus = 256;
-        (void) hipGetDevice(&dev);
-        (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        int perCu[SW_NCFG] = {12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12};     // (round 2: 16 for the small tiles, 6-8 for the large ones; profiles/r03_search_tuning.txt)
-        if (const char *e = getenv("MK_SW_WAVES_PER_CU")) {
-            int k = 0, last = 16;
-            for (const char *p = e; *p && k < SW_NCFG; k++) {
-                last = std::max(1, atoi(p));
-                perCu[k] = last;
-                while (*p && *p != ',') p++;
-                if (*p == ',') p++;
-            }
-            for (; k < SW_NCFG; k++) perCu[k] = last;
-        }
-        for (int c = 0; c < SW_NCFG; c++) persistentBlocks[c] = (uint32_t) (cus * perCu[c]);
-        if (const char *e = getenv("MK_SW_UNITS_PER_BLOCK")) unitsPerBlock = (uint32_t) std::max(0, atoi(e));
-    }
-    size_t t1 = 0, t2 = 0, t3 = 0;
-    hipcub::CountingInputIterator<uint32_t> iota(0);
-    hipcub::DeviceRadixSort::SortPairs(nullptr, t1, kb, vb, (int) n, 0, 48, stream);
-    hipcub::DeviceScan::InclusiveScan(nullptr, t2, dHead, dHead, hipcub::Max(), (int) n, stream);
-    hipcub::DeviceSelect::Flagged(nullptr, t3, iota, dFlag, dWave, dNum, (int) n, stream);
-    void *temp = dev_scratch("align_sort_temp", std::max(t1, std::max(t2, t3)));
-    ANULL(temp);
-    int th = tb("align_sort", 6.0 * 24.0 * n, 0);
-    ACHK(hipcub::DeviceRadixSort::SortPairs(temp, t1, kb, vb, (int) n, 0, 48, stream));
-    te(th);
-    th = tb("align_waves", 30.0 * n, 0);
-    hipLaunchKernelGGL(seg_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, kb.Current(), n, dHead);
-    ACHK(hipcub::DeviceScan::InclusiveScan(temp, t2, dHead, dHead, hipcub::Max(), (int) n, stream));
-    static const int narrowEnv = getenv("MK_SW_NARROW") ? atoi(getenv("MK_SW_NARROW")) : -1;
-    const bool narrow = narrowEnv >= 0 ? narrowEnv != 0 : V.q_prof != nullptr;      // profile queries meet short targets (ORF fragments)
-    hipLaunchKernelGGL(wave_flag_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, kb.Current(), dHead, n, dFlag, narrow);
-    ACHK(hipcub::DeviceSelect::Flagged(temp, t3, iota, dFlag, dWave, dNum, (int) n, stream));
-    hipLaunchKernelGGL(shared_bounds_kernel, dim3(1), dim3(64), 0, stream, kb.Current(), n, dWave, dNum, dBounds);
-    te(th);
+    const bool narrow = S.narrowForce >= 0 ? S.narrowForce != 0 : V.q_prof != nullptr;      // profile queries meet short targets (ORF fragments)
+    PlanArgs A;
+    A.hitOff = dHitOff; A.q_off = V.q_off; A.nq = nq; A.nPairs = n; A.narrow = narrow;
+    A.jobOff = dPlan; A.waveOff = dPlan + nq; A.runQuery = dPlan + 2 * (size_t) nq; A.runIndex = A.runQuery + maxRuns; A.blockSums = A.runIndex + maxRuns;
+    A.bounds = dBounds; A.waveStart = dWave;
+    int th = tb("align_sort", 24.0 * n, 0);
+    hipLaunchKernelGGL(plan_sums_kernel, dim3(nb), dim3(PLAN_BLOCK), 0, stream, A);
+    hipLaunchKernelGGL(plan_offsets_kernel, dim3(nb), dim3(PLAN_BLOCK), 0, stream, A);
     ACHK(hipGetLastError());
     ACHK(hipMemcpyAsync(hb, dBounds, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    ACHK(sync_wait(stream, "wait_align"));
+    OrderArgs O;
+    O.hitOff = dHitOff; O.q_off = V.q_off; O.hits = dHits; O.t_off = V.t_off; O.nq = nq; O.nTargets = V.n_targets; O.narrow = narrow;
+    O.jobOff = A.jobOff; O.waveOff = A.waveOff; O.runQuery = A.runQuery; O.runIndex = A.runIndex; O.order = dOrder; O.waveStart = dWave;
+    hipLaunchKernelGGL(order_wave_kernel, dim3((nq + 3) / 4), dim3(256), 0, stream, O);
+    ACHK(hipGetLastError());
+    ACHK(sync_wait(stream, "wait_align"));                                   // the bounds (and the number of runs) are on the host
+    if (hb[33] > 0) {
+        hipLaunchKernelGGL(order_block_kernel, dim3(hb[33]), dim3(256), 0, stream, O);
+        ACHK(hipGetLastError());
+    }
+    te(th);
     for (int c = 0; c < SW_NCFG; c++) {
         const uint32_t lo = hb[c], hi = hb[c + 1], wlo = hb[16 + c], whi = hb[16 + c + 1];
         if (hi <= lo || whi <= wlo) continue;
         SwLaunch L;
         L.q_res = V.q_res; L.q_bias8 = V.q_bias8; L.q_prof = V.q_prof; L.t_res = V.t_res; L.mat = V.mat_aln;
-        L.jobs = jobs; L.out = out; L.n_jobs = hi - lo; L.order = vb.Current();      // wave_start holds absolute sorted positions
+        L.jobs = jobs; L.out = out; L.n_jobs = hi - lo; L.order = dOrder;         // wave_start holds absolute ordered positions
         L.boundary = nullptr; L.boundary_stride = 0; L.boundary_job0 = lo;
         L.wave_start = dWave + wlo; L.n_waves = whi - wlo;
-        L.work_counter = dWork + c; L.persistent_blocks = persistentBlocks[c]; L.units_per_block = unitsPerBlock;
+        L.work_counter = dWork + c; L.persistent_blocks = S.persistentBlocks[c]; L.units_per_block = S.unitsPerBlock;
         L.gap_open = P.gap_open; L.gap_extend = P.gap_extend;
         L.narrow = narrow;
+        L.known_score = nullptr;
         if (c == SW_NCFG - 1 && V.max_q_len > (uint32_t) sw_cfg_rows(c)) {
             // queries beyond the largest tile run in row tiles with an HBM border per job; the border is as long as the
             // longest target of the bucket (the first key only bounds its own query)
@@ -509,6 +685,8 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const SwJob *j
     return MK_OK;
 }
 
+int scratch_lane();
+
 int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hit *hitsHost, uint64_t nPairs,
                      const std::vector<GateEntry> &gate, const mk_params &P, hipStream_t stream,
                      const double *fwdWork /* per cfg: bytes, cells; may be null */,
@@ -519,90 +697,80 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hi
     if (nPairs == 0) return MK_OK;
     if (nPairs >= 0x7FFFFFFFull) { err = "more than 2^31 pairs in one batch: split the batch"; return MK_ERR_UNSUPPORTED; }
     const uint32_t n = (uint32_t) nPairs;
+    const uint32_t nGateBlocks = (n + 255u) / 256u;
     uint64_t *dHitOff = (uint64_t *) dev_scratch("align_hitoff", ((size_t) V.n_queries + 1) * sizeof(uint64_t));
     mk_hit *dHits = (mk_hit *) dev_scratch("align_hits", (size_t) n * sizeof(mk_hit));
     SwJob *dJobs = (SwJob *) dev_scratch("align_jobs", (size_t) n * sizeof(SwJob));
     SwOut *dOut = (SwOut *) dev_scratch("align_out", (size_t) n * sizeof(SwOut));
-    uint32_t *dKeys = (uint32_t *) dev_scratch("align_keys", (size_t) n * 4), *dKeys2 = (uint32_t *) dev_scratch("align_keys2", (size_t) n * 4);
-    uint32_t *dIdx = (uint32_t *) dev_scratch("align_idx", (size_t) n * 4), *dIdx2 = (uint32_t *) dev_scratch("align_idx2", (size_t) n * 4);
     GateEntry *dGate = (GateEntry *) dev_scratch("align_gate", gate.size() * sizeof(GateEntry));
     uint32_t *dCount = (uint32_t *) dev_scratch("align_count", 16);
-    ANULL(dHitOff); ANULL(dHits); ANULL(dJobs); ANULL(dOut); ANULL(dKeys); ANULL(dKeys2); ANULL(dIdx); ANULL(dIdx2); ANULL(dGate); ANULL(dCount);
+    uint32_t *dHist = (uint32_t *) dev_scratch("align_binhist", (size_t) N_BINS * 4);
+    uint32_t *dGateBlk = (uint32_t *) dev_scratch("align_gateblk", (size_t) nGateBlocks * 4);
+    ANULL(dHitOff); ANULL(dHits); ANULL(dJobs); ANULL(dOut); ANULL(dGate); ANULL(dCount); ANULL(dHist); ANULL(dGateBlk);
     ACHK(hipMemcpyAsync(dHitOff, hitOffHost, ((size_t) V.n_queries + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
     ACHK(hipMemcpyAsync(dHits, hitsHost, (size_t) n * sizeof(mk_hit), hipMemcpyHostToDevice, stream));
     ACHK(hipMemcpyAsync(dGate, gate.data(), gate.size() * sizeof(GateEntry), hipMemcpyHostToDevice, stream));
     ACHK(hipMemsetAsync(dOut, 0, (size_t) n * sizeof(SwOut), stream));
     ACHK(hipMemsetAsync(dCount, 0, 16, stream));
-    uint64_t *dKeys64 = (uint64_t *) dev_scratch("align_keys64", (size_t) n * 8), *dKeys64b = (uint64_t *) dev_scratch("align_keys64b", (size_t) n * 8);
-    ANULL(dKeys64); ANULL(dKeys64b);
+    ACHK(hipMemsetAsync(dHist, 0, (size_t) N_BINS * 4, stream));
     unsigned long long *dFwdWork = (unsigned long long *) dev_scratch("align_fwdwork", 2 * SW_NCFG * 8);
     unsigned long long *hFwdWork = (unsigned long long *) pinned_scratch("align_fwdwork_h", 2 * SW_NCFG * 8);
     ANULL(dFwdWork); ANULL(hFwdWork);
     ACHK(hipMemsetAsync(dFwdWork, 0, 2 * SW_NCFG * 8, stream));
-    int th = tb("align_expand", 52.0 * n, 0);
-    hipLaunchKernelGGL(expand_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, V, dHitOff, dHits, (uint64_t) n, dJobs, dKeys64, dIdx, dCount + 1, dFwdWork);
+    int th = tb("align_expand", 44.0 * n, 0);
+    hipLaunchKernelGGL(expand_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, V, dHitOff, dHits, (uint64_t) n, dJobs, dCount + 1, dFwdWork);
     te(th);
     ACHK(hipGetLastError());
     ACHK(hipMemcpyAsync(hFwdWork, dFwdWork, 2 * SW_NCFG * 8, hipMemcpyDeviceToHost, stream));     // (lands before run_shared_fwd's synchronisation)
     int hFwd[SW_NCFG], hRev[SW_NCFG];
-    int rc = run_shared_fwd(V, P, dJobs, dOut, dKeys64, dIdx, dKeys64b, dIdx2, n, stream, err, tb, te, hFwd);
+    int rc = run_shared_fwd(V, P, dHitOff, dHits, dJobs, dOut, n, stream, err, tb, te, hFwd);
     (void) fwdWork;
     for (int c = 0; c < SW_NCFG; c++) if (hFwd[c] >= 0) ts(hFwd[c], (double) hFwdWork[2 * c], (double) hFwdWork[2 * c + 1]);
     if (rc != MK_OK) return rc;
     // e-value gate on the forward scores; the survivors (at most n) get a position pass, then the reverse pass
-    uint32_t *dRevPair = (uint32_t *) dev_scratch("align_revpair", (size_t) n * 4);
-    SwJob *dPosJobs = (SwJob *) dev_scratch("align_posjobs", (size_t) n * sizeof(SwJob));
-    ANULL(dRevPair); ANULL(dPosJobs);
     th = tb("align_gate", 52.0 * n, 0);
     unsigned long long *dPosWork = (unsigned long long *) dev_scratch("align_poswork", 2 * SW_NCFG * 8);
     unsigned long long *hPosWork = (unsigned long long *) pinned_scratch("align_poswork_h", 2 * SW_NCFG * 8);
     ANULL(dPosWork); ANULL(hPosWork);
     ACHK(hipMemsetAsync(dPosWork, 0, 2 * SW_NCFG * 8, stream));
-    int32_t *dPosScore = (int32_t *) dev_scratch("align_posscore", (size_t) n * 4);
-    ANULL(dPosScore);
-    hipLaunchKernelGGL(gate_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dJobs, dOut, (uint64_t) n, dGate, dCount, dRevPair, dPosJobs, dKeys, dIdx, dPosScore, dPosWork);
-    te(th);
+    hipLaunchKernelGGL(gate_count_kernel, dim3(nGateBlocks), dim3(256), 0, stream, dJobs, dOut, (uint64_t) n, dGate, dGateBlk);
     ACHK(hipGetLastError());
+    if ((rc = device_scan(dGateBlk, nGateBlocks, dGateBlk, dCount, stream, err)) != MK_OK) return rc;
     uint32_t *hCount = (uint32_t *) pinned_scratch("align_count_h", 16);
     ANULL(hCount);
-    ACHK(hipMemcpyAsync(hPosWork, dPosWork, 2 * SW_NCFG * 8, hipMemcpyDeviceToHost, stream));
     ACHK(hipMemcpyAsync(hCount, dCount, 8, hipMemcpyDeviceToHost, stream));
     ACHK(sync_wait(stream, "wait_align"));
     if (hCount[1] != 0) { err = "prefilter hit " + std::to_string(hCount[1] - 1) + " names a target outside the DB"; return MK_ERR_ARG; }
     const uint32_t nRev = hCount[0];
-    if (nRev == 0) return MK_OK;
+    if (nRev == 0) { te(th); return MK_OK; }
+    uint32_t *dRevPair = (uint32_t *) dev_scratch("align_revpair", (size_t) nRev * 4);
+    SwJob *dPosJobs = (SwJob *) dev_scratch("align_posjobs", (size_t) nRev * sizeof(SwJob));
+    int32_t *dPosScore = (int32_t *) dev_scratch("align_posscore", (size_t) nRev * 4);
+    uint32_t *dKeys = (uint32_t *) dev_scratch("align_keys", (size_t) nRev * 4), *dOrder = (uint32_t *) dev_scratch("align_posorder", (size_t) nRev * 4);
     SwOut *dPosOut = (SwOut *) dev_scratch("align_posout", (size_t) nRev * sizeof(SwOut));
     SwOut *dRevOut = (SwOut *) dev_scratch("align_revout", (size_t) nRev * sizeof(SwOut));
     SwJob *dRevJobs = (SwJob *) dev_scratch("align_revjobs", (size_t) nRev * sizeof(SwJob));
-    ANULL(dPosOut); ANULL(dRevOut); ANULL(dRevJobs);
+    ANULL(dRevPair); ANULL(dPosJobs); ANULL(dPosScore); ANULL(dKeys); ANULL(dOrder); ANULL(dPosOut); ANULL(dRevOut); ANULL(dRevJobs);
+    hipLaunchKernelGGL(gate_emit_kernel, dim3(nGateBlocks), dim3(256), 0, stream, dJobs, dOut, (uint64_t) n, dGate, (const uint32_t *) dGateBlk,
+                       dRevPair, dPosJobs, dKeys, dPosScore, dHist, dPosWork);
+    te(th);
+    ACHK(hipGetLastError());
+    ACHK(hipMemcpyAsync(hPosWork, dPosWork, 2 * SW_NCFG * 8, hipMemcpyDeviceToHost, stream));
     ACHK(hipMemsetAsync(dPosOut, 0, (size_t) nRev * sizeof(SwOut), stream));
     ACHK(hipMemsetAsync(dRevOut, 0, (size_t) nRev * sizeof(SwOut), stream));
     int hPos[SW_NCFG];
-    rc = run_sorted_sw(V, P, dPosJobs, dPosOut, dKeys, dIdx, dKeys2, dIdx2, nRev, "sw_pos", stream, err, tb, te, hPos, dPosScore);
+    rc = run_sorted_sw(V, P, dPosJobs, dPosOut, dKeys, dHist, dOrder, nRev, "sw_pos", stream, err, tb, te, hPos, dPosScore);
     if (rc != MK_OK) return rc;
     for (int c = 0; c < SW_NCFG; c++) if (hPos[c] >= 0) ts(hPos[c], (double) hPosWork[2 * c], (double) hPosWork[2 * c + 1]);
-    hipLaunchKernelGGL(rev_jobs_kernel, dim3((nRev + 255) / 256), dim3(256), 0, stream, dPosJobs, dPosOut, dRevPair, dOut, nRev, dRevJobs, dKeys, dIdx, dCount + 2);
+    hipLaunchKernelGGL(rev_jobs_kernel, dim3((nRev + 255) / 256), dim3(256), 0, stream, dPosJobs, dPosOut, dRevPair, dOut, nRev, dRevJobs, dKeys, dHist, dCount + 2);   // (bin_scan cleared the histogram)
     ACHK(hipGetLastError());
-    rc = run_sorted_sw(V, P, dRevJobs, dRevOut, dKeys, dIdx, dKeys2, dIdx2, nRev, "sw_rev", stream, err, tb, te, hRev, dPosScore);    // (rev job r = survivor r: same score)
+    rc = run_sorted_sw(V, P, dRevJobs, dRevOut, dKeys, dHist, dOrder, nRev, "sw_rev", stream, err, tb, te, hRev, dPosScore);    // (rev job r = survivor r: same score)
     if (rc != MK_OK) return rc;
-    // order the survivors by pair index and collect
-    uint32_t *dSeq = (uint32_t *) dev_scratch("align_seq", (size_t) nRev * 4), *dSeq2 = (uint32_t *) dev_scratch("align_seq2", (size_t) nRev * 4);
-    uint32_t *dPair2 = (uint32_t *) dev_scratch("align_revpair2", (size_t) nRev * 4);
+    // collect: the survivors are numbered in pair order
     AlnRaw *dRaw = (AlnRaw *) dev_scratch("align_raw", (size_t) nRev * sizeof(AlnRaw));
-    ANULL(dSeq); ANULL(dSeq2); ANULL(dPair2); ANULL(dRaw);
-    hipLaunchKernelGGL(iota_kernel, dim3((nRev + 255) / 256), dim3(256), 0, stream, dSeq, nRev);
-    ACHK(hipGetLastError());
-    hipcub::DoubleBuffer<uint32_t> pb(dRevPair, dPair2), sb(dSeq, dSeq2);
-    size_t tempBytes = 0;
-    int bits = 1; while ((1ull << bits) < nPairs) bits++;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, pb, sb, (int) nRev, 0, bits, stream);
-    void *temp = dev_scratch("align_sort_temp", tempBytes);
-    ANULL(temp);
-    th = tb("align_sort", 16.0 * nRev, 0);
-    ACHK(hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, pb, sb, (int) nRev, 0, bits, stream));
-    te(th);
+    ANULL(dRaw);
     th = tb("align_collect", 64.0 * nRev, 0);
-    hipLaunchKernelGGL(collect_kernel, dim3((nRev + 255) / 256), dim3(256), 0, stream, pb.Current(), sb.Current(), nRev, dPosOut, dRevOut, dRaw);
+    hipLaunchKernelGGL(collect_kernel, dim3((nRev + 255) / 256), dim3(256), 0, stream, (const uint32_t *) dRevPair, nRev, (const SwOut *) dPosOut, (const SwOut *) dRevOut, dRaw);
     te(th);
     ACHK(hipGetLastError());
     AlnRaw *hRaw = (AlnRaw *) pinned_scratch("align_raw_host", (size_t) nRev * sizeof(AlnRaw));
@@ -622,15 +790,25 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hi
         uint32_t *dFlags = (uint32_t *) dev_scratch("asm_flags", 16);
         uint32_t *hFlags = (uint32_t *) pinned_scratch("asm_flags_h", 16);
         ANULL(dEval); ANULL(dLenIdx); ANULL(dBit); ANULL(dTmp); ANULL(dFinal); ANULL(dPass); ANULL(dCnt); ANULL(dOff); ANULL(dFlags); ANULL(hFlags);
-        // the tables belong to the batch (same for every range of an mk_search): uploaded when they change
-        static thread_local uint64_t uploadedId = 0; static std::mutex upMutex;     // (per host thread: a second worker of the stage has buffers of its own)
+        // the tables belong to the batch (same for every range of an mk_search): uploaded when they change.  The device copies live in the
+        // scratch buffers of the calling thread's LANE (a worker of mk_search and the caller of mk_align can share lane 0), so what a lane holds
+        // is remembered per lane -- table id and the buffer it went to (a scratch buffer that grew has lost its content)
         {
+            constexpr int MAX_LANES = 16;
+            struct Uploaded { uint64_t id = 0; const void *eval = nullptr, *lenIdx = nullptr, *bit = nullptr; };
+            static Uploaded uploaded[MAX_LANES];
+            static std::mutex upMutex;
+            const int lane = scratch_lane();
             std::lock_guard<std::mutex> g(upMutex);
-            if (uploadedId != T.id) {
+            Uploaded local;
+            Uploaded &U = (lane >= 0 && lane < MAX_LANES) ? uploaded[lane] : local;
+            if (U.id != T.id || U.eval != dEval || U.lenIdx != dLenIdx || U.bit != dBit) {
                 ACHK(hipMemcpyAsync(dEval, T.evalue.data(), T.evalue.size() * sizeof(double), hipMemcpyHostToDevice, stream));
                 ACHK(hipMemcpyAsync(dLenIdx, T.lenIdx.data(), T.lenIdx.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
                 ACHK(hipMemcpyAsync(dBit, T.bitScore.data(), T.bitScore.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-                uploadedId = T.id;
+                // the copies read T's vectors, which the next batch may rebuild: they must have left the host before anybody can do that
+                ACHK(sync_wait(stream, "wait_align"));
+                U.id = T.id; U.eval = dEval; U.lenIdx = dLenIdx; U.bit = dBit;
             }
         }
         unsigned long long *dWork = (unsigned long long *) dev_scratch("asm_revwork", 2 * SW_NCFG * 8);
@@ -646,11 +824,8 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hi
         th = tb("align_assemble", (double) nRev * (sizeof(AlnRaw) + 2.0 * sizeof(mk_alignment)), 0);
         hipLaunchKernelGGL(assemble_kernel, dim3((nRev + 255) / 256), dim3(256), 0, stream, AV);
         hipLaunchKernelGGL(assemble_count_kernel, dim3((V.n_queries + 255) / 256), dim3(256), 0, stream, AV, dCnt);
-        size_t tS = 0;
-        hipcub::DeviceScan::ExclusiveSum(nullptr, tS, dCnt, dOff, (int) V.n_queries + 1, stream);
-        void *tempS = dev_scratch("align_sort_temp", tS);
-        ANULL(tempS);
-        ACHK(hipcub::DeviceScan::ExclusiveSum(tempS, tS, dCnt, dOff, (int) V.n_queries + 1, stream));
+        ACHK(hipGetLastError());
+        if ((rc = device_scan(dCnt, V.n_queries, dOff, dOff + V.n_queries, stream, err)) != MK_OK) return rc;
         hipLaunchKernelGGL(assemble_rank_kernel, dim3((nRev + 255) / 256), dim3(256), 0, stream, AV, (const uint32_t *) dOff, dFinal);
         te(th);
         ACHK(hipGetLastError());
@@ -719,6 +894,7 @@ std::map<std::string, Scratch> &scratch_map() { static std::map<std::string, Scr
 static std::mutex &scratch_mutex() { static std::mutex m; return m; }
 static thread_local int t_lane = 0;
 void set_scratch_lane(int lane) { t_lane = lane; }
+int scratch_lane() { return t_lane; }
 static std::string scratch_key(const char *prefix, const char *name) {
     std::string k = std::string(prefix) + name;
     if (t_lane > 0) { k += '#'; k += std::to_string(t_lane); }

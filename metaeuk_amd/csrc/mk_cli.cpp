@@ -36,6 +36,16 @@
 
 namespace {
 
+// the command's two doors to the environment: what a launcher tells a worker (RANK, WORLD_SIZE, LOCAL_RANK, TORCHELASTIC_RUN_ID,
+// MK_LAUNCH_ID, MK_SHARD_TIMEOUT_S, the reference's own MMSEQS_IGNORE_INDEX) is always honoured; test knobs (MK_CLI_*) only under MK_DEBUG=1
+const char *launcherEnv(const char *name) { return getenv(name); }
+const char *knobEnv(const char *name) {
+    const char *dbg = launcherEnv("MK_DEBUG");
+    if (!dbg || atoi(dbg) == 0) return nullptr;
+    const char *v = launcherEnv(name);
+    return (v && *v) ? v : nullptr;
+}
+
 struct Flag { const char *name; const char *def; bool honoured; };
 // union of the `prefilter` and `align` parameter lists (Parameters.cpp:387-455) + common ones
 const Flag FLAGS[] = {
@@ -182,7 +192,7 @@ int fillParams(const Args &a, mk_params &P, int &gpu) {
     if (auto v = get("--ref-l2-bytes")) if (!v->empty()) P.host_l2_bytes = strtoull(v->c_str(), nullptr, 10);
     gpu = 0;
     if (auto v = get("--gpu")) gpu = atoi(v->c_str());
-    if (const char *lr = getenv("LOCAL_RANK")) if (!get("--gpu")) gpu = atoi(lr);
+    if (const char *lr = launcherEnv("LOCAL_RANK")) if (!get("--gpu")) gpu = atoi(lr);
     if (P.gap_open != 11 || P.gap_extend != 1) return die("only --gap-open 11 --gap-extend 1 has a hard-coded Gumbel parameter set in the reference (EvalueComputation.h:64-69); other values are not implemented%s");
     return 0;
 }
@@ -231,7 +241,7 @@ int openTarget(const std::string &path, const mk_params &P, TargetSide &ts) {
         int32_t t = -1;
         if (f) { if (fread(&t, 4, 1, f) != 1) t = -1; fclose(f); }
         if (t >= 0 && (t & 0xFFFF) == 9) idx = path;
-        else if (!P.profile_search && !getenv("MMSEQS_IGNORE_INDEX") && mk::Database::exists(path + ".idx.dbtype")) idx = path + ".idx";
+        else if (!P.profile_search && !launcherEnv("MMSEQS_IGNORE_INDEX") && mk::Database::exists(path + ".idx.dbtype")) idx = path + ".idx";
         // (profile queries need their own masking background and an unfiltered index: a sequence-search .idx next to the DB is not used)
     }
     if (!idx.empty()) {
@@ -276,8 +286,8 @@ struct Shard { int rank = 0, world = 1; std::string token; };
 // another token (or none) and is never merged -- unless it was made by the very same command over the very same input files, in which
 // case it holds what this launch would write (the commands are deterministic; a shard's .dbtype appears last, when it is complete).
 std::string launchToken(int argc, char **argv) {
-    if (const char *id = getenv("TORCHELASTIC_RUN_ID")) if (*id && strcmp(id, "none") != 0) return std::string("run-") + id;
-    if (const char *id = getenv("MK_LAUNCH_ID")) if (*id) return std::string("id-") + id;
+    if (const char *id = launcherEnv("TORCHELASTIC_RUN_ID")) if (*id && strcmp(id, "none") != 0) return std::string("run-") + id;
+    if (const char *id = launcherEnv("MK_LAUNCH_ID")) if (*id) return std::string("id-") + id;
     uint64_t h = 1469598103934665603ull;
     int positional = 0;                                     // the first positional argument after the command is always an input DB, the second one
     const int inputs = argc > 1 && !strcmp(argv[1], "extractorfs") ? 1 : 2;     // too except for extractorfs; outputs are not looked at (they change while the workers run)
@@ -302,8 +312,8 @@ int shardOf(const Args &a, Shard &sh, int argc, char **argv) {
     auto it = a.opt.find("--shard");
     if (it != a.opt.end() && !it->second.empty()) {
         if (sscanf(it->second.c_str(), "%d/%d", &sh.rank, &sh.world) != 2) return die("--shard wants rank/world, got %s", it->second);
-    } else if (getenv("RANK") && getenv("WORLD_SIZE")) {
-        sh.rank = atoi(getenv("RANK")); sh.world = atoi(getenv("WORLD_SIZE"));
+    } else if (launcherEnv("RANK") && launcherEnv("WORLD_SIZE")) {
+        sh.rank = atoi(launcherEnv("RANK")); sh.world = atoi(launcherEnv("WORLD_SIZE"));
     }
     if (sh.world < 1 || sh.rank < 0 || sh.rank >= sh.world) return die("bad shard %s", std::to_string(sh.rank) + "/" + std::to_string(sh.world));
     sh.token = launchToken(argc, argv);
@@ -320,7 +330,7 @@ void beginShard(const std::string &out, const Shard &sh) {
     if (f) { fputs(sh.token.c_str(), f); fclose(f); }
 }
 long shardTimeoutTicks() {            // 50 ms ticks; MK_SHARD_TIMEOUT_S (default two hours): a peer that died without a marker
-    const char *e = getenv("MK_SHARD_TIMEOUT_S");
+    const char *e = launcherEnv("MK_SHARD_TIMEOUT_S");
     const long sec = e && atol(e) > 0 ? atol(e) : 7200;
     return sec * 20;
 }
@@ -634,7 +644,7 @@ int cmdPrefilterOrAlign(int mode, int argc, char **argv) {
         int32_t t = -1;
         if (f) { if (fread(&t, 4, 1, f) != 1) t = -1; fclose(f); }
         const bool explicitSplit = a.opt.count("--split") && atoi(a.opt["--split"].c_str()) > 1 && a.opt.count("--split-mode") && a.opt["--split-mode"] == "0";
-        const bool hasIdx = (t >= 0 && (t & 0xFFFF) == 9) || (!P.profile_search && !getenv("MMSEQS_IGNORE_INDEX") && mk::Database::exists(a.pos[1] + ".idx.dbtype"));
+        const bool hasIdx = (t >= 0 && (t & 0xFFFF) == 9) || (!P.profile_search && !launcherEnv("MMSEQS_IGNORE_INDEX") && mk::Database::exists(a.pos[1] + ".idx.dbtype"));
         if (explicitSplit && t >= 0 && (t & 0xFFFF) == 9) return die("--split with --split-mode 0 needs an amino-acid sequence DB as the target (index DBs hold one split)%s");
         if (t >= 0 && (t & 0xFFFF) == mk::DBTYPE_AMINO_ACIDS && (isAlign && !isSearch ? true : (explicitSplit || !hasIdx))) {
             e = tdbSeq.open(a.pos[1]);
@@ -848,7 +858,7 @@ int cmdSwapResults(int argc, char **argv) {
 // default 2^29: six-frame translation of a batch stays well below the library's 2^32 query residues), at least one
 size_t contigBatchEnd(const mk::Database &contigs, const std::vector<size_t> &ord, size_t c0) {
     uint64_t budget = 1ull << 29;
-    if (const char *e = getenv("MK_CLI_BATCH_NT")) if (atoll(e) > 0) budget = (uint64_t) atoll(e);
+    if (const char *e = knobEnv("MK_CLI_BATCH_NT")) if (atoll(e) > 0) budget = (uint64_t) atoll(e);
     uint64_t nt = 0;
     size_t c1 = c0;
     while (c1 < ord.size() && (c1 == c0 || nt + contigs.seqLen(ord[c1]) <= budget)) { nt += contigs.seqLen(ord[c1]); c1++; }
@@ -863,7 +873,7 @@ int cmdExtractOrfs(int argc, char **argv) {
     std::vector<std::string> pos;
     int minLength = 15, translate = 0, gpu = 0;
     std::string sibling;
-    if (const char *lr = getenv("LOCAL_RANK")) gpu = atoi(lr);
+    if (const char *lr = launcherEnv("LOCAL_RANK")) gpu = atoi(lr);
     for (int i = 2; i < argc; i++) {
         const std::string a = argv[i];
         auto val = [&](int &dst) { if (i + 1 >= argc) return false; dst = atoi(argv[++i]); return true; };
@@ -977,7 +987,7 @@ int invertedProfileSearch(const mk::Database &pdb, mk_targetdb *F, uint64_t nFra
         for (size_t i = 0; i < nProfAll; i++) inKeyOrder[i] = pdb.entries[pord[i]];
         mk::decomposeByLength(inKeyOrder, sh.rank, sh.world, first, count);
     }
-    const uint64_t sliceCols = getenv("MK_CLI_PROFILE_COLS") ? strtoull(getenv("MK_CLI_PROFILE_COLS"), nullptr, 10) : (1ull << 24);
+    const uint64_t sliceCols = knobEnv("MK_CLI_PROFILE_COLS") ? strtoull(knobEnv("MK_CLI_PROFILE_COLS"), nullptr, 10) : (1ull << 24);
     std::vector<mk_alignment> alnAll;
     std::vector<uint64_t> alnOff(1, 0);
     std::vector<uint32_t> pkeys;
@@ -1210,7 +1220,7 @@ int cmdPredictExons(int argc, char **argv) {
         int32_t t = -1;
         if (f) { if (fread(&t, 4, 1, f) != 1) t = -1; fclose(f); }
         const bool explicitSplit = get("--split") && atoi(get("--split")->c_str()) > 1 && get("--split-mode") && *get("--split-mode") == "0";
-        const bool hasIdx = (t >= 0 && (t & 0xFFFF) == 9) || (!getenv("MMSEQS_IGNORE_INDEX") && mk::Database::exists(a.pos[1] + ".idx.dbtype"));
+        const bool hasIdx = (t >= 0 && (t & 0xFFFF) == 9) || (!launcherEnv("MMSEQS_IGNORE_INDEX") && mk::Database::exists(a.pos[1] + ".idx.dbtype"));
         if (explicitSplit && t >= 0 && (t & 0xFFFF) == 9) return die("--split with --split-mode 0 needs an amino-acid sequence DB as the target (index DBs hold one split)%s");
         if (t >= 0 && (t & 0xFFFF) == mk::DBTYPE_AMINO_ACIDS && (explicitSplit || !hasIdx)) {
             e = tdbSeq.open(a.pos[1]);
@@ -1379,7 +1389,7 @@ int main(int argc, char **argv) {
     }
     if (cmd == "predictexons") return cmdPredictExons(argc, argv);
     // the other commands are not sharded: under a multi-process launcher worker 0 does the job
-    if (getenv("RANK") && atoi(getenv("RANK")) > 0) return EXIT_SUCCESS;
+    if (launcherEnv("RANK") && atoi(launcherEnv("RANK")) > 0) return EXIT_SUCCESS;
     if (cmd == "extractorfs") return cmdExtractOrfs(argc, argv);
     if (cmd == "predictexons") return cmdPredictExons(argc, argv);
     if (cmd == "createindex" || cmd == "indexdb") return cmdCreateIndex(argc, argv);

@@ -6,10 +6,24 @@
 #include <cstdio>
 #include <cstring>
 #include <climits>
+#include <cstdlib>
 #include <numeric>
 #include <omp.h>
 
 namespace mk {
+
+// ---- the library's two doors to the environment ----
+// launcher_env: what a launcher tells a rank (RANK, LOCAL_WORLD_SIZE, OMP_NUM_THREADS ...): always honoured.
+// knob: experiment / test switches (MK_PREFILTER_PATH, MK_SW_WAVES_PER_CU, MK_TEST_ENTRY_BASE ...).  They change tiers, paths and
+// launch shapes, so a stray variable must not reach a production run: they are read only when MK_DEBUG=1 is set as well.
+const char *launcher_env(const char *name) { return std::getenv(name); }
+const char *knob(const char *name) {
+    const char *dbg = launcher_env("MK_DEBUG");
+    if (!dbg || std::atoi(dbg) == 0) return nullptr;
+    const char *v = launcher_env(name);
+    return (v && *v) ? v : nullptr;
+}
+long knob_long(const char *name, long dflt) { const char *v = knob(name); return v ? std::atol(v) : dflt; }
 
 #include "../data/matrices.inc"
 

@@ -13,6 +13,12 @@
 
 namespace mk {
 
+// Environment: launcher_env = what a launcher tells a rank (always honoured); knob = experiment / test switches (MK_*), read only
+// under MK_DEBUG=1 -- a stray variable cannot change tiers, paths or launch shapes of a production run (list: DESIGN.md section 9)
+const char *launcher_env(const char *name);
+const char *knob(const char *name);                 // nullptr unless MK_DEBUG=1 and the variable is set and non-empty
+long knob_long(const char *name, long dflt);
+
 constexpr int ALPH = 21;       // 20 amino acids + X
 constexpr int XCODE = 20;
 constexpr int KMER = 6;

@@ -524,9 +524,6 @@ struct StreamArgs {
 #ifndef MK_STREAM_U
 #define MK_STREAM_U 2
 #endif
-#ifndef MK_STREAM_SKIP
-#define MK_STREAM_SKIP 0
-#endif
 // shapes of the two streamed tiers: waves per workgroup, LDS sort size, bitmap bits, workgroups per CU
 #ifndef MK_STREAM_NW_A
 #define MK_STREAM_NW_A 4
@@ -546,9 +543,6 @@ struct StreamArgs {
 #endif
 #ifndef MK_STREAM_MAXPOS_B
 #define MK_STREAM_MAXPOS_B 2048
-#endif
-#ifndef MK_STREAM_PROF
-#define MK_STREAM_PROF 0        // 1: per-phase cycle counters in totals[10..15] (costs ~10 %)
 #endif
 constexpr uint32_t REC_T_BITS = 22, REC_POS_BITS = 12, REC_ORD_BITS = 14;     // + 16 bits of diagonal = 64
 constexpr int STREAM_MAX_CLASSES = 64;
@@ -633,12 +627,6 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
         // ---- pass 1: enumerate + probe; hits -> region, target buckets -> the two bitmaps
         uint32_t whits = 0, kmers = 0, npos = 0;
         bool dead = false;
-#if MK_STREAM_PROF
-        unsigned long long pEnum = 0, pProbe = 0, pStore = 0, pMark = __builtin_readcyclecounter();
-#define PROF_LAP(acc) do { const unsigned long long n_ = __builtin_readcyclecounter(); acc += n_ - pMark; pMark = n_; } while (0)
-#else
-#define PROF_LAP(acc) do { } while (0)
-#endif
         while (!dead) {
             uint32_t iu = 0;
             if (lane == 0) iu = atomicAdd(&sNextPos, 1u);
@@ -653,7 +641,6 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
             uint32_t wcount = 0;                           // hits of this k-mer start so far
             kmers += enumk::enumerate_position<U>(A.V, A.V.q_res + p, thr, lane, P1.e[w],
                 [&](const uint32_t (&kmer)[U], const bool (&has)[U]) -> bool {
-                    PROF_LAP(pEnum);
                     uint32_t size[U], ex[U];
                     uint64_t o0[U];
                     uint64_t ent0[U];
@@ -661,31 +648,13 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
 #pragma unroll
                     for (int u = 0; u < U; u++) {
                         size[u] = 0; o0[u] = 0; ent0[u] = 0; inl[u] = true;
-#if MK_STREAM_SKIP == 3        // (timing experiments only: results are wrong) no bitmap, no slot, no entries
-                        if (has[u] && (kmer[u] % 3u) == 0u) { size[u] = 1; ent0[u] = (kmer[u] * 2654435761u) % A.V.n_targets | ((uint64_t) (kmer[u] & 255u) << 32); }
-#elif MK_STREAM_SKIP == 2      // bitmap only
-                        if (has[u] && kmer_present(A.V.kmer_bits, kmer[u])) { size[u] = 1; ent0[u] = (kmer[u] * 2654435761u) % A.V.n_targets | ((uint64_t) (kmer[u] & 255u) << 32); }
-#else
                         if (has[u] && kmer_present(A.V.kmer_bits, kmer[u])) { const KmerList l = load_kmer_list(A.V.kmer_slot, kmer[u]); o0[u] = l.first; size[u] = l.size; ent0[u] = l.ent0; inl[u] = l.isInline; }
-#endif
                     }
-#if MK_STREAM_SKIP == 1            // bitmap + slots, no entries
-#pragma unroll
-                    for (int u = 0; u < U; u++) if (!inl[u]) { ent0[u] = o0[u] % A.V.n_targets; size[u] = 1; }
-#else
 #pragma unroll
                     for (int u = 0; u < U; u++) if (!inl[u]) ent0[u] = ld_probe(A.V.entries + o0[u]);
-#endif
                     uint32_t totAll = 0;
 #pragma unroll
                     for (int u = 0; u < U; u++) { const uint32_t incl = enumk::wave_incl_scan(size[u]); ex[u] = incl - size[u] + totAll; totAll += enumk::wave_last(incl); }
-#if MK_STREAM_PROF
-                    { uint64_t sink = 0;
-#pragma unroll
-                      for (int u = 0; u < U; u++) sink |= ent0[u];
-                      asm volatile("" :: "v"(sink)); }                          // the entry loads have landed
-#endif
-                    PROF_LAP(pProbe);
                     if (totAll == 0) return true;
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(&sUsed, totAll);           // the batch's slots: contiguous, hence coalesced stores
@@ -711,22 +680,13 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
                         });
                     }
                     wcount += totAll;
-                    PROF_LAP(pStore);
                     return true;
                 });
             if (lane == 0) sPosBase[i] = wcount;
             whits += wcount;
         }
-        PROF_LAP(pEnum);
-#if MK_STREAM_PROF
-        const unsigned long long pEnd1 = __builtin_readcyclecounter();
-#endif
         if (lane == 0) { sWaveHits[w] = whits; sWaveKmers[w] = kmers; sWavePos[w] = npos; atomicAdd(&A.totals[7], (wall_clock64() - tStart) / NW); }
         __syncthreads();                                   // (also orders the region stores before the reads of pass 2)
-#if MK_STREAM_PROF
-        if (lane == 0) { atomicAdd(&A.totals[10], pEnum); atomicAdd(&A.totals[11], pProbe); atomicAdd(&A.totals[12], pStore); atomicAdd(&A.totals[13], __builtin_readcyclecounter() - pEnd1); }
-        unsigned long long pP2 = __builtin_readcyclecounter();
-#endif
         const unsigned long long tGather = wall_clock64();
         if (sOverflow) {
             if (tid == 0) { A.overflow_list[atomicAdd(A.overflow_count, 1u)] = q - A.q_first; atomicAdd(&A.totals[6], tGather - tStart); atomicAdd(&A.totals[8], 1ull); }
@@ -758,9 +718,6 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
             if (lane == 0 && local) atomicAdd(&sSurv, local);
         }
         __syncthreads();
-#if MK_STREAM_PROF
-        if (tid == 0) atomicAdd(&A.totals[14], __builtin_readcyclecounter() - pP2);
-#endif
         const uint32_t nSurvAll = sSurv;
         if (nSurvAll == 0) continue;
         uint32_t nClasses = 1;
@@ -816,9 +773,6 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
                 }
             }
             __syncthreads();
-#if MK_STREAM_PROF
-            if (tid == 0) atomicAdd(&A.totals[15], (wall_clock64() - tc0));
-#endif
             const uint32_t nSurv = sSurv;
             if (nSurv == 0) continue;
             uint32_t P = WAVE;
@@ -1316,7 +1270,7 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
             // one sort per query (segmented, target bits only) or one over the piece's (query, target) bits: measured both ways
             // (profiles/r03_experiments.txt) -- against 10^5 .. 2*10^6 targets the segmented sort is 2 x faster (configs 2 and 4), against
             // 1.2*10^7 (config-5 scale: 2*10^5 hits per query, 24 target bits) the whole-piece sort is 1.7 x faster.  MK_PREFILTER_SEGSORT=0/1 forces.
-            static const int sortEnv = getenv("MK_PREFILTER_SEGSORT") ? atoi(getenv("MK_PREFILTER_SEGSORT")) : -1;
+            static const int sortEnv = (int) knob_long("MK_PREFILTER_SEGSORT", -1);
             const bool wholeSort = sortEnv >= 0 ? sortEnv == 0 : X.seqBits >= 23;
             const int qBitsCap = wholeSort ? std::min(qBitsLeft, qBitsPass) : qBitsLeft;
             const uint32_t qCap = qBitsCap >= 20 ? QCAP : (qBitsCap < 1 ? 1u : (1u << qBitsCap));
@@ -1483,14 +1437,14 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
                 hSegStart.resize(hSegOut[0]);
                 PCHK(hipMemcpy(hSegStart.data(), dSegStart, (size_t) hSegOut[0] * 4, hipMemcpyDeviceToHost));
                 S.start = dSegStart; S.n = hSegOut[0]; S.stop = hSegOut[1];
-                if (getenv("MK_PREFILTER_DEBUG")) fprintf(stderr, "[prefilter] a query overflows the databaseHits buffer: %u index hits in %u lists, %u segments%s\n",
+                if (knob("MK_PREFILTER_DEBUG")) fprintf(stderr, "[prefilter] a query overflows the databaseHits buffer: %u index hits in %u lists, %u segments%s\n",
                                                           nHits, nLists, hSegOut[0], ovfStopped ? ", one list alone fills the buffer: dropped" : "");
             }
             if (ovfStopped) { q0 = q1; continue; }                        // (:313-315,318-334: nothing is reported for this query)
             // sort by (query, target): only those bits are sorted, the records of a pair stay in arrival order.  The gather pass wrote the
             // records query by query, so the sort is per query over the target bits alone (segments of ~20 K records stay in L2)
             hipcub::DoubleBuffer<uint64_t> kb(dKeys, dKeys2);
-            static const int sortEnv2 = getenv("MK_PREFILTER_SEGSORT") ? atoi(getenv("MK_PREFILTER_SEGSORT")) : -1;
+            static const int sortEnv2 = (int) knob_long("MK_PREFILTER_SEGSORT", -1);
             const bool segSort = sortEnv2 >= 0 ? sortEnv2 != 0 : X.seqBits < 23;
             void *temp = nullptr;
             if (segSort) {
@@ -1637,21 +1591,21 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     // front end: the per-query kernels keep the target id in a 22-bit field of their hit records
     bool useFused = seqBits <= REC_T_BITS;
     if (V.p_sorted || V.kmer_size == 7) useFused = false;   // profile queries, k = 7: k-mer lists in HBM + the global path (the per-query kernels enumerate two 3-mer rows)
-    else if (const char *e = getenv("MK_PREFILTER_PATH")) {
+    else if (const char *e = knob("MK_PREFILTER_PATH")) {
         if (!strcmp(e, "global")) useFused = false;
         else if (strcmp(e, "fused") && strcmp(e, "auto")) { err = "MK_PREFILTER_PATH must be auto, fused or global"; return MK_ERR_ARG; }
     }
     int tierBase = 0;
-    if (const char *e = getenv("MK_PREFILTER_TIERS")) {
+    if (const char *e = knob("MK_PREFILTER_TIERS")) {
         if (!strcmp(e, "tiny")) tierBase = N_TIERS;
         else if (strcmp(e, "default")) { err = "MK_PREFILTER_TIERS must be default or tiny"; return MK_ERR_ARG; }
     }
     const FusedTier *tiers = TIERS + tierBase;
     int nTiersUsed = N_TIERS;                          // MK_PREFILTER_MAX_TIERS: leave the largest tier(s) to the global path
-    if (const char *e = getenv("MK_PREFILTER_MAX_TIERS")) nTiersUsed = std::min(N_TIERS, std::max(1, atoi(e)));
+    if (const char *e = knob("MK_PREFILTER_MAX_TIERS")) nTiersUsed = std::min(N_TIERS, std::max(1, atoi(e)));
     if (hooks.max_tiers > 0) nTiersUsed = std::min(nTiersUsed, hooks.max_tiers);
     int firstTier = 0;                                 // MK_PREFILTER_FIRST_TIER: queries that would fit a smaller tier go to the global path
-    if (const char *e = getenv("MK_PREFILTER_FIRST_TIER")) firstTier = std::max(0, atoi(e));
+    if (const char *e = knob("MK_PREFILTER_FIRST_TIER")) firstTier = std::max(0, atoi(e));
     if (g_memo.entries != (const void *) V.entries || g_memo.nTargets != V.n_targets) { g_memo = SizingMemo(); g_memo.entries = V.entries; g_memo.nTargets = V.n_targets; }
     double candPerQuery = g_memo.candPerQuery, globalHitsPerPos = 0;
     static_assert(N_TIERS == 4, "SizingMemo holds four tiers");
@@ -1785,7 +1739,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                     if (!cus) { int dev = 0; (void) hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
                     int perCu = tiers[t].wgPerCu;
                     if (hooks.co_resident) perCu = std::max(1, tiers[t].waves * perCu > 16 ? 16 / tiers[t].waves : perCu);   // at most 16 waves per CU
-                    if (const char *e = getenv(t == 2 ? "MK_PREFILTER_WG_PER_CU_A" : (t == 3 ? "MK_PREFILTER_WG_PER_CU_B" : "MK_PREFILTER_WG_PER_CU_S"))) perCu = std::max(1, atoi(e));
+                    if (const char *e = knob(t == 2 ? "MK_PREFILTER_WG_PER_CU_A" : (t == 3 ? "MK_PREFILTER_WG_PER_CU_B" : "MK_PREFILTER_WG_PER_CU_S"))) perCu = std::max(1, atoi(e));
                     const unsigned launch = (unsigned) std::min<size_t>(grid, (size_t) cus * perCu);
                     char pn[32];
                     snprintf(pn, sizeof(pn), "pf_pool%d", t);
@@ -1812,14 +1766,11 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             PCHK(sync_wait(stream, "wait_prefilter"));
             for (int k = 0; k < 16; k++) { hFTotals[k] = 0; for (int t = 0; t < N_TIERS; t++) hFTotals[k] += hFTotals[16 * (t + 1) + k]; }
             cs.db_matches += hFTotals[1];
-            if (getenv("MK_PREFILTER_DEBUG"))
+            if (knob("MK_PREFILTER_DEBUG"))
                 for (int t = 0; t < N_TIERS; t++) {
                     const unsigned long long *T = hFTotals + 16 * (t + 1);
                     fprintf(stderr, "[prefilter]   tier %d (%s %d): queries %zu overflowed %llu | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g sort %.3g emit %.3g overflowed %.3g | extra class passes %llu\n",
                             t, "region", tiers[t].cap, lists[t].size(), T[8], (double) T[0], (double) T[1], (double) T[2], (double) T[3], (double) T[4], (double) T[5], (double) T[6], T[9]);
-                    if (MK_STREAM_PROF)
-                        fprintf(stderr, "[prefilter]     wave-cycles pass 1: enumerate %.3g probe-wait %.3g store+bitmaps %.3g idle-at-barrier %.3g | wg-cycles survivor count %.3g | wg-ticks collect %.3g\n",
-                                (double) T[10], (double) T[11], (double) T[12], (double) T[13], (double) T[14], (double) T[15]);
                 }
             const uint32_t nOvf = hCounters[4 + nTiersUsed - 1];               // what even the largest tier in use could not hold
             if (hCounters[0] > CAND_CAP) rc = RC_CAND_OVERFLOW;
@@ -1832,7 +1783,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                         const unsigned long long *T = hFTotals + 16 * (t + 1);
                         ts(thFused[t], 16.0 * (double) T[0] + 6.0 * (double) T[1], (double) T[0]);
                     }
-                if (getenv("MK_PREFILTER_DEBUG"))
+                if (knob("MK_PREFILTER_DEBUG"))
                     fprintf(stderr, "[prefilter] chunk %u..%u: tiers %zu/%zu/%zu/%zu too-long %zu overflow %u | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g (mean wave %.3g) sort %.3g emit %.3g overflowed %.3g | cand %u\n",
                             q0, q1, lists[0].size(), lists[1].size(), lists[2].size(), lists[3].size(), fallback.size(), nOvf, (double) hFTotals[0], (double) hFTotals[1],
                             (double) hFTotals[2], (double) hFTotals[3], (double) hFTotals[7], (double) hFTotals[4], (double) hFTotals[5], (double) hFTotals[6], nCand);
@@ -1927,7 +1878,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             PCHK(hipMemsetAsync(dNum, 0, 64, stream));
             th = tb("select_hits", 35.0 * nCand, 0);
             // (min-ungapped-score 0 keeps zero-score elements under rules of their own: every query at the cut is left to the host's restatement)
-            static const bool hostCutEnv = getenv("MK_PREFILTER_HOST_MAXSEQS") && atoi(getenv("MK_PREFILTER_HOST_MAXSEQS")) != 0;
+            static const bool hostCutEnv = knob_long("MK_PREFILTER_HOST_MAXSEQS", 0) != 0;
             const bool hostCut = hostCutEnv || P.min_ungapped_score <= 0;
             hipLaunchKernelGGL(keep_kernel, dim3((nCand + 255) / 256), dim3(256), 0, stream, C, nCand, P.min_ungapped_score, fin_score_max(seqBits), hostCut, dKept, dPerQ, dPerQ255);
             FinishArgs F;

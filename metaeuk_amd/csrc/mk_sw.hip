@@ -29,6 +29,7 @@
 // "SW recurrence"); the oracle keeps the literal striped semantics and the tests compare against it.
 #include "mk_kernels.hpp"
 #include <algorithm>
+#include <mutex>
 
 namespace mk {
 
@@ -614,11 +615,11 @@ static hipError_t launch_one(const SwLaunch &L, hipStream_t stream) {
     const size_t lds = (size_t) GPB * 24 * G * R;
     const uint64_t blocks = (L.n_jobs + GPB - 1) / GPB;
     if (blocks == 0) return hipSuccess;
-    static bool attr = false;
-    if (!attr && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_kernel<G, R, BLOCK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        if (e != hipSuccess) return e;
-        attr = true;
+    if (lds > 48 * 1024) {                               // once per kernel (several alignment workers launch from their own threads)
+        static std::once_flag once;
+        static hipError_t attrErr = hipSuccess;
+        std::call_once(once, [&] { attrErr = hipFuncSetAttribute(reinterpret_cast<const void *>(&sw_kernel<G, R, BLOCK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); });
+        if (attrErr != hipSuccess) return attrErr;
     }
     hipLaunchKernelGGL((sw_kernel<G, R, BLOCK, false>), dim3((unsigned) blocks), dim3(BLOCK), lds, stream, L);
     return hipGetLastError();

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the library's experiment / test switches (MK_PREFILTER_PATH, MK_TEST_ENTRY_BASE, MK_INDEX_BUILD, MK_CLI_BATCH_NT ...) are read only under
+# MK_DEBUG=1 (metaeuk_amd/csrc/mk_host.cpp: knob); the tests use them to force paths, so the whole session -- and every process it starts -- has it
+os.environ["MK_DEBUG"] = "1"
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
