@@ -517,7 +517,7 @@ static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uin
         if (prebuilt) {
             ok(hipMalloc(reinterpret_cast<void **>(&ix.masked), std::max<uint64_t>(offsets[n], 1)));
             if (e == hipSuccess && offsets[n]) ok(hipMemcpy(ix.masked, prebuilt->masked, offsets[n], hipMemcpyHostToDevice));
-            if (e == hipSuccess) rc = mk::device_index_from_file(prebuilt->fileOffsets, prebuilt->fileEntries6, prebuilt->nEntries, kmerSize, entryShift, g_stream, ix, err);
+            if (e == hipSuccess) rc = mk::device_index_from_file(prebuilt->fileOffsets, prebuilt->fileEntries6, prebuilt->nEntries, kmerSize, entryShift, n, g_stream, ix, err);
         } else {
             HostTimer ht("host_index_build_total");
             mk::IndexBuildParams B;
@@ -1281,6 +1281,7 @@ int mk_prefilter_result_set(mk_queries *q, const mk_hit *hits, const uint64_t *o
     if (offsets[0] != 0) return fail(MK_ERR_ARG, "offsets[0] must be 0");
     q->hitOff.assign(offsets, offsets + q->n + 1);
     q->nHits = offsets[q->n];
+    q->pfStats = mk::PrefilterStats();                  // an installed result has no k-mer / index-match counters (they belonged to the run that made it)
     if (!q->hits.reserve(std::max<size_t>(q->nHits, 1) * sizeof(mk_hit), 0)) return fail(MK_ERR_DEVICE, "pinned host allocation failed");
     if (q->nHits) std::memcpy(q->hits.p, hits, q->nHits * sizeof(mk_hit));
     q->havePref = true;
@@ -1503,6 +1504,14 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     // passes are one launch per tile configuration and chunk, and short launches beside the persistent prefilter workgroups run at a third of
     // their speed
     hooks.max_chunk_queries = 1u << 18;
+    // ... of a full 2.0 M-query batch.  A shard of that batch (1/8 of it on an 8-GPU node: 251 k queries) would be three chunks, with next to
+    // nothing for the two stages to overlap: the chunk follows the batch -- the largest power of two below a sixth of it, 32 768 at least
+    // (profiles/r04_shard_sweep.txt)
+    {
+        uint32_t lim = 1u << 18;
+        while (lim > (1u << 15) && (uint64_t) lim * 6 > (uint64_t) q->n) lim >>= 1;
+        hooks.max_chunk_queries = lim;
+    }
     hooks.chunk_ramp = true;
     hooks.co_resident = true;
     hooks.t_masked_host = [db]() { return masked_host(db); };

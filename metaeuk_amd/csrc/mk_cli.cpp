@@ -520,6 +520,7 @@ int splitPrefilter(mk_queries *Q, size_t nq, const mk::Database &tdb, const mk_p
         mk_targetdb *TS = nullptr;
         if (mk_targetdb_create(tres.data(), toff.data(), (uint32_t) count, &PS, &TS) != MK_OK) return die("%s", mk_last_error());
         if (mk_prefilter(TS, Q, &PS) != MK_OK) return die("%s", mk_last_error());
+        printPrefilterStatistics(Q, PS);                  // the reference logs the statistics of every split's run (Prefiltering::runSplit, :889-904)
         const mk_hit *hits; const uint64_t *hoff;
         mk_prefilter_result(Q, &hits, &hoff);
         for (size_t i = 0; i < nq; i++)

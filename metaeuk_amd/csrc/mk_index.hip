@@ -546,17 +546,24 @@ __global__ __launch_bounds__(1024) void long_global_step_kernel(const uint64_t *
 }
 
 // ---- index DB <-> device ------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lens_from_offsets_kernel(const uint64_t *off /* [n + 1], piece */, uint64_t n, uint32_t *count) {
+// (a file is not trusted: offsets that fall, a list of 2^23 entries or more and target numbers beyond the database are counted in bad[0..1];
+//  the prefilter kernels would read out of bounds through them)
+__global__ __launch_bounds__(256) void lens_from_offsets_kernel(const uint64_t *off /* [n + 1], piece */, uint64_t n, uint32_t *count, unsigned long long *bad) {
     const uint64_t k = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) count[k] = (uint32_t) (off[k + 1] - off[k]);
+    if (k >= n) return;
+    const uint64_t a = off[k], b = off[k + 1];
+    const bool ok = b >= a && b - a < (1ull << 23);
+    count[k] = ok ? (uint32_t) (b - a) : 0u;
+    if (!ok) atomicAdd(&bad[0], 1ull);
 }
-__global__ __launch_bounds__(256) void expand6_kernel(const unsigned char *raw, uint64_t n, uint64_t *out) {
+__global__ __launch_bounds__(256) void expand6_kernel(const unsigned char *raw, uint64_t n, uint64_t *out, uint32_t nSeq, unsigned long long *bad) {
     const uint64_t k = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const unsigned char *p = raw + k * 6;
     const uint32_t seq = (uint32_t) p[0] | ((uint32_t) p[1] << 8) | ((uint32_t) p[2] << 16) | ((uint32_t) p[3] << 24);
     const uint32_t pos = (uint32_t) p[4] | ((uint32_t) p[5] << 8);
     out[k] = (uint64_t) seq | ((uint64_t) pos << 32);
+    if (seq >= nSeq) atomicAdd(&bad[1], 1ull);
 }
 __global__ __launch_bounds__(256) void pack6_kernel(const uint64_t *in, uint64_t n, unsigned char *raw) {
     const uint64_t k = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -743,7 +750,8 @@ int device_build_index(const uint8_t *dRes, const uint64_t *dOff, const std::vec
     ICHK(hipMemsetAsync(dCount.p, 0, cells * 4, stream));
     ICHK(hipMemsetAsync(dFirst.p, 0, nWords * 4, stream));
     C.count = dCount.p; C.first_bits = dFirst.p; C.entries = nullptr; C.slots = nullptr;
-    const uint32_t GRID_MAX = 1u << 30;
+    // workgroups per launch: the HIP runtime refuses launches of 2^32 threads or more (gridDim.x * blockDim.x), and CT = 256
+    const uint32_t GRID_MAX = (uint32_t) knob_long("MK_TEST_INDEX_GRID_MAX", 1l << 22);
     {
         const int th = tb ? tb("index_count", (double) total * 5.0, 0) : -1;
         for (uint32_t s0 = 0; s0 < nSeq; s0 += GRID_MAX) {
@@ -801,10 +809,14 @@ int device_index_from_lists(uint32_t *dCount, uint64_t *dEntriesIn, uint64_t cel
 }
 
 int device_index_from_file(const uint64_t *hostOffsets, const unsigned char *hostEntries6, uint64_t nEntries, int kmerSize, uint64_t entryShift,
-                           hipStream_t stream, DeviceIndex &out, std::string &err) {
+                           uint32_t nSeq, hipStream_t stream, DeviceIndex &out, std::string &err) {
     const uint64_t cells = kmerSize == 7 ? 1280000000ull : 64000000ull;
+    if (hostOffsets[0] != 0 || hostOffsets[cells] != nEntries) { err = "the k-mer list offsets of the index do not add up to its entries"; return MK_ERR_ARG; }
     Tmp<uint32_t> dCount;
+    Tmp<unsigned long long> dBad;
     ICHK(dCount.alloc(cells));
+    ICHK(dBad.alloc(2));
+    ICHK(hipMemsetAsync(dBad.p, 0, 16, stream));
     const uint64_t PIECE = 1ull << 26;                                   // cells / entries per upload
     {
         Tmp<uint64_t> dOffPiece;
@@ -812,23 +824,30 @@ int device_index_from_file(const uint64_t *hostOffsets, const unsigned char *hos
         for (uint64_t c0 = 0; c0 < cells; c0 += PIECE) {
             const uint64_t n = std::min(PIECE, cells - c0);
             ICHK(hipMemcpyAsync(dOffPiece.p, hostOffsets + c0, (n + 1) * 8, hipMemcpyHostToDevice, stream));
-            hipLaunchKernelGGL(lens_from_offsets_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, dOffPiece.p, n, dCount.p + c0);
+            hipLaunchKernelGGL(lens_from_offsets_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, dOffPiece.p, n, dCount.p + c0, dBad.p);
             ICHK(hipStreamSynchronize(stream));
         }
     }
-    uint64_t *dEntries = nullptr;
-    ICHK(hipMalloc(reinterpret_cast<void **>(&dEntries), std::max<uint64_t>(nEntries, 1) * 8));
+    Tmp<uint64_t> dEntries;                                              // (handed over to the index at the end: an error on the way frees it)
+    ICHK(dEntries.alloc(std::max<uint64_t>(nEntries, 1)));
     {
         Tmp<unsigned char> dRaw;
         ICHK(dRaw.alloc(PIECE * 6));
         for (uint64_t e0 = 0; e0 < nEntries; e0 += PIECE) {
             const uint64_t n = std::min(PIECE, nEntries - e0);
             ICHK(hipMemcpyAsync(dRaw.p, hostEntries6 + e0 * 6, n * 6, hipMemcpyHostToDevice, stream));
-            hipLaunchKernelGGL(expand6_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, dRaw.p, n, dEntries + e0);
+            hipLaunchKernelGGL(expand6_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, dRaw.p, n, dEntries.p + e0, nSeq, dBad.p);
             ICHK(hipStreamSynchronize(stream));
         }
     }
-    return device_index_from_lists(dCount.p, dEntries, cells, nEntries, entryShift, stream, out, err);
+    unsigned long long bad[2] = {0, 0};
+    ICHK(hipMemcpy(bad, dBad.p, 16, hipMemcpyDeviceToHost));
+    if (bad[0]) { err = "corrupt index DB: " + std::to_string(bad[0]) + " k-mer list offsets fall or span 2^23 entries or more"; return MK_ERR_ARG; }
+    if (bad[1]) { err = "corrupt index DB: " + std::to_string(bad[1]) + " entries name a sequence beyond the database's " + std::to_string(nSeq); return MK_ERR_ARG; }
+    uint64_t *ent = dEntries.take();
+    const int rc = device_index_from_lists(dCount.p, ent, cells, nEntries, entryShift, stream, out, err);
+    if (rc != MK_OK && out.entries != ent) (void) hipFree(ent);          // (normally out.entries == ent and the caller's release() frees it)
+    return rc;
 }
 
 int device_index_offsets(const DeviceIndex &ix, hipStream_t stream, std::vector<uint64_t> &offsets, std::string &err) {

@@ -47,8 +47,9 @@ int device_index_from_lists(uint32_t *dCount, uint64_t *dEntriesIn, uint64_t cel
 // index DB -> device (cells in the reference's numbering: what the device tables use for k = 7): list lengths from the offsets, the
 // 6-byte IndexEntryLocal records expanded to 8 bytes.  hostOffsets[cells + 1], hostEntries6 = nEntries * 6 bytes (both may be mmap'd
 // file contents: they are read once, in pieces)
+// The file is not trusted: offsets that fall, lists of 2^23 entries or more and entries naming a sequence >= nSeq are an error, not a crash.
 int device_index_from_file(const uint64_t *hostOffsets, const unsigned char *hostEntries6, uint64_t nEntries, int kmerSize, uint64_t entryShift,
-                           hipStream_t stream, DeviceIndex &out, std::string &err);
+                           uint32_t nSeq, hipStream_t stream, DeviceIndex &out, std::string &err);
 
 // device index (cells in the reference's numbering) -> the arrays of an index DB: the k-mer list offsets (offsets[cells + 1]) ...
 int device_index_offsets(const DeviceIndex &ix, hipStream_t stream, std::vector<uint64_t> &offsets, std::string &err);

@@ -74,6 +74,55 @@ def test_device_index_equals_the_host_builder(gpu_api):
         a.close(); b.close()
 
 
+def test_device_index_in_several_launches(gpu_api, monkeypatch):
+    """count / fill launches are capped (the HIP runtime refuses 2^32 threads per launch: 16.7 M sequences of 256 lanes): with a cap of 97
+    workgroups the 1 200 edge sequences take a dozen launches each and give the same tables"""
+    api = gpu_api
+    seqs = _edge_targets()
+    p = api.default_params()
+    a = api.TargetDB(seqs, p)
+    monkeypatch.setenv("MK_TEST_INDEX_GRID_MAX", "97")
+    b = api.TargetDB(seqs, p)
+    _assert_same(a, b, "grid cap 97")
+    p.kmer_size = 7
+    c = api.TargetDB(seqs, p)
+    monkeypatch.delenv("MK_TEST_INDEX_GRID_MAX")
+    d = api.TargetDB(seqs, p)
+    _assert_same(c, d, "grid cap 97, k = 7")
+    for x in (a, b, c, d):
+        x.close()
+
+
+def test_corrupt_k7_index_db_is_an_error_not_a_crash(gpu_api, tmp_path):
+    """an index DB is not trusted: an entry that names a sequence beyond the database, or k-mer list offsets that fall, are reported
+    (mk_targetdb_open_index) instead of becoming out-of-bounds reads of the prefilter kernels"""
+    import shutil
+    import struct
+    api = gpu_api
+    targets = _text("e2e_targets.txt.gz").splitlines()[:60]
+    keys = list(range(len(targets)))
+    p = api.default_params()
+    p.kmer_size = 7
+    api.index_write(str(tmp_path / "good.idx"), api.seq_db_image(targets, keys), p)
+    db = api.TargetDB.from_index(str(tmp_path / "good.idx"), p)
+    assert db.kmer_size() == 7 and db.index_entries() > 1000
+    db.close()
+    where = {int(l.split("\t")[0]): (int(l.split("\t")[1]), int(l.split("\t")[2])) for l in open(tmp_path / "good.idx.index")}
+    for name, key, patch in (("entry", 9, lambda blob: struct.pack("<I", 4000000000) + blob[4:]),            # ENTRIES: first record's sequence number
+                             ("offsets", 10, lambda blob: blob[:8 * 1000] + struct.pack("<Q", 1 << 50) + blob[8 * 1001:])):   # ENTRIESOFFSETS: one huge offset
+        for ext in ("", ".index", ".dbtype"):
+            shutil.copy(str(tmp_path / "good.idx") + ext, str(tmp_path / (name + ".idx")) + ext)
+        off, length = where[key]
+        with open(tmp_path / (name + ".idx"), "r+b") as f:
+            f.seek(off)
+            blob = f.read(length)
+            f.seek(off)
+            f.write(patch(blob))
+        with pytest.raises(Exception) as e:
+            api.TargetDB.from_index(str(tmp_path / (name + ".idx")), p)
+        assert "corrupt index DB" in str(e.value) or "do not add up" in str(e.value), str(e.value)
+
+
 def test_device_index_long_lists_and_the_e2e_fixture(gpu_api):
     """10 000 near-copies of one protein: k-mer lists of 10 000 targets (the bitonic network in HBM, strides beyond one LDS chunk), and
     the e2e fixture's 200 proteins"""

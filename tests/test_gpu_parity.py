@@ -498,6 +498,35 @@ def test_search_equals_prefilter_then_align(gpu_api, pf_path):
     assert api.format_alignments(alns1, 0, n) == api.format_alignments(alns2, 0, n)
 
 
+def test_two_databases_interleaved_between_align_and_search(gpu_api):
+    """The alignment stage keeps its e-value / bit-score tables on the device per scratch lane: worker 0 of mk_search and the caller of
+    mk_align share lane 0.  mk_align(A), mk_search(B), mk_align(A) again must not align A against B's tables: the
+    databases differ in size, hence in every e-value."""
+    from metaeuk_amd import synth
+    api = gpu_api
+    tA, queries = synth.make_workload(20, 400, seed=31)
+    tB, _ = synth.make_workload(20, 2500, seed=32)
+    tB = list(tA)[:150] + list(tB)                          # shares homologs with the queries, five times the residues
+    params = api.default_params()
+    dbA, dbB = api.TargetDB(list(tA), params), api.TargetDB(tB, params)
+    def run_align(db):
+        q = api.Queries(queries, params)
+        api.prefilter(db, q)
+        alns, aoff = api.align(db, q)
+        return api.format_alignments(alns, 0, int(aoff[-1]))
+    def run_search(db):
+        q = api.Queries(queries, params)
+        (_, _), (alns, aoff) = api.search(db, q)
+        return api.format_alignments(alns, 0, int(aoff[-1]))
+    a1 = run_align(dbA)
+    b1 = run_search(dbB)
+    a2 = run_align(dbA)
+    b2 = run_align(dbB)
+    a3 = run_search(dbA)
+    assert len(a1) > 2000 and a1 != b1
+    assert a1 == a2 == a3 and b1 == b2
+
+
 def test_long_and_degenerate_inputs(gpu_api, tmp_path, pf_path):
     """queries beyond the largest SW tile (row tiles with an HBM border), long targets, query == target (prefilter scores
     above 255), queries without any k-mer, and an empty batch"""
