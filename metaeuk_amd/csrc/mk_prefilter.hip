@@ -879,6 +879,404 @@ void launch_stream(int tier, const StreamArgs &A, unsigned grid, hipStream_t str
 }
 
 // =====================================================================================================
+//  A'. the wide per-query kernel: any k-mer source, 27-bit targets, a million hits per query
+// =====================================================================================================
+// Round 4.  stream_kernel holds a query's hits in ONE region, filters them with two LDS bitmaps over the targets and sorts the
+// survivors in LDS; that works while the hits are few against the bitmap (128 K bits).  A fragment searched against a UniRef50-scale
+// database gathers 2*10^5 ... 10^6 index hits (k = 7), a profile query 10^5: the bitmaps saturate, every hit "survives", and until
+// round 4 such queries took the sort-based global path -- two probe passes, the similar k-mers materialised, a device-wide radix sort.
+// Here the region is PARTITIONED: a hit goes to one of NCLS target classes (a hash of the target; one LDS atomic per hit gives its slot
+// in the class), and pass 2 walks the classes in groups of at most GROUP_MAX records -- per group the two bitmaps, the survivor sort and
+// the double-diagonal rule of stream_kernel.  Every record is read twice whatever the number of hits; a target lives in one class, so the
+// candidates of a (query, target) pair still leave the kernel contiguous and in arrival order.  Records are 8 + 4 bytes: target (27 bits)
+// | diagonal | k-mer start, and the hit's ordinal within its start -- the arrival rank (start prefix + ordinal) has 21 bits.
+// The k-mers come from the enumerator of the k = 6 table (MODE 0), from lists in HBM (MODE 1: profile queries, k = 7), or from the
+// in-wave 7-mer enumerator (MODE 2).
+constexpr uint32_t W_T_BITS = 27, W_RANK_BITS = 21;            // + 16 bits of diagonal = 64 (sort key: target | rank | diagonal)
+constexpr int W_MODE_ENUM6 = 0, W_MODE_LIST = 1;
+struct WideArgs {
+    PrefilterDeviceView V;
+    const uint32_t *queries; uint32_t n_queries;      // view query ids, most expensive first
+    uint32_t q_first;                                 // candidates carry q - q_first
+    CandArrays C; uint32_t cand_cap;
+    uint32_t *counters;                               // [0] candidates appended
+    uint32_t *overflow_list; uint32_t *overflow_count;   // queries this kernel could not hold (view id - q_first): the global path takes them
+    unsigned long long *totals;                       // as StreamArgs::totals
+    uint32_t *work_counter;
+    uint64_t *pool; uint32_t *pool_ord;               // gridDim.x regions of NCLS * CLS_CAP records
+    const uint16_t *pos_cost; uint64_t pos_begin;     // MODE 0: work estimate of every k-mer start (kmer_count_kernel)
+};
+
+template <int CLS_CAP, int NCLS, int GROUP_MAX, int SURV, int MBITS, int MAXPOS, int NW, int U, int MODE>
+__global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {
+    constexpr int BLOCK = NW * WAVE;
+    constexpr int LOG_MBITS = ilog2(MBITS), LOG_NCLS = ilog2(NCLS);
+    constexpr int TSHIFT = 16 + (int) W_RANK_BITS;
+    static_assert((SURV & (SURV - 1)) == 0 && (MBITS & (MBITS - 1)) == 0 && (NCLS & (NCLS - 1)) == 0, "powers of two");
+    static_assert((uint64_t) NCLS * CLS_CAP <= (1ull << W_RANK_BITS) && MAXPOS <= 4096 && W_T_BITS + TSHIFT <= 64, "record / key fields");
+    static_assert(NCLS <= STREAM_MAX_CLASSES && GROUP_MAX >= SURV, "class tables");
+    struct Pass1Lds { enumk::EnumLds<U> e[NW]; uint8_t mark[NW][WAVE]; };
+    constexpr size_t RAW = sizeof(Pass1Lds) > sizeof(uint64_t) * SURV ? sizeof(Pass1Lds) : sizeof(uint64_t) * SURV;
+    __shared__ __attribute__((aligned(16))) uint8_t sRaw[RAW];
+    uint64_t *sKey = reinterpret_cast<uint64_t *>(sRaw);
+    Pass1Lds &P1 = *reinterpret_cast<Pass1Lds *>(sRaw);
+    __shared__ uint32_t sBm1[MBITS / 32], sBm2[MBITS / 32];
+    __shared__ uint32_t sPosBase[MAXPOS];
+    constexpr int ORDER_N = MAXPOS < 64 ? 64 : MAXPOS;
+    static_assert(RAW >= sizeof(uint32_t) * ORDER_N, "the start order is sorted in the shared scratch");
+    __shared__ uint16_t sOrder[ORDER_N];
+    __shared__ uint32_t sNumOrder;
+    __shared__ uint32_t sFlagBits[SURV / 32 + 2], sWordPrefix[SURV / 32 + 2];
+    __shared__ uint32_t sWaveHits[NW], sWaveKmers[NW], sWavePos[NW];
+    __shared__ uint32_t sClsUsed[NCLS];               // records in every target class
+    __shared__ uint32_t sSubCnt[STREAM_MAX_CLASSES];
+    __shared__ uint32_t sNextPos, sOverflow, sItem, sSurv, sEmitBase, sEmitCount, sSubMax;
+
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, w = tid / WAVE, lane = tid & (WAVE - 1);
+    uint64_t *region = A.pool + (size_t) blockIdx.x * NCLS * CLS_CAP;
+    uint32_t *regionOrd = A.pool_ord + (size_t) blockIdx.x * NCLS * CLS_CAP;
+    constexpr uint64_t TMASK = (1ull << W_T_BITS) - 1ull;
+    const auto survives = [&](uint64_t rec) -> bool {
+        const uint32_t hb = ((uint32_t) (rec & TMASK) * 0x9E3779B1u) >> (32 - LOG_MBITS);
+        return ((sBm2[hb >> 5] >> (hb & 31u)) & 1u) || ((uint32_t) (rec >> W_T_BITS) & 0xFFu) == 0u;
+    };
+    const auto sub_of = [&](uint64_t rec, uint32_t nSub) -> uint32_t { return (((uint32_t) (rec & TMASK) * 0x85EBCA6Bu) >> 8) % nSub; };
+    for (;;) {
+        __syncthreads();                                  // the previous query's LDS is no longer read
+        if (tid == 0) sItem = atomicAdd(A.work_counter, 1u);
+        __syncthreads();
+        const uint32_t item = sItem;
+        if (item >= A.n_queries) break;
+        const uint32_t q = A.queries[item];
+        const uint64_t qs = A.V.q_off[q];
+        const int L = (int) (A.V.q_off[q + 1] - qs);
+        const int span = A.V.kmer_size == 7 ? 11 : 10;
+        const int nStart = L >= span ? L - span + 1 : 0;
+        if (tid == 0) { sOverflow = nStart > MAXPOS ? 1u : 0u; sNextPos = 0; sSurv = 0; }
+        for (int k = tid; k < NCLS; k += BLOCK) sClsUsed[k] = 0;
+        const int nOrd = min(nStart, MAXPOS);
+        uint32_t PO = WAVE;
+        while ((int) PO < nOrd) PO <<= 1;
+        for (int k = tid; k < nOrd; k += BLOCK) sPosBase[k] = 0;
+        uint32_t *sOrdKey = reinterpret_cast<uint32_t *>(sRaw);      // cost << 12 | start (the scratch is free until pass 1 begins)
+        for (int k = tid; k < (int) PO; k += BLOCK) {
+            uint32_t cost = 0;
+            if (k < nOrd) {
+                if (MODE == W_MODE_LIST) {
+                    const uint64_t pl = qs + (uint64_t) k - A.V.klist_pos0;
+                    cost = (uint32_t) min((A.V.klist_off[pl + 1] - A.V.klist_off[pl] + 3ull) >> 2, (unsigned long long) 65535);
+                } else cost = A.pos_cost[qs - A.pos_begin + (uint64_t) k];
+            }
+            sOrdKey[k] = k < nOrd ? (cost << 12) | (uint32_t) k : 0u;
+        }
+        if (tid == 0) sNumOrder = 0;
+        __syncthreads();
+        // descending bitonic sort of the k-mer starts by cost (starts without k-mers, cost 0, come last)
+        for (uint32_t k = 2; k <= PO; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = (uint32_t) tid; i < (PO >> 1); i += BLOCK) {
+                    const uint32_t l = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
+                    const uint32_t r2 = l | j;
+                    const uint32_t x = sOrdKey[l], y = sOrdKey[r2];
+                    const bool up = (l & k) == 0;
+                    if ((x < y) == up) { sOrdKey[l] = y; sOrdKey[r2] = x; }
+                }
+                __syncthreads();
+            }
+        }
+        for (int k = tid; k < nOrd; k += BLOCK) {
+            const uint32_t key = sOrdKey[k];
+            sOrder[k] = (uint16_t) (key & 0xFFFu);
+            if ((key >> 12) != 0u && (k + 1 == nOrd || (sOrdKey[k + 1] >> 12) == 0u)) sNumOrder = (uint32_t) k + 1u;
+        }
+        __syncthreads();
+        const int nWork = (int) sNumOrder;
+        const unsigned long long tStart = wall_clock64();
+
+        // ---- pass 1: k-mers -> index probes; every hit into the region of its target class
+        uint32_t whits = 0, kmers = 0, npos = 0;
+        bool dead = false;
+        while (!dead) {
+            uint32_t iu = 0;
+            if (lane == 0) iu = atomicAdd(&sNextPos, 1u);
+            const int io = __builtin_amdgcn_readfirstlane((int) iu);
+            if (io >= nWork) break;                        // (what is left are starts without k-mers)
+            const int i = (int) sOrder[io];
+            const uint64_t p = qs + (uint64_t) i;
+            const int thr = (int) A.V.q_kmer_thr[p];
+            if (thr < 0) continue;
+            if (*(volatile uint32_t *) &sOverflow) { dead = true; break; }
+            npos++;
+            uint32_t wcount = 0;                           // hits of this k-mer start so far
+            const auto onBatch = [&](const uint32_t (&kmer)[U], const bool (&has)[U]) -> bool {
+                    uint32_t size[U], ex[U];
+                    uint64_t o0[U];
+                    uint64_t ent0[U];
+                    bool inl[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        size[u] = 0; o0[u] = 0; ent0[u] = 0; inl[u] = true;
+                        if (has[u] && kmer_present(A.V.kmer_bits, kmer[u])) { const KmerList l = load_kmer_list(A.V.kmer_slot, kmer[u]); o0[u] = l.first; size[u] = l.size; ent0[u] = l.ent0; inl[u] = l.isInline; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) if (!inl[u]) ent0[u] = ld_probe(A.V.entries + o0[u]);
+                    uint32_t totAll = 0;
+#pragma unroll
+                    for (int u = 0; u < U; u++) { const uint32_t incl = enumk::wave_incl_scan(size[u]); ex[u] = incl - size[u] + totAll; totAll += enumk::wave_last(incl); }
+                    if (totAll == 0) return true;
+                    bool over = false;
+                    const auto put = [&](uint64_t ent, uint32_t rel) {
+                        const uint32_t tgt = (uint32_t) ent;
+                        const uint32_t diag = ((uint32_t) i - ((uint32_t) (ent >> 32) & 0xFFFFu)) & 0xFFFFu;
+                        const uint32_t cls = (tgt * 2654435761u) >> (32 - LOG_NCLS);
+                        const uint32_t slot = atomicAdd(&sClsUsed[cls], 1u);
+                        if (slot < (uint32_t) CLS_CAP) {
+                            const size_t at = (size_t) cls * CLS_CAP + slot;
+                            region[at] = (uint64_t) tgt | ((uint64_t) diag << W_T_BITS) | ((uint64_t) (uint32_t) i << (W_T_BITS + 16));
+                            regionOrd[at] = wcount + rel;
+                        } else over = true;
+                    };
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const uint32_t r0 = ex[u];
+                        if (size[u]) put(ent0[u], r0);
+                        enumk::wave_deal_tail(size[u] > 1 ? size[u] - 1 : 0u, lane, P1.mark[w], [&](uint32_t owner, uint32_t e, bool valid) {
+                            const uint64_t oFirst = wave_read_lane64(o0[u], owner);
+                            const uint32_t oR0 = enumk::wave_read_lane(r0, owner);
+                            if (valid) put(ld_probe(A.V.entries + oFirst + e), oR0 + e);
+                        });
+                    }
+                    wcount += totAll;
+                    if (__ballot(over) != 0ull) { dead = true; if (lane == 0) sOverflow = 1; return false; }   // a class is full: the global path takes the query
+                    return true;
+                };
+            if constexpr (MODE == W_MODE_LIST) {
+                const uint64_t pl = p - A.V.klist_pos0;
+                const uint64_t l0 = A.V.klist_off[pl], l1 = A.V.klist_off[pl + 1];
+                kmers += enumerate_list<U>(A.V.klist + l0, (uint32_t) (l1 - l0), lane, onBatch);
+            } else {
+                kmers += enumk::enumerate_position<U>(A.V, A.V.q_res + p, thr, lane, P1.e[w], onBatch);
+            }
+            if (lane == 0) sPosBase[i] = wcount;
+            whits += wcount;
+        }
+        if (lane == 0) { sWaveHits[w] = whits; sWaveKmers[w] = kmers; sWavePos[w] = npos; atomicAdd(&A.totals[7], (wall_clock64() - tStart) / NW); }
+        __syncthreads();                                   // (also orders the region stores before the reads of pass 2)
+        const unsigned long long tGather = wall_clock64();
+        if (sOverflow) {
+            if (tid == 0) { A.overflow_list[atomicAdd(A.overflow_count, 1u)] = q - A.q_first; atomicAdd(&A.totals[6], tGather - tStart); atomicAdd(&A.totals[8], 1ull); }
+            continue;
+        }
+        uint32_t hitsAll = 0;
+        for (int k = 0; k < NW; k++) hitsAll += sWaveHits[k];
+        if (tid == 0) {
+            uint32_t km = 0, np = 0;
+            for (int k = 0; k < NW; k++) { km += sWaveKmers[k]; np += sWavePos[k]; }
+            atomicAdd(&A.totals[0], (unsigned long long) km);
+            atomicAdd(&A.totals[1], (unsigned long long) hitsAll);
+            atomicAdd(&A.totals[2], (unsigned long long) np);
+        }
+        if (hitsAll == 0) continue;
+        // arrival rank of a hit = hits of the earlier k-mer starts + its ordinal
+        if (w == 0) {
+            const uint32_t perLane = ((uint32_t) nStart + WAVE - 1) / WAVE;
+            const uint32_t b = min((uint32_t) nStart, (uint32_t) lane * perLane), e = min((uint32_t) nStart, b + perLane);
+            uint32_t sum = 0;
+            for (uint32_t k = b; k < e; k++) sum += sPosBase[k];
+            uint32_t run = enumk::wave_incl_scan(sum) - sum;
+            for (uint32_t k = b; k < e; k++) { const uint32_t c = sPosBase[k]; sPosBase[k] = run; run += c; }
+        }
+        __syncthreads();
+        unsigned long long tSortAcc = 0, tEmitAcc = 0;
+        // ---- pass 2: the classes in groups of at most GROUP_MAX records (a single class may hold more)
+        for (uint32_t c0 = 0; c0 < (uint32_t) NCLS; ) {
+            uint32_t c1 = c0, recs = 0;
+            while (c1 < (uint32_t) NCLS && (c1 == c0 || recs + sClsUsed[c1] <= (uint32_t) GROUP_MAX)) { recs += sClsUsed[c1]; c1++; }
+            const uint32_t g0 = c0, g1 = c1;
+            c0 = c1;
+            if (recs == 0) continue;
+            const unsigned long long tc0 = wall_clock64();
+            // the records of the group, BLOCK at a time (every thread of the workgroup takes part in every step)
+            const auto sweep = [&](auto &&fn) {
+                for (uint32_t c = g0; c < g1; c++) {
+                    const uint32_t nC = sClsUsed[c];
+                    const size_t base = (size_t) c * CLS_CAP;
+                    for (uint32_t s0 = 0; s0 < nC; s0 += BLOCK) {
+                        const uint32_t s = s0 + (uint32_t) tid;
+                        fn(s < nC, base + s);
+                    }
+                }
+            };
+            __syncthreads();                               // (the previous group's bitmaps and keys are no longer read)
+            for (int k = tid; k < MBITS / 32; k += BLOCK) { sBm1[k] = 0; sBm2[k] = 0; }
+            if (tid == 0) sSurv = 0;
+            __syncthreads();
+            // ---- 2a: target buckets hit once / twice
+            sweep([&](bool valid, size_t at) {
+                if (!valid) return;
+                const uint64_t rec = region[at];
+                const uint32_t hb = ((uint32_t) (rec & TMASK) * 0x9E3779B1u) >> (32 - LOG_MBITS);
+                const uint32_t bit = 1u << (hb & 31u);
+                if (atomicOr(&sBm1[hb >> 5], bit) & bit) atomicOr(&sBm2[hb >> 5], bit);
+            });
+            __syncthreads();
+            // ---- 2b: how many records survive; target sub-classes if they do not fit the LDS sort at once
+            {
+                uint32_t local = 0;
+                sweep([&](bool valid, size_t at) { if (valid && survives(region[at])) local++; });
+                local = wave_sum(local);
+                if (lane == 0 && local) atomicAdd(&sSurv, local);
+            }
+            __syncthreads();
+            const uint32_t nSurvAll = sSurv;
+            if (nSurvAll == 0) continue;
+            uint32_t nSub = 1;
+            if (nSurvAll > (uint32_t) SURV) {
+                nSub = (nSurvAll + (uint32_t) (SURV * 3 / 4) - 1) / (uint32_t) (SURV * 3 / 4);
+                for (;;) {
+                    if (nSub > (uint32_t) STREAM_MAX_CLASSES) nSub = STREAM_MAX_CLASSES;
+                    __syncthreads();
+                    for (uint32_t k = (uint32_t) tid; k < nSub; k += BLOCK) sSubCnt[k] = 0;
+                    if (tid == 0) sSubMax = 0;
+                    __syncthreads();
+                    sweep([&](bool valid, size_t at) {
+                        if (!valid) return;
+                        const uint64_t rec = region[at];
+                        if (survives(rec)) atomicAdd(&sSubCnt[sub_of(rec, nSub)], 1u);
+                    });
+                    __syncthreads();
+                    for (uint32_t k = (uint32_t) tid; k < nSub; k += BLOCK) atomicMax(&sSubMax, sSubCnt[k]);
+                    __syncthreads();
+                    if (sSubMax <= (uint32_t) SURV || nSub == (uint32_t) STREAM_MAX_CLASSES) break;
+                    nSub += 1 + nSub / 4;
+                }
+                if (tid == 0) atomicAdd(&A.totals[9], (unsigned long long) (nSub - 1));
+            }
+            // (GROUP_MAX <= STREAM_MAX_CLASSES * SURV / 2 for every shape in use: the sub-classes always fit; a sub-class that does not -- a
+            //  single target with more than SURV hits in the group -- is cut at SURV below and flagged)
+            for (uint32_t sub = 0; sub < nSub; sub++) {
+                const unsigned long long ts0 = wall_clock64();
+                __syncthreads();
+                if (tid == 0) sSurv = 0;
+                __syncthreads();
+                // ---- 2c: survivors of this sub-class -> LDS sort keys (any order: the key carries the arrival rank)
+                sweep([&](bool valid, size_t at) {
+                    bool surv = false;
+                    uint64_t rec = 0;
+                    if (valid) {
+                        rec = region[at];
+                        surv = survives(rec) && (nSub == 1 || sub_of(rec, nSub) == sub);
+                    }
+                    const unsigned long long m = __ballot(surv);
+                    if (m == 0) return;
+                    uint32_t wbase = 0;
+                    if (lane == 0) wbase = atomicAdd(&sSurv, (uint32_t) __popcll(m));
+                    wbase = (uint32_t) __builtin_amdgcn_readfirstlane((int) wbase);
+                    if (surv) {
+                        const uint32_t slot = wbase + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+                        if (slot < (uint32_t) SURV) {
+                            const uint32_t pos = (uint32_t) (rec >> (W_T_BITS + 16)) & 0xFFFu;
+                            const uint32_t rank = sPosBase[pos] + regionOrd[at];
+                            sKey[slot] = ((rec & TMASK) << TSHIFT) | ((uint64_t) rank << 16) | ((rec >> W_T_BITS) & 0xFFFFull);
+                        }
+                    }
+                });
+                __syncthreads();
+                uint32_t nSurv = sSurv;
+                if (nSurv > (uint32_t) SURV) { if (tid == 0) atomicAdd(&A.totals[10], 1ull); nSurv = SURV; }     // (reported by the host as an error: never seen)
+                if (nSurv == 0) continue;
+                uint32_t P = WAVE;
+                while (P < nSurv) P <<= 1;
+                for (uint32_t s = nSurv + (uint32_t) tid; s < P; s += BLOCK) sKey[s] = ~0ull;
+                __syncthreads();
+                // ---- bitonic sort (keys are distinct: (target, rank) is unique)
+                for (uint32_t k = 2; k <= P; k <<= 1) {
+                    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                        for (uint32_t i = (uint32_t) tid; i < (P >> 1); i += BLOCK) {
+                            const uint32_t l = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
+                            const uint32_t r2 = l | j;
+                            const uint64_t x = sKey[l], y = sKey[r2];
+                            const bool up = (l & k) == 0;
+                            if ((x > y) == up) { sKey[l] = y; sKey[r2] = x; }
+                        }
+                        __syncthreads();
+                    }
+                }
+                const unsigned long long ts1 = wall_clock64();
+                // ---- the double-diagonal rule on the target runs -> flag bits
+                for (uint32_t t0 = 0; t0 < P; t0 += BLOCK) {
+                    const uint32_t t = t0 + (uint32_t) tid;
+                    bool emit = false;
+                    const uint64_t key = t < P ? sKey[t] : ~0ull;
+                    if (key != ~0ull) {
+                        const uint64_t target = key >> TSHIFT;
+                        const uint32_t lo = (uint32_t) key & 0xFFu;
+                        const bool samePrev = t > 0 && (sKey[t - 1] >> TSHIFT) == target;
+                        const uint32_t prevLo = samePrev ? ((uint32_t) sKey[t - 1] & 0xFFu) : 0u;
+                        if (lo == prevLo) {
+                            emit = true;
+                            if (samePrev) {
+                                uint32_t u = t - 1;
+                                while (true) {
+                                    const uint32_t ulo = (uint32_t) sKey[u] & 0xFFu;
+                                    const bool uSame = u > 0 && (sKey[u - 1] >> TSHIFT) == target;
+                                    const uint32_t uprev = uSame ? ((uint32_t) sKey[u - 1] & 0xFFu) : 0u;
+                                    if (ulo == uprev) { emit = (ulo != lo); break; }
+                                    if (!uSame) break;
+                                    u--;
+                                }
+                            }
+                        }
+                    }
+                    const unsigned long long m = __ballot(emit);
+                    if (lane == 0 && t < P) { sFlagBits[t >> 5] = (uint32_t) m; sFlagBits[(t >> 5) + 1] = (uint32_t) (m >> 32); }
+                }
+                __syncthreads();
+                const uint32_t nWords = P >> 5;
+                if (w == 0) {
+                    const uint32_t perLane = (nWords + WAVE - 1) / WAVE;
+                    const uint32_t b = min(nWords, (uint32_t) lane * perLane), e = min(nWords, b + perLane);
+                    uint32_t sum = 0;
+                    for (uint32_t k = b; k < e; k++) sum += (uint32_t) __popc(sFlagBits[k]);
+                    uint32_t total;
+                    uint32_t run = wave_excl_scan(sum, total);
+                    for (uint32_t k = b; k < e; k++) { sWordPrefix[k] = run; run += (uint32_t) __popc(sFlagBits[k]); }
+                    if (lane == 0) { sEmitBase = total ? atomicAdd(&A.counters[0], total) : 0u; sEmitCount = total; }
+                }
+                __syncthreads();
+                const uint32_t nEmit = sEmitCount, ebase = sEmitBase;
+                if (nEmit != 0 && (unsigned long long) ebase + nEmit <= (unsigned long long) A.cand_cap) {   // else: the host sees counters[0] > cap and retries
+                    for (uint32_t t = (uint32_t) tid; t < P; t += BLOCK) {
+                        const uint32_t word = sFlagBits[t >> 5];
+                        if (!((word >> (t & 31u)) & 1u)) continue;
+                        const uint32_t dst = ebase + sWordPrefix[t >> 5] + (uint32_t) __popc(word & ((1u << (t & 31u)) - 1u));
+                        const uint64_t key = sKey[t];
+                        A.C.q[dst] = q - A.q_first;
+                        A.C.id[dst] = (uint32_t) (key >> TSHIFT);
+                        A.C.ordinal[dst] = (uint32_t) (key >> 16) & ((1u << W_RANK_BITS) - 1u);
+                        A.C.diag[dst] = (uint16_t) key;
+                    }
+                }
+                tSortAcc += ts1 - ts0; tEmitAcc += wall_clock64() - ts1;
+            }
+            (void) tc0;
+        }
+        if (tid == 0) { atomicAdd(&A.totals[3], tGather - tStart); atomicAdd(&A.totals[4], tSortAcc); atomicAdd(&A.totals[5], tEmitAcc); }
+    }
+}
+
+// shapes of the wide kernel: production (64 classes of 20 480 records: 1.3 M hits per query, 16 waves, groups of 16 K records), and a
+// miniature (MK_PREFILTER_TIERS=tiny) with which small test inputs fill classes, span several groups and need sub-classes
+struct WideShape { int clsCap, nCls, maxpos, waves, wgPerCu; };
+const WideShape WIDE_SHAPES[2] = {{20480, 64, 2048, 16, 2}, {96, 8, 64, 4, 4}};
+template <int MODE>
+void launch_wide(int shape, const WideArgs &A, unsigned grid, hipStream_t stream) {
+    if (shape == 0) hipLaunchKernelGGL((wide_kernel<20480, 64, 16384, 4096, 131072, 2048, 16, 2, MODE>), dim3(grid), dim3(1024), 0, stream, A);
+    else hipLaunchKernelGGL((wide_kernel<96, 8, 128, 64, 1024, 64, 4, 2, MODE>), dim3(grid), dim3(256), 0, stream, A);
+}
+
+// =====================================================================================================
 //  common back end
 // =====================================================================================================
 // exact ungapped diagonal score of every candidate
@@ -1563,6 +1961,189 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
     return MK_OK;
 }
 
+// similar k-mers of every query of a piece from the list offsets (the cost the persistent workgroups are dealt by)
+__global__ __launch_bounds__(256) void query_kmers_kernel(const uint64_t *qOff, uint32_t qFirst, uint32_t nq, uint64_t posBegin, const uint64_t *listOff, uint32_t *perQuery) {
+    const uint32_t ql = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ql >= nq) return;
+    const uint64_t n = listOff[qOff[qFirst + ql + 1] - posBegin] - listOff[qOff[qFirst + ql] - posBegin];
+    perQuery[ql] = (uint32_t) min(n, (uint64_t) 0xFFFFFFFFull);
+}
+
+// A'. the wide per-query kernel over the view queries [a, b) (one chunk).  List modes (profile queries, k = 7) work in pieces whose
+// similar k-mers fit KLIST_CAP; the queries the kernel cannot hold (more k-mer starts than it numbers, a full target class) come back
+// in `fallback` (chunk-local ids) for the global path.
+int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff, uint32_t a, uint32_t b, int shape, bool coResident,
+                    uint32_t &nCand, std::vector<uint32_t> &fallback, double &kmersPerPos, double &globalHitsPerPos, PrefilterStats *cs) {
+    std::string &err = *X.err;
+    hipStream_t stream = X.stream;
+    const WideShape &W = WIDE_SHAPES[shape];
+    const bool listed = Vin.p_sorted || Vin.kmer_size == 7;
+    const size_t KLIST_CAP = (size_t) 1 << 31;                             // similar k-mers per piece (8 GB of table cells)
+    const uint64_t POS_CAP = 48u << 20;                                    // residues per piece
+    const int span = Vin.kmer_size == 7 ? 11 : 10;
+    static int cus = 0;
+    if (!cus) { int dev = 0; (void) hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
+    uint32_t *dCtr = (uint32_t *) dev_scratch("pf_wcounters", 64);
+    uint32_t *hCtr = (uint32_t *) pinned_scratch("pf_wcounters_h", 64);
+    unsigned long long *dTot = (unsigned long long *) dev_scratch("pf_wtotals", 16 * 8);
+    unsigned long long *hTot = (unsigned long long *) pinned_scratch("pf_wtotals_h", 16 * 8);
+    PNULL(dCtr); PNULL(hCtr); PNULL(dTot); PNULL(hTot);
+    uint32_t p0 = a;
+    while (p0 < b) {
+        PrefilterDeviceView V = Vin;
+        uint32_t p1 = b;
+        uint64_t nPos = 0;
+        const size_t fallbackMark = fallback.size();    // (a piece that is redone by the global path takes its fallback queries along)
+        uint32_t *dCnt = nullptr;                       // list modes: list length of every k-mer start of the piece
+        uint32_t *dQK = nullptr;
+        uint16_t *dPosCost = nullptr;
+        if (listed) {
+            const uint64_t posBudget = kmersPerPos > 0 ? std::min<uint64_t>(POS_CAP, (uint64_t) (0.8 * (double) KLIST_CAP / kmersPerPos)) : std::min<uint64_t>(POS_CAP, 1u << 20);
+            p1 = p0;
+            while (p1 < b && (hOff[p1 + 1] - hOff[p0] <= posBudget || p1 == p0)) p1++;
+            Kmer7Tables T7;
+            T7.score2 = V.score2; T7.index2 = V.index2; T7.score3 = V.score3; T7.index3 = V.index3; T7.num3 = V.num3; T7.cum3 = V.cum3;
+            T7.hist_lo = V.hist_lo; T7.hist_range = V.hist_range;
+            for (;;) {
+                nPos = hOff[p1] - hOff[p0];
+                if (nPos == 0) break;
+                dCnt = (uint32_t *) dev_scratch("pf_klcount", (nPos + 1) * 4);
+                uint64_t *dKOff = (uint64_t *) dev_scratch("pf_kloff", (nPos + 2) * 8);
+                unsigned long long *hKTot = (unsigned long long *) pinned_scratch("pf_kltot_h", 16);
+                PNULL(dCnt); PNULL(dKOff); PNULL(hKTot);
+                int th = X.tb(V.p_sorted ? "profile_kmer_count" : "kmer7_count", 46.0 * (double) nPos, 0);
+                if (V.p_sorted) PCHK(launch_profile_kmer_count(V.p_sorted, V.q_kmer_thr, hOff[p0], hOff[p1], dCnt, stream, V.kmer_size));
+                else PCHK(launch_kmer7_count(T7, V.q_res, V.q_kmer_thr, hOff[p0], hOff[p1], dCnt, stream));
+                X.te(th);
+                PCHK(hipMemsetAsync(dCnt + nPos, 0, 4, stream));           // one more element: the scan then ends with the total
+                hipcub::TransformInputIterator<unsigned long long, hipcub::CastOp<unsigned long long>, uint32_t *> cit(dCnt, hipcub::CastOp<unsigned long long>());
+                size_t tk = 0;
+                hipcub::DeviceScan::ExclusiveSum(nullptr, tk, cit, (unsigned long long *) dKOff, (int) (nPos + 1), stream);
+                void *tempK = dev_scratch("pf_temp", tk);
+                PNULL(tempK);
+                PCHK(hipcub::DeviceScan::ExclusiveSum(tempK, tk, cit, (unsigned long long *) dKOff, (int) (nPos + 1), stream));
+                PCHK(hipMemcpyAsync(hKTot, dKOff + nPos, 8, hipMemcpyDeviceToHost, stream));
+                PCHK(sync_wait(stream, "wait_prefilter"));
+                const size_t nK = (size_t) hKTot[0];
+                kmersPerPos = std::max(1.0, (double) nK / (double) nPos);
+                if (nK > KLIST_CAP) {
+                    if (p1 - p0 > 1) { p1 = p0 + (p1 - p0) / 2; continue; }
+                    err = "one query has more than 2^31 similar k-mers"; return MK_ERR_UNSUPPORTED;
+                }
+                uint32_t *dKList = (uint32_t *) dev_scratch("pf_klist", std::max<size_t>(nK, 1) * 4);
+                PNULL(dKList);
+                th = X.tb(V.p_sorted ? "profile_kmer_fill" : "kmer7_fill", 46.0 * (double) nPos + 4.0 * (double) nK, (double) nK);
+                if (V.p_sorted) PCHK(launch_profile_kmer_fill(V.p_sorted, V.q_kmer_thr, V.addr3, hOff[p0], hOff[p1], dKOff, dKList, stream, V.kmer_size));
+                else PCHK(launch_kmer7_fill(T7, V.q_res, V.q_kmer_thr, hOff[p0], hOff[p1], dKOff, dKList, stream));
+                X.te(th);
+                V.klist = dKList; V.klist_off = dKOff; V.klist_pos0 = hOff[p0];
+                break;
+            }
+        } else {
+            nPos = hOff[p1] - hOff[p0];
+        }
+        const uint32_t nqp = p1 - p0;
+        if (nPos == 0) { p0 = p1; continue; }
+        // ---- similar k-mers of every query: the order in which the persistent workgroups take them, and the run statistics
+        dQK = (uint32_t *) dev_scratch("pf_qkmers", (size_t) nqp * 4);
+        uint32_t *hQK = (uint32_t *) pinned_scratch("pf_qkmers_h", (size_t) nqp * 4);
+        PNULL(dQK); PNULL(hQK);
+        if (listed) {
+            hipLaunchKernelGGL(query_kmers_kernel, dim3((nqp + 255) / 256), dim3(256), 0, stream, V.q_off, p0, nqp, hOff[p0], V.klist_off, dQK);
+        } else {
+            dPosCost = (uint16_t *) dev_scratch("pf_poscost", (size_t) (nPos + 16) * 2);
+            PNULL(dPosCost);
+            PCHK(hipMemsetAsync(dQK, 0, (size_t) nqp * 4, stream));
+            const int th = X.tb("kmer_count", 5.0 * (double) nPos, 0);
+            hipLaunchKernelGGL(kmer_count_kernel, dim3((unsigned) (((nPos + WAVE - 1) / WAVE + 3) / 4)), dim3(256), 0, stream, V, hOff[p0], hOff[p1], p0, dQK, dPosCost);
+            X.te(th);
+        }
+        PCHK(hipGetLastError());
+        PCHK(hipMemcpyAsync(hQK, dQK, (size_t) nqp * 4, hipMemcpyDeviceToHost, stream));
+        PCHK(sync_wait(stream, "wait_prefilter"));
+        std::vector<uint32_t> order;
+        {
+            ScopedHost sh("host_prefilter_tiers");
+            double sum = 0;
+            uint32_t most = 1;
+            for (uint32_t ql = 0; ql < nqp; ql++) most = std::max(most, hQK[ql]);
+            std::vector<uint32_t> byClass[64];             // roughly by falling size: 64 classes
+            for (uint32_t ql = 0; ql < nqp; ql++) {
+                const uint64_t L = hOff[(size_t) p0 + ql + 1] - hOff[(size_t) p0 + ql];
+                if (L) sum += (double) hQK[ql] / (double) L;
+                if (hQK[ql] == 0) continue;                 // no k-mer: no hits
+                if ((int64_t) L - span + 1 > (int64_t) W.maxpos) { fallback.push_back(p0 + ql - a); continue; }
+                byClass[63 - std::min<uint64_t>(63, (uint64_t) hQK[ql] * 63 / most)].push_back(p0 + ql);
+            }
+            for (int c = 0; c < 64; c++) order.insert(order.end(), byClass[c].begin(), byClass[c].end());
+            if (cs) cs->kmers_per_pos += sum;
+        }
+        if (!order.empty()) {
+            uint32_t *hList = (uint32_t *) pinned_scratch("pf_flist_h", order.size() * 4);
+            uint32_t *dList = (uint32_t *) dev_scratch("pf_flist", order.size() * 4);
+            uint32_t *dOvf = (uint32_t *) dev_scratch("pf_fovf", (size_t) nqp * 4);
+            PNULL(hList); PNULL(dList); PNULL(dOvf);
+            std::memcpy(hList, order.data(), order.size() * 4);
+            PCHK(hipMemcpyAsync(dList, hList, order.size() * 4, hipMemcpyHostToDevice, stream));
+            PCHK(hipMemsetAsync(dCtr, 0, 64, stream));
+            hCtr[0] = nCand;                               // (pinned: the copy below reads it when the stream gets there -- synchronised before it is reused)
+            PCHK(hipMemcpyAsync(dCtr, hCtr, 4, hipMemcpyHostToDevice, stream));
+            PCHK(hipMemsetAsync(dTot, 0, 16 * 8, stream));
+            int perCu = W.wgPerCu;
+            if (coResident) perCu = std::max(1, 16 / W.waves < perCu ? 16 / W.waves : perCu);          // at most 16 waves per CU beside the alignment stage
+            if (const char *e = knob("MK_PREFILTER_WG_PER_CU_W")) perCu = std::max(1, atoi(e));
+            const unsigned launch = (unsigned) std::min<size_t>(order.size(), (size_t) cus * perCu);
+            const size_t regionRecs = (size_t) W.nCls * W.clsCap;
+            WideArgs A;
+            A.pool = (uint64_t *) dev_scratch("pf_wpool", (size_t) launch * regionRecs * 8);
+            A.pool_ord = (uint32_t *) dev_scratch("pf_wpoolord", (size_t) launch * regionRecs * 4);
+            PNULL(A.pool); PNULL(A.pool_ord);
+            A.V = V; A.queries = dList; A.n_queries = (uint32_t) order.size(); A.q_first = a;
+            A.C = X.C; A.cand_cap = X.candCap; A.counters = dCtr;
+            A.overflow_list = dOvf; A.overflow_count = dCtr + 4; A.totals = dTot; A.work_counter = dCtr + 8;
+            A.pos_cost = dPosCost; A.pos_begin = hOff[p0];
+            const int th = X.tb("prefilter_query_wide", 0, 0);
+            if (listed) launch_wide<W_MODE_LIST>(shape, A, launch, stream);
+            else launch_wide<W_MODE_ENUM6>(shape, A, launch, stream);
+            X.te(th);
+            PCHK(hipGetLastError());
+            PCHK(hipMemcpyAsync(hCtr, dCtr, 64, hipMemcpyDeviceToHost, stream));
+            PCHK(hipMemcpyAsync(hTot, dTot, 16 * 8, hipMemcpyDeviceToHost, stream));
+            PCHK(sync_wait(stream, "wait_prefilter"));
+            if (knob("MK_PREFILTER_DEBUG"))
+                fprintf(stderr, "[prefilter] wide piece %u..%u (%s): queries %zu overflowed %llu | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g sort %.3g emit %.3g overflowed %.3g | extra sub-class passes %llu | cand %u -> %u\n",
+                        p0, p1, listed ? "lists" : "k = 6 enumerator", order.size(), hTot[8], (double) hTot[0], (double) hTot[1], (double) hTot[2], (double) hTot[3], (double) hTot[4], (double) hTot[5],
+                        (double) hTot[6], hTot[9], nCand, hCtr[0]);
+            if (hCtr[0] > X.candCap) return RC_CAND_OVERFLOW;
+            if (hTot[10] != 0) {
+                // a single target class held more double-hit survivors of one sub-class than the LDS sort: the piece's candidates are dropped
+                // (nCand is not advanced) and the sort-based path does the piece
+                const bool sk = X.statsKmers;
+                X.statsKmers = false;
+                fallback.resize(fallbackMark);
+                const int rc = global_candidates(X, Vin, hOff, p0, p1, nullptr, (uint32_t) 0 - a, nCand, globalHitsPerPos);
+                X.statsKmers = sk;
+                if (rc != MK_OK) return rc;
+            } else {
+                X.ts(th, 16.0 * (double) hTot[0] + 6.0 * (double) hTot[1], (double) hTot[0]);
+                nCand = hCtr[0];
+                if (cs) cs->db_matches += hTot[1];
+                const uint32_t nOvf = hCtr[4];
+                if (nOvf > 0) {
+                    uint32_t *hOvf = (uint32_t *) pinned_scratch("pf_fovf_h", (size_t) nOvf * 4);
+                    PNULL(hOvf);
+                    PCHK(hipMemcpyAsync(hOvf, dOvf, (size_t) nOvf * 4, hipMemcpyDeviceToHost, stream));
+                    PCHK(sync_wait(stream, "wait_prefilter"));
+                    fallback.insert(fallback.end(), hOvf, hOvf + nOvf);
+                }
+            }
+        }
+        p0 = p1;
+    }
+    std::sort(fallback.begin(), fallback.end());
+    return MK_OK;
+}
+
 }  // namespace
 
 int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOff, const std::vector<uint8_t> &qRes,
@@ -1590,10 +2171,14 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     uint32_t seqBits = 1; while ((1ull << seqBits) < dbSize) seqBits++;
     // front end: the per-query kernels keep the target id in a 22-bit field of their hit records
     bool useFused = seqBits <= REC_T_BITS;
-    if (V.p_sorted || V.kmer_size == 7) useFused = false;   // profile queries, k = 7: k-mer lists in HBM + the global path (the per-query kernels enumerate two 3-mer rows)
-    else if (const char *e = knob("MK_PREFILTER_PATH")) {
-        if (!strcmp(e, "global")) useFused = false;
-        else if (strcmp(e, "fused") && strcmp(e, "auto")) { err = "MK_PREFILTER_PATH must be auto, fused or global"; return MK_ERR_ARG; }
+    if (V.p_sorted || V.kmer_size == 7) useFused = false;   // profile queries, k = 7: k-mer lists (stream_kernel enumerates two 3-mer rows)
+    // ... and whatever the 22-bit per-query kernels do not take goes to the wide per-query kernel (round 4; up to 2^27 targets, lists or the k = 6
+    // enumerator), the sort-based global path behind it.  MK_PREFILTER_PATH = auto | fused | wide | global forces (fused: where it applies)
+    bool useWide = !useFused && seqBits <= W_T_BITS;
+    if (const char *e = knob("MK_PREFILTER_PATH")) {
+        if (!strcmp(e, "global")) { useFused = false; useWide = false; }
+        else if (!strcmp(e, "wide")) { useFused = false; useWide = seqBits <= W_T_BITS; }
+        else if (strcmp(e, "fused") && strcmp(e, "auto")) { err = "MK_PREFILTER_PATH must be auto, fused, wide or global"; return MK_ERR_ARG; }
     }
     int tierBase = 0;
     if (const char *e = knob("MK_PREFILTER_TIERS")) {
@@ -1607,7 +2192,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     int firstTier = 0;                                 // MK_PREFILTER_FIRST_TIER: queries that would fit a smaller tier go to the global path
     if (const char *e = knob("MK_PREFILTER_FIRST_TIER")) firstTier = std::max(0, atoi(e));
     if (g_memo.entries != (const void *) V.entries || g_memo.nTargets != V.n_targets) { g_memo = SizingMemo(); g_memo.entries = V.entries; g_memo.nTargets = V.n_targets; }
-    double candPerQuery = g_memo.candPerQuery, globalHitsPerPos = 0;
+    double candPerQuery = g_memo.candPerQuery, globalHitsPerPos = 0, wideKmersPerPos = 0;
     static_assert(N_TIERS == 4, "SizingMemo holds four tiers");
     SubMat ungMat;
     build_submat(ungMat, MAT_BLOSUM62, 2.0f, -0.2f);
@@ -1616,7 +2201,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     X.stream = stream; X.err = &err; X.tb = tb; X.te = te; X.ts = ts; X.seqBits = seqBits;
     X.maxDbMatches = std::max<uint64_t>(1000000, dbSize) * 2;   // QueryMatcher.cpp:43
     X.candCap = CAND_CAP;
-    X.statsKmers = hooks.stats && !useFused;
+    X.statsKmers = hooks.stats && !useFused && !useWide;
     X.qOffHost = &qOff; X.qResHost = &qRes; X.qCorrHost = V.p_sorted ? nullptr : qCorrHost; X.tMaskedHost = hooks.t_masked_host; X.tOffHost = &tOff; X.ungMat = &ungMat;
     X.dTotals = (unsigned long long *) dev_scratch("pf_totals", 64);
     X.hTotals = (unsigned long long *) pinned_scratch("pf_totals_h", 64);
@@ -1658,7 +2243,10 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
         X.stats = hooks.stats ? &cs : nullptr;
         std::vector<uint32_t> fallback;                                     // chunk-local ids for the global path
         int rc = MK_OK;
-        if (useFused) {
+        if (useWide) {
+            // ---- A'. the wide per-query kernel; what it cannot hold comes back in `fallback`
+            rc = wide_candidates(X, V, qOff.data(), q0, q1, tierBase ? 1 : 0, hooks.co_resident, nCand, fallback, wideKmersPerPos, globalHitsPerPos, hooks.stats ? &cs : nullptr);
+        } else if (useFused) {
             // ---- A. fused kernels, one launch per LDS tier; the tier follows the expected number of index hits
             std::vector<uint32_t> lists[N_TIERS];
             size_t nListed = 0;
@@ -1808,9 +2396,18 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                 }
             }
         }
-        if (rc == MK_OK && !useFused) {
+        if (rc == MK_OK && !useFused && !useWide) {
             // ---- B. the whole chunk through the global path
             rc = global_candidates(X, V, qOff.data(), q0, q1, nullptr, (uint32_t) 0 - q0, nCand, globalHitsPerPos);
+        } else if (rc == MK_OK && !fallback.empty() && V.p_sorted) {
+            // ---- B. profile queries the wide kernel could not take: their columns stay where they are (the sorted columns and the alignment
+            // profile are indexed by the batch's residue positions), run by run of neighbouring queries
+            for (size_t f0 = 0; f0 < fallback.size() && rc == MK_OK; ) {
+                size_t f1 = f0 + 1;
+                while (f1 < fallback.size() && fallback[f1] == fallback[f1 - 1] + 1) f1++;
+                rc = global_candidates(X, V, qOff.data(), q0 + fallback[f0], q0 + fallback[f1 - 1] + 1, nullptr, (uint32_t) 0 - q0, nCand, globalHitsPerPos);
+                f0 = f1;
+            }
         } else if (rc == MK_OK && !fallback.empty()) {
             // ---- B. the queries the fused kernels could not take, as a compact mini batch
             const uint32_t nMini = (uint32_t) fallback.size();

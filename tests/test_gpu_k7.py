@@ -21,8 +21,18 @@ def _text(name):
         return f.read()
 
 
-def test_k7_prefilter_matches_the_real_process(gpu_api, tmp_path):
+def test_k7_prefilter_matches_the_real_process(gpu_api, tmp_path, monkeypatch):
     api = gpu_api
+    # every front end a k = 7 search can take: the sort-based global path and the miniature of the wide per-query kernel first, the
+    # production shape of the wide kernel (the default) last -- its result goes on to the alignment checks below
+    gold = _text("e2e_process_pref_k7.txt.gz")
+    for path, tiers in (("global", "default"), ("wide", "tiny"), ("auto", "default")):
+        monkeypatch.setenv("MK_PREFILTER_PATH", path)
+        monkeypatch.setenv("MK_PREFILTER_TIERS", tiers)
+        _k7_pass(api, tmp_path, gold, check_more=(path == "auto"))
+
+
+def _k7_pass(api, tmp_path, gold, check_more):
     targets = _text("e2e_targets.txt.gz").splitlines()
     frags = [l.rsplit("\t", 1)[1] for l in _text("e2e_process_orfs.txt.gz").splitlines()]
     params = api.default_params()
@@ -33,8 +43,11 @@ def test_k7_prefilter_matches_the_real_process(gpu_api, tmp_path):
     q = api.Queries(frags, api.default_params())          # derived for k = 6: the batch follows the database it meets
     (hits, hoff), (alns, aoff) = api.search(db, q, params)
     pref = "".join(">%d\n%s" % (i, api.format_hits_bulk(hits, int(hoff[i]), int(hoff[i + 1])).decode()) for i in range(q.n))
-    assert pref == _text("e2e_process_pref_k7.txt.gz")
+    assert pref == gold
+    if not check_more:
+        return
     st = api.kernel_stats()
+    assert "prefilter_query_wide" in st and st["prefilter_query_wide"]["cells"] > 1e9      # the similar k-mers went through the wide kernel
     assert "kmer7_fill" in st and st["kmer7_fill"]["cells"] > 1e9     # ~2 119 similar k-mers per start
     # the alignments of those hits: the oracle on a prefix (its k = 7 run takes seconds per thousand fragments)
     n = 3000

@@ -113,12 +113,14 @@ def test_ungapped(gpu_api, small_workload):
         assert int(got[k]) == exp, (k, int(qi[k]), int(ti[k]), int(diag[k]), int(got[k]), exp)
 
 
-@pytest.fixture(params=["fused", "fused-tiny", "global"])
+@pytest.fixture(params=["fused", "fused-tiny", "wide", "wide-tiny", "global"])
 def pf_path(request, monkeypatch):
     """front end of the prefilter: per-query LDS kernels (production tiers / miniature tiers that force the overflow
-    hand-over on small inputs) or the global sort path; the library reads the variables on every call"""
-    monkeypatch.setenv("MK_PREFILTER_PATH", "global" if request.param == "global" else "fused")
-    monkeypatch.setenv("MK_PREFILTER_TIERS", "tiny" if request.param == "fused-tiny" else "default")
+    hand-over on small inputs), the wide per-query kernel (partitioned hit regions: what k = 7, profile queries and databases beyond
+    2^22 targets take; production shape / a miniature whose classes fill up, whose groups are many and whose survivors need sub-classes)
+    or the global sort path; the library reads the variables on every call"""
+    monkeypatch.setenv("MK_PREFILTER_PATH", request.param.split("-")[0])
+    monkeypatch.setenv("MK_PREFILTER_TIERS", "tiny" if request.param.endswith("-tiny") else "default")
     return request.param
 
 

@@ -128,10 +128,13 @@ def _synthetic_profile(rng, length, x_rate=0.0):
     return bytes(out) + b"\0", "".join(AA[max(range(20), key=lambda a: ((out[25 * i + a] + 128) % 256))] for i in range(length))
 
 
-def test_profile_search_synthetic_vs_oracle(gpu_api, tmp_path):
+@pytest.mark.parametrize("front", ["wide", "wide-tiny", "global"])
+def test_profile_search_synthetic_vs_oracle(gpu_api, tmp_path, monkeypatch, front):
     """synthetic profiles (ties inside columns, X query letters, lengths 12 .. 1500: every SW tile shape incl. row tiles) against
     fragments derived from their consensus: the oracle's stages on the same files"""
     api = gpu_api
+    monkeypatch.setenv("MK_PREFILTER_PATH", front.split("-")[0])          # profile queries: the wide per-query kernel on the k-mer lists (default), its miniature, the global path
+    monkeypatch.setenv("MK_PREFILTER_TIERS", "tiny" if front.endswith("-tiny") else "default")
     rng = random.Random(5)
     entries, cons = [], []
     for L in [12, 31, 64, 100, 129, 200, 260, 390, 520, 800, 1100, 1500] + [rng.randint(20, 400) for _ in range(28)]:

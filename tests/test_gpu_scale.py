@@ -166,12 +166,32 @@ def _config5_case(api, tmp_path, n_targets, forced_k, n_queries=20000, index_db=
         assert (int(hoff[-1]), d_pref) == (gold["reference"]["pref_hits"], gold["sha256_pref"]), report
         assert d_aln == gold["sha256_aln"], report
     if index_db:
+        # the index DB of a k = 7 database: 10.2 GB of list offsets + 6 B per entry + the sequences.  A GPU box's scratch disk may be smaller
+        # than it looks (ephemeral-storage limit of the pod): the round trip is skipped -- and said so in the report -- when the file cannot
+        # be written; the writer and the reader themselves are pinned at small scale (tests/test_gpu_index.py)
+        import shutil
+        need = 8 * 1280000000 + 6 * db.index_entries() + 2 * int(off[-1])
+        free = shutil.disk_usage(str(tmp_path)).free
         image = api.synth_seqdb(res, off)
         t0 = time.time()
-        api.index_write(str(tmp_path / "T.idx"), image, p)
+        written = False
+        if free > 1.15 * need:
+            try:
+                api.index_write(str(tmp_path / "T.idx"), image, p)
+                written = True
+            except api.MkError as e:
+                report["index_db_round_trip"] = "skipped: %s (%.1f GB needed, %.1f GB reported free)" % (e, need / 1e9, free / 1e9)
+        else:
+            report["index_db_round_trip"] = "skipped: %.1f GB needed, %.1f GB free on the scratch disk" % (need / 1e9, free / 1e9)
+        del image
+        if not written:
+            for ext in ("", ".index", ".dbtype"):
+                if os.path.exists(str(tmp_path / "T.idx") + ext):
+                    os.remove(str(tmp_path / "T.idx") + ext)
+            index_db = False
+    if index_db:
         report["t_index_db_write_s"] = round(time.time() - t0, 2)
         report["index_db_bytes"] = os.path.getsize(str(tmp_path / "T.idx"))
-        del image
         t0 = time.time()
         db2 = api.TargetDB.from_index(str(tmp_path / "T.idx"), p)
         report["t_index_db_open_s"] = round(time.time() - t0, 2)
