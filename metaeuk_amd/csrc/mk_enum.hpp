@@ -173,5 +173,97 @@ __device__ __forceinline__ uint32_t enumerate_position(const PrefilterDeviceView
     return kmers;
 }
 
+// ---- k = 7 (databases of 3.35e9 residues or more; spaced seed 11010110011) ----
+// KmerGenerator::setDivideStrategy cuts a 7-mer into a 2-mer, a 2-mer and a 3-mer row and multiplies them step by step
+// (M/src/prefiltering/KmerGenerator.cpp:41-86,107-187): the list is the lexicographic order of the three ranks (a, b, c), pruned at
+// every step against the best of the remaining rows (mk_kmer7.hip restates it as list kernels).  In a wave: the first-row candidates a
+// are walked one after the other (their scores sit in a register of the wave: v_readlane, no load in the loop), the 64 best second-row
+// candidates b are the lanes, the number of third-row partners of a pair is one lookup in the row's cumulative score histogram (staged
+// in LDS once per start), and the product -> (b, c) map of a 64 x U window is the counting trick of enumerate_position.
+// Table cell of a 7-mer = n2a + 400 n2b + 160000 n3 (the reference's numbering; V.num3 maps an index3 address code to the 3-mer number).
+template <int U>
+struct Enum7Lds {
+    uint32_t start[WAVE];        // exclusive prefix of the partner counts over the second-row candidates of the current step
+    uint32_t idx0[WAVE];         // n2a + 400 n2b of the pair
+    uint32_t cnt[U * WAVE];      // histogram of the inclusive prefixes over the current product window
+    uint32_t sec[WAVE];          // 160000 n3 of the 64 best third-row partners
+    uint16_t cum[256];           // the third row's cumulative score histogram (hist_range <= 256, checked by the host)
+};
+
+template <int U, class F>
+__device__ __forceinline__ uint32_t enumerate7_position(const PrefilterDeviceView &V, const uint8_t *r, int thr, int lane, Enum7Lds<U> &S, F &&onBatch) {
+    constexpr int N2 = 400;
+    const uint32_t idx0 = r[0] + 20u * r[1];
+    const uint32_t idx1 = r[3] + 20u * r[5];
+    const uint32_t idx2 = r[6] + 20u * r[9] + 400u * r[10];
+    const int16_t *s0 = V.score2 + (size_t) idx0 * N2, *s1 = V.score2 + (size_t) idx1 * N2;
+    const uint16_t *i0 = V.index2 + (size_t) idx0 * N2, *i1 = V.index2 + (size_t) idx1 * N2, *i2 = V.index3 + (size_t) idx2 * N3;
+    const int R = V.hist_range, lo = V.hist_lo;
+    const uint16_t *cum = V.cum3 + (size_t) idx2 * R;
+    for (int k = lane; k < 256; k += WAVE) S.cum[k] = k < R ? cum[k] : (uint16_t) 0;
+    S.sec[lane] = 160000u * (uint32_t) V.num3[i2[lane]];
+    const int rest1 = (int) V.score3[(size_t) idx2 * N3];
+    const int saReg = (int) s0[lane];                    // the 64 best first-row candidates (a walk rarely passes them) ...
+    const uint32_t iaReg = (uint32_t) i0[lane];
+    const int sb0 = (int) s1[lane];                      // ... and second-row candidates
+    const uint32_t ib0 = (uint32_t) i1[lane];
+    const int rest0 = __builtin_amdgcn_readlane(sb0, 0) + rest1;
+    wave_sync_lds();
+    uint32_t kmers = 0;
+    for (int a = 0; a < N2; a++) {
+        int sa;
+        uint32_t ca;
+        if (a < WAVE) { sa = __builtin_amdgcn_readlane(saReg, a); ca = (uint32_t) __builtin_amdgcn_readlane((int) iaReg, a); }
+        else { sa = (int) s0[a]; ca = (uint32_t) i0[a]; }
+        if (sa < thr - rest0) break;
+        const int cutB = thr - sa - rest1;
+        for (int b0 = 0; b0 < N2; b0 += WAVE) {
+            int sb = sb0;
+            uint32_t cb = ib0;
+            if (b0 != 0) { const int b = b0 + lane; sb = b < N2 ? (int) s1[b] : -32768; cb = b < N2 ? (uint32_t) i1[b] : 0u; }
+            uint32_t nb = 0;
+            if (sb >= cutB) {
+                const int xb = thr - sa - sb - lo;
+                nb = xb <= 0 ? (uint32_t) N3 : (xb >= R ? 0u : (uint32_t) S.cum[xb]);
+            }
+            const uint32_t incl = wave_incl_scan(nb);
+            const uint32_t total = wave_last(incl);
+            S.start[lane] = incl - nb;
+            S.idx0[lane] = ca + 400u * cb;
+            const bool more = __builtin_amdgcn_readlane(sb, WAVE - 1) >= cutB;      // the step's last candidate is still valid
+            kmers += total;
+            for (uint32_t base = 0; base < total; base += U * WAVE) {
+#pragma unroll
+                for (int u = 0; u < U; u++) S.cnt[u * WAVE + lane] = 0;
+                wave_sync_lds();
+                const uint32_t rel = incl - base;                       // wraps for incl < base: not in the window
+                if (incl >= base && rel < (uint32_t) (U * WAVE)) atomicAdd(&S.cnt[rel], 1u);
+                uint32_t carry = (uint32_t) __popcll(__ballot(incl < base));
+                wave_sync_lds();
+                uint32_t kmer[U];
+                bool has[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint32_t x = base + (uint32_t) (u * WAVE + lane);
+                    const uint32_t sc = wave_incl_scan(S.cnt[u * WAVE + lane]);
+                    const uint32_t owner = carry + sc;
+                    carry += wave_last(sc);
+                    has[u] = x < total;
+                    kmer[u] = 0;
+                    if (has[u]) {
+                        const uint32_t c = x - S.start[owner];
+                        kmer[u] = S.idx0[owner] + (c < (uint32_t) WAVE ? S.sec[c] : 160000u * (uint32_t) V.num3[i2[c]]);
+                    }
+                }
+                if (!onBatch(kmer, has)) return kmers;
+                wave_sync_lds();
+            }
+            wave_sync_lds();
+            if (!more) break;
+        }
+    }
+    return kmers;
+}
+
 }  // namespace enumk
 }  // namespace mk

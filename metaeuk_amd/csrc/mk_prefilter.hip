@@ -49,6 +49,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <type_traits>
 
 namespace mk {
 
@@ -893,7 +894,7 @@ void launch_stream(int tier, const StreamArgs &A, unsigned grid, hipStream_t str
 // The k-mers come from the enumerator of the k = 6 table (MODE 0), from lists in HBM (MODE 1: profile queries, k = 7), or from the
 // in-wave 7-mer enumerator (MODE 2).
 constexpr uint32_t W_T_BITS = 27, W_RANK_BITS = 21;            // + 16 bits of diagonal = 64 (sort key: target | rank | diagonal)
-constexpr int W_MODE_ENUM6 = 0, W_MODE_LIST = 1;
+constexpr int W_MODE_ENUM6 = 0, W_MODE_LIST = 1, W_MODE_ENUM7 = 2;
 struct WideArgs {
     PrefilterDeviceView V;
     const uint32_t *queries; uint32_t n_queries;      // view query ids, most expensive first
@@ -901,7 +902,8 @@ struct WideArgs {
     CandArrays C; uint32_t cand_cap;
     uint32_t *counters;                               // [0] candidates appended
     uint32_t *overflow_list; uint32_t *overflow_count;   // queries this kernel could not hold (view id - q_first): the global path takes them
-    unsigned long long *totals;                       // as StreamArgs::totals
+    unsigned long long *totals;                       // as StreamArgs::totals; [10] sub-classes beyond the LDS sort (the host redoes the piece)
+                                                      // [11] (a double) MODE 2: sum over the finished queries of similar k-mers / length (run statistics)
     uint32_t *work_counter;
     uint64_t *pool; uint32_t *pool_ord;               // gridDim.x regions of NCLS * CLS_CAP records
     const uint16_t *pos_cost; uint64_t pos_begin;     // MODE 0: work estimate of every k-mer start (kmer_count_kernel)
@@ -915,7 +917,8 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {
     static_assert((SURV & (SURV - 1)) == 0 && (MBITS & (MBITS - 1)) == 0 && (NCLS & (NCLS - 1)) == 0, "powers of two");
     static_assert((uint64_t) NCLS * CLS_CAP <= (1ull << W_RANK_BITS) && MAXPOS <= 4096 && W_T_BITS + TSHIFT <= 64, "record / key fields");
     static_assert(NCLS <= STREAM_MAX_CLASSES && GROUP_MAX >= SURV, "class tables");
-    struct Pass1Lds { enumk::EnumLds<U> e[NW]; uint8_t mark[NW][WAVE]; };
+    using EnumScratch = typename std::conditional<MODE == W_MODE_ENUM7, enumk::Enum7Lds<U>, enumk::EnumLds<U>>::type;
+    struct Pass1Lds { EnumScratch e[NW]; uint8_t mark[NW][WAVE]; };
     constexpr size_t RAW = sizeof(Pass1Lds) > sizeof(uint64_t) * SURV ? sizeof(Pass1Lds) : sizeof(uint64_t) * SURV;
     __shared__ __attribute__((aligned(16))) uint8_t sRaw[RAW];
     uint64_t *sKey = reinterpret_cast<uint64_t *>(sRaw);
@@ -966,6 +969,16 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {
                 if (MODE == W_MODE_LIST) {
                     const uint64_t pl = qs + (uint64_t) k - A.V.klist_pos0;
                     cost = (uint32_t) min((A.V.klist_off[pl + 1] - A.V.klist_off[pl] + 3ull) >> 2, (unsigned long long) 65535);
+                } else if (MODE == W_MODE_ENUM7) {
+                    // no count pass in front of this mode: the margin of the k-mer's own best similar k-mer over the threshold stands for the
+                    // number of similar k-mers (it grows with it); 0 = no k-mer start here
+                    const int thrK = (int) A.V.q_kmer_thr[qs + (uint64_t) k];
+                    if (thrK >= 0) {
+                        const uint8_t *r = A.V.q_res + qs + (uint64_t) k;
+                        const int best = (int) A.V.score2[(size_t) (r[0] + 20u * r[1]) * 400u] + (int) A.V.score2[(size_t) (r[3] + 20u * r[5]) * 400u] +
+                                         (int) A.V.score3[(size_t) (r[6] + 20u * r[9] + 400u * r[10]) * N3];
+                        cost = best >= thrK ? (uint32_t) min(best - thrK + 1, 65535) : 0u;
+                    }
                 } else cost = A.pos_cost[qs - A.pos_begin + (uint64_t) k];
             }
             sOrdKey[k] = k < nOrd ? (cost << 12) | (uint32_t) k : 0u;
@@ -1029,7 +1042,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {
                     const auto put = [&](uint64_t ent, uint32_t rel) {
                         const uint32_t tgt = (uint32_t) ent;
                         const uint32_t diag = ((uint32_t) i - ((uint32_t) (ent >> 32) & 0xFFFFu)) & 0xFFFFu;
-                        const uint32_t cls = (tgt * 2654435761u) >> (32 - LOG_NCLS);
+                        const uint32_t cls = (tgt * 0x7FEB352Du) >> (32 - LOG_NCLS);       // (its own multiplier: the bitmap buckets of pass 2 must not follow the class)
                         const uint32_t slot = atomicAdd(&sClsUsed[cls], 1u);
                         if (slot < (uint32_t) CLS_CAP) {
                             const size_t at = (size_t) cls * CLS_CAP + slot;
@@ -1055,6 +1068,8 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {
                 const uint64_t pl = p - A.V.klist_pos0;
                 const uint64_t l0 = A.V.klist_off[pl], l1 = A.V.klist_off[pl + 1];
                 kmers += enumerate_list<U>(A.V.klist + l0, (uint32_t) (l1 - l0), lane, onBatch);
+            } else if constexpr (MODE == W_MODE_ENUM7) {
+                kmers += enumk::enumerate7_position<U>(A.V, A.V.q_res + p, thr, lane, P1.e[w], onBatch);
             } else {
                 kmers += enumk::enumerate_position<U>(A.V, A.V.q_res + p, thr, lane, P1.e[w], onBatch);
             }
@@ -1076,6 +1091,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {
             atomicAdd(&A.totals[0], (unsigned long long) km);
             atomicAdd(&A.totals[1], (unsigned long long) hitsAll);
             atomicAdd(&A.totals[2], (unsigned long long) np);
+            if (MODE == W_MODE_ENUM7 && km != 0 && L > 0) atomicAdd(reinterpret_cast<double *>(&A.totals[11]), (double) km / (double) L);
         }
         if (hitsAll == 0) continue;
         // arrival rank of a hit = hits of the earlier k-mer starts + its ordinal
@@ -1108,6 +1124,10 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {
                     }
                 }
             };
+            // a class with more records than a group holds is taken in SUBSETS of its targets (a second hash): the bitmaps stay sparse
+            const uint32_t nSets = (recs + (uint32_t) GROUP_MAX - 1u) / (uint32_t) GROUP_MAX;
+            for (uint32_t set = 0; set < nSets; set++) {
+            const auto in_set = [&](uint64_t rec) -> bool { return nSets == 1u || (((uint32_t) (rec & TMASK) * 0xC2B2AE35u) >> 8) % nSets == set; };
             __syncthreads();                               // (the previous group's bitmaps and keys are no longer read)
             for (int k = tid; k < MBITS / 32; k += BLOCK) { sBm1[k] = 0; sBm2[k] = 0; }
             if (tid == 0) sSurv = 0;
@@ -1116,6 +1136,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {
             sweep([&](bool valid, size_t at) {
                 if (!valid) return;
                 const uint64_t rec = region[at];
+                if (!in_set(rec)) return;
                 const uint32_t hb = ((uint32_t) (rec & TMASK) * 0x9E3779B1u) >> (32 - LOG_MBITS);
                 const uint32_t bit = 1u << (hb & 31u);
                 if (atomicOr(&sBm1[hb >> 5], bit) & bit) atomicOr(&sBm2[hb >> 5], bit);
@@ -1124,7 +1145,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {
             // ---- 2b: how many records survive; target sub-classes if they do not fit the LDS sort at once
             {
                 uint32_t local = 0;
-                sweep([&](bool valid, size_t at) { if (valid && survives(region[at])) local++; });
+                sweep([&](bool valid, size_t at) { if (valid) { const uint64_t rec = region[at]; if (in_set(rec) && survives(rec)) local++; } });
                 local = wave_sum(local);
                 if (lane == 0 && local) atomicAdd(&sSurv, local);
             }
@@ -1143,7 +1164,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {
                     sweep([&](bool valid, size_t at) {
                         if (!valid) return;
                         const uint64_t rec = region[at];
-                        if (survives(rec)) atomicAdd(&sSubCnt[sub_of(rec, nSub)], 1u);
+                        if (in_set(rec) && survives(rec)) atomicAdd(&sSubCnt[sub_of(rec, nSub)], 1u);
                     });
                     __syncthreads();
                     for (uint32_t k = (uint32_t) tid; k < nSub; k += BLOCK) atomicMax(&sSubMax, sSubCnt[k]);
@@ -1166,7 +1187,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {
                     uint64_t rec = 0;
                     if (valid) {
                         rec = region[at];
-                        surv = survives(rec) && (nSub == 1 || sub_of(rec, nSub) == sub);
+                        surv = in_set(rec) && survives(rec) && (nSub == 1 || sub_of(rec, nSub) == sub);
                     }
                     const unsigned long long m = __ballot(surv);
                     if (m == 0) return;
@@ -1260,20 +1281,24 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {
                 }
                 tSortAcc += ts1 - ts0; tEmitAcc += wall_clock64() - ts1;
             }
+            }   // subsets of the group
             (void) tc0;
         }
         if (tid == 0) { atomicAdd(&A.totals[3], tGather - tStart); atomicAdd(&A.totals[4], tSortAcc); atomicAdd(&A.totals[5], tEmitAcc); }
     }
 }
 
-// shapes of the wide kernel: production (64 classes of 20 480 records: 1.3 M hits per query, 16 waves, groups of 16 K records), and a
-// miniature (MK_PREFILTER_TIERS=tiny) with which small test inputs fill classes, span several groups and need sub-classes
+// shapes of the wide kernel: production (16 classes of 81 920 records: 1.3 M hits per query, 16 waves, groups / subsets of 16 K records) and a
+// miniature (MK_PREFILTER_TIERS=tiny) with which small test inputs fill classes, span several groups, split classes into subsets and need
+// sub-classes.  Few classes on purpose: a class's write pointer is a partially written 128-byte line that must survive in L2 until its 16
+// records have arrived -- with 64 classes (the first version) the index probes of 32 workgroups per XCD evicted every such line between two of
+// its records, every 8-byte record cost a line fill and a write-back, and the kernel ran at a twentieth of its speed (profiles/r04_wide_kernel.txt)
 struct WideShape { int clsCap, nCls, maxpos, waves, wgPerCu; };
-const WideShape WIDE_SHAPES[2] = {{20480, 64, 2048, 16, 2}, {96, 8, 64, 4, 4}};
+const WideShape WIDE_SHAPES[2] = {{81920, 16, 2048, 16, 2}, {192, 4, 64, 4, 4}};
 template <int MODE>
 void launch_wide(int shape, const WideArgs &A, unsigned grid, hipStream_t stream) {
-    if (shape == 0) hipLaunchKernelGGL((wide_kernel<20480, 64, 16384, 4096, 131072, 2048, 16, 2, MODE>), dim3(grid), dim3(1024), 0, stream, A);
-    else hipLaunchKernelGGL((wide_kernel<96, 8, 128, 64, 1024, 64, 4, 2, MODE>), dim3(grid), dim3(256), 0, stream, A);
+    if (shape == 0) hipLaunchKernelGGL((wide_kernel<81920, 16, 16384, 4096, 131072, 2048, 16, 2, MODE>), dim3(grid), dim3(1024), 0, stream, A);
+    else hipLaunchKernelGGL((wide_kernel<192, 4, 64, 64, 1024, 64, 4, 2, MODE>), dim3(grid), dim3(256), 0, stream, A);
 }
 
 // =====================================================================================================
@@ -1973,11 +1998,14 @@ __global__ __launch_bounds__(256) void query_kmers_kernel(const uint64_t *qOff, 
 // similar k-mers fit KLIST_CAP; the queries the kernel cannot hold (more k-mer starts than it numbers, a full target class) come back
 // in `fallback` (chunk-local ids) for the global path.
 int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff, uint32_t a, uint32_t b, int shape, bool coResident,
-                    uint32_t &nCand, std::vector<uint32_t> &fallback, double &kmersPerPos, double &globalHitsPerPos, PrefilterStats *cs) {
+                    uint32_t &nCand, std::vector<uint32_t> &fallback, double &kmersPerPos, double &globalHitsPerPos, PrefilterStats *cs, bool &fallbackKmerStats) {
     std::string &err = *X.err;
     hipStream_t stream = X.stream;
     const WideShape &W = WIDE_SHAPES[shape];
-    const bool listed = Vin.p_sorted || Vin.kmer_size == 7;
+    // sequence queries with k = 7: the 7-mers are enumerated inside the kernel (no lists in HBM, no count pass); MK_PREFILTER_K7_LISTS=1 keeps the lists
+    const bool k7enum = !Vin.p_sorted && Vin.kmer_size == 7 && Vin.hist_range <= 256 && knob_long("MK_PREFILTER_K7_LISTS", 0) == 0;
+    const bool listed = (Vin.p_sorted || Vin.kmer_size == 7) && !k7enum;
+    fallbackKmerStats = k7enum;                        // (no per-query k-mer counts on the host in that mode: the global path counts those of the queries it takes)
     const size_t KLIST_CAP = (size_t) 1 << 31;                             // similar k-mers per piece (8 GB of table cells)
     const uint64_t POS_CAP = 48u << 20;                                    // residues per piece
     const int span = Vin.kmer_size == 7 ? 11 : 10;
@@ -2048,7 +2076,12 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
         dQK = (uint32_t *) dev_scratch("pf_qkmers", (size_t) nqp * 4);
         uint32_t *hQK = (uint32_t *) pinned_scratch("pf_qkmers_h", (size_t) nqp * 4);
         PNULL(dQK); PNULL(hQK);
-        if (listed) {
+        if (k7enum) {
+            for (uint32_t ql = 0; ql < nqp; ql++) {         // dealt by length: the number of k-mer starts stands for the work
+                const int64_t L = (int64_t) (hOff[(size_t) p0 + ql + 1] - hOff[(size_t) p0 + ql]);
+                hQK[ql] = (uint32_t) std::max<int64_t>(0, L - span + 1);
+            }
+        } else if (listed) {
             hipLaunchKernelGGL(query_kmers_kernel, dim3((nqp + 255) / 256), dim3(256), 0, stream, V.q_off, p0, nqp, hOff[p0], V.klist_off, dQK);
         } else {
             dPosCost = (uint16_t *) dev_scratch("pf_poscost", (size_t) (nPos + 16) * 2);
@@ -2059,8 +2092,10 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
             X.te(th);
         }
         PCHK(hipGetLastError());
-        PCHK(hipMemcpyAsync(hQK, dQK, (size_t) nqp * 4, hipMemcpyDeviceToHost, stream));
-        PCHK(sync_wait(stream, "wait_prefilter"));
+        if (!k7enum) {
+            PCHK(hipMemcpyAsync(hQK, dQK, (size_t) nqp * 4, hipMemcpyDeviceToHost, stream));
+            PCHK(sync_wait(stream, "wait_prefilter"));
+        }
         std::vector<uint32_t> order;
         {
             ScopedHost sh("host_prefilter_tiers");
@@ -2076,7 +2111,7 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
                 byClass[63 - std::min<uint64_t>(63, (uint64_t) hQK[ql] * 63 / most)].push_back(p0 + ql);
             }
             for (int c = 0; c < 64; c++) order.insert(order.end(), byClass[c].begin(), byClass[c].end());
-            if (cs) cs->kmers_per_pos += sum;
+            if (cs && !k7enum) cs->kmers_per_pos += sum;
         }
         if (!order.empty()) {
             uint32_t *hList = (uint32_t *) pinned_scratch("pf_flist_h", order.size() * 4);
@@ -2103,7 +2138,8 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
             A.overflow_list = dOvf; A.overflow_count = dCtr + 4; A.totals = dTot; A.work_counter = dCtr + 8;
             A.pos_cost = dPosCost; A.pos_begin = hOff[p0];
             const int th = X.tb("prefilter_query_wide", 0, 0);
-            if (listed) launch_wide<W_MODE_LIST>(shape, A, launch, stream);
+            if (k7enum) launch_wide<W_MODE_ENUM7>(shape, A, launch, stream);
+            else if (listed) launch_wide<W_MODE_LIST>(shape, A, launch, stream);
             else launch_wide<W_MODE_ENUM6>(shape, A, launch, stream);
             X.te(th);
             PCHK(hipGetLastError());
@@ -2112,14 +2148,14 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
             PCHK(sync_wait(stream, "wait_prefilter"));
             if (knob("MK_PREFILTER_DEBUG"))
                 fprintf(stderr, "[prefilter] wide piece %u..%u (%s): queries %zu overflowed %llu | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g sort %.3g emit %.3g overflowed %.3g | extra sub-class passes %llu | cand %u -> %u\n",
-                        p0, p1, listed ? "lists" : "k = 6 enumerator", order.size(), hTot[8], (double) hTot[0], (double) hTot[1], (double) hTot[2], (double) hTot[3], (double) hTot[4], (double) hTot[5],
+                        p0, p1, k7enum ? "7-mers in the kernel" : (listed ? "lists" : "k = 6 enumerator"), order.size(), hTot[8], (double) hTot[0], (double) hTot[1], (double) hTot[2], (double) hTot[3], (double) hTot[4], (double) hTot[5],
                         (double) hTot[6], hTot[9], nCand, hCtr[0]);
             if (hCtr[0] > X.candCap) return RC_CAND_OVERFLOW;
             if (hTot[10] != 0) {
                 // a single target class held more double-hit survivors of one sub-class than the LDS sort: the piece's candidates are dropped
                 // (nCand is not advanced) and the sort-based path does the piece
                 const bool sk = X.statsKmers;
-                X.statsKmers = false;
+                X.statsKmers = X.stats != nullptr && k7enum;
                 fallback.resize(fallbackMark);
                 const int rc = global_candidates(X, Vin, hOff, p0, p1, nullptr, (uint32_t) 0 - a, nCand, globalHitsPerPos);
                 X.statsKmers = sk;
@@ -2128,6 +2164,7 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
                 X.ts(th, 16.0 * (double) hTot[0] + 6.0 * (double) hTot[1], (double) hTot[0]);
                 nCand = hCtr[0];
                 if (cs) cs->db_matches += hTot[1];
+                if (cs && k7enum) { double sumK; std::memcpy(&sumK, &hTot[11], 8); cs->kmers_per_pos += sumK; }
                 const uint32_t nOvf = hCtr[4];
                 if (nOvf > 0) {
                     uint32_t *hOvf = (uint32_t *) pinned_scratch("pf_fovf_h", (size_t) nOvf * 4);
@@ -2242,10 +2279,13 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
         PrefilterStats cs;                                                 // this attempt at the chunk; committed when it is final
         X.stats = hooks.stats ? &cs : nullptr;
         std::vector<uint32_t> fallback;                                     // chunk-local ids for the global path
+        bool fallbackKmerStats = false;
         int rc = MK_OK;
         if (useWide) {
             // ---- A'. the wide per-query kernel; what it cannot hold comes back in `fallback`
-            rc = wide_candidates(X, V, qOff.data(), q0, q1, tierBase ? 1 : 0, hooks.co_resident, nCand, fallback, wideKmersPerPos, globalHitsPerPos, hooks.stats ? &cs : nullptr);
+            rc = wide_candidates(X, V, qOff.data(), q0, q1, tierBase ? 1 : 0, hooks.co_resident, nCand, fallback, wideKmersPerPos, globalHitsPerPos, hooks.stats ? &cs : nullptr,
+                                 fallbackKmerStats);
+            X.statsKmers = hooks.stats && fallbackKmerStats;
         } else if (useFused) {
             // ---- A. fused kernels, one launch per LDS tier; the tier follows the expected number of index hits
             std::vector<uint32_t> lists[N_TIERS];
