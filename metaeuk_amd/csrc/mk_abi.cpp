@@ -1225,15 +1225,17 @@ int mk_prefilter(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     return MK_OK;
 }
 
-// experiment hook (not part of the documented ABI): see mk::debug_probe_order
-int mk_debug_probe_order(mk_targetdb *db, mk_queries *q, uint32_t nq, int tileOrder, double out[4]) {
+// experiment hook (not part of the documented ABI; tools/micro/mk_experiments.hip is its only user): the device view of a (database,
+// batch) pair -- pointers into HBM, valid while both handles live -- and the batch's host offsets
+int mk_debug_prefilter_view(mk_targetdb *db, mk_queries *q, void *viewOut, size_t viewBytes, const uint64_t **qOffHost) {
     int rc = ensure_ready();
     if (rc) return rc;
-    if (!db || !q || !out || nq > q->n) return fail(MK_ERR_ARG, "bad argument");
+    if (!db || !q || !viewOut || viewBytes != sizeof(mk::PrefilterDeviceView)) return fail(MK_ERR_ARG, "bad argument (view of %zu bytes expected)", sizeof(mk::PrefilterDeviceView));
+    if ((rc = check_indexed(db, "mk_debug_prefilter_view")) != MK_OK) return rc;
     if ((rc = match_kmer_size(db, q)) != MK_OK) return rc;
-    std::string err;
-    rc = mk::debug_probe_order(prefilter_view(db, q), q->off, nq, tileOrder, g_stream, out, err);
-    if (rc != MK_OK) return fail(rc, "%s", err.c_str());
+    const mk::PrefilterDeviceView V = prefilter_view(db, q);
+    std::memcpy(viewOut, &V, sizeof(V));
+    if (qOffHost) *qOffHost = q->off.data();
     return MK_OK;
 }
 

@@ -474,23 +474,6 @@ __global__ __launch_bounds__(256) void kmer_count_kernel(PrefilterDeviceView V, 
     if (acc && lane == 0) atomicAdd(&perQuery[q - qFirst], acc);
 }
 
-// home tile of the k-mer that starts at a residue position (k = 6): the quads of its six letters, base 5 -- the 4096-cell tile of the
-// index table its in-quad variants share (mk_host.cpp: KMER_ADDR_LETTER).  Similar k-mers are substitutions of similar residues, so the
-// probes of starts with the same home tile fall into the same few hundred bitmap / slot lines.
-struct QuadOf { uint8_t q[20]; };
-__global__ __launch_bounds__(256) void tile_key_kernel(PrefilterDeviceView V, uint64_t posBegin, uint64_t nPos, QuadOf Q, uint16_t *key, uint32_t *idx) {
-    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nPos) return;
-    const uint64_t p = posBegin + i;
-    uint32_t k = 0xFFFFu;
-    if ((int) V.q_kmer_thr[p] >= 0) {
-        const uint8_t *r = V.q_res + p;
-        k = (uint32_t) Q.q[r[0]] + 5u * Q.q[r[1]] + 25u * Q.q[r[3]] + 125u * ((uint32_t) Q.q[r[5]] + 5u * Q.q[r[8]] + 25u * Q.q[r[9]]);
-    }
-    key[i] = (uint16_t) k;
-    idx[i] = (uint32_t) i;
-}
-
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 
 // =====================================================================================================
@@ -1104,7 +1087,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {
             for (uint32_t k = b; k < e; k++) { const uint32_t c = sPosBase[k]; sPosBase[k] = run; run += c; }
         }
         __syncthreads();
-        unsigned long long tSortAcc = 0, tEmitAcc = 0;
+        unsigned long long tSortAcc = 0, tEmitAcc = 0, tFilterAcc = 0;
         // ---- pass 2: the classes in groups of at most GROUP_MAX records (a single class may hold more)
         for (uint32_t c0 = 0; c0 < (uint32_t) NCLS; ) {
             uint32_t c1 = c0, recs = 0;
@@ -1128,6 +1111,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {
             const uint32_t nSets = (recs + (uint32_t) GROUP_MAX - 1u) / (uint32_t) GROUP_MAX;
             for (uint32_t set = 0; set < nSets; set++) {
             const auto in_set = [&](uint64_t rec) -> bool { return nSets == 1u || (((uint32_t) (rec & TMASK) * 0xC2B2AE35u) >> 8) % nSets == set; };
+            const unsigned long long tSet0 = wall_clock64();
             __syncthreads();                               // (the previous group's bitmaps and keys are no longer read)
             for (int k = tid; k < MBITS / 32; k += BLOCK) { sBm1[k] = 0; sBm2[k] = 0; }
             if (tid == 0) sSurv = 0;
@@ -1150,6 +1134,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {
                 if (lane == 0 && local) atomicAdd(&sSurv, local);
             }
             __syncthreads();
+            tFilterAcc += wall_clock64() - tSet0;
             const uint32_t nSurvAll = sSurv;
             if (nSurvAll == 0) continue;
             uint32_t nSub = 1;
@@ -1284,7 +1269,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {
             }   // subsets of the group
             (void) tc0;
         }
-        if (tid == 0) { atomicAdd(&A.totals[3], tGather - tStart); atomicAdd(&A.totals[4], tSortAcc); atomicAdd(&A.totals[5], tEmitAcc); }
+        if (tid == 0) { atomicAdd(&A.totals[3], tGather - tStart); atomicAdd(&A.totals[4], tSortAcc); atomicAdd(&A.totals[5], tEmitAcc); atomicAdd(&A.totals[12], tFilterAcc); }
     }
 }
 
@@ -2147,8 +2132,8 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
             PCHK(hipMemcpyAsync(hTot, dTot, 16 * 8, hipMemcpyDeviceToHost, stream));
             PCHK(sync_wait(stream, "wait_prefilter"));
             if (knob("MK_PREFILTER_DEBUG"))
-                fprintf(stderr, "[prefilter] wide piece %u..%u (%s): queries %zu overflowed %llu | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g sort %.3g emit %.3g overflowed %.3g | extra sub-class passes %llu | cand %u -> %u\n",
-                        p0, p1, k7enum ? "7-mers in the kernel" : (listed ? "lists" : "k = 6 enumerator"), order.size(), hTot[8], (double) hTot[0], (double) hTot[1], (double) hTot[2], (double) hTot[3], (double) hTot[4], (double) hTot[5],
+                fprintf(stderr, "[prefilter] wide piece %u..%u (%s): queries %zu overflowed %llu | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g filter %.3g collect+sort %.3g rule+emit %.3g overflowed %.3g | extra sub-class passes %llu | cand %u -> %u\n",
+                        p0, p1, k7enum ? "7-mers in the kernel" : (listed ? "lists" : "k = 6 enumerator"), order.size(), hTot[8], (double) hTot[0], (double) hTot[1], (double) hTot[2], (double) hTot[3], (double) hTot[12], (double) hTot[4], (double) hTot[5],
                         (double) hTot[6], hTot[9], nCand, hCtr[0]);
             if (hCtr[0] > X.candCap) return RC_CAND_OVERFLOW;
             if (hTot[10] != 0) {
@@ -2698,57 +2683,6 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     g_memo.candPerQuery = candPerQuery;
     (void) tOff;
     PCHK(sync_wait(stream, "wait_prefilter"));         // the last DMA into the result block
-    return MK_OK;
-}
-
-// experiment hook (tools/probe_order_experiment.py): the index probes of the k-mer starts of queries [0, nq) -- enumeration, bitmap, slot --
-// in natural order or ordered by home tile; out = {ms, similar k-mers, index hits, starts}
-int debug_probe_order(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOff, uint32_t nq, int tileOrder, hipStream_t stream, double out[4], std::string &err) {
-    const uint64_t nPos = qOff[nq] - qOff[0];
-    if (nPos == 0 || nPos >= 0xFFFFFFFFull) { err = "empty or too large"; return MK_ERR_ARG; }
-    uint32_t *dHit = (uint32_t *) dev_scratch("dbg_hit", (nPos + 1) * 4), *dKmer = (uint32_t *) dev_scratch("dbg_kmer", (nPos + 1) * 4);
-    uint16_t *dKey = (uint16_t *) dev_scratch("dbg_key", nPos * 2), *dKey2 = (uint16_t *) dev_scratch("dbg_key2", nPos * 2);
-    uint32_t *dIdx = (uint32_t *) dev_scratch("dbg_idx", nPos * 4), *dIdx2 = (uint32_t *) dev_scratch("dbg_idx2", nPos * 4);
-    PNULL(dHit); PNULL(dKmer); PNULL(dKey); PNULL(dKey2); PNULL(dIdx); PNULL(dIdx2);
-    ProbeArgs A;
-    A.V = V; A.pos_begin = qOff[0]; A.pos_end = qOff[nq]; A.q_first = 0; A.seq_bits = 0; A.hit_bits = 0;
-    A.hit_count = dHit; A.kmer_count = dKmer; A.keys = nullptr; A.diag_hi = nullptr;
-    uint64_t nItems = nPos;
-    if (tileOrder) {
-        QuadOf Q;
-        const uint8_t *addr = kmer_addr_letters();
-        for (int a = 0; a < 20; a++) Q.q[a] = addr[a] >> 2;
-        hipLaunchKernelGGL(tile_key_kernel, dim3((unsigned) ((nPos + 255) / 256)), dim3(256), 0, stream, V, A.pos_begin, nPos, Q, dKey, dIdx);
-        hipcub::DoubleBuffer<uint16_t> kb(dKey, dKey2);
-        hipcub::DoubleBuffer<uint32_t> ib(dIdx, dIdx2);
-        size_t tb = 0;
-        hipcub::DeviceRadixSort::SortPairs(nullptr, tb, kb, ib, (int) nPos, 0, 16, stream);
-        void *temp = dev_scratch("dbg_temp", tb);
-        PNULL(temp);
-        PCHK(hipcub::DeviceRadixSort::SortPairs(temp, tb, kb, ib, (int) nPos, 0, 16, stream));
-        A.order = ib.Current(); A.n_order = nPos;
-        PCHK(hipMemsetAsync(dHit, 0, (nPos + 1) * 4, stream));
-        PCHK(hipMemsetAsync(dKmer, 0, (nPos + 1) * 4, stream));
-    }
-    hipEvent_t e0, e1;
-    PCHK(hipEventCreate(&e0)); PCHK(hipEventCreate(&e1));
-    float best = 1e30f;
-    for (int rep = 0; rep < 3; rep++) {
-        PCHK(hipEventRecord(e0, stream));
-        hipLaunchKernelGGL(probe_kernel<false>, dim3((unsigned) ((nItems + 3) / 4)), dim3(256), 0, stream, A);
-        PCHK(hipEventRecord(e1, stream));
-        PCHK(hipStreamSynchronize(stream));
-        float ms = 0;
-        PCHK(hipEventElapsedTime(&ms, e0, e1));
-        best = std::min(best, ms);
-    }
-    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
-    std::vector<uint32_t> hHit(nPos), hKmer(nPos);
-    PCHK(hipMemcpy(hHit.data(), dHit, nPos * 4, hipMemcpyDeviceToHost));
-    PCHK(hipMemcpy(hKmer.data(), dKmer, nPos * 4, hipMemcpyDeviceToHost));
-    double kmers = 0, hits = 0, starts = 0;
-    for (uint64_t i = 0; i < nPos; i++) { kmers += hKmer[i]; hits += hHit[i]; starts += hKmer[i] != 0; }
-    out[0] = best; out[1] = kmers; out[2] = hits; out[3] = starts;
     return MK_OK;
 }
 

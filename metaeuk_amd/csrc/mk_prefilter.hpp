@@ -67,7 +67,4 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &q_o
                   struct HostBlock &outHits, size_t &nOutHits, std::vector<uint64_t> &outOff, std::string &err, timed_begin_fn tb, timed_end_fn te, timed_set_fn ts,
                   const PrefilterHooks &hooks);
 
-// experiment hook: index probes of the first nq queries' k-mer starts in natural (0) or home-tile (1) order; out = {ms, k-mers, hits, starts}
-int debug_probe_order(const PrefilterDeviceView &V, const std::vector<uint64_t> &q_off_host, uint32_t nq, int tileOrder, hipStream_t stream, double out[4], std::string &err);
-
 }  // namespace mk

@@ -26,9 +26,10 @@ def test_k7_prefilter_matches_the_real_process(gpu_api, tmp_path, monkeypatch):
     # every front end a k = 7 search can take: the sort-based global path and the miniature of the wide per-query kernel first, the
     # production shape of the wide kernel (the default) last -- its result goes on to the alignment checks below
     gold = _text("e2e_process_pref_k7.txt.gz")
-    for path, tiers in (("global", "default"), ("wide", "tiny"), ("auto", "default")):
+    for path, tiers, lists in (("global", "default", "0"), ("wide", "tiny", "0"), ("wide", "default", "1"), ("wide", "tiny", "1"), ("auto", "default", "0")):
         monkeypatch.setenv("MK_PREFILTER_PATH", path)
         monkeypatch.setenv("MK_PREFILTER_TIERS", tiers)
+        monkeypatch.setenv("MK_PREFILTER_K7_LISTS", lists)        # 1: the 7-mers as lists in HBM (what profile queries use); 0: enumerated inside the kernel
         _k7_pass(api, tmp_path, gold, check_more=(path == "auto"))
 
 
