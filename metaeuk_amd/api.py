@@ -99,6 +99,13 @@ def device_name():
     return buf.value.decode()
 
 
+def device_memory():
+    """(free, total) bytes of the device's HBM"""
+    f, t = C.c_uint64(), C.c_uint64()
+    _chk(lib().mk_device_memory(C.byref(f), C.byref(t)))
+    return int(f.value), int(t.value)
+
+
 def encode(seqs):
     """list of str -> (uint8 residues, uint64 offsets[n+1])"""
     off = np.zeros(len(seqs) + 1, dtype=np.uint64)

@@ -892,8 +892,8 @@ struct WideArgs {
     const uint16_t *pos_cost; uint64_t pos_begin;     // MODE 0: work estimate of every k-mer start (kmer_count_kernel)
 };
 
-template <int CLS_CAP, int NCLS, int GROUP_MAX, int SURV, int MBITS, int MAXPOS, int NW, int U, int MODE>
-__global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {
+template <int CLS_CAP, int NCLS, int GROUP_MAX, int SURV, int MBITS, int MAXPOS, int NW, int U, int MODE, int MINW = 8>
+__global__ __launch_bounds__(NW * 64, MINW) void wide_kernel(WideArgs A) {
     constexpr int BLOCK = NW * WAVE;
     constexpr int LOG_MBITS = ilog2(MBITS), LOG_NCLS = ilog2(NCLS);
     constexpr int TSHIFT = 16 + (int) W_RANK_BITS;
@@ -1096,14 +1096,23 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {
             c0 = c1;
             if (recs == 0) continue;
             const unsigned long long tc0 = wall_clock64();
-            // the records of the group, BLOCK at a time (every thread of the workgroup takes part in every step)
+            // the records of the group, 4 x BLOCK at a time: four loads in flight per thread (the sweeps are bound by memory latency), and every
+            // thread of the workgroup takes part in every step
             const auto sweep = [&](auto &&fn) {
                 for (uint32_t c = g0; c < g1; c++) {
                     const uint32_t nC = sClsUsed[c];
                     const size_t base = (size_t) c * CLS_CAP;
-                    for (uint32_t s0 = 0; s0 < nC; s0 += BLOCK) {
-                        const uint32_t s = s0 + (uint32_t) tid;
-                        fn(s < nC, base + s);
+                    for (uint32_t s0 = 0; s0 < nC; s0 += 4u * BLOCK) {
+                        uint64_t rec[4];
+                        bool ok[4];
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++) {
+                            const uint32_t s = s0 + k * BLOCK + (uint32_t) tid;
+                            ok[k] = s < nC;
+                            rec[k] = ok[k] ? region[base + s] : 0ull;
+                        }
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++) fn(ok[k], base + s0 + k * BLOCK + (uint32_t) tid, rec[k]);
                     }
                 }
             };
@@ -1114,66 +1123,24 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {
             const unsigned long long tSet0 = wall_clock64();
             __syncthreads();                               // (the previous group's bitmaps and keys are no longer read)
             for (int k = tid; k < MBITS / 32; k += BLOCK) { sBm1[k] = 0; sBm2[k] = 0; }
-            if (tid == 0) sSurv = 0;
             __syncthreads();
             // ---- 2a: target buckets hit once / twice
-            sweep([&](bool valid, size_t at) {
-                if (!valid) return;
-                const uint64_t rec = region[at];
-                if (!in_set(rec)) return;
+            sweep([&](bool valid, size_t, uint64_t rec) {
+                if (!valid || !in_set(rec)) return;
                 const uint32_t hb = ((uint32_t) (rec & TMASK) * 0x9E3779B1u) >> (32 - LOG_MBITS);
                 const uint32_t bit = 1u << (hb & 31u);
                 if (atomicOr(&sBm1[hb >> 5], bit) & bit) atomicOr(&sBm2[hb >> 5], bit);
             });
             __syncthreads();
-            // ---- 2b: how many records survive; target sub-classes if they do not fit the LDS sort at once
-            {
-                uint32_t local = 0;
-                sweep([&](bool valid, size_t at) { if (valid) { const uint64_t rec = region[at]; if (in_set(rec) && survives(rec)) local++; } });
-                local = wave_sum(local);
-                if (lane == 0 && local) atomicAdd(&sSurv, local);
-            }
-            __syncthreads();
             tFilterAcc += wall_clock64() - tSet0;
-            const uint32_t nSurvAll = sSurv;
-            if (nSurvAll == 0) continue;
-            uint32_t nSub = 1;
-            if (nSurvAll > (uint32_t) SURV) {
-                nSub = (nSurvAll + (uint32_t) (SURV * 3 / 4) - 1) / (uint32_t) (SURV * 3 / 4);
-                for (;;) {
-                    if (nSub > (uint32_t) STREAM_MAX_CLASSES) nSub = STREAM_MAX_CLASSES;
-                    __syncthreads();
-                    for (uint32_t k = (uint32_t) tid; k < nSub; k += BLOCK) sSubCnt[k] = 0;
-                    if (tid == 0) sSubMax = 0;
-                    __syncthreads();
-                    sweep([&](bool valid, size_t at) {
-                        if (!valid) return;
-                        const uint64_t rec = region[at];
-                        if (in_set(rec) && survives(rec)) atomicAdd(&sSubCnt[sub_of(rec, nSub)], 1u);
-                    });
-                    __syncthreads();
-                    for (uint32_t k = (uint32_t) tid; k < nSub; k += BLOCK) atomicMax(&sSubMax, sSubCnt[k]);
-                    __syncthreads();
-                    if (sSubMax <= (uint32_t) SURV || nSub == (uint32_t) STREAM_MAX_CLASSES) break;
-                    nSub += 1 + nSub / 4;
-                }
-                if (tid == 0) atomicAdd(&A.totals[9], (unsigned long long) (nSub - 1));
-            }
-            // (GROUP_MAX <= STREAM_MAX_CLASSES * SURV / 2 for every shape in use: the sub-classes always fit; a sub-class that does not -- a
-            //  single target with more than SURV hits in the group -- is cut at SURV below and flagged)
-            for (uint32_t sub = 0; sub < nSub; sub++) {
-                const unsigned long long ts0 = wall_clock64();
+            // ---- 2b: the survivors of sub-class `sub` of `nSub` -> LDS sort keys (any order: the key carries the arrival rank); sSurv counts
+            // them all, the keys beyond the LDS sort are dropped (the caller looks at sSurv)
+            const auto collect = [&](uint32_t sub, uint32_t nSub) {
                 __syncthreads();
                 if (tid == 0) sSurv = 0;
                 __syncthreads();
-                // ---- 2c: survivors of this sub-class -> LDS sort keys (any order: the key carries the arrival rank)
-                sweep([&](bool valid, size_t at) {
-                    bool surv = false;
-                    uint64_t rec = 0;
-                    if (valid) {
-                        rec = region[at];
-                        surv = in_set(rec) && survives(rec) && (nSub == 1 || sub_of(rec, nSub) == sub);
-                    }
+                sweep([&](bool valid, size_t at, uint64_t rec) {
+                    const bool surv = valid && in_set(rec) && survives(rec) && (nSub == 1 || sub_of(rec, nSub) == sub);
                     const unsigned long long m = __ballot(surv);
                     if (m == 0) return;
                     uint32_t wbase = 0;
@@ -1188,6 +1155,42 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {
                         }
                     }
                 });
+                __syncthreads();
+            };
+            // optimistically as ONE sub-class (no counting sweep): nearly every group's survivors fit the LDS sort
+            const unsigned long long tOpt0 = wall_clock64();
+            collect(0u, 1u);
+            const uint32_t nSurvAll = sSurv;
+            if (nSurvAll == 0) continue;
+            uint32_t nSub = 1;
+            bool collected = true;                         // sKey holds the survivors of sub-class 0 of 1
+            if (nSurvAll > (uint32_t) SURV) {
+                // target sub-classes that fit
+                collected = false;
+                nSub = (nSurvAll + (uint32_t) (SURV * 3 / 4) - 1) / (uint32_t) (SURV * 3 / 4);
+                for (;;) {
+                    if (nSub > (uint32_t) STREAM_MAX_CLASSES) nSub = STREAM_MAX_CLASSES;
+                    __syncthreads();
+                    for (uint32_t k = (uint32_t) tid; k < nSub; k += BLOCK) sSubCnt[k] = 0;
+                    if (tid == 0) sSubMax = 0;
+                    __syncthreads();
+                    sweep([&](bool valid, size_t, uint64_t rec) {
+                        if (valid && in_set(rec) && survives(rec)) atomicAdd(&sSubCnt[sub_of(rec, nSub)], 1u);
+                    });
+                    __syncthreads();
+                    for (uint32_t k = (uint32_t) tid; k < nSub; k += BLOCK) atomicMax(&sSubMax, sSubCnt[k]);
+                    __syncthreads();
+                    if (sSubMax <= (uint32_t) SURV || nSub == (uint32_t) STREAM_MAX_CLASSES) break;
+                    nSub += 1 + nSub / 4;
+                }
+                if (tid == 0) atomicAdd(&A.totals[9], (unsigned long long) (nSub - 1));
+            }
+            // (GROUP_MAX <= STREAM_MAX_CLASSES * SURV / 2 for every shape in use: the sub-classes always fit; a sub-class that does not -- a
+            //  single target with more than SURV hits in the group -- is cut at SURV below and flagged)
+            for (uint32_t sub = 0; sub < nSub; sub++) {
+                const unsigned long long ts0 = sub == 0 ? tOpt0 : wall_clock64();
+                if (!collected) collect(sub, nSub);
+                collected = false;
                 __syncthreads();
                 uint32_t nSurv = sSurv;
                 if (nSurv > (uint32_t) SURV) { if (tid == 0) atomicAdd(&A.totals[10], 1ull); nSurv = SURV; }     // (reported by the host as an error: never seen)
@@ -1273,22 +1276,61 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {
     }
 }
 
-// shapes of the wide kernel: production (16 classes of 81 920 records: 1.3 M hits per query, 16 waves, groups / subsets of 16 K records) and a
+// shapes of the wide kernel: production (16 classes of 131 072 records: 2.1 M hits per query, 16 waves, groups / subsets of 16 K records) and a
 // miniature (MK_PREFILTER_TIERS=tiny) with which small test inputs fill classes, span several groups, split classes into subsets and need
 // sub-classes.  Few classes on purpose: a class's write pointer is a partially written 128-byte line that must survive in L2 until its 16
 // records have arrived -- with 64 classes (the first version) the index probes of 32 workgroups per XCD evicted every such line between two of
 // its records, every 8-byte record cost a line fill and a write-back, and the kernel ran at a twentieth of its speed (profiles/r04_wide_kernel.txt)
 struct WideShape { int clsCap, nCls, maxpos, waves, wgPerCu; };
-const WideShape WIDE_SHAPES[2] = {{81920, 16, 2048, 16, 2}, {192, 4, 64, 4, 4}};
+const WideShape WIDE_SHAPES[2] = {{131072, 16, 2048, 16, 2}, {192, 4, 64, 4, 4}};
 template <int MODE>
 void launch_wide(int shape, const WideArgs &A, unsigned grid, hipStream_t stream) {
-    if (shape == 0) hipLaunchKernelGGL((wide_kernel<81920, 16, 16384, 4096, 131072, 2048, 16, 2, MODE>), dim3(grid), dim3(1024), 0, stream, A);
+    // MK_PREFILTER_WIDE_REGS=128: the build with 128 instead of 64 vector registers per lane (one workgroup per CU)
+    if (shape == 0 && knob_long("MK_PREFILTER_WIDE_REGS", 64) == 128) hipLaunchKernelGGL((wide_kernel<131072, 16, 16384, 4096, 131072, 2048, 16, 2, MODE, 4>), dim3(grid), dim3(1024), 0, stream, A);
+    else if (shape == 0) hipLaunchKernelGGL((wide_kernel<131072, 16, 16384, 4096, 131072, 2048, 16, 2, MODE>), dim3(grid), dim3(1024), 0, stream, A);
     else hipLaunchKernelGGL((wide_kernel<192, 4, 64, 64, 1024, 64, 4, 2, MODE>), dim3(grid), dim3(256), 0, stream, A);
 }
 
 // =====================================================================================================
 //  common back end
 // =====================================================================================================
+// ungapped_score for a sequence query when both sequences are shorter than 32 768 (the common case: one real diagonal), with the three byte
+// streams -- query residues, their int8 correction, target residues -- read as aligned dwords, four cells per load (a lane walks its own
+// diagonal: byte loads cost the texture unit a transaction per lane and cell, and the kernel runs beside both other stages).  Same arithmetic
+// as ungapped_on_diagonal_fn (mk_kernels.hpp), cell by cell.
+__device__ __forceinline__ int ungapped_score_dwords(const int8_t *smat, const uint8_t *q, const int8_t *corr, uint32_t qLen, const uint8_t *t, uint32_t tLen, uint32_t d16) {
+    const uint32_t wrapped = (0x10000u - d16) & 0xFFFFu;
+    const uint32_t dist = wrapped < d16 ? wrapped : d16;                     // distanceFromDiagonal
+    const int diagonal = (int) (short) (uint16_t) d16;
+    uint32_t len = 0, q0 = 0, t0 = 0;
+    if (diagonal >= 0 && dist < qLen) { len = tLen < qLen - dist ? tLen : qLen - dist; q0 = dist; }
+    else if (diagonal < 0 && dist < tLen) { len = tLen - dist < qLen ? tLen - dist : qLen; t0 = dist; }
+    const uint8_t *qp = q + q0, *tp = t + t0;
+    const uint8_t *cp = reinterpret_cast<const uint8_t *>(corr) + q0;
+    int score = 0, best = 0;
+    const auto cell = [&](uint32_t qb, uint32_t cb, uint32_t tb) {
+        const int curr = (int) (int8_t) (uint8_t) ((uint32_t) (uint8_t) smat[qb * 21u + tb] + cb);
+        score = score + curr > 0 ? score + curr : 0;
+        best = best > score ? best : score;
+    };
+    uint32_t k = 0;
+    if (len >= 8) {
+        const uint32_t aq = (uint32_t) (reinterpret_cast<uintptr_t>(qp) & 3u), ac = (uint32_t) (reinterpret_cast<uintptr_t>(cp) & 3u), at = (uint32_t) (reinterpret_cast<uintptr_t>(tp) & 3u);
+        const uint32_t *qw = reinterpret_cast<const uint32_t *>(qp - aq), *cw = reinterpret_cast<const uint32_t *>(cp - ac), *tw = reinterpret_cast<const uint32_t *>(tp - at);
+        uint32_t q0w = qw[0], c0w = cw[0], t0w = tw[0];
+        // chunk c = bytes 4c .. 4c + 3 of a stream = bytes a .. a + 3 of the dword pair (w[c], w[c + 1]); the pair ends at stream byte 4c + 7 - a
+        for (uint32_t c = 0; k + 8 <= len; c++, k += 4) {
+            const uint32_t q1w = qw[c + 1], c1w = cw[c + 1], t1w = tw[c + 1];
+            const uint32_t qv = __builtin_amdgcn_alignbyte(q1w, q0w, aq), cv = __builtin_amdgcn_alignbyte(c1w, c0w, ac), tv = __builtin_amdgcn_alignbyte(t1w, t0w, at);
+            q0w = q1w; c0w = c1w; t0w = t1w;
+#pragma unroll
+            for (int b = 0; b < 4; b++) cell((qv >> (8 * b)) & 0xFFu, (cv >> (8 * b)) & 0xFFu, (tv >> (8 * b)) & 0xFFu);
+        }
+    }
+    for (; k < len; k++) cell((uint32_t) qp[k], (uint32_t) cp[k], (uint32_t) tp[k]);
+    return best;
+}
+
 // exact ungapped diagonal score of every candidate
 __global__ __launch_bounds__(256) void diag_score_kernel(PrefilterDeviceView V, uint32_t qFirst, uint32_t n, CandArrays C) {
     helper_prio();
@@ -1302,7 +1344,8 @@ __global__ __launch_bounds__(256) void diag_score_kernel(PrefilterDeviceView V, 
     const uint64_t qs = V.q_off[q], ts = V.t_off[id];
     const uint32_t qLen = (uint32_t) (V.q_off[q + 1] - qs), tLen = (uint32_t) (V.t_off[id + 1] - ts);
     const int best = V.p_aln ? ungapped_score_profile(V.p_aln + qs * PROFILE_ALN_STRIDE, qLen, V.t_masked + ts, tLen, d16)
-                             : ungapped_score(smat, V.q_res + qs, V.q_corr + qs, qLen, V.t_masked + ts, tLen, d16);
+                   : ((qLen < 32768u && tLen < 32768u) ? ungapped_score_dwords(smat, V.q_res + qs, V.q_corr + qs, qLen, V.t_masked + ts, tLen, d16)
+                                                       : ungapped_score(smat, V.q_res + qs, V.q_corr + qs, qLen, V.t_masked + ts, tLen, d16));
     C.score[c] = best;
 }
 

@@ -225,3 +225,76 @@ def test_config5_scale_4e9_residues_index_beyond_2_32_entries(gpu_api, tmp_path)
     more than 2^32 entries (40-bit list starts without MK_TEST_ENTRY_BASE), built in HBM, written as an index DB and loaded back"""
     r = _config5_case(gpu_api, tmp_path, int(os.environ.get("MK_TEST_CONFIG5_TARGETS", "11800000")), 0)
     assert r["target_residues"] >= 4.4e9 and r["index_entries"] > 2 ** 32
+
+
+def test_config5_full_scale_60M_proteins_on_one_gpu(gpu_api, tmp_path, monkeypatch):
+    """BASELINE config 5's target side at its stated size on ONE MI355X: 60 000 000 proteins (2.2e10 residues with the native generator's
+    375-residue families -- UniRef50's ~1.8e10 and more), k = 7 chosen by IndexTable::computeKmerSize, masked and indexed in HBM (2.2e10
+    entries: 175 GB of the 288), searched with planted fragments.  What is checked at this size: the index totals, planted-homolog recall,
+    and that the two independent prefilter front ends -- the wide per-query kernel (7-mers enumerated in the kernel) and the sort-based
+    global path (7-mers as lists) -- return byte-identical hits and alignments for a sample of the fragments.  NOT checked here: the
+    reference's own run (its index build alone needs ~270 GB of host memory and minutes of a 16-core quota at this size; the same code
+    paths are digest-equal to it at 1.0e9 and 4.4e9 residues above), and the index-DB round trip (133 GB of scratch disk)."""
+    import json
+    import sys
+    import time
+    api = gpu_api
+    n_targets = int(os.environ.get("MK_TEST_CONFIG5_FULL", "60000000"))
+    free, total = api.device_memory()
+    if total < 280e9 and n_targets >= 60000000:
+        pytest.skip("needs a 288 GB device")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import config5_digest as c5
+    n_queries = 4000
+    t0 = time.time()
+    res, off = api.synth_targets(n_targets, seed=c5.TARGET_SEED)
+    fr, foff, src = api.synth_fragments(n_queries, res, off, **c5.FRAGMENTS)
+    t_gen = time.time() - t0
+    p = api.default_params()
+    api.kernel_stats(reset=True)
+    t0 = time.time()
+    db = api.TargetDB.from_codes(res, off, p)
+    t_build = time.time() - t0
+    st = api.kernel_stats()
+    assert db.kmer_size() == 7
+    n_res = int(off[-1])
+    report = dict(n_targets=n_targets, target_residues=n_res, index_entries=db.index_entries(), masked_residues=db.masked_residues(), longest_list=db.longest_list(),
+                  t_generate_s=round(t_gen, 2), t_targetdb_s=round(t_build, 2),
+                  index_kernels_ms={k: round(v["ms"], 1) for k, v in st.items() if k.startswith("index_") or k.startswith("host_index")},
+                  device_memory_free_after_build_gb=round(api.device_memory()[0] / 1e9, 1))
+    del res
+    assert report["index_entries"] > 0.9 * n_res and report["index_entries"] < n_res
+    q = api.Queries.from_codes(fr, foff, p)
+    api.kernel_stats(reset=True)
+    t0 = time.time()
+    (hits, hoff), (alns, aoff) = api.search(db, q, p)
+    report["t_search_s"] = round(time.time() - t0, 2)
+    report["fragments"] = n_queries
+    report["fragments_per_s"] = round(n_queries / (time.time() - t0), 1)
+    report["search_kernels_ms"] = {k: round(v["ms"], 1) for k, v in sorted(api.kernel_stats().items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] >= 5.0}
+    report["pref_hits"], report["alignments"] = int(hoff[-1]), int(aoff[-1])
+    alns_np = np.frombuffer(alns, dtype=np.dtype([("db_key", "<u4"), ("rest", "V60")])) if int(aoff[-1]) else None
+    planted = np.flatnonzero(src != 0xFFFFFFFF)
+    found = sum(int(np.any(alns_np["db_key"][int(aoff[k]):int(aoff[k + 1])] // 10 == src[k] // 10)) for k in planted) if alns_np is not None else 0
+    report["planted_recall"] = round(found / float(len(planted)), 4)
+    assert report["planted_recall"] > 0.97, report
+    # the other front end on a sample: same bytes
+    n_s = 400
+    monkeypatch.setenv("MK_PREFILTER_PATH", "global")
+    qs = api.Queries.from_codes(fr[:int(foff[n_s])], foff[:n_s + 1], p)
+    t0 = time.time()
+    (h2, ho2), (a2, ao2) = api.search(db, qs, p)
+    report["t_search_global_path_sample_s"] = round(time.time() - t0, 2)
+    monkeypatch.delenv("MK_PREFILTER_PATH")
+    assert np.array_equal(np.asarray(ho2), np.asarray(hoff[:n_s + 1])) and np.array_equal(np.asarray(ao2), np.asarray(aoff[:n_s + 1]))
+    assert api.format_hits_bulk(h2, 0, int(ho2[-1])) == api.format_hits_bulk(hits, 0, int(hoff[n_s]))
+    assert api.format_alignments_bulk(a2, 0, int(ao2[-1])) == api.format_alignments_bulk(alns, 0, int(aoff[n_s]))
+    report["front_ends_agree_on_sample"] = n_s
+    report["sha256_pref"] = oracle.digest_arrays(hoff, api.format_hits_bulk(hits, 0, int(hoff[-1])), n_queries)
+    report["sha256_aln"] = oracle.digest_arrays(aoff, api.format_alignments_bulk(alns, 0, int(aoff[-1])), n_queries)
+    print("config-5 full scale:", json.dumps(report))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "config5_case_%d.json" % n_targets), "w") as f:
+            json.dump(report, f, indent=1)
+    db.close()

@@ -74,14 +74,26 @@ __global__ __launch_bounds__(256) void direct_probe_kernel(const uint32_t *cells
 }
 
 // B1. tile of TILE k-mers -> LDS counting sort by partition -> one reservation per (tile, partition), runs written coalesced
+__global__ __launch_bounds__(256) void partition_count_kernel(const uint32_t *cells, uint64_t n, uint32_t cellsPerPart, uint32_t nPart, unsigned long long *count) {
+    extern __shared__ uint32_t smem[];
+    for (uint32_t k = threadIdx.x; k < nPart; k += 256) smem[k] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t) gridDim.x * 256;
+    for (uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += stride) atomicAdd(&smem[cells[i] / cellsPerPart], 1u);
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < nPart; k += 256) if (smem[k]) atomicAdd(&count[k], (unsigned long long) smem[k]);
+}
+
+// (cursor[p] starts at the partition's first record: the partitions are sized exactly by a counting pass -- the k-mer space is probed very
+//  unevenly, the largest of 256 cell ranges holds 7 x the mean)
 template <int TILE, int REC_WORDS>
 __global__ __launch_bounds__(256) void partition_kernel(const uint32_t *cells, uint64_t n, uint32_t cellsPerPart, uint32_t nPart, unsigned long long *cursor /* [nPart]: next free record */,
-                                                        uint64_t partCap, uint32_t *records /* [nPart][partCap][REC_WORDS] */, unsigned long long *overflow) {
+                                                        uint32_t *records /* [n][REC_WORDS] */) {
     extern __shared__ uint32_t smem[];
     uint32_t *sCount = smem;                       // [nPart] counts, then starts
-    uint32_t *sBase = smem + nPart;                // [nPart] global start of the tile's run
+    unsigned long long *sBase = reinterpret_cast<unsigned long long *>(smem + 4 * nPart + (size_t) TILE * REC_WORDS);     // [nPart] global start of the tile's run (behind the cells)
     uint32_t *sFill = smem + 2 * nPart;            // [nPart] cursor inside the tile
-    uint32_t *sCell = smem + 3 * nPart;            // [TILE] cells ordered by partition
+    uint32_t *sCell = smem + 4 * nPart;            // [TILE] cells ordered by partition (4 nPart: keeps the 64-bit starts behind them aligned)
     uint32_t *sSrc = sCell + TILE;                 // [TILE] origin (REC_WORDS == 2)
     const uint64_t t0 = (uint64_t) blockIdx.x * TILE;
     const uint32_t m = (uint32_t) min((uint64_t) TILE, n - t0);
@@ -105,9 +117,7 @@ __global__ __launch_bounds__(256) void partition_kernel(const uint32_t *cells, u
             for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t) __shfl_up((int) x, d, 64); if ((int) threadIdx.x >= d) x += y; }
             if (p < nPart) {
                 sCount[p] = carry + x - c;
-                unsigned long long g = c ? atomicAdd(&cursor[p], (unsigned long long) c) : 0ull;
-                if (g + c > partCap) { atomicAdd(overflow, 1ull); g = 0; }
-                sBase[p] = (uint32_t) g;
+                sBase[p] = c ? atomicAdd(&cursor[p], (unsigned long long) c) : 0ull;
             }
             carry += (uint32_t) __shfl((int) x, 63, 64);
         }
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(256) void partition_kernel(const uint32_t *cells, u
         uint32_t lo = 0, hi = nPart;
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sCount[mid] <= x) lo = mid; else hi = mid; }
         // (empty partitions share their start with the next one: take the last partition whose start is <= x)
-        const uint64_t dst = ((uint64_t) lo * partCap + sBase[lo] + (x - sCount[lo])) * REC_WORDS;
+        const uint64_t dst = (sBase[lo] + (x - sCount[lo])) * REC_WORDS;
         records[dst] = sCell[x];
         if (REC_WORDS == 2) records[dst + 1] = sSrc[x];
     }
@@ -137,13 +147,13 @@ __global__ __launch_bounds__(256) void partition_kernel(const uint32_t *cells, u
 
 // B2. partition p is probed by the persistent workgroups of XCD p % 8; G workgroups per XCD
 template <int REC_WORDS, int ILP>
-__global__ __launch_bounds__(256) void partition_probe_kernel(const uint32_t *records, const unsigned long long *cursor, uint32_t nPart, uint64_t partCap,
+__global__ __launch_bounds__(256) void partition_probe_kernel(const uint32_t *records, const unsigned long long *partStart /* [nPart + 1] */, uint32_t nPart,
                                                               const uint32_t *bits, const uint64_t *slots, unsigned long long *out) {
     const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, G = gridDim.x >> 3;
     unsigned long long hits = 0, acc = 0;
     for (uint32_t p = xcd; p < nPart; p += 8) {
-        const uint64_t n = min((uint64_t) cursor[p], partCap);      // (an overflowing partition -- reported, its case not compared -- is read up to its room)
-        const uint32_t *rec = records + (uint64_t) p * partCap * REC_WORDS;
+        const uint64_t n = partStart[p + 1] - partStart[p];
+        const uint32_t *rec = records + partStart[p] * REC_WORDS;
         const uint64_t stride = (uint64_t) G * 256 * ILP;
         for (uint64_t base = (uint64_t) j * 256 * ILP; base < n; base += stride) {
             uint32_t c[ILP];
@@ -186,8 +196,8 @@ extern "C" const char *mkx_last_error() { return g_err; }
 // view: mk::PrefilterDeviceView of a k = 6 database and a sequence batch (mk_debug_prefilter_view); qOff: the batch's host offsets.
 // nParts[nCases] partitions to try (each <= 1024), recWords[nCases] 1 or 2.  out[0..7]: k-mers, index hits (present k-mers), ms of the count
 // enumeration, ms of the fill enumeration, ms direct ILP 2, ms direct ILP 4, ms direct ILP 8, checksum agreement (1 = every variant found the
-// same present k-mers and slot sum); out[8 + 4 c ...]: case c: ms partition pass, ms probe pass (G = 8 workgroups per CU... best of the grids tried),
-// overflowing reservations, largest partition / mean
+// same present k-mers and slot sum); out[8 + 4 c ...]: case c: ms partition pass, ms probe pass (best of 4 / 8 / 16 workgroups per CU),
+// ms of the counting pass that sizes the partitions, largest partition / mean
 extern "C" int mkx_partition_probe(const void *view, size_t viewBytes, const uint64_t *qOff, uint32_t nq, const int *nParts, const int *recWords, int nCases, double *out) {
     if (viewBytes != sizeof(PrefilterDeviceView)) { snprintf(g_err, sizeof(g_err), "view size mismatch"); return -1; }
     PrefilterDeviceView V = *static_cast<const PrefilterDeviceView *>(view);
@@ -243,42 +253,46 @@ extern "C" int mkx_partition_probe(const void *view, size_t viewBytes, const uin
         const uint32_t P = (uint32_t) nParts[c];
         const int RW = recWords[c];
         const uint32_t cellsPerPart = (uint32_t) ((cellsTotal + P - 1) / P);
-        const uint64_t partCap = (uint64_t) ((double) nK / P * 1.6) + 65536;       // the k-mer space is not probed evenly
-        uint32_t *dRec = nullptr; unsigned long long *dCur = nullptr, *dOvf = nullptr;
-        XCHK(hipMalloc(&dRec, (uint64_t) P * partCap * RW * 4)); XCHK(hipMalloc(&dCur, (size_t) P * 8)); XCHK(hipMalloc(&dOvf, 8));
+        uint32_t *dRec = nullptr; unsigned long long *dCur = nullptr, *dStart = nullptr;
+        XCHK(hipMalloc(&dRec, nK * RW * 4)); XCHK(hipMalloc(&dCur, (size_t) P * 8)); XCHK(hipMalloc(&dStart, (size_t) (P + 1) * 8));
         constexpr int TILE = 8192;
         const unsigned pb = (unsigned) ((nK + TILE - 1) / TILE);
-        const size_t lds = (size_t) (3 * P + TILE * RW) * 4;
+        const size_t lds = (size_t) (4 * P + TILE * RW) * 4 + (size_t) P * 8;
         if (RW == 1) XCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&partition_kernel<TILE, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         else XCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&partition_kernel<TILE, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-        float msPart = 0, msProbe = 1e30f;
-        int rc = timed(s, 3, msPart, [&] {
-            (void) hipMemsetAsync(dCur, 0, (size_t) P * 8, s); (void) hipMemsetAsync(dOvf, 0, 8, s);
-            if (RW == 1) hipLaunchKernelGGL((partition_kernel<TILE, 1>), dim3(pb), dim3(256), lds, s, dCells, nK, cellsPerPart, P, dCur, partCap, dRec, dOvf);
-            else hipLaunchKernelGGL((partition_kernel<TILE, 2>), dim3(pb), dim3(256), lds, s, dCells, nK, cellsPerPart, P, dCur, partCap, dRec, dOvf);
+        // counting pass (timed with the partition pass: a real implementation needs it too, or generous slack)
+        std::vector<unsigned long long> hCnt(P), hStart(P + 1, 0);
+        float msCountP = 0, msPart = 0, msProbe = 1e30f;
+        int rc = timed(s, 3, msCountP, [&] {
+            (void) hipMemsetAsync(dCur, 0, (size_t) P * 8, s);
+            hipLaunchKernelGGL(partition_count_kernel, dim3(cus * 8), dim3(256), (size_t) P * 4, s, dCells, nK, cellsPerPart, P, dCur);
         });
         if (rc) return -1;
-        std::vector<unsigned long long> hCur(P);
-        unsigned long long hOvf = 0;
-        XCHK(hipMemcpy(hCur.data(), dCur, (size_t) P * 8, hipMemcpyDeviceToHost));
-        XCHK(hipMemcpy(&hOvf, dOvf, 8, hipMemcpyDeviceToHost));
+        XCHK(hipMemcpy(hCnt.data(), dCur, (size_t) P * 8, hipMemcpyDeviceToHost));
         unsigned long long mx = 0, sum = 0;
-        for (uint32_t p = 0; p < P; p++) { mx = std::max(mx, hCur[p]); sum += hCur[p]; }
+        for (uint32_t p = 0; p < P; p++) { hStart[p + 1] = hStart[p] + hCnt[p]; mx = std::max(mx, hCnt[p]); sum += hCnt[p]; }
+        XCHK(hipMemcpy(dStart, hStart.data(), (size_t) (P + 1) * 8, hipMemcpyHostToDevice));
+        rc = timed(s, 3, msPart, [&] {
+            (void) hipMemcpyAsync(dCur, dStart, (size_t) P * 8, hipMemcpyDeviceToDevice, s);
+            if (RW == 1) hipLaunchKernelGGL((partition_kernel<TILE, 1>), dim3(pb), dim3(256), lds, s, dCells, nK, cellsPerPart, P, dCur, dRec);
+            else hipLaunchKernelGGL((partition_kernel<TILE, 2>), dim3(pb), dim3(256), lds, s, dCells, nK, cellsPerPart, P, dCur, dRec);
+        });
+        if (rc) return -1;
         for (unsigned perCu : {4u, 8u, 16u}) {
             XCHK(hipMemset(dOut, 0, 64));
             const unsigned grid = cus * perCu;                       // a multiple of 8: G workgroups per XCD
             float m2 = 0;
-            if (RW == 1) rc = timed(s, 3, m2, [&] { hipLaunchKernelGGL((partition_probe_kernel<1, 4>), dim3(grid), dim3(256), 0, s, dRec, dCur, P, partCap, V.kmer_bits, V.kmer_slot, dOut); });
-            else rc = timed(s, 3, m2, [&] { hipLaunchKernelGGL((partition_probe_kernel<2, 4>), dim3(grid), dim3(256), 0, s, dRec, dCur, P, partCap, V.kmer_bits, V.kmer_slot, dOut); });
+            if (RW == 1) rc = timed(s, 3, m2, [&] { hipLaunchKernelGGL((partition_probe_kernel<1, 4>), dim3(grid), dim3(256), 0, s, dRec, dStart, P, V.kmer_bits, V.kmer_slot, dOut); });
+            else rc = timed(s, 3, m2, [&] { hipLaunchKernelGGL((partition_probe_kernel<2, 4>), dim3(grid), dim3(256), 0, s, dRec, dStart, P, V.kmer_bits, V.kmer_slot, dOut); });
             if (rc) return -1;
             unsigned long long h[2];
             XCHK(hipMemcpy(h, dOut, 16, hipMemcpyDeviceToHost));
             h[0] /= 3; h[1] /= 3;
-            if (hOvf == 0) same = same && h[0] == ref[0] && h[1] == ref[1] && sum == nK;
+            same = same && h[0] == ref[0] && h[1] == ref[1] && sum == nK;
             msProbe = std::min(msProbe, m2);
         }
-        out[8 + 4 * c + 0] = msPart; out[8 + 4 * c + 1] = msProbe; out[8 + 4 * c + 2] = (double) hOvf; out[8 + 4 * c + 3] = (double) mx / ((double) nK / P);
-        (void) hipFree(dRec); (void) hipFree(dCur); (void) hipFree(dOvf);
+        out[8 + 4 * c + 0] = msPart; out[8 + 4 * c + 1] = msProbe; out[8 + 4 * c + 2] = msCountP; out[8 + 4 * c + 3] = (double) mx / ((double) nK / P);
+        (void) hipFree(dRec); (void) hipFree(dCur); (void) hipFree(dStart);
     }
     out[7] = same ? 1.0 : 0.0;
     (void) hipFree(dCount); (void) hipFree(dOff); (void) hipFree(dCells); (void) hipFree(dOut);
