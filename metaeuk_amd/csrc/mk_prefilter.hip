@@ -876,7 +876,9 @@ void launch_stream(int tier, const StreamArgs &A, unsigned grid, hipStream_t str
 // | diagonal | k-mer start, and the hit's ordinal within its start -- the arrival rank (start prefix + ordinal) has 21 bits.
 // The k-mers come from the enumerator of the k = 6 table (MODE 0), from lists in HBM (MODE 1: profile queries, k = 7), or from the
 // in-wave 7-mer enumerator (MODE 2).
-constexpr uint32_t W_T_BITS = 27, W_RANK_BITS = 21;            // + 16 bits of diagonal = 64 (sort key: target | rank | diagonal)
+constexpr uint32_t W_T_BITS_MAX = 27;                          // sort key = target | arrival rank | diagonal (16 bits): the target field is as wide as the
+                                                               // database needs (WideArgs::t_bits <= 27), the rank takes the other 48 - t_bits bits -- a
+                                                               // query may gather 2^21 hits against 2^27 targets, 4 M against UniRef50's 60 M (26 bits)
 constexpr int W_MODE_ENUM6 = 0, W_MODE_LIST = 1, W_MODE_ENUM7 = 2;
 struct WideArgs {
     PrefilterDeviceView V;
@@ -888,17 +890,19 @@ struct WideArgs {
     unsigned long long *totals;                       // as StreamArgs::totals; [10] sub-classes beyond the LDS sort (the host redoes the piece)
                                                       // [11] (a double) MODE 2: sum over the finished queries of similar k-mers / length (run statistics)
     uint32_t *work_counter;
-    uint64_t *pool; uint32_t *pool_ord;               // gridDim.x regions of NCLS * CLS_CAP records
+    uint64_t *pool; uint32_t *pool_ord;               // gridDim.x regions of NCLS * cls_cap records
+    uint32_t cls_cap;                                 // records per target class (NCLS * cls_cap <= 2^rank_bits)
+    uint32_t t_bits, rank_bits;                       // t_bits + rank_bits = 48
     const uint16_t *pos_cost; uint64_t pos_begin;     // MODE 0: work estimate of every k-mer start (kmer_count_kernel)
 };
 
-template <int CLS_CAP, int NCLS, int GROUP_MAX, int SURV, int MBITS, int MAXPOS, int NW, int U, int MODE, int MINW = 8>
+template <int NCLS, int GROUP_MAX, int SURV, int MBITS, int MAXPOS, int NW, int U, int MODE, int MINW = 8>
 __global__ __launch_bounds__(NW * 64, MINW) void wide_kernel(WideArgs A) {
     constexpr int BLOCK = NW * WAVE;
     constexpr int LOG_MBITS = ilog2(MBITS), LOG_NCLS = ilog2(NCLS);
-    constexpr int TSHIFT = 16 + (int) W_RANK_BITS;
     static_assert((SURV & (SURV - 1)) == 0 && (MBITS & (MBITS - 1)) == 0 && (NCLS & (NCLS - 1)) == 0, "powers of two");
-    static_assert((uint64_t) NCLS * CLS_CAP <= (1ull << W_RANK_BITS) && MAXPOS <= 4096 && W_T_BITS + TSHIFT <= 64, "record / key fields");
+    static_assert(MAXPOS <= 4096, "record / key fields");
+    static_assert(2 * (MBITS / 32) >= 2 * SURV, "the exact-target table of pass 2 lives in the bitmaps' memory");
     static_assert(NCLS <= STREAM_MAX_CLASSES && GROUP_MAX >= SURV, "class tables");
     using EnumScratch = typename std::conditional<MODE == W_MODE_ENUM7, enumk::Enum7Lds<U>, enumk::EnumLds<U>>::type;
     struct Pass1Lds { EnumScratch e[NW]; uint8_t mark[NW][WAVE]; };
@@ -906,7 +910,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void wide_kernel(WideArgs A) {
     __shared__ __attribute__((aligned(16))) uint8_t sRaw[RAW];
     uint64_t *sKey = reinterpret_cast<uint64_t *>(sRaw);
     Pass1Lds &P1 = *reinterpret_cast<Pass1Lds *>(sRaw);
-    __shared__ uint32_t sBm1[MBITS / 32], sBm2[MBITS / 32];
+    __shared__ uint32_t sBm[2 * (MBITS / 32)];        // the two bitmaps; after a group's survivors are collected, the exact-target table
+    uint32_t *sBm1 = sBm, *sBm2 = sBm + MBITS / 32;
     __shared__ uint32_t sPosBase[MAXPOS];
     constexpr int ORDER_N = MAXPOS < 64 ? 64 : MAXPOS;
     static_assert(RAW >= sizeof(uint32_t) * ORDER_N, "the start order is sorted in the shared scratch");
@@ -920,12 +925,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void wide_kernel(WideArgs A) {
 
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, w = tid / WAVE, lane = tid & (WAVE - 1);
+    const uint32_t CLS_CAP = A.cls_cap, T_BITS = A.t_bits, TSHIFT = 16u + A.rank_bits;
     uint64_t *region = A.pool + (size_t) blockIdx.x * NCLS * CLS_CAP;
     uint32_t *regionOrd = A.pool_ord + (size_t) blockIdx.x * NCLS * CLS_CAP;
-    constexpr uint64_t TMASK = (1ull << W_T_BITS) - 1ull;
+    const uint64_t TMASK = (1ull << T_BITS) - 1ull;
     const auto survives = [&](uint64_t rec) -> bool {
         const uint32_t hb = ((uint32_t) (rec & TMASK) * 0x9E3779B1u) >> (32 - LOG_MBITS);
-        return ((sBm2[hb >> 5] >> (hb & 31u)) & 1u) || ((uint32_t) (rec >> W_T_BITS) & 0xFFu) == 0u;
+        return ((sBm2[hb >> 5] >> (hb & 31u)) & 1u) || ((uint32_t) (rec >> T_BITS) & 0xFFu) == 0u;
     };
     const auto sub_of = [&](uint64_t rec, uint32_t nSub) -> uint32_t { return (((uint32_t) (rec & TMASK) * 0x85EBCA6Bu) >> 8) % nSub; };
     for (;;) {
@@ -1027,9 +1033,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void wide_kernel(WideArgs A) {
                         const uint32_t diag = ((uint32_t) i - ((uint32_t) (ent >> 32) & 0xFFFFu)) & 0xFFFFu;
                         const uint32_t cls = (tgt * 0x7FEB352Du) >> (32 - LOG_NCLS);       // (its own multiplier: the bitmap buckets of pass 2 must not follow the class)
                         const uint32_t slot = atomicAdd(&sClsUsed[cls], 1u);
-                        if (slot < (uint32_t) CLS_CAP) {
+                        if (slot < CLS_CAP) {
                             const size_t at = (size_t) cls * CLS_CAP + slot;
-                            region[at] = (uint64_t) tgt | ((uint64_t) diag << W_T_BITS) | ((uint64_t) (uint32_t) i << (W_T_BITS + 16));
+                            region[at] = (uint64_t) tgt | ((uint64_t) diag << T_BITS) | ((uint64_t) (uint32_t) i << (T_BITS + 16u));
                             regionOrd[at] = wcount + rel;
                         } else over = true;
                     };
@@ -1149,9 +1155,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void wide_kernel(WideArgs A) {
                     if (surv) {
                         const uint32_t slot = wbase + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
                         if (slot < (uint32_t) SURV) {
-                            const uint32_t pos = (uint32_t) (rec >> (W_T_BITS + 16)) & 0xFFFu;
+                            const uint32_t pos = (uint32_t) (rec >> (T_BITS + 16u)) & 0xFFFu;
                             const uint32_t rank = sPosBase[pos] + regionOrd[at];
-                            sKey[slot] = ((rec & TMASK) << TSHIFT) | ((uint64_t) rank << 16) | ((rec >> W_T_BITS) & 0xFFFFull);
+                            sKey[slot] = ((rec & TMASK) << TSHIFT) | ((uint64_t) rank << 16) | ((rec >> T_BITS) & 0xFFFFull);
                         }
                     }
                 });
@@ -1191,6 +1197,54 @@ __global__ __launch_bounds__(NW * 64, MINW) void wide_kernel(WideArgs A) {
                 const unsigned long long ts0 = sub == 0 ? tOpt0 : wall_clock64();
                 if (!collected) collect(sub, nSub);
                 collected = false;
+                // ---- 2c: the exact filter.  The bitmaps passed every record whose target BUCKET was hit twice; most of those are two targets
+                // sharing a bucket.  A target with a single record can only matter when that record's low diagonal byte is 0 (the first hit of
+                // a target is compared with 0), so: count the records per TARGET in an open-addressing table (in the bitmaps' memory: they are
+                // done when there is one sub-class) and keep what the rule can use -- the sort below then has a few dozen keys, not thousands
+                if (nSub == 1) {
+                    constexpr uint32_t HT = 2u * (MBITS / 32);
+                    constexpr uint32_t KPT = (SURV + BLOCK - 1) / BLOCK;
+                    const uint32_t nAll = min(sSurv, (uint32_t) SURV);
+                    uint64_t mine[KPT];
+                    for (uint32_t k = (uint32_t) tid; k < HT; k += BLOCK) sBm[k] = 0;
+                    __syncthreads();
+#pragma unroll
+                    for (uint32_t k = 0; k < KPT; k++) {
+                        const uint32_t t = k * BLOCK + (uint32_t) tid;
+                        mine[k] = t < nAll ? sKey[t] : ~0ull;
+                        if (t < nAll) {
+                            const uint32_t tg = (uint32_t) (mine[k] >> TSHIFT) + 1u;
+                            uint32_t h = (tg * 0x9E3779B1u) % HT;
+                            for (;;) {
+                                const uint32_t old = atomicCAS(&sBm[h], 0u, tg);
+                                if (old == 0u) break;
+                                if ((old & 0x7FFFFFFFu) == tg) { if (!(old >> 31)) atomicOr(&sBm[h], 0x80000000u); break; }
+                                h = h + 1u == HT ? 0u : h + 1u;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    if (tid == 0) sSurv = 0;
+                    __syncthreads();
+#pragma unroll
+                    for (uint32_t k = 0; k < KPT; k++) {
+                        bool keep = false;
+                        if (mine[k] != ~0ull) {
+                            const uint32_t tg = (uint32_t) (mine[k] >> TSHIFT) + 1u;
+                            uint32_t h = (tg * 0x9E3779B1u) % HT;
+                            while ((sBm[h] & 0x7FFFFFFFu) != tg) h = h + 1u == HT ? 0u : h + 1u;
+                            keep = (sBm[h] >> 31) != 0u || ((uint32_t) mine[k] & 0xFFu) == 0u;
+                        }
+                        const unsigned long long m = __ballot(keep);
+                        if (m != 0ull) {
+                            uint32_t wbase = 0;
+                            if (lane == 0) wbase = atomicAdd(&sSurv, (uint32_t) __popcll(m));
+                            wbase = (uint32_t) __builtin_amdgcn_readfirstlane((int) wbase);
+                            if (keep) sKey[wbase + (uint32_t) __popcll(m & ((1ull << lane) - 1ull))] = mine[k];
+                        }
+                    }
+                    __syncthreads();
+                }
                 __syncthreads();
                 uint32_t nSurv = sSurv;
                 if (nSurv > (uint32_t) SURV) { if (tid == 0) atomicAdd(&A.totals[10], 1ull); nSurv = SURV; }     // (reported by the host as an error: never seen)
@@ -1263,7 +1317,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void wide_kernel(WideArgs A) {
                         const uint64_t key = sKey[t];
                         A.C.q[dst] = q - A.q_first;
                         A.C.id[dst] = (uint32_t) (key >> TSHIFT);
-                        A.C.ordinal[dst] = (uint32_t) (key >> 16) & ((1u << W_RANK_BITS) - 1u);
+                        A.C.ordinal[dst] = (uint32_t) (key >> 16) & ((1u << A.rank_bits) - 1u);
                         A.C.diag[dst] = (uint16_t) key;
                     }
                 }
@@ -1276,19 +1330,20 @@ __global__ __launch_bounds__(NW * 64, MINW) void wide_kernel(WideArgs A) {
     }
 }
 
-// shapes of the wide kernel: production (16 classes of 131 072 records: 2.1 M hits per query, 16 waves, groups / subsets of 16 K records) and a
+// shapes of the wide kernel: production (16 classes, their size from the rank bits the database leaves and a memory budget: 2^21 ... 2^24 hits
+// per query; 16 waves, groups / subsets of 16 K records) and a
 // miniature (MK_PREFILTER_TIERS=tiny) with which small test inputs fill classes, span several groups, split classes into subsets and need
 // sub-classes.  Few classes on purpose: a class's write pointer is a partially written 128-byte line that must survive in L2 until its 16
 // records have arrived -- with 64 classes (the first version) the index probes of 32 workgroups per XCD evicted every such line between two of
 // its records, every 8-byte record cost a line fill and a write-back, and the kernel ran at a twentieth of its speed (profiles/r04_wide_kernel.txt)
-struct WideShape { int clsCap, nCls, maxpos, waves, wgPerCu; };
-const WideShape WIDE_SHAPES[2] = {{131072, 16, 2048, 16, 2}, {192, 4, 64, 4, 4}};
+struct WideShape { int clsCap /* 0: from the rank bits and the memory budget */, nCls, maxpos, waves, wgPerCu; };
+const WideShape WIDE_SHAPES[2] = {{0, 16, 2048, 16, 2}, {192, 4, 64, 4, 4}};
 template <int MODE>
 void launch_wide(int shape, const WideArgs &A, unsigned grid, hipStream_t stream) {
     // MK_PREFILTER_WIDE_REGS=128: the build with 128 instead of 64 vector registers per lane (one workgroup per CU)
-    if (shape == 0 && knob_long("MK_PREFILTER_WIDE_REGS", 64) == 128) hipLaunchKernelGGL((wide_kernel<131072, 16, 16384, 4096, 131072, 2048, 16, 2, MODE, 4>), dim3(grid), dim3(1024), 0, stream, A);
-    else if (shape == 0) hipLaunchKernelGGL((wide_kernel<131072, 16, 16384, 4096, 131072, 2048, 16, 2, MODE>), dim3(grid), dim3(1024), 0, stream, A);
-    else hipLaunchKernelGGL((wide_kernel<192, 4, 64, 64, 1024, 64, 4, 2, MODE>), dim3(grid), dim3(256), 0, stream, A);
+    if (shape == 0 && knob_long("MK_PREFILTER_WIDE_REGS", 64) == 128) hipLaunchKernelGGL((wide_kernel<16, 16384, 4096, 131072, 2048, 16, 2, MODE, 4>), dim3(grid), dim3(1024), 0, stream, A);
+    else if (shape == 0) hipLaunchKernelGGL((wide_kernel<16, 16384, 4096, 131072, 2048, 16, 2, MODE>), dim3(grid), dim3(1024), 0, stream, A);
+    else hipLaunchKernelGGL((wide_kernel<4, 64, 64, 4096, 64, 4, 2, MODE>), dim3(grid), dim3(256), 0, stream, A);
 }
 
 // =====================================================================================================
@@ -2156,8 +2211,18 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
             if (coResident) perCu = std::max(1, 16 / W.waves < perCu ? 16 / W.waves : perCu);          // at most 16 waves per CU beside the alignment stage
             if (const char *e = knob("MK_PREFILTER_WG_PER_CU_W")) perCu = std::max(1, atoi(e));
             const unsigned launch = (unsigned) std::min<size_t>(order.size(), (size_t) cus * perCu);
-            const size_t regionRecs = (size_t) W.nCls * W.clsCap;
+            // sort key = target | arrival rank | 16-bit diagonal: the rank takes the bits the targets leave; a class holds what that allows,
+            // within a budget of 24 GB for the regions of the persistent workgroups (12 bytes per record)
             WideArgs A;
+            A.t_bits = std::max<uint32_t>(X.seqBits, 20u);
+            A.rank_bits = std::min<uint32_t>(48u - A.t_bits, 24u);
+            A.cls_cap = (uint32_t) W.clsCap;
+            if (W.clsCap == 0) {
+                const uint64_t budget = (uint64_t) std::max<long>(1, knob_long("MK_PREFILTER_WIDE_POOL_GB", 24)) << 30;
+                const uint64_t byRank = (1ull << A.rank_bits) / (uint64_t) W.nCls, byBudget = budget / ((uint64_t) cus * perCu * W.nCls * 12ull);
+                A.cls_cap = (uint32_t) std::max<uint64_t>(4096, std::min(byRank, byBudget) & ~63ull);
+            }
+            const size_t regionRecs = (size_t) W.nCls * A.cls_cap;
             A.pool = (uint64_t *) dev_scratch("pf_wpool", (size_t) launch * regionRecs * 8);
             A.pool_ord = (uint32_t *) dev_scratch("pf_wpoolord", (size_t) launch * regionRecs * 4);
             PNULL(A.pool); PNULL(A.pool_ord);
@@ -2239,10 +2304,10 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     if (V.p_sorted || V.kmer_size == 7) useFused = false;   // profile queries, k = 7: k-mer lists (stream_kernel enumerates two 3-mer rows)
     // ... and whatever the 22-bit per-query kernels do not take goes to the wide per-query kernel (round 4; up to 2^27 targets, lists or the k = 6
     // enumerator), the sort-based global path behind it.  MK_PREFILTER_PATH = auto | fused | wide | global forces (fused: where it applies)
-    bool useWide = !useFused && seqBits <= W_T_BITS;
+    bool useWide = !useFused && seqBits <= W_T_BITS_MAX;
     if (const char *e = knob("MK_PREFILTER_PATH")) {
         if (!strcmp(e, "global")) { useFused = false; useWide = false; }
-        else if (!strcmp(e, "wide")) { useFused = false; useWide = seqBits <= W_T_BITS; }
+        else if (!strcmp(e, "wide")) { useFused = false; useWide = seqBits <= W_T_BITS_MAX; }
         else if (strcmp(e, "fused") && strcmp(e, "auto")) { err = "MK_PREFILTER_PATH must be auto, fused, wide or global"; return MK_ERR_ARG; }
     }
     int tierBase = 0;
