@@ -1,0 +1,5 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r04i; mkdir -p $O
+export MK_DEBUG=1
+timeout 900 python tools/_diag_one.py 8000000 60 100 2000 > $O/diag_one.txt 2>&1; tail -62 $O/diag_one.txt | cut -c1-200
