@@ -101,6 +101,14 @@ __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// 32-bit finaliser (MurmurHash3's fmix32): the partition functions of the per-query kernels -- target class, bitmap bucket, subset, sub-class --
+// take different bit ranges of differently seeded mixes, so that they are independent of each other (a class must spread evenly over the
+// buckets, a subset over the sub-classes); single multiplicative hashes scaled to a range were visibly correlated (profiles/r04_wide_kernel.txt)
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+
 // number of leading entries of a descending int16 row that are >= cutoff
 __device__ __forceinline__ int count_ge(const int16_t *lds, int nLds, const int16_t *row, int cutoff) {
     if (nLds > 0 && (int) lds[nLds - 1] < cutoff) {
@@ -569,7 +577,7 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
     // target class of a record: a 24-bit hash scaled to the range (multiply and shift).  Not `hash % n`: in the wide kernel below that form lost
     // every record of subset 10 of 11 (and of a few other counts) on gfx950 although the arithmetic alone tests clean (tools/micro/urem24.hip,
     // profiles/r04_wide_kernel.txt); a partition function only has to be a function
-    const auto class_of = [&](uint64_t rec, uint32_t n) -> uint32_t { return ((((uint32_t) (rec & TMASK) * 0x85EBCA6Bu) >> 8) * n) >> 24; };
+    const auto class_of = [&](uint64_t rec, uint32_t n) -> uint32_t { return ((mix32((uint32_t) (rec & TMASK) ^ 0x85EBCA6Bu) >> 8) * n) >> 24; };
     for (;;) {
         __syncthreads();                                  // the previous query's LDS is no longer read
         if (tid == 0) sItem = atomicAdd(A.work_counter, 1u);
@@ -933,12 +941,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void wide_kernel(WideArgs A) {
     uint64_t *region = A.pool + (size_t) blockIdx.x * NCLS * CLS_CAP;
     uint32_t *regionOrd = A.pool_ord + (size_t) blockIdx.x * NCLS * CLS_CAP;
     const uint64_t TMASK = (1ull << T_BITS) - 1ull;
+    static_assert(LOG_MBITS <= 17, "bucket = the top bits of the mix, subset = its low 15 bits");
     const auto survives = [&](uint64_t rec) -> bool {
-        const uint32_t hb = ((uint32_t) (rec & TMASK) * 0x9E3779B1u) >> (32 - LOG_MBITS);
+        const uint32_t hb = mix32((uint32_t) (rec & TMASK)) >> (32 - LOG_MBITS);
         return ((sBm2[hb >> 5] >> (hb & 31u)) & 1u) || ((uint32_t) (rec >> T_BITS) & 0xFFu) == 0u;
     };
-    // (subset / sub-class of a target = a 24-bit hash scaled to the range: multiply and shift, no division)
-    const auto sub_of = [&](uint64_t rec, uint32_t nSub) -> uint32_t { return ((((uint32_t) (rec & TMASK) * 0x85EBCA6Bu) >> 8) * nSub) >> 24; };
+    // (subset / sub-class of a target = hash bits scaled to the range: multiply and shift, no division)
+    const auto sub_of = [&](uint64_t rec, uint32_t nSub) -> uint32_t { return ((mix32((uint32_t) (rec & TMASK) + 0x9E3779B9u) >> 8) * nSub) >> 24; };
     for (;;) {
         __syncthreads();                                  // the previous query's LDS is no longer read
         if (tid == 0) sItem = atomicAdd(A.work_counter, 1u);
@@ -1036,7 +1045,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void wide_kernel(WideArgs A) {
                     const auto put = [&](uint64_t ent, uint32_t rel) {
                         const uint32_t tgt = (uint32_t) ent;
                         const uint32_t diag = ((uint32_t) i - ((uint32_t) (ent >> 32) & 0xFFFFu)) & 0xFFFFu;
-                        const uint32_t cls = (tgt * 0x7FEB352Du) >> (32 - LOG_NCLS);       // (its own multiplier: the bitmap buckets of pass 2 must not follow the class)
+                        const uint32_t cls = mix32(tgt ^ 0x7FEB352Du) >> (32 - LOG_NCLS);  // (its own seed: the bitmap buckets of pass 2 must not follow the class)
                         const uint32_t slot = atomicAdd(&sClsUsed[cls], 1u);
                         if (slot < CLS_CAP) {
                             const size_t at = (size_t) cls * CLS_CAP + slot;
@@ -1130,7 +1139,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void wide_kernel(WideArgs A) {
             // a class with more records than a group holds is taken in SUBSETS of its targets (a second hash): the bitmaps stay sparse
             const uint32_t nSets = (recs + (uint32_t) GROUP_MAX - 1u) / (uint32_t) GROUP_MAX;
             for (uint32_t set = 0; set < nSets; set++) {
-            const auto in_set = [&](uint64_t rec) -> bool { return nSets == 1u || ((((uint32_t) (rec & TMASK) * 0xC2B2AE35u) >> 8) * nSets) >> 24 == set; };
+            const auto in_set = [&](uint64_t rec) -> bool { return nSets == 1u || ((mix32((uint32_t) (rec & TMASK)) & 0x7FFFu) * nSets) >> 15 == set; };
             const unsigned long long tSet0 = wall_clock64();
             __syncthreads();                               // (the previous group's bitmaps and keys are no longer read)
             for (int k = tid; k < MBITS / 32; k += BLOCK) { sBm1[k] = 0; sBm2[k] = 0; }
@@ -1138,7 +1147,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void wide_kernel(WideArgs A) {
             // ---- 2a: target buckets hit once / twice
             sweep([&](bool valid, size_t, uint64_t rec) {
                 if (!valid || !in_set(rec)) return;
-                const uint32_t hb = ((uint32_t) (rec & TMASK) * 0x9E3779B1u) >> (32 - LOG_MBITS);
+                const uint32_t hb = mix32((uint32_t) (rec & TMASK)) >> (32 - LOG_MBITS);
                 const uint32_t bit = 1u << (hb & 31u);
                 if (atomicOr(&sBm1[hb >> 5], bit) & bit) atomicOr(&sBm2[hb >> 5], bit);
             });
@@ -1219,7 +1228,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void wide_kernel(WideArgs A) {
                         mine[k] = t < nAll ? sKey[t] : ~0ull;
                         if (t < nAll) {
                             const uint32_t tg = (uint32_t) (mine[k] >> TSHIFT) + 1u;
-                            uint32_t h = (tg * 0x9E3779B1u) % HT;
+                            uint32_t h = mix32(tg) % HT;
                             for (;;) {
                                 const uint32_t old = atomicCAS(&sBm[h], 0u, tg);
                                 if (old == 0u) break;
@@ -1236,7 +1245,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void wide_kernel(WideArgs A) {
                         bool keep = false;
                         if (mine[k] != ~0ull) {
                             const uint32_t tg = (uint32_t) (mine[k] >> TSHIFT) + 1u;
-                            uint32_t h = (tg * 0x9E3779B1u) % HT;
+                            uint32_t h = mix32(tg) % HT;
                             while ((sBm[h] & 0x7FFFFFFFu) != tg) h = h + 1u == HT ? 0u : h + 1u;
                             keep = (sBm[h] >> 31) != 0u || ((uint32_t) mine[k] & 0xFFu) == 0u;
                         }
@@ -2213,7 +2222,10 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
             PCHK(hipMemcpyAsync(dCtr, hCtr, 4, hipMemcpyHostToDevice, stream));
             PCHK(hipMemsetAsync(dTot, 0, 16 * 8, stream));
             int perCu = W.wgPerCu;
-            if (coResident) perCu = std::max(1, 16 / W.waves < perCu ? 16 / W.waves : perCu);          // at most 16 waves per CU beside the alignment stage
+            // beside the alignment stage of mk_search: profile queries leave it most of the work (config 4: at most 16 prefilter waves per CU);
+            // a sequence search with k = 7 or beyond 2^22 targets is 90 % prefilter (2*10^5 ... 3*10^6 index hits per fragment, 300 pairs to align):
+            // the prefilter keeps both workgroups per CU (25.6 k against 19.2 k fragments/s at 11.8 M proteins, profiles/r04_wide_kernel.txt)
+            if (coResident && Vin.p_sorted) perCu = std::max(1, 16 / W.waves < perCu ? 16 / W.waves : perCu);
             if (const char *e = knob("MK_PREFILTER_WG_PER_CU_W")) perCu = std::max(1, atoi(e));
             const unsigned launch = (unsigned) std::min<size_t>(order.size(), (size_t) cus * perCu);
             // sort key = target | arrival rank | 16-bit diagonal: the rank takes the bits the targets leave; a class holds what that allows,
