@@ -1507,11 +1507,11 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     // their speed
     hooks.max_chunk_queries = 1u << 18;
     // ... of a full 2.0 M-query batch.  A shard of that batch (1/8 of it on an 8-GPU node: 251 k queries) would be three chunks, with next to
-    // nothing for the two stages to overlap: the chunk follows the batch -- the largest power of two below a sixth of it, 32 768 at least
-    // (profiles/r04_shard_sweep.txt)
+    // nothing for the two stages to overlap: the chunk follows the batch -- the largest power of two below a sixth of it, 65 536 at least
+    // (32 768-query chunks are too many short launches beside the persistent workgroups: profiles/r04_shard_sweep.txt)
     {
         uint32_t lim = 1u << 18;
-        while (lim > (1u << 15) && (uint64_t) lim * 6 > (uint64_t) q->n) lim >>= 1;
+        while (lim > (1u << 16) && (uint64_t) lim * 6 > (uint64_t) q->n) lim >>= 1;
         hooks.max_chunk_queries = lim;
     }
     hooks.chunk_ramp = true;

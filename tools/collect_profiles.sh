@@ -2,16 +2,16 @@
 # Round evidence on a GPU box: the default bench line, rocprofv3 kernel statistics of the same command, the HBM traffic artefact
 # (tools/pmc_traffic.sh), SQ counters, the two-stage timeline and the host-thread sensitivity.  Writes under gpurun_out/evidence/ ; copy
 # the files to be judged into profiles/.
-#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r03'
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'QUICK=1 bash tools/collect_profiles.sh r04'
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/evidence
 mkdir -p $OUT
 cd $R
 # the HBM traffic of THIS build first: bench.py reads profiles/<tag>_pmc_hbm_traffic.json for roofline.traffic
 bash tools/pmc_traffic.sh $TAG > $OUT/pmc_traffic.log 2>&1; cp gpurun_out/pmc/${TAG}_pmc_hbm_traffic.json $OUT/ 2>/dev/null; cp gpurun_out/pmc/${TAG}_pmc_hbm_traffic.json profiles/ 2>/dev/null
-python bench.py --steps 2 --warmup 1 > $OUT/${TAG}_bench_n1.json 2> $OUT/bench.err
+python bench.py --steps 5 --warmup 2 > $OUT/${TAG}_bench_n1.json 2> $OUT/bench.err
 X="--config4-profiles 0"
 [ -n "${QUICK:-}" ] || for th in 16 2; do MK_HOST_THREADS=$th python bench.py --steps 2 --warmup 1 --cpu-sample 0 $X 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.read());print('MK_HOST_THREADS=$th  ms_per_step %.1f  fragments/s %.0f  host phases (ms/step): %s' % (d['ms_per_step'], d['value'], {k: round(v / d['steps'], 1) for k, v in d['kernels_ms'].items() if k.startswith('host_')}))"; done > $OUT/${TAG}_bench_host_threads.txt
 python bench.py --steps 2 --warmup 1 --cpu-sample 0 --two-calls $X > $OUT/${TAG}_bench_two_calls.json 2>/dev/null

@@ -5,7 +5,7 @@
 # Bytes = 128 B x 128-byte requests + 32 B x 32-byte requests + 64 B x the rest (reads); 64 B x 64-byte requests + 32 B x the rest
 # (writes).  FETCH_SIZE is NOT used: it tallies a 128-byte request as 64 B (profiles/r02_random_probe_rates.txt).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/pmc
 mkdir -p $OUT
@@ -21,6 +21,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = colle
 def name_of(k):
     m = re.search(r"stream_kernel<(\d+),", k)
     if m: return "prefilter_query_cap" + m.group(1)
+    if "wide_kernel<" in k: return "prefilter_query_wide"
     if "probe_kernel<true" in k: return "kmer_probe_gather"
     if "probe_kernel<false" in k: return "kmer_probe_count"
     if "kmer_count_kernel" in k: return "kmer_count"
