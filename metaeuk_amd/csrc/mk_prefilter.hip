@@ -915,7 +915,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void wide_kernel(WideArgs A) {
     static_assert((SURV & (SURV - 1)) == 0 && (MBITS & (MBITS - 1)) == 0 && (NCLS & (NCLS - 1)) == 0, "powers of two");
     static_assert(MAXPOS <= 4096, "record / key fields");
     static_assert(2 * (MBITS / 32) >= 2 * SURV, "the exact-target table of pass 2 lives in the bitmaps' memory");
-    static_assert(NCLS <= STREAM_MAX_CLASSES && GROUP_MAX >= SURV, "class tables");
+    static_assert(GROUP_MAX >= SURV, "a group holds at least one LDS sort");
     using EnumScratch = typename std::conditional<MODE == W_MODE_ENUM7, enumk::Enum7Lds<U>, enumk::EnumLds<U>>::type;
     struct Pass1Lds { EnumScratch e[NW]; uint8_t mark[NW][WAVE]; };
     constexpr size_t RAW = sizeof(Pass1Lds) > sizeof(uint64_t) * SURV ? sizeof(Pass1Lds) : sizeof(uint64_t) * SURV;
@@ -1351,12 +1351,15 @@ __global__ __launch_bounds__(NW * 64, MINW) void wide_kernel(WideArgs A) {
 // records have arrived -- with 64 classes (the first version) the index probes of 32 workgroups per XCD evicted every such line between two of
 // its records, every 8-byte record cost a line fill and a write-back, and the kernel ran at a twentieth of its speed (profiles/r04_wide_kernel.txt)
 struct WideShape { int clsCap /* 0: from the rank bits and the memory budget */, nCls, maxpos, waves, wgPerCu; };
-const WideShape WIDE_SHAPES[2] = {{0, 16, 2048, 16, 2}, {192, 4, 64, 4, 4}};
+const WideShape WIDE_SHAPES[5] = {{0, 16, 2048, 16, 2}, {192, 4, 64, 4, 4}, {0, 64, 2048, 16, 2}, {0, 128, 2048, 16, 2}, {0, 256, 2048, 16, 2}};
 template <int MODE>
 void launch_wide(int shape, const WideArgs &A, unsigned grid, hipStream_t stream) {
     // MK_PREFILTER_WIDE_REGS=128: the build with 128 instead of 64 vector registers per lane (one workgroup per CU)
     if (shape == 0 && knob_long("MK_PREFILTER_WIDE_REGS", 64) == 128) hipLaunchKernelGGL((wide_kernel<16, 16384, 4096, 131072, 2048, 16, 2, MODE, 4>), dim3(grid), dim3(1024), 0, stream, A);
     else if (shape == 0) hipLaunchKernelGGL((wide_kernel<16, 16384, 4096, 131072, 2048, 16, 2, MODE>), dim3(grid), dim3(1024), 0, stream, A);
+    else if (shape == 2) hipLaunchKernelGGL((wide_kernel<64, 16384, 4096, 131072, 2048, 16, 2, MODE>), dim3(grid), dim3(1024), 0, stream, A);
+    else if (shape == 3) hipLaunchKernelGGL((wide_kernel<128, 16384, 4096, 131072, 2048, 16, 2, MODE>), dim3(grid), dim3(1024), 0, stream, A);
+    else if (shape == 4) hipLaunchKernelGGL((wide_kernel<256, 16384, 4096, 131072, 2048, 16, 2, MODE>), dim3(grid), dim3(1024), 0, stream, A);
     else hipLaunchKernelGGL((wide_kernel<4, 64, 64, 4096, 64, 4, 2, MODE>), dim3(grid), dim3(256), 0, stream, A);
 }
 
@@ -2098,6 +2101,11 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
                     uint32_t &nCand, std::vector<uint32_t> &fallback, double &kmersPerPos, double &globalHitsPerPos, PrefilterStats *cs, bool &fallbackKmerStats) {
     std::string &err = *X.err;
     hipStream_t stream = X.stream;
+    // target classes of the production shape: MK_PREFILTER_WIDE_CLASSES = 16 / 64 / 128 / 256 (experiments: profiles/r04_wide_kernel.txt)
+    if (shape == 0) {
+        const long n = knob_long("MK_PREFILTER_WIDE_CLASSES", 64);
+        shape = n == 16 ? 0 : (n == 128 ? 3 : (n == 256 ? 4 : 2));
+    }
     const WideShape &W = WIDE_SHAPES[shape];
     // sequence queries with k = 7: the 7-mers are enumerated inside the kernel (no lists in HBM, no count pass); MK_PREFILTER_K7_LISTS=1 keeps the lists
     const bool k7enum = !Vin.p_sorted && Vin.kmer_size == 7 && Vin.hist_range <= 256 && knob_long("MK_PREFILTER_K7_LISTS", 0) == 0;

@@ -298,3 +298,37 @@ def test_config5_full_scale_60M_proteins_on_one_gpu(gpu_api, tmp_path, monkeypat
         with open(os.path.join(out, "config5_case_%d.json" % n_targets), "w") as f:
             json.dump(report, f, indent=1)
     db.close()
+
+
+def test_heavy_queries_wide_kernel_equals_the_global_path(gpu_api, monkeypatch):
+    """Fragments that gather millions of index hits (100 ... 2 000 residues against 8 M proteins, k = 7: 0.7 ... 15 M hits each): the wide per-query
+    kernel cuts a target class of such a query into subsets and sub-classes -- the regime in which round 4 found (against the reference's own run,
+    profiles/r04_wide_kernel.txt) that one subset of eleven was lost.  The sort-based global path, equal to the reference there, is the check."""
+    import sys
+    api = gpu_api
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import config5_digest as c5
+    n_q = 60
+    res, off = api.synth_targets(8000000, seed=c5.TARGET_SEED)
+    fr, foff, src = api.synth_fragments(n_q, res, off, seed=5, mutation_rate=0.1, min_len=100, max_len=2000, random_every=10)
+    p = api.default_params()
+    p.kmer_size = 7
+    db = api.TargetDB.from_codes(res, off, p)
+    del res
+    out = {}
+    for name, env in (("global", {"MK_PREFILTER_PATH": "global"}), ("wide", {"MK_PREFILTER_PATH": "wide"}), ("wide, room for every query", {"MK_PREFILTER_PATH": "wide", "MK_PREFILTER_WIDE_POOL_GB": "64"})):
+        for k in ("MK_PREFILTER_PATH", "MK_PREFILTER_WIDE_POOL_GB"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        q = api.Queries.from_codes(fr, foff, p)
+        hits, hoff = api.prefilter(db, q, p)
+        out[name] = [api.format_hits_bulk(hits, int(hoff[i]), int(hoff[i + 1])) for i in range(n_q)]
+        if name != "global":
+            st = api.kernel_stats()
+            assert st["prefilter_query_wide"]["cells"] > 5e7
+    for name in out:
+        bad = [i for i in range(n_q) if out[name][i] != out["global"][i]]
+        assert not bad, (name, bad)
+    assert sum(len(x) for x in out["global"]) > 100000
+    db.close()
