@@ -2101,9 +2101,11 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
                     uint32_t &nCand, std::vector<uint32_t> &fallback, double &kmersPerPos, double &globalHitsPerPos, PrefilterStats *cs, bool &fallbackKmerStats) {
     std::string &err = *X.err;
     hipStream_t stream = X.stream;
-    // target classes of the production shape: MK_PREFILTER_WIDE_CLASSES = 16 / 64 / 128 / 256 (experiments: profiles/r04_wide_kernel.txt)
+    // target classes of the production shape (MK_PREFILTER_WIDE_CLASSES = 16 / 64 / 128 / 256 forces; measured: profiles/r04_wide_kernel.txt): 64 for
+    // sequence queries (6e5 ... 3e6 index hits per fragment against a UniRef50-scale database: no or few subsets per class), 16 for profile
+    // queries (1e5 hits per profile: 64 classes of a thousand records are all group overhead -- 245 against 185 ms per config-4 pass)
     if (shape == 0) {
-        const long n = knob_long("MK_PREFILTER_WIDE_CLASSES", 64);
+        const long n = knob_long("MK_PREFILTER_WIDE_CLASSES", Vin.p_sorted ? 16 : 64);
         shape = n == 16 ? 0 : (n == 128 ? 3 : (n == 256 ? 4 : 2));
     }
     const WideShape &W = WIDE_SHAPES[shape];
