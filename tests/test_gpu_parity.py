@@ -500,6 +500,25 @@ def test_search_equals_prefilter_then_align(gpu_api, pf_path):
     assert api.format_alignments(alns1, 0, n) == api.format_alignments(alns2, 0, n)
 
 
+def test_switches_are_read_only_under_mk_debug(gpu_api, small_workload, monkeypatch):
+    """experiment / test switches (MK_PREFILTER_PATH ...) change tiers and paths: the library reads them only when MK_DEBUG=1 is set as well, so that
+    a stray variable cannot reach a production run (metaeuk_amd/csrc/mk_host.cpp: knob).  A value the library would refuse shows which way it went."""
+    targets, queries = small_workload
+    api = gpu_api
+    params = api.default_params()
+    db = api.TargetDB(targets, params)
+    monkeypatch.setenv("MK_PREFILTER_PATH", "no-such-path")
+    monkeypatch.setenv("MK_DEBUG", "0")
+    q = api.Queries(queries[:200], params)
+    hits, hoff = api.prefilter(db, q)                     # ignored: runs as usual
+    assert int(hoff[-1]) > 0
+    monkeypatch.setenv("MK_DEBUG", "1")
+    with pytest.raises(api.MkError) as e:
+        api.prefilter(db, api.Queries(queries[:200], params))
+    assert "MK_PREFILTER_PATH" in str(e.value)
+    monkeypatch.setenv("MK_PREFILTER_PATH", "auto")
+
+
 def test_two_databases_interleaved_between_align_and_search(gpu_api):
     """The alignment stage keeps its e-value / bit-score tables on the device per scratch lane: worker 0 of mk_search and the caller of
     mk_align share lane 0.  mk_align(A), mk_search(B), mk_align(A) again must not align A against B's tables: the
