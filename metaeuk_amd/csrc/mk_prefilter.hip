@@ -881,13 +881,14 @@ void launch_stream(int tier, const StreamArgs &A, unsigned grid, hipStream_t str
 // survivors in LDS; that works while the hits are few against the bitmap (128 K bits).  A fragment searched against a UniRef50-scale
 // database gathers 2*10^5 ... 10^6 index hits (k = 7), a profile query 10^5: the bitmaps saturate, every hit "survives", and until
 // round 4 such queries took the sort-based global path -- two probe passes, the similar k-mers materialised, a device-wide radix sort.
-// Here the region is PARTITIONED: a hit goes to one of NCLS target classes (a hash of the target; one LDS atomic per hit gives its slot
-// in the class), and pass 2 walks the classes in groups of at most GROUP_MAX records -- per group the two bitmaps, the survivor sort and
-// the double-diagonal rule of stream_kernel.  Every record is read twice whatever the number of hits; a target lives in one class, so the
-// candidates of a (query, target) pair still leave the kernel contiguous and in arrival order.  Records are 8 + 4 bytes: target (27 bits)
-// | diagonal | k-mer start, and the hit's ordinal within its start -- the arrival rank (start prefix + ordinal) has 21 bits.
-// The k-mers come from the enumerator of the k = 6 table (MODE 0), from lists in HBM (MODE 1: profile queries, k = 7), or from the
-// in-wave 7-mer enumerator (MODE 2).
+// Here the region is PARTITIONED: a hit goes to one of NCLS target classes (a mixing hash of the target; one LDS atomic per hit gives its
+// slot in the class), and pass 2 walks the classes in groups of at most GROUP_MAX records -- a class beyond that in subsets of its targets --
+// with the two bitmaps, an exact per-target filter, the survivor sort and the double-diagonal rule of stream_kernel per group.  A target
+// lives in one class, one subset, one sub-class, so the candidates of a (query, target) pair still leave the kernel contiguous and in arrival
+// order.  Records are 8 + 4 bytes: target | diagonal | k-mer start, and the hit's ordinal within its start; the sort key target | arrival
+// rank | diagonal gives the rank the 48 bits the target leaves.
+// The k-mers come from the enumerator of the k = 6 table (MODE 0), from lists in HBM (MODE 1: profile queries), or from the in-wave 7-mer
+// enumerator (MODE 2).  DESIGN.md 4.13; what was measured on the way: profiles/r04_wide_kernel.txt.
 constexpr uint32_t W_T_BITS_MAX = 27;                          // sort key = target | arrival rank | diagonal (16 bits): the target field is as wide as the
                                                                // database needs (WideArgs::t_bits <= 27), the rank takes the other 48 - t_bits bits -- a
                                                                // query may gather 2^21 hits against 2^27 targets, 4 M against UniRef50's 60 M (26 bits)
@@ -908,8 +909,9 @@ struct WideArgs {
     const uint16_t *pos_cost; uint64_t pos_begin;     // MODE 0: work estimate of every k-mer start (kmer_count_kernel)
 };
 
-template <int NCLS, int GROUP_MAX, int SURV, int MBITS, int MAXPOS, int NW, int U, int MODE, int MINW = 8>
-__global__ __launch_bounds__(NW * 64, MINW) void wide_kernel(WideArgs A) {
+template <int NCLS, int GROUP_MAX, int SURV, int MBITS, int MAXPOS, int NW, int U, int MODE>
+__global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        // (8 waves per SIMD = 64 registers; a 128-register build ran 5 % faster with ONE workgroup
+                                                                                //  per CU and lost to two: profiles/r04_wide_kernel.txt)
     constexpr int BLOCK = NW * WAVE;
     constexpr int LOG_MBITS = ilog2(MBITS), LOG_NCLS = ilog2(NCLS);
     static_assert((SURV & (SURV - 1)) == 0 && (MBITS & (MBITS - 1)) == 0 && (NCLS & (NCLS - 1)) == 0, "powers of two");
@@ -1344,22 +1346,16 @@ __global__ __launch_bounds__(NW * 64, MINW) void wide_kernel(WideArgs A) {
     }
 }
 
-// shapes of the wide kernel: production (16 classes, their size from the rank bits the database leaves and a memory budget: 2^21 ... 2^24 hits
-// per query; 16 waves, groups / subsets of 16 K records) and a
-// miniature (MK_PREFILTER_TIERS=tiny) with which small test inputs fill classes, span several groups, split classes into subsets and need
-// sub-classes.  Few classes on purpose: a class's write pointer is a partially written 128-byte line that must survive in L2 until its 16
-// records have arrived -- with 64 classes (the first version) the index probes of 32 workgroups per XCD evicted every such line between two of
-// its records, every 8-byte record cost a line fill and a write-back, and the kernel ran at a twentieth of its speed (profiles/r04_wide_kernel.txt)
+// shapes of the wide kernel: production -- 16 waves, groups / subsets of 16 K records, a class as large as the rank bits the database leaves and
+// the memory budget allow (2^21 ... 2^24 hits per query), with 64 target classes for sequence queries and 16 for profile queries (16 / 64 / 128 /
+// 256 measured: profiles/r04_wide_kernel.txt) -- and a miniature (MK_PREFILTER_TIERS=tiny) with which small test inputs fill classes, span
+// several groups, split classes into subsets and need sub-classes
 struct WideShape { int clsCap /* 0: from the rank bits and the memory budget */, nCls, maxpos, waves, wgPerCu; };
-const WideShape WIDE_SHAPES[5] = {{0, 16, 2048, 16, 2}, {192, 4, 64, 4, 4}, {0, 64, 2048, 16, 2}, {0, 128, 2048, 16, 2}, {0, 256, 2048, 16, 2}};
+const WideShape WIDE_SHAPES[3] = {{0, 16, 2048, 16, 2}, {192, 4, 64, 4, 4}, {0, 64, 2048, 16, 2}};
 template <int MODE>
 void launch_wide(int shape, const WideArgs &A, unsigned grid, hipStream_t stream) {
-    // MK_PREFILTER_WIDE_REGS=128: the build with 128 instead of 64 vector registers per lane (one workgroup per CU)
-    if (shape == 0 && knob_long("MK_PREFILTER_WIDE_REGS", 64) == 128) hipLaunchKernelGGL((wide_kernel<16, 16384, 4096, 131072, 2048, 16, 2, MODE, 4>), dim3(grid), dim3(1024), 0, stream, A);
-    else if (shape == 0) hipLaunchKernelGGL((wide_kernel<16, 16384, 4096, 131072, 2048, 16, 2, MODE>), dim3(grid), dim3(1024), 0, stream, A);
+    if (shape == 0) hipLaunchKernelGGL((wide_kernel<16, 16384, 4096, 131072, 2048, 16, 2, MODE>), dim3(grid), dim3(1024), 0, stream, A);
     else if (shape == 2) hipLaunchKernelGGL((wide_kernel<64, 16384, 4096, 131072, 2048, 16, 2, MODE>), dim3(grid), dim3(1024), 0, stream, A);
-    else if (shape == 3) hipLaunchKernelGGL((wide_kernel<128, 16384, 4096, 131072, 2048, 16, 2, MODE>), dim3(grid), dim3(1024), 0, stream, A);
-    else if (shape == 4) hipLaunchKernelGGL((wide_kernel<256, 16384, 4096, 131072, 2048, 16, 2, MODE>), dim3(grid), dim3(1024), 0, stream, A);
     else hipLaunchKernelGGL((wide_kernel<4, 64, 64, 4096, 64, 4, 2, MODE>), dim3(grid), dim3(256), 0, stream, A);
 }
 
@@ -2101,12 +2097,12 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
                     uint32_t &nCand, std::vector<uint32_t> &fallback, double &kmersPerPos, double &globalHitsPerPos, PrefilterStats *cs, bool &fallbackKmerStats) {
     std::string &err = *X.err;
     hipStream_t stream = X.stream;
-    // target classes of the production shape (MK_PREFILTER_WIDE_CLASSES = 16 / 64 / 128 / 256 forces; measured: profiles/r04_wide_kernel.txt): 64 for
+    // target classes of the production shape (MK_PREFILTER_WIDE_CLASSES = 16 / 64 forces; 128 and 256 were measured too: profiles/r04_wide_kernel.txt): 64 for
     // sequence queries (6e5 ... 3e6 index hits per fragment against a UniRef50-scale database: no or few subsets per class), 16 for profile
     // queries (1e5 hits per profile: 64 classes of a thousand records are all group overhead -- 245 against 185 ms per config-4 pass)
     if (shape == 0) {
         const long n = knob_long("MK_PREFILTER_WIDE_CLASSES", Vin.p_sorted ? 16 : 64);
-        shape = n == 16 ? 0 : (n == 128 ? 3 : (n == 256 ? 4 : 2));
+        shape = n == 16 ? 0 : 2;
     }
     const WideShape &W = WIDE_SHAPES[shape];
     // sequence queries with k = 7: the 7-mers are enumerated inside the kernel (no lists in HBM, no count pass); MK_PREFILTER_K7_LISTS=1 keeps the lists

@@ -14,7 +14,7 @@ db = api.TargetDB.from_codes(res, off, p)
 del res
 out = {"n_targets": n_targets, "fragments": n_q, "runs": []}
 ref = None
-for classes in ("64", "16", "64", "128", "256", "64", "128", "256"):
+for classes in ("64", "16", "64", "16"):       # (128 and 256 classes were instantiated for GPU call r04n and removed afterwards)
     os.environ["MK_PREFILTER_WIDE_CLASSES"] = classes
     q = api.Queries.from_codes(fr, foff, p)
     api.kernel_stats(reset=True)
