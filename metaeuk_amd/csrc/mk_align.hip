@@ -242,7 +242,8 @@ __global__ __launch_bounds__(256) void gate_count_kernel(const SwJob *fwdJobs, c
 }
 __global__ __launch_bounds__(256) void gate_emit_kernel(const SwJob *fwdJobs, const SwOut *fwdOut, uint64_t n, const GateEntry *gate, const uint32_t *blockStart,
                                                         uint32_t *posPair, SwJob *posJobs, uint32_t *posKeys, int32_t *posScore, uint32_t *hist,
-                                                        unsigned long long *work /* [2 * cfg]: bytes, [2 * cfg + 1]: cells of the position pass (statistics) */) {
+                                                        unsigned long long *work /* [2 * cfg]: bytes, [2 * cfg + 1]: cells of the position pass (statistics) */,
+                                                        bool useBound) {
     helper_prio();
     __shared__ unsigned long long sWork[2 * SW_NCFG];
     __shared__ uint32_t sWave[4];
@@ -257,6 +258,10 @@ __global__ __launch_bounds__(256) void gate_emit_kernel(const SwJob *fwdJobs, co
     if (pass) {
         uint32_t r = blockStart[blockIdx.x] + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
         for (int k = 0; k < w; k++) r += sWave[k];
+        // the score pass bounds the column of the end cell (swp_kernel; the int32 forward kernels of the largest tile report the end cell itself):
+        // the position pass asks for the FIRST column that reaches the maximum, which the columns behind that bound cannot change
+        const int bound = fwdOut[p].end_col;
+        if (useBound && bound >= 0 && (uint32_t) bound + 1u < j.t_len) j.t_len = (uint32_t) bound + 1u;
         const int c = sw_cfg_of(j.q_len);
         atomicAdd(&sWork[2 * c], (unsigned long long) (j.t_len + 2u * j.q_len + (uint32_t) (sizeof(SwJob) + sizeof(SwOut))));
         atomicAdd(&sWork[2 * c + 1], (unsigned long long) j.q_len * j.t_len);
@@ -525,6 +530,8 @@ struct AlignShapes {
     uint32_t persistentBlocks[SW_NCFG];      // persistent score pass: one-wave workgroups per tile configuration
     uint32_t unitsPerBlock = 0;              // MK_SW_UNITS_PER_BLOCK: short-lived workgroups instead of the persistent launch
     int knownForce = -1, knownWaves = 12, narrowForce = -1;
+    bool earlyExit = true;                   // MK_SW_EARLY_EXIT=0: the position / reverse passes run every column of their jobs (no bound from the score
+                                             // pass, no stop at the known score)
 };
 static const AlignShapes &align_shapes() {
     static AlignShapes S;
@@ -552,6 +559,7 @@ static const AlignShapes &align_shapes() {
         S.knownForce = (int) knob_long("MK_SW_KNOWN", -1);
         S.knownWaves = (int) std::max(1L, knob_long("MK_SW_KNOWN_WAVES", 12));
         S.narrowForce = (int) knob_long("MK_SW_NARROW", -1);
+        S.earlyExit = knob_long("MK_SW_EARLY_EXIT", 1) != 0;
     });
     return S;
 }
@@ -609,6 +617,7 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
             L.persistent_blocks = (uint32_t) S.cus * (uint32_t) (sw_cfg_rows(c) <= 32 ? S.knownWaves : std::max(1, S.knownWaves / 2));
             ACHK(launch_sw_known(L, c, stream));
         } else {
+            if (S.earlyExit) L.known_score = knownScore;           // sw_unit stops a DP once its known maximum has been seen in a finished column
             ACHK(launch_sw(L, c, stream));
         }
         te(th);
@@ -752,7 +761,7 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hi
     SwJob *dRevJobs = (SwJob *) dev_scratch("align_revjobs", (size_t) nRev * sizeof(SwJob));
     ANULL(dRevPair); ANULL(dPosJobs); ANULL(dPosScore); ANULL(dKeys); ANULL(dOrder); ANULL(dPosOut); ANULL(dRevOut); ANULL(dRevJobs);
     hipLaunchKernelGGL(gate_emit_kernel, dim3(nGateBlocks), dim3(256), 0, stream, dJobs, dOut, (uint64_t) n, dGate, (const uint32_t *) dGateBlk,
-                       dRevPair, dPosJobs, dKeys, dPosScore, dHist, dPosWork);
+                       dRevPair, dPosJobs, dKeys, dPosScore, dHist, dPosWork, align_shapes().earlyExit);
     te(th);
     ACHK(hipGetLastError());
     ACHK(hipMemcpyAsync(hPosWork, dPosWork, 2 * SW_NCFG * 8, hipMemcpyDeviceToHost, stream));

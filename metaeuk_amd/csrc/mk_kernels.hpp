@@ -39,7 +39,8 @@ struct SwLaunch {
     uint32_t persistent_blocks; // ... and how many workgroups to launch (0: one per wave)
     uint32_t units_per_block;   // a workgroup retires after this many waves of jobs (0: runs until the counter is exhausted)
     uint64_t boundary_job0;     // job index that owns the first boundary_stride entries of `boundary`
-    const int32_t *known_score; // position / reverse pass of the small tiles (launch_sw_known): the maximum score of job j is known_score[jobs[j].slot]
+    const int32_t *known_score; // position / reverse pass: the maximum score of job j is known_score[jobs[j].slot] (launch_sw_known needs it; launch_sw, per-job
+                                // profiles, stops a DP once that score has been seen in a finished column; null: unknown)
     bool narrow = false;        // score pass: the 16-lane variant of the 384-row tile (the waves were cut with sw_cfg_jobs_per_wave(c, true))
 };
 

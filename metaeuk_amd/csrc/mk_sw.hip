@@ -106,6 +106,13 @@ __device__ __forceinline__ void sw_unit(const SwLaunch &L, const uint32_t unit, 
     const int nTiles = (qLen + ROWS - 1) / ROWS;
     uint32_t *border = L.boundary ? L.boundary + (jobId - L.boundary_job0) * (uint64_t) L.boundary_stride : nullptr;
 
+    // position / reverse pass: the maximum this DP will reach is known (the score pass found it).  What is asked for is the FIRST column that
+    // reaches it and the smallest row there -- final as soon as every lane has passed that column, i.e. G - 1 steps after the first lane saw
+    // the score: the DP stops NEED whole blocks of 16 steps after the block in which the score appeared (a reverse job is the whole prefix
+    // before the end cell, ~ 200 columns, of which the alignment spans ~ as many as the query has rows)
+    constexpr int NEED = (G - 1 + 15) / 16;
+    int known = -1, after = 0;
+    if constexpr (!SHARED) { if (L.known_score && have && nTiles == 1) known = L.known_score[job.slot]; }
     uint32_t bestKey = 0;
     int bestRow = 0;
     for (int tile = 0; tile < nTiles; tile++) {
@@ -197,6 +204,16 @@ __device__ __forceinline__ void sw_unit(const SwLaunch &L, const uint32_t unit, 
                 out0 = (uint32_t) H[R - 1] | ((uint32_t) F << 16);
                 out1 = tres;
                 if (writeBottom && lane == G - 1 && c >= 0 && c < tLen) border[c] = out0;
+            }
+            if constexpr (!SHARED) {
+                if (known > 0) {                                   // (the same for every lane of the group)
+                    bool seen = false;
+#pragma unroll
+                    for (int r = 0; r < R; r++) seen |= (key[r] >> 17) == (uint32_t) known;
+                    const unsigned long long m = __ballot(seen);
+                    const unsigned long long mine = G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull) << (((unsigned) threadIdx.x & 63u) / G * G);
+                    if ((m & mine) != 0ull && ++after > NEED) break;
+                }
             }
         }
 #pragma unroll
@@ -333,6 +350,7 @@ __global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
 #pragma unroll
         for (int r = 0; r < R; r++) { H[r] = zero2; E[r] = zero2; }
         pk16 best = zero2, hupPrev = zero2;
+        int roseA = 0, roseB = 0;                                  // first step of the block of 16 in which this lane's running maximum last rose
         // what travels with a column is not the two residues but the byte offsets of their profile rows (residue * ROWS * 2, code 21 =
         // "no column": an all-zero row), packed in one dword and prepared when the column is fetched -- nothing per step
         constexpr uint32_t ROWB = (uint32_t) ROWS * 2u, NOCOL = 21u * ROWB | (21u * ROWB) << 16;
@@ -357,6 +375,7 @@ __global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
             uint32_t tcur = tq0;
             tq0 = tq1; tq1 = tq2;
             tq2 = fetch(s0 + 48 + laneRow);
+            const uint32_t bestIn = pk_bits(best);
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const uint32_t top = tcur;
@@ -387,16 +406,29 @@ __global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
                 outF = pk_bits(F);
                 outRes = tres;
             }
+            const uint32_t rose = pk_bits(best) ^ bestIn;
+            if (rose & 0xFFFFu) roseA = s0;
+            if (rose >> 16) roseB = s0;
         }
         // group reduction of the two maxima
         uint32_t b = pk_bits(best);
 #pragma unroll
         for (int m = G / 2; m >= 1; m >>= 1) b = pk_bits(pk_max(pk_from(b), pk_from((uint32_t) __shfl_xor((int) b, m, G))));
+        // ... and a bound for the position pass: a lane whose rows hold the maximum reached it in the block of steps in which its running
+        // maximum last rose, i.e. in a column <= that block's last step - lane; the first column that reaches the maximum (what the position
+        // pass reports) is not beyond the smallest such bound, so the position pass may stop there (the columns behind it cannot change its answer)
+        uint32_t cA = (pk_bits(best) & 0xFFFFu) == (b & 0xFFFFu) ? (uint32_t) max(roseA + 15 - lane, 0) : 0x7FFFFFFFu;
+        uint32_t cB = (pk_bits(best) >> 16) == (b >> 16) ? (uint32_t) max(roseB + 15 - lane, 0) : 0x7FFFFFFFu;
+#pragma unroll
+        for (int m = G / 2; m >= 1; m >>= 1) {
+            cA = min(cA, (uint32_t) __shfl_xor((int) cA, m, G));
+            cB = min(cB, (uint32_t) __shfl_xor((int) cB, m, G));
+        }
         if (lane == 0) {
             SwOut o;
-            o.end_col = -1; o.end_row = -1; o.pad = 0;
-            if (haveA) { o.score = (int32_t) (int16_t) (b & 0xFFFFu); L.out[jobA.slot] = o; }
-            if (haveB) { o.score = (int32_t) (int16_t) (b >> 16); L.out[jobB.slot] = o; }
+            o.end_row = -1; o.pad = 0;                              // end_col: not the end cell's column but a bound for it (gate_emit_kernel cuts the position job there)
+            if (haveA) { o.score = (int32_t) (int16_t) (b & 0xFFFFu); o.end_col = (int32_t) min(cA, (uint32_t) lastA); L.out[jobA.slot] = o; }
+            if (haveB) { o.score = (int32_t) (int16_t) (b >> 16); o.end_col = (int32_t) min(cB, (uint32_t) lastB); L.out[jobB.slot] = o; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
