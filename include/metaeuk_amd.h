@@ -18,7 +18,7 @@
  * Process model: one process drives one GPU (mk_init(device)); the library owns its HIP streams, its device scratch and
  * a pool of pinned result blocks.  Calls into the library must come from one thread at a time (the reference's modules
  * are one process per step as well); the library itself runs the stages of mk_search on internal threads (the prefilter on the caller's,
- * the alignment stage on two workers with a stream each).
+ * the alignment stage on three workers with a stream each).
  * Sizing knobs for experiments (never needed for correctness): MK_PREFILTER_PATH, MK_PREFILTER_TIERS,
  * MK_PREFILTER_MAX_TIERS, MK_PREFILTER_WG_PER_CU_S/_A/_B, MK_SW_WAVES_PER_CU, MK_SW_UNITS_PER_BLOCK, MK_STREAM_PRIORITY, MK_SEARCH_CHUNK_QUERIES,
  * MK_PREFILTER_DEBUG.

@@ -1455,8 +1455,9 @@ int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     const int hostThreads = omp_get_max_threads();
     // the alignment stage: MK_ALIGN_WORKERS host threads, each with a stream and scratch buffers of its own, take the chunks in turn --
     // the position and reverse passes of one chunk (short launches, slow beside persistent workgroups) then run beside the
-    // forward pass of the next one instead of in front of it.  Results are appended in chunk order.
-    static const int nWorkers = std::min(MAX_ALIGN_WORKERS, std::max(1, (int) mk::knob_long("MK_ALIGN_WORKERS", 2)));
+    // forward pass of the next one instead of in front of it.  Results are appended in chunk order.  Three workers since the position /
+    // reverse passes became short (profiles/r04_sw_early_exit.txt: 926 -> 910 ms per step against two; the same within the noise before).
+    static const int nWorkers = std::min(MAX_ALIGN_WORKERS, std::max(1, (int) mk::knob_long("MK_ALIGN_WORKERS", 3)));
     const int half = std::max(1, hostThreads / (1 + nWorkers));
     {   // the per-length score tables of the batch (cached per database and query lengths)
         HostTimer ht("host_gate_table");

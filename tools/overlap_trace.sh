@@ -16,7 +16,11 @@ ev = []
 for r in rows:
     n = r["Kernel_Name"]
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    stage = "align" if ("sw_kernel" in n or "swp_kernel" in n or "gate_kernel" in n or "expand_pairs" in n or "rev_jobs" in n or "collect_kernel" in n or "seg_mark" in n or "wave_flag" in n) else ("pref" if ("stream_kernel" in n or "fused_kernel" in n or "probe_kernel" in n or "kmer_count" in n or "diag_score" in n or "keep_kernel" in n or "double_hit" in n or "outkey" in n or "emit_kernel" in n) else "other")
+    al = ("sw_kernel", "swp_kernel", "swq_kernel", "gate_count", "gate_emit", "expand_pairs", "rev_jobs", "collect_kernel", "plan_sums", "plan_offsets",
+          "order_wave", "order_block", "bin_scan", "bin_scatter", "assemble", "scan_sums", "scan_apply")
+    pf = ("stream_kernel", "wide_kernel", "kmer_count", "diag_score", "finish_", "keep_", "double_hit", "select_", "derive_kernel", "kthr_kernel",
+          "probe_", "global_", "sort_", "hits_")
+    stage = "align" if any(k in n for k in al) else ("pref" if any(k in n for k in pf) else "other")
     ev.append((s, e, stage, n, r.get("Queue_Id", "")))
 ev.sort()
 t0 = ev[len(ev) // 2][0]      # second half = the timed step (roughly)
