@@ -1,5 +1,6 @@
-// tools/micro/mk_experiments.hip -- experiments on the prefilter's index probes (NOT part of the product: built into
-// tools/micro/_build/libmk_experiments.so by tools/micro/build.sh, driven by tools/partition_probe_experiment.py).
+// tools/micro/mk_experiments.hip -- experiments on the prefilter's index probes and on the score pass's layout (NOT part of the product:
+// built into tools/micro/_build/libmk_experiments.so by tools/micro/build.sh, driven by tools/partition_probe_experiment.py and
+// tools/interseq_experiment.py).  The second experiment (inter-sequence score pass) is at the end of the file.
 //
 // Question: the per-query kernels move 3.7 x their algorithmic bytes because every probe of the k-mer presence
 // bitmap (8 MB), the slot table (512 MB) and the entries that misses L2 fetches a 128-byte line.  Would a RADIX-PARTITIONED probe -- write
@@ -296,5 +297,250 @@ extern "C" int mkx_partition_probe(const void *view, size_t viewBytes, const uin
     }
     out[7] = same ? 1.0 : 0.0;
     (void) hipFree(dCount); (void) hipFree(dOff); (void) hipFree(dCells); (void) hipFree(dOut);
+    return 0;
+}
+
+// =================================================================================================================================
+// Experiment 2 ("next round" item 3): an INTER-SEQUENCE score pass for queries of at most 64 rows.
+//
+// The product's score pass (mk_sw.hip: swp_kernel) runs a DP on a 16-lane group as an anti-diagonal wavefront, R = 2..4 rows per lane: per
+// step 8 hand-over instructions next to 10 R of recurrence, 15 ramp steps per DP, rows padded to 32 / 48 / 64, and a wave holds at most 8
+// pairs of ONE query.  tools/sw_schedule_model.py puts the alternatives in numbers (profiles/r04_sw_schedule_model.txt); this is the variant
+// it found worth measuring:
+//   * one lane = one packed PAIR of targets (low / high int16 halves), all R rows of the query in its registers (H, E), the column loop has
+//     no lane-to-lane traffic at all: 10 instructions per pair of cells + ~ 12 per column;
+//   * the lane's scores come from its query's profile in LDS, prof[residue][row] int16, one ds_read_b128 per 8 rows and target; a group of
+//     G = 8 lanes shares one query (one profile, rows padded by 16 bytes so that the lanes' rows start in different banks), a wave has 8 groups;
+//   * a group works through ONE query's pairs (falling target length): its lanes take the next two targets when theirs end; when the
+//     query is used up and every lane of the group is idle the group takes the next query from the launch's work counter and rebuilds its
+//     profile -- the other groups of the wave wait for that (~ 2 % by the model);
+//   * target residues are fetched a block of 4 columns ahead (byte loads, clamped), a lane is retired at the end of the block in which its
+//     longer target ended (the columns behind a target's end see the all-zero profile row and cannot raise the maximum).
+// Scores only (the e-value gate needs nothing else).  Verified by the driver against mk_sw_pairs of the product on a sample; timed against
+// sw_fwd_rows32 / 48 / 64 of the product's alignment stage alone on the same pairs.
+namespace {
+
+typedef short xpk16 __attribute__((ext_vector_type(2)));
+typedef unsigned short xpku16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ xpk16 xpk_from(uint32_t v) { return __builtin_bit_cast(xpk16, v); }
+__device__ __forceinline__ uint32_t xpk_bits(xpk16 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ xpk16 xpk_max(xpk16 a, xpk16 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ xpk16 xpk_splat(int v) { xpk16 r; r.x = (short) v; r.y = (short) v; return r; }
+__device__ __forceinline__ xpk16 xpk_subs0(xpk16 a, xpk16 b) {          // a - b clamped at 0 for non-negative halves
+    return __builtin_bit_cast(xpk16, __builtin_elementwise_sub_sat(__builtin_bit_cast(xpku16, a), __builtin_bit_cast(xpku16, b)));
+}
+
+struct InterArgs {
+    const uint8_t *q_res; const int8_t *q_bias; const uint64_t *q_off;
+    const uint8_t *t_res; const int8_t *mat;                              // mat[t * 21 + q], 21 x 21
+    const uint64_t *j_tstart; const uint32_t *j_tlen; const uint32_t *j_q; // the ordered pairs: by query, inside a query by falling target length
+    const uint32_t *unit_start; uint32_t n_units;                          // unit u = pairs [unit_start[u], unit_start[u + 1]) of one query
+    int gap_open, gap_extend;
+    int32_t *out;                                                          // score of every pair
+    uint32_t *work_counter;
+    unsigned long long *stats;                                             // [0] lane-blocks with a pair, [1] lane-blocks in all, [2] profile builds
+};
+
+template <int R>
+__global__ __launch_bounds__(64) void interseq_kernel(InterArgs A) {
+    constexpr int G = 8, NG = 64 / G;
+    constexpr int ROWB = 2 * R + 16;                                       // bytes of a profile row (padded)
+    constexpr int PROFB = 22 * ROWB;                                       // 21 residues + the all-zero row of "no column"
+    static_assert(R % 8 == 0 && ROWB % 16 == 0, "a lane reads its scores 8 rows (16 bytes) at a time");
+    extern __shared__ __attribute__((aligned(16))) char interSmem[];
+    char *prof = interSmem;                                                // [group][residue][row]
+    int8_t *sMat = reinterpret_cast<int8_t *>(interSmem + NG * PROFB);
+    uint8_t *sQ = reinterpret_cast<uint8_t *>(sMat + 448);                 // [group][row]: the query's residues ...
+    int8_t *sB = reinterpret_cast<int8_t *>(sQ + NG * R);                  // ... and composition bias, staged for the profile build
+    const int lane = (int) threadIdx.x, g = lane / G, lig = lane % G;
+    for (int k = lane; k < 441; k += 64) sMat[k] = A.mat[k];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const xpk16 go2 = xpk_splat(A.gap_open), ge2 = xpk_splat(A.gap_extend), zero2 = xpk_splat(0);
+    char *myProf = prof + g * PROFB;
+    // the group's query (the same in all its lanes): remaining pairs [next, end), and whether the work counter ran dry for it
+    uint32_t next = 0, end = 0;
+    bool exhausted = false;
+    // the lane's pair
+    bool active = false;
+    xpk16 H[R], E[R];
+    xpk16 best = zero2;
+#pragma unroll
+    for (int r = 0; r < R; r++) { H[r] = zero2; E[r] = zero2; }
+    int col = 0, len = 0, tLenA = 0, tLenB = 0;
+    uint64_t baseA = 0, baseB = 0;
+    uint32_t jA = 0;
+    bool haveB = false;
+    uint32_t rowA[4] = {0, 0, 0, 0}, rowB[4] = {0, 0, 0, 0};               // byte offsets of the profile rows of the block's 4 columns
+    unsigned long long busy = 0, blocks = 0, builds = 0;
+    const auto rowOf = [&](uint64_t base, int tLen, int c) -> uint32_t {
+        const uint32_t res = c < tLen ? (uint32_t) A.t_res[base + (uint64_t) min(c, max(tLen - 1, 0))] : 21u;
+        return min(res, 21u) * (uint32_t) ROWB;
+    };
+    for (;;) {
+        // ---- lanes without a pair take the next one of their group's query; groups without a query take the next one ----
+        for (;;) {
+            const unsigned long long am = __ballot(active);
+            const uint32_t gAct = (uint32_t) (am >> (g * G)) & 0xFFu;
+            const bool want = !active && !exhausted;
+            const bool canPull = want && next >= end && gAct == 0u;        // (the same in every lane of the group)
+            bool canTake = want && next < end;
+            if (__ballot(canTake || canPull) == 0ull) break;
+            if (canPull) {
+                uint32_t u = 0;
+                if (lig == 0) u = atomicAdd(A.work_counter, 1u);
+                u = (uint32_t) __shfl((int) u, g * G, 64);
+                if (u >= A.n_units) exhausted = true;
+                else {
+                    next = A.unit_start[u]; end = A.unit_start[u + 1];
+                    const uint32_t qi = A.j_q[next];
+                    const uint64_t q0 = A.q_off[qi];
+                    const int qLen = (int) (A.q_off[qi + 1] - q0);
+                    for (int row = lig; row < R; row += G) {
+                        const bool real = row < qLen;
+                        sQ[g * R + row] = real ? A.q_res[q0 + (uint64_t) row] : (uint8_t) 255;
+                        sB[g * R + row] = real ? A.q_bias[q0 + (uint64_t) row] : (int8_t) 0;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    for (int idx = lig; idx < 22 * R; idx += G) {
+                        const int t = idx / R, row = idx - t * R;
+                        const uint32_t qc = sQ[g * R + row];
+                        const int v = (t < 21 && qc < 21u) ? (int) sMat[t * 21 + (int) qc] + (int) sB[g * R + row] : 0;
+                        *reinterpret_cast<int16_t *>(myProf + t * ROWB + row * 2) = (int16_t) v;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (lig == 0) builds++;
+                    canTake = next < end;
+                }
+            }
+            const unsigned long long tm = __ballot(canTake);
+            const uint32_t gm = (uint32_t) (tm >> (g * G)) & 0xFFu;
+            const uint32_t rank = (uint32_t) __popc(gm & ((1u << lig) - 1u)), cnt = (uint32_t) __popc(gm);
+            if (canTake) {
+                const uint32_t j = next + 2u * rank;
+                if (j < end) {
+                    jA = j; haveB = j + 1u < end;
+                    baseA = A.j_tstart[j]; tLenA = (int) A.j_tlen[j];
+                    baseB = haveB ? A.j_tstart[j + 1u] : baseA; tLenB = haveB ? (int) A.j_tlen[j + 1u] : 0;
+                    len = max(tLenA, tLenB); col = 0; best = zero2;
+#pragma unroll
+                    for (int r = 0; r < R; r++) { H[r] = zero2; E[r] = zero2; }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { rowA[k] = rowOf(baseA, tLenA, k); rowB[k] = rowOf(baseB, tLenB, k); }
+                    active = true;
+                }
+            }
+            next = min(end, next + 2u * cnt);                              // (every lane of the group, whether it took a pair or not)
+        }
+        if (__ballot(active) == 0ull) break;                               // nothing left anywhere in this wave
+        blocks++;
+        if (active) {
+            busy++;
+            // the next block's residues first: their loads land while this block's columns are computed
+            uint32_t nA[4], nB[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { nA[k] = rowOf(baseA, tLenA, col + 4 + k); nB[k] = rowOf(baseB, tLenB, col + 4 + k); }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const char *pa = myProf + rowA[k], *pb = myProf + rowB[k];
+                xpk16 F = zero2, diag = zero2;                             // above row 0: nothing
+#pragma unroll
+                for (int r0 = 0; r0 < R; r0 += 8) {
+                    const uint4 wa = *reinterpret_cast<const uint4 *>(pa + r0 * 2), wb = *reinterpret_cast<const uint4 *>(pb + r0 * 2);
+                    const uint32_t a4[4] = {wa.x, wa.y, wa.z, wa.w}, b4[4] = {wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int r = r0 + i;
+                        const xpk16 sc = xpk_from(__builtin_amdgcn_perm(b4[i / 2], a4[i / 2], (i & 1) ? 0x07060302u : 0x05040100u));
+                        const xpk16 d = diag + sc;
+                        diag = H[r];
+                        const xpk16 h = xpk_max(xpk_max(d, E[r]), F);      // E, F >= 0 keep H non-negative
+                        best = xpk_max(best, h);
+                        const xpk16 ho = xpk_subs0(h, go2);
+                        E[r] = xpk_max(xpk_subs0(E[r], ge2), ho);
+                        F = xpk_max(xpk_subs0(F, ge2), ho);
+                        H[r] = h;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);                         // a column's profile reads stay in their column: registers for 2 waves per SIMD
+            }
+            col += 4;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { rowA[k] = nA[k]; rowB[k] = nB[k]; }
+            if (col >= len) {
+                A.out[jA] = (int32_t) (int16_t) (xpk_bits(best) & 0xFFFFu);
+                if (haveB) A.out[jA + 1u] = (int32_t) (int16_t) (xpk_bits(best) >> 16);
+                active = false;
+            }
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) { busy += __shfl_xor((long long) busy, d, 64); builds += __shfl_xor((long long) builds, d, 64); }
+    if (lane == 0) { atomicAdd(&A.stats[0], busy); atomicAdd(&A.stats[1], blocks * 64ull); atomicAdd(&A.stats[2], builds); }
+}
+
+template <int R>
+int launch_interseq(const InterArgs &A, unsigned grid, hipStream_t s) {
+    constexpr int ROWB = 2 * R + 16;
+    const size_t lds = (size_t) 8 * 22 * ROWB + 448 + 2 * 8 * R;
+    hipLaunchKernelGGL((interseq_kernel<R>), dim3(grid), dim3(64), lds, s, A);
+    return 0;
+}
+
+}  // namespace
+
+// Host arrays in, scores out.  q_res / q_bias / q_off: the query batch (residue codes 0..20, int8 composition bias, offsets); t_res: the
+// targets' residues (tBytes, unmasked); mat441: int8 scores [t * 21 + q]; the pairs (jTStart, jTLen, jQ) ordered by query and falling target
+// length; unitStart[nUnits + 1] cuts them into runs of one query; rows = 32 / 48 / 64 (every query of the call has at most that many
+// residues).  out[0] best ms of `reps` launches, out[1] lane-blocks with a pair / lane-blocks in all (how busy the lanes were),
+// out[2] profile builds, out[3] LDS bytes per wave.
+extern "C" int mkx_interseq_score(const uint8_t *qRes, const int8_t *qBias, const uint64_t *qOff, uint32_t nq, const uint8_t *tRes, uint64_t tBytes,
+                                  const int8_t *mat441, const uint64_t *jTStart, const uint32_t *jTLen, const uint32_t *jQ, uint64_t nJobs,
+                                  const uint32_t *unitStart, uint32_t nUnits, int rows, int gapOpen, int gapExtend, int wavesPerCu, int reps,
+                                  int32_t *outScore, double *out) {
+    if (rows != 32 && rows != 48 && rows != 64) { snprintf(g_err, sizeof(g_err), "rows: 32, 48 or 64"); return -1; }
+    if (nJobs == 0 || nJobs >= 0x7FFFFFFFull || nUnits == 0) { snprintf(g_err, sizeof(g_err), "no pairs, or too many"); return -1; }
+    const uint64_t qBytes = qOff[nq];
+    uint8_t *dQ = nullptr, *dT = nullptr; int8_t *dB = nullptr, *dM = nullptr; uint64_t *dQOff = nullptr, *dJT = nullptr;
+    uint32_t *dJL = nullptr, *dJQ = nullptr, *dU = nullptr, *dCounter = nullptr; int32_t *dOut = nullptr; unsigned long long *dStats = nullptr;
+    XCHK(hipMalloc(&dQ, qBytes + 16)); XCHK(hipMalloc(&dB, qBytes + 16)); XCHK(hipMalloc(&dQOff, ((size_t) nq + 1) * 8));
+    XCHK(hipMalloc(&dT, tBytes + 16)); XCHK(hipMalloc(&dM, 448));
+    XCHK(hipMalloc(&dJT, nJobs * 8)); XCHK(hipMalloc(&dJL, nJobs * 4)); XCHK(hipMalloc(&dJQ, nJobs * 4)); XCHK(hipMalloc(&dU, ((size_t) nUnits + 1) * 4));
+    XCHK(hipMalloc(&dOut, nJobs * 4)); XCHK(hipMalloc(&dCounter, 64)); XCHK(hipMalloc(&dStats, 64));
+    XCHK(hipMemcpy(dQ, qRes, qBytes, hipMemcpyHostToDevice)); XCHK(hipMemcpy(dB, qBias, qBytes, hipMemcpyHostToDevice));
+    XCHK(hipMemcpy(dQOff, qOff, ((size_t) nq + 1) * 8, hipMemcpyHostToDevice));
+    XCHK(hipMemcpy(dT, tRes, tBytes, hipMemcpyHostToDevice)); XCHK(hipMemcpy(dM, mat441, 441, hipMemcpyHostToDevice));
+    XCHK(hipMemcpy(dJT, jTStart, nJobs * 8, hipMemcpyHostToDevice)); XCHK(hipMemcpy(dJL, jTLen, nJobs * 4, hipMemcpyHostToDevice));
+    XCHK(hipMemcpy(dJQ, jQ, nJobs * 4, hipMemcpyHostToDevice)); XCHK(hipMemcpy(dU, unitStart, ((size_t) nUnits + 1) * 4, hipMemcpyHostToDevice));
+    XCHK(hipMemset(dOut, 0xFF, nJobs * 4));
+    int dev = 0, cus = 256;
+    XCHK(hipGetDevice(&dev));
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    InterArgs A;
+    A.q_res = dQ; A.q_bias = dB; A.q_off = dQOff; A.t_res = dT; A.mat = dM; A.j_tstart = dJT; A.j_tlen = dJL; A.j_q = dJQ;
+    A.unit_start = dU; A.n_units = nUnits; A.gap_open = gapOpen; A.gap_extend = gapExtend; A.out = dOut; A.work_counter = dCounter; A.stats = dStats;
+    const unsigned grid = (unsigned) std::min<uint64_t>((uint64_t) cus * (uint64_t) std::max(1, wavesPerCu), ((uint64_t) nUnits + 7) / 8);
+    hipStream_t s = nullptr;
+    float best = 1e30f;
+    hipEvent_t e0, e1;
+    XCHK(hipEventCreate(&e0)); XCHK(hipEventCreate(&e1));
+    for (int r = 0; r < std::max(1, reps); r++) {
+        XCHK(hipMemsetAsync(dCounter, 0, 64, s)); XCHK(hipMemsetAsync(dStats, 0, 64, s));
+        XCHK(hipEventRecord(e0, s));
+        if (rows == 32) launch_interseq<32>(A, grid, s); else if (rows == 48) launch_interseq<48>(A, grid, s); else launch_interseq<64>(A, grid, s);
+        XCHK(hipEventRecord(e1, s));
+        XCHK(hipStreamSynchronize(s));
+        XCHK(hipGetLastError());
+        float ms = 0;
+        XCHK(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, ms);
+    }
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    unsigned long long st[8] = {0};
+    XCHK(hipMemcpy(st, dStats, 64, hipMemcpyDeviceToHost));
+    XCHK(hipMemcpy(outScore, dOut, nJobs * 4, hipMemcpyDeviceToHost));
+    out[0] = best; out[1] = st[1] ? (double) st[0] / (double) st[1] : 0.0; out[2] = (double) st[2]; out[3] = (double) (8 * 22 * (2 * rows + 16) + 448 + 16 * rows);
+    for (void *p : {(void *) dQ, (void *) dB, (void *) dQOff, (void *) dT, (void *) dM, (void *) dJT, (void *) dJL, (void *) dJQ, (void *) dU, (void *) dOut, (void *) dCounter, (void *) dStats}) (void) hipFree(p);
     return 0;
 }
