@@ -880,7 +880,7 @@ int mk_profiles_derived(const mk_queries *q, uint8_t *letters, int8_t *sorted40,
 
 // ---- swapresults on arrays (host code) ----
 struct mk_swapped {
-    std::vector<mk_alignment> alns;
+    std::unique_ptr<mk_alignment[]> alns;      // (not a vector: 300 MB of records at config-4 scale must not be zero-filled by one thread first)
     std::vector<uint64_t> off;
 };
 
@@ -888,57 +888,65 @@ int mk_swap_alignments(const mk_alignment *alns, const uint64_t *offsets, uint32
                        uint64_t swappedDbResidues, const mk_params *P, mk_swapped **out) {
     if (!offsets || !P || !out || (!alns && offsets[nq] > 0)) return fail(MK_ERR_ARG, "null argument");
     const uint64_t total = offsets[nq];
-    for (uint64_t k = 0; k < total; k++) if (alns[k].db_key >= nTargets) return fail(MK_ERR_ARG, "alignment %llu names target %u of %u", (unsigned long long) k, alns[k].db_key, nTargets);
     HostTimer ht("host_swap_total");
     mk::Evaluer ev;
     ev.init(swappedDbResidues);                        // swapresults.cpp:76-77,102
     const double ln2 = std::log(2.0);
-    // 1. every record swapped in place of a copy (parallel over the queries); a record beyond -e is marked (the workflow passes DBL_MAX)
-    std::vector<mk_alignment> tmp(total);
-    std::vector<uint32_t> target(total);
+    // 1. per record: the target's list it goes to (none beyond -e; the workflow passes DBL_MAX) and its e-value against the swapped database;
+    //    list sizes.  The buffers are written by the threads that read them again (no value-initialisation by one thread in front).
+    std::unique_ptr<uint32_t[]> target(new uint32_t[std::max<uint64_t>(total, 1)]);
+    std::unique_ptr<double[]> evalue(new double[std::max<uint64_t>(total, 1)]);
     std::vector<uint64_t> cnt((size_t) nTargets + 1, 0);
-#pragma omp parallel for schedule(dynamic, 64)
-    for (uint32_t i = 0; i < nq; i++) {
-        for (uint64_t k = offsets[i]; k < offsets[i + 1]; k++) {
-            mk_alignment a = alns[k];
-            // the record as swapresults re-reads it from its text (Matcher::parseAlignmentRecord, Matcher.cpp:203-239): the identity has
-            // three decimals there -- "0.xyz" with xyz = (int)(seqId * 1000) (Util::fastSeqIdToBuffer), "1.00" for 1.0 -- and the nearest
-            // double of that decimal is the correctly rounded quotient xyz / 1000
-            if (!(a.seq_id == 1.0f)) a.seq_id = (float) ((double) (int) (a.seq_id * 1000) / 1000.0);
-            // Matcher::result_t::swapResult (Matcher.h:93-115)
-            const double rawScore = (ev.logK + (double) a.bit_score * ln2) / ev.lambda;        // EvalueComputation.h:22-24
-            a.evalue = ev.evalue(rawScore, (double) a.db_len);
-            target[k] = a.db_key;
-            std::swap(a.q_start, a.db_start); std::swap(a.q_end, a.db_end); std::swap(a.q_len, a.db_len); std::swap(a.qcov, a.dbcov);
-            a.db_key = queryKeys ? queryKeys[i] : i;
-            if (!(a.evalue <= P->evalue_thr)) target[k] = 0xFFFFFFFFu;                       // swapresults.cpp:291-295 (-e)
-            tmp[k] = a;
-        }
+    uint64_t badRecord = ~0ull;
+#pragma omp parallel for schedule(static) reduction(min : badRecord)
+    for (uint64_t k = 0; k < total; k++) {
+        const mk_alignment &a = alns[k];
+        if (a.db_key >= nTargets) { badRecord = std::min(badRecord, k); target[k] = 0xFFFFFFFFu; evalue[k] = 0; continue; }
+        // Matcher::result_t::swapResult (Matcher.h:93-115): the e-value of the bit score against the swapped database, the record's
+        // target length as the query length
+        const double rawScore = (ev.logK + (double) a.bit_score * ln2) / ev.lambda;            // EvalueComputation.h:22-24
+        const double e = ev.evalue(rawScore, (double) a.db_len);
+        evalue[k] = e;
+        const bool keep = e <= P->evalue_thr;                                                    // swapresults.cpp:291-295 (-e)
+        target[k] = keep ? a.db_key : 0xFFFFFFFFu;
+        if (keep) __atomic_fetch_add(&cnt[(size_t) a.db_key + 1], 1ull, __ATOMIC_RELAXED);
     }
-    // 2. lists per target: counts, offsets, scatter (the order inside a list is settled by the sort: compareHits is a total order here,
-    //    its last key -- the query's DB key -- is unique within a list)
-#pragma omp parallel for schedule(static)
-    for (uint64_t k = 0; k < total; k++) if (target[k] != 0xFFFFFFFFu) __atomic_fetch_add(&cnt[(size_t) target[k] + 1], 1ull, __ATOMIC_RELAXED);
+    if (badRecord != ~0ull) return fail(MK_ERR_ARG, "alignment %llu names target %u of %u", (unsigned long long) badRecord, alns[badRecord].db_key, nTargets);
     for (uint32_t t = 0; t < nTargets; t++) cnt[t + 1] += cnt[t];
     mk_swapped *s = new mk_swapped();
-    s->off = cnt;
-    s->alns.resize(cnt[nTargets]);
+    s->alns.reset(new mk_alignment[std::max<uint64_t>(cnt[nTargets], 1)]);
+    // 2. every kept record swapped straight into its target's list (parallel over the queries; the order inside a list is settled by the
+    //    sort: compareHits is a total order here, its last key -- the query's DB key -- is unique within a list)
     {
         std::vector<uint64_t> fill(cnt.begin(), cnt.end() - 1);
-#pragma omp parallel for schedule(static)
-        for (uint64_t k = 0; k < total; k++)
-            if (target[k] != 0xFFFFFFFFu) s->alns[__atomic_fetch_add(&fill[target[k]], 1ull, __ATOMIC_RELAXED)] = tmp[k];
+#pragma omp parallel for schedule(dynamic, 64)
+        for (uint32_t i = 0; i < nq; i++) {
+            for (uint64_t k = offsets[i]; k < offsets[i + 1]; k++) {
+                if (target[k] == 0xFFFFFFFFu) continue;
+                mk_alignment a = alns[k];
+                // the record as swapresults re-reads it from its text (Matcher::parseAlignmentRecord, Matcher.cpp:203-239): the identity has
+                // three decimals there -- "0.xyz" with xyz = (int)(seqId * 1000) (Util::fastSeqIdToBuffer), "1.00" for 1.0 -- and the nearest
+                // double of that decimal is the correctly rounded quotient xyz / 1000
+                if (!(a.seq_id == 1.0f)) a.seq_id = (float) ((double) (int) (a.seq_id * 1000) / 1000.0);
+                a.evalue = evalue[k];
+                std::swap(a.q_start, a.db_start); std::swap(a.q_end, a.db_end); std::swap(a.q_len, a.db_len); std::swap(a.qcov, a.dbcov);
+                a.db_key = queryKeys ? queryKeys[i] : i;
+                s->alns[__atomic_fetch_add(&fill[target[k]], 1ull, __ATOMIC_RELAXED)] = a;
+            }
+        }
     }
+    s->off.swap(cnt);
+    mk_alignment *base = s->alns.get();
 #pragma omp parallel for schedule(dynamic, 1024)
     for (uint32_t t = 0; t < nTargets; t++)
-        if (s->off[t + 1] - s->off[t] > 1) std::sort(s->alns.begin() + s->off[t], s->alns.begin() + s->off[t + 1], mk::alignment_less);
+        if (s->off[t + 1] - s->off[t] > 1) std::sort(base + s->off[t], base + s->off[t + 1], mk::alignment_less);
     *out = s;
     return MK_OK;
 }
 
 int mk_swapped_result(const mk_swapped *s, const mk_alignment **alns, const uint64_t **offsets) {
     if (!s || !alns || !offsets) return fail(MK_ERR_ARG, "null argument");
-    *alns = s->alns.data(); *offsets = s->off.data();
+    *alns = s->alns.get(); *offsets = s->off.data();
     return MK_OK;
 }
 void mk_swapped_destroy(mk_swapped *s) { delete s; }
