@@ -215,6 +215,10 @@ def main():
     ap.add_argument("--targets", type=int, default=100000)
     ap.add_argument("--seed", type=int, default=11)
     ap.add_argument("--two-calls", action="store_true", help="mk_prefilter then mk_align instead of the pipelined mk_search")
+    ap.add_argument("--blocking", action="store_true", help="time the blocking mk_search (one batch at a time) as the headline figure instead of the "
+                    "queued mk_search_begin / mk_search_wait loop")
+    ap.add_argument("--blocking-steps", type=int, default=5, help="steps of the blocking mk_search timed after the headline region and reported beside it "
+                    "(`blocking`; 0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=400000, help="queries in the CPU baseline sample (0 = skip)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default=None, help="multi-GPU mode (default: strong when --gpus > 1)")
     ap.add_argument("--config4-profiles", type=int, default=50000, help="BASELINE config 4 beside the headline number (N = 1 only): this many synthetic "
@@ -306,16 +310,54 @@ def main():
             q.close()
         return res
 
-    for _ in range(args.warmup):
-        step()
+    def collect(q, keep=False):
+        (hits, hoff), (alns, aoff) = api.search_wait(q)
+        res = (int(hoff[-1]), int(aoff[-1]))
+        if keep:
+            last.update(q=q, hits=hits, hoff=hoff, alns=alns, aoff=aoff)
+        else:
+            q.close()
+        return res
+
+    def run_steps(n, keep_last):
+        """n steps; the result of every step is on the host when this returns.  Default: the batches are QUEUED (mk_search_begin /
+        mk_search_wait) -- batch k + 1 is uploaded, derived and begun before the results of batch k are collected, so the prefilter of
+        k + 1 runs beside the alignment tail of k (what a caller that walks a DB in batches gets, e.g. `metaeuk-amd predictexons`).
+        --blocking / --two-calls: one batch at a time."""
+        res = (0, 0)
+        if args.two_calls or args.blocking:
+            for k in range(n):
+                res = step(keep=(keep_last and k == n - 1))
+            return res
+        pending = None
+        for k in range(n):
+            q = api.Queries.from_codes(q_res, q_off, params)
+            api.search_begin(db, q)
+            if pending is not None:
+                collect(pending)
+            pending = q
+        if pending is not None:
+            res = collect(pending, keep=keep_last)
+        return res
+
+    run_steps(args.warmup, False)
     api.kernel_stats(reset=True)
     barrier()
     t0 = time.time()
-    nhits = npass = 0
-    for k in range(args.steps):
-        nhits, npass = step(keep=(k == args.steps - 1))
+    nhits, npass = run_steps(args.steps, True)
     barrier()
     elapsed = time.time() - t0
+    stats = api.kernel_stats()
+    blocking = None
+    if not (args.two_calls or args.blocking) and args.blocking_steps > 0:
+        # the same step with the blocking call, one batch at a time (round 4's figure), outside the headline region
+        barrier()
+        tb0 = time.time()
+        for _ in range(args.blocking_steps):
+            step()
+        barrier()
+        blocking = {"ms_per_step": (time.time() - tb0) / args.blocking_steps * 1e3, "steps": args.blocking_steps,
+                    "note": "mk_search, one batch at a time: every step pays the fill and drain of the two-stage pipeline"}
     total_queries = len(queries)
     if dist is not None:
         import torch
@@ -326,7 +368,6 @@ def main():
         dist.all_reduce(tq, op=dist.ReduceOp.SUM)
         total_queries = int(tq.item())
 
-    stats = api.kernel_stats()
     nq = len(queries)
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
     frag_per_s = total_queries * args.steps / elapsed
@@ -355,6 +396,9 @@ def main():
         "config": {"workload": "predictexons hot path: %d synthetic 5-kb contigs (%d ORF fragments/rank, %d aa) x %d-protein DB (%d aa), -s 5.7" % (
             args.contigs, nq, int(q_off[-1]), args.targets, int(t_off[-1])), "parallelism": "query-shard x%d" % world,
             "seed": args.seed},
+        "mode": "two calls" if args.two_calls else ("blocking mk_search" if args.blocking else "queued batches (mk_search_begin / mk_search_wait): every "
+                "result of every step on the host inside the timed region"),
+        "blocking": blocking,
         "gcups_sw": gcups_total,
         "gcups_sw_kernel_only": (cells_sw / max(sw_ms * 1e-3, 1e-12) / 1e9) if sw_ms else None,      # (kernel durations summed: overlapping launches count twice)
         "prefilter_hits": nhits, "alignments_passed": npass,

@@ -17,8 +17,8 @@
  *
  * Process model: one process drives one GPU (mk_init(device)); the library owns its HIP streams, its device scratch and
  * a pool of pinned result blocks.  Calls into the library must come from one thread at a time (the reference's modules
- * are one process per step as well); the library itself runs the stages of mk_search on internal threads (the prefilter on the caller's,
- * the alignment stage on three workers with a stream each).
+ * are one process per step as well); the library itself runs the stages of mk_search on internal, persistent threads (one for the
+ * prefilter, three alignment workers, a stream each).
  * Sizing knobs for experiments (never needed for correctness): MK_PREFILTER_PATH, MK_PREFILTER_TIERS,
  * MK_PREFILTER_MAX_TIERS, MK_PREFILTER_WG_PER_CU_S/_A/_B, MK_SW_WAVES_PER_CU, MK_SW_UNITS_PER_BLOCK, MK_STREAM_PRIORITY, MK_SEARCH_CHUNK_QUERIES,
  * MK_PREFILTER_DEBUG.
@@ -268,6 +268,18 @@ size_t mk_format_prediction_exon(char *buf, const mk_prediction *p, const mk_exo
  * (blastp.sh:70,85 via predictexons.sh:68).  Same results as mk_prefilter followed by mk_align (both result
  * getters work afterwards); the stages run concurrently on two HIP streams, chunk by chunk. */
 int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *params);
+/* The same pass without blocking the caller (round 5): mk_search_begin queues the batch and returns; mk_search_wait returns once every hit and
+ * alignment of THAT batch is in host memory (its return code is the search's; the result getters work afterwards).  mk_search = begin + wait.
+ * Batches are searched in the order they were begun, by the library's own threads (one for the prefilter, three alignment workers): the
+ * prefilter of batch k + 1 runs beside the alignment of the last chunks of batch k -- what Prefiltering::runSplit / Alignment::run get from
+ * one OpenMP loop over ALL queries (Prefiltering.cpp:817-886, Alignment.cpp:312-514: no barrier between a caller's batches) -- so a caller that
+ * walks a DB in batches (the contig batches of `metaeuk-amd predictexons`, the steps of bench.py) pays the fill and drain of the two-stage
+ * pipeline once per run instead of once per batch.  Between begin and wait the batch and the database must stay alive and untouched; the one
+ * call meant to be made meanwhile is mk_queries_create for the NEXT batch (it uploads and derives on a stream of its own).  Every other
+ * compute entry point first waits for the searches in flight to finish (their results stay collectable); mk_queries_destroy of a batch in
+ * flight waits for it, mk_targetdb_destroy for all. */
+int mk_search_begin(mk_targetdb *db, mk_queries *q, const mk_params *params);
+int mk_search_wait(mk_queries *q);
 
 /* ---- kernel-level entry points (used by the parity tests and bench.py) ---- */
 /* Smith-Waterman on explicit pairs: for pair p, query q_idx[p] vs target t_idx[p].

@@ -22,7 +22,9 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <iterator>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <omp.h>
 #include <thread>
@@ -60,7 +62,9 @@ std::map<std::string, StatAcc> g_stats;
 std::mutex g_statsMutex;
 std::vector<std::string> g_statNames;
 hipStream_t g_stream2 = nullptr;                         // alignment stage of mk_search
+hipStream_t g_uploadStream = nullptr;                    // mk_queries_create: upload + derivation of the NEXT batch beside a search in flight
 constexpr int MAX_ALIGN_WORKERS = 4;
+constexpr int UPLOAD_LANE = 8;                           // scratch lane of mk_queries_create
 hipStream_t g_alignStreams[MAX_ALIGN_WORKERS] = {};      // [0] = g_stream2; the further workers of the alignment stage
 thread_local hipStream_t t_stream = nullptr;             // stream of the calling thread's stage (null: g_stream)
 hipStream_t cur_stream() { return t_stream ? t_stream : g_stream; }
@@ -102,20 +106,67 @@ struct HostTimer {
     }
 };
 
+// Device blocks of the query batches come from a small pool: a batch of ORF fragments is created and destroyed per call of the hot
+// path, and hipFree waits for the whole device -- with a search of the previous batch still in flight (mk_search_begin) that would
+// serialise what the pipeline overlaps.  Blocks of more than 1 GB are not kept.
+struct DevPoolBlock { void *p; size_t cap; };
+std::vector<DevPoolBlock> g_devPool;
+std::mutex g_devPoolMutex;
+constexpr size_t DEV_POOL_BLOCKS = 24, DEV_POOL_BLOCK_MAX = 1ull << 30;
+void *dev_pool_alloc(size_t bytes, size_t *cap) {
+    {
+        std::lock_guard<std::mutex> g(g_devPoolMutex);
+        int best = -1;
+        for (int i = 0; i < (int) g_devPool.size(); i++)
+            if (g_devPool[i].cap >= bytes && g_devPool[i].cap <= 2 * bytes + 65536 && (best < 0 || g_devPool[i].cap < g_devPool[best].cap)) best = i;
+        if (best >= 0) { void *p = g_devPool[best].p; *cap = g_devPool[best].cap; g_devPool.erase(g_devPool.begin() + best); return p; }
+    }
+    void *p = nullptr;
+    const size_t want = bytes + bytes / 16 + 256;
+    if (hipMalloc(&p, want) != hipSuccess) return nullptr;
+    *cap = want;
+    return p;
+}
+void dev_pool_free(void *p, size_t cap) {
+    void *drop = nullptr;
+    if (cap > DEV_POOL_BLOCK_MAX) drop = p;
+    else {
+        std::lock_guard<std::mutex> g(g_devPoolMutex);
+        g_devPool.push_back(DevPoolBlock{p, cap});
+        if (g_devPool.size() > DEV_POOL_BLOCKS) {            // the smallest block goes
+            int small = 0;
+            for (int i = 1; i < (int) g_devPool.size(); i++) if (g_devPool[i].cap < g_devPool[small].cap) small = i;
+            drop = g_devPool[small].p;
+            g_devPool.erase(g_devPool.begin() + small);
+        }
+    }
+    if (drop) (void) hipFree(drop);
+}
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr; size_t n = 0;
-    ~DevBuf() { if (p) (void) hipFree(p); }
+    bool pooled = false; size_t poolCap = 0;                 // pooled: the block comes from / returns to the device pool
+    ~DevBuf() { drop(); }
+    void drop() {
+        if (!p) return;
+        if (pooled && poolCap) dev_pool_free(p, poolCap); else (void) hipFree(p);
+        p = nullptr; poolCap = 0;
+    }
     hipError_t alloc(size_t count) {
-        if (p) { (void) hipFree(p); p = nullptr; }
+        drop();
         n = count;
         if (count == 0) return hipSuccess;
+        if (pooled) {
+            p = reinterpret_cast<T *>(dev_pool_alloc(count * sizeof(T), &poolCap));
+            return p ? hipSuccess : hipErrorOutOfMemory;
+        }
         return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
     }
-    hipError_t upload(const T *h, size_t count) {
+    hipError_t upload(const T *h, size_t count, hipStream_t stream = nullptr) {
         hipError_t e = alloc(count);
         if (e != hipSuccess || count == 0) return e;
-        return hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, g_stream);
+        return hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, stream ? stream : g_stream);
     }
 };
 
@@ -188,11 +239,11 @@ struct mk_targetdb {
     // score tables of the alignment stage, kept from call to call: the e-value row of a query length depends on the database alone, and
     // consecutive batches of ORF fragments bring the same lengths (a batch of other lengths adds its rows; the device copy follows the id)
     std::unordered_map<uint32_t, std::vector<double>> evalueRows;
-    std::vector<uint32_t> tableLens;       // the distinct query lengths the cached tables were assembled for
-    double gateThr = -1.0;
-    mk::AssembleTables tables;
-    std::vector<mk::GateEntry> gate;
+    std::shared_ptr<const struct ScoreTabs> scoreTabs;     // the newest snapshot (immutable: the batches in flight hold the one they were given)
 };
+
+// score tables of the alignment stage for a set of query lengths: e-value per (length, score), bit scores, the gate
+struct ScoreTabs { mk::AssembleTables tables; std::vector<mk::GateEntry> gate; std::vector<uint32_t> lens; double thr = -1.0; };
 
 struct mk_queries {
     uint32_t n = 0;
@@ -212,10 +263,14 @@ struct mk_queries {
     mk::HostBlock hits; size_t nHits = 0; std::vector<uint64_t> hitOff; bool havePref = false;
     mk::PrefilterStats pfStats;      // run statistics of the prefilter over this batch (Prefiltering.cpp:889-904)
     mk::HostBlock alns; std::vector<uint64_t> alnOff; bool haveAln = false;
+    struct SearchJob *job = nullptr; // mk_search_begin: the search in flight over this batch (mk_search_wait clears it)
+    mk_queries() { dRes.pooled = dOff.pooled = dKmerThr.pooled = dCorr.pooled = dBias8.pooled = true; }
 };
 
-// the alignment stage's score tables for batch q (e-value per query length and score, the gate), from the database's cache
-static void score_tables(mk_targetdb *db, const mk_queries *q, double evalThr, const mk::AssembleTables *&tables, const std::vector<mk::GateEntry> *&gate) {
+// the alignment stage's score tables for batch q (e-value per query length and score, the gate), from the database's cache.  A snapshot
+// serves every batch whose query lengths it covers; a batch that brings new lengths gets a new snapshot over the union (the rows come from
+// the per-length cache), and the batches still in flight keep theirs.
+static std::shared_ptr<const ScoreTabs> score_tables(mk_targetdb *db, const mk_queries *q, double evalThr) {
     std::vector<uint32_t> lens;
     {
         uint32_t maxLen = 0;
@@ -224,22 +279,36 @@ static void score_tables(mk_targetdb *db, const mk_queries *q, double evalThr, c
         for (uint32_t i = 0; i < q->n; i++) present[q->off[i + 1] - q->off[i]] = 1;
         for (uint32_t L = 0; L <= maxLen; L++) if (present[L] && (L > 0 || q->n > 0)) lens.push_back(L);
     }
-    if (!(lens == db->tableLens && evalThr == db->gateThr && !db->tables.evalue.empty())) {
-        db->tables.bitScore = db->bitScoreTable;
-        mk::build_assemble_tables(db->evaluer, q->off, db->tables, &db->evalueRows);
-        mk::build_gate_table(db->evaluer, evalThr, q->off, db->gate, &db->tables);
-        db->tableLens = lens; db->gateThr = evalThr;
-        if (db->evalueRows.size() > 8192) db->evalueRows.clear();           // (bounded: 32 KB per length)
+    std::shared_ptr<const ScoreTabs> cur = db->scoreTabs;
+    const bool sameThr = cur && cur->thr == evalThr && !cur->tables.lenIdx.empty();
+    if (sameThr && std::includes(cur->lens.begin(), cur->lens.end(), lens.begin(), lens.end())) return cur;
+    std::vector<uint32_t> all = lens;
+    if (sameThr) {
+        std::vector<uint32_t> merged;
+        std::set_union(cur->lens.begin(), cur->lens.end(), lens.begin(), lens.end(), std::back_inserter(merged));
+        if (merged.size() <= 4096) all.swap(merged);                          // (bounded: 32 KB per length and snapshot)
     }
-    tables = &db->tables; gate = &db->gate;
+    std::vector<uint64_t> off(all.size() + 1, 0);                             // one stand-in query per length
+    for (size_t k = 0; k < all.size(); k++) off[k + 1] = off[k] + all[k];
+    auto nt = std::make_shared<ScoreTabs>();
+    nt->tables.bitScore = db->bitScoreTable;
+    mk::build_assemble_tables(db->evaluer, off, nt->tables, &db->evalueRows);
+    mk::build_gate_table(db->evaluer, evalThr, off, nt->gate, &nt->tables);
+    nt->lens = all; nt->thr = evalThr;
+    if (db->evalueRows.size() > 8192) db->evalueRows.clear();                 // (bounded: 32 KB per length)
+    db->scoreTabs = nt;
+    return nt;
 }
 
 
 
 namespace {
 
-int ensure_ready() {
+void engine_drain_if_running();
+// drain: the entry points that use the library's streams and scratch buffers first let the searches in flight (mk_search_begin) finish
+int ensure_ready(bool drain = true) {
     if (!g_ready) return fail(MK_ERR_DEVICE, "mk_init() was not called or no HIP device is usable");
+    if (drain) engine_drain_if_running();
     return MK_OK;
 }
 
@@ -357,6 +426,7 @@ int mk_init(int device) {
         if (!g_stream) HIPCHK(prio ? hipStreamCreateWithPriority(&g_stream, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
         if (!g_stream2) HIPCHK(prio ? hipStreamCreateWithPriority(&g_stream2, hipStreamNonBlocking, least) : hipStreamCreateWithFlags(&g_stream2, hipStreamNonBlocking));
         g_alignStreams[0] = g_stream2;
+        if (!g_uploadStream) HIPCHK(hipStreamCreateWithFlags(&g_uploadStream, hipStreamNonBlocking));
         for (int w = 1; w < MAX_ALIGN_WORKERS; w++)
             if (!g_alignStreams[w]) HIPCHK(prio ? hipStreamCreateWithPriority(&g_alignStreams[w], hipStreamNonBlocking, least) : hipStreamCreateWithFlags(&g_alignStreams[w], hipStreamNonBlocking));
     }
@@ -564,7 +634,7 @@ static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uin
     return MK_OK;
 }
 
-void mk_targetdb_destroy(mk_targetdb *db) { delete db; }
+void mk_targetdb_destroy(mk_targetdb *db) { engine_drain_if_running(); delete db; }
 int mk_targetdb_create(const uint8_t *residues, const uint64_t *offsets, uint32_t n, const mk_params *P, mk_targetdb **out) {
     return targetdb_create(residues, offsets, n, P, nullptr, out);
 }
@@ -760,7 +830,7 @@ int mk_targetdb_index_compare(const mk_targetdb *a, const mk_targetdb *b, uint64
 // residues come from the host (upload) or are already in HBM (devResidues: device-to-device copy); the host copy is kept
 // for the rare exact self-score of the --max-seqs path
 static int queries_create(const uint8_t *residues, const uint8_t *devResidues, const uint64_t *offsets, uint32_t n, const mk_params *P, mk_queries **out) {
-    int rc = ensure_ready();
+    int rc = ensure_ready(false);          // does not wait for the searches in flight: the next batch is uploaded and derived beside them
     if (rc) return rc;
     if (!residues || !offsets || !P || !out) return fail(MK_ERR_ARG, "null argument");
     if (offsets[n] >= 0xFFFFFFFFull) return fail(MK_ERR_ARG, "query batch too large (>= 2^32 residues): split it");
@@ -776,16 +846,22 @@ static int queries_create(const uint8_t *residues, const uint8_t *devResidues, c
     mk::SubMat kmerMat, alnMat;
     mk::build_submat(kmerMat, mk::MAT_VTML80, 8.0f, -0.2f);
     mk::build_submat(alnMat, mk::MAT_BLOSUM62, 2.0f, 0.0f);
+    // a stream of its own: g_stream carries the prefilter of the batch in flight
+    hipStream_t up = g_uploadStream ? g_uploadStream : g_stream;
+    hipStream_t callerStream = t_stream;
+    t_stream = up;                               // (the timing events follow the calling thread's stream)
+    const int callerLane = mk::scratch_lane();
+    mk::set_scratch_lane(UPLOAD_LANE);           // ... and scratch buffers of its own (launch_derive's)
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; };
     const uint64_t total = offsets[n];
     if (devResidues) {
         ok(q->dRes.alloc(total));
-        if (e == hipSuccess && total) ok(hipMemcpyAsync(q->dRes.p, devResidues, total, hipMemcpyDeviceToDevice, g_stream));
+        if (e == hipSuccess && total) ok(hipMemcpyAsync(q->dRes.p, devResidues, total, hipMemcpyDeviceToDevice, up));
     } else {
-        ok(q->dRes.upload(residues, total));
+        ok(q->dRes.upload(residues, total, up));
     }
-    ok(q->dOff.upload(offsets, n + 1));
+    ok(q->dOff.upload(offsets, n + 1, up));
     ok(q->dKmerThr.alloc(total));
     ok(q->dCorr.alloc(total));
     ok(q->dBias8.alloc(total));
@@ -795,11 +871,13 @@ static int queries_create(const uint8_t *residues, const uint8_t *devResidues, c
         q->derivedWith = *P;
         ok(mk::launch_derive(q->dRes.p, q->dOff.p, n, total, kmerMat, alnMat,
                              q->kmerSize == 7 ? mk::kmer_threshold_k7(P->sensitivity, P->kmer_score) : mk::kmer_threshold(P->sensitivity, P->kmer_score),
-                             P->comp_bias_corr != 0, P->comp_bias_scale, q->dKmerThr.p, q->dCorr.p, q->dBias8.p, g_stream, q->kmerSize));
+                             P->comp_bias_corr != 0, P->comp_bias_scale, q->dKmerThr.p, q->dCorr.p, q->dBias8.p, up, q->kmerSize));
         timed_end(th);
     }
-    ok(hipStreamSynchronize(g_stream));
+    ok(hipStreamSynchronize(up));
     timed_flush();
+    t_stream = callerStream;
+    mk::set_scratch_lane(callerLane);
     if (e != hipSuccess) { delete q; return fail(MK_ERR_DEVICE, "query upload failed: %s", hipGetErrorString(e)); }
     *out = q;
     return MK_OK;
@@ -1068,7 +1146,7 @@ int mk_predictions_result(const mk_predictions *p, const mk_prediction **preds, 
 void mk_predictions_destroy(mk_predictions *p) { delete p; }
 size_t mk_format_prediction_exon(char *buf, const mk_prediction *p, const mk_exon *e) { return mk::format_prediction_exon(buf, *p, *e); }
 
-void mk_queries_destroy(mk_queries *q) { delete q; }
+void mk_queries_destroy(mk_queries *q) { if (q && q->job) (void) mk_search_wait(q); delete q; }
 
 // test hook: the per-residue arrays the device derived for this batch (kmer threshold per k-mer start,
 // int8 diagonal correction, int8 SW composition bias)
@@ -1411,159 +1489,249 @@ int mk_align(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     if (!q->havePref) return fail(MK_ERR_ARG, "mk_align: the batch has no prefilter result");
     if ((rc = check_roles(db, q)) != MK_OK) return rc;
     HostTimer htAll("host_align_total");
-    const std::vector<mk::GateEntry> *gatep = nullptr;
-    const mk::AssembleTables *tablesp = nullptr;
+    std::shared_ptr<const ScoreTabs> tabs;
     {
         HostTimer ht("host_gate_table");
-        score_tables(db, q, P->evalue_thr, tablesp, gatep);
+        tabs = score_tables(db, q, P->evalue_thr);
     }
     q->alnOff.assign((size_t) q->n + 1, 0);
     size_t nAln = 0;
-    rc = align_range(db, q, P, 0, q->n, *gatep, tablesp, g_stream, nAln);
+    rc = align_range(db, q, P, 0, q->n, tabs->gate, &tabs->tables, g_stream, nAln);
     if (rc != MK_OK) return rc;
     q->haveAln = true;
     return MK_OK;
 }
 
-// prefilter + align of the batch as ONE pipelined pass (the reference's `search` workflow runs the two modules back to back,
-// blastp.sh:70,85): the prefilter works through the queries in chunks on one stream; every finished chunk is aligned on a
-// second stream by a second host thread while the prefilter is already on the next chunk.  The prefilter is bound by memory
-// latency and the Smith-Waterman kernels by the vector ALUs, so the two stages share the GPU well.  Results are identical to
-// mk_prefilter followed by mk_align.
-int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
-    int rc = ensure_ready();
+// ---- the search engine --------------------------------------------------------------------------------------------------------
+// prefilter + align of a batch as ONE pipelined pass (the reference's `search` workflow runs the two modules back to back,
+// blastp.sh:70,85): the prefilter works through the queries in chunks on one stream; every finished chunk is aligned on another
+// stream by another host thread while the prefilter is already on the next chunk.  The prefilter is bound by memory latency and the
+// Smith-Waterman kernels by the vector ALUs, so the two stages share the GPU.  Results are identical to mk_prefilter followed by mk_align.
+//
+// Round 5: the threads are PERSISTENT and the batches QUEUE (mk_search_begin / mk_search_wait): one prefilter thread takes the batches
+// in the order they were begun, the alignment workers take the chunks of all batches in that order.  The prefilter of batch k + 1 then
+// runs beside the alignment of the last chunks of batch k, and the alignment of its first chunk starts the moment the workers are free:
+// the fill and drain of the two-stage pipeline (2 x 8 ms of a 133 ms query shard, profiles/r04_shard_sweep.txt) are paid once per run,
+// not once per batch.  mk_search = begin + wait.
+struct SearchJob {
+    mk_targetdb *db = nullptr; mk_queries *q = nullptr; mk_params P;
+    std::shared_ptr<const ScoreTabs> tabs;
+    int hostThreads = 1;                                 // OpenMP threads of the caller (mk_init sizes them): split between the stages
+    uint32_t pushed = 0, turn = 0;                       // chunks handed over; the chunk whose alignments are appended next
+    int outstanding = 0;                                 // chunks queued or being aligned
+    bool prefilterDone = false, finished = false;
+    int rc = MK_OK; std::string err;
+    size_t nAln = 0;
+    double tStart = 0;
+};
+
+namespace {
+
+struct SearchEngine {
+    struct Item { SearchJob *job; uint32_t seq, q0, q1; };
+    std::mutex m; std::condition_variable cv;
+    std::deque<SearchJob *> batches;                     // begun, not yet through the prefilter
+    std::deque<Item> items;                              // finished prefilter chunks of all batches, in order
+    int unfinished = 0;                                  // batches begun whose results are not complete yet
+    bool started = false;
+    int nWorkers = 3;
+};
+SearchEngine *g_engine = nullptr;                        // never destroyed: its threads sleep on the condition variable until the process ends
+std::once_flag g_engineOnce;
+
+void engine_finish_locked(SearchEngine &E, SearchJob *job) {      // (E.m held) prefilter done and no chunk outstanding
+    if (job->finished || !job->prefilterDone || job->outstanding != 0) return;
+    job->finished = true;
+    E.unfinished--;
+    mk::host_stat("host_search_total", mk::ScopedHost::now_ms() - job->tStart);
+}
+
+void engine_prefilter_thread(SearchEngine *Ep) {
+    SearchEngine &E = *Ep;
+    (void) hipSetDevice(g_device);
+    kmp_set_blocktime(0);
+    for (;;) {
+        SearchJob *job;
+        {
+            std::unique_lock<std::mutex> lk(E.m);
+            E.cv.wait(lk, [&] { return !E.batches.empty(); });
+            job = E.batches.front(); E.batches.pop_front();
+        }
+        mk_targetdb *db = job->db; mk_queries *q = job->q; const mk_params *P = &job->P;
+        job->tStart = mk::ScopedHost::now_ms();
+        const int half = std::max(1, job->hostThreads / (1 + E.nWorkers));
+        omp_set_num_threads(half);
+        int rc = match_kmer_size(db, q);
+        std::string err = rc != MK_OK ? g_err : std::string();
+        static const int profilePipe = (int) mk::knob_long("MK_SEARCH_PROFILE_PIPELINE", 1);
+        if (rc == MK_OK) {
+            HostTimer ht("host_gate_table");       // the per-length score tables of the batch (cached per database and query lengths)
+            job->tabs = score_tables(db, q, P->evalue_thr);
+        }
+        q->alnOff.assign((size_t) q->n + 1, 0);
+        mk::PrefilterHooks hooks;
+        // chunks of 262 144 queries, the first ones smaller (65 536, 131 072: the alignment stage starts when the first chunk is done).  Measured on
+        // config 2 (profiles/r03_search_tuning.txt): 131 072-query chunks 1.095 s per step, 262 144 with the ramp 0.99 s -- the position and reverse
+        // passes are launches per tile configuration and chunk, and short launches beside the persistent prefilter workgroups run at a third of
+        // their speed.  A shard of that batch (1/8 of it on an 8-GPU node: 251 k queries) would be three chunks, with next to nothing for the two
+        // stages to overlap: the chunk follows the batch -- the largest power of two below a sixth of it, 65 536 at least (32 768-query chunks are
+        // too many short launches beside the persistent workgroups: profiles/r04_shard_sweep.txt)
+        {
+            uint32_t lim = 1u << 18;
+            while (lim > (1u << 16) && (uint64_t) lim * 6 > (uint64_t) q->n) lim >>= 1;
+            hooks.max_chunk_queries = lim;
+        }
+        hooks.chunk_ramp = true;
+        hooks.co_resident = true;
+        hooks.t_masked_host = [db]() { return masked_host(db); };
+        q->pfStats = mk::PrefilterStats();
+        hooks.stats = &q->pfStats;
+        if (q->isProfile) hooks.max_chunk_queries = (uint32_t) std::max(64L, mk::knob_long("MK_SEARCH_PROFILE_CHUNK", 8192));
+        if (const char *e = mk::knob("MK_SEARCH_CHUNK_QUERIES")) hooks.max_chunk_queries = (uint32_t) std::max(1024L, atol(e));
+        if (const char *e = mk::knob("MK_SEARCH_CHUNK_RAMP")) hooks.chunk_ramp = atoi(e) != 0;
+        // the last chunk can be dealt out in pieces: its alignment is the tail of the pass and every worker takes a share of it
+        static const int tailPieces = (int) std::max(1L, mk::knob_long("MK_ALIGN_TAIL_PIECES", 1));
+        const bool backToBack = q->isProfile && !profilePipe;        // MK_SEARCH_PROFILE_PIPELINE=0: the whole batch is one chunk for the alignment stage
+        hooks.on_chunk = [&](uint32_t a, uint32_t b) {
+            if (backToBack && b != q->n) return;
+            if (backToBack) a = 0;
+            {
+                std::lock_guard<std::mutex> lk(E.m);
+                const uint32_t pieces = (b == q->n && b - a >= 4096u) ? (uint32_t) tailPieces : 1u;
+                for (uint32_t k = 0; k < pieces; k++) {
+                    const uint32_t lo = a + (uint32_t) ((uint64_t) (b - a) * k / pieces), hi = a + (uint32_t) ((uint64_t) (b - a) * (k + 1) / pieces);
+                    if (hi > lo) { E.items.push_back(SearchEngine::Item{job, job->pushed++, lo, hi}); job->outstanding++; }
+                }
+            }
+            E.cv.notify_all();
+        };
+        hooks.before_grow = [&]() {                                // the result block moves: nobody may be reading it
+            std::unique_lock<std::mutex> lk(E.m);
+            E.cv.wait(lk, [&] { return job->outstanding == 0; });
+        };
+        if (rc == MK_OK) {
+            HostTimer ht("host_prefilter_total");
+            const int binCount = mk::bin_count_for(db->n, P->host_l2_bytes);
+            rc = mk::run_prefilter(prefilter_view(db, q), q->off, q->res, nullptr, db->off, *P, binCount, g_stream, q->hits, q->nHits, q->hitOff, err,
+                                   timed_begin, timed_end, timed_set, hooks);
+        }
+        timed_flush();
+        {
+            std::lock_guard<std::mutex> lk(E.m);
+            if (rc != MK_OK && job->rc == MK_OK) { job->rc = rc; job->err = err; }
+            job->prefilterDone = true;
+            engine_finish_locked(E, job);
+        }
+        E.cv.notify_all();
+    }
+}
+
+// the alignment stage: MK_ALIGN_WORKERS host threads, each with a stream and scratch buffers of its own, take the chunks in turn -- the
+// position and reverse passes of one chunk (short launches, slow beside persistent workgroups) then run beside the forward pass of the
+// next one instead of in front of it.  Results are appended in chunk order.  Three workers since the position / reverse passes became
+// short (profiles/r04_sw_early_exit.txt: 926 -> 910 ms per step against two; the same within the noise before).
+void engine_align_thread(SearchEngine *Ep, int w) {
+    SearchEngine &E = *Ep;
+    t_stream = g_alignStreams[w];
+    mk::set_scratch_lane(w);
+    (void) hipSetDevice(g_device);
+    kmp_set_blocktime(0);
+    for (;;) {
+        SearchEngine::Item it;
+        {
+            std::unique_lock<std::mutex> lk(E.m);
+            E.cv.wait(lk, [&] { return !E.items.empty(); });
+            it = E.items.front(); E.items.pop_front();
+        }
+        SearchJob *job = it.job;
+        omp_set_num_threads(std::max(1, job->hostThreads / (1 + E.nWorkers)));
+        int r = MK_OK;
+        const auto wait_turn = [&]() {
+            std::unique_lock<std::mutex> lk(E.m);
+            E.cv.wait(lk, [&] { return job->turn == it.seq; });
+        };
+        bool healthy;
+        { std::lock_guard<std::mutex> lk(E.m); healthy = job->rc == MK_OK; }
+        if (healthy) {
+            HostTimer ht("host_align_total");
+            r = align_range(job->db, job->q, &job->P, it.q0, it.q1, job->tabs->gate, &job->tabs->tables, g_alignStreams[w], job->nAln, wait_turn);
+        }
+        wait_turn();
+        {
+            std::lock_guard<std::mutex> lk(E.m);
+            if (r != MK_OK && job->rc == MK_OK) { job->rc = r; job->err = g_err; }
+            job->outstanding--;
+            job->turn = it.seq + 1;
+            engine_finish_locked(E, job);
+        }
+        E.cv.notify_all();
+    }
+}
+
+SearchEngine &engine() {
+    std::call_once(g_engineOnce, [] {
+        g_engine = new SearchEngine();
+        g_engine->nWorkers = std::min(MAX_ALIGN_WORKERS, std::max(1, (int) mk::knob_long("MK_ALIGN_WORKERS", 3)));
+        std::thread(engine_prefilter_thread, g_engine).detach();
+        for (int w = 0; w < g_engine->nWorkers; w++) std::thread(engine_align_thread, g_engine, w).detach();
+        g_engine->started = true;
+    });
+    return *g_engine;
+}
+
+// every batch begun so far has its results complete (not necessarily collected): what the blocking entry points wait for before they
+// use the library's streams and scratch buffers themselves
+void engine_drain_if_running() {
+    if (!g_engine) return;
+    std::unique_lock<std::mutex> lk(g_engine->m);
+    g_engine->cv.wait(lk, [&] { return g_engine->unfinished == 0; });
+}
+
+}  // namespace
+
+int mk_search_begin(mk_targetdb *db, mk_queries *q, const mk_params *P) {
+    int rc = ensure_ready(false);
     if (rc) return rc;
     if (!db || !q || !P) return fail(MK_ERR_ARG, "null argument");
+    if (q->job) return fail(MK_ERR_ARG, "mk_search_begin: a search of this batch is in flight (mk_search_wait collects it)");
     if ((rc = check_indexed(db, "mk_search")) != MK_OK) return rc;
     if ((rc = check_roles(db, q)) != MK_OK) return rc;
-    if ((rc = match_kmer_size(db, q)) != MK_OK) return rc;
-    static const int profilePipe = (int) mk::knob_long("MK_SEARCH_PROFILE_PIPELINE", 1);
-    // profile queries (the inverted search of BASELINE config 4) take the pipeline too since round 3: 1.34 -> 1.20 s per config-4 pass
-    // (MK_SEARCH_PROFILE_PIPELINE=0: the two stages back to back)
-    if (q->isProfile && !profilePipe) {
-        if ((rc = mk_prefilter(db, q, P)) != MK_OK) return rc;
-        return mk_align(db, q, P);
-    }
-    HostTimer htAll("host_search_total");
-    const std::vector<mk::GateEntry> *gatep = nullptr;
-    const mk::AssembleTables *tablesp = nullptr;
-    q->alnOff.assign((size_t) q->n + 1, 0);
+    SearchJob *job = new SearchJob();
+    job->db = db; job->q = q; job->P = *P;
+    job->hostThreads = omp_get_max_threads();
     q->havePref = false; q->haveAln = false;
-
-    struct Item { uint32_t seq, q0, q1; };
-    struct Pipe {
-        std::mutex m; std::condition_variable cv;
-        std::deque<Item> items;                              // finished prefilter chunks [q0, q1), numbered
-        bool done = false;
-        int busy = 0;
-        uint32_t pushed = 0, turn = 0;                       // chunks handed over; the chunk whose alignments are appended next
-        int rc = MK_OK; std::string err;
-    } pipe;
-    size_t nAln = 0;
-    const int hostThreads = omp_get_max_threads();
-    // the alignment stage: MK_ALIGN_WORKERS host threads, each with a stream and scratch buffers of its own, take the chunks in turn --
-    // the position and reverse passes of one chunk (short launches, slow beside persistent workgroups) then run beside the
-    // forward pass of the next one instead of in front of it.  Results are appended in chunk order.  Three workers since the position /
-    // reverse passes became short (profiles/r04_sw_early_exit.txt: 926 -> 910 ms per step against two; the same within the noise before).
-    static const int nWorkers = std::min(MAX_ALIGN_WORKERS, std::max(1, (int) mk::knob_long("MK_ALIGN_WORKERS", 3)));
-    const int half = std::max(1, hostThreads / (1 + nWorkers));
-    {   // the per-length score tables of the batch (cached per database and query lengths)
-        HostTimer ht("host_gate_table");
-        score_tables(db, q, P->evalue_thr, tablesp, gatep);
-    }
-    const auto worker = [&](int w) {
-        t_stream = g_alignStreams[w];
-        mk::set_scratch_lane(w);
-        (void) hipSetDevice(g_device);
-        kmp_set_blocktime(0);
-        omp_set_num_threads(half);
-        for (;;) {
-            Item it;
-            {
-                std::unique_lock<std::mutex> lk(pipe.m);
-                pipe.cv.wait(lk, [&] { return !pipe.items.empty() || pipe.done; });
-                if (pipe.items.empty()) break;
-                it = pipe.items.front(); pipe.items.pop_front();
-                pipe.busy++;
-            }
-            int r = MK_OK;
-            const auto wait_turn = [&]() {
-                std::unique_lock<std::mutex> lk(pipe.m);
-                pipe.cv.wait(lk, [&] { return pipe.turn == it.seq; });
-            };
-            bool healthy;
-            { std::lock_guard<std::mutex> lk(pipe.m); healthy = pipe.rc == MK_OK; }
-            if (healthy) {
-                HostTimer ht("host_align_total");
-                r = align_range(db, q, P, it.q0, it.q1, *gatep, tablesp, g_alignStreams[w], nAln, wait_turn);
-            }
-            wait_turn();
-            {
-                std::lock_guard<std::mutex> lk(pipe.m);
-                if (r != MK_OK && pipe.rc == MK_OK) { pipe.rc = r; pipe.err = g_err; }
-                pipe.busy--;
-                pipe.turn = it.seq + 1;
-            }
-            pipe.cv.notify_all();
-        }
-    };
-    std::vector<std::thread> consumers;
-    for (int w = 0; w < nWorkers; w++) consumers.emplace_back(worker, w);
-    mk::PrefilterHooks hooks;
-    // chunks of 262 144 queries, the first ones smaller (65 536, 131 072: the alignment stage starts when the first chunk is done).  Measured on
-    // config 2 (profiles/r03_search_tuning.txt): 131 072-query chunks 1.095 s per step, 262 144 with the ramp 0.99 s -- the position and reverse
-    // passes are one launch per tile configuration and chunk, and short launches beside the persistent prefilter workgroups run at a third of
-    // their speed
-    hooks.max_chunk_queries = 1u << 18;
-    // ... of a full 2.0 M-query batch.  A shard of that batch (1/8 of it on an 8-GPU node: 251 k queries) would be three chunks, with next to
-    // nothing for the two stages to overlap: the chunk follows the batch -- the largest power of two below a sixth of it, 65 536 at least
-    // (32 768-query chunks are too many short launches beside the persistent workgroups: profiles/r04_shard_sweep.txt)
+    q->job = job;
+    SearchEngine &E = engine();
     {
-        uint32_t lim = 1u << 18;
-        while (lim > (1u << 16) && (uint64_t) lim * 6 > (uint64_t) q->n) lim >>= 1;
-        hooks.max_chunk_queries = lim;
+        std::lock_guard<std::mutex> lk(E.m);
+        E.batches.push_back(job);
+        E.unfinished++;
     }
-    hooks.chunk_ramp = true;
-    hooks.co_resident = true;
-    hooks.t_masked_host = [db]() { return masked_host(db); };
-    q->pfStats = mk::PrefilterStats();
-    hooks.stats = &q->pfStats;
-    if (q->isProfile) hooks.max_chunk_queries = (uint32_t) std::max(64L, mk::knob_long("MK_SEARCH_PROFILE_CHUNK", 8192));
-    if (const char *e = mk::knob("MK_SEARCH_CHUNK_QUERIES")) hooks.max_chunk_queries = (uint32_t) std::max(1024L, atol(e));
-    if (const char *e = mk::knob("MK_SEARCH_CHUNK_RAMP")) hooks.chunk_ramp = atoi(e) != 0;
-    // the last chunk is dealt out in pieces: its alignment is the tail of the pass and every worker takes a share of it
-    static const int tailPieces = (int) std::max(1L, mk::knob_long("MK_ALIGN_TAIL_PIECES", 1));
-    hooks.on_chunk = [&](uint32_t a, uint32_t b) {
-        {
-            std::lock_guard<std::mutex> lk(pipe.m);
-            const uint32_t pieces = (b == q->n && b - a >= 4096u) ? (uint32_t) tailPieces : 1u;
-            for (uint32_t k = 0; k < pieces; k++) {
-                const uint32_t lo = a + (uint32_t) ((uint64_t) (b - a) * k / pieces), hi = a + (uint32_t) ((uint64_t) (b - a) * (k + 1) / pieces);
-                if (hi > lo) pipe.items.push_back(Item{pipe.pushed++, lo, hi});
-            }
-        }
-        pipe.cv.notify_all();
-    };
-    hooks.before_grow = [&]() {                                // the result block moves: nobody may be reading it
-        std::unique_lock<std::mutex> lk(pipe.m);
-        pipe.cv.wait(lk, [&] { return pipe.items.empty() && pipe.busy == 0; });
-    };
-    std::string err;
-    const int binCount = mk::bin_count_for(db->n, P->host_l2_bytes);
-    omp_set_num_threads(half);
-    {
-        HostTimer ht("host_prefilter_total");
-        rc = mk::run_prefilter(prefilter_view(db, q), q->off, q->res, nullptr, db->off, *P, binCount, g_stream, q->hits, q->nHits, q->hitOff, err,
-                               timed_begin, timed_end, timed_set, hooks);
-    }
-    omp_set_num_threads(hostThreads);
-    timed_flush();
-    { std::lock_guard<std::mutex> lk(pipe.m); pipe.done = true; if (rc != MK_OK && pipe.rc == MK_OK) { pipe.rc = rc; pipe.err = err; } }
-    pipe.cv.notify_all();
-    for (std::thread &t : consumers) t.join();
-    if (pipe.rc != MK_OK) return fail(pipe.rc, "%s", pipe.err.c_str());
-    q->havePref = true; q->haveAln = true;
+    E.cv.notify_all();
     return MK_OK;
+}
+
+int mk_search_wait(mk_queries *q) {
+    if (!q) return fail(MK_ERR_ARG, "null argument");
+    SearchJob *job = q->job;
+    if (!job) return fail(MK_ERR_ARG, "mk_search_wait: no search of this batch is in flight");
+    SearchEngine &E = engine();
+    {
+        std::unique_lock<std::mutex> lk(E.m);
+        E.cv.wait(lk, [&] { return job->finished; });
+    }
+    const int rc = job->rc;
+    if (rc != MK_OK) g_err = job->err;
+    else { q->havePref = true; q->haveAln = true; }
+    q->job = nullptr;
+    delete job;
+    return rc;
+}
+
+int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
+    const int rc = mk_search_begin(db, q, P);
+    if (rc != MK_OK) return rc;
+    return mk_search_wait(q);
 }
 
 int mk_align_result(const mk_queries *q, const mk_alignment **alns, const uint64_t **offsets) {

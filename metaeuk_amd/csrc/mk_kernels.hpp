@@ -152,6 +152,7 @@ void *dev_scratch(const char *name, size_t bytes);          // nullptr on alloca
 void *pinned_scratch(const char *name, size_t bytes);
 void scratch_release_all();
 void set_scratch_lane(int lane);                            // of the calling thread: lane > 0 gets buffers of its own under the same names (a second worker of one stage)
+int scratch_lane();
 
 // Pinned host block holding a batch's results (prefilter hits / alignments).  Blocks come from a small pool and
 // go back to it when the batch handle dies: the next batch writes into already-mapped, already-pinned pages

@@ -1,0 +1,111 @@
+"""mk_search_begin / mk_search_wait (round 5): batches queued behind each other return exactly what the blocking mk_search returns --
+the reference has no notion of a caller's batches (Prefiltering::runSplit and Alignment::run loop over ALL queries of the DB,
+Prefiltering.cpp:817-886, Alignment.cpp:312-514), so the result of a query must not depend on what is in flight around it."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _blocks(api, res, n):
+    (hits, hoff), (alns, aoff) = res
+    return [(api.format_hits(hits, int(hoff[i]), int(hoff[i + 1])), api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1]))) for i in range(n)]
+
+
+def test_queued_batches_equal_the_blocking_search_and_the_oracle(gpu_api, tmp_path):
+    api = gpu_api
+    from metaeuk_amd import synth
+    targets, queries = synth.make_workload(30, 400, seed=23)
+    params = api.default_params()
+    db = api.TargetDB(targets, params)
+    # three batches of DIFFERENT query lengths (the score tables of the alignment stage are snapshots per set of lengths: a batch in flight
+    # keeps its own while the next one extends them), the middle one tiny, the last one with an empty query
+    third = len(queries) // 3
+    short = [q for q in queries if len(q) <= 40][:200]
+    batches = [queries[:third], short[:7], queries[third:2 * third] + [""] + queries[2 * third:]]
+    want = []
+    for b in batches:
+        q = api.Queries(b, params)
+        want.append(_blocks(api, api.search(db, q), len(b)))
+        q.close()
+    # all three in flight at once, collected in order
+    qs = [api.Queries(b, params) for b in batches]
+    for q in qs:
+        api.search_begin(db, q)
+    got = [_blocks(api, api.search_wait(q), len(b)) for q, b in zip(qs, batches)]
+    assert got == want
+    # begin the next while the previous one is collected (the loop of bench.py), twice over
+    for rnd in range(2):
+        pending, out = None, []
+        for b in batches:
+            q = api.Queries(b, params)
+            api.search_begin(db, q)
+            if pending is not None:
+                out.append(_blocks(api, api.search_wait(pending[0]), len(pending[1])))
+                pending[0].close()
+            pending = (q, b)
+        out.append(_blocks(api, api.search_wait(pending[0]), len(pending[1])))
+        pending[0].close()
+        assert out == want, "round %d" % rnd
+    # ... and the oracle on the first batch
+    opref, oaln = oracle.run_pipeline(targets, batches[0], str(tmp_path), extra=["--l2", str(params.host_l2_bytes)])
+    assert [w[0] for w in want[0]] == opref
+    assert [w[1] for w in want[0]] == oaln
+    for q in qs:
+        q.close()
+
+
+def test_blocking_calls_and_destruction_while_a_search_is_in_flight(gpu_api):
+    api = gpu_api
+    from metaeuk_amd import synth
+    targets, queries = synth.make_workload(20, 300, seed=29)
+    params = api.default_params()
+    db = api.TargetDB(targets, params)
+    q1 = api.Queries(queries, params)
+    ref = _blocks(api, api.search(db, q1), len(queries))
+    qa, qb = api.Queries(queries, params), api.Queries(queries[:50], params)
+    api.search_begin(db, qa)
+    # a blocking entry point first lets the search in flight finish; the queued batch stays collectable afterwards
+    hb, ob = api.prefilter(db, qb)
+    assert [api.format_hits(hb, int(ob[i]), int(ob[i + 1])) for i in range(50)] == [r[0] for r in ref[:50]]
+    assert _blocks(api, api.search_wait(qa), len(queries)) == ref
+    # waiting twice, or for a batch that was never begun, is an error -- not a hang
+    with pytest.raises(Exception):
+        api.search_wait(qa)
+    with pytest.raises(Exception):
+        api.search_wait(qb)
+    # beginning a batch twice is refused; destroying a batch in flight waits for it
+    api.search_begin(db, qa)
+    with pytest.raises(Exception):
+        api.search_begin(db, qa)
+    qa.close()
+    api.search_begin(db, qb)
+    qb.close()
+    q1.close()
+    db.close()
+
+
+def test_queued_searches_against_two_databases(gpu_api):
+    """batches queued against different databases: each is searched against its own (the sizing memo and the score tables follow the database)"""
+    api = gpu_api
+    from metaeuk_amd import synth
+    targets, queries = synth.make_workload(10, 200, seed=31)
+    params = api.default_params()
+    db = api.TargetDB(targets, params)
+    q_ok = api.Queries(queries, params)
+    ref = _blocks(api, api.search(db, q_ok), len(queries))
+    small = api.TargetDB(targets[:20], params)          # its hits name targets < 20 only; the big database's name up to 199
+    qa, qb, qc = api.Queries(queries, params), api.Queries(queries, params), api.Queries(queries, params)
+    api.search_begin(db, qa)
+    api.search_begin(small, qb)
+    api.search_begin(db, qc)
+    assert _blocks(api, api.search_wait(qa), len(queries)) == ref
+    (hits_b, hoff_b), _ = api.search_wait(qb)
+    assert int(hoff_b[-1]) == 0 or int(np.array(hits_b["seq_id"]).max()) < 20
+    assert _blocks(api, api.search_wait(qc), len(queries)) == ref
+    for x in (qa, qb, qc, q_ok):
+        x.close()
+    small.close()
+    db.close()

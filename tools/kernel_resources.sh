@@ -8,7 +8,7 @@ LL=/opt/rocm/lib/llvm/bin
 $LL/llvm-objcopy -O binary --only-section=.hip_fatbin $OBJ $T/fat.bin
 $LL/clang-offload-bundler --unbundle --type=o --input=$T/fat.bin --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$T/dev.o
 $LL/llvm-readelf --notes $T/dev.o | awk '
-/\.lds_size:/ {lds=$2} /\.name:/ {name=$2} /\.private_segment_fixed_size:/ {scr=$2} /\.sgpr_count:/ {sg=$2} /\.vgpr_count:/ {vg=$2}
-/\.agpr_count:/ {ag=$2} /\.vgpr_spill_count:/ {sp=$2; printf "vgpr %-4s agpr %-3s sgpr %-4s lds(static) %-6s scratch %-5s spills %-3s %s\n", vg, ag, sg, lds, scr, sp, name}' | while read l; do
+/\.lds_size:/ {lds=$NF} /\.name:/ {name=$NF} /\.private_segment_fixed_size:/ {scr=$NF} /\.sgpr_count:/ {sg=$NF} /\.vgpr_count:/ {vg=$NF}
+/\.agpr_count:/ {ag=$NF} /\.vgpr_spill_count:/ {sp=$NF; printf "vgpr %-4s agpr %-3s sgpr %-4s lds(static) %-6s scratch %-5s spills %-3s %s\n", vg, ag, sg, lds, scr, sp, name}' | while read l; do
   n=$(echo "$l" | awk '{print $NF}'); echo "${l% *} $(echo $n | c++filt | sed 's/(anonymous namespace):://; s/mk:://g; s/(.*//')"; done | grep -E "$FILTER"
 rm -rf $T

@@ -20,7 +20,8 @@ def run(contigs, steps, chunk):
                                    "--cpu-sample", "0", "--config4-profiles", "0"], env=env, stderr=subprocess.DEVNULL).decode().strip().splitlines()[-1]
     d = json.loads(out)
     host = {k: round(v / d["steps"], 1) for k, v in d["kernels_ms"].items() if k.startswith("host_") or k.startswith("wait_")}
-    return d["ms_per_step"], d["value"], int(d["config"]["workload"].split("(")[1].split(" ")[0]), host
+    blocking = (d.get("blocking") or {}).get("ms_per_step")
+    return d["ms_per_step"], d["value"], int(d["config"]["workload"].split("(")[1].split(" ")[0]), host, blocking
 
 
 def main():
@@ -30,13 +31,14 @@ def main():
     a = ap.parse_args()
     for chunk in [int(x) for x in a.chunks.split(",")]:
         print("# chunk schedule: %s" % ("library default (a function of the batch size, mk_abi.cpp: mk_search)" if not chunk else "MK_SEARCH_CHUNK_QUERIES=%d" % chunk))
-        print("# ranks  contigs/rank  fragments/rank  ms_per_step  fragments/s(rank)  implied node fragments/s  implied efficiency   host phases (ms/step)")
-        base = None
+        print("# ranks  contigs/rank  fragments/rank  ms_per_step  fragments/s(rank)  implied node fragments/s  implied efficiency  | blocking mk_search: ms_per_step  implied efficiency |  host phases (ms/step)")
+        base = base_b = None
         for n in (1, 2, 4, 8):
-            ms, fps, nq, host = run(10000 // n, a.steps, chunk)
+            ms, fps, nq, host, blk = run(10000 // n, a.steps, chunk)
             if base is None:
-                base = ms
-            print("  %d      %6d        %8d       %8.1f      %10.0f          %10.0f            %.3f          %s" % (n, 10000 // n, nq, ms, fps, fps * n, base / (n * ms), host), flush=True)
+                base, base_b = ms, blk
+            print("  %d      %6d        %8d       %8.1f      %10.0f          %10.0f            %.3f          |  %8s  %6s  |  %s" % (
+                n, 10000 // n, nq, ms, fps, fps * n, base / (n * ms), "%.1f" % blk if blk else "-", "%.3f" % (base_b / (n * blk)) if blk and base_b else "-", host), flush=True)
 
 
 if __name__ == "__main__":
