@@ -298,19 +298,6 @@ typedef struct { const char *name; double ms; uint64_t launches; double alg_byte
 int mk_kernel_stats(mk_kernel_stat *out, int cap);
 void mk_kernel_stats_reset(void);
 
-/* ---- test and bench support (host code): the seeded generator of the synthetic workload of SURVEY.md 8(d) at database sizes the Python
- * generator cannot reach.  Families of ten proteins (founder of 150 .. 600 residues from the Robinson background, member j = the founder
- * with every residue redrawn with probability 0.05 (1 + j)); residues = NULL: only offsets[n + 1] and *total are filled. */
-int mk_synth_targets(uint64_t n_targets, uint64_t seed, uint8_t *residues, uint64_t cap, uint64_t *offsets, uint64_t *total);
-/* query fragments cut out of the targets ("planted homologs"): fragment k = min_len .. max_len residues of a random target, every residue
- * redrawn with probability mutation_rate; every random_every-th fragment is pure background (0: none).  source[k] = the target it came
- * from (0xFFFFFFFF: background).  residues = NULL: only offsets, source and *total. */
-int mk_synth_fragments(uint64_t n_fragments, uint64_t seed, const uint8_t *target_residues, const uint64_t *target_offsets, uint64_t n_targets,
-                       double mutation_rate, uint32_t min_len, uint32_t max_len, uint64_t random_every, uint8_t *residues, uint64_t cap,
-                       uint64_t *offsets, uint32_t *source, uint64_t *total);
-/* residue codes -> an MMseqs2 sequence DB in memory: data[total + 2 n] = "SEQ\n\0" entries, rows of its .index (key = position) */
-int mk_synth_seqdb(const uint8_t *residues, const uint64_t *offsets, uint64_t n, char *data, uint32_t *keys, uint64_t *data_offsets, uint32_t *lengths);
-
 /* ---- formatting: QueryMatcher::prefilterHitToBuffer (QueryMatcher.h:118-130),
  * Matcher::resultToBuffer (Matcher.cpp:280-327) ---- */
 size_t mk_format_hit(char *buf, uint32_t db_key, int32_t score, uint16_t diagonal);

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", f) for f in ("mk_host.cpp", "mk_exons.cpp", "mk_indexfile.cpp", "mk_abi.cpp", "mk_sw.hip", "mk_align.hip", "mk_prefilter.hip", "mk_derive.hip", "mk_profile.hip", "mk_kmer7.hip", "mk_orf.hip", "mk_index.hip", "mk_synth.cpp", "mk_cli.cpp")]
 HDR = [os.path.join(HERE, "csrc", f) for f in ("mk_host.hpp", "mk_kernels.hpp", "mk_prefilter.hpp", "mk_align.hpp", "mk_dbio.hpp", "mk_enum.hpp", "mk_profile.hpp", "mk_kmer7.hpp", "mk_orf.hpp", "mk_exons.hpp", "mk_indexfile.hpp", "mk_index.hpp", "mk_segsort.hpp")] + [
-    os.path.join(HERE, "..", "include", "metaeuk_amd.h"), os.path.join(HERE, "data", "matrices.inc")]
+    os.path.join(HERE, "..", "include", "metaeuk_amd.h"), os.path.join(HERE, "..", "include", "metaeuk_amd_debug.h"), os.path.join(HERE, "data", "matrices.inc")]
 LIB = os.path.join(HERE, "lib", "libmetaeuk_amd.so")
 BIN = os.path.join(HERE, "lib", "metaeuk-amd")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fopenmp", "-ffp-contract=off",

@@ -2,7 +2,7 @@
 // One process drives one GPU (mk_init); all device work goes through one HIP stream owned by the
 // library.  There is NO CPU fallback for the kernels: without a usable HIP device every compute
 // entry point fails with MK_ERR_DEVICE.
-#include "../../include/metaeuk_amd.h"
+#include "../../include/metaeuk_amd_debug.h"
 #include "mk_align.hpp"
 #include "mk_host.hpp"
 #include "mk_kernels.hpp"
@@ -1668,7 +1668,7 @@ void engine_align_thread(SearchEngine *Ep, int w) {
     }
 }
 
-SearchEngine &engine() {
+SearchEngine *engine_ptr() {
     std::call_once(g_engineOnce, [] {
         g_engine = new SearchEngine();
         g_engine->nWorkers = std::min(MAX_ALIGN_WORKERS, std::max(1, (int) mk::knob_long("MK_ALIGN_WORKERS", 3)));
@@ -1676,7 +1676,7 @@ SearchEngine &engine() {
         for (int w = 0; w < g_engine->nWorkers; w++) std::thread(engine_align_thread, g_engine, w).detach();
         g_engine->started = true;
     });
-    return *g_engine;
+    return g_engine;
 }
 
 // every batch begun so far has its results complete (not necessarily collected): what the blocking entry points wait for before they
@@ -1701,7 +1701,7 @@ int mk_search_begin(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     job->hostThreads = omp_get_max_threads();
     q->havePref = false; q->haveAln = false;
     q->job = job;
-    SearchEngine &E = engine();
+    SearchEngine &E = *engine_ptr();
     {
         std::lock_guard<std::mutex> lk(E.m);
         E.batches.push_back(job);
@@ -1715,7 +1715,7 @@ int mk_search_wait(mk_queries *q) {
     if (!q) return fail(MK_ERR_ARG, "null argument");
     SearchJob *job = q->job;
     if (!job) return fail(MK_ERR_ARG, "mk_search_wait: no search of this batch is in flight");
-    SearchEngine &E = engine();
+    SearchEngine &E = *engine_ptr();
     {
         std::unique_lock<std::mutex> lk(E.m);
         E.cv.wait(lk, [&] { return job->finished; });

@@ -530,6 +530,8 @@ struct AlignShapes {
     uint32_t persistentBlocks[SW_NCFG];      // persistent score pass: one-wave workgroups per tile configuration
     uint32_t unitsPerBlock = 0;              // MK_SW_UNITS_PER_BLOCK: short-lived workgroups instead of the persistent launch
     int knownForce = -1, knownWaves = 12, narrowForce = -1;
+    bool multiLaunch = true;                 // MK_SW_MULTI=0: the position / reverse passes as one launch per tile configuration behind a host round trip (rounds 1-4)
+    uint32_t multiPerCu[3] = {24, 12, 12};   // MK_SW_MULTI_WAVES: one-wave workgroups per CU of the three register classes (<= 64, 96 .. 256, >= 384 rows)
     bool earlyExit = true;                   // MK_SW_EARLY_EXIT=0: the position / reverse passes run every column of their jobs (no bound from the score
                                              // pass, no stop at the known score)
 };
@@ -560,6 +562,11 @@ static const AlignShapes &align_shapes() {
         S.knownWaves = (int) std::max(1L, knob_long("MK_SW_KNOWN_WAVES", 12));
         S.narrowForce = (int) knob_long("MK_SW_NARROW", -1);
         S.earlyExit = knob_long("MK_SW_EARLY_EXIT", 1) != 0;
+        S.multiLaunch = knob_long("MK_SW_MULTI", 1) != 0;
+        if (const char *e = knob("MK_SW_MULTI_WAVES")) {
+            int k = 0;
+            for (const char *p = e; *p && k < 3; k++) { S.multiPerCu[k] = (uint32_t) std::max(1, atoi(p)); while (*p && *p != ',') p++; if (*p == ',') p++; }
+        }
     });
     return S;
 }
@@ -582,6 +589,34 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
     hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, keys, n, dCursor, order);
     te(th);
     ACHK(hipGetLastError());
+    // One persistent launch per register class, the tile configurations' bounds read on the device (launch_sw_multi): no copy-back, no host
+    // synchronisation, 3 launches instead of up to 10 per pass.  Not for queries beyond the largest tile (row tiles need a border whose size
+    // follows the bounds) and not where the packed known-score kernel is preferred (the stage alone on the GPU: mk_align).
+    const bool knownPreferred = knownScore && !V.q_prof && (S.knownForce >= 0 ? S.knownForce != 0 : !V.co_resident);
+    if (S.multiLaunch && !knownPreferred && V.max_q_len <= (uint32_t) sw_cfg_rows(SW_NCFG - 1)) {
+        uint32_t *dCnt = (uint32_t *) dev_scratch("align_multicounters", 64);
+        ANULL(dCnt);
+        ACHK(hipMemsetAsync(dCnt, 0, 64, stream));
+        SwLaunch L;
+        L.q_res = V.q_res; L.q_bias8 = V.q_bias8; L.q_prof = V.q_prof; L.t_res = V.t_res; L.mat = V.mat_aln;
+        L.jobs = jobs; L.out = out; L.n_jobs = n; L.order = order;
+        L.boundary = nullptr; L.boundary_stride = 0; L.boundary_job0 = 0;
+        L.wave_start = nullptr; L.n_waves = 0; L.work_counter = nullptr; L.persistent_blocks = 0; L.units_per_block = 0;
+        L.known_score = S.earlyExit ? knownScore : nullptr;
+        L.gap_open = P.gap_open; L.gap_extend = P.gap_extend;
+        static const char *clsName[3] = {"rows32_64", "rows96_256", "rows384_1024"};
+        static const int clsFirst[3] = {0, 3, 7};
+        for (int k = 2; k >= 0; k--) {                         // the long DPs first: they are the tail otherwise
+            char nm[64];
+            snprintf(nm, sizeof(nm), "%s_%s", tag, clsName[k]);
+            th = tb(nm, 0, 0);
+            if (handles) handles[clsFirst[k]] = th;
+            const uint32_t units = (n + 3u) / 4u + (uint32_t) SW_NCFG;          // upper bound of the units of the class
+            ACHK(launch_sw_multi(L, dBounds, dCnt + k, k, std::min(units, (uint32_t) S.cus * S.multiPerCu[k]), stream));
+            te(th);
+        }
+        return MK_OK;
+    }
     ACHK(hipMemcpyAsync(hb, dBounds, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     ACHK(sync_wait(stream, "wait_align"));
     for (int c = 0; c < SW_NCFG; c++) {
@@ -694,7 +729,16 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const uint64_t
     return MK_OK;
 }
 
-int scratch_lane();
+// a timing handle at tile configuration c stands for the configurations from c up to the next handle (one launch per register class covers
+// several; with one launch per configuration the ones in between are empty)
+static void set_range_work(const int *handles, const unsigned long long *work /* [2 * cfg]: bytes, [2 * cfg + 1]: cells */, timed_set_fn ts) {
+    for (int c = 0; c < SW_NCFG; c++) {
+        if (handles[c] < 0) continue;
+        double bytes = 0, cells = 0;
+        for (int k = c; k < SW_NCFG && (k == c || handles[k] < 0); k++) { bytes += (double) work[2 * k]; cells += (double) work[2 * k + 1]; }
+        ts(handles[c], bytes, cells);
+    }
+}
 
 int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hit *hitsHost, uint64_t nPairs,
                      const std::vector<GateEntry> &gate, const mk_params &P, hipStream_t stream,
@@ -770,7 +814,7 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hi
     int hPos[SW_NCFG];
     rc = run_sorted_sw(V, P, dPosJobs, dPosOut, dKeys, dHist, dOrder, nRev, "sw_pos", stream, err, tb, te, hPos, dPosScore);
     if (rc != MK_OK) return rc;
-    for (int c = 0; c < SW_NCFG; c++) if (hPos[c] >= 0) ts(hPos[c], (double) hPosWork[2 * c], (double) hPosWork[2 * c + 1]);
+    set_range_work(hPos, hPosWork, ts);
     hipLaunchKernelGGL(rev_jobs_kernel, dim3((nRev + 255) / 256), dim3(256), 0, stream, dPosJobs, dPosOut, dRevPair, dOut, nRev, dRevJobs, dKeys, dHist, dCount + 2);   // (bin_scan cleared the histogram)
     ACHK(hipGetLastError());
     rc = run_sorted_sw(V, P, dRevJobs, dRevOut, dKeys, dHist, dOrder, nRev, "sw_rev", stream, err, tb, te, hRev, dPosScore);    // (rev job r = survivor r: same score)
@@ -863,7 +907,7 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hi
     if (assemble) assemble->done = assembled;
     if (assembled) {
         unsigned long long *hWork = (unsigned long long *) pinned_scratch("asm_revwork_h", 2 * SW_NCFG * 8);
-        for (int c = 0; c < SW_NCFG; c++) if (hRev[c] >= 0) ts(hRev[c], (double) hWork[2 * c], (double) hWork[2 * c + 1]);
+        set_range_work(hRev, hWork, ts);
         return MK_OK;
     }
     ACHK(hipMemcpyAsync(hRaw, dRaw, (size_t) nRev * sizeof(AlnRaw), hipMemcpyDeviceToHost, stream));
@@ -889,7 +933,9 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hi
 #pragma omp critical(mk_align_revwork)
             for (int c = 0; c < 2 * SW_NCFG; c++) w[c] += wl[c];
         }
-        for (int c = 0; c < SW_NCFG; c++) if (hRev[c] >= 0) ts(hRev[c], w[2 * c], w[2 * c + 1]);
+        unsigned long long wi[2 * SW_NCFG];
+        for (int c = 0; c < 2 * SW_NCFG; c++) wi[c] = (unsigned long long) w[c];
+        set_range_work(hRev, wi, ts);
     }
     return MK_OK;
 }

@@ -500,7 +500,8 @@ constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 // of a (query, target) pair stay contiguous, which is all the back end needs.
 struct StreamArgs {
     PrefilterDeviceView V;
-    const uint32_t *queries; uint32_t n_own;          // (global) query ids assigned to this tier ...
+    const uint32_t *queries;                          // (global) query ids assigned to the tiers by tier_scatter_kernel, tier after tier ...
+    const uint32_t *own_first, *own_count;            // ... this tier's share of that list (device: nothing of the assignment passes through the host)
     const uint32_t *prev_list;                        // ... followed by the queries that overflowed the next smaller tier (chunk-local ids,
     const uint32_t *prev_count;                       //     count known on the device only)
     uint32_t q_first;
@@ -568,7 +569,8 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, w = tid / WAVE, lane = tid & (WAVE - 1);
     uint64_t *region = A.pool + (size_t) blockIdx.x * CAPH;
-    const uint32_t nItems = A.n_own + A.prev_count[0];
+    const uint32_t nOwn = A.own_count[0], ownFirst = A.own_first[0];
+    const uint32_t nItems = nOwn + A.prev_count[0];
     constexpr uint64_t TMASK = (1ull << REC_T_BITS) - 1ull;
     const auto survives = [&](uint64_t rec) -> bool {
         const uint32_t hb = ((uint32_t) (rec & TMASK) * 2654435761u) >> (32 - LOG_MBITS);
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
         __syncthreads();
         const uint32_t item = sItem;
         if (item >= nItems) break;
-        const uint32_t q = item < A.n_own ? A.queries[item] : A.q_first + A.prev_list[item - A.n_own];
+        const uint32_t q = item < nOwn ? A.queries[ownFirst + item] : A.q_first + A.prev_list[item - nOwn];
         const uint64_t qs = A.V.q_off[q];
         const int L = (int) (A.V.q_off[q + 1] - qs);
         const int nStart = L >= 10 ? L - 9 : 0;
@@ -852,6 +854,94 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
 // Tiers of the per-query path: region size (hits), waves per workgroup, most k-mer starts, persistent workgroups per CU.  The two
 // small tiers are one-wave workgroups (no barriers; most ORF fragments are tiny), the larger ones spread the k-mer starts of a
 // query over 4 / 16 waves.
+
+// ---- the tier of every query of a chunk, on the device (round 5) -----------------------------------------------------------------
+// Rounds 2-4 brought the per-query k-mer counts of kmer_count_kernel to the host, chose the tiers there and sent the lists back: 21 ms of
+// host time per config-2 step and a synchronisation per chunk between two launches of the prefilter's own chain -- which is the critical
+// path of the queued search.  Now: classify (tier from the expected index hits and the number of k-mer starts, 64 size classes inside a
+// tier so that the persistent workgroups take the large queries first) -> scan of the (tier, class) histogram -> scatter.  The kernels
+// of the tiers read their share of the list from `info`; the host sees the counts and the global path's list after the tier kernels,
+// with the counters it waits for anyway.
+constexpr int TIER_CLS = 64, TIER_BINS = (4 + 1) * TIER_CLS;       // tier 4 = the global path's list (chunk-local ids)
+struct TierPlan {
+    const uint32_t *qk; const uint64_t *q_off; uint32_t q0, nqc;
+    double limit[4]; int maxpos[4]; int nTiersUsed, firstTier;
+    uint32_t *hist, *cursor;        // [TIER_BINS]
+    uint16_t *bin;                  // per query: tier * 64 + class, 0xFFFF = no k-mer, no hits
+    uint32_t *list, *fallback;      // [nqc] each
+    uint32_t *info;                 // [0..3] first entry of tier t in `list` [4..7] its count [8] queries for the global path
+    double *kpp;                    // statistics: sum over the queries of k-mers / length (null: not wanted)
+};
+__global__ __launch_bounds__(256) void tier_classify_kernel(TierPlan T) {
+    helper_prio();
+    __shared__ uint32_t sHist[TIER_BINS];
+    for (int k = threadIdx.x; k < TIER_BINS; k += 256) sHist[k] = 0;
+    __syncthreads();
+    const uint32_t ql = blockIdx.x * 256u + threadIdx.x;
+    double v = 0.0;
+    if (ql < T.nqc) {
+        const uint32_t kmers = T.qk[ql];
+        const uint32_t L = (uint32_t) (T.q_off[(size_t) T.q0 + ql + 1] - T.q_off[(size_t) T.q0 + ql]);
+        uint32_t bin = 0xFFFFu;
+        if (kmers != 0u) {
+            const double km = (double) kmers;
+            const int npos = (int) L - 9;
+            int t = 0;
+            while (t < T.nTiersUsed && (km > T.limit[t] || npos > T.maxpos[t])) t++;
+            if (t == T.nTiersUsed || t < T.firstTier) bin = 4u * TIER_CLS;
+            else {
+                const double scale = 63.0 / (T.limit[t] > 1.0 ? T.limit[t] : 1.0);
+                const int c = (int) (km * scale);
+                bin = (uint32_t) t * TIER_CLS + (uint32_t) (63 - (c < 63 ? c : 63));
+            }
+            atomicAdd(&sHist[bin], 1u);
+            if (L) v = km / (double) L;
+        }
+        T.bin[ql] = (uint16_t) bin;
+    }
+    if (T.kpp) {
+#pragma unroll
+        for (int d = WAVE / 2; d >= 1; d >>= 1) {
+            const uint32_t lo = (uint32_t) __shfl_xor((int) (uint32_t) __double_as_longlong(v), d, WAVE), hi = (uint32_t) __shfl_xor((int) (uint32_t) (__double_as_longlong(v) >> 32), d, WAVE);
+            v += __longlong_as_double((long long) (((uint64_t) hi << 32) | lo));
+        }
+        if ((threadIdx.x & (WAVE - 1)) == 0 && v != 0.0) atomicAdd(T.kpp, v);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < TIER_BINS; k += 256) if (sHist[k]) atomicAdd(&T.hist[k], sHist[k]);
+}
+__global__ __launch_bounds__(64) void tier_scan_kernel(TierPlan T) {       // one wave: 320 bins, five per lane
+    helper_prio();
+    const int lane = threadIdx.x;
+    uint32_t h[5], pre[5], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) { h[k] = T.hist[lane * 5 + k]; sum += h[k]; T.hist[lane * 5 + k] = 0; }      // (cleared for the next chunk)
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) { const uint32_t o = (uint32_t) __shfl_up((int) incl, d, WAVE); if (lane >= d) incl += o; }
+    uint32_t run = incl - sum;
+#pragma unroll
+    for (int k = 0; k < 5; k++) { pre[k] = run; T.cursor[lane * 5 + k] = run; run += h[k]; }
+    // first entry of tier t = the prefix at bin 64 t, held by lane (64 t) / 5 in slot (64 t) % 5
+    const uint32_t f0 = (uint32_t) __shfl((int) pre[0], 0, WAVE), f1 = (uint32_t) __shfl((int) pre[4], 12, WAVE), f2 = (uint32_t) __shfl((int) pre[3], 25, WAVE),
+                   f3 = (uint32_t) __shfl((int) pre[2], 38, WAVE), f4 = (uint32_t) __shfl((int) pre[1], 51, WAVE);
+    const uint32_t total = (uint32_t) __shfl((int) incl, WAVE - 1, WAVE);
+    if (lane == 0) {
+        T.info[0] = f0; T.info[1] = f1; T.info[2] = f2; T.info[3] = f3;
+        T.info[4] = f1 - f0; T.info[5] = f2 - f1; T.info[6] = f3 - f2; T.info[7] = f4 - f3; T.info[8] = total - f4;
+        T.info[9] = f4;                                                    // base of the global path's cursor (tier_scatter_kernel subtracts it)
+    }
+}
+__global__ __launch_bounds__(256) void tier_scatter_kernel(TierPlan T) {
+    helper_prio();
+    const uint32_t ql = blockIdx.x * 256u + threadIdx.x;
+    if (ql >= T.nqc) return;
+    const uint32_t bin = T.bin[ql];
+    if (bin == 0xFFFFu) return;
+    const uint32_t at = atomicAdd(&T.cursor[bin], 1u);
+    if (bin >= 4u * TIER_CLS) T.fallback[at - T.info[9]] = ql; else T.list[at] = T.q0 + ql;
+}
+
 struct FusedTier { int cap; int waves; int maxpos; int wgPerCu; };
 constexpr int N_TIERS = 4;
 // production tiers, then a miniature set (MK_PREFILTER_TIERS=tiny) with which small test inputs exercise every
@@ -2404,93 +2494,67 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             X.statsKmers = hooks.stats && fallbackKmerStats;
         } else if (useFused) {
             // ---- A. fused kernels, one launch per LDS tier; the tier follows the expected number of index hits
-            std::vector<uint32_t> lists[N_TIERS];
-            size_t nListed = 0;
-            uint32_t *hList = nullptr, *dList = nullptr, *dOvf = nullptr;
-            // exact similar-k-mer count per query -> expected index hits -> LDS tier
+            // similar-k-mer count per query (exact, kmer_count_kernel) -> expected index hits -> tier, all on the device (tier_*_kernel): nothing
+            // between the count and the tiers' launches waits for the host
+            constexpr uint32_t LIST_PEEK = 4096;                                 // entries of the global path's two lists fetched with the counters
             uint16_t *dPosCost = (uint16_t *) dev_scratch("pf_poscost", (size_t) (qOff[q1] - qOff[q0] + 16) * 2);
             PNULL(dPosCost);
             uint32_t *dQK = (uint32_t *) dev_scratch("pf_qkmers", (size_t) nqc * 4);
-            uint32_t *hQK = (uint32_t *) pinned_scratch("pf_qkmers_h", (size_t) nqc * 4);
-            PNULL(dQK); PNULL(hQK);
+            uint32_t *dList = (uint32_t *) dev_scratch("pf_flist", (size_t) nqc * 4), *dFallback = (uint32_t *) dev_scratch("pf_ffallback", (size_t) nqc * 4);
+            uint32_t *dOvf = (uint32_t *) dev_scratch("pf_fovf", (size_t) nqc * 4 * N_TIERS);
+            uint32_t *dTier = (uint32_t *) dev_scratch("pf_tierplan", (2 * TIER_BINS + 16 + 4) * 4);      // hist, cursor, info, statistics (a double)
+            uint16_t *dBin = (uint16_t *) dev_scratch("pf_tierbin", (size_t) nqc * 2);
+            uint32_t *hTier = (uint32_t *) pinned_scratch("pf_tierplan_h", (16 + 4 + 2 * LIST_PEEK) * 4);
+            PNULL(dQK); PNULL(dList); PNULL(dFallback); PNULL(dOvf); PNULL(dTier); PNULL(dBin); PNULL(hTier);
+            uint32_t *dInfo = dTier + 2 * TIER_BINS;
+            double *dKpp = reinterpret_cast<double *>(dInfo + 16);
+            double limit[N_TIERS];                                      // most k-mers a query may have to be tried in tier t
+            for (int t = 0; t < N_TIERS; t++) {
+                const double hpk = g_memo.hitsPerKmer[t] > 0 ? g_memo.hitsPerKmer[t] : std::max(0.05, (double) V.n_entries / 64.0e6);
+                limit[t] = (double) tiers[t].cap / (hpk * g_memo.margin[t]);
+            }
             {
                 const uint64_t pb = qOff[q0], pe = qOff[q1];
                 PCHK(hipMemsetAsync(dQK, 0, (size_t) nqc * 4, stream));
+                PCHK(hipMemsetAsync(dTier, 0, (2 * TIER_BINS + 16 + 4) * 4, stream));
                 if (pe > pb) {
                     const int th = tb("kmer_count", 5.0 * (double) (pe - pb), 0);
                     hipLaunchKernelGGL(kmer_count_kernel, dim3((unsigned) (((pe - pb + WAVE - 1) / WAVE + 3) / 4)), dim3(256), 0, stream, V, pb, pe, q0, dQK, dPosCost);
                     te(th);
                     PCHK(hipGetLastError());
                 }
-                PCHK(hipMemcpyAsync(hQK, dQK, (size_t) nqc * 4, hipMemcpyDeviceToHost, stream));
-                PCHK(sync_wait(stream, "wait_prefilter"));
+                TierPlan T;
+                T.qk = dQK; T.q_off = V.q_off; T.q0 = q0; T.nqc = nqc;
+                for (int t = 0; t < N_TIERS; t++) { T.limit[t] = limit[t]; T.maxpos[t] = tiers[t].maxpos; }
+                T.nTiersUsed = nTiersUsed; T.firstTier = firstTier;
+                T.hist = dTier; T.cursor = dTier + TIER_BINS; T.bin = dBin; T.list = dList; T.fallback = dFallback; T.info = dInfo;
+                T.kpp = hooks.stats ? dKpp : nullptr;
+                const int th = tb("tier_assign", 10.0 * nqc, 0);
+                hipLaunchKernelGGL(tier_classify_kernel, dim3((nqc + 255) / 256), dim3(256), 0, stream, T);
+                hipLaunchKernelGGL(tier_scan_kernel, dim3(1), dim3(64), 0, stream, T);
+                hipLaunchKernelGGL(tier_scatter_kernel, dim3((nqc + 255) / 256), dim3(256), 0, stream, T);
+                te(th);
+                PCHK(hipGetLastError());
             }
-            if (hooks.stats) {
-                double sum = 0;
-                for (uint32_t ql = 0; ql < nqc; ql++) {
-                    const uint64_t L = qOff[(size_t) q0 + ql + 1] - qOff[(size_t) q0 + ql];
-                    if (L) sum += (double) hQK[ql] / (double) L;
-                }
-                cs.kmers_per_pos += sum;
-            }
-            {
-                ScopedHost sh("host_prefilter_tiers");
-                double limit[N_TIERS];                                      // most k-mers a query may have to be tried in tier t
-                for (int t = 0; t < N_TIERS; t++) {
-                    const double hpk = g_memo.hitsPerKmer[t] > 0 ? g_memo.hitsPerKmer[t] : std::max(0.05, (double) V.n_entries / 64.0e6);
-                    limit[t] = (double) tiers[t].cap / (hpk * g_memo.margin[t]);
-                }
-                for (uint32_t ql = 0; ql < nqc; ql++) {
-                    if (hQK[ql] == 0) continue;                             // no k-mer: no hits
-                    const double km = (double) hQK[ql];
-                    const int npos = (int) (qOff[(size_t) q0 + ql + 1] - qOff[(size_t) q0 + ql]) - 9;
-                    int t = 0;
-                    while (t < nTiersUsed && (km > limit[t] || npos > tiers[t].maxpos)) t++;
-                    if (t == nTiersUsed || t < firstTier) fallback.push_back(ql); else lists[t].push_back(q0 + ql);
-                }
-                // streamed tiers: persistent workgroups pull from the list -- largest queries first, so that no workgroup starts a
-                // long query when the others are about to run dry
-                for (int t = 0; t < N_TIERS; t++)
-                    if (lists[t].size() > 1) {       // (counting sort over 64 size classes: the order only has to be roughly by size)
-                        const double scale = 63.0 / std::max(1.0, limit[t]);
-                        size_t cnt[65] = {0};
-                        std::vector<uint8_t> cls(lists[t].size());
-                        for (size_t k = 0; k < lists[t].size(); k++) { cls[k] = (uint8_t) (63 - std::min(63, (int) ((double) hQK[lists[t][k] - q0] * scale))); cnt[cls[k] + 1]++; }
-                        for (int c = 0; c < 64; c++) cnt[c + 1] += cnt[c];
-                        std::vector<uint32_t> ordered(lists[t].size());
-                        for (size_t k = 0; k < lists[t].size(); k++) ordered[cnt[cls[k]]++] = lists[t][k];
-                        lists[t].swap(ordered);
-                    }
-                for (int t = 0; t < N_TIERS; t++) nListed += lists[t].size();
-                hList = (uint32_t *) pinned_scratch("pf_flist_h", std::max<size_t>(nListed, 1) * 4);
-                dList = (uint32_t *) dev_scratch("pf_flist", std::max<size_t>(nListed, 1) * 4);
-                dOvf = (uint32_t *) dev_scratch("pf_fovf", (size_t) nqc * 4 * N_TIERS);
-                PNULL(hList); PNULL(dList); PNULL(dOvf);
-                size_t at = 0;
-                for (int t = 0; t < N_TIERS; t++) { if (!lists[t].empty()) std::memcpy(hList + at, lists[t].data(), lists[t].size() * 4); at += lists[t].size(); }
-            }
-            PCHK(hipMemcpyAsync(dList, hList, nListed * 4, hipMemcpyHostToDevice, stream));
             PCHK(hipMemsetAsync(dCounters, 0, 64, stream));
             PCHK(hipMemsetAsync(dFTotals, 0, 16 * 8 * N_TIERS, stream));
             int thFused[N_TIERS];
-            size_t at = 0, lower = 0;                                       // lower: queries of the smaller tiers (bound on what can overflow into this one)
             for (int t = 0; t < N_TIERS; t++) {
                 thFused[t] = -1;
-                const size_t grid = t < nTiersUsed ? lists[t].size() + lower : 0;
-                if (grid > 0) {
-                    // streamed tier: persistent workgroups, each with its own hit region
+                if (t < nTiersUsed) {
+                    // streamed tier: persistent workgroups, each with its own hit region; how many queries it has is known on the device only
                     static int cus = 0;
                     if (!cus) { int dev = 0; (void) hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
                     int perCu = tiers[t].wgPerCu;
                     if (hooks.co_resident) perCu = std::max(1, tiers[t].waves * perCu > 16 ? 16 / tiers[t].waves : perCu);   // at most 16 waves per CU
                     if (const char *e = knob(t == 2 ? "MK_PREFILTER_WG_PER_CU_A" : (t == 3 ? "MK_PREFILTER_WG_PER_CU_B" : "MK_PREFILTER_WG_PER_CU_S"))) perCu = std::max(1, atoi(e));
-                    const unsigned launch = (unsigned) std::min<size_t>(grid, (size_t) cus * perCu);
+                    const unsigned launch = (unsigned) std::min<size_t>((size_t) nqc, (size_t) cus * perCu);     // (a chunk has at most nqc queries for any tier)
                     char pn[32];
                     snprintf(pn, sizeof(pn), "pf_pool%d", t);
                     StreamArgs A;
                     A.pool = (uint64_t *) dev_scratch(pn, (size_t) launch * tiers[t].cap * 8);
                     PNULL(A.pool);
-                    A.V = V; A.queries = dList + at; A.n_own = (uint32_t) lists[t].size(); A.q_first = q0;
+                    A.V = V; A.queries = dList; A.own_first = dInfo + t; A.own_count = dInfo + 4 + t; A.q_first = q0;
                     A.prev_list = t > 0 ? dOvf + (size_t) (t - 1) * nqc : nullptr; A.prev_count = t > 0 ? dCounters + 4 + (t - 1) : dCounters + 15;
                     A.C = C; A.cand_cap = CAND_CAP; A.counters = dCounters;
                     A.overflow_list = dOvf + (size_t) t * nqc; A.overflow_count = dCounters + 4 + t; A.totals = dFTotals + 16 * t;
@@ -2503,18 +2567,28 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                     te(thFused[t]);
                     PCHK(hipGetLastError());
                 }
-                at += lists[t].size(); lower += lists[t].size();
             }
+            // the counts of the assignment, the statistics and the head of the two lists the global path takes (its own and what the largest tier
+            // could not hold) come with the counters: one synchronisation per chunk here
+            const uint32_t peek = std::min(nqc, LIST_PEEK);
+            PCHK(hipMemcpyAsync(hTier, dInfo, (16 + 4) * 4, hipMemcpyDeviceToHost, stream));
+            PCHK(hipMemcpyAsync(hTier + 20, dFallback, (size_t) peek * 4, hipMemcpyDeviceToHost, stream));
+            PCHK(hipMemcpyAsync(hTier + 20 + LIST_PEEK, dOvf + (size_t) (nTiersUsed - 1) * nqc, (size_t) peek * 4, hipMemcpyDeviceToHost, stream));
             PCHK(hipMemcpyAsync(hCounters, dCounters, 64, hipMemcpyDeviceToHost, stream));
             PCHK(hipMemcpyAsync(hFTotals + 16, dFTotals, 16 * 8 * N_TIERS, hipMemcpyDeviceToHost, stream));
             PCHK(sync_wait(stream, "wait_prefilter"));
+            const uint32_t *hInfo = hTier;
+            size_t listed[N_TIERS];
+            for (int t = 0; t < N_TIERS; t++) listed[t] = hInfo[4 + t];
+            const uint32_t nFallback = hInfo[8];
+            if (hooks.stats) { double sum; std::memcpy(&sum, hTier + 16, 8); cs.kmers_per_pos += sum; }
             for (int k = 0; k < 16; k++) { hFTotals[k] = 0; for (int t = 0; t < N_TIERS; t++) hFTotals[k] += hFTotals[16 * (t + 1) + k]; }
             cs.db_matches += hFTotals[1];
             if (knob("MK_PREFILTER_DEBUG"))
                 for (int t = 0; t < N_TIERS; t++) {
                     const unsigned long long *T = hFTotals + 16 * (t + 1);
                     fprintf(stderr, "[prefilter]   tier %d (%s %d): queries %zu overflowed %llu | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g sort %.3g emit %.3g overflowed %.3g | extra class passes %llu\n",
-                            t, "region", tiers[t].cap, lists[t].size(), T[8], (double) T[0], (double) T[1], (double) T[2], (double) T[3], (double) T[4], (double) T[5], (double) T[6], T[9]);
+                            t, "region", tiers[t].cap, listed[t], T[8], (double) T[0], (double) T[1], (double) T[2], (double) T[3], (double) T[4], (double) T[5], (double) T[6], T[9]);
                 }
             const uint32_t nOvf = hCounters[4 + nTiersUsed - 1];               // what even the largest tier in use could not hold
             if (hCounters[0] > CAND_CAP) rc = RC_CAND_OVERFLOW;
@@ -2529,24 +2603,31 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                     }
                 if (knob("MK_PREFILTER_DEBUG"))
                     fprintf(stderr, "[prefilter] chunk %u..%u: tiers %zu/%zu/%zu/%zu too-long %zu overflow %u | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g (mean wave %.3g) sort %.3g emit %.3g overflowed %.3g | cand %u\n",
-                            q0, q1, lists[0].size(), lists[1].size(), lists[2].size(), lists[3].size(), fallback.size(), nOvf, (double) hFTotals[0], (double) hFTotals[1],
+                            q0, q1, listed[0], listed[1], listed[2], listed[3], (size_t) nFallback, nOvf, (double) hFTotals[0], (double) hFTotals[1],
                             (double) hFTotals[2], (double) hFTotals[3], (double) hFTotals[7], (double) hFTotals[4], (double) hFTotals[5], (double) hFTotals[6], nCand);
                 // per tier: hits per similar k-mer of the queries that fitted, and a safety margin that follows the overflow rate
                 for (int t = 0; t < N_TIERS; t++) {
                     const unsigned long long *T = hFTotals + 16 * (t + 1);
                     if (T[0] > 0) g_memo.hitsPerKmer[t] = std::max(0.01, (double) T[1] / (double) T[0]);
-                    const double tried = (double) lists[t].size() + (t > 0 ? (double) hCounters[4 + t - 1] : 0.0);
+                    const double tried = (double) listed[t] + (t > 0 ? (double) hCounters[4 + t - 1] : 0.0);
                     if (tried >= 256) {
                         const double frac = (double) hCounters[4 + t] / tried;
                         if (frac > 0.04) g_memo.margin[t] = std::min(3.0, g_memo.margin[t] * 1.08);
                         else if (frac < 0.01) g_memo.margin[t] = std::max(1.05, g_memo.margin[t] * 0.98);
                     }
                 }
-                if (nOvf > 0) {
-                    uint32_t *hOvf = (uint32_t *) pinned_scratch("pf_fovf_h", (size_t) nOvf * 4);
-                    PNULL(hOvf);
-                    PCHK(hipMemcpyAsync(hOvf, dOvf + (size_t) (nTiersUsed - 1) * nqc, (size_t) nOvf * 4, hipMemcpyDeviceToHost, stream));
-                    PCHK(sync_wait(stream, "wait_prefilter"));
+                if (nFallback > 0 || nOvf > 0) {
+                    // what the global path takes: the queries no tier was tried for and the ones the largest tier could not hold
+                    const uint32_t *hFb = hTier + 20, *hOvf = hTier + 20 + LIST_PEEK;
+                    if (nFallback > peek || nOvf > peek) {                     // (rare: the lists are longer than what came with the counters)
+                        uint32_t *hMore = (uint32_t *) pinned_scratch("pf_fovf_h", ((size_t) nFallback + nOvf + 2) * 4);
+                        PNULL(hMore);
+                        if (nFallback) PCHK(hipMemcpyAsync(hMore, dFallback, (size_t) nFallback * 4, hipMemcpyDeviceToHost, stream));
+                        if (nOvf) PCHK(hipMemcpyAsync(hMore + nFallback, dOvf + (size_t) (nTiersUsed - 1) * nqc, (size_t) nOvf * 4, hipMemcpyDeviceToHost, stream));
+                        PCHK(sync_wait(stream, "wait_prefilter"));
+                        hFb = hMore; hOvf = hMore + nFallback;
+                    }
+                    fallback.assign(hFb, hFb + nFallback);
                     fallback.insert(fallback.end(), hOvf, hOvf + nOvf);
                     std::sort(fallback.begin(), fallback.end());
                 }

@@ -267,6 +267,77 @@ __global__ __launch_bounds__(BLOCK) void sw_kernel(SwLaunch L) {
     }
 }
 
+// Position / reverse pass of the pipeline as ONE launch per register class (round 5).  The jobs are ordered by (tile configuration, target
+// length class) -- a counting sort on the device -- and `bounds[c]` = first job of tile configuration c stays on the device: nothing of it
+// passes through the host, where rounds 1-4 fetched the bounds, synchronised, and launched one kernel per tile configuration (~ 100 short
+// launches of ~ 6 000 jobs per config-2 step, each behind a host round trip, beside three streams of persistent workgroups).  Persistent
+// one-wave workgroups pull units of 64 / G jobs from a counter, the largest tile configuration of the class first; a unit runs in the lane
+// shape of its tile configuration (sw_unit, own profile per job).  Three classes so that the small tiles keep their occupancy: <= 64 rows
+// (72 VGPRs, 6 KB of LDS per wave), 96 .. 256 rows and >= 384 rows (128 VGPRs, 24.5 KB).
+template <int CLS>
+__global__ __launch_bounds__(64) void sw_multi_kernel(SwLaunch L, const uint32_t *bounds, uint32_t *counter) {
+    if (MK_HELPER_PRIO) __builtin_amdgcn_s_setprio(MK_HELPER_PRIO);
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    __shared__ int8_t sMat[448];
+    for (int k = (int) threadIdx.x; k < 441; k += 64) sMat[k] = L.mat[k];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    constexpr int C0 = CLS == 0 ? 0 : (CLS == 1 ? 3 : 7), C1 = CLS == 0 ? 3 : (CLS == 1 ? 7 : SW_NCFG), NC = C1 - C0;
+    // units of every tile configuration of the class, the largest configuration first
+    uint32_t lo[NC], nj[NC], ub[NC + 1];
+    ub[0] = 0;
+#pragma unroll
+    for (int k = 0; k < NC; k++) {
+        const int c = C1 - 1 - k;
+        lo[k] = bounds[c]; nj[k] = bounds[c + 1] - lo[k];
+        const uint32_t gpb = c >= 9 ? 1u : (c >= 7 ? 2u : 4u);         // 64 / G jobs per wave: G = 64 for 768 / 1024 rows, 32 for 384 / 512, 16 below
+        ub[k + 1] = ub[k] + (nj[k] + gpb - 1u) / gpb;
+    }
+    for (;;) {
+        uint32_t u = 0;
+        if (threadIdx.x == 0) u = atomicAdd(counter, 1u);
+        u = (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
+        if (u >= ub[NC]) break;
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < NC; j++) if (u >= ub[j]) k = j;
+        SwLaunch Lc = L;
+        uint32_t first = 0, base = 0, count = 0;
+#pragma unroll
+        for (int j = 0; j < NC; j++) if (j == k) { first = lo[j]; base = ub[j]; count = nj[j]; }
+        Lc.order = L.order + first; Lc.n_jobs = count;
+        const uint32_t unit = u - base;
+        const int c = C1 - 1 - k;
+        if constexpr (CLS == 0) {
+            if (c == 0) sw_unit<16, 2, 64, false>(Lc, unit, smem, sMat);
+            else sw_unit<16, 4, 64, false>(Lc, unit, smem, sMat);                 // 48 and 64 rows
+        } else if constexpr (CLS == 1) {
+            if (c <= 4) sw_unit<16, 8, 64, false>(Lc, unit, smem, sMat);         // 96 and 128 rows
+            else sw_unit<16, 16, 64, false>(Lc, unit, smem, sMat);               // 192 and 256 rows
+        } else {
+            if (c == 7) sw_unit<32, 12, 64, false>(Lc, unit, smem, sMat);
+            else if (c == 8) sw_unit<32, 16, 64, false>(Lc, unit, smem, sMat);
+            else if (c == 9) sw_unit<64, 12, 64, false>(Lc, unit, smem, sMat);
+            else sw_unit<64, 16, 64, false>(Lc, unit, smem, sMat);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// L.order = the jobs' order by (tile configuration, target length class), bounds = device array of SW_NCFG + 1 first-job indices into it,
+// counter = a zeroed device word; cls 0 / 1 / 2 = tile configurations of <= 64 / 96 .. 256 / >= 384 rows.  Single-tile jobs only (no border).
+hipError_t launch_sw_multi(const SwLaunch &L, const uint32_t *bounds, uint32_t *counter, int cls, uint32_t blocks, hipStream_t stream) {
+    if (!L.order || !bounds || !counter || L.boundary || blocks == 0) return hipErrorInvalidValue;
+    switch (cls) {
+        case 0: hipLaunchKernelGGL((sw_multi_kernel<0>), dim3(blocks), dim3(64), (size_t) 64 * 24 * 4, stream, L, bounds, counter); break;
+        case 1: hipLaunchKernelGGL((sw_multi_kernel<1>), dim3(blocks), dim3(64), (size_t) 64 * 24 * 16, stream, L, bounds, counter); break;
+        case 2: hipLaunchKernelGGL((sw_multi_kernel<2>), dim3(blocks), dim3(64), (size_t) 64 * 24 * 16, stream, L, bounds, counter); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // Score-only forward pass, two DPs per lane group in packed int16 (v_pk_add/max/sub_i16): the low halves of every
 // register belong to one target, the high halves to another; both run against the SAME query (shared-query mode), so

@@ -4,7 +4,7 @@
 // probability 0.05 (1 + j)), and query fragments cut out of known targets and mutated ("planted homologs").  Every family / fragment has
 // its own counter-based random stream (splitmix64 of seed and number -> xoshiro256**), so the bytes depend on the seed alone -- not on the
 // thread count, and they are the same in the build container and on the GPU box.  Host code, no GPU, nothing of the search path.
-#include "../../include/metaeuk_amd.h"
+#include "../../include/metaeuk_amd_debug.h"
 #include <algorithm>
 #include <cstring>
 #include <omp.h>

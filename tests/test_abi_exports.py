@@ -23,6 +23,21 @@ def test_library_exports_every_declared_symbol():
     assert len(_declared()) >= 20
 
 
+def test_every_exported_mk_symbol_is_declared_in_a_header():
+    """the converse: the headers are the contract -- an mk_* symbol in the export table that neither include/metaeuk_amd.h (the drop-in boundary)
+    nor include/metaeuk_amd_debug.h (generator + experiment hook) declares is an undocumented entry point"""
+    import subprocess
+    from metaeuk_amd import build
+    out = subprocess.check_output(["nm", "-D", "--defined-only", build.build()]).decode()
+    exported = {ln.split()[-1] for ln in out.splitlines() if re.search(r" [TW] mk_[a-z0-9_]+$", ln)}
+    assert len(exported) >= 20
+    undeclared = sorted(exported - set(_declared()))
+    assert not undeclared, undeclared
+    # the boundary header itself carries no test-support or experiment entry point
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "metaeuk_amd.h")).read(), flags=re.S)
+    assert not re.findall(r"\b(mk_synth_[a-z0-9_]+|mk_debug_[a-z0-9_]+)\s*\(", txt)
+
+
 def test_no_gpu_means_loud_failure():
     """without a usable HIP device compute entry points fail with MK_ERR_DEVICE instead of falling back"""
     import numpy as np
