@@ -217,6 +217,7 @@ def main():
     ap.add_argument("--two-calls", action="store_true", help="mk_prefilter then mk_align instead of the pipelined mk_search")
     ap.add_argument("--blocking", action="store_true", help="time the blocking mk_search (one batch at a time) as the headline figure instead of the "
                     "queued mk_search_begin / mk_search_wait loop")
+    ap.add_argument("--queue-depth", type=int, default=2, help="batches begun before the oldest one is collected (queued mode)")
     ap.add_argument("--blocking-steps", type=int, default=5, help="steps of the blocking mk_search timed after the headline region and reported beside it "
                     "(`blocking`; 0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=400000, help="queries in the CPU baseline sample (0 = skip)")
@@ -329,15 +330,16 @@ def main():
             for k in range(n):
                 res = step(keep=(keep_last and k == n - 1))
             return res
-        pending = None
+        pending = []
         for k in range(n):
             q = api.Queries.from_codes(q_res, q_off, params)
             api.search_begin(db, q)
-            if pending is not None:
-                collect(pending)
-            pending = q
-        if pending is not None:
-            res = collect(pending, keep=keep_last)
+            pending.append(q)
+            if len(pending) >= max(1, args.queue_depth):
+                collect(pending.pop(0))
+        while pending:
+            q = pending.pop(0)
+            res = collect(q, keep=keep_last and not pending)
         return res
 
     run_steps(args.warmup, False)

@@ -62,8 +62,10 @@ std::map<std::string, StatAcc> g_stats;
 std::mutex g_statsMutex;
 std::vector<std::string> g_statNames;
 hipStream_t g_stream2 = nullptr;                         // alignment stage of mk_search
+hipStream_t g_prefStream2 = nullptr;                     // the search engine's second prefilter thread
 hipStream_t g_uploadStream = nullptr;                    // mk_queries_create: upload + derivation of the NEXT batch beside a search in flight
 constexpr int MAX_ALIGN_WORKERS = 4;
+constexpr int PREFILTER2_LANE = 5;                       // scratch lane of the second prefilter thread (the alignment workers: 0 .. 3)
 constexpr int UPLOAD_LANE = 8;                           // scratch lane of mk_queries_create
 hipStream_t g_alignStreams[MAX_ALIGN_WORKERS] = {};      // [0] = g_stream2; the further workers of the alignment stage
 thread_local hipStream_t t_stream = nullptr;             // stream of the calling thread's stage (null: g_stream)
@@ -427,6 +429,7 @@ int mk_init(int device) {
         if (!g_stream2) HIPCHK(prio ? hipStreamCreateWithPriority(&g_stream2, hipStreamNonBlocking, least) : hipStreamCreateWithFlags(&g_stream2, hipStreamNonBlocking));
         g_alignStreams[0] = g_stream2;
         if (!g_uploadStream) HIPCHK(hipStreamCreateWithFlags(&g_uploadStream, hipStreamNonBlocking));
+        if (!g_prefStream2) HIPCHK(hipStreamCreateWithFlags(&g_prefStream2, hipStreamNonBlocking));
         for (int w = 1; w < MAX_ALIGN_WORKERS; w++)
             if (!g_alignStreams[w]) HIPCHK(prio ? hipStreamCreateWithPriority(&g_alignStreams[w], hipStreamNonBlocking, least) : hipStreamCreateWithFlags(&g_alignStreams[w], hipStreamNonBlocking));
     }
@@ -475,6 +478,8 @@ struct PrebuiltIndex {
 };
 
 static const uint8_t *masked_host(mk_targetdb *db) {
+    static std::mutex m;                                 // (two prefilter threads of the search engine may ask at once)
+    std::lock_guard<std::mutex> lk(m);
     if (!db->maskedHostReady) {
         db->maskedHost.resize(db->off[db->n]);
         if (db->off[db->n] && hipMemcpy(db->maskedHost.data(), db->dMasked.p, db->off[db->n], hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
@@ -1257,8 +1262,8 @@ static int match_kmer_size(const mk_targetdb *db, mk_queries *q) {
     if (q->isProfile) {          // the k-mer starts of a profile batch follow the seed pattern and threshold of the database's k
         const uint64_t total = q->off[q->n];
         HIPCHK(mk::launch_profile_kthr(q->dRes.p, q->dOff.p, q->n, total, db->kmerSize == 7 ? mk::kmer_threshold_profile_k7(P.sensitivity) : mk::kmer_threshold_profile(P.sensitivity),
-                                       db->kmerSize, q->dKmerThr.p, g_stream));
-        HIPCHK(hipStreamSynchronize(g_stream));
+                                       db->kmerSize, q->dKmerThr.p, cur_stream()));
+        HIPCHK(hipStreamSynchronize(cur_stream()));
         q->kmerSize = db->kmerSize;
         return MK_OK;
     }
@@ -1268,8 +1273,8 @@ static int match_kmer_size(const mk_targetdb *db, mk_queries *q) {
     const uint64_t total = q->off[q->n];
     HIPCHK(mk::launch_derive(q->dRes.p, q->dOff.p, q->n, total, kmerMat, alnMat,
                              db->kmerSize == 7 ? mk::kmer_threshold_k7(P.sensitivity, P.kmer_score) : mk::kmer_threshold(P.sensitivity, P.kmer_score),
-                             P.comp_bias_corr != 0, P.comp_bias_scale, q->dKmerThr.p, q->dCorr.p, q->dBias8.p, g_stream, db->kmerSize));
-    HIPCHK(hipStreamSynchronize(g_stream));
+                             P.comp_bias_corr != 0, P.comp_bias_scale, q->dKmerThr.p, q->dCorr.p, q->dBias8.p, cur_stream(), db->kmerSize));
+    HIPCHK(hipStreamSynchronize(cur_stream()));
     q->kmerSize = db->kmerSize;
     return MK_OK;
 }
@@ -1535,6 +1540,10 @@ struct SearchEngine {
     int unfinished = 0;                                  // batches begun whose results are not complete yet
     bool started = false;
     int nWorkers = 3;
+    int nPrefilter = 1;                                  // MK_PREFILTER_THREADS = 2: the prefilters of two batches at once.  Measured and NOT the default
+                                                         // (profiles/r05_search_engine.txt: 923 against 880 ms per config-2 step): the GPU is saturated by one
+                                                         // prefilter chain and the alignment workers, two chains only stretch each other
+    std::mutex tablesMutex;                              // the databases' score-table caches
 };
 SearchEngine *g_engine = nullptr;                        // never destroyed: its threads sleep on the condition variable until the process ends
 std::once_flag g_engineOnce;
@@ -1546,10 +1555,14 @@ void engine_finish_locked(SearchEngine &E, SearchJob *job) {      // (E.m held) 
     mk::host_stat("host_search_total", mk::ScopedHost::now_ms() - job->tStart);
 }
 
-void engine_prefilter_thread(SearchEngine *Ep) {
+void engine_prefilter_thread(SearchEngine *Ep, int idx) {
     SearchEngine &E = *Ep;
     (void) hipSetDevice(g_device);
     kmp_set_blocktime(0);
+    // thread 0 works on the library's first stream with the default scratch lane (what the blocking mk_prefilter uses, which waits for the engine
+    // to drain first); thread 1 has a stream and a lane of its own
+    hipStream_t myStream = idx == 0 ? g_stream : g_prefStream2;
+    if (idx != 0) { t_stream = myStream; mk::set_scratch_lane(PREFILTER2_LANE); }
     for (;;) {
         SearchJob *job;
         {
@@ -1559,13 +1572,14 @@ void engine_prefilter_thread(SearchEngine *Ep) {
         }
         mk_targetdb *db = job->db; mk_queries *q = job->q; const mk_params *P = &job->P;
         job->tStart = mk::ScopedHost::now_ms();
-        const int half = std::max(1, job->hostThreads / (1 + E.nWorkers));
+        const int half = std::max(1, job->hostThreads / (E.nPrefilter + E.nWorkers));
         omp_set_num_threads(half);
         int rc = match_kmer_size(db, q);
         std::string err = rc != MK_OK ? g_err : std::string();
         static const int profilePipe = (int) mk::knob_long("MK_SEARCH_PROFILE_PIPELINE", 1);
         if (rc == MK_OK) {
             HostTimer ht("host_gate_table");       // the per-length score tables of the batch (cached per database and query lengths)
+            std::lock_guard<std::mutex> lk(E.tablesMutex);
             job->tabs = score_tables(db, q, P->evalue_thr);
         }
         q->alnOff.assign((size_t) q->n + 1, 0);
@@ -1612,7 +1626,7 @@ void engine_prefilter_thread(SearchEngine *Ep) {
         if (rc == MK_OK) {
             HostTimer ht("host_prefilter_total");
             const int binCount = mk::bin_count_for(db->n, P->host_l2_bytes);
-            rc = mk::run_prefilter(prefilter_view(db, q), q->off, q->res, nullptr, db->off, *P, binCount, g_stream, q->hits, q->nHits, q->hitOff, err,
+            rc = mk::run_prefilter(prefilter_view(db, q), q->off, q->res, nullptr, db->off, *P, binCount, myStream, q->hits, q->nHits, q->hitOff, err,
                                    timed_begin, timed_end, timed_set, hooks);
         }
         timed_flush();
@@ -1644,7 +1658,7 @@ void engine_align_thread(SearchEngine *Ep, int w) {
             it = E.items.front(); E.items.pop_front();
         }
         SearchJob *job = it.job;
-        omp_set_num_threads(std::max(1, job->hostThreads / (1 + E.nWorkers)));
+        omp_set_num_threads(std::max(1, job->hostThreads / (E.nPrefilter + E.nWorkers)));
         int r = MK_OK;
         const auto wait_turn = [&]() {
             std::unique_lock<std::mutex> lk(E.m);
@@ -1672,7 +1686,8 @@ SearchEngine *engine_ptr() {
     std::call_once(g_engineOnce, [] {
         g_engine = new SearchEngine();
         g_engine->nWorkers = std::min(MAX_ALIGN_WORKERS, std::max(1, (int) mk::knob_long("MK_ALIGN_WORKERS", 3)));
-        std::thread(engine_prefilter_thread, g_engine).detach();
+        g_engine->nPrefilter = std::min(2, std::max(1, (int) mk::knob_long("MK_PREFILTER_THREADS", 1)));
+        for (int k = 0; k < g_engine->nPrefilter; k++) std::thread(engine_prefilter_thread, g_engine, k).detach();
         for (int w = 0; w < g_engine->nWorkers; w++) std::thread(engine_align_thread, g_engine, w).detach();
         g_engine->started = true;
     });

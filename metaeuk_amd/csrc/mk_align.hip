@@ -698,7 +698,7 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const uint64_t
         ACHK(hipGetLastError());
     }
     te(th);
-    for (int c = 0; c < SW_NCFG; c++) {
+    for (int c = SW_NCFG - 1; c >= 0; c--) {                // the tiles of the long queries first: a handful of long DPs per wave, the tail of the pass otherwise
         const uint32_t lo = hb[c], hi = hb[c + 1], wlo = hb[16 + c], whi = hb[16 + c + 1];
         if (hi <= lo || whi <= wlo) continue;
         SwLaunch L;

@@ -48,6 +48,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <type_traits>
 
@@ -1759,6 +1760,7 @@ struct SizingMemo {
     double margin[4] = {1.15, 1.15, 1.15, 1.15};
 };
 SizingMemo g_memo;
+std::mutex g_memoMutex;        // two batches can be in the prefilter at once (the search engine's two prefilter threads): the memo is shared
 
 }  // namespace
 
@@ -2434,8 +2436,12 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     if (hooks.max_tiers > 0) nTiersUsed = std::min(nTiersUsed, hooks.max_tiers);
     int firstTier = 0;                                 // MK_PREFILTER_FIRST_TIER: queries that would fit a smaller tier go to the global path
     if (const char *e = knob("MK_PREFILTER_FIRST_TIER")) firstTier = std::max(0, atoi(e));
-    if (g_memo.entries != (const void *) V.entries || g_memo.nTargets != V.n_targets) { g_memo = SizingMemo(); g_memo.entries = V.entries; g_memo.nTargets = V.n_targets; }
-    double candPerQuery = g_memo.candPerQuery, globalHitsPerPos = 0, wideKmersPerPos = 0;
+    double candPerQuery, globalHitsPerPos = 0, wideKmersPerPos = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_memoMutex);
+        if (g_memo.entries != (const void *) V.entries || g_memo.nTargets != V.n_targets) { g_memo = SizingMemo(); g_memo.entries = V.entries; g_memo.nTargets = V.n_targets; }
+        candPerQuery = g_memo.candPerQuery;
+    }
     static_assert(N_TIERS == 4, "SizingMemo holds four tiers");
     SubMat ungMat;
     build_submat(ungMat, MAT_BLOSUM62, 2.0f, -0.2f);
@@ -2509,9 +2515,12 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             uint32_t *dInfo = dTier + 2 * TIER_BINS;
             double *dKpp = reinterpret_cast<double *>(dInfo + 16);
             double limit[N_TIERS];                                      // most k-mers a query may have to be tried in tier t
-            for (int t = 0; t < N_TIERS; t++) {
-                const double hpk = g_memo.hitsPerKmer[t] > 0 ? g_memo.hitsPerKmer[t] : std::max(0.05, (double) V.n_entries / 64.0e6);
-                limit[t] = (double) tiers[t].cap / (hpk * g_memo.margin[t]);
+            {
+                std::lock_guard<std::mutex> lk(g_memoMutex);
+                for (int t = 0; t < N_TIERS; t++) {
+                    const double hpk = g_memo.hitsPerKmer[t] > 0 ? g_memo.hitsPerKmer[t] : std::max(0.05, (double) V.n_entries / 64.0e6);
+                    limit[t] = (double) tiers[t].cap / (hpk * g_memo.margin[t]);
+                }
             }
             {
                 const uint64_t pb = qOff[q0], pe = qOff[q1];
@@ -2606,14 +2615,17 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                             q0, q1, listed[0], listed[1], listed[2], listed[3], (size_t) nFallback, nOvf, (double) hFTotals[0], (double) hFTotals[1],
                             (double) hFTotals[2], (double) hFTotals[3], (double) hFTotals[7], (double) hFTotals[4], (double) hFTotals[5], (double) hFTotals[6], nCand);
                 // per tier: hits per similar k-mer of the queries that fitted, and a safety margin that follows the overflow rate
-                for (int t = 0; t < N_TIERS; t++) {
-                    const unsigned long long *T = hFTotals + 16 * (t + 1);
-                    if (T[0] > 0) g_memo.hitsPerKmer[t] = std::max(0.01, (double) T[1] / (double) T[0]);
-                    const double tried = (double) listed[t] + (t > 0 ? (double) hCounters[4 + t - 1] : 0.0);
-                    if (tried >= 256) {
-                        const double frac = (double) hCounters[4 + t] / tried;
-                        if (frac > 0.04) g_memo.margin[t] = std::min(3.0, g_memo.margin[t] * 1.08);
-                        else if (frac < 0.01) g_memo.margin[t] = std::max(1.05, g_memo.margin[t] * 0.98);
+                {
+                    std::lock_guard<std::mutex> lkMemo(g_memoMutex);
+                    for (int t = 0; t < N_TIERS; t++) {
+                        const unsigned long long *T = hFTotals + 16 * (t + 1);
+                        if (T[0] > 0) g_memo.hitsPerKmer[t] = std::max(0.01, (double) T[1] / (double) T[0]);
+                        const double tried = (double) listed[t] + (t > 0 ? (double) hCounters[4 + t - 1] : 0.0);
+                        if (tried >= 256) {
+                            const double frac = (double) hCounters[4 + t] / tried;
+                            if (frac > 0.04) g_memo.margin[t] = std::min(3.0, g_memo.margin[t] * 1.08);
+                            else if (frac < 0.01) g_memo.margin[t] = std::max(1.05, g_memo.margin[t] * 0.98);
+                        }
                     }
                 }
                 if (nFallback > 0 || nOvf > 0) {
@@ -2892,7 +2904,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
         }
         q0 = q1;
     }
-    g_memo.candPerQuery = candPerQuery;
+    { std::lock_guard<std::mutex> lk(g_memoMutex); if (g_memo.entries == (const void *) V.entries) g_memo.candPerQuery = candPerQuery; }
     (void) tOff;
     PCHK(sync_wait(stream, "wait_prefilter"));         // the last DMA into the result block
     return MK_OK;
