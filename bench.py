@@ -54,23 +54,30 @@ def pmc_traffic(kernel_name):
     import hashlib
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
     if not cands:
-        return None, None
+        return None, None, None
     art = json.load(open(cands[-1]))
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "metaeuk_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "metaeuk_amd", "csrc", "mk_enum.hpp"))):
         h.update(open(f, "rb").read())
     k = art.get("kernels", {}).get(kernel_name)
     if not k:
-        return None, os.path.basename(cands[-1])
+        return None, os.path.basename(cands[-1]), None
     note = os.path.basename(cands[-1]) + ("" if art.get("build") == h.hexdigest()[:16] else " (taken on an older build of the kernels)")
-    return (k["fetch_bytes"] + k["write_bytes"]) / max(k["launches"], 1), note
+    total = (k["fetch_bytes"] + k["write_bytes"]) / max(k["launches"], 1)
+    dram = None
+    if k.get("read_requests_dram") is not None and k.get("read_requests"):
+        # the share of the requests that is bound for the memory controllers, applied to the bytes (Infinity Cache hits are inside it)
+        rd_share = k["read_requests_dram"] / k["read_requests"]
+        wr_share = (k["write_requests_dram"] / k["write_requests"]) if k.get("write_requests") and k.get("write_requests_dram") is not None else 1.0
+        dram = (k["fetch_bytes"] * rd_share + k["write_bytes"] * wr_share) / max(k["launches"], 1)
+    return total, note, dram
 
 
 def make_inputs(n_contigs, n_targets, seed, rank):
     from metaeuk_amd import synth
     targets, founders = synth.make_targets(n_targets, seed)
     queries = synth.make_queries(n_contigs, founders, seed + 7919 * rank)
-    return targets, queries
+    return targets, queries, founders
 
 
 def pack(codes_list):
@@ -206,6 +213,85 @@ def config4_leg(api, args, params, q_res, q_off, nq):
     return out
 
 
+def e2e_leg(api, args, params, targets, founders, t_res, t_off):
+    """The drop-in as a user meets it: `metaeuk-amd predictexons <contigsDB> <targetsDB> <out> <tmp>` (data/predictexons.sh:42-87: extractorfs ->
+    search = prefilter + align -> resultspercontig + collectoptimalset) as ONE process over MMseqs2 DBs on disk, on the headline workload -- the
+    contigs as nucleotides this time.  Wall clock of the command (process start, DB reads, target masking + index, every stage, DB writes), contigs/s,
+    and the exon sets of a SAMPLE of the contigs against the reference's own chain (oracle/_ref/ref_harness orfs | pipeline | exons: Orf.cpp,
+    the prefilter / align code, collectoptimalset.cpp compiled in place) run on the host cores.  Outside the timed region of the headline figure."""
+    from metaeuk_amd import build, synth
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    out = {"command": "metaeuk-amd predictexons contigsDB targetsDB outDB tmp -s 5.7 (predictexons defaults)", "contigs": args.contigs}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        contigs = synth.make_contigs(args.contigs, founders, args.seed)
+        cstr = ["".join("ACGT"[x] for x in c) for c in contigs] if args.contigs <= 2000 else None
+        lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+        # contigs DB (nucleotides, dbtype 1) and targets DB, data order = key order
+        blobs = [lut[c].tobytes() + b"\n\0" for c in contigs]
+        offs = np.zeros(len(blobs) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(b) for b in blobs], dtype=np.uint64)
+        api.write_seq_db(os.path.join(tmp, "contigs"), (b"".join(blobs), np.arange(len(blobs), dtype=np.uint32), offs[:-1], np.array([len(b) for b in blobs], dtype=np.uint32)), dbtype=1)
+        api.write_seq_db(os.path.join(tmp, "targets"), api.synth_seqdb(t_res, t_off))
+        out["nucleotides"] = int(sum(len(c) for c in contigs))
+        cmd = [build.BIN, "predictexons", os.path.join(tmp, "contigs"), os.path.join(tmp, "targets"), os.path.join(tmp, "calls"), os.path.join(tmp, "tmp"),
+               "-s", "5.7", "--ref-l2-bytes", str(params.host_l2_bytes), "--threads", str(int(api.lib().mk_host_threads())), "--remove-tmp-files", "1"]
+        best = None
+        for rep in range(2):                                     # the second run finds the DB files in the page cache
+            for suffix in ("", ".index", ".dbtype"):
+                if os.path.exists(os.path.join(tmp, "calls" + suffix)):
+                    os.remove(os.path.join(tmp, "calls" + suffix))
+            t0 = time.time()
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            dt = time.time() - t0
+            if r.returncode != 0:
+                raise RuntimeError("metaeuk-amd predictexons failed: " + r.stderr.decode()[-800:])
+            best = dt if best is None else min(best, dt)
+        out.update({"wall_s": round(best, 3), "contigs_per_s": round(args.contigs / best, 1), "runs": 2})
+        data = open(os.path.join(tmp, "calls"), "rb").read()
+        got = {}
+        for line in open(os.path.join(tmp, "calls.index")):
+            k, o, l = line.split("\t")
+            got[int(k)] = data[int(o):int(o) + int(l) - 1].decode()
+        out["contigs_with_predictions"] = sum(1 for v in got.values() if v)
+        out["prediction_lines"] = sum(v.count("\n") for v in got.values())
+        n_s = min(args.e2e_sample, args.contigs)
+        if n_s > 0 and os.path.exists(oracle.REF):
+            t1 = time.time()
+            d = os.path.join(tmp, "ref")
+            os.makedirs(os.path.join(d, "out"))
+            matdir = oracle.write_matrix_files(os.path.join(d, "mat"))
+            with open(os.path.join(d, "t.txt"), "w") as f:
+                f.write("\n".join(synth.codes_to_str(t) for t in targets) + "\n")
+            with open(os.path.join(d, "c.txt"), "w") as f:
+                f.write("\n".join(lut[c].tobytes().decode() for c in contigs[:n_s]) + "\n")
+            subprocess.check_call([oracle.REF, "orfs", os.path.join(d, "c.txt"), os.path.join(d, "orfs.txt")], stdout=subprocess.DEVNULL)
+            with open(os.path.join(d, "q.txt"), "w") as f:
+                for line in open(os.path.join(d, "orfs.txt")):
+                    if not line.startswith(">"):
+                        f.write(line.rstrip("\n").rsplit("\t", 1)[1] + "\n")
+            subprocess.check_call([oracle.REF, "pipeline", matdir, os.path.join(d, "t.txt"), os.path.join(d, "q.txt"), os.path.join(d, "out"),
+                                   "--threads", str(int(api.lib().mk_host_threads()))], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            subprocess.check_call([oracle.REF, "exons", os.path.join(d, "t.txt"), os.path.join(d, "c.txt"), os.path.join(d, "orfs.txt"),
+                                   os.path.join(d, "out", "aln.txt"), os.path.join(d, "exons.txt")], stdout=subprocess.DEVNULL)
+            exp, cur = {}, None
+            for line in open(os.path.join(d, "exons.txt")):
+                if line.startswith(">"):
+                    cur = int(line[1:])
+                    exp[cur] = ""
+                else:
+                    exp[cur] += line
+            bad = [c for c in range(n_s) if got.get(c, "") != exp.get(c, "")]
+            import hashlib
+            dig = lambda dd: hashlib.sha256("".join(">%d\n%s" % (c, dd.get(c, "")) for c in range(n_s)).encode()).hexdigest()
+            out["result_digest"] = {"contigs": n_s, "gpu": dig(got), "cpu": dig(exp), "match": not bad, "differing_contigs": bad[:10],
+                                    "contigs_with_predictions_in_the_sample": sum(1 for c in range(n_s) if exp.get(c)),
+                                    "reference_s": round(time.time() - t1, 1), "reference": "oracle/_ref/ref_harness orfs | pipeline | exons on the first contigs"}
+        else:
+            out["result_digest"] = {"contigs": 0, "match": None}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -228,6 +314,8 @@ def main():
                     "from that one file (mk_targetdb_open_index) instead of masking and indexing its own replica")
     ap.add_argument("--digest-queries", type=int, default=-1, help="queries of the last timed step whose hits and alignments are compared with the reference's own "
                     "run (-1 = all of them, in pieces of --cpu-sample queries outside the timed region; 0 = only the CPU-baseline sample)")
+    ap.add_argument("--e2e-sample", type=int, default=500, help="contigs of the end-to-end leg (`metaeuk-amd predictexons` over DBs on disk, N = 1 only) whose exon sets are "
+                    "compared with the reference's chain; -1 = skip the leg")
     ap.add_argument("--config4-sample", type=int, default=2048, help="profiles of the config-4 leg whose hits and alignments are compared with the reference")
     args = ap.parse_args()
 
@@ -266,7 +354,7 @@ def main():
 
     scaling = args.scaling or ("strong" if world > 1 else "weak")
     t0 = time.time()
-    targets, queries = make_inputs(args.contigs, args.targets, args.seed, rank if scaling == "weak" else 0)
+    targets, queries, founders = make_inputs(args.contigs, args.targets, args.seed, rank if scaling == "weak" else 0)
     if scaling == "strong" and world > 1:
         # BASELINE config 3: the same workload, query-sharded with the reference's residue-balanced rule
         from metaeuk_amd import shard
@@ -389,7 +477,7 @@ def main():
     dom_name, dom = max(kstats.items(), key=lambda kv: kv[1]["ms"]) if kstats else ("none", dict(ms=0, launches=1, alg_bytes=0, cells=0))
     per_launch_ms = dom["ms"] / max(dom["launches"], 1)
     achieved = (dom["alg_bytes"] / max(dom["launches"], 1)) / max(per_launch_ms * 1e-3, 1e-12) / 1e9
-    traffic, traffic_note = pmc_traffic(dom_name)
+    traffic, traffic_note, traffic_dram = pmc_traffic(dom_name)
     line = {
         "metric": "prefilter+align ORF-fragments/sec (hits UNVERIFIED in this run: no CPU reference digest)",
         "value": frag_per_s, "unit": "fragments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -411,12 +499,15 @@ def main():
         # dominant kernel against HBM; `traffic` (PMC FETCH_SIZE + WRITE_SIZE per launch) comes from the rocprofv3 passes kept
         # under profiles/ -- bench.py cannot read PMC counters itself
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_fabric": traffic, "traffic_dram": traffic_dram, "traffic_source": traffic_note,
                      "avg_launch_ms": per_launch_ms, "launches": dom["launches"],
                      "note": "achieved = SURVEY 8(d) algorithmic bytes (16 B per probed k-mer + 6 B per index entry) / launch time; traffic = "
                              "fabric bytes per launch from the L2 request counters (PMC): every 8-byte index probe that misses L2 fetches a "
                              "128-byte line, so the prefilter kernels move ~5x their algorithmic bytes and are bound by HBM line bandwidth "
-                             "(~5 TB/s when they run alone); the Smith-Waterman kernels are vector-ALU bound (valu_roofline)"},
+                             "(~5 TB/s when they run alone); the Smith-Waterman kernels are vector-ALU bound (valu_roofline).  traffic_fabric = traffic; "
+                             "traffic_dram = the part of it bound for the memory controllers (TCC_EA0_*REQ_DRAM; the Infinity Cache is on that side of the fabric "
+                             "and no counter separates its hits).  The bound is the FABRIC's request rate, not DRAM: random 8-byte reads run at 56.8 G/s from a "
+                             "128 MB table that the 256 MB Infinity Cache holds and at 54.4 G/s from 2 GB (profiles/r02_random_probe_rates.txt)"},
         # the Smith-Waterman kernels against the integer vector-ALU issue rate: the cell arithmetic alone (5 lane-ops per cell in the packed
         # score pass, 10 in the int32 passes), not counting the wavefront's hand-over instructions, padding rows or fill / drain steps
         # (denominator: the wall clock of the timed region -- the kernels of the two alignment workers overlap each other and the prefilter's,
@@ -436,6 +527,8 @@ def main():
         # swapresults), reported beside the headline metric and outside its timed region.  DESIGN.md 4.7; parity: tests/test_gpu_profile.py.
         # A failure here is a failure of the run (no blanket except): the leg is part of the reported result.
         line["config4_profile_targets"] = config4_leg(api, args, params, q_res, q_off, nq)
+    if rank == 0 and world == 1 and args.e2e_sample >= 0:
+        line["end_to_end_predictexons"] = e2e_leg(api, args, params, targets, founders, t_res, t_off)
     if rank == 0:
         if world == 1 and args.cpu_sample > 0:
             n_s = min(args.cpu_sample, nq)
@@ -479,6 +572,8 @@ def main():
         verdicts = [line.get("result_digest", {}).get("match")]
         if "config4_profile_targets" in line:
             verdicts.append(line["config4_profile_targets"].get("result_digest", {}).get("match"))
+        if line.get("end_to_end_predictexons", {}).get("result_digest", {}).get("match") is not None:
+            verdicts.append(line["end_to_end_predictexons"]["result_digest"]["match"])
         if any(v is False for v in verdicts):
             line["metric"] = "prefilter+align ORF-fragments/sec (RESULT MISMATCH vs the CPU reference)"
         elif verdicts[0] is True and all(v is True for v in verdicts):

@@ -530,7 +530,9 @@ struct AlignShapes {
     uint32_t persistentBlocks[SW_NCFG];      // persistent score pass: one-wave workgroups per tile configuration
     uint32_t unitsPerBlock = 0;              // MK_SW_UNITS_PER_BLOCK: short-lived workgroups instead of the persistent launch
     int knownForce = -1, knownWaves = 12, narrowForce = -1;
-    bool multiLaunch = true;                 // MK_SW_MULTI=0: the position / reverse passes as one launch per tile configuration behind a host round trip (rounds 1-4)
+    bool fwdLargeFirst = false;              // MK_SW_FWD_LARGE_FIRST=1
+    bool multiLargeFirst = true;             // MK_SW_MULTI_LARGE_FIRST=0: the register classes of the position / reverse passes small tiles first
+    bool multiPrio = true;                   // MK_SW_MULTI_PRIO=0: the persistent position / reverse workgroups do not ask for issue priority
     uint32_t multiPerCu[3] = {24, 12, 12};   // MK_SW_MULTI_WAVES: one-wave workgroups per CU of the three register classes (<= 64, 96 .. 256, >= 384 rows)
     bool earlyExit = true;                   // MK_SW_EARLY_EXIT=0: the position / reverse passes run every column of their jobs (no bound from the score
                                              // pass, no stop at the known score)
@@ -562,7 +564,9 @@ static const AlignShapes &align_shapes() {
         S.knownWaves = (int) std::max(1L, knob_long("MK_SW_KNOWN_WAVES", 12));
         S.narrowForce = (int) knob_long("MK_SW_NARROW", -1);
         S.earlyExit = knob_long("MK_SW_EARLY_EXIT", 1) != 0;
-        S.multiLaunch = knob_long("MK_SW_MULTI", 1) != 0;
+        S.multiPrio = knob_long("MK_SW_MULTI_PRIO", 1) != 0;
+        S.fwdLargeFirst = knob_long("MK_SW_FWD_LARGE_FIRST", 0) != 0;
+        S.multiLargeFirst = knob_long("MK_SW_MULTI_LARGE_FIRST", 1) != 0;
         if (const char *e = knob("MK_SW_MULTI_WAVES")) {
             int k = 0;
             for (const char *p = e; *p && k < 3; k++) { S.multiPerCu[k] = (uint32_t) std::max(1, atoi(p)); while (*p && *p != ',') p++; if (*p == ',') p++; }
@@ -593,7 +597,13 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
     // synchronisation, 3 launches instead of up to 10 per pass.  Not for queries beyond the largest tile (row tiles need a border whose size
     // follows the bounds) and not where the packed known-score kernel is preferred (the stage alone on the GPU: mk_align).
     const bool knownPreferred = knownScore && !V.q_prof && (S.knownForce >= 0 ? S.knownForce != 0 : !V.co_resident);
-    if (S.multiLaunch && !knownPreferred && V.max_q_len <= (uint32_t) sw_cfg_rows(SW_NCFG - 1)) {
+    // MEASURED AND NOT THE DEFAULT (profiles/r05_search_engine.txt, calls c8 / c9, same box, two repetitions each): sw_pos_* + sw_rev_* kernel time
+    // 700 -> 230 ms per config-2 step and host_align_total 1 910 -> 1 430 ms, but the STEP is 2.5 % slower (875-880 against 855-860 ms): the prefilter
+    // chain is the critical path of the queued search, and the persistent position / reverse workgroups slow its large-tier kernel (450 -> 467 ms
+    // per step) more than the short launches with their host round trips did.  MK_SW_MULTI=1 (MK_DEBUG=1) selects it; read per call so that the
+    // tests can run both.
+    const bool multiLaunch = knob_long("MK_SW_MULTI", 0) != 0;
+    if (multiLaunch && !knownPreferred && V.max_q_len <= (uint32_t) sw_cfg_rows(SW_NCFG - 1)) {
         uint32_t *dCnt = (uint32_t *) dev_scratch("align_multicounters", 64);
         ANULL(dCnt);
         ACHK(hipMemsetAsync(dCnt, 0, 64, stream));
@@ -606,13 +616,14 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
         L.gap_open = P.gap_open; L.gap_extend = P.gap_extend;
         static const char *clsName[3] = {"rows32_64", "rows96_256", "rows384_1024"};
         static const int clsFirst[3] = {0, 3, 7};
-        for (int k = 2; k >= 0; k--) {                         // the long DPs first: they are the tail otherwise
+        for (int kk = 0; kk < 3; kk++) {
+            const int k = S.multiLargeFirst ? 2 - kk : kk;
             char nm[64];
             snprintf(nm, sizeof(nm), "%s_%s", tag, clsName[k]);
             th = tb(nm, 0, 0);
             if (handles) handles[clsFirst[k]] = th;
             const uint32_t units = (n + 3u) / 4u + (uint32_t) SW_NCFG;          // upper bound of the units of the class
-            ACHK(launch_sw_multi(L, dBounds, dCnt + k, k, std::min(units, (uint32_t) S.cus * S.multiPerCu[k]), stream));
+            ACHK(launch_sw_multi(L, dBounds, dCnt + k, k, std::min(units, (uint32_t) S.cus * S.multiPerCu[k]), stream, S.multiPrio));
             te(th);
         }
         return MK_OK;
@@ -698,7 +709,12 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const uint64_t
         ACHK(hipGetLastError());
     }
     te(th);
-    for (int c = SW_NCFG - 1; c >= 0; c--) {                // the tiles of the long queries first: a handful of long DPs per wave, the tail of the pass otherwise
+    // Small tiles first.  (Large first -- so that the handful of long DPs never form the tail of the pass -- was measured in round 5 and is worse beside
+    // persistent workgroups: a launch takes the wave slots its predecessor IN THE SAME STREAM has just freed; behind the tiny planning kernels a
+    // low-parallelism launch waits for another stream's persistent kernel to end instead.  sw_fwd_rows384 / 512 / 768: 64 / 46 / 41 -> 116 / 101 / 61 ms
+    // of kernel time per step, profiles/r05_search_engine.txt.  MK_SW_FWD_LARGE_FIRST=1 restores it.)
+    for (int cc = 0; cc < SW_NCFG; cc++) {
+        const int c = S.fwdLargeFirst ? SW_NCFG - 1 - cc : cc;
         const uint32_t lo = hb[c], hi = hb[c + 1], wlo = hb[16 + c], whi = hb[16 + c + 1];
         if (hi <= lo || whi <= wlo) continue;
         SwLaunch L;

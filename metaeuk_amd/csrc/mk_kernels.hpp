@@ -75,7 +75,7 @@ __host__ __device__ inline bool sw_cfg_known(int c) { return sw_cfg_rows(c) <= 6
 hipError_t launch_sw_known(const SwLaunch &L, int cfg, hipStream_t stream);
 // position / reverse pass over ALL tile configurations of a register class in one persistent launch, the bounds of the tile configurations
 // read on the device (mk_sw.hip: sw_multi_kernel)
-hipError_t launch_sw_multi(const SwLaunch &L, const uint32_t *bounds, uint32_t *counter, int cls, uint32_t blocks, hipStream_t stream);
+hipError_t launch_sw_multi(const SwLaunch &L, const uint32_t *bounds, uint32_t *counter, int cls, uint32_t blocks, hipStream_t stream, bool prio = true);
 
 // Ungapped score of a (query, target, 16-bit diagonal) candidate: UngappedAlignment::scoreSingleSequence
 // (M/src/prefiltering/UngappedAlignment.cpp:438-447).  Both sequences below 32768 residues: the diagonal is the signed 16-bit value.

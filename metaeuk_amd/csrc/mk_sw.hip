@@ -275,8 +275,8 @@ __global__ __launch_bounds__(BLOCK) void sw_kernel(SwLaunch L) {
 // shape of its tile configuration (sw_unit, own profile per job).  Three classes so that the small tiles keep their occupancy: <= 64 rows
 // (72 VGPRs, 6 KB of LDS per wave), 96 .. 256 rows and >= 384 rows (128 VGPRs, 24.5 KB).
 template <int CLS>
-__global__ __launch_bounds__(64) void sw_multi_kernel(SwLaunch L, const uint32_t *bounds, uint32_t *counter) {
-    if (MK_HELPER_PRIO) __builtin_amdgcn_s_setprio(MK_HELPER_PRIO);
+__global__ __launch_bounds__(64) void sw_multi_kernel(SwLaunch L, const uint32_t *bounds, uint32_t *counter, int prio) {
+    if (prio) __builtin_amdgcn_s_setprio(MK_HELPER_PRIO);
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     __shared__ int8_t sMat[448];
     for (int k = (int) threadIdx.x; k < 441; k += 64) sMat[k] = L.mat[k];
@@ -327,12 +327,12 @@ __global__ __launch_bounds__(64) void sw_multi_kernel(SwLaunch L, const uint32_t
 
 // L.order = the jobs' order by (tile configuration, target length class), bounds = device array of SW_NCFG + 1 first-job indices into it,
 // counter = a zeroed device word; cls 0 / 1 / 2 = tile configurations of <= 64 / 96 .. 256 / >= 384 rows.  Single-tile jobs only (no border).
-hipError_t launch_sw_multi(const SwLaunch &L, const uint32_t *bounds, uint32_t *counter, int cls, uint32_t blocks, hipStream_t stream) {
+hipError_t launch_sw_multi(const SwLaunch &L, const uint32_t *bounds, uint32_t *counter, int cls, uint32_t blocks, hipStream_t stream, bool prio) {
     if (!L.order || !bounds || !counter || L.boundary || blocks == 0) return hipErrorInvalidValue;
     switch (cls) {
-        case 0: hipLaunchKernelGGL((sw_multi_kernel<0>), dim3(blocks), dim3(64), (size_t) 64 * 24 * 4, stream, L, bounds, counter); break;
-        case 1: hipLaunchKernelGGL((sw_multi_kernel<1>), dim3(blocks), dim3(64), (size_t) 64 * 24 * 16, stream, L, bounds, counter); break;
-        case 2: hipLaunchKernelGGL((sw_multi_kernel<2>), dim3(blocks), dim3(64), (size_t) 64 * 24 * 16, stream, L, bounds, counter); break;
+        case 0: hipLaunchKernelGGL((sw_multi_kernel<0>), dim3(blocks), dim3(64), (size_t) 64 * 24 * 4, stream, L, bounds, counter, prio ? 1 : 0); break;
+        case 1: hipLaunchKernelGGL((sw_multi_kernel<1>), dim3(blocks), dim3(64), (size_t) 64 * 24 * 16, stream, L, bounds, counter, prio ? 1 : 0); break;
+        case 2: hipLaunchKernelGGL((sw_multi_kernel<2>), dim3(blocks), dim3(64), (size_t) 64 * 24 * 16, stream, L, bounds, counter, prio ? 1 : 0); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

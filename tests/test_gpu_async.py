@@ -109,3 +109,33 @@ def test_queued_searches_against_two_databases(gpu_api):
         x.close()
     small.close()
     db.close()
+
+
+def test_one_launch_per_register_class_equals_the_launches_per_tile_configuration(gpu_api, monkeypatch):
+    """MK_SW_MULTI=1: the position / reverse passes as one persistent launch per register class with the bounds of the tile configurations read on the
+    device (mk_sw.hip: sw_multi_kernel) -- measured, not the default (profiles/r05_search_engine.txt) -- return what the launches per tile
+    configuration return; queries of every tile class, and one beyond the largest tile (row tiles: the per-configuration path serves that batch)."""
+    api = gpu_api
+    import random
+    from metaeuk_amd import synth
+    targets, queries = synth.make_workload(30, 400, seed=37)
+    rng = random.Random(3)
+    aa = synth.AA
+    # long queries made of target pieces so that they align: 300 .. 1 000 rows
+    for L in (300, 420, 600, 800, 1000):
+        t = rng.choice([x for x in targets if len(x) >= 150])
+        s = (t * (L // len(t) + 1))[:L]
+        queries.append("".join(c if rng.random() > 0.1 else rng.choice(aa) for c in s))
+    params = api.default_params()
+    db = api.TargetDB(targets, params)
+    results = {}
+    for name, batch in (("single tile", queries), ("with a query of 1 500 rows", queries + [(targets[0] * 12)[:1500]])):
+        for multi in ("0", "1"):
+            monkeypatch.setenv("MK_SW_MULTI", multi)
+            q = api.Queries(batch, params)
+            results[(name, multi)] = _blocks(api, api.search(db, q), len(batch))
+            q.close()
+        assert results[(name, "0")] == results[(name, "1")], name
+    assert sum(len(b[1]) for b in results[("single tile", "1")]) > 1000
+    monkeypatch.delenv("MK_SW_MULTI")
+    db.close()

@@ -332,3 +332,76 @@ def test_heavy_queries_wide_kernel_equals_the_global_path(gpu_api, monkeypatch):
         assert not bad, (name, bad)
     assert sum(len(x) for x in out["global"]) > 100000
     db.close()
+
+
+def test_contigs_to_exon_sets_against_a_k7_database(gpu_api, tmp_path):
+    """data/predictexons.sh:42-87 end to end at the k-mer size of a UniRef50-scale database: contigs -> six-frame fragments -> prefilter + align
+    with k = 7 against 2.7 M proteins (1.0e9 residues, the native generator's database; -k 7 as IndexTable::computeKmerSize picks it from 3.35e9
+    residues on) -> resultspercontig + collectoptimalset; every contig's exon sets against the reference's own chain run on this box's host cores
+    (oracle/_ref/ref_harness orfs | pipeline -k 7 | exons: Orf.cpp, the prefilter / align code and collectoptimalset.cpp compiled in place)."""
+    import subprocess
+    import sys
+    import time
+    api = gpu_api
+    if not os.path.exists(oracle.REF):
+        pytest.skip("needs oracle/_ref/ref_harness")
+    from metaeuk_amd import synth
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import config5_digest as c5
+    n_targets = int(os.environ.get("MK_TEST_K7_EXON_TARGETS", "2700000"))
+    res, off = api.synth_targets(n_targets, seed=c5.TARGET_SEED)
+    rs = np.random.RandomState(17)
+    picked = rs.randint(0, n_targets, size=48)
+    founders = [np.array(res[int(off[t]):int(off[t + 1])], dtype=np.uint8) for t in picked]
+    contigs = ["".join("ACGT"[x] for x in c) for c in synth.make_contigs(48, founders, seed=3)]
+    contigs.append("ACGT" * 600)                                    # a contig without a gene: an empty record
+    p = api.default_params()
+    p.kmer_size = 7
+    l2 = ctypes.CDLL(None).sysconf(191)                             # the reference sizes its hit bins from the L2 of the host it runs on: this host's
+    p.host_l2_bytes = l2 if l2 and l2 > 0 else 262144
+    db = api.TargetDB.from_codes(res, off, p)
+    assert db.kmer_size() == 7
+    t0 = time.time()
+    o = api.Orfs(contigs)
+    q = o.queries(p)
+    api.search(db, q, p)
+    pred = api.Predictions(db, o, q)
+    t_gpu = time.time() - t0
+    got = [pred.lines(c) for c in range(len(contigs))]
+    # the reference's chain over the same files
+    d = str(tmp_path)
+    c5.write_lines(os.path.join(d, "t.txt"), res, off)
+    del res
+    with open(os.path.join(d, "c.txt"), "w") as f:
+        f.write("\n".join(contigs) + "\n")
+    matdir = oracle.write_matrix_files(os.path.join(d, "mat"))
+    subprocess.check_call([oracle.REF, "orfs", os.path.join(d, "c.txt"), os.path.join(d, "orfs.txt")], stdout=subprocess.DEVNULL)
+    n_orf = 0
+    with open(os.path.join(d, "q.txt"), "w") as f:
+        for line in open(os.path.join(d, "orfs.txt")):
+            if not line.startswith(">"):
+                f.write(line.rstrip("\n").rsplit("\t", 1)[1] + "\n")
+                n_orf += 1
+    assert n_orf == o.n
+    os.makedirs(os.path.join(d, "out"))
+    t0 = time.time()
+    subprocess.check_call([oracle.REF, "pipeline", matdir, os.path.join(d, "t.txt"), os.path.join(d, "q.txt"), os.path.join(d, "out"), "-k", "7",
+                           "--threads", str(int(api.lib().mk_host_threads()))], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([oracle.REF, "exons", os.path.join(d, "t.txt"), os.path.join(d, "c.txt"), os.path.join(d, "orfs.txt"),
+                           os.path.join(d, "out", "aln.txt"), os.path.join(d, "exons.txt")], stdout=subprocess.DEVNULL)
+    t_ref = time.time() - t0
+    exp, cur = {}, None
+    for line in open(os.path.join(d, "exons.txt")):
+        if line.startswith(">"):
+            cur = int(line[1:])
+            exp[cur] = ""
+        else:
+            exp[cur] += line
+    bad = [c for c in range(len(contigs)) if got[c] != exp.get(c, "")]
+    assert not bad, (bad[:5], got[bad[0]][:300], exp.get(bad[0], "")[:300])
+    with_pred = sum(1 for c in range(len(contigs)) if exp.get(c))
+    multi = sum(1 for c in range(len(contigs)) if exp.get(c, "").count("\n") > 1)
+    assert with_pred >= 40 and multi >= 20 and got[-1] == ""
+    print("k = 7 contigs -> exon sets: %d contigs, %d fragments, %d with predictions; GPU chain %.2f s, reference chain %.1f s" % (len(contigs), o.n, with_pred, t_gpu, t_ref))
+    os.remove(os.path.join(d, "t.txt"))
+    pred.close(); q.close(); o.close(); db.close()

@@ -17,7 +17,7 @@ def run(contigs, steps, chunk):
     if chunk:
         env.update(MK_DEBUG="1", MK_SEARCH_CHUNK_QUERIES=str(chunk))
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--contigs", str(contigs), "--steps", str(steps), "--warmup", "2",
-                                   "--cpu-sample", "0", "--config4-profiles", "0"], env=env, stderr=subprocess.DEVNULL).decode().strip().splitlines()[-1]
+                                   "--cpu-sample", "0", "--config4-profiles", "0", "--e2e-sample", "-1"], env=env, stderr=subprocess.DEVNULL).decode().strip().splitlines()[-1]
     d = json.loads(out)
     host = {k: round(v / d["steps"], 1) for k, v in d["kernels_ms"].items() if k.startswith("host_") or k.startswith("wait_")}
     blocking = (d.get("blocking") or {}).get("ms_per_step")
