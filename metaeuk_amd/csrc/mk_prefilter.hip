@@ -519,11 +519,24 @@ struct StreamArgs {
 #define MK_STREAM_U 2
 #endif
 // shapes of the two streamed tiers: waves per workgroup, LDS sort size, bitmap bits, workgroups per CU
+#ifndef MK_STREAM_SURV_1
+#define MK_STREAM_SURV_1 256       // second tier (4096 hits, one wave): LDS sort size and bitmap bits
+#define MK_STREAM_MBITS_1 8192
+#endif
+// Third tier: 32 768 hits and 1 024 k-mer starts on 8 waves since round 5 (rounds 2-4: 8 192 hits, 512 starts, 4 waves).  The queries of the largest tier
+// average 11 400 hits -- just beyond the old third tier -- and ran on 16 waves with 79 KB of LDS, ONE workgroup per CU beside the alignment stage.
+// Measured on config 2, queued search, same box, two repetitions (profiles/r05_prefilter_tiers.txt; kernel ms per step, third + largest tier):
+//   8 192 x 4 waves: 149 + 450, step 859 | 16 384 x 4: 345 + 250, 860 | 32 768 x 4 (sort 1 024 / 2 048): 471 + 173 / 514 + 129, 900-919 |
+//   16 384 x 8 waves: 372 + 192, 839 | 32 768 x 8: 448 + 110, 841-845 | 65 536 x 8: 525 + 80, 885 | 32 768 x 8, sort 4 096: 545 + 104, 910
+#ifndef MK_STREAM_CAP_A
+#define MK_STREAM_CAP_A 32768      // hits and k-mer starts of a query of the third tier
+#define MK_STREAM_MAXPOS_A 1024
+#endif
 #ifndef MK_STREAM_NW_A
-#define MK_STREAM_NW_A 4
-#define MK_STREAM_SURV_A 1024
-#define MK_STREAM_MBITS_A 32768
-#define MK_STREAM_WG_A 8
+#define MK_STREAM_NW_A 8
+#define MK_STREAM_SURV_A 2048
+#define MK_STREAM_MBITS_A 65536
+#define MK_STREAM_WG_A 4
 #endif
 #ifndef MK_STREAM_NW_B
 #define MK_STREAM_NW_B 16
@@ -948,15 +961,15 @@ constexpr int N_TIERS = 4;
 // production tiers, then a miniature set (MK_PREFILTER_TIERS=tiny) with which small test inputs exercise every
 // workgroup shape, the overflow hand-over, the class passes and the global path
 const FusedTier TIERS[2 * N_TIERS] = {{2048, 1, 64, 28}, {4096, 1, 128, 24},
-                                      {8192, MK_STREAM_NW_A, 512, MK_STREAM_WG_A}, {MK_STREAM_CAP_B, MK_STREAM_NW_B, MK_STREAM_MAXPOS_B, MK_STREAM_WG_B},
+                                      {MK_STREAM_CAP_A, MK_STREAM_NW_A, MK_STREAM_MAXPOS_A, MK_STREAM_WG_A}, {MK_STREAM_CAP_B, MK_STREAM_NW_B, MK_STREAM_MAXPOS_B, MK_STREAM_WG_B},
                                       {256, 1, 32, 8}, {512, 1, 64, 8}, {1024, 4, 64, 4}, {4096, 8, 256, 4}};
 
 //                                    region (hits)  LDS sort  bitmap bits  k-mer starts  waves  probe groups
 void launch_stream(int tier, const StreamArgs &A, unsigned grid, hipStream_t stream) {
     switch (tier) {
         case 0: hipLaunchKernelGGL((stream_kernel<2048, 256, 8192, 64, 1, MK_STREAM_U>), dim3(grid), dim3(64), 0, stream, A); break;
-        case 1: hipLaunchKernelGGL((stream_kernel<4096, 256, 8192, 128, 1, MK_STREAM_U>), dim3(grid), dim3(64), 0, stream, A); break;
-        case 2: hipLaunchKernelGGL((stream_kernel<8192, MK_STREAM_SURV_A, MK_STREAM_MBITS_A, 512, MK_STREAM_NW_A, MK_STREAM_U>), dim3(grid), dim3(64 * MK_STREAM_NW_A), 0, stream, A); break;
+        case 1: hipLaunchKernelGGL((stream_kernel<4096, MK_STREAM_SURV_1, MK_STREAM_MBITS_1, 128, 1, MK_STREAM_U>), dim3(grid), dim3(64), 0, stream, A); break;
+        case 2: hipLaunchKernelGGL((stream_kernel<MK_STREAM_CAP_A, MK_STREAM_SURV_A, MK_STREAM_MBITS_A, MK_STREAM_MAXPOS_A, MK_STREAM_NW_A, MK_STREAM_U>), dim3(grid), dim3(64 * MK_STREAM_NW_A), 0, stream, A); break;
         case 3: hipLaunchKernelGGL((stream_kernel<MK_STREAM_CAP_B, MK_STREAM_SURV_B, MK_STREAM_MBITS_B, MK_STREAM_MAXPOS_B, MK_STREAM_NW_B, MK_STREAM_U>), dim3(grid), dim3(64 * MK_STREAM_NW_B), 0, stream, A); break;
         case 4: hipLaunchKernelGGL((stream_kernel<256, 64, 1024, 32, 1, 2>), dim3(grid), dim3(64), 0, stream, A); break;
         case 5: hipLaunchKernelGGL((stream_kernel<512, 64, 1024, 64, 1, 2>), dim3(grid), dim3(64), 0, stream, A); break;

@@ -1,19 +1,14 @@
 #!/bin/bash
-# Kernel-variant experiments: builds metaeuk_amd/lib/variants/lib<name>.so from the current sources with extra -D flags for
-# mk_prefilter.hip / mk_sw.hip / mk_align.hip; run with METAEUK_AMD_LIB=<that file> (metaeuk_amd/api.py honours it).
-#   tools/build_variant.sh nt1 -DMK_NT_LOADS=1
+# a variant of the product library with other compile-time shapes of the prefilter kernels (experiments; the result is not tracked):
+#   tools/build_variant.sh <name> -DMK_STREAM_CAP_A=32768 ...   ->  tools/_variants/libmetaeuk_amd_<name>.so   (use: METAEUK_AMD_LIB=<that> python bench.py ...)
 set -e
-name=$1; shift
 R=$(cd $(dirname $0)/.. && pwd)
-O=$R/metaeuk_amd/lib/variants/obj_$name
+NAME=$1; shift
+O=$R/tools/_variants
 mkdir -p $O
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fopenmp -ffp-contract=off -Wno-unused-value -Wno-unused-result"
-pids=""
-for f in mk_prefilter.hip mk_sw.hip mk_align.hip; do
-  /opt/rocm/bin/hipcc $FLAGS "$@" -c $R/metaeuk_amd/csrc/$f -o $O/$f.o & pids="$pids $!"
-done
-for p in $pids; do wait $p; done
-objs=""
-for f in mk_host.cpp mk_exons.cpp mk_indexfile.cpp mk_abi.cpp mk_derive.hip mk_orf.hip mk_profile.hip mk_kmer7.hip mk_index.hip mk_synth.cpp; do objs="$objs $R/metaeuk_amd/lib/obj/$f.o"; done
-/opt/rocm/bin/hipcc $FLAGS -shared $objs $O/mk_prefilter.hip.o $O/mk_sw.hip.o $O/mk_align.hip.o -o $R/metaeuk_amd/lib/variants/lib$name.so
-echo $R/metaeuk_amd/lib/variants/lib$name.so
+/opt/rocm/bin/hipcc $FLAGS "$@" -c $R/metaeuk_amd/csrc/mk_prefilter.hip -o $O/mk_prefilter_$NAME.o
+OBJS=$(ls $R/metaeuk_amd/lib/obj/*.o | grep -v mk_prefilter.hip.o)
+/opt/rocm/bin/hipcc $FLAGS -shared $OBJS $O/mk_prefilter_$NAME.o -o $O/libmetaeuk_amd_$NAME.so
+rm -f $O/mk_prefilter_$NAME.o
+echo $O/libmetaeuk_amd_$NAME.so
