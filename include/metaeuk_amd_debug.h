@@ -24,6 +24,10 @@ int mk_synth_fragments(uint64_t n_fragments, uint64_t seed, const uint8_t *targe
 /* residue codes -> an MMseqs2 sequence DB in memory: data[total + 2 n] = "SEQ\n\0" entries, rows of its .index (key = position) */
 int mk_synth_seqdb(const uint8_t *residues, const uint64_t *offsets, uint64_t n, char *data, uint32_t *keys, uint64_t *data_offsets, uint32_t *lengths);
 
+/* ... and straight to disk: <base>, <base>.index, <base>.dbtype (amino acids; key = position), piece by piece -- a 2.2e10-residue database is 23 GB of
+ * data and 6e7 index rows.  with_lines != 0: <base>.txt too, one sequence per line (what oracle/ref_harness reads). */
+int mk_synth_write_seqdb(const char *base, const uint8_t *residues, const uint64_t *offsets, uint64_t n, int with_lines);
+
 /* ---- experiment hook (tools/micro/mk_experiments.hip is its only user): the device view of a (database, batch) pair -- a
  * mk::PrefilterDeviceView (metaeuk_amd/csrc/mk_prefilter.hpp: pointers into HBM, valid while both handles live) copied into view_out, whose
  * size must be given as view_bytes -- and the batch's host offsets.  The layout of that struct is NOT stable across builds. */

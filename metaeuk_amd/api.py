@@ -48,7 +48,7 @@ EXPORTS = ["mk_init", "mk_last_error", "mk_default_params", "mk_device_name", "m
            "mk_kernel_stats", "mk_kernel_stats_reset", "mk_format_hit", "mk_format_alignment", "mk_format_hits", "mk_format_alignments", "mk_targetdb_set_keys",
            "mk_profiles_create", "mk_profiles_derived", "mk_swap_alignments", "mk_swapped_result", "mk_swapped_destroy",
            "mk_targetdb_masked_residues", "mk_targetdb_kmer_size", "mk_targetdb_longest_list", "mk_targetdb_index_compare",
-           "mk_synth_targets", "mk_synth_fragments", "mk_synth_seqdb", "mk_targetdb_create_sequences", "mk_prefilter_statistics",
+           "mk_synth_targets", "mk_synth_fragments", "mk_synth_seqdb", "mk_synth_write_seqdb", "mk_targetdb_create_sequences", "mk_prefilter_statistics",
            "mk_format_prefilter_statistics", "mk_device_memory"]
 
 
@@ -212,6 +212,11 @@ def synth_seqdb(res, off):
     keys = np.zeros(n, dtype=np.uint32); offs = np.zeros(n, dtype=np.uint64); lens = np.zeros(n, dtype=np.uint32)
     _chk(lib().mk_synth_seqdb(_p(res), _p(off), C.c_uint64(n), _p(data), _p(keys), _p(offs), _p(lens)))
     return data, keys, offs, lens
+
+
+def synth_write_seqdb(base, res, off, with_lines=False):
+    """residue codes -> an MMseqs2 sequence DB on disk (<base>, .index, .dbtype; key = position), written natively piece by piece; with_lines: <base>.txt too"""
+    _chk(lib().mk_synth_write_seqdb(C.c_char_p(base.encode()), _p(res), _p(off), C.c_uint64(len(off) - 1), C.c_int(1 if with_lines else 0)))
 
 
 def seq_db_image(seqs, keys=None, order=None):

@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <cstring>
 #include <omp.h>
+#include <string>
+#include <cstdio>
 #include <vector>
 
 namespace {
@@ -152,6 +154,48 @@ int mk_synth_seqdb(const uint8_t *residues, const uint64_t *offsets, uint64_t n,
         keys[i] = (uint32_t) i; dataOffsets[i] = at; lengths[i] = (uint32_t) (L + 2);
     }
     return MK_OK;
+}
+
+// ... and straight to disk (<base>, <base>.index, <base>.dbtype = amino acids; key = position), piece by piece: a 2.2e10-residue database is 23 GB
+// of data and 60 M index rows, which a Python loop would write for minutes.  with_lines != 0: also <base>.txt, one sequence per line (what the
+// reference harness reads).
+int mk_synth_write_seqdb(const char *base, const uint8_t *residues, const uint64_t *offsets, uint64_t n, int with_lines) {
+    if (!base || !residues || !offsets) return MK_ERR_ARG;
+    static const char LETTERS[] = "ACDEFGHIKLMNPQRSTVWYX";
+    const std::string b(base);
+    FILE *fd = fopen(b.c_str(), "wb"), *fi = fopen((b + ".index").c_str(), "wb"), *ft = fopen((b + ".dbtype").c_str(), "wb");
+    FILE *fl = with_lines ? fopen((b + ".txt").c_str(), "wb") : nullptr;
+    if (!fd || !fi || !ft || (with_lines && !fl)) { if (fd) fclose(fd); if (fi) fclose(fi); if (ft) fclose(ft); if (fl) fclose(fl); return MK_ERR_ARG; }
+    const int dbtype = 0;
+    fwrite(&dbtype, 4, 1, ft);
+    fclose(ft);
+    const uint64_t PIECE = 1u << 20;                              // sequences per piece
+    std::vector<char> data, lines, index;
+    bool ok = true;
+    for (uint64_t i0 = 0; i0 < n && ok; i0 += PIECE) {
+        const uint64_t i1 = std::min(n, i0 + PIECE), r0 = offsets[i0], r1 = offsets[i1];
+        data.resize((size_t) (r1 - r0) + 2 * (size_t) (i1 - i0));
+        if (fl) lines.resize((size_t) (r1 - r0) + (size_t) (i1 - i0));
+#pragma omp parallel for schedule(static)
+        for (uint64_t i = i0; i < i1; i++) {
+            const uint64_t L = offsets[i + 1] - offsets[i], at = (offsets[i] - r0) + 2 * (i - i0), lt = (offsets[i] - r0) + (i - i0);
+            const uint8_t *s = residues + offsets[i];
+            for (uint64_t p = 0; p < L; p++) { const char c = LETTERS[s[p] <= 20 ? s[p] : 20]; data[at + p] = c; if (fl) lines[lt + p] = c; }
+            data[at + L] = '\n'; data[at + L + 1] = '\0';
+            if (fl) lines[lt + L] = '\n';
+        }
+        index.clear();
+        char row[64];
+        for (uint64_t i = i0; i < i1; i++) {
+            const int w = snprintf(row, sizeof(row), "%llu\t%llu\t%llu\n", (unsigned long long) i, (unsigned long long) (offsets[i] + 2 * i), (unsigned long long) (offsets[i + 1] - offsets[i] + 2));
+            index.insert(index.end(), row, row + w);
+        }
+        ok = fwrite(data.data(), 1, data.size(), fd) == data.size() && fwrite(index.data(), 1, index.size(), fi) == index.size() &&
+             (!fl || fwrite(lines.data(), 1, lines.size(), fl) == lines.size());
+    }
+    ok = (fclose(fd) == 0) & ok; ok = (fclose(fi) == 0) & ok;
+    if (fl) ok = (fclose(fl) == 0) & ok;
+    return ok ? MK_OK : MK_ERR_ARG;
 }
 
 }  // extern "C"

@@ -405,3 +405,93 @@ def test_contigs_to_exon_sets_against_a_k7_database(gpu_api, tmp_path):
     print("k = 7 contigs -> exon sets: %d contigs, %d fragments, %d with predictions; GPU chain %.2f s, reference chain %.1f s" % (len(contigs), o.n, with_pred, t_gpu, t_ref))
     os.remove(os.path.join(d, "t.txt"))
     pred.close(); q.close(); o.close(); db.close()
+
+
+def _db_digest(base, n):
+    """digest of a result DB (entries in key order 0 .. n-1) as tests/oracle.py digests the harness's block files: per-entry line counts, then the bodies"""
+    import hashlib
+    data = np.fromfile(base, dtype=np.uint8)
+    rows = np.loadtxt(base + ".index", dtype=np.int64, ndmin=2)
+    rows = rows[np.argsort(rows[:, 0], kind="stable")]
+    assert rows.shape[0] == n and np.array_equal(rows[:, 0], np.arange(n))
+    counts, bodies = np.zeros(n, dtype="<u8"), []
+    for k in range(n):
+        b = data[rows[k, 1]:rows[k, 1] + rows[k, 2] - 1].tobytes()
+        counts[k] = b.count(b"\n")
+        bodies.append(b)
+    h = hashlib.sha256()
+    h.update(counts.tobytes())
+    h.update(b"".join(bodies))
+    return h.hexdigest(), int(counts.sum())
+
+
+@pytest.mark.parametrize("n_targets", [200000, 60000000])
+def test_config5_60M_proteins_pinned_to_the_reference_by_target_splits(gpu_api, tmp_path, n_targets):
+    """BASELINE config 5's database at its stated size against the REFERENCE's own run: 60 000 000 proteins (2.25e10 residues) searched in
+    TARGET_DB_SPLIT mode -- how the reference itself runs a database whose index does not fit its host (Prefiltering.cpp:273-377,352-362; the
+    unsplit index needs ~270 GB).  tools/config5_digest.py --split N ran oracle/_ref/ref_harness pipeline --split N on a GPU box's host cores
+    (tests/golden/config5_digest_60000000_split<N>.json: N residue-balanced ranges of 15 M proteins, k = 7 from the residues per range, the
+    lists joined by the reference's own mergeTargetSplits); here `metaeuk-amd prefilter --split N --split-mode 0` + `align` over the same
+    database written as an MMseqs2 DB (23 GB) and the same planted + long fragments: digests of the prefilter DB and of the alignment DB equal.
+    The 200 000-protein case (three ranges, k = 6; its digest comes from the build container) keeps the path under test where the big one cannot run."""
+    import glob
+    import json
+    import shutil
+    import subprocess
+    import sys
+    import time
+    from metaeuk_amd import build
+    api = gpu_api
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    golds = sorted(glob.glob(os.path.join(root, "tests", "golden", "config5_digest_%d_split*.json" % n_targets)))
+    if os.environ.get("MK_TEST_CONFIG5_SPLIT_GOLDEN"):
+        golds = [os.environ["MK_TEST_CONFIG5_SPLIT_GOLDEN"]]
+    if not golds:
+        pytest.skip("no reference digest for %d proteins in target-split mode (tools/config5_digest.py --split N)" % n_targets)
+    gold = json.load(open(golds[-1]))
+    free, total = api.device_memory()
+    if total < 280e9 and n_targets >= 60000000:
+        pytest.skip("needs a 288 GB device")
+    if shutil.disk_usage(str(tmp_path)).free < 1.3 * gold["target_residues"] + 4e9:
+        pytest.skip("needs %.0f GB of scratch disk" % (1.3 * gold["target_residues"] / 1e9 + 4))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import config5_digest as c5
+    t0 = time.time()
+    res, off = api.synth_targets(n_targets, seed=c5.TARGET_SEED)
+    assert int(off[-1]) == gold["target_residues"]
+    fr, foff, src = c5.make_fragments(api, res, off, gold["n_queries"], gold.get("n_long_queries", 0))
+    nq = len(foff) - 1
+    api.synth_write_seqdb(str(tmp_path / "T"), res, off)
+    api.synth_write_seqdb(str(tmp_path / "Q"), fr, foff)
+    del res
+    t_gen = time.time() - t0
+    N = gold["target_splits"]
+    run = lambda *a: subprocess.run([build.BIN] + [str(x) for x in a], stderr=subprocess.PIPE)
+    t0 = time.time()
+    r = run("prefilter", tmp_path / "Q", tmp_path / "T", tmp_path / "pref", "--split", N, "--split-mode", "0", "-s", "5.7", "--ref-l2-bytes", gold["host_l2_bytes"],
+            "--threads", int(api.lib().mk_host_threads()))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert ("%d target splits" % N).encode() in r.stderr, r.stderr.decode()[-600:]
+    t_pref = time.time() - t0
+    t0 = time.time()
+    r = run("align", tmp_path / "Q", tmp_path / "T", tmp_path / "pref", tmp_path / "aln", "--alignment-mode", "2", "-e", "100", "--min-aln-len", "11",
+            "--threads", int(api.lib().mk_host_threads()))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    t_aln = time.time() - t0
+    d_pref, n_hits = _db_digest(str(tmp_path / "pref"), nq)
+    d_aln, n_aln = _db_digest(str(tmp_path / "aln"), nq)
+    report = dict(n_targets=n_targets, target_residues=gold["target_residues"], target_splits=N, fragments=nq, pref_hits=n_hits, alignments=n_aln,
+                  reference=dict(pref_hits=gold["reference"]["pref_hits"], passed=gold["reference"]["passed"], wall_s=gold["reference"]["wall_s"]),
+                  t_generate_and_write_db_s=round(t_gen, 1), t_prefilter_command_s=round(t_pref, 1), t_align_command_s=round(t_aln, 1),
+                  sha256_pref=d_pref, sha256_aln=d_aln, match=(d_pref == gold["sha256_pref"] and d_aln == gold["sha256_aln"]))
+    print("config 5, target splits:", json.dumps(report))
+    out = os.path.join(root, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "config5_split_case_%d.json" % n_targets), "w") as f:
+            json.dump(report, f, indent=1)
+    for name in ("T", "Q"):
+        for sfx in ("", ".index", ".dbtype"):
+            os.remove(str(tmp_path / (name + sfx)))
+    assert n_hits == gold["reference"]["pref_hits"], report
+    assert d_pref == gold["sha256_pref"], report
+    assert n_aln == gold["reference"]["passed"] and d_aln == gold["sha256_aln"], report
