@@ -19,9 +19,11 @@
  * a pool of pinned result blocks.  Calls into the library must come from one thread at a time (the reference's modules
  * are one process per step as well); the library itself runs the stages of mk_search on internal, persistent threads (one for the
  * prefilter, three alignment workers, a stream each).
- * Sizing knobs for experiments (never needed for correctness): MK_PREFILTER_PATH, MK_PREFILTER_TIERS,
- * MK_PREFILTER_MAX_TIERS, MK_PREFILTER_WG_PER_CU_S/_A/_B, MK_SW_WAVES_PER_CU, MK_SW_UNITS_PER_BLOCK, MK_STREAM_PRIORITY, MK_SEARCH_CHUNK_QUERIES,
- * MK_PREFILTER_DEBUG.
+ * Experiment and test switches (MK_PREFILTER_PATH, MK_PREFILTER_TIERS, MK_SW_WAVES_PER_CU, MK_SW_MULTI, MK_ALIGN_WORKERS, MK_SEARCH_CHUNK_QUERIES, ... --
+ * the full list is DESIGN.md section 9) are read ONLY when MK_DEBUG=1 is set in the environment: a stray variable cannot change tiers, paths or launch
+ * shapes of a production run, and setting one without MK_DEBUG has no effect.  Always honoured: RANK / WORLD_SIZE / LOCAL_RANK / LOCAL_WORLD_SIZE,
+ * OMP_NUM_THREADS, MK_SHARD_TIMEOUT_S.  Defaults worth knowing: three alignment workers (each with per-chunk scratch in HBM), one prefilter thread,
+ * query batches' device blocks pooled (at most 24 blocks of at most 1 GB kept).
  */
 #ifndef METAEUK_AMD_H
 #define METAEUK_AMD_H

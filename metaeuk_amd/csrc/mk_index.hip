@@ -552,9 +552,11 @@ __global__ __launch_bounds__(256) void lens_from_offsets_kernel(const uint64_t *
     const uint64_t k = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const uint64_t a = off[k], b = off[k + 1];
-    const bool ok = b >= a && b - a < (1ull << 23);
+    const bool falls = b < a, tooLong = !falls && b - a >= (1ull << 23);      // falling offsets: a corrupt file; a list of 2^23 entries: this build's slot width
+    const bool ok = !falls && !tooLong;
     count[k] = ok ? (uint32_t) (b - a) : 0u;
-    if (!ok) atomicAdd(&bad[0], 1ull);
+    if (falls) atomicAdd(&bad[0], 1ull);
+    if (tooLong) atomicAdd(&bad[2], 1ull);
 }
 __global__ __launch_bounds__(256) void expand6_kernel(const unsigned char *raw, uint64_t n, uint64_t *out, uint32_t nSeq, unsigned long long *bad) {
     const uint64_t k = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -815,8 +817,8 @@ int device_index_from_file(const uint64_t *hostOffsets, const unsigned char *hos
     Tmp<uint32_t> dCount;
     Tmp<unsigned long long> dBad;
     ICHK(dCount.alloc(cells));
-    ICHK(dBad.alloc(2));
-    ICHK(hipMemsetAsync(dBad.p, 0, 16, stream));
+    ICHK(dBad.alloc(3));
+    ICHK(hipMemsetAsync(dBad.p, 0, 24, stream));
     const uint64_t PIECE = 1ull << 26;                                   // cells / entries per upload
     {
         Tmp<uint64_t> dOffPiece;
@@ -840,9 +842,11 @@ int device_index_from_file(const uint64_t *hostOffsets, const unsigned char *hos
             ICHK(hipStreamSynchronize(stream));
         }
     }
-    unsigned long long bad[2] = {0, 0};
-    ICHK(hipMemcpy(bad, dBad.p, 16, hipMemcpyDeviceToHost));
-    if (bad[0]) { err = "corrupt index DB: " + std::to_string(bad[0]) + " k-mer list offsets fall or span 2^23 entries or more"; return MK_ERR_ARG; }
+    unsigned long long bad[3] = {0, 0, 0};
+    ICHK(hipMemcpy(bad, dBad.p, 24, hipMemcpyDeviceToHost));
+    if (bad[0]) { err = "corrupt index DB: " + std::to_string(bad[0]) + " k-mer list offsets fall"; return MK_ERR_ARG; }
+    // (a valid index of a very large or low-complexity database can hold such a list: a limit of this build, as in the build path)
+    if (bad[2]) { err = std::to_string(bad[2]) + " k-mers of the index DB occur in 2^23 targets or more: the slots of this build hold 23 bits of list length"; return MK_ERR_UNSUPPORTED; }
     if (bad[1]) { err = "corrupt index DB: " + std::to_string(bad[1]) + " entries name a sequence beyond the database's " + std::to_string(nSeq); return MK_ERR_ARG; }
     uint64_t *ent = dEntries.take();
     const int rc = device_index_from_lists(dCount.p, ent, cells, nEntries, entryShift, stream, out, err);

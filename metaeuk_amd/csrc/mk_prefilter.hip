@@ -590,9 +590,10 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
         const uint32_t hb = ((uint32_t) (rec & TMASK) * 2654435761u) >> (32 - LOG_MBITS);
         return ((sBm2[hb >> 5] >> (hb & 31u)) & 1u) || ((uint32_t) (rec >> REC_T_BITS) & 0xFFu) == 0u;
     };
-    // target class of a record: a 24-bit hash scaled to the range (multiply and shift).  Not `hash % n`: in the wide kernel below that form lost
-    // every record of subset 10 of 11 (and of a few other counts) on gfx950 although the arithmetic alone tests clean (tools/micro/urem24.hip,
-    // profiles/r04_wide_kernel.txt); a partition function only has to be a function
+    // target class of a record: a 24-bit hash scaled to the range (multiply and shift).  NOT `hash % n`: for operands the compiler can bound below 2^24
+    // it emits a float-reciprocal division that returns remainder 0xFFFFFF where the true one is n - 1 (large numerators; n = 11, 44, 46, 57 ... on this
+    // chip) -- such a record is in NO class.  Rounds 2-4 had that form here and in the wide kernel ("the lost subset"; root cause, device reproducer and
+    // host model: tools/micro/urem24.hip, profiles/r05_lost_subset_root_cause.txt; tests/test_div24.py scans every kernel for the sequence)
     const auto class_of = [&](uint64_t rec, uint32_t n) -> uint32_t { return ((mix32((uint32_t) (rec & TMASK) ^ 0x85EBCA6Bu) >> 8) * n) >> 24; };
     for (;;) {
         __syncthreads();                                  // the previous query's LDS is no longer read
@@ -2346,13 +2347,22 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
             A.rank_bits = std::min<uint32_t>(48u - A.t_bits, 24u);
             A.cls_cap = (uint32_t) W.clsCap;
             if (W.clsCap == 0) {
-                const uint64_t budget = (uint64_t) std::max<long>(1, knob_long("MK_PREFILTER_WIDE_POOL_GB", 24)) << 30;
+                // 24 GB at most (MK_PREFILTER_WIDE_POOL_GB), and never more than a third of what the device had free when the pool was first sized
+                // (a database that fills the HBM -- 60 M proteins leave 35 GB -- must not be refused a search for want of region space)
+                static uint64_t byFree = 0;
+                if (!byFree) { size_t f = 0, t = 0; byFree = (hipMemGetInfo(&f, &t) == hipSuccess && f) ? std::max<uint64_t>(1ull << 30, (uint64_t) f / 3) : (24ull << 30); }
+                const uint64_t budget = std::min<uint64_t>((uint64_t) std::max<long>(1, knob_long("MK_PREFILTER_WIDE_POOL_GB", 24)) << 30, byFree);
                 const uint64_t byRank = (1ull << A.rank_bits) / (uint64_t) W.nCls, byBudget = budget / ((uint64_t) cus * perCu * W.nCls * 12ull);
                 A.cls_cap = (uint32_t) std::max<uint64_t>(4096, std::min(byRank, byBudget) & ~63ull);
             }
-            const size_t regionRecs = (size_t) W.nCls * A.cls_cap;
-            A.pool = (uint64_t *) dev_scratch("pf_wpool", (size_t) launch * regionRecs * 8);
-            A.pool_ord = (uint32_t *) dev_scratch("pf_wpoolord", (size_t) launch * regionRecs * 4);
+            for (;;) {                                         // a pool that cannot be had is halved (fuller classes send more queries to the global path)
+                const size_t regionRecs = (size_t) W.nCls * A.cls_cap;
+                A.pool = (uint64_t *) dev_scratch("pf_wpool", (size_t) launch * regionRecs * 8);
+                A.pool_ord = A.pool ? (uint32_t *) dev_scratch("pf_wpoolord", (size_t) launch * regionRecs * 4) : nullptr;
+                if ((A.pool && A.pool_ord) || W.clsCap != 0 || A.cls_cap <= 4096) break;
+                (void) hipGetLastError();
+                A.cls_cap = std::max<uint32_t>(4096, (A.cls_cap / 2) & ~63u);
+            }
             PNULL(A.pool); PNULL(A.pool_ord);
             A.V = V; A.queries = dList; A.n_queries = (uint32_t) order.size(); A.q_first = a;
             A.C = X.C; A.cand_cap = X.candCap; A.counters = dCtr;
@@ -2481,23 +2491,39 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
 
     uint32_t q0 = 0;
     uint32_t chunkLimit = QCAP;
-    while (q0 < nq) {
-        // ---- chunk size: bounded by the query field of the sort key and by the candidate buffers
-        uint32_t want = chunkLimit;
+    // ---- chunk size: bounded by the query field of the sort key and by the candidate buffers
+    const auto chunk_end = [&](uint32_t from, uint32_t limit) -> uint32_t {
+        uint32_t want = limit;
         if (hooks.max_chunk_queries) {
             // the consumer of the chunks (the alignment stage of mk_search) starts when the FIRST chunk is done: the first chunks are small
             // (1/4, then 1/2 of the limit), the later ones large enough to keep the launches of both stages long
             uint32_t lim = hooks.max_chunk_queries;
             if (hooks.chunk_ramp) {
                 const uint32_t full = lim;
-                lim = q0 == 0 ? std::max(1024u, full / 4) : (q0 < full ? std::max(1024u, full / 2) : full);
+                lim = from == 0 ? std::max(1024u, full / 4) : (from < full ? std::max(1024u, full / 2) : full);
                 // (shrinking the LAST chunks as well, to shorten the consumer's tail, was measured and costs more in short launches than it saves)
             }
             want = std::min(want, lim);
         }
         if (candPerQuery > 0) want = (uint32_t) std::min<double>(want, std::max(1.0, 0.6 * (double) CAND_CAP / candPerQuery));
         else want = std::min<uint32_t>(want, 1u << 16);                    // nothing known yet: a small probe chunk
-        const uint32_t q1 = (uint32_t) std::min<uint64_t>(nq, (uint64_t) q0 + std::max<uint32_t>(want, 1));
+        return (uint32_t) std::min<uint64_t>(nq, (uint64_t) from + std::max<uint32_t>(want, 1));
+    };
+    // Round 5: the similar-k-mer count of the NEXT chunk (kmer_count_kernel: a sizing pass that reads the queries and the 3-mer histograms only) runs
+    // on a side stream while the tier kernels of this chunk run -- it was 33-36 ms per config-2 step at the head of a chain that IS the step
+    // (DESIGN 4.3).  Two sets of count buffers; the next chunk takes the counts when its range is the predicted one.  MK_PREFILTER_COUNT_AHEAD=0: off
+    struct CountAhead { bool valid = false; uint32_t q0 = 0, q1 = 0; int set = 0; hipEvent_t done = nullptr; } ahead;
+    static const bool countAheadOn = knob_long("MK_PREFILTER_COUNT_AHEAD", 1) != 0;
+    static thread_local hipStream_t sideStream = nullptr;
+    if (countAheadOn && useFused && !sideStream && hipStreamCreateWithFlags(&sideStream, hipStreamNonBlocking) != hipSuccess) sideStream = nullptr;
+    if (sideStream) PCHK(hipEventCreateWithFlags(&ahead.done, hipEventDisableTiming));
+    struct EventGuard { hipEvent_t &e; ~EventGuard() { if (e) (void) hipEventDestroy(e); } } aheadGuard{ahead.done};
+    const auto count_buffers = [&](int set, uint32_t nQueries, uint64_t nPositions, uint32_t *&dQKout, uint16_t *&dPosOut) {
+        dPosOut = (uint16_t *) dev_scratch(set ? "pf_poscost1" : "pf_poscost", (size_t) (nPositions + 16) * 2);
+        dQKout = (uint32_t *) dev_scratch(set ? "pf_qkmers1" : "pf_qkmers", (size_t) nQueries * 4);
+    };
+    while (q0 < nq) {
+        const uint32_t q1 = chunk_end(q0, chunkLimit);
         const uint32_t nqc = q1 - q0;
         uint32_t nCand = 0;
         X.chunkQ0 = q0;
@@ -2516,9 +2542,16 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             // similar-k-mer count per query (exact, kmer_count_kernel) -> expected index hits -> tier, all on the device (tier_*_kernel): nothing
             // between the count and the tiers' launches waits for the host
             constexpr uint32_t LIST_PEEK = 4096;                                 // entries of the global path's two lists fetched with the counters
-            uint16_t *dPosCost = (uint16_t *) dev_scratch("pf_poscost", (size_t) (qOff[q1] - qOff[q0] + 16) * 2);
+            const bool haveAhead = ahead.valid && ahead.q0 == q0 && ahead.q1 >= q1;
+            const int countSet = haveAhead ? ahead.set : 0;
+            // (counts made ahead for another range -- a chunk that was retried smaller -- are dropped; their kernel must be off the buffers first)
+            if (ahead.valid && !haveAhead) PCHK(hipStreamWaitEvent(stream, ahead.done, 0));
+            ahead.valid = false;
+            uint16_t *dPosCost = nullptr;
+            uint32_t *dQK = nullptr;
+            if (haveAhead) count_buffers(countSet, ahead.q1 - ahead.q0, qOff[ahead.q1] - qOff[ahead.q0], dQK, dPosCost);      // (sized when they were filled)
+            else count_buffers(0, nqc, qOff[q1] - qOff[q0], dQK, dPosCost);
             PNULL(dPosCost);
-            uint32_t *dQK = (uint32_t *) dev_scratch("pf_qkmers", (size_t) nqc * 4);
             uint32_t *dList = (uint32_t *) dev_scratch("pf_flist", (size_t) nqc * 4), *dFallback = (uint32_t *) dev_scratch("pf_ffallback", (size_t) nqc * 4);
             uint32_t *dOvf = (uint32_t *) dev_scratch("pf_fovf", (size_t) nqc * 4 * N_TIERS);
             uint32_t *dTier = (uint32_t *) dev_scratch("pf_tierplan", (2 * TIER_BINS + 16 + 4) * 4);      // hist, cursor, info, statistics (a double)
@@ -2537,13 +2570,16 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             }
             {
                 const uint64_t pb = qOff[q0], pe = qOff[q1];
-                PCHK(hipMemsetAsync(dQK, 0, (size_t) nqc * 4, stream));
                 PCHK(hipMemsetAsync(dTier, 0, (2 * TIER_BINS + 16 + 4) * 4, stream));
-                if (pe > pb) {
-                    const int th = tb("kmer_count", 5.0 * (double) (pe - pb), 0);
-                    hipLaunchKernelGGL(kmer_count_kernel, dim3((unsigned) (((pe - pb + WAVE - 1) / WAVE + 3) / 4)), dim3(256), 0, stream, V, pb, pe, q0, dQK, dPosCost);
-                    te(th);
-                    PCHK(hipGetLastError());
+                if (haveAhead) PCHK(hipStreamWaitEvent(stream, ahead.done, 0));           // the counts were computed beside the previous chunk's tiers
+                else {
+                    PCHK(hipMemsetAsync(dQK, 0, (size_t) nqc * 4, stream));
+                    if (pe > pb) {
+                        const int th = tb("kmer_count", 5.0 * (double) (pe - pb), 0);
+                        hipLaunchKernelGGL(kmer_count_kernel, dim3((unsigned) (((pe - pb + WAVE - 1) / WAVE + 3) / 4)), dim3(256), 0, stream, V, pb, pe, q0, dQK, dPosCost);
+                        te(th);
+                        PCHK(hipGetLastError());
+                    }
                 }
                 TierPlan T;
                 T.qk = dQK; T.q_off = V.q_off; T.q0 = q0; T.nqc = nqc;
@@ -2588,6 +2624,19 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                     launch_stream(tierBase + t, A, launch, stream);
                     te(thFused[t]);
                     PCHK(hipGetLastError());
+                }
+            }
+            if (sideStream && q1 < nq) {
+                const uint32_t n1 = chunk_end(q1, QCAP);
+                uint32_t *dQKn = nullptr; uint16_t *dPosn = nullptr;
+                count_buffers(1 - countSet, n1 - q1, qOff[n1] - qOff[q1], dQKn, dPosn);
+                if (dQKn && dPosn) {
+                    const uint64_t pb = qOff[q1], pe = qOff[n1];
+                    PCHK(hipMemsetAsync(dQKn, 0, (size_t) (n1 - q1) * 4, sideStream));
+                    if (pe > pb) hipLaunchKernelGGL(kmer_count_kernel, dim3((unsigned) (((pe - pb + WAVE - 1) / WAVE + 3) / 4)), dim3(256), 0, sideStream, V, pb, pe, q1, dQKn, dPosn);
+                    PCHK(hipGetLastError());
+                    PCHK(hipEventRecord(ahead.done, sideStream));
+                    ahead.valid = true; ahead.q0 = q1; ahead.q1 = n1; ahead.set = 1 - countSet;
                 }
             }
             // the counts of the assignment, the statistics and the head of the two lists the global path takes (its own and what the largest tier

@@ -742,9 +742,13 @@ hipError_t launch_sw(const SwLaunch &L, int cfg, hipStream_t stream) {
         case 128: return launch_one<16, 8, MK_SW_POS_BLOCK_S>(L, stream);
         case 192:
         case 256: return launch_one<16, 16, MK_SW_POS_BLOCK_L>(L, stream);
-        case 384: return launch_one<32, 12, MK_SW_POS_BLOCK_L>(L, stream);
-        case 512: return launch_one<32, 16, MK_SW_POS_BLOCK_L>(L, stream);
-        case 768: return launch_one<64, 12, MK_SW_POS_BLOCK_L>(L, stream);
+        // narrow (profile queries against ORF fragments: ~40 columns): half the lanes per DP, twice the rows per lane -- the ramp of G - 1 steps is most of
+        // a 40-column DP on 32 / 64 lanes (71 / 103 steps, rounded to blocks of 16: 80 / 112) and the hand-over between lanes costs the same per step
+        // whatever the rows: 1.3-1.5 x fewer lane-instructions per job (position / reverse pass, per-job profiles; one-wave workgroups keep the LDS per
+        // workgroup at 4 profiles)
+        case 384: return (L.narrow && !L.wave_start) ? launch_one<16, 24, 64>(L, stream) : launch_one<32, 12, MK_SW_POS_BLOCK_L>(L, stream);
+        case 512: return (L.narrow && !L.wave_start) ? launch_one<16, 32, 64>(L, stream) : launch_one<32, 16, MK_SW_POS_BLOCK_L>(L, stream);
+        case 768: return (L.narrow && !L.wave_start) ? launch_one<32, 24, 64>(L, stream) : launch_one<64, 12, MK_SW_POS_BLOCK_L>(L, stream);
         case 1024: return launch_one<64, 16, MK_SW_POS_BLOCK_L>(L, stream);
         default: return hipErrorInvalidValue;
     }
