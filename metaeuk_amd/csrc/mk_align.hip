@@ -639,7 +639,6 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
         L.boundary = nullptr; L.boundary_stride = 0; L.boundary_job0 = 0;
         L.wave_start = nullptr; L.n_waves = 0; L.work_counter = nullptr; L.persistent_blocks = 0; L.units_per_block = 0; L.known_score = nullptr;
         L.gap_open = P.gap_open; L.gap_extend = P.gap_extend;
-        L.narrow = S.narrowForce >= 0 ? S.narrowForce != 0 : V.q_prof != nullptr;      // profile queries meet short targets (ORF fragments)
         if (c == SW_NCFG - 1 && V.max_q_len > (uint32_t) sw_cfg_rows(c)) {
             const uint32_t cls = KEY_CLS - 1 - (hb[32 + c] % KEY_CLS);          // largest target-length class in this bucket
             const uint32_t stride = std::min<uint32_t>(V.max_t_len, (cls + 1) * 16);

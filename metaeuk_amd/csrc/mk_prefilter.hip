@@ -2509,19 +2509,9 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
         else want = std::min<uint32_t>(want, 1u << 16);                    // nothing known yet: a small probe chunk
         return (uint32_t) std::min<uint64_t>(nq, (uint64_t) from + std::max<uint32_t>(want, 1));
     };
-    // Round 5: the similar-k-mer count of the NEXT chunk (kmer_count_kernel: a sizing pass that reads the queries and the 3-mer histograms only) runs
-    // on a side stream while the tier kernels of this chunk run -- it was 33-36 ms per config-2 step at the head of a chain that IS the step
-    // (DESIGN 4.3).  Two sets of count buffers; the next chunk takes the counts when its range is the predicted one.  MK_PREFILTER_COUNT_AHEAD=0: off
-    struct CountAhead { bool valid = false; uint32_t q0 = 0, q1 = 0; int set = 0; hipEvent_t done = nullptr; } ahead;
-    static const bool countAheadOn = knob_long("MK_PREFILTER_COUNT_AHEAD", 1) != 0;
-    static thread_local hipStream_t sideStream = nullptr;
-    if (countAheadOn && useFused && !sideStream && hipStreamCreateWithFlags(&sideStream, hipStreamNonBlocking) != hipSuccess) sideStream = nullptr;
-    if (sideStream) PCHK(hipEventCreateWithFlags(&ahead.done, hipEventDisableTiming));
-    struct EventGuard { hipEvent_t &e; ~EventGuard() { if (e) (void) hipEventDestroy(e); } } aheadGuard{ahead.done};
-    const auto count_buffers = [&](int set, uint32_t nQueries, uint64_t nPositions, uint32_t *&dQKout, uint16_t *&dPosOut) {
-        dPosOut = (uint16_t *) dev_scratch(set ? "pf_poscost1" : "pf_poscost", (size_t) (nPositions + 16) * 2);
-        dQKout = (uint32_t *) dev_scratch(set ? "pf_qkmers1" : "pf_qkmers", (size_t) nQueries * 4);
-    };
+    // (Measured in round 5 and not kept: the similar-k-mer count of the NEXT chunk on a side stream beside this chunk's tier kernels -- 36 ms per step
+    //  off the head of the prefilter chain, and the step 852-862 against 838-844 ms: the sizing kernel slows the largest tier by more than it saves,
+    //  profiles/r05_prefilter_tiers.txt.)
     while (q0 < nq) {
         const uint32_t q1 = chunk_end(q0, chunkLimit);
         const uint32_t nqc = q1 - q0;
@@ -2542,15 +2532,8 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             // similar-k-mer count per query (exact, kmer_count_kernel) -> expected index hits -> tier, all on the device (tier_*_kernel): nothing
             // between the count and the tiers' launches waits for the host
             constexpr uint32_t LIST_PEEK = 4096;                                 // entries of the global path's two lists fetched with the counters
-            const bool haveAhead = ahead.valid && ahead.q0 == q0 && ahead.q1 >= q1;
-            const int countSet = haveAhead ? ahead.set : 0;
-            // (counts made ahead for another range -- a chunk that was retried smaller -- are dropped; their kernel must be off the buffers first)
-            if (ahead.valid && !haveAhead) PCHK(hipStreamWaitEvent(stream, ahead.done, 0));
-            ahead.valid = false;
-            uint16_t *dPosCost = nullptr;
-            uint32_t *dQK = nullptr;
-            if (haveAhead) count_buffers(countSet, ahead.q1 - ahead.q0, qOff[ahead.q1] - qOff[ahead.q0], dQK, dPosCost);      // (sized when they were filled)
-            else count_buffers(0, nqc, qOff[q1] - qOff[q0], dQK, dPosCost);
+            uint16_t *dPosCost = (uint16_t *) dev_scratch("pf_poscost", (size_t) (qOff[q1] - qOff[q0] + 16) * 2);
+            uint32_t *dQK = (uint32_t *) dev_scratch("pf_qkmers", (size_t) nqc * 4);
             PNULL(dPosCost);
             uint32_t *dList = (uint32_t *) dev_scratch("pf_flist", (size_t) nqc * 4), *dFallback = (uint32_t *) dev_scratch("pf_ffallback", (size_t) nqc * 4);
             uint32_t *dOvf = (uint32_t *) dev_scratch("pf_fovf", (size_t) nqc * 4 * N_TIERS);
@@ -2571,15 +2554,12 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             {
                 const uint64_t pb = qOff[q0], pe = qOff[q1];
                 PCHK(hipMemsetAsync(dTier, 0, (2 * TIER_BINS + 16 + 4) * 4, stream));
-                if (haveAhead) PCHK(hipStreamWaitEvent(stream, ahead.done, 0));           // the counts were computed beside the previous chunk's tiers
-                else {
-                    PCHK(hipMemsetAsync(dQK, 0, (size_t) nqc * 4, stream));
-                    if (pe > pb) {
-                        const int th = tb("kmer_count", 5.0 * (double) (pe - pb), 0);
-                        hipLaunchKernelGGL(kmer_count_kernel, dim3((unsigned) (((pe - pb + WAVE - 1) / WAVE + 3) / 4)), dim3(256), 0, stream, V, pb, pe, q0, dQK, dPosCost);
-                        te(th);
-                        PCHK(hipGetLastError());
-                    }
+                PCHK(hipMemsetAsync(dQK, 0, (size_t) nqc * 4, stream));
+                if (pe > pb) {
+                    const int th = tb("kmer_count", 5.0 * (double) (pe - pb), 0);
+                    hipLaunchKernelGGL(kmer_count_kernel, dim3((unsigned) (((pe - pb + WAVE - 1) / WAVE + 3) / 4)), dim3(256), 0, stream, V, pb, pe, q0, dQK, dPosCost);
+                    te(th);
+                    PCHK(hipGetLastError());
                 }
                 TierPlan T;
                 T.qk = dQK; T.q_off = V.q_off; T.q0 = q0; T.nqc = nqc;
@@ -2624,19 +2604,6 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                     launch_stream(tierBase + t, A, launch, stream);
                     te(thFused[t]);
                     PCHK(hipGetLastError());
-                }
-            }
-            if (sideStream && q1 < nq) {
-                const uint32_t n1 = chunk_end(q1, QCAP);
-                uint32_t *dQKn = nullptr; uint16_t *dPosn = nullptr;
-                count_buffers(1 - countSet, n1 - q1, qOff[n1] - qOff[q1], dQKn, dPosn);
-                if (dQKn && dPosn) {
-                    const uint64_t pb = qOff[q1], pe = qOff[n1];
-                    PCHK(hipMemsetAsync(dQKn, 0, (size_t) (n1 - q1) * 4, sideStream));
-                    if (pe > pb) hipLaunchKernelGGL(kmer_count_kernel, dim3((unsigned) (((pe - pb + WAVE - 1) / WAVE + 3) / 4)), dim3(256), 0, sideStream, V, pb, pe, q1, dQKn, dPosn);
-                    PCHK(hipGetLastError());
-                    PCHK(hipEventRecord(ahead.done, sideStream));
-                    ahead.valid = true; ahead.q0 = q1; ahead.q1 = n1; ahead.set = 1 - countSet;
                 }
             }
             // the counts of the assignment, the statistics and the head of the two lists the global path takes (its own and what the largest tier

@@ -742,13 +742,12 @@ hipError_t launch_sw(const SwLaunch &L, int cfg, hipStream_t stream) {
         case 128: return launch_one<16, 8, MK_SW_POS_BLOCK_S>(L, stream);
         case 192:
         case 256: return launch_one<16, 16, MK_SW_POS_BLOCK_L>(L, stream);
-        // narrow (profile queries against ORF fragments: ~40 columns): half the lanes per DP, twice the rows per lane -- the ramp of G - 1 steps is most of
-        // a 40-column DP on 32 / 64 lanes (71 / 103 steps, rounded to blocks of 16: 80 / 112) and the hand-over between lanes costs the same per step
-        // whatever the rows: 1.3-1.5 x fewer lane-instructions per job (position / reverse pass, per-job profiles; one-wave workgroups keep the LDS per
-        // workgroup at 4 profiles)
-        case 384: return (L.narrow && !L.wave_start) ? launch_one<16, 24, 64>(L, stream) : launch_one<32, 12, MK_SW_POS_BLOCK_L>(L, stream);
-        case 512: return (L.narrow && !L.wave_start) ? launch_one<16, 32, 64>(L, stream) : launch_one<32, 16, MK_SW_POS_BLOCK_L>(L, stream);
-        case 768: return (L.narrow && !L.wave_start) ? launch_one<32, 24, 64>(L, stream) : launch_one<64, 12, MK_SW_POS_BLOCK_L>(L, stream);
+        // (Measured in round 5 and not kept: half the lanes per DP and twice the rows per lane for profile queries against ~40-column fragments --
+        //  <16,24> / <16,32> / <32,24>: 1.3-1.5 x fewer lane-instructions per job on paper, 152-192 VGPRs in fact, and the config-4 pass 1.20-1.22 s against
+        //  1.13-1.15 s (position pass 1 620 against 1 200 ms of kernel time): occupancy, not the ramp, is what these kernels live on.)
+        case 384: return launch_one<32, 12, MK_SW_POS_BLOCK_L>(L, stream);
+        case 512: return launch_one<32, 16, MK_SW_POS_BLOCK_L>(L, stream);
+        case 768: return launch_one<64, 12, MK_SW_POS_BLOCK_L>(L, stream);
         case 1024: return launch_one<64, 16, MK_SW_POS_BLOCK_L>(L, stream);
         default: return hipErrorInvalidValue;
     }
