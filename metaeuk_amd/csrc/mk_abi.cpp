@@ -1595,7 +1595,13 @@ void engine_prefilter_thread(SearchEngine *Ep, int idx) {
             while (lim > (1u << 16) && (uint64_t) lim * 6 > (uint64_t) q->n) lim >>= 1;
             hooks.max_chunk_queries = lim;
         }
-        hooks.chunk_ramp = true;
+        // the ramp (first chunks of 1/4 and 1/2 of the limit) lets the alignment stage start early on a batch that arrives at an idle engine; when
+        // another batch is still in flight the workers are busy with its tail anyway and the small chunks only cost launches: 120.5 -> 111.6 ms per
+        // 251 601-fragment shard, 231 -> 215-221 ms at 502 351, 836.8 -> 831.1 ms for the full batch (queued, profiles/r05_search_engine.txt)
+        {
+            std::lock_guard<std::mutex> lk(E.m);
+            hooks.chunk_ramp = E.unfinished <= 1;
+        }
         hooks.co_resident = true;
         hooks.t_masked_host = [db]() { return masked_host(db); };
         q->pfStats = mk::PrefilterStats();
