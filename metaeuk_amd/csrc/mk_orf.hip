@@ -7,13 +7,14 @@
 // Layout: contigs stay as the caller's ASCII in HBM; nothing is copied or reverse-complemented -- the minus strand is an
 // index transform + complement lookup.  Three kernels:
 //   orf_mark_kernel          one lane per strand position: does a fragment end here, and how many codons has it
-//   prefix sums (hipcub)     rank of every fragment = the reference's output order (= the renumbered ORF ids), residue offsets
+//   orf_scan_*_kernel        two prefix sums in one pass (fragments, residues): the rank of every fragment = the reference's output order
+//                            (= the renumbered ORF ids) and its residue offset
 //   orf_write_kernel         one record per fragment at its rank
 //   orf_translate_kernel     one lane per amino acid: codon -> residue (ASCII, case preserved) and aa2num code
 // The fragment codes stay in HBM and become the query batch of mk_search without a host round trip.
 #include "mk_orf.hpp"
 #include "mk_kernels.hpp"
-#include <hipcub/hipcub.hpp>
+#include "mk_segsort.hpp"
 #include <climits>
 #include <cstring>
 
@@ -111,8 +112,62 @@ __global__ __launch_bounds__(256) void orf_write_kernel(OrfScanArgs A, uint64_t 
     A.aa_off[rank[x]] = aaBase[x];
 }
 
-struct NonZero { __host__ __device__ uint64_t operator()(uint16_t v) const { return v ? 1ull : 0ull; } };
-struct Widen { __host__ __device__ uint64_t operator()(uint16_t v) const { return (uint64_t) v; } };
+// ---- the two exclusive prefix sums over the strand positions -- fragments ending at or before a position (its rank) and their residues (its
+// offset) -- in one pass of two sweeps: 4096 positions per workgroup (16 per thread), the workgroups' sums in 64 bits, the rest in 32
+// (a workgroup holds at most 4096 x 65535 residues).  [n] of both outputs = the totals.
+constexpr uint32_t ORF_SCAN_TILE = 4096;
+__global__ __launch_bounds__(256) void orf_scan_sums_kernel(const uint16_t *naa, uint64_t n, uint64_t *blockSums /* [2 * blocks] */) {
+    __shared__ uint32_t sm[2 * 16];
+    const uint64_t i0 = (uint64_t) blockIdx.x * ORF_SCAN_TILE + (uint64_t) threadIdx.x * 16u;
+    uint32_t v[2] = {0, 0}, excl[2], total[2];
+    for (uint32_t k = 0; k < 16; k++) if (i0 + k < n) { const uint32_t x = naa[i0 + k]; v[0] += x ? 1u : 0u; v[1] += x; }
+    segsort::block_scan<2>(v, excl, total, sm);
+    if (threadIdx.x == 0) { blockSums[2 * (size_t) blockIdx.x] = total[0]; blockSums[2 * (size_t) blockIdx.x + 1] = total[1]; }
+}
+// one workgroup: exclusive scan of the workgroups' sums in place, the grand totals behind them ([2 * blocks], [2 * blocks + 1])
+__global__ __launch_bounds__(1024) void orf_scan_blocks_kernel(uint64_t *blockSums, uint32_t blocks) {
+    __shared__ uint64_t sCarry[2];
+    __shared__ uint64_t sWave[2][16];
+    if (threadIdx.x == 0) { sCarry[0] = 0; sCarry[1] = 0; }
+    __syncthreads();
+    const int lane = (int) (threadIdx.x & 63u), w = (int) (threadIdx.x >> 6);
+    for (uint32_t b0 = 0; b0 < blocks; b0 += 1024) {
+        const uint32_t b = b0 + threadIdx.x;
+        uint64_t v[2] = {b < blocks ? blockSums[2 * (size_t) b] : 0ull, b < blocks ? blockSums[2 * (size_t) b + 1] : 0ull}, inc[2];
+        for (int k = 0; k < 2; k++) {
+            uint64_t x = v[k];
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t lo = (uint32_t) __shfl_up((int) (uint32_t) x, d, 64), hi = (uint32_t) __shfl_up((int) (uint32_t) (x >> 32), d, 64);
+                if (lane >= d) x += ((uint64_t) hi << 32) | lo;
+            }
+            inc[k] = x;
+            if (lane == 63) sWave[k][w] = x;
+        }
+        __syncthreads();
+        for (int k = 0; k < 2; k++) {
+            uint64_t base = sCarry[k];
+            for (int i = 0; i < w; i++) base += sWave[k][i];
+            if (b < blocks) blockSums[2 * (size_t) b + k] = base + inc[k] - v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) for (int k = 0; k < 2; k++) { uint64_t t = 0; for (int i = 0; i < 16; i++) t += sWave[k][i]; sCarry[k] += t; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { blockSums[2 * (size_t) blocks] = sCarry[0]; blockSums[2 * (size_t) blocks + 1] = sCarry[1]; }
+}
+__global__ __launch_bounds__(256) void orf_scan_apply_kernel(const uint16_t *naa, uint64_t n, const uint64_t *blockSums, uint32_t blocks, uint64_t *rank, uint64_t *aaBase) {
+    __shared__ uint32_t sm[2 * 16];
+    const uint64_t i0 = (uint64_t) blockIdx.x * ORF_SCAN_TILE + (uint64_t) threadIdx.x * 16u;
+    uint32_t x[16], v[2] = {0, 0}, excl[2], total[2];
+    for (uint32_t k = 0; k < 16; k++) { x[k] = i0 + k < n ? (uint32_t) naa[i0 + k] : 0u; v[0] += x[k] ? 1u : 0u; v[1] += x[k]; }
+    segsort::block_scan<2>(v, excl, total, sm);
+    uint64_t r = blockSums[2 * (size_t) blockIdx.x] + excl[0], a = blockSums[2 * (size_t) blockIdx.x + 1] + excl[1];
+    for (uint32_t k = 0; k < 16; k++) {
+        if (i0 + k < n) { rank[i0 + k] = r; aaBase[i0 + k] = a; }
+        r += x[k] ? 1u : 0u; a += x[k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { rank[n] = blockSums[2 * (size_t) blocks]; aaBase[n] = blockSums[2 * (size_t) blocks + 1]; }
+}
 
 __global__ __launch_bounds__(256) void orf_translate_kernel(OrfScanArgs A, uint64_t nFrag, uint64_t nAa, const char *table /* [4096] */,
                                                             char *aaAscii, uint8_t *aaCode) {
@@ -182,19 +237,15 @@ int run_extract_orfs(const char *dNucl, const uint64_t *dOffsets, uint32_t nCont
     const unsigned blocks = (unsigned) ((nPos + 255) / 256);
     hipLaunchKernelGGL(orf_mark_kernel, dim3(blocks), dim3(256), 0, stream, A, nPos, dNaa);
     OCHK(hipGetLastError());
-    hipcub::TransformInputIterator<uint64_t, NonZero, const uint16_t *> itFlag(dNaa, NonZero());
-    hipcub::TransformInputIterator<uint64_t, Widen, const uint16_t *> itAa(dNaa, Widen());
-    size_t tb = 0, tb2 = 0, tb3 = 0, tb4 = 0;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, tb, itFlag, dRank, (int) nPos, stream);
-    hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, itAa, dAaBase, (int) nPos, stream);
-    hipcub::DeviceReduce::Sum(nullptr, tb3, itFlag, dRank + nPos, (int) nPos, stream);
-    hipcub::DeviceReduce::Sum(nullptr, tb4, itAa, dAaBase + nPos, (int) nPos, stream);
-    void *temp = dev_scratch("orf_temp", std::max(std::max(tb, tb2), std::max(tb3, tb4)));
-    ONULL(temp);
-    OCHK(hipcub::DeviceScan::ExclusiveSum(temp, tb, itFlag, dRank, (int) nPos, stream));
-    OCHK(hipcub::DeviceScan::ExclusiveSum(temp, tb2, itAa, dAaBase, (int) nPos, stream));
-    OCHK(hipcub::DeviceReduce::Sum(temp, tb3, itFlag, dRank + nPos, (int) nPos, stream));
-    OCHK(hipcub::DeviceReduce::Sum(temp, tb4, itAa, dAaBase + nPos, (int) nPos, stream));
+    {
+        const uint32_t sb = (uint32_t) ((nPos + ORF_SCAN_TILE - 1) / ORF_SCAN_TILE);
+        uint64_t *dBlockSums = (uint64_t *) dev_scratch("orf_scansums", ((size_t) sb + 1) * 16);
+        ONULL(dBlockSums);
+        hipLaunchKernelGGL(orf_scan_sums_kernel, dim3(sb), dim3(256), 0, stream, (const uint16_t *) dNaa, nPos, dBlockSums);
+        hipLaunchKernelGGL(orf_scan_blocks_kernel, dim3(1), dim3(1024), 0, stream, dBlockSums, sb);
+        hipLaunchKernelGGL(orf_scan_apply_kernel, dim3(sb), dim3(256), 0, stream, (const uint16_t *) dNaa, nPos, (const uint64_t *) dBlockSums, sb, dRank, dAaBase);
+        OCHK(hipGetLastError());
+    }
     OCHK(hipMemcpyAsync(hTotals, dRank + nPos, 8, hipMemcpyDeviceToHost, stream));
     OCHK(hipMemcpyAsync(hTotals + 1, dAaBase + nPos, 8, hipMemcpyDeviceToHost, stream));
     OCHK(hipStreamSynchronize(stream));
