@@ -53,3 +53,38 @@ def test_native_generator_does_not_depend_on_the_thread_count():
         env = dict(os.environ, OMP_NUM_THREADS=threads)
         outs.append(subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip())
     assert outs[0] == outs[1] and len(outs[0]) == 64
+
+
+def test_native_seqdb_writer_equals_the_python_writer(tmp_path):
+    """mk_synth_write_seqdb (the streaming writer the 60 M-protein tests use) writes byte for byte what api.write_seq_db writes from the in-memory
+    image, in pieces of 2^20 sequences (a piece boundary is crossed here with empty and one-residue sequences around it), and the line file the
+    reference harness reads"""
+    from metaeuk_amd import api
+    res, off = api.synth_targets(3000, seed=11)
+    # ragged: an empty sequence and a one-residue sequence in front
+    res2 = np.concatenate([np.array([4], dtype=np.uint8), res])
+    off2 = np.concatenate([np.array([0, 0, 1], dtype=np.uint64), off[1:] + 1]).astype(np.uint64)
+    api.synth_write_seqdb(str(tmp_path / "T"), res2, off2, with_lines=True)
+    api.write_seq_db(str(tmp_path / "P"), api.synth_seqdb(res2, off2))
+    for sfx in ("", ".index", ".dbtype"):
+        assert open(str(tmp_path / "T") + sfx, "rb").read() == open(str(tmp_path / "P") + sfx, "rb").read(), sfx
+    lines = open(str(tmp_path / "T.txt")).read().split("\n")
+    assert len(lines) == len(off2) and lines[0] == "" and lines[1] == "F" and len(lines[2]) == int(off2[3] - off2[2])
+
+
+def test_config5_fragment_sets_are_reproducible():
+    """tools/config5_digest.make_fragments: the planted fragments followed by the long ones, the same bytes for the digest tool (reference side) and
+    the test (product side)"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import config5_digest as c5
+    from metaeuk_amd import api
+    res, off = api.synth_targets(5000, seed=c5.TARGET_SEED)
+    a = c5.make_fragments(api, res, off, 300, 20)
+    b = c5.make_fragments(api, res, off, 300, 20)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    fr, foff, src = a
+    assert len(foff) == 321 and len(src) == 320 and int(foff[-1]) == len(fr)
+    lens = np.diff(foff.astype(np.int64))
+    assert lens[:300].max() <= 120 and lens[300:].min() >= 150 and lens[300:].max() <= 1500     # (a long fragment is cut at its target's end)
+    short_only = c5.make_fragments(api, res, off, 300, 0)
+    assert np.array_equal(short_only[0][:int(short_only[1][-1])], fr[:int(foff[300])])
