@@ -145,6 +145,17 @@ void dev_pool_free(void *p, size_t cap) {
     if (drop) (void) hipFree(drop);
 }
 
+// every pooled block back to the device (before a database is built -- the index of a UniRef50-scale database takes most of the HBM -- and when an
+// allocation fails)
+void dev_pool_trim() {
+    std::vector<DevPoolBlock> drop;
+    {
+        std::lock_guard<std::mutex> g(g_devPoolMutex);
+        drop.swap(g_devPool);
+    }
+    for (DevPoolBlock &b : drop) (void) hipFree(b.p);
+}
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr; size_t n = 0;
@@ -163,7 +174,14 @@ struct DevBuf {
             p = reinterpret_cast<T *>(dev_pool_alloc(count * sizeof(T), &poolCap));
             return p ? hipSuccess : hipErrorOutOfMemory;
         }
-        return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        if (e != hipSuccess) {                                // the pool of the query batches may hold what is missing
+            (void) hipGetLastError();
+            p = nullptr;
+            dev_pool_trim();
+            e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        }
+        return e;
     }
     hipError_t upload(const T *h, size_t count, hipStream_t stream = nullptr) {
         hipError_t e = alloc(count);
@@ -500,6 +518,7 @@ static void adopt_index(mk_targetdb *db, mk::DeviceIndex &ix, uint64_t total) {
 // target side: matrices, tables, masking + k-mer index (built in HBM, or taken from an index DB), upload
 static int targetdb_create(const uint8_t *residues, const uint64_t *offsets, uint32_t n, const mk_params *P, const PrebuiltIndex *prebuilt, mk_targetdb **out,
                            bool noIndex = false) {
+    dev_pool_trim();                                     // (a database is built rarely and may need every byte)
     int rc = ensure_ready();
     if (rc) return rc;
     if (!residues || !offsets || !P || !out) return fail(MK_ERR_ARG, "null argument");
