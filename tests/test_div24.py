@@ -39,3 +39,25 @@ def test_the_division_reproducer_behaves_as_modelled():
     assert r.returncode in (0, 3), out
     if r.returncode == 3:
         assert "n = 11: device wrong for" in out and "n = 16: device wrong for        0" in out, out
+
+
+def test_host_model_of_the_division_sequence_matches_what_the_device_returned():
+    """The emitted sequence -- fq = trunc(float(y) * rcp(float(n))), fr = fma(-fq, n, y), q = fq + (|fr| >= n), r = (y - q n) & 0xFFFFFF -- modelled in numpy
+    float32 with a correctly rounded reciprocal: for n = 11, 44, 46, 57 it returns a wrong remainder for exactly as many of the 2^24 numerators as the
+    MI355X did (profiles/r05_urem24_reproducer.txt), every one of them with true remainder n - 1 in the upper part of the range; for powers of two
+    and for 10 (whose reciprocal rounds down) it is exact."""
+    import numpy as np
+    y = np.arange(1 << 24, dtype=np.uint32)
+    fa = y.astype(np.float32)
+    device_counts = {11: 476625, 44: 119156, 46: 36473, 57: 32193, 2: 0, 10: 0, 16: 0, 64: 0, 80: 0}
+    for n, expected in device_counts.items():
+        fb = np.float32(n)
+        rc = np.float32(1.0) / fb
+        fq = np.trunc(fa * rc).astype(np.float32)
+        fr = fa.astype(np.float64) - fq.astype(np.float64) * float(n)           # the fma is exact on these operands
+        q = fq.astype(np.uint32) + (np.abs(fr) >= float(n)).astype(np.uint32)
+        r = (y - q * np.uint32(n)) & np.uint32(0xFFFFFF)
+        bad = np.flatnonzero(r != y % np.uint32(n))
+        assert len(bad) == expected, (n, len(bad))
+        if len(bad):
+            assert np.all(y[bad] % n == n - 1) and int(y[bad].min()) >= (1 << 22) and np.all(r[bad] == 0xFFFFFF)
