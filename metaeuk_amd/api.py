@@ -43,7 +43,7 @@ HIT_DTYPE = np.dtype([("seq_id", "<u4"), ("pref_score", "<i4"), ("diagonal", "<u
 EXPORTS = ["mk_init", "mk_last_error", "mk_default_params", "mk_device_name", "mk_encode", "mk_targetdb_create",
            "mk_targetdb_destroy", "mk_targetdb_residues", "mk_targetdb_index_entries", "mk_targetdb_masked",
            "mk_queries_create", "mk_queries_destroy", "mk_queries_derived", "mk_prefilter", "mk_prefilter_result", "mk_prefilter_result_set",
-           "mk_align", "mk_align_result", "mk_search", "mk_search_begin", "mk_search_wait", "mk_extract_orfs", "mk_orfs_result", "mk_queries_from_orfs",
+           "mk_align", "mk_align_result", "mk_search", "mk_search_begin", "mk_search_wait", "mk_shutdown", "mk_extract_orfs", "mk_orfs_result", "mk_queries_from_orfs",
            "mk_orfs_destroy", "mk_format_orf_header", "mk_sw_pairs", "mk_ungapped",
            "mk_kernel_stats", "mk_kernel_stats_reset", "mk_format_hit", "mk_format_alignment", "mk_format_hits", "mk_format_alignments", "mk_targetdb_set_keys",
            "mk_profiles_create", "mk_profiles_derived", "mk_swap_alignments", "mk_swapped_result", "mk_swapped_destroy",
@@ -524,6 +524,12 @@ def search_wait(q):
     """-> ((hits, hit_offsets), (alignments, aln_offsets)) of a batch begun with search_begin"""
     _chk(lib().mk_search_wait(q.h))
     return prefilter_result(q), align_result(q)
+
+
+def shutdown():
+    """waits for the searches in flight, stops and joins the library's search threads (mk_shutdown); the next search starts them again"""
+    lib().mk_shutdown.restype = None
+    lib().mk_shutdown()
 
 
 def align(db, q, params=None):

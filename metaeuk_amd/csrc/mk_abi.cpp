@@ -114,44 +114,62 @@ struct HostTimer {
 struct DevPoolBlock { void *p; size_t cap; };
 std::vector<DevPoolBlock> g_devPool;
 std::mutex g_devPoolMutex;
+size_t g_devPoolBytes = 0;                               // idle bytes in the pool (under the mutex)
 constexpr size_t DEV_POOL_BLOCKS = 24, DEV_POOL_BLOCK_MAX = 1ull << 30;
+constexpr size_t DEV_POOL_BYTES_MAX = 6ull << 30;       // idle blocks are worth about two batches of the largest shape in use, never more
+void dev_pool_trim();
 void *dev_pool_alloc(size_t bytes, size_t *cap) {
     {
         std::lock_guard<std::mutex> g(g_devPoolMutex);
         int best = -1;
         for (int i = 0; i < (int) g_devPool.size(); i++)
             if (g_devPool[i].cap >= bytes && g_devPool[i].cap <= 2 * bytes + 65536 && (best < 0 || g_devPool[i].cap < g_devPool[best].cap)) best = i;
-        if (best >= 0) { void *p = g_devPool[best].p; *cap = g_devPool[best].cap; g_devPool.erase(g_devPool.begin() + best); return p; }
+        if (best >= 0) {
+            void *p = g_devPool[best].p; *cap = g_devPool[best].cap;
+            g_devPoolBytes -= g_devPool[best].cap;
+            g_devPool.erase(g_devPool.begin() + best);
+            return p;
+        }
     }
     void *p = nullptr;
     const size_t want = bytes + bytes / 16 + 256;
-    if (hipMalloc(&p, want) != hipSuccess) return nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) {                 // the idle blocks may hold what is missing: give them back and ask once more
+        (void) hipGetLastError();
+        dev_pool_trim();
+        p = nullptr;
+        if (hipMalloc(&p, want) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    }
     *cap = want;
     return p;
 }
 void dev_pool_free(void *p, size_t cap) {
-    void *drop = nullptr;
-    if (cap > DEV_POOL_BLOCK_MAX) drop = p;
+    std::vector<void *> drop;
+    if (cap > DEV_POOL_BLOCK_MAX) drop.push_back(p);
     else {
         std::lock_guard<std::mutex> g(g_devPoolMutex);
         g_devPool.push_back(DevPoolBlock{p, cap});
-        if (g_devPool.size() > DEV_POOL_BLOCKS) {            // the smallest block goes
-            int small = 0;
-            for (int i = 1; i < (int) g_devPool.size(); i++) if (g_devPool[i].cap < g_devPool[small].cap) small = i;
-            drop = g_devPool[small].p;
-            g_devPool.erase(g_devPool.begin() + small);
+        g_devPoolBytes += cap;
+        while (g_devPool.size() > DEV_POOL_BLOCKS || (g_devPoolBytes > DEV_POOL_BYTES_MAX && g_devPool.size() > 1)) {
+            // too many blocks: the smallest goes; too many bytes: the OLDEST goes (varying batch sizes leave blocks behind that no later batch fits)
+            int victim = 0;
+            if (g_devPool.size() > DEV_POOL_BLOCKS)
+                for (int i = 1; i < (int) g_devPool.size(); i++) if (g_devPool[i].cap < g_devPool[victim].cap) victim = i;
+            drop.push_back(g_devPool[victim].p);
+            g_devPoolBytes -= g_devPool[victim].cap;
+            g_devPool.erase(g_devPool.begin() + victim);
         }
     }
-    if (drop) (void) hipFree(drop);
+    for (void *d : drop) (void) hipFree(d);
 }
 
 // every pooled block back to the device (before a database is built -- the index of a UniRef50-scale database takes most of the HBM -- and when an
-// allocation fails)
+// allocation fails, here or in the scratch buffers of the stages: mk::dev_pool_release)
 void dev_pool_trim() {
     std::vector<DevPoolBlock> drop;
     {
         std::lock_guard<std::mutex> g(g_devPoolMutex);
         drop.swap(g_devPool);
+        g_devPoolBytes = 0;
     }
     for (DevPoolBlock &b : drop) (void) hipFree(b.p);
 }
@@ -193,6 +211,7 @@ struct DevBuf {
 }  // namespace
 
 namespace mk {
+void dev_pool_release() { dev_pool_trim(); }
 void host_stat(const char *name, double ms) { std::lock_guard<std::mutex> g(g_statsMutex); g_stats[name].ms += ms; }
 hipError_t sync_wait(hipStream_t stream, const char *statName) {
     const double t0 = ScopedHost::now_ms();
@@ -1558,14 +1577,16 @@ struct SearchEngine {
     std::deque<Item> items;                              // finished prefilter chunks of all batches, in order
     int unfinished = 0;                                  // batches begun whose results are not complete yet
     bool started = false;
+    bool stop = false;                                   // (under m) mk_shutdown / process exit: the threads leave their loops
+    std::vector<std::thread> threads;
     int nWorkers = 3;
     int nPrefilter = 1;                                  // MK_PREFILTER_THREADS = 2: the prefilters of two batches at once.  Measured and NOT the default
                                                          // (profiles/r05_search_engine.txt: 923 against 880 ms per config-2 step): the GPU is saturated by one
                                                          // prefilter chain and the alignment workers, two chains only stretch each other
     std::mutex tablesMutex;                              // the databases' score-table caches
 };
-SearchEngine *g_engine = nullptr;                        // never destroyed: its threads sleep on the condition variable until the process ends
-std::once_flag g_engineOnce;
+SearchEngine *g_engine = nullptr;                        // its threads sleep on the condition variable until mk_shutdown or the end of the process
+std::mutex g_engineMutex;                                // creation and shutdown of the engine
 
 void engine_finish_locked(SearchEngine &E, SearchJob *job) {      // (E.m held) prefilter done and no chunk outstanding
     if (job->finished || !job->prefilterDone || job->outstanding != 0) return;
@@ -1586,7 +1607,8 @@ void engine_prefilter_thread(SearchEngine *Ep, int idx) {
         SearchJob *job;
         {
             std::unique_lock<std::mutex> lk(E.m);
-            E.cv.wait(lk, [&] { return !E.batches.empty(); });
+            E.cv.wait(lk, [&] { return E.stop || !E.batches.empty(); });
+            if (E.batches.empty()) return;                 // (stop: only once nothing is queued)
             job = E.batches.front(); E.batches.pop_front();
         }
         mk_targetdb *db = job->db; mk_queries *q = job->q; const mk_params *P = &job->P;
@@ -1679,7 +1701,8 @@ void engine_align_thread(SearchEngine *Ep, int w) {
         SearchEngine::Item it;
         {
             std::unique_lock<std::mutex> lk(E.m);
-            E.cv.wait(lk, [&] { return !E.items.empty(); });
+            E.cv.wait(lk, [&] { return E.stop || !E.items.empty(); });
+            if (E.items.empty()) return;
             it = E.items.front(); E.items.pop_front();
         }
         SearchJob *job = it.job;
@@ -1707,24 +1730,51 @@ void engine_align_thread(SearchEngine *Ep, int w) {
     }
 }
 
+// Drains the engine (every batch begun is finished), stops and joins its threads.  Registered with atexit when the engine starts -- a host that
+// exits between mk_search_begin and mk_search_wait (an exception, an interpreter shutting down) must not leave threads behind that use the
+// statistics map, the scratch buffers and the HIP runtime while the process tears them down -- and callable as mk_shutdown.
+void engine_shutdown() {
+    SearchEngine *E;
+    {
+        std::lock_guard<std::mutex> g(g_engineMutex);
+        E = g_engine;
+        g_engine = nullptr;
+    }
+    if (!E) return;
+    {
+        std::unique_lock<std::mutex> lk(E->m);
+        E->cv.wait(lk, [&] { return E->unfinished == 0; });
+        E->stop = true;
+    }
+    E->cv.notify_all();
+    for (std::thread &t : E->threads) if (t.joinable()) t.join();
+    delete E;
+}
+
 SearchEngine *engine_ptr() {
-    std::call_once(g_engineOnce, [] {
-        g_engine = new SearchEngine();
-        g_engine->nWorkers = std::min(MAX_ALIGN_WORKERS, std::max(1, (int) mk::knob_long("MK_ALIGN_WORKERS", 3)));
-        g_engine->nPrefilter = std::min(2, std::max(1, (int) mk::knob_long("MK_PREFILTER_THREADS", 1)));
-        for (int k = 0; k < g_engine->nPrefilter; k++) std::thread(engine_prefilter_thread, g_engine, k).detach();
-        for (int w = 0; w < g_engine->nWorkers; w++) std::thread(engine_align_thread, g_engine, w).detach();
-        g_engine->started = true;
-    });
+    std::lock_guard<std::mutex> g(g_engineMutex);
+    if (!g_engine) {
+        SearchEngine *E = new SearchEngine();
+        E->nWorkers = std::min(MAX_ALIGN_WORKERS, std::max(1, (int) mk::knob_long("MK_ALIGN_WORKERS", 3)));
+        E->nPrefilter = std::min(2, std::max(1, (int) mk::knob_long("MK_PREFILTER_THREADS", 1)));
+        for (int k = 0; k < E->nPrefilter; k++) E->threads.emplace_back(engine_prefilter_thread, E, k);
+        for (int w = 0; w < E->nWorkers; w++) E->threads.emplace_back(engine_align_thread, E, w);
+        E->started = true;
+        static bool registered = false;
+        if (!registered) { registered = true; atexit(engine_shutdown); }
+        g_engine = E;
+    }
     return g_engine;
 }
 
 // every batch begun so far has its results complete (not necessarily collected): what the blocking entry points wait for before they
 // use the library's streams and scratch buffers themselves
 void engine_drain_if_running() {
-    if (!g_engine) return;
-    std::unique_lock<std::mutex> lk(g_engine->m);
-    g_engine->cv.wait(lk, [&] { return g_engine->unfinished == 0; });
+    SearchEngine *E;
+    { std::lock_guard<std::mutex> g(g_engineMutex); E = g_engine; }
+    if (!E) return;
+    std::unique_lock<std::mutex> lk(E->m);
+    E->cv.wait(lk, [&] { return E->unfinished == 0; });
 }
 
 }  // namespace
@@ -1767,6 +1817,8 @@ int mk_search_wait(mk_queries *q) {
     delete job;
     return rc;
 }
+
+void mk_shutdown(void) { engine_shutdown(); }
 
 int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     const int rc = mk_search_begin(db, q, P);

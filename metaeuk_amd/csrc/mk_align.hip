@@ -534,9 +534,10 @@ struct AlignShapes {
     bool multiLargeFirst = true;             // MK_SW_MULTI_LARGE_FIRST=0: the register classes of the position / reverse passes small tiles first
     bool multiPrio = true;                   // MK_SW_MULTI_PRIO=0: the persistent position / reverse workgroups do not ask for issue priority
     uint32_t multiPerCu[3] = {24, 12, 12};   // MK_SW_MULTI_WAVES: one-wave workgroups per CU of the three register classes (<= 64, 96 .. 256, >= 384 rows)
-    bool earlyExit = true;                   // MK_SW_EARLY_EXIT=0: the position / reverse passes run every column of their jobs (no bound from the score
-                                             // pass, no stop at the known score)
 };
+// MK_SW_EARLY_EXIT=0 (MK_DEBUG=1): the position / reverse passes run every column of their jobs (no bound from the score pass, no stop at the known
+// score).  Read per call, like MK_SW_MULTI, so that one process can compare both forms (tests/test_gpu_parity.py::test_full_dp_position_passes...)
+static bool sw_early_exit() { return knob_long("MK_SW_EARLY_EXIT", 1) != 0; }
 static const AlignShapes &align_shapes() {
     static AlignShapes S;
     static std::once_flag once;
@@ -563,7 +564,6 @@ static const AlignShapes &align_shapes() {
         S.knownForce = (int) knob_long("MK_SW_KNOWN", -1);
         S.knownWaves = (int) std::max(1L, knob_long("MK_SW_KNOWN_WAVES", 12));
         S.narrowForce = (int) knob_long("MK_SW_NARROW", -1);
-        S.earlyExit = knob_long("MK_SW_EARLY_EXIT", 1) != 0;
         S.multiPrio = knob_long("MK_SW_MULTI_PRIO", 1) != 0;
         S.fwdLargeFirst = knob_long("MK_SW_FWD_LARGE_FIRST", 0) != 0;
         S.multiLargeFirst = knob_long("MK_SW_MULTI_LARGE_FIRST", 1) != 0;
@@ -612,7 +612,7 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
         L.jobs = jobs; L.out = out; L.n_jobs = n; L.order = order;
         L.boundary = nullptr; L.boundary_stride = 0; L.boundary_job0 = 0;
         L.wave_start = nullptr; L.n_waves = 0; L.work_counter = nullptr; L.persistent_blocks = 0; L.units_per_block = 0;
-        L.known_score = S.earlyExit ? knownScore : nullptr;
+        L.known_score = sw_early_exit() ? knownScore : nullptr;
         L.gap_open = P.gap_open; L.gap_extend = P.gap_extend;
         static const char *clsName[3] = {"rows32_64", "rows96_256", "rows384_1024"};
         static const int clsFirst[3] = {0, 3, 7};
@@ -663,7 +663,7 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
             L.persistent_blocks = (uint32_t) S.cus * (uint32_t) (sw_cfg_rows(c) <= 32 ? S.knownWaves : std::max(1, S.knownWaves / 2));
             ACHK(launch_sw_known(L, c, stream));
         } else {
-            if (S.earlyExit) L.known_score = knownScore;           // sw_unit stops a DP once its known maximum has been seen in a finished column
+            if (sw_early_exit()) L.known_score = knownScore;           // sw_unit stops a DP once its known maximum has been seen in a finished column
             ACHK(launch_sw(L, c, stream));
         }
         te(th);
@@ -821,7 +821,7 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hi
     SwJob *dRevJobs = (SwJob *) dev_scratch("align_revjobs", (size_t) nRev * sizeof(SwJob));
     ANULL(dRevPair); ANULL(dPosJobs); ANULL(dPosScore); ANULL(dKeys); ANULL(dOrder); ANULL(dPosOut); ANULL(dRevOut); ANULL(dRevJobs);
     hipLaunchKernelGGL(gate_emit_kernel, dim3(nGateBlocks), dim3(256), 0, stream, dJobs, dOut, (uint64_t) n, dGate, (const uint32_t *) dGateBlk,
-                       dRevPair, dPosJobs, dKeys, dPosScore, dHist, dPosWork, align_shapes().earlyExit);
+                       dRevPair, dPosJobs, dKeys, dPosScore, dHist, dPosWork, sw_early_exit());
     te(th);
     ACHK(hipGetLastError());
     ACHK(hipMemcpyAsync(hPosWork, dPosWork, 2 * SW_NCFG * 8, hipMemcpyDeviceToHost, stream));
@@ -979,7 +979,12 @@ void *dev_scratch(const char *name, size_t bytes) {
     if (s.p) (void) hipFree(s.p);
     s.p = nullptr; s.cap = 0;
     const size_t want = std::max<size_t>(bytes + bytes / 8, 256);
-    if (hipMalloc(&s.p, want) != hipSuccess) { s.p = nullptr; return nullptr; }
+    if (hipMalloc(&s.p, want) != hipSuccess) {                // the pool of the query batches may sit on what is missing
+        (void) hipGetLastError();
+        dev_pool_release();
+        s.p = nullptr;
+        if (hipMalloc(&s.p, want) != hipSuccess) { (void) hipGetLastError(); s.p = nullptr; return nullptr; }
+    }
     s.cap = want;
     return s.p;
 }

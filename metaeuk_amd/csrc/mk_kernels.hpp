@@ -151,7 +151,8 @@ struct ScopedHost {
 };
 
 // persistent, growable device / pinned-host buffers (one set per process; no hipMalloc on the hot path)
-void *dev_scratch(const char *name, size_t bytes);          // nullptr on allocation failure
+void *dev_scratch(const char *name, size_t bytes);          // nullptr on allocation failure (after the idle query-batch blocks were given back and the request repeated)
+void dev_pool_release();                                    // mk_abi.cpp: every idle block of the query batches' device pool back to the device
 void *pinned_scratch(const char *name, size_t bytes);
 void scratch_release_all();
 void set_scratch_lane(int lane);                            // of the calling thread: lane > 0 gets buffers of its own under the same names (a second worker of one stage)

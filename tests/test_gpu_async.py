@@ -139,3 +139,46 @@ def test_one_launch_per_register_class_equals_the_launches_per_tile_configuratio
     assert sum(len(b[1]) for b in results[("single tile", "1")]) > 1000
     monkeypatch.delenv("MK_SW_MULTI")
     db.close()
+
+
+def test_shutdown_joins_the_search_threads_and_the_next_search_restarts_them(gpu_api):
+    """mk_shutdown (round 6): waits for the batch in flight, stops and joins the engine's threads; the batch stays collectable; the next search
+    starts the threads again and returns the same bytes."""
+    api = gpu_api
+    from metaeuk_amd import synth
+    targets, queries = synth.make_workload(10, 200, seed=43)
+    params = api.default_params()
+    db = api.TargetDB(targets, params)
+    q0 = api.Queries(queries, params)
+    ref = _blocks(api, api.search(db, q0), len(queries))
+    qa = api.Queries(queries, params)
+    api.search_begin(db, qa)
+    api.shutdown()
+    api.shutdown()                                   # idempotent
+    assert _blocks(api, api.search_wait(qa), len(queries)) == ref
+    qb = api.Queries(queries, params)
+    assert _blocks(api, api.search(db, qb), len(queries)) == ref
+    for x in (q0, qa, qb):
+        x.close()
+    db.close()
+
+
+def test_a_process_that_exits_with_a_search_in_flight_ends_cleanly():
+    """the library registers mk_shutdown with atexit when the first search begins: a host that exits between mk_search_begin and mk_search_wait
+    (an exception, an interpreter shutting down) ends with its own exit code -- no hang, no crash in the teardown of the statistics map, the
+    scratch buffers or the HIP runtime under the feet of the engine's threads."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from metaeuk_amd import api, synth\n"
+            "api.init(0)\n"
+            "t, qs = synth.make_workload(30, 400, seed=47)\n"
+            "p = api.default_params(); db = api.TargetDB(t, p); q = api.Queries(qs, p)\n"
+            "api.search_begin(db, q)\n"
+            "print('begun', flush=True)\n"
+            "sys.exit(7)\n") % root
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 7, (r.returncode, r.stderr.decode()[-2000:])
+    assert b"begun" in r.stdout

@@ -87,6 +87,48 @@ def test_sw_stripe_semantics(gpu_api):
     _check_sw(gpu_api, targets, queries, pairs, lb=16, lw=8)
 
 
+def test_full_dp_position_passes_equal_the_early_exit(gpu_api, monkeypatch):
+    """MK_SW_EARLY_EXIT=0 -- the position / reverse passes over EVERY column of their jobs, the reference's literal second and third DP
+    (StripedSmithWaterman.cpp:400-476) -- against the default (the score pass bounds the end column, both passes leave at the known score:
+    DESIGN.md 4.2 item 5): identical mk_alignments, and no forward / position / reverse score mismatch (mk_search would return
+    MK_ERR_SW_MISMATCH).  Inputs: the adversarial pairs of test_sw_stripe_semantics as queries x targets, related pairs of every tile
+    configuration, and a slice of the headline workload."""
+    api = gpu_api
+    from metaeuk_amd import synth
+    rng = random.Random(3)
+    targets, queries = [], []
+    for rep in range(60):
+        a, b, c = _rand_seq(rng, rng.randrange(20, 60)), _rand_seq(rng, rng.randrange(8, 30)), _rand_seq(rng, rng.randrange(20, 60))
+        ins = _rand_seq(rng, rng.randrange(8, 30))
+        queries += [a + b + c, a + c]
+        targets += [a + ins + c]
+    for L in (31, 33, 48, 65, 100, 129, 200, 257, 400, 700, 1025, 1500):
+        base = _rand_seq(rng, L)
+        queries.append(base)
+        for rate, indel in ((0.05, 0.0), (0.2, 0.05), (0.3, 0.1)):
+            targets.append(_rand_seq(rng, rng.randrange(0, 60)) + _mutate(rng, base, rate, indel) + _rand_seq(rng, rng.randrange(0, 60)))
+        # the maximum early in a long target, and twice in one target: the position pass must report the FIRST column that reaches it
+        targets.append(base + _rand_seq(rng, 300))
+        targets.append(base + _rand_seq(rng, 40) + base)
+    cases = [("adversarial", targets, queries)]
+    t2, q2 = synth.make_workload(60, 2000, seed=41)
+    cases.append(("headline slice", t2, q2))
+    for name, T, Q in cases:
+        params = api.default_params()
+        db = api.TargetDB(T, params)
+        got = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("MK_SW_EARLY_EXIT", flag)
+            q = api.Queries(Q, params)
+            (hits, hoff), (alns, aoff) = api.search(db, q)          # (raises on MK_ERR_SW_MISMATCH: the mismatch counter is zero)
+            got[flag] = (int(hoff[-1]), [api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1])) for i in range(len(Q))])
+            q.close()
+        monkeypatch.delenv("MK_SW_EARLY_EXIT")
+        assert got["1"] == got["0"], name
+        assert sum(len(b) for b in got["1"][1]) > 1000, name
+        db.close()
+
+
 def test_ungapped(gpu_api, small_workload):
     import ctypes as C
     targets, queries = small_workload
