@@ -26,6 +26,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import re
 import subprocess
 import sys
 import tempfile
@@ -46,6 +47,11 @@ SW_OPS_PER_CELL_INT32, SW_OPS_PER_CELL_PACKED = 10, 5
 PACKED_ROWS_MAX = 768     # tiles of at most 768 rows run the packed score pass (mk_kernels.hpp: sw_cfg_packed)
 
 
+PMC_LAST = {}             # the artefact's record of the kernel pmc_traffic() was last asked about (per-step figures of the roofline object)
+RANDOM_REQUEST_PEAK = 55.0e9   # independent random 128-byte fabric requests per second, measured on this chip (profiles/r02_random_probe_rates.txt: 56.8 G/s from
+                               # 128 MB, 54.4 G/s from 2 GB)
+
+
 def pmc_traffic(kernel_name):
     """HBM bytes per launch of a kernel from the newest PMC artefact under profiles/ (written by tools/pmc_aggregate.py
     from separate rocprofv3 --pmc passes): {"build": <sha of the kernel sources>, "kernels": {name: {"fetch_bytes":..,
@@ -62,6 +68,8 @@ def pmc_traffic(kernel_name):
     k = art.get("kernels", {}).get(kernel_name)
     if not k:
         return None, os.path.basename(cands[-1]), None
+    PMC_LAST.clear()
+    PMC_LAST.update(k, passes=art.get("passes", 2))              # (the artefact's command runs warm-up + 1 step: two passes of the workload)
     note = os.path.basename(cands[-1]) + ("" if art.get("build") == h.hexdigest()[:16] else " (taken on an older build of the kernels)")
     total = (k["fetch_bytes"] + k["write_bytes"]) / max(k["launches"], 1)
     dram = None
@@ -205,6 +213,8 @@ def config4_leg(api, args, params, q_res, q_off, nq):
             t_ref = time.time() - t1
             c = {"prefilter": oracle.digest_blocks_file(os.path.join(tmp, "o", "pref.txt"))[0],
                  "alignments": oracle.digest_blocks_file(os.path.join(tmp, "o", "aln.txt"))[0]}
+        out["cpu_baseline"] = {"value": round(n_s / max(t_ref, 1e-9), 2), "unit": "profiles/s", "cores": int(api.lib().mk_host_threads()), "kind": "reference",
+                               "sample": "%d of the profiles against all %d fragments (ref_harness profilesearch, fragment index build included)" % (n_s, nq)}
         out["result_digest"] = {"profiles": n_s, "gpu": g, "cpu": c, "match": c == g, "reference_s": round(t_ref, 1),
                                 "reference": "oracle/_ref/ref_harness profilesearch (index build of the fragments included in reference_s)"}
     else:
@@ -250,7 +260,23 @@ def e2e_leg(api, args, params, targets, founders, t_res, t_off):
                 best = dt
                 rep_lines = [ln for ln in r.stderr.decode().splitlines() if ln.startswith("predictexons:")]
                 out["command_report"] = rep_lines[-1] if rep_lines else None      # the command's own account of its stages
+                st_lines = [ln for ln in r.stderr.decode().splitlines() if ln.startswith("predictexons stages:")]
+                if st_lines:                                                       # round 6: per-stage seconds of the command's main thread
+                    stages = {k.strip().replace(" ", "_").replace("(", "").replace(")", "").replace("+_", ""): float(v)
+                              for k, v in re.findall(r"([a-z+ ()]+?) (\d+\.\d+) s", st_lines[-1].split(";", 1)[1])}
+                    m = re.search(r"(\d+) batches of <= (\d+) nt", st_lines[-1])
+                    out["stages_s"] = stages
+                    if m:
+                        out["batches"] = int(m.group(1)); out["batch_nt"] = int(m.group(2))
+                m = re.search(r"-> (\d+) fragments", out["command_report"] or "") if rep_lines else None
+                if m:
+                    out["fragments"] = int(m.group(1))
+                m = re.search(r"; (\d+\.\d+) s \(", out["command_report"] or "")
+                if m:
+                    out["command_s"] = float(m.group(1))
         out.update({"wall_s": round(best, 3), "contigs_per_s": round(args.contigs / best, 1), "runs": 2})
+        if out.get("fragments"):
+            out["fragments_per_s"] = round(out["fragments"] / best, 1)
         data = open(os.path.join(tmp, "calls"), "rb").read()
         got = {}
         for line in open(os.path.join(tmp, "calls.index")):
@@ -287,6 +313,10 @@ def e2e_leg(api, args, params, targets, founders, t_res, t_off):
             bad = [c for c in range(n_s) if got.get(c, "") != exp.get(c, "")]
             import hashlib
             dig = lambda dd: hashlib.sha256("".join(">%d\n%s" % (c, dd.get(c, "")) for c in range(n_s)).encode()).hexdigest()
+            n_frag_ref = sum(1 for line in open(os.path.join(d, "q.txt")))
+            # the reference's chain on the host cores over the sample, as a rate (its target index build is inside: it is inside wall_s too)
+            out["cpu_baseline"] = {"value": round(n_frag_ref / max(time.time() - t1, 1e-9), 1), "unit": "fragments/s", "cores": int(api.lib().mk_host_threads()), "kind": "reference",
+                                   "sample": "the first %d contigs (%d fragments) through ref_harness orfs | pipeline | exons, target index build included" % (n_s, n_frag_ref)}
             out["result_digest"] = {"contigs": n_s, "gpu": dig(got), "cpu": dig(exp), "match": not bad, "differing_contigs": bad[:10],
                                     "contigs_with_predictions_in_the_sample": sum(1 for c in range(n_s) if exp.get(c)),
                                     "reference_s": round(time.time() - t1, 1), "reference": "oracle/_ref/ref_harness orfs | pipeline | exons on the first contigs"}
@@ -309,6 +339,8 @@ def main():
     ap.add_argument("--queue-depth", type=int, default=2, help="batches begun before the oldest one is collected (queued mode)")
     ap.add_argument("--blocking-steps", type=int, default=5, help="steps of the blocking mk_search timed after the headline region and reported beside it "
                     "(`blocking`; 0 = skip)")
+    ap.add_argument("--alone-steps", type=int, default=2, help="steps of mk_prefilter alone (no alignment stage beside it) after the headline region: the dominant "
+                    "kernel's time per step with the GPU to itself, for request_roofline (0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=400000, help="queries in the CPU baseline sample (0 = skip)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default=None, help="multi-GPU mode (default: strong when --gpus > 1)")
     ap.add_argument("--config4-profiles", type=int, default=50000, help="BASELINE config 4 beside the headline number (N = 1 only): this many synthetic "
@@ -451,6 +483,16 @@ def main():
         barrier()
         blocking = {"ms_per_step": (time.time() - tb0) / args.blocking_steps * 1e3, "steps": args.blocking_steps,
                     "note": "mk_search, one batch at a time: every step pays the fill and drain of the two-stage pipeline"}
+    alone = None
+    if not (args.two_calls or args.blocking) and args.alone_steps > 0 and world == 1:
+        # the prefilter stage with the GPU to itself (mk_prefilter, no alignment workers beside it): the dominant kernel's time per step alone, for
+        # the request roofline's co-resident / alone pair.  Outside the headline region
+        api.kernel_stats(reset=True)
+        for _ in range(args.alone_steps):
+            qa = api.Queries.from_codes(q_res, q_off, params)
+            api.prefilter(db, qa)
+            qa.close()
+        alone = {k: v["ms"] / args.alone_steps for k, v in api.kernel_stats().items()}
     total_queries = len(queries)
     if dist is not None:
         import torch
@@ -525,6 +567,29 @@ def main():
                                   "per CU: profiles/r02_valu_issue_rates.txt, tools/micro/hammer.hip) -- the figure this line trusts; peak_guide / frac_guide price "
                                   "the same work against MI355X_MICROARCH.md's SIMD-32 with a 2-cycle wave64 issue (twice the measured rate)"},
     }
+    # one launch definition for both byte counts: PER STEP.  Algorithmic bytes of the dominant kernel per step (this run), fabric bytes per pass of the
+    # same workload from the PMC artefact (its run is warm-up + 1 step = `passes` passes), their ratio; and the same kernel against the chip's measured
+    # random-request rate -- the bound DESIGN.md 4.1 names -- beside the other stage (this run's event time) and alone (mk_prefilter on its own)
+    steps_n = max(args.steps, 1)
+    rl = line["roofline"]
+    rl["per_step"] = {"algorithmic_bytes": dom["alg_bytes"] / steps_n, "kernel_ms": dom["ms"] / steps_n, "launches": dom["launches"] / steps_n}
+    if PMC_LAST:
+        fabric = (PMC_LAST["fetch_bytes"] + PMC_LAST["write_bytes"]) / max(PMC_LAST["passes"], 1)
+        rl["per_step"].update({"fabric_bytes": fabric, "fabric_over_algorithmic": fabric / max(dom["alg_bytes"] / steps_n, 1.0),
+                               "pmc_launches_per_pass": PMC_LAST["launches"] / max(PMC_LAST["passes"], 1)})
+        req = (PMC_LAST.get("read_requests", 0.0) + PMC_LAST.get("write_requests", 0.0)) / max(PMC_LAST["passes"], 1)
+        rr = {"kernel": dom_name, "requests_per_step": req, "peak": RANDOM_REQUEST_PEAK, "unit": "requests/s",
+              "co_resident": {"kernel_ms_per_step": dom["ms"] / steps_n, "achieved": req / max(dom["ms"] / steps_n * 1e-3, 1e-12)},
+              "note": "fabric requests (reads + writes, PMC) of the dominant kernel per step / its event time per step, against the measured rate of independent "
+                      "random 128-byte requests (profiles/r02_random_probe_rates.txt); co_resident = beside the alignment stage in the timed region, alone = "
+                      "mk_prefilter with the GPU to itself"}
+        rr["co_resident"]["frac"] = rr["co_resident"]["achieved"] / RANDOM_REQUEST_PEAK
+        if alone and alone.get(dom_name):
+            rr["alone"] = {"kernel_ms_per_step": alone[dom_name], "achieved": req / max(alone[dom_name] * 1e-3, 1e-12)}
+            rr["alone"]["frac"] = rr["alone"]["achieved"] / RANDOM_REQUEST_PEAK
+            rl["alone"] = {"kernel_ms_per_step": alone[dom_name], "achieved": dom["alg_bytes"] / steps_n / max(alone[dom_name] * 1e-3, 1e-12) / 1e9,
+                           "frac": dom["alg_bytes"] / steps_n / max(alone[dom_name] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS}
+        line["request_roofline"] = rr
     if rank == 0 and world == 1 and args.config4_profiles > 0:
         # BASELINE config 4 (profile targets: the reference's inverted search -- profiles as queries, the fragments as the indexed side,
         # swapresults), reported beside the headline metric and outside its timed region.  DESIGN.md 4.7; parity: tests/test_gpu_profile.py.

@@ -212,6 +212,8 @@ struct DevBuf {
 
 namespace mk {
 void dev_pool_release() { dev_pool_trim(); }
+void *dev_block_alloc(size_t bytes, size_t *cap) { return dev_pool_alloc(bytes, cap); }
+void dev_block_free(void *p, size_t cap) { if (p) dev_pool_free(p, cap); }
 void host_stat(const char *name, double ms) { std::lock_guard<std::mutex> g(g_statsMutex); g_stats[name].ms += ms; }
 hipError_t sync_wait(hipStream_t stream, const char *statName) {
     const double t0 = ScopedHost::now_ms();
@@ -1084,7 +1086,9 @@ struct mk_orfs {
 };
 
 int mk_extract_orfs(const char *nucleotides, const uint64_t *offsets, uint32_t nContigs, int minCodons, mk_orfs **out) {
-    int rc = ensure_ready();
+    // (round 6) like mk_queries_create this does NOT wait for the searches in flight: the contigs of the next batch are uploaded, scanned and translated
+    // on the upload stream with scratch buffers and pooled device blocks of their own, beside the search of the previous batch
+    int rc = ensure_ready(false);
     if (rc) return rc;
     if (!offsets || !out || (!nucleotides && offsets[nContigs] > 0) || minCodons < 1) return fail(MK_ERR_ARG, "bad argument");
     for (uint32_t i = 0; i < nContigs; i++) {
@@ -1092,17 +1096,25 @@ int mk_extract_orfs(const char *nucleotides, const uint64_t *offsets, uint32_t n
         if (offsets[i + 1] - offsets[i] >= 0x7FFFFFF0ull) return fail(MK_ERR_UNSUPPORTED, "contig %u is >= 2^31 nucleotides", i);
     }
     HostTimer ht("host_extract_orfs_total");
+    hipStream_t up = g_uploadStream ? g_uploadStream : g_stream;
+    struct Restore {
+        hipStream_t s; int lane;
+        ~Restore() { t_stream = s; mk::set_scratch_lane(lane); }
+    } restore{t_stream, mk::scratch_lane()};
+    t_stream = up;
+    mk::set_scratch_lane(UPLOAD_LANE);
     mk_orfs *o = new mk_orfs();
     o->nContigs = nContigs;
     DevBuf<char> dNucl;
     DevBuf<uint64_t> dOff;
+    dNucl.pooled = true; dOff.pooled = true;
     hipError_t e = dNucl.alloc(std::max<uint64_t>(offsets[nContigs], 1));
-    if (e == hipSuccess && offsets[nContigs]) e = hipMemcpyAsync(dNucl.p, nucleotides, offsets[nContigs], hipMemcpyHostToDevice, g_stream);
-    if (e == hipSuccess) e = dOff.upload(offsets, (size_t) nContigs + 1);
+    if (e == hipSuccess && offsets[nContigs]) e = hipMemcpyAsync(dNucl.p, nucleotides, offsets[nContigs], hipMemcpyHostToDevice, up);
+    if (e == hipSuccess) e = dOff.upload(offsets, (size_t) nContigs + 1, up);
     if (e != hipSuccess) { delete o; return fail(MK_ERR_DEVICE, "contig upload failed: %s", hipGetErrorString(e)); }
     std::string err;
     const int th = timed_begin("extract_orfs", (double) offsets[nContigs] * 2.0, 0);
-    rc = mk::run_extract_orfs(dNucl.p, dOff.p, nContigs, (uint32_t) minCodons, 32734u, (uint64_t) INT_MAX, g_stream, o->dev, err);
+    rc = mk::run_extract_orfs(dNucl.p, dOff.p, nContigs, (uint32_t) minCodons, 32734u, (uint64_t) INT_MAX, up, o->dev, err);
     timed_end(th);
     timed_flush();
     if (rc != MK_OK) { delete o; return fail(rc, "%s", err.c_str()); }
@@ -1110,10 +1122,12 @@ int mk_extract_orfs(const char *nucleotides, const uint64_t *offsets, uint32_t n
     o->orfs.resize(nf); o->aaOff.assign(nf + 1, 0); o->aa.resize(na); o->codes.resize(na);
     if (nf) {
         std::vector<mk::OrfRecord> rec(nf);
-        HIPCHK(hipMemcpy(rec.data(), o->dev.records, nf * sizeof(mk::OrfRecord), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(o->aaOff.data(), o->dev.aa_off, (nf + 1) * 8, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(o->aa.data(), o->dev.aa_ascii, na, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(o->codes.data(), o->dev.aa_code, na, hipMemcpyDeviceToHost));
+        hipError_t c = hipMemcpyAsync(rec.data(), o->dev.records, nf * sizeof(mk::OrfRecord), hipMemcpyDeviceToHost, up);
+        if (c == hipSuccess) c = hipMemcpyAsync(o->aaOff.data(), o->dev.aa_off, (nf + 1) * 8, hipMemcpyDeviceToHost, up);
+        if (c == hipSuccess) c = hipMemcpyAsync(o->aa.data(), o->dev.aa_ascii, na, hipMemcpyDeviceToHost, up);
+        if (c == hipSuccess) c = hipMemcpyAsync(o->codes.data(), o->dev.aa_code, na, hipMemcpyDeviceToHost, up);
+        if (c == hipSuccess) c = hipStreamSynchronize(up);
+        if (c != hipSuccess) { delete o; return fail(MK_ERR_DEVICE, "fragment download failed: %s", hipGetErrorString(c)); }
 #pragma omp parallel for schedule(static)
         for (uint64_t k = 0; k < nf; k++) {
             const mk::OrfRecord &r = rec[k];

@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <deque>
 #include <map>
 #include <string>
 #include <vector>
@@ -1189,6 +1190,7 @@ int cmdPredictExons(int argc, char **argv) {
     std::string e = contigs.open(a.pos[0]);
     if (!e.empty()) return die("%s", e);
     if (mk_init(gpu) != MK_OK) return die("%s", mk_last_error());
+    const double tInit = now();
     // contigs by ascending key: the order in which createRenumberedDB numbers their fragments (extractorfs.cpp:140-155)
     std::vector<size_t> ord = contigs.keyOrder();
     Shard sh;
@@ -1284,42 +1286,96 @@ int cmdPredictExons(int argc, char **argv) {
     std::string buf;
     char line[512];
     uint64_t nOrfs = 0, np = 0;
-    // the contigs go through the chain in batches bounded by their nucleotides (a metagenome assembly does not fit one library call);
-    // the target index stays resident, the fragment keys run on from batch to batch
-    for (size_t c0 = 0; c0 < ord.size() || (c0 == 0 && ord.empty()); ) {
-        const size_t c1 = contigBatchEnd(contigs, ord, c0);
-        loadBatch(c0, c1);
-        mk_orfs *O = nullptr;
-        mk_queries *Q = nullptr;
+    // The contigs go through the chain in batches bounded by their nucleotides (a metagenome assembly does not fit one library call); the target
+    // index stays resident, the fragment keys run on from batch to batch.  Round 6: the batches are QUEUED in the library's search engine
+    // (mk_search_begin / mk_search_wait) -- the reference's `search` is one OpenMP loop over all fragments (Prefiltering.cpp:817-886,
+    // Alignment.cpp:312-514), a caller's batches must not put a seam into it: while batch k is searched, the contigs of batch k + 1 are read,
+    // scanned and translated (mk_extract_orfs / mk_queries_from_orfs run on a stream of their own and do not wait for the engine), and the exon
+    // sets of batch k - 1 are chained and written by this thread.  The batch follows the input: an eighth of the nucleotides, between 2^23 and
+    // 2^27 (MK_CLI_BATCH_NT fixes it) -- ~6 batches for 10 000 contigs of 5 kb, so that the first search starts after a sixth of the reading and
+    // the last exon stage is a sixth of the work.  The results do not depend on the batches (tests/test_gpu_parity.py::test_cli_contig_batches).
+    uint64_t budget = 0;
+    if (const char *eb = knobEnv("MK_CLI_BATCH_NT")) { if (atoll(eb) > 0) budget = (uint64_t) atoll(eb); }
+    if (budget == 0) {
+        uint64_t totalNt = 0;
+        for (size_t i = 0; i < ord.size(); i++) totalNt += contigs.seqLen(ord[i]);
+        budget = std::min<uint64_t>(1ull << 27, std::max<uint64_t>(1ull << 23, totalNt / 8));
+        if (plan.splits > 1) budget = 1ull << 29;                  // target splits index every split again per batch: as few batches as possible
+    }
+    auto batchEnd = [&](size_t c0) {
+        uint64_t nt = 0;
+        size_t c1 = c0;
+        while (c1 < ord.size() && (c1 == c0 || nt + contigs.seqLen(ord[c1]) <= budget)) { nt += contigs.seqLen(ord[c1]); c1++; }
+        return c1;
+    };
+    struct Batch { size_t c0, c1; mk_orfs *O; mk_queries *Q; uint64_t nb, orfFirst; bool begun; };
+    std::deque<Batch> inflight;
+    double tRead = 0, tExtract = 0, tSearchWait = 0, tExons = 0, tWrite = 0;
+    size_t nBatches = 0;
+    // collect batch b: wait for its search (if it was queued), chain its exon sets, write them
+    auto finish = [&](Batch &b) -> int {
+        double ta = now();
+        if (b.begun && mk_search_wait(b.Q) != MK_OK) return die("%s", mk_last_error());
+        double tb = now();
+        tSearchWait += tb - ta;
         mk_predictions *R = nullptr;
-        if (mk_extract_orfs(nucl.empty() ? &none : nucl.data(), off.data(), (uint32_t) (c1 - c0), minLength, &O) != MK_OK) return die("%s", mk_last_error());
-        const mk_orf *orfs; const uint64_t *aaOff; const char *aa; uint64_t nb = 0;
-        mk_orfs_result(O, &orfs, &aaOff, &aa, &nb);
-        if (mk_queries_from_orfs(O, &P, &Q) != MK_OK) return die("%s", mk_last_error());
-        if (plan.splits > 1) {
-            uint64_t total = 0;
-            if (int rc = splitPrefilter(Q, (size_t) nb, tdbSeq, P, plan, total)) return rc;
-            if (mk_align(T, Q, &P) != MK_OK) return die("%s", mk_last_error());
-        } else if (mk_search(T, Q, &P) != MK_OK) return die("%s", mk_last_error());
-        if (mk_predict_exons(T, O, Q, &X, tkeys.data(), &R) != MK_OK) return die("%s", mk_last_error());
+        if (mk_predict_exons(T, b.O, b.Q, &X, tkeys.data(), &R) != MK_OK) return die("%s", mk_last_error());
         const mk_prediction *preds; const uint64_t *coff; const mk_exon *exons; uint64_t npb = 0;
         mk_predictions_result(R, &preds, &coff, &exons, &npb);
-        for (size_t c = c0; c < c1; c++) {
+        ta = now();
+        tExons += ta - tb;
+        for (size_t c = b.c0; c < b.c1; c++) {
             buf.clear();
-            for (uint64_t k = coff[c - c0]; k < coff[c - c0 + 1]; k++)
+            for (uint64_t k = coff[c - b.c0]; k < coff[c - b.c0 + 1]; k++)
                 for (uint64_t x = preds[k].first_exon; x < preds[k].first_exon + preds[k].n_exons; x++) {
                     mk_exon ex = exons[x];
-                    ex.orf += (uint32_t) (orfBase + nOrfs);
+                    ex.orf += (uint32_t) (orfBase + b.orfFirst);
                     buf.append(line, mk_format_prediction_exon(line, &preds[k], &ex));
                 }
             w.write(contigs.entries[ord[c]].key, buf.data(), buf.size());
         }
-        nOrfs += nb; np += npb;
+        np += npb;
         mk_predictions_destroy(R);
-        mk_queries_destroy(Q);
-        mk_orfs_destroy(O);
+        mk_queries_destroy(b.Q);
+        mk_orfs_destroy(b.O);
+        tWrite += now() - ta;
+        return 0;
+    };
+    for (size_t c0 = 0; c0 < ord.size() || (c0 == 0 && ord.empty()); ) {
+        const size_t c1 = batchEnd(c0);
+        double ta = now();
+        loadBatch(c0, c1);
+        double tb = now();
+        tRead += tb - ta;
+        Batch b{c0, c1, nullptr, nullptr, 0, nOrfs, false};
+        if (mk_extract_orfs(nucl.empty() ? &none : nucl.data(), off.data(), (uint32_t) (c1 - c0), minLength, &b.O) != MK_OK) return die("%s", mk_last_error());
+        const mk_orf *orfs; const uint64_t *aaOff; const char *aa;
+        mk_orfs_result(b.O, &orfs, &aaOff, &aa, &b.nb);
+        if (mk_queries_from_orfs(b.O, &P, &b.Q) != MK_OK) return die("%s", mk_last_error());
+        tExtract += now() - tb;
+        nOrfs += b.nb;
+        nBatches++;
+        if (plan.splits > 1) {                                       // (blocking: every split is indexed and searched in turn, then the whole batch is aligned)
+            ta = now();
+            uint64_t total = 0;
+            if (int rc = splitPrefilter(b.Q, (size_t) b.nb, tdbSeq, P, plan, total)) return rc;
+            if (mk_align(T, b.Q, &P) != MK_OK) return die("%s", mk_last_error());
+            tSearchWait += now() - ta;
+        } else {
+            if (mk_search_begin(T, b.Q, &P) != MK_OK) return die("%s", mk_last_error());
+            b.begun = true;
+        }
+        inflight.push_back(b);
+        while (inflight.size() > 1) {                                // batch k is queued: collect batch k - 1 beside it
+            if (int rc = finish(inflight.front())) return rc;
+            inflight.pop_front();
+        }
         if (c1 == c0) break;                                       // (no contigs at all)
         c0 = c1;
+    }
+    while (!inflight.empty()) {
+        if (int rc = finish(inflight.front())) return rc;
+        inflight.pop_front();
     }
     const double t2 = now();
     e = w.close();
@@ -1327,6 +1383,10 @@ int cmdPredictExons(int argc, char **argv) {
     if (plan.splits > 1) fprintf(stderr, "predictexons: %d target splits%s (--max-seqs %d per split, k = %d)\n", plan.splits, plan.chosen ? " [chosen from the memory limit]" : "", plan.maxSeqs, plan.kmerSize);
     fprintf(stderr, "predictexons: %zu contigs -> %llu fragments x %zu targets -> %llu predictions; %.2f s (target index %.2f s, fragments to exon sets %.2f s)\n",
             ord.size(), (unsigned long long) nOrfs, tkeys.size(), (unsigned long long) np, now() - t0, t1 - t0, t2 - t1);
+    // the per-stage account of this thread (what it did while the searches ran in the library's engine; `search (blocked)` = the time it sat in
+    // mk_search_wait, i.e. what the other stages did NOT hide)
+    fprintf(stderr, "predictexons stages: %zu batches of <= %llu nt; open + init %.3f s, target index %.3f s, read %.3f s, extract + upload %.3f s, search (blocked) %.3f s, exons %.3f s, "
+                    "write %.3f s, close %.3f s\n", nBatches, (unsigned long long) budget, tInit - t0, t1 - tInit, tRead, tExtract, tSearchWait, tExons, tWrite, now() - t2);
     mk_targetdb_destroy(T);
     if (int rc = finishShards(a.pos[2], sh, 12)) return rc;
     if (sh.world > 1 && sh.rank == 0) for (int r = 0; r < sh.world; r++) remove((a.pos[2] + "_" + std::to_string(r) + ".orfs").c_str());

@@ -153,6 +153,10 @@ struct ScopedHost {
 // persistent, growable device / pinned-host buffers (one set per process; no hipMalloc on the hot path)
 void *dev_scratch(const char *name, size_t bytes);          // nullptr on allocation failure (after the idle query-batch blocks were given back and the request repeated)
 void dev_pool_release();                                    // mk_abi.cpp: every idle block of the query batches' device pool back to the device
+// device blocks that live as long as a batch (query residues, ORF fragments): from / back to that pool -- hipFree waits for the whole device and
+// would serialise the batch in flight with the one being prepared.  *cap = what dev_block_free must be told
+void *dev_block_alloc(size_t bytes, size_t *cap);
+void dev_block_free(void *p, size_t cap);
 void *pinned_scratch(const char *name, size_t bytes);
 void scratch_release_all();
 void set_scratch_lane(int lane);                            // of the calling thread: lane > 0 gets buffers of its own under the same names (a second worker of one stage)

@@ -253,10 +253,12 @@ int run_extract_orfs(const char *dNucl, const uint64_t *dOffsets, uint32_t nCont
     if (nFrag >= 0xFFFFFFFFull || nAa >= 0xFFFFFFFFull) { err = "more than 2^32 ORF fragments or residues in one batch: split the contigs"; return MK_ERR_UNSUPPORTED; }
     R.n_frag = nFrag; R.n_aa = nAa;
     if (nFrag == 0) return MK_OK;
-    OCHK(hipMalloc((void **) &R.records, nFrag * sizeof(OrfRecord)));
-    OCHK(hipMalloc((void **) &R.aa_off, (nFrag + 1) * 8));
-    OCHK(hipMalloc((void **) &R.aa_ascii, nAa));
-    OCHK(hipMalloc((void **) &R.aa_code, nAa));
+    // (pooled blocks: a hipFree at the end of the batch would wait for the search of the next one)
+    R.records = (OrfRecord *) dev_block_alloc(nFrag * sizeof(OrfRecord), &R.cap[0]);
+    R.aa_off = (uint64_t *) dev_block_alloc((nFrag + 1) * 8, &R.cap[1]);
+    R.aa_ascii = (char *) dev_block_alloc(std::max<uint64_t>(nAa, 1), &R.cap[2]);
+    R.aa_code = (uint8_t *) dev_block_alloc(std::max<uint64_t>(nAa, 1), &R.cap[3]);
+    ONULL(R.records); ONULL(R.aa_off); ONULL(R.aa_ascii); ONULL(R.aa_code);
     A.records = R.records; A.aa_off = R.aa_off;
     hipLaunchKernelGGL(orf_write_kernel, dim3(blocks), dim3(256), 0, stream, A, nPos, dNaa, dRank, dAaBase);
     OCHK(hipGetLastError());
@@ -268,10 +270,10 @@ int run_extract_orfs(const char *dNucl, const uint64_t *dOffsets, uint32_t nCont
 }
 
 void OrfDeviceResult::release() {
-    if (records) (void) hipFree(records);
-    if (aa_off) (void) hipFree(aa_off);
-    if (aa_ascii) (void) hipFree(aa_ascii);
-    if (aa_code) (void) hipFree(aa_code);
+    dev_block_free(records, cap[0]);
+    dev_block_free(aa_off, cap[1]);
+    dev_block_free(aa_ascii, cap[2]);
+    dev_block_free(aa_code, cap[3]);
     records = nullptr; aa_off = nullptr; aa_ascii = nullptr; aa_code = nullptr; n_frag = 0; n_aa = 0;
 }
 

@@ -22,6 +22,7 @@ struct OrfDeviceResult {
     uint64_t n_frag = 0, n_aa = 0;
     OrfRecord *records = nullptr; uint64_t *aa_off = nullptr;        // [n_frag], [n_frag + 1]
     char *aa_ascii = nullptr; uint8_t *aa_code = nullptr;            // [n_aa]
+    size_t cap[4] = {0, 0, 0, 0};                                    // the four blocks come from the batch pool (mk::dev_block_alloc)
     void release();
 };
 

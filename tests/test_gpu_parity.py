@@ -971,6 +971,18 @@ def test_cli_contig_batches(gpu_api, tmp_path):
                           env=env, stderr=subprocess.DEVNULL)
     got = _read_result_db(str(tmp_path / "calls"))
     assert "".join(">%d\n%s" % (c, got[c]) for c in range(len(contigs))) == _text("e2e_exons_expected.txt.gz")
+    # round 6: the batches are queued in the search engine (batch k + 1 is read, scanned and translated while batch k is searched and the exon
+    # sets of batch k - 1 are written); the DB is byte-identical to the run with everything in ONE batch, and the command accounts for its stages
+    r = subprocess.run([build.BIN, "predictexons", str(tmp_path / "contigs"), str(tmp_path / "targets"), str(tmp_path / "calls_one"), str(tmp_path / "tmp")] + flags,
+                       env=dict(os.environ, MK_CLI_BATCH_NT=str(1 << 29)), stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-1000:]
+    assert b"predictexons stages: 1 batches" in r.stderr and b"search (blocked)" in r.stderr, r.stderr.decode()[-600:]
+    for sfx in ("", ".index", ".dbtype"):
+        assert open(str(tmp_path / "calls") + sfx, "rb").read() == open(str(tmp_path / "calls_one") + sfx, "rb").read(), sfx
+    r = subprocess.run([build.BIN, "predictexons", str(tmp_path / "contigs"), str(tmp_path / "targets"), str(tmp_path / "calls_dflt"), str(tmp_path / "tmp")] + flags,
+                       env=dict(os.environ), stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-1000:]
+    assert open(str(tmp_path / "calls"), "rb").read() == open(str(tmp_path / "calls_dflt"), "rb").read()
     procs = []
     for r in range(2):
         e2 = dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0")

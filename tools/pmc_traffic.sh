@@ -5,12 +5,12 @@
 # Bytes = 128 B x 128-byte requests + 32 B x 32-byte requests + 64 B x the rest (reads); 64 B x 64-byte requests + 32 B x the rest
 # (writes).  FETCH_SIZE is NOT used: it tallies a 128-byte request as 64 B (profiles/r02_random_probe_rates.txt).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/pmc
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 1 --warmup 1 --cpu-sample 0 --config4-profiles 0 --blocking-steps 0 --e2e-sample -1"
+BENCH="python $R/bench.py --steps 1 --warmup 1 --cpu-sample 0 --config4-profiles 0 --blocking-steps 0 --alone-steps 0 --e2e-sample -1"
 rm -rf $OUT/rd $OUT/wr $OUT/dram
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace --output-format csv -d $OUT/rd -- $BENCH > $OUT/rd.log 2>&1
 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d $OUT/wr -- $BENCH > $OUT/wr.log 2>&1
@@ -51,7 +51,7 @@ for k, v in agg.items():
                "read_requests": rd, "read_requests_128B": r128, "write_requests": wr,
                "read_requests_dram": v.get("TCC_EA0_RDREQ_DRAM_sum"), "write_requests_dram": v.get("TCC_EA0_WRREQ_DRAM_sum"),
                "read_dram_credit_stall_cycles": v.get("TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum")}
-art = {"build": h.hexdigest()[:16], "command": "rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum (pass 1) / TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum (pass 2) --kernel-trace -- python bench.py --steps 1 --warmup 1 --cpu-sample 0 --config4-profiles 0",
+art = {"build": h.hexdigest()[:16], "passes": 2, "command": "rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum (pass 1) / TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum (pass 2) --kernel-trace -- python bench.py --steps 1 --warmup 1 --cpu-sample 0 --config4-profiles 0",
        "note": "sums over all dispatches of a pass of the run (warm-up + 1 step; every pass is its own run of the same command); bench.py divides by launches. "
                "read_requests_dram / write_requests_dram: requests bound for the memory controllers (Infinity Cache hits included: no counter separates them)", "kernels": kern}
 json.dump(art, open(out + "/${TAG}_pmc_hbm_traffic.json", "w"), indent=1)
