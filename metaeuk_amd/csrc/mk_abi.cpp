@@ -349,6 +349,9 @@ void engine_drain_if_running();
 // drain: the entry points that use the library's streams and scratch buffers first let the searches in flight (mk_search_begin) finish
 int ensure_ready(bool drain = true) {
     if (!g_ready) return fail(MK_ERR_DEVICE, "mk_init() was not called or no HIP device is usable");
+    // the device binding is per host thread: a caller's helper thread (the commands prefetch their first batch on one) works on the GPU mk_init chose
+    static thread_local bool deviceBound = false;
+    if (!deviceBound) { (void) hipSetDevice(g_device); deviceBound = true; }
     if (drain) engine_drain_if_running();
     return MK_OK;
 }

@@ -32,6 +32,7 @@
 #include <deque>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 #include <unistd.h>
 
@@ -1212,6 +1213,53 @@ int cmdPredictExons(int argc, char **argv) {
         ord = std::vector<size_t>(ord.begin() + (std::ptrdiff_t) first, ord.begin() + (std::ptrdiff_t) (first + count));
     }
     const std::string outPath = sh.world > 1 ? a.pos[2] + "_" + std::to_string(sh.rank) : a.pos[2];
+    static const char none = 0;
+    // The contigs go through the chain in batches bounded by their nucleotides (a metagenome assembly does not fit one library call).  The batch
+    // follows the input: an eighth of the nucleotides, between 2^23 and 2^27 (MK_CLI_BATCH_NT fixes it) -- ~6 batches for 10 000 contigs of 5 kb, so
+    // that the first search starts after a sixth of the reading and the last exon stage is a sixth of the work
+    uint64_t budget = 0;
+    if (const char *eb = knobEnv("MK_CLI_BATCH_NT")) { if (atoll(eb) > 0) budget = (uint64_t) atoll(eb); }
+    const bool budgetFixed = budget != 0;
+    if (budget == 0) {
+        uint64_t totalNt = 0;
+        for (size_t i = 0; i < ord.size(); i++) totalNt += contigs.seqLen(ord[i]);
+        budget = std::min<uint64_t>(1ull << 27, std::max<uint64_t>(1ull << 23, totalNt / 8));
+    }
+    auto batchEnd = [&](size_t c0) {
+        uint64_t nt = 0;
+        size_t c1 = c0;
+        while (c1 < ord.size() && (c1 == c0 || nt + contigs.seqLen(ord[c1]) <= budget)) { nt += contigs.seqLen(ord[c1]); c1++; }
+        return c1;
+    };
+    // Round 6: the FIRST batch of contigs is read, scanned and translated by a helper thread WHILE this thread masks and indexes the target side
+    // (mk_extract_orfs / mk_queries_from_orfs work on a stream of their own; neither needs the target database) -- the reference's workflow runs
+    // extractorfs in front of everything (predictexons.sh:42-60); here it hides behind the index build.  Not with several workers (the counting pass
+    // below walks all batches first) and not when target splits may change the batch size.  MK_CLI_WARM=0 switches it off.
+    struct Prefetched { mk_orfs *O = nullptr; mk_queries *Q = nullptr; size_t c1 = 0; uint64_t nb = 0; int rc = 0; std::string err; double seconds = 0; bool valid = false; } pre;
+    std::thread preThread;
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{preThread};
+    {
+        const bool splitAsked = (get("--split") && atoi(get("--split")->c_str()) > 1) || get("--split-memory-limit");
+        const char *warm = knobEnv("MK_CLI_WARM");
+        if (sh.world == 1 && !splitAsked && !ord.empty() && !(warm && !strcmp(warm, "0"))) {
+            pre.c1 = batchEnd(0);
+            pre.valid = true;
+            preThread = std::thread([&]() {
+                const double ta = now();
+                std::vector<char> nuclP;
+                std::vector<uint64_t> offP(1, 0);
+                for (size_t i = 0; i < pre.c1; i++) {
+                    nuclP.insert(nuclP.end(), contigs.entry(ord[i]), contigs.entry(ord[i]) + contigs.seqLen(ord[i]));
+                    offP.push_back(nuclP.size());
+                }
+                if (mk_extract_orfs(nuclP.empty() ? &none : nuclP.data(), offP.data(), (uint32_t) pre.c1, minLength, &pre.O) != MK_OK) { pre.rc = EXIT_FAILURE; pre.err = mk_last_error(); return; }
+                const mk_orf *orfs; const uint64_t *aaOff; const char *aa;
+                mk_orfs_result(pre.O, &orfs, &aaOff, &aa, &pre.nb);
+                if (mk_queries_from_orfs(pre.O, &P, &pre.Q) != MK_OK) { pre.rc = EXIT_FAILURE; pre.err = mk_last_error(); }
+                pre.seconds = now() - ta;
+            });
+        }
+    }
     // the target side; a sequence DB that needs (or is told to use) target splits keeps only its residues resident: every contig batch then
     // runs the prefilter split by split and aligns against the whole database (splitPrefilter)
     TargetSide ts;
@@ -1239,7 +1287,13 @@ int cmdPredictExons(int argc, char **argv) {
     mk_targetdb *T = ts.T;
     const std::vector<uint32_t> &tkeys = ts.keys;
     const double t1 = now();
-    static const char none = 0;
+    if (preThread.joinable()) preThread.join();
+    if (pre.rc) return die("%s", pre.err);
+    if (plan.splits > 1) {                                         // target splits index every split again per batch: as few batches as possible
+        if (!budgetFixed) budget = 1ull << 29;
+        if (pre.valid) { mk_queries_destroy(pre.Q); mk_orfs_destroy(pre.O); pre.valid = false; }
+    }
+    const double t1b = now();
     std::vector<char> nucl;
     std::vector<uint64_t> off;
     auto loadBatch = [&](size_t c0, size_t c1) {
@@ -1294,21 +1348,7 @@ int cmdPredictExons(int argc, char **argv) {
     // sets of batch k - 1 are chained and written by this thread.  The batch follows the input: an eighth of the nucleotides, between 2^23 and
     // 2^27 (MK_CLI_BATCH_NT fixes it) -- ~6 batches for 10 000 contigs of 5 kb, so that the first search starts after a sixth of the reading and
     // the last exon stage is a sixth of the work.  The results do not depend on the batches (tests/test_gpu_parity.py::test_cli_contig_batches).
-    uint64_t budget = 0;
-    if (const char *eb = knobEnv("MK_CLI_BATCH_NT")) { if (atoll(eb) > 0) budget = (uint64_t) atoll(eb); }
-    if (budget == 0) {
-        uint64_t totalNt = 0;
-        for (size_t i = 0; i < ord.size(); i++) totalNt += contigs.seqLen(ord[i]);
-        budget = std::min<uint64_t>(1ull << 27, std::max<uint64_t>(1ull << 23, totalNt / 8));
-        if (plan.splits > 1) budget = 1ull << 29;                  // target splits index every split again per batch: as few batches as possible
-    }
-    auto batchEnd = [&](size_t c0) {
-        uint64_t nt = 0;
-        size_t c1 = c0;
-        while (c1 < ord.size() && (c1 == c0 || nt + contigs.seqLen(ord[c1]) <= budget)) { nt += contigs.seqLen(ord[c1]); c1++; }
-        return c1;
-    };
-    struct Batch { size_t c0, c1; mk_orfs *O; mk_queries *Q; uint64_t nb, orfFirst; bool begun; };
+    struct Batch { size_t c0, c1; mk_orfs *O; mk_queries *Q; uint64_t nb, orfFirst; bool begun; double tBegun; };
     std::deque<Batch> inflight;
     double tRead = 0, tExtract = 0, tSearchWait = 0, tExons = 0, tWrite = 0;
     size_t nBatches = 0;
@@ -1318,6 +1358,7 @@ int cmdPredictExons(int argc, char **argv) {
         if (b.begun && mk_search_wait(b.Q) != MK_OK) return die("%s", mk_last_error());
         double tb = now();
         tSearchWait += tb - ta;
+        if (knobEnv("MK_CLI_TIMELINE")) fprintf(stderr, "[predictexons] batch of %llu fragments: begun at %.3f s, collected at %.3f s (blocked %.3f s)\n", (unsigned long long) b.nb, b.tBegun - t0, tb - t0, tb - ta);
         mk_predictions *R = nullptr;
         if (mk_predict_exons(T, b.O, b.Q, &X, tkeys.data(), &R) != MK_OK) return die("%s", mk_last_error());
         const mk_prediction *preds; const uint64_t *coff; const mk_exon *exons; uint64_t npb = 0;
@@ -1342,17 +1383,22 @@ int cmdPredictExons(int argc, char **argv) {
         return 0;
     };
     for (size_t c0 = 0; c0 < ord.size() || (c0 == 0 && ord.empty()); ) {
-        const size_t c1 = batchEnd(c0);
+        const size_t c1 = (c0 == 0 && pre.valid) ? pre.c1 : batchEnd(c0);
         double ta = now();
-        loadBatch(c0, c1);
-        double tb = now();
-        tRead += tb - ta;
-        Batch b{c0, c1, nullptr, nullptr, 0, nOrfs, false};
-        if (mk_extract_orfs(nucl.empty() ? &none : nucl.data(), off.data(), (uint32_t) (c1 - c0), minLength, &b.O) != MK_OK) return die("%s", mk_last_error());
-        const mk_orf *orfs; const uint64_t *aaOff; const char *aa;
-        mk_orfs_result(b.O, &orfs, &aaOff, &aa, &b.nb);
-        if (mk_queries_from_orfs(b.O, &P, &b.Q) != MK_OK) return die("%s", mk_last_error());
-        tExtract += now() - tb;
+        Batch b{c0, c1, nullptr, nullptr, 0, nOrfs, false, 0.0};
+        if (c0 == 0 && pre.valid) {                                  // (read, scanned and translated beside the target index)
+            b.O = pre.O; b.Q = pre.Q; b.nb = pre.nb;
+            pre.valid = false;
+        } else {
+            loadBatch(c0, c1);
+            double tb = now();
+            tRead += tb - ta;
+            if (mk_extract_orfs(nucl.empty() ? &none : nucl.data(), off.data(), (uint32_t) (c1 - c0), minLength, &b.O) != MK_OK) return die("%s", mk_last_error());
+            const mk_orf *orfs; const uint64_t *aaOff; const char *aa;
+            mk_orfs_result(b.O, &orfs, &aaOff, &aa, &b.nb);
+            if (mk_queries_from_orfs(b.O, &P, &b.Q) != MK_OK) return die("%s", mk_last_error());
+            tExtract += now() - tb;
+        }
         nOrfs += b.nb;
         nBatches++;
         if (plan.splits > 1) {                                       // (blocking: every split is indexed and searched in turn, then the whole batch is aligned)
@@ -1364,9 +1410,14 @@ int cmdPredictExons(int argc, char **argv) {
         } else {
             if (mk_search_begin(T, b.Q, &P) != MK_OK) return die("%s", mk_last_error());
             b.begun = true;
+            b.tBegun = now();
         }
         inflight.push_back(b);
-        while (inflight.size() > 1) {                                // batch k is queued: collect batch k - 1 beside it
+        // two batches stay queued while the oldest is collected (MK_CLI_QUEUE_DEPTH): the engine's prefilter thread finishes a batch well before its
+        // alignments are complete, and with one batch behind it it idled until this thread had collected, chained and written the previous one and
+        // translated the next (the timeline of 10 000 contigs: batch k + 1 begun 50 ms before batch k was complete)
+        static const size_t depth = (size_t) std::max(1L, knobEnv("MK_CLI_QUEUE_DEPTH") ? atol(knobEnv("MK_CLI_QUEUE_DEPTH")) : 2L);
+        while (inflight.size() > depth) {                            // batches k and k - 1 are queued: collect batch k - 2 beside them
             if (int rc = finish(inflight.front())) return rc;
             inflight.pop_front();
         }
@@ -1383,10 +1434,15 @@ int cmdPredictExons(int argc, char **argv) {
     if (plan.splits > 1) fprintf(stderr, "predictexons: %d target splits%s (--max-seqs %d per split, k = %d)\n", plan.splits, plan.chosen ? " [chosen from the memory limit]" : "", plan.maxSeqs, plan.kmerSize);
     fprintf(stderr, "predictexons: %zu contigs -> %llu fragments x %zu targets -> %llu predictions; %.2f s (target index %.2f s, fragments to exon sets %.2f s)\n",
             ord.size(), (unsigned long long) nOrfs, tkeys.size(), (unsigned long long) np, now() - t0, t1 - t0, t2 - t1);
+    if (knobEnv("MK_CLI_TIMELINE")) {                               // the library's own account: kernel event times and host phases of the whole run
+        static mk_kernel_stat st[512];
+        const int n = mk_kernel_stats(st, 512);
+        for (int k = 0; k < n; k++) if (st[k].ms >= 2.0) fprintf(stderr, "[predictexons] %-28s %9.1f ms %7llu launches\n", st[k].name, st[k].ms, (unsigned long long) st[k].launches);
+    }
     // the per-stage account of this thread (what it did while the searches ran in the library's engine; `search (blocked)` = the time it sat in
     // mk_search_wait, i.e. what the other stages did NOT hide)
-    fprintf(stderr, "predictexons stages: %zu batches of <= %llu nt; open + init %.3f s, target index %.3f s, read %.3f s, extract + upload %.3f s, search (blocked) %.3f s, exons %.3f s, "
-                    "write %.3f s, close %.3f s\n", nBatches, (unsigned long long) budget, tInit - t0, t1 - tInit, tRead, tExtract, tSearchWait, tExons, tWrite, now() - t2);
+    fprintf(stderr, "predictexons stages: %zu batches of <= %llu nt; open + init %.3f s, target index %.3f s, first batch beside it %.3f s, waited for it %.3f s, read %.3f s, extract + upload %.3f s, search (blocked) %.3f s, exons %.3f s, "
+                    "write %.3f s, close %.3f s\n", nBatches, (unsigned long long) budget, tInit - t0, t1 - tInit, pre.seconds, t1b - t1, tRead, tExtract, tSearchWait, tExons, tWrite, now() - t2);
     mk_targetdb_destroy(T);
     if (int rc = finishShards(a.pos[2], sh, 12)) return rc;
     if (sh.world > 1 && sh.rank == 0) for (int r = 0; r < sh.world; r++) remove((a.pos[2] + "_" + std::to_string(r) + ".orfs").c_str());

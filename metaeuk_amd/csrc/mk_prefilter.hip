@@ -519,6 +519,12 @@ struct StreamArgs {
 #define MK_STREAM_U 2
 #endif
 // shapes of the two streamed tiers: waves per workgroup, LDS sort size, bitmap bits, workgroups per CU
+#ifndef MK_STREAM_U_A
+#define MK_STREAM_U_A MK_STREAM_U   // probe groups of the third / the largest tier (experiments: tools/build_variant.sh)
+#endif
+#ifndef MK_STREAM_U_B
+#define MK_STREAM_U_B MK_STREAM_U
+#endif
 #ifndef MK_STREAM_SURV_1
 #define MK_STREAM_SURV_1 256       // second tier (4096 hits, one wave): LDS sort size and bitmap bits
 #define MK_STREAM_MBITS_1 8192
@@ -970,8 +976,8 @@ void launch_stream(int tier, const StreamArgs &A, unsigned grid, hipStream_t str
     switch (tier) {
         case 0: hipLaunchKernelGGL((stream_kernel<2048, 256, 8192, 64, 1, MK_STREAM_U>), dim3(grid), dim3(64), 0, stream, A); break;
         case 1: hipLaunchKernelGGL((stream_kernel<4096, MK_STREAM_SURV_1, MK_STREAM_MBITS_1, 128, 1, MK_STREAM_U>), dim3(grid), dim3(64), 0, stream, A); break;
-        case 2: hipLaunchKernelGGL((stream_kernel<MK_STREAM_CAP_A, MK_STREAM_SURV_A, MK_STREAM_MBITS_A, MK_STREAM_MAXPOS_A, MK_STREAM_NW_A, MK_STREAM_U>), dim3(grid), dim3(64 * MK_STREAM_NW_A), 0, stream, A); break;
-        case 3: hipLaunchKernelGGL((stream_kernel<MK_STREAM_CAP_B, MK_STREAM_SURV_B, MK_STREAM_MBITS_B, MK_STREAM_MAXPOS_B, MK_STREAM_NW_B, MK_STREAM_U>), dim3(grid), dim3(64 * MK_STREAM_NW_B), 0, stream, A); break;
+        case 2: hipLaunchKernelGGL((stream_kernel<MK_STREAM_CAP_A, MK_STREAM_SURV_A, MK_STREAM_MBITS_A, MK_STREAM_MAXPOS_A, MK_STREAM_NW_A, MK_STREAM_U_A>), dim3(grid), dim3(64 * MK_STREAM_NW_A), 0, stream, A); break;
+        case 3: hipLaunchKernelGGL((stream_kernel<MK_STREAM_CAP_B, MK_STREAM_SURV_B, MK_STREAM_MBITS_B, MK_STREAM_MAXPOS_B, MK_STREAM_NW_B, MK_STREAM_U_B>), dim3(grid), dim3(64 * MK_STREAM_NW_B), 0, stream, A); break;
         case 4: hipLaunchKernelGGL((stream_kernel<256, 64, 1024, 32, 1, 2>), dim3(grid), dim3(64), 0, stream, A); break;
         case 5: hipLaunchKernelGGL((stream_kernel<512, 64, 1024, 64, 1, 2>), dim3(grid), dim3(64), 0, stream, A); break;
         case 6: hipLaunchKernelGGL((stream_kernel<1024, 128, 2048, 64, 4, 2>), dim3(grid), dim3(256), 0, stream, A); break;
@@ -998,6 +1004,23 @@ constexpr uint32_t W_T_BITS_MAX = 27;                          // sort key = tar
                                                                // database needs (WideArgs::t_bits <= 27), the rank takes the other 48 - t_bits bits -- a
                                                                // query may gather 2^21 hits against 2^27 targets, 4 M against UniRef50's 60 M (26 bits)
 constexpr int W_MODE_ENUM6 = 0, W_MODE_LIST = 1, W_MODE_ENUM7 = 2;
+// Round 6: the target CLASS of a hit is the top bits of a BIJECTION of the t-bit target ids (multiply, xor-shift, multiply, xor-shift, all modulo 2^t:
+// every step is invertible), so a sort key of a group that lies inside one class needs only the other t - log2(classes) bits to name the target -- and
+// the arrival rank gets the bits the class number took: 2^28 hits per query at 60 M targets (26 bits, 64 classes) where the whole id left room for 2^22
+// and sent a third of the fragments of a UniRef50-scale search to the sort-based global path.  wide_inv gives the id back when a candidate is emitted.
+constexpr uint32_t WIDE_MUL_A = 0x9E3779B1u, WIDE_MUL_B = 0x7FEB352Du;
+constexpr uint32_t inverse_mod_2_32(uint32_t a) { uint32_t x = a; for (int k = 0; k < 6; k++) x *= 2u - a * x; return x; }
+static_assert(WIDE_MUL_A * inverse_mod_2_32(WIDE_MUL_A) == 1u && WIDE_MUL_B * inverse_mod_2_32(WIDE_MUL_B) == 1u, "odd multipliers");
+__host__ __device__ __forceinline__ uint32_t wide_fwd(uint32_t x, uint32_t tBits) {
+    const uint32_t m = (1u << tBits) - 1u, s = (tBits + 1u) >> 1;     // (x ^= x >> s with 2 s >= t undoes itself)
+    x = (x * WIDE_MUL_A) & m; x ^= x >> s; x = (x * WIDE_MUL_B) & m; x ^= x >> s;
+    return x;
+}
+__host__ __device__ __forceinline__ uint32_t wide_inv(uint32_t y, uint32_t tBits) {
+    const uint32_t m = (1u << tBits) - 1u, s = (tBits + 1u) >> 1;
+    y ^= y >> s; y = (y * inverse_mod_2_32(WIDE_MUL_B)) & m; y ^= y >> s; y = (y * inverse_mod_2_32(WIDE_MUL_A)) & m;
+    return y;
+}
 struct WideArgs {
     PrefilterDeviceView V;
     const uint32_t *queries; uint32_t n_queries;      // view query ids, most expensive first
@@ -1009,9 +1032,12 @@ struct WideArgs {
                                                       // [11] (a double) MODE 2: sum over the finished queries of similar k-mers / length (run statistics)
     uint32_t *work_counter;
     uint64_t *pool; uint32_t *pool_ord;               // gridDim.x regions of NCLS * cls_cap records
-    uint32_t cls_cap;                                 // records per target class (NCLS * cls_cap <= 2^rank_bits)
-    uint32_t t_bits, rank_bits;                       // t_bits + rank_bits = 48
+    uint32_t cls_cap;                                 // records per target class (NCLS * cls_cap <= 2^(48 - t_bits) * NCLS and < 2^31: the arrival rank of a hit
+                                                      // shares the sort key with the target bits a class leaves open)
+    uint32_t t_bits;                                  // bits of a target id (>= 20)
+    uint32_t one_class_hits;                          // a query with at least this many hits takes its classes one by one (2^(48 - t_bits); the tests force 0)
     const uint16_t *pos_cost; uint64_t pos_begin;     // MODE 0: work estimate of every k-mer start (kmer_count_kernel)
+    uint32_t exp;                                     // EXPERIMENT (MK_PREFILTER_WIDE_EXP, results WRONG): 1 no region stores, 2 no class atomic, 4 no tail entry loads, 8 no pass 2
 };
 
 template <int NCLS, int GROUP_MAX, int SURV, int MBITS, int MAXPOS, int NW, int U, int MODE>
@@ -1044,7 +1070,8 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
 
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, w = tid / WAVE, lane = tid & (WAVE - 1);
-    const uint32_t CLS_CAP = A.cls_cap, T_BITS = A.t_bits, TSHIFT = 16u + A.rank_bits;
+    const uint32_t CLS_CAP = A.cls_cap, T_BITS = A.t_bits;
+    const uint32_t RES_BITS = T_BITS - (uint32_t) LOG_NCLS;           // what names a target inside its class
     uint64_t *region = A.pool + (size_t) blockIdx.x * NCLS * CLS_CAP;
     uint32_t *regionOrd = A.pool_ord + (size_t) blockIdx.x * NCLS * CLS_CAP;
     const uint64_t TMASK = (1ull << T_BITS) - 1ull;
@@ -1152,12 +1179,14 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
                     const auto put = [&](uint64_t ent, uint32_t rel) {
                         const uint32_t tgt = (uint32_t) ent;
                         const uint32_t diag = ((uint32_t) i - ((uint32_t) (ent >> 32) & 0xFFFFu)) & 0xFFFFu;
-                        const uint32_t cls = mix32(tgt ^ 0x7FEB352Du) >> (32 - LOG_NCLS);  // (its own seed: the bitmap buckets of pass 2 must not follow the class)
-                        const uint32_t slot = atomicAdd(&sClsUsed[cls], 1u);
+                        const uint32_t cls = wide_fwd(tgt, T_BITS) >> RES_BITS;            // (a function of its own: the bitmap buckets of pass 2 must not follow the class)
+                        const uint32_t slot = (A.exp & 2u) ? (tgt & 1023u) : atomicAdd(&sClsUsed[cls], 1u);
                         if (slot < CLS_CAP) {
                             const size_t at = (size_t) cls * CLS_CAP + slot;
+                            if (!(A.exp & 1u) || tgt == 0xFFFFFFFFu) {
                             region[at] = (uint64_t) tgt | ((uint64_t) diag << T_BITS) | ((uint64_t) (uint32_t) i << (T_BITS + 16u));
                             regionOrd[at] = wcount + rel;
+                            }
                         } else over = true;
                     };
 #pragma unroll
@@ -1167,7 +1196,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
                         enumk::wave_deal_tail(size[u] > 1 ? size[u] - 1 : 0u, lane, P1.mark[w], [&](uint32_t owner, uint32_t e, bool valid) {
                             const uint64_t oFirst = wave_read_lane64(o0[u], owner);
                             const uint32_t oR0 = enumk::wave_read_lane(r0, owner);
-                            if (valid) put(ld_probe(A.V.entries + oFirst + e), oR0 + e);
+                            if (valid) put((A.exp & 4u) ? (oFirst + e) * 0x9E3779B97F4A7C15ull : ld_probe(A.V.entries + oFirst + e), oR0 + e);
                         });
                     }
                     wcount += totAll;
@@ -1203,7 +1232,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
             atomicAdd(&A.totals[2], (unsigned long long) np);
             if (MODE == W_MODE_ENUM7 && km != 0 && L > 0) atomicAdd(reinterpret_cast<double *>(&A.totals[11]), (double) km / (double) L);
         }
-        if (hitsAll == 0) continue;
+        if (hitsAll == 0 || (A.exp & 8u)) continue;
         // arrival rank of a hit = hits of the earlier k-mer starts + its ordinal
         if (w == 0) {
             const uint32_t perLane = ((uint32_t) nStart + WAVE - 1) / WAVE;
@@ -1216,12 +1245,18 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
         __syncthreads();
         unsigned long long tSortAcc = 0, tEmitAcc = 0, tFilterAcc = 0;
         // ---- pass 2: the classes in groups of at most GROUP_MAX records (a single class may hold more)
+        // a group of several small classes sorts on the whole (mapped) target id and leaves the rank 48 - T_BITS bits; a query with more hits than that
+        // takes its classes one by one (the class number is then implied: RES_BITS of target, the rank gets LOG_NCLS bits more)
+        const bool oneClassGroups = hitsAll >= A.one_class_hits;
         for (uint32_t c0 = 0; c0 < (uint32_t) NCLS; ) {
             uint32_t c1 = c0, recs = 0;
-            while (c1 < (uint32_t) NCLS && (c1 == c0 || recs + sClsUsed[c1] <= (uint32_t) GROUP_MAX)) { recs += sClsUsed[c1]; c1++; }
+            while (c1 < (uint32_t) NCLS && (c1 == c0 || (!oneClassGroups && recs + sClsUsed[c1] <= (uint32_t) GROUP_MAX))) { recs += sClsUsed[c1]; c1++; }
             const uint32_t g0 = c0, g1 = c1;
             c0 = c1;
             if (recs == 0) continue;
+            const bool single = g1 == g0 + 1u;
+            const uint32_t FIELD_BITS = single ? RES_BITS : T_BITS, TSHIFT = 64u - FIELD_BITS;
+            const uint32_t FIELD_MASK = (1u << FIELD_BITS) - 1u;
             const unsigned long long tc0 = wall_clock64();
             // the records of the group, 4 x BLOCK at a time: four loads in flight per thread (the sweeps are bound by memory latency), and every
             // thread of the workgroup takes part in every step
@@ -1278,7 +1313,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
                         if (slot < (uint32_t) SURV) {
                             const uint32_t pos = (uint32_t) (rec >> (T_BITS + 16u)) & 0xFFFu;
                             const uint32_t rank = sPosBase[pos] + regionOrd[at];
-                            sKey[slot] = ((rec & TMASK) << TSHIFT) | ((uint64_t) rank << 16) | ((rec >> T_BITS) & 0xFFFFull);
+                            sKey[slot] = ((uint64_t) (wide_fwd((uint32_t) (rec & TMASK), T_BITS) & FIELD_MASK) << TSHIFT) | ((uint64_t) rank << 16) | ((rec >> T_BITS) & 0xFFFFull);
                         }
                     }
                 });
@@ -1437,8 +1472,8 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
                         const uint32_t dst = ebase + sWordPrefix[t >> 5] + (uint32_t) __popc(word & ((1u << (t & 31u)) - 1u));
                         const uint64_t key = sKey[t];
                         A.C.q[dst] = q - A.q_first;
-                        A.C.id[dst] = (uint32_t) (key >> TSHIFT);
-                        A.C.ordinal[dst] = (uint32_t) (key >> 16) & ((1u << A.rank_bits) - 1u);
+                        A.C.id[dst] = wide_inv((uint32_t) (key >> TSHIFT) | (single ? g0 << RES_BITS : 0u), T_BITS);
+                        A.C.ordinal[dst] = (uint32_t) ((key << FIELD_BITS) >> (FIELD_BITS + 16u));
                         A.C.diag[dst] = (uint16_t) key;
                     }
                 }
@@ -1770,6 +1805,7 @@ int self_score(const SubMat &ung, const uint8_t *q, const int8_t *corr, int L) {
 struct SizingMemo {
     const void *entries = nullptr; uint32_t nTargets = 0;
     double candPerQuery = 0;
+    double wideHitsPerUnit = 0;               // wide kernel: index hits per similar k-mer (per k-mer START when the 7-mers are enumerated in the kernel), learned
     double hitsPerKmer[4] = {0, 0, 0, 0};     // per LDS tier (short fragments and long ORFs differ in composition)
     double margin[4] = {1.15, 1.15, 1.15, 1.15};
 };
@@ -2306,6 +2342,7 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
             PCHK(sync_wait(stream, "wait_prefilter"));
         }
         std::vector<uint32_t> order;
+        std::vector<uint32_t> orderUnits;                  // hQK of order[k]: what the tier of a query is estimated from
         {
             ScopedHost sh("host_prefilter_tiers");
             double sum = 0;
@@ -2320,6 +2357,8 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
                 byClass[63 - std::min<uint64_t>(63, (uint64_t) hQK[ql] * 63 / most)].push_back(p0 + ql);
             }
             for (int c = 0; c < 64; c++) order.insert(order.end(), byClass[c].begin(), byClass[c].end());
+            orderUnits.resize(order.size());
+            for (size_t k = 0; k < order.size(); k++) orderUnits[k] = hQK[order[k] - p0];
             if (cs && !k7enum) cs->kmers_per_pos += sum;
         }
         if (!order.empty()) {
@@ -2327,83 +2366,131 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
             uint32_t *dList = (uint32_t *) dev_scratch("pf_flist", order.size() * 4);
             uint32_t *dOvf = (uint32_t *) dev_scratch("pf_fovf", (size_t) nqp * 4);
             PNULL(hList); PNULL(dList); PNULL(dOvf);
-            std::memcpy(hList, order.data(), order.size() * 4);
-            PCHK(hipMemcpyAsync(dList, hList, order.size() * 4, hipMemcpyHostToDevice, stream));
-            PCHK(hipMemsetAsync(dCtr, 0, 64, stream));
-            hCtr[0] = nCand;                               // (pinned: the copy below reads it when the stream gets there -- synchronised before it is reused)
-            PCHK(hipMemcpyAsync(dCtr, hCtr, 4, hipMemcpyHostToDevice, stream));
-            PCHK(hipMemsetAsync(dTot, 0, 16 * 8, stream));
             int perCu = W.wgPerCu;
             // beside the alignment stage of mk_search: profile queries leave it most of the work (config 4: at most 16 prefilter waves per CU);
             // a sequence search with k = 7 or beyond 2^22 targets is 90 % prefilter (2*10^5 ... 3*10^6 index hits per fragment, 300 pairs to align):
             // the prefilter keeps both workgroups per CU (25.6 k against 19.2 k fragments/s at 11.8 M proteins, profiles/r04_wide_kernel.txt)
             if (coResident && Vin.p_sorted) perCu = std::max(1, 16 / W.waves < perCu ? 16 / W.waves : perCu);
             if (const char *e = knob("MK_PREFILTER_WG_PER_CU_W")) perCu = std::max(1, atoi(e));
-            const unsigned launch = (unsigned) std::min<size_t>(order.size(), (size_t) cus * perCu);
-            // sort key = target | arrival rank | 16-bit diagonal: the rank takes the bits the targets leave; a class holds what that allows,
-            // within a budget of 24 GB for the regions of the persistent workgroups (12 bytes per record)
+            // sort key = target | arrival rank | 16-bit diagonal: the rank takes the bits the targets leave (one-class groups: the class number's bits
+            // as well, wide_fwd); a class holds what that allows, within a budget for the regions of the persistent workgroups (12 bytes per record):
+            // 24 GB at most (MK_PREFILTER_WIDE_POOL_GB), and never more than 45 % of what the device had free when the pool was first sized (a database
+            // that fills the HBM -- 60 M proteins leave 35 GB -- must not be refused a search for want of region space)
+            static uint64_t byFree = 0;
+            if (!byFree) { size_t f = 0, t = 0; byFree = (hipMemGetInfo(&f, &t) == hipSuccess && f) ? std::max<uint64_t>(1ull << 30, (uint64_t) ((double) f * 0.45)) : (24ull << 30); }
+            const uint64_t budget = std::min<uint64_t>((uint64_t) std::max<long>(1, knob_long("MK_PREFILTER_WIDE_POOL_GB", 24)) << 30, byFree);
             WideArgs A;
             A.t_bits = std::max<uint32_t>(X.seqBits, 20u);
-            A.rank_bits = std::min<uint32_t>(48u - A.t_bits, 24u);
-            A.cls_cap = (uint32_t) W.clsCap;
-            if (W.clsCap == 0) {
-                // 24 GB at most (MK_PREFILTER_WIDE_POOL_GB), and never more than a third of what the device had free when the pool was first sized
-                // (a database that fills the HBM -- 60 M proteins leave 35 GB -- must not be refused a search for want of region space)
-                static uint64_t byFree = 0;
-                if (!byFree) { size_t f = 0, t = 0; byFree = (hipMemGetInfo(&f, &t) == hipSuccess && f) ? std::max<uint64_t>(1ull << 30, (uint64_t) f / 3) : (24ull << 30); }
-                const uint64_t budget = std::min<uint64_t>((uint64_t) std::max<long>(1, knob_long("MK_PREFILTER_WIDE_POOL_GB", 24)) << 30, byFree);
-                const uint64_t byRank = (1ull << A.rank_bits) / (uint64_t) W.nCls, byBudget = budget / ((uint64_t) cus * perCu * W.nCls * 12ull);
-                A.cls_cap = (uint32_t) std::max<uint64_t>(4096, std::min(byRank, byBudget) & ~63ull);
+            A.one_class_hits = knob_long("MK_TEST_WIDE_ONE_CLASS", 0) ? 0u : (uint32_t) std::min<uint64_t>(1ull << (48u - A.t_bits), 0xFFFFFFFFull);
+            // (the rank of a hit has 48 - t_bits + log2(classes) bits in the key of a one-class group; the arrival ordinal of a candidate is a uint32)
+            const uint64_t byRank = std::min<uint64_t>(1ull << (48u - A.t_bits), (1ull << 31) / (uint64_t) W.nCls);
+            const uint32_t nCandPiece = nCand;
+            // Round 6: TIERS.  The regions of the persistent workgroups share one pool; a query that fills a class of the first launch (512 regions) is
+            // tried again by a launch with a QUARTER of the workgroups and four times the class -- 128, 32, 8 regions -- in the same pool, and only what
+            // overflows the last one (or has more k-mer starts than the kernel numbers) goes to the sort-based global path.  At 60 M proteins the pool
+            // holds 2-3 M hits per query at 512 regions and a third of the fragments of a metagenome gather more (profiles/r06_config5.txt).
+            const int maxTiers = (int) std::max(1L, std::min(4L, knob_long("MK_PREFILTER_WIDE_TIERS", 4)));
+            const auto tier_grid = [&](int tier) { return std::max<unsigned>(1u, ((unsigned) cus * perCu) >> (2 * tier)); };
+            const auto tier_cap = [&](int tier) -> uint32_t {
+                return W.clsCap != 0 ? (uint32_t) std::min<uint64_t>(byRank, (uint64_t) W.clsCap << (2 * tier))
+                                     : (uint32_t) std::max<uint64_t>(4096, std::min<uint64_t>(byRank, budget / ((uint64_t) tier_grid(tier) * W.nCls * 12ull)) & ~63ull);
+            };
+            // A query that fills a class has wasted its pass 1 (a quarter of the kernel's time at 60 M proteins when everything starts in the first
+            // tier): every query STARTS in the tier its expected hits fit -- similar k-mers (k-mer starts when the 7-mers are enumerated in the kernel)
+            // x the hits per unit this database has shown so far (before the first launch: index entries per table cell, x 2 500 similar 7-mers per
+            // start) with a quarter of headroom -- and only the misjudged ones are retried
+            double perUnit;
+            { std::lock_guard<std::mutex> lk(g_memoMutex); perUnit = g_memo.entries == (const void *) Vin.entries ? g_memo.wideHitsPerUnit : 0.0; }
+            if (perUnit <= 0) perUnit = (double) Vin.n_entries / (Vin.kmer_size == 7 ? 1.28e9 : 6.4e7) * (k7enum ? 2500.0 : 1.0);
+            std::vector<uint32_t> tierQ[4];
+            for (size_t k = 0; k < order.size(); k++) {
+                const double est = 1.25 * perUnit * (double) orderUnits[k];
+                int t = 0;
+                while (t + 1 < maxTiers && est > (double) W.nCls * (double) tier_cap(t) && tier_cap(t + 1) > tier_cap(t)) t++;
+                tierQ[t].push_back(order[k]);
             }
-            for (;;) {                                         // a pool that cannot be had is halved (fuller classes send more queries to the global path)
-                const size_t regionRecs = (size_t) W.nCls * A.cls_cap;
-                A.pool = (uint64_t *) dev_scratch("pf_wpool", (size_t) launch * regionRecs * 8);
-                A.pool_ord = A.pool ? (uint32_t *) dev_scratch("pf_wpoolord", (size_t) launch * regionRecs * 4) : nullptr;
-                if ((A.pool && A.pool_ord) || W.clsCap != 0 || A.cls_cap <= 4096) break;
-                (void) hipGetLastError();
-                A.cls_cap = std::max<uint32_t>(4096, (A.cls_cap / 2) & ~63u);
-            }
-            PNULL(A.pool); PNULL(A.pool_ord);
-            A.V = V; A.queries = dList; A.n_queries = (uint32_t) order.size(); A.q_first = a;
-            A.C = X.C; A.cand_cap = X.candCap; A.counters = dCtr;
-            A.overflow_list = dOvf; A.overflow_count = dCtr + 4; A.totals = dTot; A.work_counter = dCtr + 8;
-            A.pos_cost = dPosCost; A.pos_begin = hOff[p0];
-            const int th = X.tb("prefilter_query_wide", 0, 0);
-            if (k7enum) launch_wide<W_MODE_ENUM7>(shape, A, launch, stream);
-            else if (listed) launch_wide<W_MODE_LIST>(shape, A, launch, stream);
-            else launch_wide<W_MODE_ENUM6>(shape, A, launch, stream);
-            X.te(th);
-            PCHK(hipGetLastError());
-            PCHK(hipMemcpyAsync(hCtr, dCtr, 64, hipMemcpyDeviceToHost, stream));
-            PCHK(hipMemcpyAsync(hTot, dTot, 16 * 8, hipMemcpyDeviceToHost, stream));
-            PCHK(sync_wait(stream, "wait_prefilter"));
-            if (knob("MK_PREFILTER_DEBUG"))
-                fprintf(stderr, "[prefilter] wide piece %u..%u (%s): queries %zu overflowed %llu | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g filter %.3g collect+sort %.3g rule+emit %.3g overflowed %.3g | extra sub-class passes %llu | cand %u -> %u\n",
-                        p0, p1, k7enum ? "7-mers in the kernel" : (listed ? "lists" : "k = 6 enumerator"), order.size(), hTot[8], (double) hTot[0], (double) hTot[1], (double) hTot[2], (double) hTot[3], (double) hTot[12], (double) hTot[4], (double) hTot[5],
-                        (double) hTot[6], hTot[9], nCand, hCtr[0]);
-            if (hCtr[0] > X.candCap) return RC_CAND_OVERFLOW;
-            if (hTot[10] != 0) {
-                // a single target class held more double-hit survivors of one sub-class than the LDS sort: the piece's candidates are dropped
-                // (nCand is not advanced) and the sort-based path does the piece
-                const bool sk = X.statsKmers;
-                X.statsKmers = X.stats != nullptr && k7enum;
-                fallback.resize(fallbackMark);
-                const int rc = global_candidates(X, Vin, hOff, p0, p1, nullptr, (uint32_t) 0 - a, nCand, globalHitsPerPos);
-                X.statsKmers = sk;
-                if (rc != MK_OK) return rc;
-            } else {
+            size_t nList = 0;                              // queries handed on by the tier before (view ids in hList[0 .. nList))
+            uint32_t prevCap = 0;
+            bool redoGlobal = false;
+            double unitsDone = 0, hitsDone = 0;
+            for (int tier = 0; tier < maxTiers; tier++) {
+                if (nList + tierQ[tier].size() > order.size()) { err = "wide tiers: list overrun"; return MK_ERR_DEVICE; }
+                std::memcpy(hList + nList, tierQ[tier].data(), tierQ[tier].size() * 4);      // (the overflowed ones of the tier before first: they are the largest)
+                nList += tierQ[tier].size();
+                if (nList == 0) continue;
+                const unsigned gridMax = tier_grid(tier);
+                const unsigned launch = (unsigned) std::min<size_t>(nList, gridMax);
+                A.cls_cap = tier_cap(tier);
+                if (tier > 0 && A.cls_cap <= prevCap) break;          // (the rank bits are spent: a larger class cannot be numbered)
+                for (;;) {                                         // a pool that cannot be had is halved (fuller classes send more queries to the next tier / the global path)
+                    const size_t regionRecs = (size_t) W.nCls * A.cls_cap;
+                    A.pool = (uint64_t *) dev_scratch("pf_wpool", (size_t) gridMax * regionRecs * 8);
+                    A.pool_ord = A.pool ? (uint32_t *) dev_scratch("pf_wpoolord", (size_t) gridMax * regionRecs * 4) : nullptr;
+                    if ((A.pool && A.pool_ord) || W.clsCap != 0 || A.cls_cap <= 4096) break;
+                    (void) hipGetLastError();
+                    A.cls_cap = std::max<uint32_t>(4096, (A.cls_cap / 2) & ~63u);
+                }
+                PNULL(A.pool); PNULL(A.pool_ord);
+                if (tier > 0 && A.cls_cap <= prevCap) break;
+                prevCap = A.cls_cap;
+                PCHK(hipMemcpyAsync(dList, hList, nList * 4, hipMemcpyHostToDevice, stream));
+                PCHK(hipMemsetAsync(dCtr, 0, 64, stream));
+                hCtr[0] = nCand;                               // (pinned: the copy below reads it when the stream gets there -- synchronised before it is reused)
+                PCHK(hipMemcpyAsync(dCtr, hCtr, 4, hipMemcpyHostToDevice, stream));
+                PCHK(hipMemsetAsync(dTot, 0, 16 * 8, stream));
+                A.V = V; A.queries = dList; A.n_queries = (uint32_t) nList; A.q_first = a;
+                A.C = X.C; A.cand_cap = X.candCap; A.counters = dCtr;
+                A.overflow_list = dOvf; A.overflow_count = dCtr + 4; A.totals = dTot; A.work_counter = dCtr + 8;
+                A.pos_cost = dPosCost; A.pos_begin = hOff[p0];
+                A.exp = (uint32_t) knob_long("MK_PREFILTER_WIDE_EXP", 0);
+                static const char *const tierName[4] = {"prefilter_query_wide", "prefilter_query_wide_tier1", "prefilter_query_wide_tier2", "prefilter_query_wide_tier3"};
+                const int th = X.tb(tierName[tier], 0, 0);
+                if (k7enum) launch_wide<W_MODE_ENUM7>(shape, A, launch, stream);
+                else if (listed) launch_wide<W_MODE_LIST>(shape, A, launch, stream);
+                else launch_wide<W_MODE_ENUM6>(shape, A, launch, stream);
+                X.te(th);
+                PCHK(hipGetLastError());
+                PCHK(hipMemcpyAsync(hCtr, dCtr, 64, hipMemcpyDeviceToHost, stream));
+                PCHK(hipMemcpyAsync(hTot, dTot, 16 * 8, hipMemcpyDeviceToHost, stream));
+                PCHK(sync_wait(stream, "wait_prefilter"));
+                if (knob("MK_PREFILTER_DEBUG"))
+                    fprintf(stderr, "[prefilter] wide piece %u..%u tier %d (%s; %u regions of %d x %u records): queries %zu overflowed %llu | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g filter %.3g collect+sort %.3g rule+emit %.3g overflowed %.3g | extra sub-class passes %llu | cand %u -> %u\n",
+                            p0, p1, tier, k7enum ? "7-mers in the kernel" : (listed ? "lists" : "k = 6 enumerator"), launch, W.nCls, A.cls_cap, nList, hTot[8], (double) hTot[0], (double) hTot[1], (double) hTot[2], (double) hTot[3], (double) hTot[12], (double) hTot[4], (double) hTot[5],
+                            (double) hTot[6], hTot[9], nCand, hCtr[0]);
+                if (hCtr[0] > X.candCap) return RC_CAND_OVERFLOW;
+                if (hTot[10] != 0) { redoGlobal = true; break; }
                 X.ts(th, 16.0 * (double) hTot[0] + 6.0 * (double) hTot[1], (double) hTot[0]);
                 nCand = hCtr[0];
                 if (cs) cs->db_matches += hTot[1];
                 if (cs && k7enum) { double sumK; std::memcpy(&sumK, &hTot[11], 8); cs->kmers_per_pos += sumK; }
+                unitsDone += (double) (k7enum ? hTot[2] : hTot[0]); hitsDone += (double) hTot[1];
                 const uint32_t nOvf = hCtr[4];
+                nList = 0;
                 if (nOvf > 0) {
                     uint32_t *hOvf = (uint32_t *) pinned_scratch("pf_fovf_h", (size_t) nOvf * 4);
                     PNULL(hOvf);
                     PCHK(hipMemcpyAsync(hOvf, dOvf, (size_t) nOvf * 4, hipMemcpyDeviceToHost, stream));
                     PCHK(sync_wait(stream, "wait_prefilter"));
-                    fallback.insert(fallback.end(), hOvf, hOvf + nOvf);
+                    for (uint32_t k = 0; k < nOvf; k++) hList[k] = hOvf[k] + a;          // (chunk-local ids -> view query ids: the next tier's list)
+                    nList = nOvf;
                 }
+            }
+            if (unitsDone > 0 && hitsDone > 0) {
+                std::lock_guard<std::mutex> lk(g_memoMutex);
+                if (g_memo.entries == (const void *) Vin.entries) g_memo.wideHitsPerUnit = g_memo.wideHitsPerUnit > 0 ? 0.5 * (g_memo.wideHitsPerUnit + hitsDone / unitsDone) : hitsDone / unitsDone;
+            }
+            if (redoGlobal) {
+                // a single target class held more double-hit survivors of one sub-class than the LDS sort: the piece's candidates are dropped
+                // (nCand goes back to where the piece began) and the sort-based path does the piece
+                const bool sk = X.statsKmers;
+                X.statsKmers = X.stats != nullptr && k7enum;
+                fallback.resize(fallbackMark);
+                nCand = nCandPiece;
+                const int rc = global_candidates(X, Vin, hOff, p0, p1, nullptr, (uint32_t) 0 - a, nCand, globalHitsPerPos);
+                X.statsKmers = sk;
+                if (rc != MK_OK) return rc;
+            } else {
+                for (size_t k = 0; k < nList; k++) fallback.push_back(hList[k] - a);   // what the last tier could not hold
             }
         }
         p0 = p1;

@@ -290,6 +290,51 @@ def test_database_hits_overflow_path(gpu_api, tmp_path):
     assert "host_prefilter_overflow" in api.kernel_stats()
 
 
+def test_wide_kernel_tiers_and_one_class_groups(gpu_api, tmp_path, monkeypatch):
+    """Round 6: the wide per-query kernel retries a query that fills a target class with a quarter of the workgroups and four times the class
+    (three more tiers in the same pool), and a query with more hits than the rank bits beside a whole target id number takes its classes one by
+    one (the class number leaves the sort key: mk_prefilter.hip wide_fwd / wide_inv).  The miniature shape (4 classes of 192 records) on families
+    of near-copies -- 1 000 ... 40 000 index hits per query: every tier, and beyond the last one the global path -- with one tier / four tiers and
+    multi-class / one-class groups: always the oracle's bytes (QueryMatcher.cpp:213-346)."""
+    rng = random.Random(11)
+    mut = lambda s, r: "".join(rng.choice(AA) if rng.random() < r else c for c in s)
+    targets, queries = [], []
+    for copies in (30, 120, 500, 2000):
+        base = _rand_seq(rng, 160)
+        targets += [mut(base, 0.03) for _ in range(copies)]
+        queries += [base[10:60], mut(base[40:140], 0.05), base]
+    targets += [_rand_seq(rng, rng.randrange(50, 300)) for _ in range(300)]
+    queries += [_rand_seq(rng, 40), ""]
+    order = list(range(len(targets)))
+    rng.shuffle(order)
+    targets = [targets[i] for i in order]
+    api = gpu_api
+    params = api.default_params()
+    params.host_l2_bytes = 2097152
+    db = api.TargetDB(targets, params)
+    opref, oaln = oracle.run_pipeline(targets, queries, str(tmp_path), extra=["--l2", "2097152"])
+    monkeypatch.setenv("MK_PREFILTER_PATH", "wide")
+    monkeypatch.setenv("MK_PREFILTER_TIERS", "tiny")
+    seen_retry = False
+    for tiers in ("1", "4"):
+        for one_class in ("0", "1"):
+            monkeypatch.setenv("MK_PREFILTER_WIDE_TIERS", tiers)
+            monkeypatch.setenv("MK_TEST_WIDE_ONE_CLASS", one_class)
+            api.kernel_stats(reset=True)
+            q = api.Queries(queries, params)
+            (hits, hoff), (alns, aoff) = api.search(db, q)
+            for i in range(len(queries)):
+                assert api.format_hits(hits, int(hoff[i]), int(hoff[i + 1])) == opref[i], ("pref", tiers, one_class, i)
+                assert api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1])) == oaln[i], ("aln", tiers, one_class, i)
+            st = api.kernel_stats()
+            later = [k for k in st if k.startswith("prefilter_query_wide_tier")]
+            assert bool(later) == (tiers == "4"), (tiers, sorted(st))
+            seen_retry = seen_retry or len(later) >= 2
+            q.close()
+    assert seen_retry and int(hoff[-1]) > 1000
+    db.close()
+
+
 def test_sw_vs_golden(gpu_api):
     """400 adversarial pairs (gap next to gap, poly-residue inserts, long related pairs): coordinates and bit
     scores printed by the reference (AVX2 == SSE4.1) vs the kernel's integers"""
