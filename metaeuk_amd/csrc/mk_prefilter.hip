@@ -1023,7 +1023,9 @@ __host__ __device__ __forceinline__ uint32_t wide_inv(uint32_t y, uint32_t tBits
 }
 struct WideArgs {
     PrefilterDeviceView V;
-    const uint32_t *queries; uint32_t n_queries;      // view query ids, most expensive first
+    const uint32_t *queries; uint32_t n_queries;      // view query ids, most expensive first (an ITEM of the work list: a query, or a part of one)
+    const uint32_t *parts;                            // per item: r | log2(M) << 8 -- the workgroup takes the target classes c with (c & (M - 1)) == r (null: all)
+    uint32_t *overflow_parts;                         // the part word of every entry of overflow_list
     uint32_t q_first;                                 // candidates carry q - q_first
     CandArrays C; uint32_t cand_cap;
     uint32_t *counters;                               // [0] candidates appended
@@ -1070,10 +1072,10 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
 
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, w = tid / WAVE, lane = tid & (WAVE - 1);
-    const uint32_t CLS_CAP = A.cls_cap, T_BITS = A.t_bits;
+    const uint32_t T_BITS = A.t_bits;
     const uint32_t RES_BITS = T_BITS - (uint32_t) LOG_NCLS;           // what names a target inside its class
-    uint64_t *region = A.pool + (size_t) blockIdx.x * NCLS * CLS_CAP;
-    uint32_t *regionOrd = A.pool_ord + (size_t) blockIdx.x * NCLS * CLS_CAP;
+    uint64_t *region = A.pool + (size_t) blockIdx.x * NCLS * A.cls_cap;
+    uint32_t *regionOrd = A.pool_ord + (size_t) blockIdx.x * NCLS * A.cls_cap;
     const uint64_t TMASK = (1ull << T_BITS) - 1ull;
     static_assert(LOG_MBITS <= 17, "bucket = the top bits of the mix, subset = its low 15 bits");
     const auto survives = [&](uint64_t rec) -> bool {
@@ -1089,6 +1091,14 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
         const uint32_t item = sItem;
         if (item >= A.n_queries) break;
         const uint32_t q = A.queries[item];
+        // Round 6: a query with more hits than a region holds is taken by M = 2, 4, 8 ... workgroups at once: each enumerates and probes ALL k-mers (a
+        // seventh of the kernel's time at 60 M proteins: profiles/r06_config5.txt) but keeps only the hits of ITS target classes -- (class & (M - 1))
+        // == r --, whose NCLS / M classes share its region (M times the records per class), and runs pass 2 on them.  Arrival ranks count all hits, so
+        // the parts' candidates are what one workgroup would have emitted, class by class.
+        const uint32_t part = A.parts ? A.parts[item] : 0u;
+        const uint32_t PART_R = part & 0xFFu, LOG_M = part >> 8, PART_MASK = (1u << LOG_M) - 1u;
+        const uint32_t NLOC = (uint32_t) NCLS >> LOG_M;                  // classes of this part, numbered class >> LOG_M
+        const uint32_t CLS_CAP = A.cls_cap << LOG_M;                     // ... and their room in the region
         const uint64_t qs = A.V.q_off[q];
         const int L = (int) (A.V.q_off[q + 1] - qs);
         const int span = A.V.kmer_size == 7 ? 11 : 10;
@@ -1179,7 +1189,9 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
                     const auto put = [&](uint64_t ent, uint32_t rel) {
                         const uint32_t tgt = (uint32_t) ent;
                         const uint32_t diag = ((uint32_t) i - ((uint32_t) (ent >> 32) & 0xFFFFu)) & 0xFFFFu;
-                        const uint32_t cls = wide_fwd(tgt, T_BITS) >> RES_BITS;            // (a function of its own: the bitmap buckets of pass 2 must not follow the class)
+                        const uint32_t cls0 = wide_fwd(tgt, T_BITS) >> RES_BITS;           // (a function of its own: the bitmap buckets of pass 2 must not follow the class)
+                        if ((cls0 & PART_MASK) != PART_R) return;                          // another part's class
+                        const uint32_t cls = cls0 >> LOG_M;
                         const uint32_t slot = (A.exp & 2u) ? (tgt & 1023u) : atomicAdd(&sClsUsed[cls], 1u);
                         if (slot < CLS_CAP) {
                             const size_t at = (size_t) cls * CLS_CAP + slot;
@@ -1219,12 +1231,16 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
         __syncthreads();                                   // (also orders the region stores before the reads of pass 2)
         const unsigned long long tGather = wall_clock64();
         if (sOverflow) {
-            if (tid == 0) { A.overflow_list[atomicAdd(A.overflow_count, 1u)] = q - A.q_first; atomicAdd(&A.totals[6], tGather - tStart); atomicAdd(&A.totals[8], 1ull); }
+            if (tid == 0) {
+                const uint32_t at = atomicAdd(A.overflow_count, 1u);
+                A.overflow_list[at] = q - A.q_first; A.overflow_parts[at] = part;
+                atomicAdd(&A.totals[6], tGather - tStart); atomicAdd(&A.totals[8], 1ull);
+            }
             continue;
         }
         uint32_t hitsAll = 0;
         for (int k = 0; k < NW; k++) hitsAll += sWaveHits[k];
-        if (tid == 0) {
+        if (tid == 0 && PART_R == 0u) {                    // (the statistics of a query are its first part's: every part enumerates everything)
             uint32_t km = 0, np = 0;
             for (int k = 0; k < NW; k++) { km += sWaveKmers[k]; np += sWavePos[k]; }
             atomicAdd(&A.totals[0], (unsigned long long) km);
@@ -1248,9 +1264,9 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
         // a group of several small classes sorts on the whole (mapped) target id and leaves the rank 48 - T_BITS bits; a query with more hits than that
         // takes its classes one by one (the class number is then implied: RES_BITS of target, the rank gets LOG_NCLS bits more)
         const bool oneClassGroups = hitsAll >= A.one_class_hits;
-        for (uint32_t c0 = 0; c0 < (uint32_t) NCLS; ) {
+        for (uint32_t c0 = 0; c0 < NLOC; ) {
             uint32_t c1 = c0, recs = 0;
-            while (c1 < (uint32_t) NCLS && (c1 == c0 || (!oneClassGroups && recs + sClsUsed[c1] <= (uint32_t) GROUP_MAX))) { recs += sClsUsed[c1]; c1++; }
+            while (c1 < NLOC && (c1 == c0 || (!oneClassGroups && recs + sClsUsed[c1] <= (uint32_t) GROUP_MAX))) { recs += sClsUsed[c1]; c1++; }
             const uint32_t g0 = c0, g1 = c1;
             c0 = c1;
             if (recs == 0) continue;
@@ -1472,7 +1488,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
                         const uint32_t dst = ebase + sWordPrefix[t >> 5] + (uint32_t) __popc(word & ((1u << (t & 31u)) - 1u));
                         const uint64_t key = sKey[t];
                         A.C.q[dst] = q - A.q_first;
-                        A.C.id[dst] = wide_inv((uint32_t) (key >> TSHIFT) | (single ? g0 << RES_BITS : 0u), T_BITS);
+                        A.C.id[dst] = wide_inv((uint32_t) (key >> TSHIFT) | (single ? ((g0 << LOG_M) | PART_R) << RES_BITS : 0u), T_BITS);
                         A.C.ordinal[dst] = (uint32_t) ((key << FIELD_BITS) >> (FIELD_BITS + 16u));
                         A.C.diag[dst] = (uint16_t) key;
                     }
@@ -2362,10 +2378,6 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
             if (cs && !k7enum) cs->kmers_per_pos += sum;
         }
         if (!order.empty()) {
-            uint32_t *hList = (uint32_t *) pinned_scratch("pf_flist_h", order.size() * 4);
-            uint32_t *dList = (uint32_t *) dev_scratch("pf_flist", order.size() * 4);
-            uint32_t *dOvf = (uint32_t *) dev_scratch("pf_fovf", (size_t) nqp * 4);
-            PNULL(hList); PNULL(dList); PNULL(dOvf);
             int perCu = W.wgPerCu;
             // beside the alignment stage of mk_search: profile queries leave it most of the work (config 4: at most 16 prefilter waves per CU);
             // a sequence search with k = 7 or beyond 2^22 targets is 90 % prefilter (2*10^5 ... 3*10^6 index hits per fragment, 300 pairs to align):
@@ -2385,66 +2397,66 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
             // (the rank of a hit has 48 - t_bits + log2(classes) bits in the key of a one-class group; the arrival ordinal of a candidate is a uint32)
             const uint64_t byRank = std::min<uint64_t>(1ull << (48u - A.t_bits), (1ull << 31) / (uint64_t) W.nCls);
             const uint32_t nCandPiece = nCand;
-            // Round 6: TIERS.  The regions of the persistent workgroups share one pool; a query that fills a class of the first launch (512 regions) is
-            // tried again by a launch with a QUARTER of the workgroups and four times the class -- 128, 32, 8 regions -- in the same pool, and only what
-            // overflows the last one (or has more k-mer starts than the kernel numbers) goes to the sort-based global path.  At 60 M proteins the pool
-            // holds 2-3 M hits per query at 512 regions and a third of the fragments of a metagenome gather more (profiles/r06_config5.txt).
-            const int maxTiers = (int) std::max(1L, std::min(4L, knob_long("MK_PREFILTER_WIDE_TIERS", 4)));
-            const auto tier_grid = [&](int tier) { return std::max<unsigned>(1u, ((unsigned) cus * perCu) >> (2 * tier)); };
-            const auto tier_cap = [&](int tier) -> uint32_t {
-                return W.clsCap != 0 ? (uint32_t) std::min<uint64_t>(byRank, (uint64_t) W.clsCap << (2 * tier))
-                                     : (uint32_t) std::max<uint64_t>(4096, std::min<uint64_t>(byRank, budget / ((uint64_t) tier_grid(tier) * W.nCls * 12ull)) & ~63ull);
-            };
-            // A query that fills a class has wasted its pass 1 (a quarter of the kernel's time at 60 M proteins when everything starts in the first
-            // tier): every query STARTS in the tier its expected hits fit -- similar k-mers (k-mer starts when the 7-mers are enumerated in the kernel)
-            // x the hits per unit this database has shown so far (before the first launch: index entries per table cell, x 2 500 similar 7-mers per
-            // start) with a quarter of headroom -- and only the misjudged ones are retried
+            // Round 6: PARTS.  A query whose hits do not fit one region is taken by M = 2, 4, 8 ... workgroups, each keeping the target classes of one
+            // residue modulo M (wide_kernel): every region stays in use, whatever the hits per query -- at 60 M proteins a region of the 24 GB pool
+            // holds 4 M hits and a third of the fragments of a metagenome gather more; they went to the sort-based global path (rounds 4-5), and as a
+            // first attempt of this round to launches with a quarter of the workgroups and four times the region, which ran at a third of the speed
+            // (profiles/r06_config5.txt).  A part that fills a class has wasted its pass 1, so every query STARTS with the M its expected hits need --
+            // similar k-mers (k-mer starts when the 7-mers are enumerated in the kernel) x the hits per unit this database has shown so far (before
+            // the first launch: index entries per table cell, x 2 500 similar 7-mers per start), a quarter of headroom -- and only a misjudged part
+            // is run again, as its two halves.
+            A.cls_cap = W.clsCap != 0 ? (uint32_t) W.clsCap
+                                      : (uint32_t) std::max<uint64_t>(4096, std::min<uint64_t>(byRank, budget / ((uint64_t) cus * perCu * W.nCls * 12ull)) & ~63ull);
+            const unsigned gridMax = (unsigned) cus * perCu;
+            for (;;) {                                         // a pool that cannot be had is halved (fuller classes: more parts per query)
+                const size_t regionRecs = (size_t) W.nCls * A.cls_cap;
+                A.pool = (uint64_t *) dev_scratch("pf_wpool", (size_t) gridMax * regionRecs * 8);
+                A.pool_ord = A.pool ? (uint32_t *) dev_scratch("pf_wpoolord", (size_t) gridMax * regionRecs * 4) : nullptr;
+                if ((A.pool && A.pool_ord) || W.clsCap != 0 || A.cls_cap <= 4096) break;
+                (void) hipGetLastError();
+                A.cls_cap = std::max<uint32_t>(4096, (A.cls_cap / 2) & ~63u);
+            }
+            PNULL(A.pool); PNULL(A.pool_ord);
+            int nClsLog = 0; while ((1 << nClsLog) < W.nCls) nClsLog++;
+            // (a part keeps at least two classes, its classes at most what the rank bits number)
+            int maxLogM = std::max(0, nClsLog - 1);
+            while (maxLogM > 0 && ((uint64_t) A.cls_cap << maxLogM) > byRank) maxLogM--;
+            maxLogM = (int) std::min<long>(maxLogM, std::max(0L, knob_long("MK_PREFILTER_WIDE_MAX_LOGM", 4)));
             double perUnit;
             { std::lock_guard<std::mutex> lk(g_memoMutex); perUnit = g_memo.entries == (const void *) Vin.entries ? g_memo.wideHitsPerUnit : 0.0; }
             if (perUnit <= 0) perUnit = (double) Vin.n_entries / (Vin.kmer_size == 7 ? 1.28e9 : 6.4e7) * (k7enum ? 2500.0 : 1.0);
-            std::vector<uint32_t> tierQ[4];
+            std::vector<uint32_t> itemQ, itemPart;           // the work list: view query id, r | log2(M) << 8
+            const double regionHits = (double) W.nCls * (double) A.cls_cap;
             for (size_t k = 0; k < order.size(); k++) {
                 const double est = 1.25 * perUnit * (double) orderUnits[k];
-                int t = 0;
-                while (t + 1 < maxTiers && est > (double) W.nCls * (double) tier_cap(t) && tier_cap(t + 1) > tier_cap(t)) t++;
-                tierQ[t].push_back(order[k]);
+                int lm = 0;
+                while (lm < maxLogM && est > regionHits * (double) (1u << lm)) lm++;
+                if (est > 4.0 * regionHits * (double) (1u << lm)) { fallback.push_back(order[k] - a); continue; }   // (far beyond every region: the global path)
+                for (uint32_t r = 0; r < (1u << lm); r++) { itemQ.push_back(order[k]); itemPart.push_back(r | ((uint32_t) lm << 8)); }
             }
-            size_t nList = 0;                              // queries handed on by the tier before (view ids in hList[0 .. nList))
-            uint32_t prevCap = 0;
             bool redoGlobal = false;
-            double unitsDone = 0, hitsDone = 0;
-            for (int tier = 0; tier < maxTiers; tier++) {
-                if (nList + tierQ[tier].size() > order.size()) { err = "wide tiers: list overrun"; return MK_ERR_DEVICE; }
-                std::memcpy(hList + nList, tierQ[tier].data(), tierQ[tier].size() * 4);      // (the overflowed ones of the tier before first: they are the largest)
-                nList += tierQ[tier].size();
-                if (nList == 0) continue;
-                const unsigned gridMax = tier_grid(tier);
-                const unsigned launch = (unsigned) std::min<size_t>(nList, gridMax);
-                A.cls_cap = tier_cap(tier);
-                if (tier > 0 && A.cls_cap <= prevCap) break;          // (the rank bits are spent: a larger class cannot be numbered)
-                for (;;) {                                         // a pool that cannot be had is halved (fuller classes send more queries to the next tier / the global path)
-                    const size_t regionRecs = (size_t) W.nCls * A.cls_cap;
-                    A.pool = (uint64_t *) dev_scratch("pf_wpool", (size_t) gridMax * regionRecs * 8);
-                    A.pool_ord = A.pool ? (uint32_t *) dev_scratch("pf_wpoolord", (size_t) gridMax * regionRecs * 4) : nullptr;
-                    if ((A.pool && A.pool_ord) || W.clsCap != 0 || A.cls_cap <= 4096) break;
-                    (void) hipGetLastError();
-                    A.cls_cap = std::max<uint32_t>(4096, (A.cls_cap / 2) & ~63u);
-                }
-                PNULL(A.pool); PNULL(A.pool_ord);
-                if (tier > 0 && A.cls_cap <= prevCap) break;
-                prevCap = A.cls_cap;
-                PCHK(hipMemcpyAsync(dList, hList, nList * 4, hipMemcpyHostToDevice, stream));
+            double unitsDone = 0, hitsDone = 0, kmersPerPosDone = 0;
+            unsigned long long dbMatchesDone = 0;
+            for (int round = 0; !itemQ.empty(); round++) {
+                const size_t nItems = itemQ.size();
+                uint32_t *hItems = (uint32_t *) pinned_scratch("pf_witems_h", nItems * 8);
+                uint32_t *dItems = (uint32_t *) dev_scratch("pf_witems", nItems * 8);
+                uint32_t *dOvfItems = (uint32_t *) dev_scratch("pf_wovf", nItems * 8);
+                PNULL(hItems); PNULL(dItems); PNULL(dOvfItems);
+                std::memcpy(hItems, itemQ.data(), nItems * 4);
+                std::memcpy(hItems + nItems, itemPart.data(), nItems * 4);
+                const unsigned launch = (unsigned) std::min<size_t>(nItems, gridMax);
+                PCHK(hipMemcpyAsync(dItems, hItems, nItems * 8, hipMemcpyHostToDevice, stream));
                 PCHK(hipMemsetAsync(dCtr, 0, 64, stream));
                 hCtr[0] = nCand;                               // (pinned: the copy below reads it when the stream gets there -- synchronised before it is reused)
                 PCHK(hipMemcpyAsync(dCtr, hCtr, 4, hipMemcpyHostToDevice, stream));
                 PCHK(hipMemsetAsync(dTot, 0, 16 * 8, stream));
-                A.V = V; A.queries = dList; A.n_queries = (uint32_t) nList; A.q_first = a;
+                A.V = V; A.queries = dItems; A.parts = dItems + nItems; A.n_queries = (uint32_t) nItems; A.q_first = a;
                 A.C = X.C; A.cand_cap = X.candCap; A.counters = dCtr;
-                A.overflow_list = dOvf; A.overflow_count = dCtr + 4; A.totals = dTot; A.work_counter = dCtr + 8;
+                A.overflow_list = dOvfItems; A.overflow_parts = dOvfItems + nItems; A.overflow_count = dCtr + 4; A.totals = dTot; A.work_counter = dCtr + 8;
                 A.pos_cost = dPosCost; A.pos_begin = hOff[p0];
                 A.exp = (uint32_t) knob_long("MK_PREFILTER_WIDE_EXP", 0);
-                static const char *const tierName[4] = {"prefilter_query_wide", "prefilter_query_wide_tier1", "prefilter_query_wide_tier2", "prefilter_query_wide_tier3"};
-                const int th = X.tb(tierName[tier], 0, 0);
+                const int th = X.tb(round == 0 ? "prefilter_query_wide" : "prefilter_query_wide_retry", 0, 0);
                 if (k7enum) launch_wide<W_MODE_ENUM7>(shape, A, launch, stream);
                 else if (listed) launch_wide<W_MODE_LIST>(shape, A, launch, stream);
                 else launch_wide<W_MODE_ENUM6>(shape, A, launch, stream);
@@ -2454,30 +2466,40 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
                 PCHK(hipMemcpyAsync(hTot, dTot, 16 * 8, hipMemcpyDeviceToHost, stream));
                 PCHK(sync_wait(stream, "wait_prefilter"));
                 if (knob("MK_PREFILTER_DEBUG"))
-                    fprintf(stderr, "[prefilter] wide piece %u..%u tier %d (%s; %u regions of %d x %u records): queries %zu overflowed %llu | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g filter %.3g collect+sort %.3g rule+emit %.3g overflowed %.3g | extra sub-class passes %llu | cand %u -> %u\n",
-                            p0, p1, tier, k7enum ? "7-mers in the kernel" : (listed ? "lists" : "k = 6 enumerator"), launch, W.nCls, A.cls_cap, nList, hTot[8], (double) hTot[0], (double) hTot[1], (double) hTot[2], (double) hTot[3], (double) hTot[12], (double) hTot[4], (double) hTot[5],
+                    fprintf(stderr, "[prefilter] wide piece %u..%u round %d (%s; %u regions of %d x %u records): items %zu overflowed %llu | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g filter %.3g collect+sort %.3g rule+emit %.3g overflowed %.3g | extra sub-class passes %llu | cand %u -> %u\n",
+                            p0, p1, round, k7enum ? "7-mers in the kernel" : (listed ? "lists" : "k = 6 enumerator"), launch, W.nCls, A.cls_cap, nItems, hTot[8], (double) hTot[0], (double) hTot[1], (double) hTot[2], (double) hTot[3], (double) hTot[12], (double) hTot[4], (double) hTot[5],
                             (double) hTot[6], hTot[9], nCand, hCtr[0]);
                 if (hCtr[0] > X.candCap) return RC_CAND_OVERFLOW;
                 if (hTot[10] != 0) { redoGlobal = true; break; }
                 X.ts(th, 16.0 * (double) hTot[0] + 6.0 * (double) hTot[1], (double) hTot[0]);
                 nCand = hCtr[0];
-                if (cs) cs->db_matches += hTot[1];
-                if (cs && k7enum) { double sumK; std::memcpy(&sumK, &hTot[11], 8); cs->kmers_per_pos += sumK; }
+                dbMatchesDone += hTot[1];
+                if (k7enum) { double sumK; std::memcpy(&sumK, &hTot[11], 8); kmersPerPosDone += sumK; }
                 unitsDone += (double) (k7enum ? hTot[2] : hTot[0]); hitsDone += (double) hTot[1];
                 const uint32_t nOvf = hCtr[4];
-                nList = 0;
+                itemQ.clear(); itemPart.clear();
                 if (nOvf > 0) {
-                    uint32_t *hOvf = (uint32_t *) pinned_scratch("pf_fovf_h", (size_t) nOvf * 4);
+                    uint32_t *hOvf = (uint32_t *) pinned_scratch("pf_wovf_h", (size_t) nOvf * 8);
                     PNULL(hOvf);
-                    PCHK(hipMemcpyAsync(hOvf, dOvf, (size_t) nOvf * 4, hipMemcpyDeviceToHost, stream));
+                    PCHK(hipMemcpyAsync(hOvf, dOvfItems, (size_t) nOvf * 4, hipMemcpyDeviceToHost, stream));
+                    PCHK(hipMemcpyAsync(hOvf + nOvf, dOvfItems + nItems, (size_t) nOvf * 4, hipMemcpyDeviceToHost, stream));
                     PCHK(sync_wait(stream, "wait_prefilter"));
-                    for (uint32_t k = 0; k < nOvf; k++) hList[k] = hOvf[k] + a;          // (chunk-local ids -> view query ids: the next tier's list)
-                    nList = nOvf;
+                    for (uint32_t k = 0; k < nOvf && !redoGlobal; k++) {
+                        const uint32_t r = hOvf[nOvf + k] & 0xFFu, lm = hOvf[nOvf + k] >> 8;
+                        // the part's two halves; a part that cannot be halved any more has emitted nothing, but the other parts of its query have:
+                        // the piece is done again by the global path (never seen: the estimate would have to be off by the factor of 4 above)
+                        if ((int) lm >= maxLogM) { redoGlobal = true; break; }
+                        for (uint32_t h = 0; h < 2; h++) { itemQ.push_back(hOvf[k] + a); itemPart.push_back((r | (h << lm)) | ((lm + 1) << 8)); }
+                    }
                 }
+                if (redoGlobal) break;
             }
-            if (unitsDone > 0 && hitsDone > 0) {
-                std::lock_guard<std::mutex> lk(g_memoMutex);
-                if (g_memo.entries == (const void *) Vin.entries) g_memo.wideHitsPerUnit = g_memo.wideHitsPerUnit > 0 ? 0.5 * (g_memo.wideHitsPerUnit + hitsDone / unitsDone) : hitsDone / unitsDone;
+            if (!redoGlobal) {
+                if (cs) { cs->db_matches += dbMatchesDone; if (k7enum) cs->kmers_per_pos += kmersPerPosDone; }
+                if (unitsDone > 0 && hitsDone > 0) {
+                    std::lock_guard<std::mutex> lk(g_memoMutex);
+                    if (g_memo.entries == (const void *) Vin.entries) g_memo.wideHitsPerUnit = g_memo.wideHitsPerUnit > 0 ? 0.5 * (g_memo.wideHitsPerUnit + hitsDone / unitsDone) : hitsDone / unitsDone;
+                }
             }
             if (redoGlobal) {
                 // a single target class held more double-hit survivors of one sub-class than the LDS sort: the piece's candidates are dropped
@@ -2489,8 +2511,6 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
                 const int rc = global_candidates(X, Vin, hOff, p0, p1, nullptr, (uint32_t) 0 - a, nCand, globalHitsPerPos);
                 X.statsKmers = sk;
                 if (rc != MK_OK) return rc;
-            } else {
-                for (size_t k = 0; k < nList; k++) fallback.push_back(hList[k] - a);   // what the last tier could not hold
             }
         }
         p0 = p1;

@@ -290,19 +290,20 @@ def test_database_hits_overflow_path(gpu_api, tmp_path):
     assert "host_prefilter_overflow" in api.kernel_stats()
 
 
-def test_wide_kernel_tiers_and_one_class_groups(gpu_api, tmp_path, monkeypatch):
-    """Round 6: the wide per-query kernel retries a query that fills a target class with a quarter of the workgroups and four times the class
-    (three more tiers in the same pool), and a query with more hits than the rank bits beside a whole target id number takes its classes one by
-    one (the class number leaves the sort key: mk_prefilter.hip wide_fwd / wide_inv).  The miniature shape (4 classes of 192 records) on families
-    of near-copies -- 1 000 ... 40 000 index hits per query: every tier, and beyond the last one the global path -- with one tier / four tiers and
+def test_wide_kernel_query_parts_and_one_class_groups(gpu_api, tmp_path, monkeypatch):
+    """Round 6: a query whose hits do not fit one region of the wide per-query kernel is taken by M workgroups, each keeping the target classes of
+    one residue modulo M (every part enumerates everything; arrival ranks count all hits); a part that still fills a class is run again as its two
+    halves; and a query with more hits than the rank bits beside a whole target id number takes its classes one by one (the class number leaves
+    the sort key: mk_prefilter.hip wide_fwd / wide_inv).  The miniature shape (4 classes of 192 records: parts of two classes) on families of
+    near-copies -- 1 000 ... 40 000 index hits per query: one part, two parts, retries, and beyond them the global path -- with and without parts,
     multi-class / one-class groups: always the oracle's bytes (QueryMatcher.cpp:213-346)."""
     rng = random.Random(11)
     mut = lambda s, r: "".join(rng.choice(AA) if rng.random() < r else c for c in s)
     targets, queries = [], []
-    for copies in (30, 120, 500, 2000):
+    for copies in (8, 20, 60, 500):
         base = _rand_seq(rng, 160)
         targets += [mut(base, 0.03) for _ in range(copies)]
-        queries += [base[10:60], mut(base[40:140], 0.05), base]
+        queries += [base[10:40], base[10:60], mut(base[40:140], 0.05), base]
     targets += [_rand_seq(rng, rng.randrange(50, 300)) for _ in range(300)]
     queries += [_rand_seq(rng, 40), ""]
     order = list(range(len(targets)))
@@ -315,23 +316,19 @@ def test_wide_kernel_tiers_and_one_class_groups(gpu_api, tmp_path, monkeypatch):
     opref, oaln = oracle.run_pipeline(targets, queries, str(tmp_path), extra=["--l2", "2097152"])
     monkeypatch.setenv("MK_PREFILTER_PATH", "wide")
     monkeypatch.setenv("MK_PREFILTER_TIERS", "tiny")
-    seen_retry = False
-    for tiers in ("1", "4"):
+    monkeypatch.setenv("MK_PREFILTER_DEBUG", "1")
+    for max_logm in ("0", "4"):
         for one_class in ("0", "1"):
-            monkeypatch.setenv("MK_PREFILTER_WIDE_TIERS", tiers)
+            monkeypatch.setenv("MK_PREFILTER_WIDE_MAX_LOGM", max_logm)
             monkeypatch.setenv("MK_TEST_WIDE_ONE_CLASS", one_class)
-            api.kernel_stats(reset=True)
-            q = api.Queries(queries, params)
-            (hits, hoff), (alns, aoff) = api.search(db, q)
-            for i in range(len(queries)):
-                assert api.format_hits(hits, int(hoff[i]), int(hoff[i + 1])) == opref[i], ("pref", tiers, one_class, i)
-                assert api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1])) == oaln[i], ("aln", tiers, one_class, i)
-            st = api.kernel_stats()
-            later = [k for k in st if k.startswith("prefilter_query_wide_tier")]
-            assert bool(later) == (tiers == "4"), (tiers, sorted(st))
-            seen_retry = seen_retry or len(later) >= 2
-            q.close()
-    assert seen_retry and int(hoff[-1]) > 1000
+            for rep in range(2):                                 # (the second call routes the queries with the hits per k-mer the first one has seen)
+                q = api.Queries(queries, params)
+                (hits, hoff), (alns, aoff) = api.search(db, q)
+                for i in range(len(queries)):
+                    assert api.format_hits(hits, int(hoff[i]), int(hoff[i + 1])) == opref[i], ("pref", max_logm, one_class, rep, i)
+                    assert api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1])) == oaln[i], ("aln", max_logm, one_class, rep, i)
+                q.close()
+    assert int(hoff[-1]) > 300
     db.close()
 
 

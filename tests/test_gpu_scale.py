@@ -475,6 +475,11 @@ def test_config5_60M_proteins_pinned_to_the_reference_by_target_splits(gpu_api, 
     assert int(off[-1]) == gold["target_residues"]
     fr, foff, src = c5.make_fragments(api, res, off, gold["n_queries"], gold.get("n_long_queries", 0))
     nq = len(foff) - 1
+    # round 6: the END-TO-END pin over the same database (tools/config5_digest.py --contigs: ref_harness orfs | pipeline --split N | exons on
+    # seeded contigs whose genes derive from proteins of this database -> tests/golden/config5_e2e_<n>_split<N>.json)
+    e2e_path = os.path.join(root, "tests", "golden", "config5_e2e_%d_split%d.json" % (n_targets, gold["target_splits"]))
+    e2e = json.load(open(e2e_path)) if os.path.exists(e2e_path) else None
+    contigs = c5.make_contigs(api, res, off, e2e["n_contigs"] - 1) if e2e else None
     api.synth_write_seqdb(str(tmp_path / "T"), res, off)
     api.synth_write_seqdb(str(tmp_path / "Q"), fr, foff)
     del res
@@ -503,6 +508,34 @@ def test_config5_60M_proteins_pinned_to_the_reference_by_target_splits(gpu_api, 
     if os.path.isdir(out):
         with open(os.path.join(out, "config5_split_case_%d.json" % n_targets), "w") as f:
             json.dump(report, f, indent=1)
+    e2e_report = None
+    if e2e:
+        # `metaeuk-amd predictexons --split N --split-mode 0`: extractorfs on the device, every target range masked, indexed and searched in turn, the
+        # joined lists aligned against the whole database, resultspercontig + collectoptimalset (data/predictexons.sh:42-87)
+        assert len(contigs) == e2e["n_contigs"]
+        api.write_seq_db(str(tmp_path / "C"), api.seq_db_image(contigs), dbtype=1)
+        t0 = time.time()
+        r = run("predictexons", tmp_path / "C", tmp_path / "T", tmp_path / "calls", tmp_path / "tmp", "--split", N, "--split-mode", "0", "-s", "5.7",
+                "--ref-l2-bytes", e2e["host_l2_bytes"], "--threads", int(api.lib().mk_host_threads()))
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        t_e2e = time.time() - t0
+        frag = [ln for ln in r.stderr.decode().splitlines() if ln.startswith("predictexons:") and "fragments" in ln]
+        n_frag = int(frag[-1].split("->")[1].split("fragments")[0]) if frag else -1
+        data = open(str(tmp_path / "calls"), "rb").read()
+        got = {}
+        for line in open(str(tmp_path / "calls.index")):
+            k, o, l = line.split("\t")
+            got[int(k)] = data[int(o):int(o) + int(l) - 1].decode()
+        per = [got.get(c, "") for c in range(len(contigs))]
+        e2e_report = dict(contigs=len(contigs), fragments=n_frag, t_predictexons_command_s=round(t_e2e, 1), contigs_with_predictions=sum(1 for x in per if x),
+                          prediction_lines=sum(x.count("\n") for x in per), sha256_exon_sets=c5.exon_sets_digest(per),
+                          reference=dict(fragments=e2e["fragments"], contigs_with_predictions=e2e["reference"]["contigs_with_predictions"],
+                                         prediction_lines=e2e["reference"]["prediction_lines"], sha256_exon_sets=e2e["sha256_exon_sets"]),
+                          match=(c5.exon_sets_digest(per) == e2e["sha256_exon_sets"]))
+        print("config 5, contigs -> exon sets over target splits:", json.dumps(e2e_report))
+        if os.path.isdir(out):
+            with open(os.path.join(out, "config5_e2e_case_%d.json" % n_targets), "w") as f:
+                json.dump(e2e_report, f, indent=1)
     for name in ("T", "Q"):
         for sfx in ("", ".index", ".dbtype"):
             os.remove(str(tmp_path / (name + sfx)))
@@ -511,3 +544,7 @@ def test_config5_60M_proteins_pinned_to_the_reference_by_target_splits(gpu_api, 
     assert n_hits == gold["reference"]["pref_hits"], report
     assert d_pref == gold["sha256_pref"], report
     assert n_aln == gold["reference"]["passed"] and d_aln == gold["sha256_aln"], report
+    if e2e_report is not None:
+        assert e2e_report["fragments"] == e2e["fragments"], e2e_report
+        assert e2e_report["contigs_with_predictions"] == e2e["reference"]["contigs_with_predictions"] and e2e_report["match"], e2e_report
+        assert e2e_report["contigs_with_predictions"] >= 0.8 * (len(contigs) - 1), e2e_report
