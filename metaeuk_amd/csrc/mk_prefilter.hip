@@ -1072,8 +1072,8 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
 
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, w = tid / WAVE, lane = tid & (WAVE - 1);
-    const uint32_t T_BITS = A.t_bits;
-    const uint32_t RES_BITS = T_BITS - (uint32_t) LOG_NCLS;           // what names a target inside its class
+    const uint32_t T_BITS = A.t_bits, CLS_CAP = A.cls_cap;
+    const uint32_t CLS_SHIFT = T_BITS - (uint32_t) LOG_NCLS;          // class of a target = the top bits of its mapped id
     uint64_t *region = A.pool + (size_t) blockIdx.x * NCLS * A.cls_cap;
     uint32_t *regionOrd = A.pool_ord + (size_t) blockIdx.x * NCLS * A.cls_cap;
     const uint64_t TMASK = (1ull << T_BITS) - 1ull;
@@ -1092,13 +1092,13 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
         if (item >= A.n_queries) break;
         const uint32_t q = A.queries[item];
         // Round 6: a query with more hits than a region holds is taken by M = 2, 4, 8 ... workgroups at once: each enumerates and probes ALL k-mers (a
-        // seventh of the kernel's time at 60 M proteins: profiles/r06_config5.txt) but keeps only the hits of ITS target classes -- (class & (M - 1))
-        // == r --, whose NCLS / M classes share its region (M times the records per class), and runs pass 2 on them.  Arrival ranks count all hits, so
-        // the parts' candidates are what one workgroup would have emitted, class by class.
+        // seventh of the kernel's time at 60 M proteins: profiles/r06_config5.txt) but keeps only the hits of ITS targets -- the log2(M) bits of the
+        // mapped id below the class bits == r -- in the NCLS classes of its region, and runs pass 2 on them: the query's hits lie in M x NCLS classes
+        // of the usual size (M times larger classes cost pass 2 quadratically: subsets x sweeps).  Arrival ranks count all hits, so the parts'
+        // candidates are what one workgroup would have emitted, target by target.
         const uint32_t part = A.parts ? A.parts[item] : 0u;
         const uint32_t PART_R = part & 0xFFu, LOG_M = part >> 8, PART_MASK = (1u << LOG_M) - 1u;
-        const uint32_t NLOC = (uint32_t) NCLS >> LOG_M;                  // classes of this part, numbered class >> LOG_M
-        const uint32_t CLS_CAP = A.cls_cap << LOG_M;                     // ... and their room in the region
+        const uint32_t RES_BITS = T_BITS - (uint32_t) LOG_NCLS - LOG_M;  // what names a target inside its class and part
         const uint64_t qs = A.V.q_off[q];
         const int L = (int) (A.V.q_off[q + 1] - qs);
         const int span = A.V.kmer_size == 7 ? 11 : 10;
@@ -1189,9 +1189,9 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
                     const auto put = [&](uint64_t ent, uint32_t rel) {
                         const uint32_t tgt = (uint32_t) ent;
                         const uint32_t diag = ((uint32_t) i - ((uint32_t) (ent >> 32) & 0xFFFFu)) & 0xFFFFu;
-                        const uint32_t cls0 = wide_fwd(tgt, T_BITS) >> RES_BITS;           // (a function of its own: the bitmap buckets of pass 2 must not follow the class)
-                        if ((cls0 & PART_MASK) != PART_R) return;                          // another part's class
-                        const uint32_t cls = cls0 >> LOG_M;
+                        const uint32_t f = wide_fwd(tgt, T_BITS);                          // (a function of its own: the bitmap buckets of pass 2 must not follow the class)
+                        if (((f >> RES_BITS) & PART_MASK) != PART_R) return;               // another part's target
+                        const uint32_t cls = f >> CLS_SHIFT;
                         const uint32_t slot = (A.exp & 2u) ? (tgt & 1023u) : atomicAdd(&sClsUsed[cls], 1u);
                         if (slot < CLS_CAP) {
                             const size_t at = (size_t) cls * CLS_CAP + slot;
@@ -1264,9 +1264,9 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
         // a group of several small classes sorts on the whole (mapped) target id and leaves the rank 48 - T_BITS bits; a query with more hits than that
         // takes its classes one by one (the class number is then implied: RES_BITS of target, the rank gets LOG_NCLS bits more)
         const bool oneClassGroups = hitsAll >= A.one_class_hits;
-        for (uint32_t c0 = 0; c0 < NLOC; ) {
+        for (uint32_t c0 = 0; c0 < (uint32_t) NCLS; ) {
             uint32_t c1 = c0, recs = 0;
-            while (c1 < NLOC && (c1 == c0 || (!oneClassGroups && recs + sClsUsed[c1] <= (uint32_t) GROUP_MAX))) { recs += sClsUsed[c1]; c1++; }
+            while (c1 < (uint32_t) NCLS && (c1 == c0 || (!oneClassGroups && recs + sClsUsed[c1] <= (uint32_t) GROUP_MAX))) { recs += sClsUsed[c1]; c1++; }
             const uint32_t g0 = c0, g1 = c1;
             c0 = c1;
             if (recs == 0) continue;
@@ -1488,7 +1488,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
                         const uint32_t dst = ebase + sWordPrefix[t >> 5] + (uint32_t) __popc(word & ((1u << (t & 31u)) - 1u));
                         const uint64_t key = sKey[t];
                         A.C.q[dst] = q - A.q_first;
-                        A.C.id[dst] = wide_inv((uint32_t) (key >> TSHIFT) | (single ? ((g0 << LOG_M) | PART_R) << RES_BITS : 0u), T_BITS);
+                        A.C.id[dst] = wide_inv((uint32_t) (key >> TSHIFT) | (single ? (g0 << CLS_SHIFT) | (PART_R << RES_BITS) : 0u), T_BITS);
                         A.C.ordinal[dst] = (uint32_t) ((key << FIELD_BITS) >> (FIELD_BITS + 16u));
                         A.C.diag[dst] = (uint16_t) key;
                     }
@@ -2403,7 +2403,7 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
             // first attempt of this round to launches with a quarter of the workgroups and four times the region, which ran at a third of the speed
             // (profiles/r06_config5.txt).  A part that fills a class has wasted its pass 1, so every query STARTS with the M its expected hits need --
             // similar k-mers (k-mer starts when the 7-mers are enumerated in the kernel) x the hits per unit this database has shown so far (before
-            // the first launch: index entries per table cell, x 2 500 similar 7-mers per start), a quarter of headroom -- and only a misjudged part
+            // the first launch: index entries per table cell, x 2 500 similar 7-mers per start), 40 % of headroom -- and only a misjudged part
             // is run again, as its two halves.
             A.cls_cap = W.clsCap != 0 ? (uint32_t) W.clsCap
                                       : (uint32_t) std::max<uint64_t>(4096, std::min<uint64_t>(byRank, budget / ((uint64_t) cus * perCu * W.nCls * 12ull)) & ~63ull);
@@ -2418,9 +2418,8 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
             }
             PNULL(A.pool); PNULL(A.pool_ord);
             int nClsLog = 0; while ((1 << nClsLog) < W.nCls) nClsLog++;
-            // (a part keeps at least two classes, its classes at most what the rank bits number)
-            int maxLogM = std::max(0, nClsLog - 1);
-            while (maxLogM > 0 && ((uint64_t) A.cls_cap << maxLogM) > byRank) maxLogM--;
+            // (the part number takes bits of the mapped target id below the class: at most 16 parts, and 8 bits stay for the targets of a class and part)
+            int maxLogM = std::max(0, std::min(4, (int) A.t_bits - nClsLog - 8));
             maxLogM = (int) std::min<long>(maxLogM, std::max(0L, knob_long("MK_PREFILTER_WIDE_MAX_LOGM", 4)));
             double perUnit;
             { std::lock_guard<std::mutex> lk(g_memoMutex); perUnit = g_memo.entries == (const void *) Vin.entries ? g_memo.wideHitsPerUnit : 0.0; }
@@ -2428,7 +2427,7 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
             std::vector<uint32_t> itemQ, itemPart;           // the work list: view query id, r | log2(M) << 8
             const double regionHits = (double) W.nCls * (double) A.cls_cap;
             for (size_t k = 0; k < order.size(); k++) {
-                const double est = 1.25 * perUnit * (double) orderUnits[k];
+                const double est = 1.4 * perUnit * (double) orderUnits[k];
                 int lm = 0;
                 while (lm < maxLogM && est > regionHits * (double) (1u << lm)) lm++;
                 if (est > 4.0 * regionHits * (double) (1u << lm)) { fallback.push_back(order[k] - a); continue; }   // (far beyond every region: the global path)
@@ -2489,7 +2488,7 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
                         // the part's two halves; a part that cannot be halved any more has emitted nothing, but the other parts of its query have:
                         // the piece is done again by the global path (never seen: the estimate would have to be off by the factor of 4 above)
                         if ((int) lm >= maxLogM) { redoGlobal = true; break; }
-                        for (uint32_t h = 0; h < 2; h++) { itemQ.push_back(hOvf[k] + a); itemPart.push_back((r | (h << lm)) | ((lm + 1) << 8)); }
+                        for (uint32_t h = 0; h < 2; h++) { itemQ.push_back(hOvf[k] + a); itemPart.push_back((2u * r + h) | ((lm + 1) << 8)); }
                     }
                 }
                 if (redoGlobal) break;

@@ -290,7 +290,7 @@ def test_database_hits_overflow_path(gpu_api, tmp_path):
     assert "host_prefilter_overflow" in api.kernel_stats()
 
 
-def test_wide_kernel_query_parts_and_one_class_groups(gpu_api, tmp_path, monkeypatch):
+def test_wide_kernel_query_parts_and_one_class_groups(gpu_api, tmp_path, monkeypatch, capfd):
     """Round 6: a query whose hits do not fit one region of the wide per-query kernel is taken by M workgroups, each keeping the target classes of
     one residue modulo M (every part enumerates everything; arrival ranks count all hits); a part that still fills a class is run again as its two
     halves; and a query with more hits than the rank bits beside a whole target id number takes its classes one by one (the class number leaves
@@ -328,7 +328,10 @@ def test_wide_kernel_query_parts_and_one_class_groups(gpu_api, tmp_path, monkeyp
                     assert api.format_hits(hits, int(hoff[i]), int(hoff[i + 1])) == opref[i], ("pref", max_logm, one_class, rep, i)
                     assert api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1])) == oaln[i], ("aln", max_logm, one_class, rep, i)
                 q.close()
-    assert int(hoff[-1]) > 300
+            err = capfd.readouterr().err
+            # (the library's debug lines: with parts there are retry rounds and work lists longer than the queries; without, the global path steps in)
+            assert ("round 1" in err) == (max_logm == "4"), (max_logm, err[-1500:])
+    assert int(hoff[-1]) > 100
     db.close()
 
 
