@@ -1037,6 +1037,7 @@ struct WideArgs {
     uint32_t cls_cap;                                 // records per target class (NCLS * cls_cap <= 2^(48 - t_bits) * NCLS and < 2^31: the arrival rank of a hit
                                                       // shares the sort key with the target bits a class leaves open)
     uint32_t t_bits;                                  // bits of a target id (>= 20)
+    uint32_t max_log_m;                               // a part that fills a class is halved by its workgroup up to M = 2^max_log_m; beyond: overflow_list
     uint32_t one_class_hits;                          // a query with at least this many hits takes its classes one by one (2^(48 - t_bits); the tests force 0)
     const uint16_t *pos_cost; uint64_t pos_begin;     // MODE 0: work estimate of every k-mer start (kmer_count_kernel)
     uint32_t exp;                                     // EXPERIMENT (MK_PREFILTER_WIDE_EXP, results WRONG): 1 no region stores, 2 no class atomic, 4 no tail entry loads, 8 no pass 2
@@ -1069,9 +1070,11 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
     __shared__ uint32_t sClsUsed[NCLS];               // records in every target class
     __shared__ uint32_t sSubCnt[STREAM_MAX_CLASSES];
     __shared__ uint32_t sNextPos, sOverflow, sItem, sSurv, sEmitBase, sEmitCount, sSubMax;
+    __shared__ uint32_t sRedo[2 * 8 + 2], sRedoN, sCurQ, sCurPart;     // halves of a part that filled a class, still to do (depth first: two per level)
 
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, w = tid / WAVE, lane = tid & (WAVE - 1);
+    if (tid == 0) sRedoN = 0;
     const uint32_t T_BITS = A.t_bits, CLS_CAP = A.cls_cap;
     const uint32_t CLS_SHIFT = T_BITS - (uint32_t) LOG_NCLS;          // class of a target = the top bits of its mapped id
     uint64_t *region = A.pool + (size_t) blockIdx.x * NCLS * A.cls_cap;
@@ -1086,17 +1089,23 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
     const auto sub_of = [&](uint64_t rec, uint32_t nSub) -> uint32_t { return ((mix32((uint32_t) (rec & TMASK) + 0x9E3779B9u) >> 8) * nSub) >> 24; };
     for (;;) {
         __syncthreads();                                  // the previous query's LDS is no longer read
-        if (tid == 0) sItem = atomicAdd(A.work_counter, 1u);
+        if (tid == 0) {
+            if (sRedoN > 0) { sCurPart = sRedo[--sRedoN]; sItem = 1; }     // a half of the part that has just filled a class (the query stays: sCurQ)
+            else {
+                const uint32_t it = atomicAdd(A.work_counter, 1u);
+                sItem = it < A.n_queries ? 1u : 0u;
+                if (it < A.n_queries) { sCurQ = A.queries[it]; sCurPart = A.parts ? A.parts[it] : 0u; }
+            }
+        }
         __syncthreads();
-        const uint32_t item = sItem;
-        if (item >= A.n_queries) break;
-        const uint32_t q = A.queries[item];
+        if (!sItem) break;
+        const uint32_t q = sCurQ;
         // Round 6: a query with more hits than a region holds is taken by M = 2, 4, 8 ... workgroups at once: each enumerates and probes ALL k-mers (a
         // seventh of the kernel's time at 60 M proteins: profiles/r06_config5.txt) but keeps only the hits of ITS targets -- the log2(M) bits of the
         // mapped id below the class bits == r -- in the NCLS classes of its region, and runs pass 2 on them: the query's hits lie in M x NCLS classes
         // of the usual size (M times larger classes cost pass 2 quadratically: subsets x sweeps).  Arrival ranks count all hits, so the parts'
         // candidates are what one workgroup would have emitted, target by target.
-        const uint32_t part = A.parts ? A.parts[item] : 0u;
+        const uint32_t part = sCurPart;
         const uint32_t PART_R = part & 0xFFu, LOG_M = part >> 8, PART_MASK = (1u << LOG_M) - 1u;
         const uint32_t RES_BITS = T_BITS - (uint32_t) LOG_NCLS - LOG_M;  // what names a target inside its class and part
         const uint64_t qs = A.V.q_off[q];
@@ -1232,8 +1241,16 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
         const unsigned long long tGather = wall_clock64();
         if (sOverflow) {
             if (tid == 0) {
-                const uint32_t at = atomicAdd(A.overflow_count, 1u);
-                A.overflow_list[at] = q - A.q_first; A.overflow_parts[at] = part;
+                if (LOG_M < A.max_log_m) {
+                    // the part is done again at once, as its two halves (one bit more of the mapped target id): the pass 1 just made is lost, but no
+                    // launch with a handful of workgroups follows (three retry launches were a fifth of a 60 M-protein search: profiles/r06_config5.txt)
+                    sRedo[sRedoN++] = (2u * PART_R + 1u) | ((LOG_M + 1u) << 8);
+                    sRedo[sRedoN++] = (2u * PART_R) | ((LOG_M + 1u) << 8);
+                    atomicAdd(&A.totals[13], 1ull);
+                } else {
+                    const uint32_t at = atomicAdd(A.overflow_count, 1u);
+                    A.overflow_list[at] = q - A.q_first; A.overflow_parts[at] = part;
+                }
                 atomicAdd(&A.totals[6], tGather - tStart); atomicAdd(&A.totals[8], 1ull);
             }
             continue;
@@ -2455,6 +2472,7 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
                 A.overflow_list = dOvfItems; A.overflow_parts = dOvfItems + nItems; A.overflow_count = dCtr + 4; A.totals = dTot; A.work_counter = dCtr + 8;
                 A.pos_cost = dPosCost; A.pos_begin = hOff[p0];
                 A.exp = (uint32_t) knob_long("MK_PREFILTER_WIDE_EXP", 0);
+                A.max_log_m = knob_long("MK_PREFILTER_WIDE_KERNEL_HALVES", 1) ? (uint32_t) maxLogM : 0u;
                 const int th = X.tb(round == 0 ? "prefilter_query_wide" : "prefilter_query_wide_retry", 0, 0);
                 if (k7enum) launch_wide<W_MODE_ENUM7>(shape, A, launch, stream);
                 else if (listed) launch_wide<W_MODE_LIST>(shape, A, launch, stream);
@@ -2465,8 +2483,8 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
                 PCHK(hipMemcpyAsync(hTot, dTot, 16 * 8, hipMemcpyDeviceToHost, stream));
                 PCHK(sync_wait(stream, "wait_prefilter"));
                 if (knob("MK_PREFILTER_DEBUG"))
-                    fprintf(stderr, "[prefilter] wide piece %u..%u round %d (%s; %u regions of %d x %u records): items %zu overflowed %llu | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g filter %.3g collect+sort %.3g rule+emit %.3g overflowed %.3g | extra sub-class passes %llu | cand %u -> %u\n",
-                            p0, p1, round, k7enum ? "7-mers in the kernel" : (listed ? "lists" : "k = 6 enumerator"), launch, W.nCls, A.cls_cap, nItems, hTot[8], (double) hTot[0], (double) hTot[1], (double) hTot[2], (double) hTot[3], (double) hTot[12], (double) hTot[4], (double) hTot[5],
+                    fprintf(stderr, "[prefilter] wide piece %u..%u round %d (%s; %u regions of %d x %u records): items %zu overflowed %llu (halved in the kernel %llu) | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g filter %.3g collect+sort %.3g rule+emit %.3g overflowed %.3g | extra sub-class passes %llu | cand %u -> %u\n",
+                            p0, p1, round, k7enum ? "7-mers in the kernel" : (listed ? "lists" : "k = 6 enumerator"), launch, W.nCls, A.cls_cap, nItems, hTot[8], hTot[13], (double) hTot[0], (double) hTot[1], (double) hTot[2], (double) hTot[3], (double) hTot[12], (double) hTot[4], (double) hTot[5],
                             (double) hTot[6], hTot[9], nCand, hCtr[0]);
                 if (hCtr[0] > X.candCap) return RC_CAND_OVERFLOW;
                 if (hTot[10] != 0) { redoGlobal = true; break; }
