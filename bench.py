@@ -325,6 +325,134 @@ def e2e_leg(api, args, params, targets, founders, t_res, t_off):
     return out
 
 
+
+def config5_leg_child(args):
+    """Runs in a process of its own (`bench.py --config5-only`; the 60 M-protein index takes 230 of the 288 GB): BASELINE config 5's target side at its
+    stated size -- 60 000 000 proteins, 2.25e10 residues, k = 7 -- masked and indexed in HBM once, then (a) `--config5-fragments` planted fragments searched
+    UNSPLIT with mk_search, twice: fragments/s of the warm pass and its kernel table; (b) the committed golden's fragments through `metaeuk-amd prefilter
+    --split N --split-mode 0` + `align`, digests against tests/golden/config5_digest_60000000_split<N>.json -- the reference's own run in TARGET_DB_SPLIT
+    mode (Prefiltering.cpp:273-377,352-362) on a GPU box's host cores, recorded there with its times."""
+    import glob
+    import hashlib
+    import shutil
+    from metaeuk_amd import api, build
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import config5_digest as c5
+    api.init(0)
+    n_targets = args.config5_targets
+    out = {"workload": "%d planted fragments (30-120 aa, 10 %% redrawn, every tenth background) x %d proteins of the native generator, -s 5.7, k = 7; mk_search unsplit" % (
+        args.config5_fragments, n_targets)}
+    free, total = api.device_memory()
+    if n_targets >= 60000000 and total < 280e9:
+        return {"skipped": "needs a 288 GB device (this one: %.0f GB)" % (total / 1e9)}
+    t0 = time.time()
+    res, off = api.synth_targets(n_targets, seed=c5.TARGET_SEED)
+    out["target_residues"] = int(off[-1])
+    fr, foff, src = api.synth_fragments(args.config5_fragments, res, off, **c5.FRAGMENTS)
+    golds = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "config5_digest_%d_split*.json" % n_targets)))
+    gold = json.load(open(golds[-1])) if golds else None
+    tmp = None
+    if gold and args.config5_digest:
+        need = 1.3 * gold["target_residues"] + 4e9
+        for cand in (os.environ.get("MK_TEST_SCRATCH"), os.environ.get("TMPDIR"), "/tmp", "/var/tmp", os.path.join(ROOT, "gpurun_out")):
+            if cand and os.path.isdir(cand) and os.access(cand, os.W_OK) and shutil.disk_usage(cand).free >= need:
+                tmp = tempfile.mkdtemp(prefix="mk_bench_config5_", dir=cand)
+                break
+        if tmp:
+            gfr, gfoff, _ = c5.make_fragments(api, res, off, gold["n_queries"], gold.get("n_long_queries", 0))
+            api.synth_write_seqdb(os.path.join(tmp, "T"), res, off)
+            api.synth_write_seqdb(os.path.join(tmp, "Q"), gfr, gfoff)
+    out["setup_s"] = {"generate_and_write_dbs": round(time.time() - t0, 1)}
+    p = api.default_params()
+    t0 = time.time()
+    db = api.TargetDB.from_codes(res, off, p)
+    out["setup_s"]["mask_and_index_in_hbm"] = round(time.time() - t0, 1)
+    out["kmer_size"], out["index_entries"] = db.kmer_size(), db.index_entries()
+    del res
+    times = []
+    for it in range(3):
+        api.kernel_stats(reset=True)
+        q = api.Queries.from_codes(fr, foff, p)
+        t0 = time.time()
+        (hits, hoff), (alns, aoff) = api.search(db, q, p)
+        times.append(time.time() - t0)
+        st = api.kernel_stats()
+        counts = (int(hoff[-1]), int(aoff[-1]))
+        q.close()
+    warm = min(times[1:])
+    out.update({"fragments": args.config5_fragments, "fragment_residues": int(foff[-1]), "s_per_pass_warm": round(warm, 3), "first_pass_s": round(times[0], 3),
+                "fragments_per_s": round(args.config5_fragments / warm, 1), "prefilter_hits": counts[0], "alignments": counts[1],
+                "device_memory_free_gb": round(api.device_memory()[0] / 1e9, 1),
+                "kernels_ms": {k: round(v["ms"], 1) for k, v in sorted(st.items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] >= 2.0}})
+    wide = {k: v for k, v in st.items() if k.startswith("prefilter_query_wide")}
+    if wide:
+        ms = sum(v["ms"] for v in wide.values())
+        kmers = sum(v["cells"] for v in wide.values())
+        ab = sum(v["alg_bytes"] for v in wide.values())
+        out["roofline"] = {"bound": "hbm", "kernel": "prefilter_query_wide", "achieved": ab / max(ms * 1e-3, 1e-12) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ab / max(ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms, "similar_kmers": kmers, "traffic": None,
+                           "note": "algorithmic bytes = 16 B per probed k-mer + 6 B per index entry (SURVEY 8(d)) of the wide per-query kernel over the warm pass / its event time"}
+    db.close()
+    if gold:
+        ref = gold["reference"]
+        out["cpu_baseline"] = {"value": round((gold["n_queries"] + gold.get("n_long_queries", 0)) / max(ref["t_prefilter_s"] + ref["t_align_s"], 1e-9), 1), "unit": "fragments/s",
+                               "cores": ref["threads"], "kind": "reference", "recorded": True,
+                               "sample": "RECORDED in %s, not re-run here (%.0f s): ref_harness pipeline --split %d over %d fragments on a GPU box's host cores, prefilter %.1f s + align %.1f s, "
+                                         "the four index builds (%.0f s) excluded" % (os.path.basename(golds[-1]), ref["wall_s"], gold["target_splits"],
+                                                                                    gold["n_queries"] + gold.get("n_long_queries", 0), ref["t_prefilter_s"], ref["t_align_s"], ref["t_index_s"])}
+    if gold and tmp:
+        def db_digest(base, n):
+            data = np.fromfile(base, dtype=np.uint8)
+            rows = np.loadtxt(base + ".index", dtype=np.int64, ndmin=2)
+            rows = rows[np.argsort(rows[:, 0], kind="stable")]
+            counts, bodies = np.zeros(n, dtype="<u8"), []
+            for k in range(n):
+                b = data[rows[k, 1]:rows[k, 1] + rows[k, 2] - 1].tobytes()
+                counts[k] = b.count(b"\n")
+                bodies.append(b)
+            h = hashlib.sha256()
+            h.update(counts.tobytes())
+            h.update(b"".join(bodies))
+            return h.hexdigest(), int(counts.sum())
+        N, nq = gold["target_splits"], gold["n_queries"] + gold.get("n_long_queries", 0)
+        thr = str(int(api.lib().mk_host_threads()))
+        t0 = time.time()
+        r1 = subprocess.run([build.BIN, "prefilter", os.path.join(tmp, "Q"), os.path.join(tmp, "T"), os.path.join(tmp, "pref"), "--split", str(N), "--split-mode", "0", "-s", "5.7",
+                             "--ref-l2-bytes", str(gold["host_l2_bytes"]), "--threads", thr], stderr=subprocess.PIPE)
+        t_pref = time.time() - t0
+        t0 = time.time()
+        r2 = subprocess.run([build.BIN, "align", os.path.join(tmp, "Q"), os.path.join(tmp, "T"), os.path.join(tmp, "pref"), os.path.join(tmp, "aln"), "--alignment-mode", "2", "-e", "100",
+                             "--min-aln-len", "11", "--threads", thr], stderr=subprocess.PIPE) if r1.returncode == 0 else None
+        t_aln = time.time() - t0
+        if r1.returncode == 0 and r2 is not None and r2.returncode == 0:
+            dp, nh = db_digest(os.path.join(tmp, "pref"), nq)
+            da, na = db_digest(os.path.join(tmp, "aln"), nq)
+            out["result_digest"] = {"fragments": nq, "target_splits": N, "gpu": {"prefilter": dp, "alignments": da}, "cpu": {"prefilter": gold["sha256_pref"], "alignments": gold["sha256_aln"]},
+                                    "match": dp == gold["sha256_pref"] and da == gold["sha256_aln"], "prefilter_hits": nh, "alignments": na,
+                                    "prefilter_command_s": round(t_pref, 1), "align_command_s": round(t_aln, 1),
+                                    "reference": "tests/golden/%s: oracle/_ref/ref_harness pipeline --split %d (the reference's TARGET_DB_SPLIT run, mergeTargetSplits)" % (os.path.basename(golds[-1]), N)}
+        else:
+            out["result_digest"] = {"match": False, "error": ((r1.stderr if r1.returncode else r2.stderr) or b"").decode()[-400:]}
+        shutil.rmtree(tmp, ignore_errors=True)
+    elif gold:
+        out["result_digest"] = {"match": None, "skipped": "no scratch directory with room for the 23 GB sequence DB" if args.config5_digest else "--config5-digest 0"}
+    return out
+
+
+def config5_leg(args):
+    """the config-5 leg in a process of its own; its one JSON line comes back on stdout"""
+    cmd = [sys.executable, os.path.abspath(__file__), "--config5-only", "--config5-targets", str(args.config5_targets), "--config5-fragments", str(args.config5_fragments),
+           "--config5-digest", str(args.config5_digest)]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.config5_timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": "the config-5 leg did not finish in %d s" % args.config5_timeout}
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "config-5 leg failed (rc %d): %s" % (r.returncode, r.stderr.decode()[-600:])}
+    return json.loads(lines[-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -351,9 +479,19 @@ def main():
                     "run (-1 = all of them, in pieces of --cpu-sample queries outside the timed region; 0 = only the CPU-baseline sample)")
     ap.add_argument("--e2e-sample", type=int, default=500, help="contigs of the end-to-end leg (`metaeuk-amd predictexons` over DBs on disk, N = 1 only) whose exon sets are "
                     "compared with the reference's chain; -1 = skip the leg")
+    ap.add_argument("--config5-targets", type=int, default=60000000, help="BASELINE config 5's target side beside the headline number (N = 1 only, a process of its own): "
+                    "this many proteins of the native generator, k = 7, masked and indexed in HBM; 0 = skip the leg")
+    ap.add_argument("--config5-fragments", type=int, default=20000, help="planted fragments of the config-5 leg's unsplit search")
+    ap.add_argument("--config5-digest", type=int, default=1, help="1: the leg also runs the committed golden's fragments through `metaeuk-amd prefilter --split N` + `align` and "
+                    "compares the digests with the reference's recorded TARGET_DB_SPLIT run (writes a 23 GB sequence DB to scratch)")
+    ap.add_argument("--config5-timeout", type=int, default=900)
+    ap.add_argument("--config5-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--config4-sample", type=int, default=2048, help="profiles of the config-4 leg whose hits and alignments are compared with the reference")
     args = ap.parse_args()
 
+    if args.config5_only:
+        print(json.dumps(config5_leg_child(args)))
+        return
     # the one JSON line goes to the real stdout; whatever libraries print there (RCCL's version banner at communicator creation) is
     # sent to stderr instead
     real_stdout = os.fdopen(os.dup(1), "w")
@@ -597,6 +735,7 @@ def main():
         line["config4_profile_targets"] = config4_leg(api, args, params, q_res, q_off, nq)
     if rank == 0 and world == 1 and args.e2e_sample >= 0:
         line["end_to_end_predictexons"] = e2e_leg(api, args, params, targets, founders, t_res, t_off)
+    run_config5 = rank == 0 and world == 1 and args.config5_targets > 0
     if rank == 0:
         if world == 1 and args.cpu_sample > 0:
             n_s = min(args.cpu_sample, nq)
@@ -636,8 +775,16 @@ def main():
                                                  "reference harness's own output for the same queries); gpu / cpu = SHA-256 over the pieces' digests"}
             except Exception as e:
                 line["result_digest"] = {"queries": n_s, "error": repr(e)}
+        if run_config5:
+            # (this process gives its HBM back first: the 60 M-protein index needs 230 of the 288 GB)
+            last.clear()
+            db.close()
+            api.shutdown()
+            line["config5_60M"] = config5_leg(args)
         # the metric names what was CHECKED in this run: matched / mismatched / not compared
         verdicts = [line.get("result_digest", {}).get("match")]
+        if line.get("config5_60M", {}).get("result_digest", {}).get("match") is not None:
+            verdicts.append(line["config5_60M"]["result_digest"]["match"])
         if "config4_profile_targets" in line:
             verdicts.append(line["config4_profile_targets"].get("result_digest", {}).get("match"))
         if line.get("end_to_end_predictexons", {}).get("result_digest", {}).get("match") is not None:

@@ -285,8 +285,9 @@ int mk_search_wait(mk_queries *q);
 /* Round 6: waits for every search in flight, then stops and JOINS the library's search threads (the reference's OpenMP team dies with its
  * parallel region, Prefiltering.cpp:817-886; a persistent engine needs an explicit end).  An in-process host calls it before it unloads the
  * library or tears its own state down; the library registers it with atexit when the first search begins, so a process that exits between
- * mk_search_begin and mk_search_wait leaves no thread behind.  The next mk_search / mk_search_begin starts the threads again.  Not to be
- * called concurrently with another entry point. */
+ * mk_search_begin and mk_search_wait leaves no thread behind.  The explicit call also gives the memory back that the library keeps between
+ * calls (pooled device blocks, the stages' device and pinned scratch, pooled result blocks); handles the caller holds stay valid.  The next
+ * mk_search / mk_search_begin starts the threads and allocates again.  Not to be called concurrently with another entry point. */
 void mk_shutdown(void);
 
 /* ---- kernel-level entry points (used by the parity tests and bench.py) ---- */

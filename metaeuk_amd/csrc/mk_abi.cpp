@@ -1835,7 +1835,17 @@ int mk_search_wait(mk_queries *q) {
     return rc;
 }
 
-void mk_shutdown(void) { engine_shutdown(); }
+void mk_shutdown(void) {
+    engine_shutdown();
+    // ... and the memory the library keeps between calls goes back: the device blocks of the query batches, the persistent device and pinned scratch
+    // of the stages, the pinned result blocks (a host that is done searching, or about to hand the GPU to another process, gets the HBM back; the
+    // next call allocates again).  Databases and batches the caller still holds are untouched
+    if (g_ready) {
+        (void) hipDeviceSynchronize();
+        dev_pool_trim();
+        mk::scratch_release_all();
+    }
+}
 
 int mk_search(mk_targetdb *db, mk_queries *q, const mk_params *P) {
     const int rc = mk_search_begin(db, q, P);

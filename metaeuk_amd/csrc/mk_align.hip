@@ -864,20 +864,20 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hi
         // is remembered per lane -- table id and the buffer it went to (a scratch buffer that grew has lost its content)
         {
             constexpr int MAX_LANES = 16;
-            struct Uploaded { uint64_t id = 0; const void *eval = nullptr, *lenIdx = nullptr, *bit = nullptr; };
+            struct Uploaded { uint64_t id = 0; const void *eval = nullptr, *lenIdx = nullptr, *bit = nullptr; uint64_t epoch = 0; };
             static Uploaded uploaded[MAX_LANES];
             static std::mutex upMutex;
             const int lane = scratch_lane();
             std::lock_guard<std::mutex> g(upMutex);
             Uploaded local;
             Uploaded &U = (lane >= 0 && lane < MAX_LANES) ? uploaded[lane] : local;
-            if (U.id != T.id || U.eval != dEval || U.lenIdx != dLenIdx || U.bit != dBit) {
+            if (U.id != T.id || U.eval != dEval || U.lenIdx != dLenIdx || U.bit != dBit || U.epoch != scratch_epoch()) {   // (epoch: mk_shutdown released every buffer)
                 ACHK(hipMemcpyAsync(dEval, T.evalue.data(), T.evalue.size() * sizeof(double), hipMemcpyHostToDevice, stream));
                 ACHK(hipMemcpyAsync(dLenIdx, T.lenIdx.data(), T.lenIdx.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
                 ACHK(hipMemcpyAsync(dBit, T.bitScore.data(), T.bitScore.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
                 // the copies read T's vectors, which the next batch may rebuild: they must have left the host before anybody can do that
                 ACHK(sync_wait(stream, "wait_align"));
-                U.id = T.id; U.eval = dEval; U.lenIdx = dLenIdx; U.bit = dBit;
+                U.id = T.id; U.eval = dEval; U.lenIdx = dLenIdx; U.bit = dBit; U.epoch = scratch_epoch();
             }
         }
         unsigned long long *dWork = (unsigned long long *) dev_scratch("asm_revwork", 2 * SW_NCFG * 8);
@@ -1047,7 +1047,12 @@ void HostBlock::release() {
     p = nullptr; cap = 0;
 }
 
+static std::atomic<uint64_t> g_scratchEpoch{1};
+uint64_t scratch_epoch() { return g_scratchEpoch.load(); }
+
 void scratch_release_all() {
+    std::lock_guard<std::mutex> gs(scratch_mutex());
+    g_scratchEpoch++;
     for (auto &kv : scratch_map()) {
         if (!kv.second.p) continue;
         if (kv.first[0] == 'h') (void) hipHostFree(kv.second.p); else (void) hipFree(kv.second.p);

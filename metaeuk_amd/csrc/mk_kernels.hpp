@@ -159,6 +159,7 @@ void *dev_block_alloc(size_t bytes, size_t *cap);
 void dev_block_free(void *p, size_t cap);
 void *pinned_scratch(const char *name, size_t bytes);
 void scratch_release_all();
+uint64_t scratch_epoch();                                   // changes whenever scratch_release_all has run (whoever remembers what a buffer holds compares it)
 void set_scratch_lane(int lane);                            // of the calling thread: lane > 0 gets buffers of its own under the same names (a second worker of one stage)
 int scratch_lane();
 
