@@ -1033,7 +1033,9 @@ struct WideArgs {
     unsigned long long *totals;                       // as StreamArgs::totals; [10] sub-classes beyond the LDS sort (the host redoes the piece)
                                                       // [11] (a double) MODE 2: sum over the finished queries of similar k-mers / length (run statistics)
     uint32_t *work_counter;
-    uint64_t *pool; uint32_t *pool_ord;               // gridDim.x regions of NCLS * cls_cap records
+    uint32_t *pool;                                   // gridDim.x regions of NCLS * cls_cap records of THREE dwords: target | diagonal | k-mer start (64 bits), the hit's
+                                                      // ordinal within its start -- one 12-byte store per hit (rounds 4-5: an 8-byte and a 4-byte array; the
+                                                      // scattered stores of pass 1 are half of its time at 60 M proteins, profiles/r06_config5.txt)
     uint32_t cls_cap;                                 // records per target class (NCLS * cls_cap <= 2^(48 - t_bits) * NCLS and < 2^31: the arrival rank of a hit
                                                       // shares the sort key with the target bits a class leaves open)
     uint32_t t_bits;                                  // bits of a target id (>= 20)
@@ -1077,8 +1079,8 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
     if (tid == 0) sRedoN = 0;
     const uint32_t T_BITS = A.t_bits, CLS_CAP = A.cls_cap;
     const uint32_t CLS_SHIFT = T_BITS - (uint32_t) LOG_NCLS;          // class of a target = the top bits of its mapped id
-    uint64_t *region = A.pool + (size_t) blockIdx.x * NCLS * A.cls_cap;
-    uint32_t *regionOrd = A.pool_ord + (size_t) blockIdx.x * NCLS * A.cls_cap;
+    struct Rec12 { uint32_t lo, hi, ord; };
+    Rec12 *region = reinterpret_cast<Rec12 *>(A.pool) + (size_t) blockIdx.x * NCLS * A.cls_cap;
     const uint64_t TMASK = (1ull << T_BITS) - 1ull;
     static_assert(LOG_MBITS <= 17, "bucket = the top bits of the mix, subset = its low 15 bits");
     const auto survives = [&](uint64_t rec) -> bool {
@@ -1205,8 +1207,8 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
                         if (slot < CLS_CAP) {
                             const size_t at = (size_t) cls * CLS_CAP + slot;
                             if (!(A.exp & 1u) || tgt == 0xFFFFFFFFu) {
-                            region[at] = (uint64_t) tgt | ((uint64_t) diag << T_BITS) | ((uint64_t) (uint32_t) i << (T_BITS + 16u));
-                            regionOrd[at] = wcount + rel;
+                            const uint64_t rec = (uint64_t) tgt | ((uint64_t) diag << T_BITS) | ((uint64_t) (uint32_t) i << (T_BITS + 16u));
+                            region[at] = Rec12{(uint32_t) rec, (uint32_t) (rec >> 32), wcount + rel};
                             }
                         } else over = true;
                     };
@@ -1298,16 +1300,16 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
                     const uint32_t nC = sClsUsed[c];
                     const size_t base = (size_t) c * CLS_CAP;
                     for (uint32_t s0 = 0; s0 < nC; s0 += 4u * BLOCK) {
-                        uint64_t rec[4];
+                        Rec12 rec[4];
                         bool ok[4];
 #pragma unroll
                         for (uint32_t k = 0; k < 4; k++) {
                             const uint32_t s = s0 + k * BLOCK + (uint32_t) tid;
                             ok[k] = s < nC;
-                            rec[k] = ok[k] ? region[base + s] : 0ull;
+                            rec[k] = ok[k] ? region[base + s] : Rec12{0u, 0u, 0u};
                         }
 #pragma unroll
-                        for (uint32_t k = 0; k < 4; k++) fn(ok[k], base + s0 + k * BLOCK + (uint32_t) tid, rec[k]);
+                        for (uint32_t k = 0; k < 4; k++) fn(ok[k], rec[k].ord, (uint64_t) rec[k].lo | ((uint64_t) rec[k].hi << 32));
                     }
                 }
             };
@@ -1320,7 +1322,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
             for (int k = tid; k < MBITS / 32; k += BLOCK) { sBm1[k] = 0; sBm2[k] = 0; }
             __syncthreads();
             // ---- 2a: target buckets hit once / twice
-            sweep([&](bool valid, size_t, uint64_t rec) {
+            sweep([&](bool valid, uint32_t, uint64_t rec) {
                 if (!valid || !in_set(rec)) return;
                 const uint32_t hb = mix32((uint32_t) (rec & TMASK)) >> (32 - LOG_MBITS);
                 const uint32_t bit = 1u << (hb & 31u);
@@ -1334,7 +1336,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
                 __syncthreads();
                 if (tid == 0) sSurv = 0;
                 __syncthreads();
-                sweep([&](bool valid, size_t at, uint64_t rec) {
+                sweep([&](bool valid, uint32_t ord, uint64_t rec) {
                     const bool surv = valid && in_set(rec) && survives(rec) && (nSub == 1 || sub_of(rec, nSub) == sub);
                     const unsigned long long m = __ballot(surv);
                     if (m == 0) return;
@@ -1345,7 +1347,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
                         const uint32_t slot = wbase + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
                         if (slot < (uint32_t) SURV) {
                             const uint32_t pos = (uint32_t) (rec >> (T_BITS + 16u)) & 0xFFFu;
-                            const uint32_t rank = sPosBase[pos] + regionOrd[at];
+                            const uint32_t rank = sPosBase[pos] + ord;
                             sKey[slot] = ((uint64_t) (wide_fwd((uint32_t) (rec & TMASK), T_BITS) & FIELD_MASK) << TSHIFT) | ((uint64_t) rank << 16) | ((rec >> T_BITS) & 0xFFFFull);
                         }
                     }
@@ -1369,7 +1371,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
                     for (uint32_t k = (uint32_t) tid; k < nSub; k += BLOCK) sSubCnt[k] = 0;
                     if (tid == 0) sSubMax = 0;
                     __syncthreads();
-                    sweep([&](bool valid, size_t, uint64_t rec) {
+                    sweep([&](bool valid, uint32_t, uint64_t rec) {
                         if (valid && in_set(rec) && survives(rec)) atomicAdd(&sSubCnt[sub_of(rec, nSub)], 1u);
                     });
                     __syncthreads();
@@ -2427,13 +2429,12 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
             const unsigned gridMax = (unsigned) cus * perCu;
             for (;;) {                                         // a pool that cannot be had is halved (fuller classes: more parts per query)
                 const size_t regionRecs = (size_t) W.nCls * A.cls_cap;
-                A.pool = (uint64_t *) dev_scratch("pf_wpool", (size_t) gridMax * regionRecs * 8);
-                A.pool_ord = A.pool ? (uint32_t *) dev_scratch("pf_wpoolord", (size_t) gridMax * regionRecs * 4) : nullptr;
-                if ((A.pool && A.pool_ord) || W.clsCap != 0 || A.cls_cap <= 4096) break;
+                A.pool = (uint32_t *) dev_scratch("pf_wpool", (size_t) gridMax * regionRecs * 12);
+                if (A.pool || W.clsCap != 0 || A.cls_cap <= 4096) break;
                 (void) hipGetLastError();
                 A.cls_cap = std::max<uint32_t>(4096, (A.cls_cap / 2) & ~63u);
             }
-            PNULL(A.pool); PNULL(A.pool_ord);
+            PNULL(A.pool);
             int nClsLog = 0; while ((1 << nClsLog) < W.nCls) nClsLog++;
             // (the part number takes bits of the mapped target id below the class: at most 16 parts, and 8 bits stay for the targets of a class and part)
             int maxLogM = std::max(0, std::min(4, (int) A.t_bits - nClsLog - 8));
