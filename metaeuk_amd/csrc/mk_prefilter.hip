@@ -1042,9 +1042,11 @@ struct WideArgs {
     uint32_t max_log_m;                               // a part that fills a class is halved by its workgroup up to M = 2^max_log_m; beyond: overflow_list
     uint32_t one_class_hits;                          // a query with at least this many hits takes its classes one by one (2^(48 - t_bits); the tests force 0)
     const uint16_t *pos_cost; uint64_t pos_begin;     // MODE 0: work estimate of every k-mer start (kmer_count_kernel)
-    uint32_t exp;                                     // EXPERIMENT (MK_PREFILTER_WIDE_EXP, results WRONG): 1 no region stores, 2 no class atomic, 4 no tail entry loads, 8 no pass 2
 };
 
+#ifndef MK_WIDE_SWEEP_ILP
+#define MK_WIDE_SWEEP_ILP 4        // records in flight per thread in the sweeps of pass 2 (they are bound by memory latency)
+#endif
 template <int NCLS, int GROUP_MAX, int SURV, int MBITS, int MAXPOS, int NW, int U, int MODE>
 __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        // (8 waves per SIMD = 64 registers; a 128-register build ran 5 % faster with ONE workgroup
                                                                                 //  per CU and lost to two: profiles/r04_wide_kernel.txt)
@@ -1203,13 +1205,11 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
                         const uint32_t f = wide_fwd(tgt, T_BITS);                          // (a function of its own: the bitmap buckets of pass 2 must not follow the class)
                         if (((f >> RES_BITS) & PART_MASK) != PART_R) return;               // another part's target
                         const uint32_t cls = f >> CLS_SHIFT;
-                        const uint32_t slot = (A.exp & 2u) ? (tgt & 1023u) : atomicAdd(&sClsUsed[cls], 1u);
+                        const uint32_t slot = atomicAdd(&sClsUsed[cls], 1u);
                         if (slot < CLS_CAP) {
                             const size_t at = (size_t) cls * CLS_CAP + slot;
-                            if (!(A.exp & 1u) || tgt == 0xFFFFFFFFu) {
                             const uint64_t rec = (uint64_t) tgt | ((uint64_t) diag << T_BITS) | ((uint64_t) (uint32_t) i << (T_BITS + 16u));
                             region[at] = Rec12{(uint32_t) rec, (uint32_t) (rec >> 32), wcount + rel};
-                            }
                         } else over = true;
                     };
 #pragma unroll
@@ -1219,7 +1219,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
                         enumk::wave_deal_tail(size[u] > 1 ? size[u] - 1 : 0u, lane, P1.mark[w], [&](uint32_t owner, uint32_t e, bool valid) {
                             const uint64_t oFirst = wave_read_lane64(o0[u], owner);
                             const uint32_t oR0 = enumk::wave_read_lane(r0, owner);
-                            if (valid) put((A.exp & 4u) ? (oFirst + e) * 0x9E3779B97F4A7C15ull : ld_probe(A.V.entries + oFirst + e), oR0 + e);
+                            if (valid) put(ld_probe(A.V.entries + oFirst + e), oR0 + e);
                         });
                     }
                     wcount += totAll;
@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
             atomicAdd(&A.totals[2], (unsigned long long) np);
             if (MODE == W_MODE_ENUM7 && km != 0 && L > 0) atomicAdd(reinterpret_cast<double *>(&A.totals[11]), (double) km / (double) L);
         }
-        if (hitsAll == 0 || (A.exp & 8u)) continue;
+        if (hitsAll == 0) continue;
         // arrival rank of a hit = hits of the earlier k-mer starts + its ordinal
         if (w == 0) {
             const uint32_t perLane = ((uint32_t) nStart + WAVE - 1) / WAVE;
@@ -1299,17 +1299,17 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
                 for (uint32_t c = g0; c < g1; c++) {
                     const uint32_t nC = sClsUsed[c];
                     const size_t base = (size_t) c * CLS_CAP;
-                    for (uint32_t s0 = 0; s0 < nC; s0 += 4u * BLOCK) {
-                        Rec12 rec[4];
-                        bool ok[4];
+                    for (uint32_t s0 = 0; s0 < nC; s0 += (uint32_t) MK_WIDE_SWEEP_ILP * BLOCK) {
+                        Rec12 rec[MK_WIDE_SWEEP_ILP];
+                        bool ok[MK_WIDE_SWEEP_ILP];
 #pragma unroll
-                        for (uint32_t k = 0; k < 4; k++) {
+                        for (uint32_t k = 0; k < (uint32_t) MK_WIDE_SWEEP_ILP; k++) {
                             const uint32_t s = s0 + k * BLOCK + (uint32_t) tid;
                             ok[k] = s < nC;
                             rec[k] = ok[k] ? region[base + s] : Rec12{0u, 0u, 0u};
                         }
 #pragma unroll
-                        for (uint32_t k = 0; k < 4; k++) fn(ok[k], rec[k].ord, (uint64_t) rec[k].lo | ((uint64_t) rec[k].hi << 32));
+                        for (uint32_t k = 0; k < (uint32_t) MK_WIDE_SWEEP_ILP; k++) fn(ok[k], rec[k].ord, (uint64_t) rec[k].lo | ((uint64_t) rec[k].hi << 32));
                     }
                 }
             };
@@ -2472,7 +2472,6 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
                 A.C = X.C; A.cand_cap = X.candCap; A.counters = dCtr;
                 A.overflow_list = dOvfItems; A.overflow_parts = dOvfItems + nItems; A.overflow_count = dCtr + 4; A.totals = dTot; A.work_counter = dCtr + 8;
                 A.pos_cost = dPosCost; A.pos_begin = hOff[p0];
-                A.exp = (uint32_t) knob_long("MK_PREFILTER_WIDE_EXP", 0);
                 A.max_log_m = knob_long("MK_PREFILTER_WIDE_KERNEL_HALVES", 1) ? (uint32_t) maxLogM : 0u;
                 const int th = X.tb(round == 0 ? "prefilter_query_wide" : "prefilter_query_wide_retry", 0, 0);
                 if (k7enum) launch_wide<W_MODE_ENUM7>(shape, A, launch, stream);

@@ -1,5 +1,7 @@
-"""What bounds pass 1 of the wide per-query kernel at config-5 scale: the kernel with parts of its work switched off (MK_PREFILTER_WIDE_EXP; the results are
-wrong, only the times count).  gpurun -- 'python tools/wide_exp.py 60000000 4000 > gpurun_out/wide_exp.txt 2>&1'"""
+"""The prefilter at config-5 scale with the library's debug lines (MK_PREFILTER_DEBUG: work items, halved parts, workgroup ticks per phase of the wide
+per-query kernel).  Early in round 6 the kernel had a switch that left parts of its work out (MK_PREFILTER_WIDE_EXP: no region stores / no class
+atomic / no pass 2; profiles/r06_config5.txt item 2); the switch is gone, the third argument is kept as a repetition count.
+   gpurun -- 'timeout 500 python tools/wide_exp.py 60000000 4000 > gpurun_out/wide_exp.txt 2>&1'"""
 import os
 import sys
 import time
@@ -13,7 +15,7 @@ from metaeuk_amd import api  # noqa: E402
 
 n_targets = int(sys.argv[1]) if len(sys.argv) > 1 else 60000000
 n_frag = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
-exps = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 1, 3, 4, 5, 7, 8, 15, 0]
+exps = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
 api.init(0)
 res, off = api.synth_targets(n_targets, seed=c5.TARGET_SEED)
 p = api.default_params()
@@ -22,7 +24,6 @@ fr, foff, src = api.synth_fragments(n_frag, res, off, **c5.FRAGMENTS)
 del res
 q = api.Queries.from_codes(fr, foff, p)
 for e in exps:
-    os.environ["MK_PREFILTER_WIDE_EXP"] = str(e)
     for rep in range(2):
         api.kernel_stats(reset=True)
         t0 = time.time()
