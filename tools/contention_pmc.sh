@@ -5,26 +5,26 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/contention
-mkdir -p $OUT
+RAW=/tmp/mk_contention_raw          # the counter CSVs are hundreds of MB: only the summary goes to gpurun_out/
+mkdir -p $OUT $RAW
 cd /tmp && export TMPDIR=/tmp
-COMMON="--steps 1 --warmup 1 --cpu-sample 0 --config4-profiles 0 --e2e-sample -1 --blocking-steps 0 --alone-steps 0"
+COMMON="--steps 1 --warmup 0 --config5-targets 0 --cpu-sample 0 --config4-profiles 0 --e2e-sample -1 --blocking-steps 0 --alone-steps 0"
 G1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY"
 G2="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_ANY"
 G3="TCP_PENDING_STALL_CYCLES_sum TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TA_FLAT_READ_WAVEFRONTS_sum"
 G4="TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"
-G5="SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_IFETCH SQ_INSTS_SMEM SQ_WAIT_INST_ANY"
 for mode in alone coresident; do
     EXTRA=""; [ $mode = alone ] && EXTRA="--two-calls"
     k=0
-    for G in "$G1" "$G2" "$G3" "$G4" "$G5"; do
+    for G in "$G1" "$G2" "$G3" "$G4"; do
         k=$((k + 1))
-        rm -rf $OUT/${mode}_g$k
-        timeout 600 rocprofv3 --pmc $G --kernel-trace --output-format csv -d $OUT/${mode}_g$k -- python $R/bench.py $COMMON $EXTRA > $OUT/${mode}_g$k.log 2>&1 || echo "pass $mode g$k failed (see $OUT/${mode}_g$k.log)"
+        rm -rf $RAW/${mode}_g$k
+        timeout 400 rocprofv3 --pmc $G --kernel-trace --output-format csv -d $RAW/${mode}_g$k -- python $R/bench.py $COMMON $EXTRA > $OUT/${mode}_g$k.log 2>&1 || echo "pass $mode g$k failed (see $OUT/${mode}_g$k.log)"
     done
 done
 python - <<PY
 import csv, glob, collections, re
-out = "$OUT"
+out, raw = "$OUT", "$RAW"
 want = [("stream_kernel<32768", "prefilter third tier  stream_kernel<32768,2048,65536,1024,8,2>"), ("stream_kernel<131072", "prefilter largest tier stream_kernel<131072,...,16,2>"),
         ("stream_kernel<2048", "prefilter first tier  stream_kernel<2048,...,1,2>"), ("swp_kernel<2, 2, 16>", "score pass rows32  swp_kernel<2,2,16>"),
         ("swp_kernel<3, 4, 16>", "score pass rows48  swp_kernel<3,4,16>"), ("swp_kernel<4, 4, 16>", "score pass rows64  swp_kernel<4,4,16>"), ("swp_kernel<6, 6, 16>", "score pass rows96  swp_kernel<6,6,16>")]
@@ -33,8 +33,8 @@ for mode in ("alone", "coresident"):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     disp = collections.Counter()
     dur = collections.defaultdict(float)
-    for g in range(1, 6):
-        fs = sorted(glob.glob("%s/%s_g%d/**/*counter_collection.csv" % (out, mode, g), recursive=True))
+    for g in range(1, 5):
+        fs = sorted(glob.glob("%s/%s_g%d/**/*counter_collection.csv" % (raw, mode, g), recursive=True))
         if not fs:
             continue
         for r in csv.DictReader(open(fs[-1])):
@@ -43,7 +43,7 @@ for mode in ("alone", "coresident"):
                     agg[key][r["Counter_Name"]] += float(r["Counter_Value"])
                     if r["Counter_Name"] in ("SQ_WAVES",):
                         disp[key] += 1
-        ks = sorted(glob.glob("%s/%s_g%d/**/*kernel_trace.csv" % (out, mode, g), recursive=True))
+        ks = sorted(glob.glob("%s/%s_g%d/**/*kernel_trace.csv" % (raw, mode, g), recursive=True))
         if ks and g == 1:
             for r in csv.DictReader(open(ks[-1])):
                 for key, _ in want:
@@ -57,7 +57,7 @@ for mode in data:
             if c not in names:
                 names.append(c)
 with open(out + "/r06_contention.txt", "w") as w:
-    w.write("# rocprofv3 --pmc (five passes per mode, --kernel-trace only) -- python bench.py --steps 1 --warmup 1 [--two-calls]; sums over all dispatches of both passes of the workload\\n")
+    w.write("# rocprofv3 --pmc (four passes per mode, --kernel-trace only) -- python bench.py --steps 1 --warmup 0 [--two-calls]; sums over all dispatches of the one pass of the workload\\n")
     w.write("# alone = mk_prefilter then mk_align (a kernel's counters are its own); coresident = the queued mk_search (the counters of a dispatch include what shares its CUs)\\n")
     for key, label in want:
         w.write("\\n== %s\\n" % label)
@@ -78,4 +78,5 @@ with open(out + "/r06_contention.txt", "w") as w:
                 v.get("TCC_HIT_sum", 0) / max(v.get("TCC_REQ_sum", 0), 1), v.get("SQ_LDS_BANK_CONFLICT", 0) / max(v.get("SQ_ACTIVE_INST_LDS", 0), 1),
                 v.get("TCP_PENDING_STALL_CYCLES_sum", 0) / max(v.get("TA_BUSY_sum", 0), 1)))
 PY
+rm -rf $RAW
 cat $OUT/r06_contention.txt | head -150

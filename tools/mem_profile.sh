@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/mem
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 1 --warmup 1 --cpu-sample 0 --config4-profiles 0 --e2e-sample -1 --two-calls ${BENCH_EXTRA:-}"
+BENCH="python $R/bench.py --steps 1 --warmup 1 --cpu-sample 0 --config5-targets 0 --config4-profiles 0 --e2e-sample -1 --two-calls ${BENCH_EXTRA:-}"
 rm -rf $OUT/p1 $OUT/p2 $OUT/p3
 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/p1 -- $BENCH > $OUT/p1.log 2>&1
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum TCC_READ_SECTORS_sum --kernel-trace --output-format csv -d $OUT/p2 -- $BENCH > $OUT/p2.log 2>&1

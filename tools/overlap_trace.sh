@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/trace
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/kt
-rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -- python $R/bench.py --steps 1 --warmup 1 --cpu-sample 0 --config4-profiles 0 --e2e-sample -1 --blocking-steps 0 ${BENCH_EXTRA:-} > $OUT/kt.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -- python $R/bench.py --steps 1 --warmup 1 --cpu-sample 0 --config4-profiles 0 --config5-targets 0 --alone-steps 0 --e2e-sample -1 --blocking-steps 0 ${BENCH_EXTRA:-} > $OUT/kt.log 2>&1
 python - <<PY
 import csv, glob, collections
 f = sorted(glob.glob("$OUT/kt/**/*kernel_trace.csv", recursive=True))[-1]

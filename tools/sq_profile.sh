@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/sq
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 1 --warmup 1 --cpu-sample 0 --config4-profiles 0 --e2e-sample -1 --blocking-steps 0 ${BENCH_MODE---two-calls} ${BENCH_EXTRA:-}"
+BENCH="python $R/bench.py --steps 1 --warmup 1 --cpu-sample 0 --config5-targets 0 --config4-profiles 0 --e2e-sample -1 --blocking-steps 0 ${BENCH_MODE---two-calls} ${BENCH_EXTRA:-}"
 rm -rf $OUT/pmc
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc -- $BENCH > $OUT/pmc.log 2>&1
 python - <<PY
