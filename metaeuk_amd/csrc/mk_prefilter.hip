@@ -2558,7 +2558,10 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
     const int maxHits = std::min<int>(P.max_seqs, (int) V.n_targets);
     const uint64_t dbSize = V.n_targets;
     const uint32_t QCAP = 1u << 20;                   // queries per chunk (20-bit field of the output sort key)
-    const uint32_t CAND_CAP = 96u << 20;              // candidates per chunk held in HBM (~44 B each)
+    // candidates per chunk held in HBM (~44 B each).  Against a database of more than 2^24 targets a fragment leaves 4e4 candidates (60 M proteins): twice
+    // the room there -- a piece of the wide kernel's work then has twice the items per workgroup and half as many launch tails (a quarter of a
+    // piece's time with 4.5 items per workgroup, profiles/r06_config5.txt)
+    const uint32_t CAND_CAP = (V.n_targets > (1u << 24) ? 192u : 96u) << 20;
     if (dbSize >= (1ull << 27)) { err = "more than 2^27 targets"; return MK_ERR_UNSUPPORTED; }
     uint32_t seqBits = 1; while ((1ull << seqBits) < dbSize) seqBits++;
     // front end: the per-query kernels keep the target id in a 22-bit field of their hit records

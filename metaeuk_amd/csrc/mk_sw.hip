@@ -456,8 +456,20 @@ __global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
                 const uint32_t tres = shift_up<G>(top, outRes, lane);
                 const int16_t *pa = reinterpret_cast<const int16_t *>(profLane + (tres & 0xFFFFu)), *pb = reinterpret_cast<const int16_t *>(profLane + (tres >> 16));
                 uint32_t wa[RP / 2], wb[RP / 2];                   // R int16 scores per target, two per dword
+                if constexpr (RP % 4 == 0) {
+                    // a lane's RP scores are RP * 2 bytes at a multiple of 8: read as 64-bit words.  As dwords (ds_read2_b32) the lanes of a group sit on
+                    // every second bank and two groups share a cycle: 3.0 conflict cycles per active LDS cycle in the 48- / 64-row tiles
+                    // (profiles/r06_contention.txt)
+                    const uint64_t *qa = reinterpret_cast<const uint64_t *>(__builtin_assume_aligned(pa, 8)), *qb = reinterpret_cast<const uint64_t *>(__builtin_assume_aligned(pb, 8));
+#pragma unroll
+                    for (int k = 0; k < RP / 4; k++) {
+                        const uint64_t xa = qa[k], xb = qb[k];
+                        wa[2 * k] = (uint32_t) xa; wa[2 * k + 1] = (uint32_t) (xa >> 32); wb[2 * k] = (uint32_t) xb; wb[2 * k + 1] = (uint32_t) (xb >> 32);
+                    }
+                } else {
 #pragma unroll
                 for (int k = 0; k < RP / 2; k++) { wa[k] = reinterpret_cast<const uint32_t *>(pa)[k]; wb[k] = reinterpret_cast<const uint32_t *>(pb)[k]; }
+                }
                 pk16 dsave = hupPrev;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
