@@ -979,6 +979,7 @@ void *dev_scratch(const char *name, size_t bytes) {
     if (s.p) (void) hipFree(s.p);
     s.p = nullptr; s.cap = 0;
     const size_t want = std::max<size_t>(bytes + bytes / 8, 256);
+    ScopedHost sh("host_alloc_device");                       // (what a first call pays for its buffers shows in the statistics)
     if (hipMalloc(&s.p, want) != hipSuccess) {                // the pool of the query batches may sit on what is missing
         (void) hipGetLastError();
         dev_pool_release();
@@ -996,6 +997,7 @@ void *pinned_scratch(const char *name, size_t bytes) {
     if (s.p) (void) hipHostFree(s.p);
     s.p = nullptr; s.cap = 0;
     const size_t want = std::max<size_t>(bytes + bytes / 8, 256);
+    ScopedHost sh("host_alloc_pinned");
     if (hipHostMalloc(&s.p, want, hipHostMallocDefault) != hipSuccess) { s.p = nullptr; return nullptr; }
     s.cap = want; s.pinned = true;
     return s.p;
@@ -1021,6 +1023,7 @@ bool HostBlock::reserve(size_t bytes, size_t keepBytes) {
     }
     if (!np) {
         ncap = std::max<size_t>(bytes + bytes / 8, 4096);
+        ScopedHost sh("host_alloc_pinned");
         if (hipHostMalloc(&np, ncap, hipHostMallocDefault) != hipSuccess) return false;
     }
     if (p && keepBytes) std::memcpy(np, p, std::min(keepBytes, cap));

@@ -1039,6 +1039,7 @@ struct WideArgs {
     uint32_t cls_cap;                                 // records per target class (NCLS * cls_cap <= 2^(48 - t_bits) * NCLS and < 2^31: the arrival rank of a hit
                                                       // shares the sort key with the target bits a class leaves open)
     uint32_t t_bits;                                  // bits of a target id (>= 20)
+    uint32_t max_db_matches;                          // QueryMatcher's maxDbMatches (clamped to 2^32 - 1): from here on the reference's overflow path decides
     uint32_t max_log_m;                               // a part that fills a class is halved by its workgroup up to M = 2^max_log_m; beyond: overflow_list
     uint32_t one_class_hits;                          // a query with at least this many hits takes its classes one by one (2^(48 - t_bits); the tests force 0)
     const uint16_t *pos_cost; uint64_t pos_begin;     // MODE 0: work estimate of every k-mer start (kmer_count_kernel)
@@ -1259,6 +1260,16 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
         }
         uint32_t hitsAll = 0;
         for (int k = 0; k < NW; k++) hitsAll += sWaveHits[k];
+        // A query with at least 2 max(10^6, #targets) index hits does not fit the REFERENCE's per-thread buffer: QueryMatcher::match then works in segments
+        // with a double-diagonal rule each (QueryMatcher.cpp:281-334), which only the global path restates (replay_overflow).  Since round 6 a query of that
+        // size would fit here (2^28 hits), so it is handed over explicitly: every part sees the same total and emits nothing, the first one reports it.
+        if (hitsAll >= A.max_db_matches) {
+            if (tid == 0 && PART_R == 0u) {
+                const uint32_t at = atomicAdd(A.overflow_count, 1u);
+                A.overflow_list[at] = q - A.q_first; A.overflow_parts[at] = 0x80000000u;
+            }
+            continue;
+        }
         if (tid == 0 && PART_R == 0u) {                    // (the statistics of a query are its first part's: every part enumerates everything)
             uint32_t km = 0, np = 0;
             for (int k = 0; k < NW; k++) { km += sWaveKmers[k]; np += sWavePos[k]; }
@@ -2449,6 +2460,8 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
                 int lm = 0;
                 while (lm < maxLogM && est > regionHits * (double) (1u << lm)) lm++;
                 if (est > 4.0 * regionHits * (double) (1u << lm)) { fallback.push_back(order[k] - a); continue; }   // (far beyond every region: the global path)
+                // (clearly beyond the reference's maxDbMatches: its overflow path decides, which the global path restates -- no pass 1 to find that out)
+                if (perUnit * (double) orderUnits[k] > 1.5 * (double) X.maxDbMatches) { fallback.push_back(order[k] - a); continue; }
                 for (uint32_t r = 0; r < (1u << lm); r++) { itemQ.push_back(order[k]); itemPart.push_back(r | ((uint32_t) lm << 8)); }
             }
             bool redoGlobal = false;
@@ -2473,6 +2486,7 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
                 A.overflow_list = dOvfItems; A.overflow_parts = dOvfItems + nItems; A.overflow_count = dCtr + 4; A.totals = dTot; A.work_counter = dCtr + 8;
                 A.pos_cost = dPosCost; A.pos_begin = hOff[p0];
                 A.max_log_m = knob_long("MK_PREFILTER_WIDE_KERNEL_HALVES", 1) ? (uint32_t) maxLogM : 0u;
+                A.max_db_matches = (uint32_t) std::min<uint64_t>(X.maxDbMatches, 0xFFFFFFFFull);
                 const int th = X.tb(round == 0 ? "prefilter_query_wide" : "prefilter_query_wide_retry", 0, 0);
                 if (k7enum) launch_wide<W_MODE_ENUM7>(shape, A, launch, stream);
                 else if (listed) launch_wide<W_MODE_LIST>(shape, A, launch, stream);
@@ -2502,6 +2516,7 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
                     PCHK(hipMemcpyAsync(hOvf + nOvf, dOvfItems + nItems, (size_t) nOvf * 4, hipMemcpyDeviceToHost, stream));
                     PCHK(sync_wait(stream, "wait_prefilter"));
                     for (uint32_t k = 0; k < nOvf && !redoGlobal; k++) {
+                        if (hOvf[nOvf + k] == 0x80000000u) { fallback.push_back(hOvf[k]); continue; }      // the reference's databaseHits overflow: the global path
                         const uint32_t r = hOvf[nOvf + k] & 0xFFu, lm = hOvf[nOvf + k] >> 8;
                         // the part's two halves; a part that cannot be halved any more has emitted nothing, but the other parts of its query have:
                         // the piece is done again by the global path (never seen: the estimate would have to be off by the factor of 4 above)

@@ -265,7 +265,7 @@ def test_index_list_starts_beyond_32_bits(gpu_api, pf_path, monkeypatch):
         assert api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1])) == galn[i], ("aln", i)
 
 
-def test_database_hits_overflow_path(gpu_api, tmp_path):
+def test_database_hits_overflow_path(gpu_api, tmp_path, monkeypatch):
     """QueryMatcher::match's overflow path (QueryMatcher.cpp:281-334): 70 000 near-copies of one protein make three of four queries gather
     10 ... 27 million index entries where the reference's buffer holds 2 million -- segments with a double-diagonal rule each, merged as
     the overflow events merge them, ties at the --max-seqs cut in the reference's array order.  Against the oracle's literal restatement
@@ -279,15 +279,20 @@ def test_database_hits_overflow_path(gpu_api, tmp_path):
     params = api.default_params()
     params.host_l2_bytes = 2097152
     db = api.TargetDB(targets, params)
-    # (the overflowing queries between ordinary ones: they are isolated piece by piece)
-    batch = queries + [mut(base, 0.4), queries[0]]
-    q = api.Queries(batch, params)
-    (hits, hoff), (alns, aoff) = api.search(db, q)
+    # (the overflowing queries between ordinary ones: they are isolated piece by piece; base[:40] / base[:52] gather 2-4 million entries -- just beyond the
+    #  buffer, and since round 6 well within what the wide per-query kernel holds: it must hand them to the overflow path, not apply the plain rule)
+    batch = queries + [mut(base, 0.4), queries[0], base[:40], base[:52], base[:30]]
     opref, oaln = oracle.run_pipeline(targets, batch, str(tmp_path), extra=["--l2", "2097152"])
-    for i in range(len(batch)):
-        assert api.format_hits(hits, int(hoff[i]), int(hoff[i + 1])) == opref[i], ("pref", i)
-        assert api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1])) == oaln[i], ("aln", i)
-    assert "host_prefilter_overflow" in api.kernel_stats()
+    for path in ("auto", "wide"):
+        monkeypatch.setenv("MK_PREFILTER_PATH", path)
+        api.kernel_stats(reset=True)
+        q = api.Queries(batch, params)
+        (hits, hoff), (alns, aoff) = api.search(db, q)
+        for i in range(len(batch)):
+            assert api.format_hits(hits, int(hoff[i]), int(hoff[i + 1])) == opref[i], ("pref", path, i)
+            assert api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1])) == oaln[i], ("aln", path, i)
+        assert "host_prefilter_overflow" in api.kernel_stats(), path
+        q.close()
 
 
 def test_wide_kernel_query_parts_and_one_class_groups(gpu_api, tmp_path, monkeypatch, capfd):
