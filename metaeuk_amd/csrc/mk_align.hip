@@ -529,7 +529,7 @@ struct AlignShapes {
     int cus = 256;
     uint32_t persistentBlocks[SW_NCFG];      // persistent score pass: one-wave workgroups per tile configuration
     uint32_t unitsPerBlock = 0;              // MK_SW_UNITS_PER_BLOCK: short-lived workgroups instead of the persistent launch
-    int knownForce = -1, knownWaves = 12, narrowForce = -1;
+    int knownForce = -1, knownWaves = 12;
     bool fwdLargeFirst = false;              // MK_SW_FWD_LARGE_FIRST=1
     bool multiLargeFirst = true;             // MK_SW_MULTI_LARGE_FIRST=0: the register classes of the position / reverse passes small tiles first
     bool multiPrio = true;                   // MK_SW_MULTI_PRIO=0: the persistent position / reverse workgroups do not ask for issue priority
@@ -563,7 +563,6 @@ static const AlignShapes &align_shapes() {
         S.unitsPerBlock = (uint32_t) std::max(0L, knob_long("MK_SW_UNITS_PER_BLOCK", 0));
         S.knownForce = (int) knob_long("MK_SW_KNOWN", -1);
         S.knownWaves = (int) std::max(1L, knob_long("MK_SW_KNOWN_WAVES", 12));
-        S.narrowForce = (int) knob_long("MK_SW_NARROW", -1);
         S.multiPrio = knob_long("MK_SW_MULTI_PRIO", 1) != 0;
         S.fwdLargeFirst = knob_long("MK_SW_FWD_LARGE_FIRST", 0) != 0;
         S.multiLargeFirst = knob_long("MK_SW_MULTI_LARGE_FIRST", 1) != 0;
@@ -685,10 +684,13 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const uint64_t
     uint32_t *dPlan = (uint32_t *) dev_scratch("align_plan", ((size_t) nq * 2 + (size_t) maxRuns * 2 + (size_t) nb * (PLAN_NV + 1)) * 4);
     uint32_t *dBounds = (uint32_t *) dev_scratch("align_bounds", 64 * sizeof(uint32_t));
     uint32_t *hb = (uint32_t *) pinned_scratch("align_bounds_h", 64 * sizeof(uint32_t));
-    uint32_t *dWork = (uint32_t *) dev_scratch("align_workcounters", 64);
+    uint32_t *dWork = (uint32_t *) dev_scratch("align_workcounters", 256);        // [cfg]: the score kernels' wave counters, [16 (1 + class) + cfg]: the transposed kernels'
     ANULL(dOrder); ANULL(dWave); ANULL(dPlan); ANULL(dBounds); ANULL(hb); ANULL(dWork);
-    ACHK(hipMemsetAsync(dWork, 0, 64, stream));
-    const bool narrow = S.narrowForce >= 0 ? S.narrowForce != 0 : V.q_prof != nullptr;      // profile queries meet short targets (ORF fragments)
+    ACHK(hipMemsetAsync(dWork, 0, 256, stream));
+    // profile queries meet short targets (ORF fragments): waves of 8 jobs on every packed tile, the transposed score kernel (mk_sw.hip: swt_kernel) for the
+    // waves whose fragments fit 256 rows.  MK_SW_NARROW=0 / 1 forces (read per call: a test compares both forms in one process)
+    const long narrowForce = knob_long("MK_SW_NARROW", -1);
+    const bool narrow = narrowForce >= 0 ? narrowForce != 0 : V.q_prof != nullptr;
     PlanArgs A;
     A.hitOff = dHitOff; A.q_off = V.q_off; A.nq = nq; A.nPairs = n; A.narrow = narrow;
     A.jobOff = dPlan; A.waveOff = dPlan + nq; A.runQuery = dPlan + 2 * (size_t) nq; A.runIndex = A.runQuery + maxRuns; A.blockSums = A.runIndex + maxRuns;
@@ -722,7 +724,7 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const uint64_t
         L.jobs = jobs; L.out = out; L.n_jobs = hi - lo; L.order = dOrder;         // wave_start holds absolute ordered positions
         L.boundary = nullptr; L.boundary_stride = 0; L.boundary_job0 = lo;
         L.wave_start = dWave + wlo; L.n_waves = whi - wlo;
-        L.work_counter = dWork + c; L.persistent_blocks = S.persistentBlocks[c]; L.units_per_block = S.unitsPerBlock;
+        L.work_counter = dWork + c; L.work_counter_t = dWork + 16 + c; L.persistent_blocks = S.persistentBlocks[c]; L.units_per_block = S.unitsPerBlock;
         L.gap_open = P.gap_open; L.gap_extend = P.gap_extend;
         L.narrow = narrow;
         L.known_score = nullptr;

@@ -36,6 +36,7 @@ struct SwLaunch {
     // null: every job builds its own profile (test path, reverse pass).
     const uint32_t *wave_start; uint64_t n_waves;
     uint32_t *work_counter;     // shared-query mode: zeroed device counter the persistent workgroups pull wave numbers from
+    uint32_t *work_counter_t = nullptr;   // ... and the transposed score kernel's (profile queries: launch_sw_score runs it over the same waves)
     uint32_t persistent_blocks; // ... and how many workgroups to launch (0: one per wave)
     uint32_t units_per_block;   // a workgroup retires after this many waves of jobs (0: runs until the counter is exhausted)
     uint64_t boundary_job0;     // job index that owns the first boundary_stride entries of `boundary`
@@ -59,7 +60,9 @@ __host__ __device__ inline bool sw_cfg_packed(int c) { return sw_cfg_rows(c) <= 
 // 512-row tile, 32 rows per lane and 133 VGPRs, was slower: 166 -> 225 ms)
 __host__ __device__ inline uint32_t sw_cfg_jobs_per_wave(int c, bool narrow = false) {
     const int rows = sw_cfg_rows(c);
-    return rows <= 256 ? 8u : (rows <= 768 ? ((narrow && rows == 384) ? 8u : 4u) : 1u);
+    return rows <= 256 ? 8u : (rows <= 768 ? (narrow ? 8u : 4u) : 1u);     // (round 6: every packed tile of a profile query cuts its waves at 8 jobs --
+                                                                            //  the transposed unit of mk_sw.hip runs 8 on 16-lane groups, the 32-lane classic
+                                                                            //  path takes such a wave in two rounds)
 }
 __host__ __device__ inline int sw_cfg_of(uint32_t qLen) {
     int c = 0;

@@ -356,6 +356,164 @@ __device__ __forceinline__ pk16 pk_subs0(pk16 a, pk16 b) {
     return __builtin_bit_cast(pk16, __builtin_elementwise_sub_sat(__builtin_bit_cast(pku16, a), __builtin_bit_cast(pku16, b)));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 6: the score pass of PROFILE queries, transposed.  A profile of 300-700 columns meets ORF fragments of 40-100 residues
+// (searchslicedtargetprofile.sh: the fragments are the targets): with the profile in the lanes' rows a 512-row tile on 32 lanes spends 31 ramp steps per
+// ~ 90 useful ones and a fifth of its rows on padding -- 45-58 % of the lane-steps carry a cell (DESIGN.md 8.3 of round 5).  Here the FRAGMENT lies in the
+// rows (16 lanes x R rows, R chosen per wave from its longest fragment: 32 ... 256 rows) and the profile's columns are the steps: qLen + 15 of them, the
+// rows filled to ~ 90 %.  Two fragments per lane group in the packed halves, eight per wave, all against one profile -- the jobs of a wave as before.
+// The scores of a step come from an LDS image of the profile LETTER-major, prof[t][16 + c] (int8, 16 zero entries in front of column 0 and 32 behind the
+// last: the ramps read zeros without a test): a row's address is (its residue's row + the lane's column at the head of the block) + the step within the
+// unrolled block as the instruction's immediate offset -- no address arithmetic per cell.  H, E, F and the lane hand-over are swp_kernel's; what
+// crosses the lanes is H of a lane's last row and F (two DPP moves), no residues.  The maximum is kept per ROW, so the bound handed to the position pass
+// is exact: the first fragment position that reaches the maximum.  Fragments of at most 256 rows: 256 x 127 < 32 767, no saturation.
+constexpr int SWT_MARGIN = 16, SWT_TAIL = 32, SWT_COL = 36;       // zero columns in front of / behind the profile; bytes per column of the LDS image
+__host__ __device__ inline size_t swt_image_bytes(int qLen) { return (size_t) (SWT_MARGIN + qLen + SWT_TAIL) * SWT_COL; }
+
+template <int R>
+__device__ __forceinline__ void swt_unit(const SwLaunch &L, const uint32_t w0, const uint32_t count, const int qLen) {
+    constexpr int G = 16;
+    // steps per trip of the column loop: what it reads ahead (2 R scores per step, a register each) stays within ~ 64 registers
+    constexpr int UNR = R <= 2 ? 16 : (R <= 4 ? 8 : (R <= 8 ? 4 : 2));
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];      // the image (the kernel's dynamic LDS): addressed by 32-bit offsets, read with ds_read_i8
+    const int lane = threadIdx.x % G, grp = threadIdx.x / G;
+    const pk16 go2 = pk_splat(L.gap_open), ge2 = pk_splat(L.gap_extend), zero2 = pk_splat(0);
+    const bool haveA = (uint32_t) (2 * grp) < count, haveB = (uint32_t) (2 * grp + 1) < count;
+    const SwJob jobA = L.jobs[L.order[(uint64_t) w0 + (haveA ? 2 * grp : 0)]];
+    const SwJob jobB = L.jobs[L.order[(uint64_t) w0 + (haveB ? 2 * grp + 1 : 0)]];
+    const int tLenA = haveA ? (int) jobA.t_len : 0, tLenB = haveB ? (int) jobB.t_len : 0;
+    // this lane's rows: the residue of the fragment position (21 = the zero entry of every column: no fragment position here), as the LDS offset of that
+    // entry in this lane's column at the head of the current trip -- column s0 - lane, >= -15 (the front margin)
+    uint32_t offA[R], offB[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = lane * R + r;
+        const uint32_t a = i < tLenA ? (uint32_t) L.t_res[(int64_t) jobA.t_start + (int64_t) i * jobA.t_step] : 21u;
+        const uint32_t b = i < tLenB ? (uint32_t) L.t_res[(int64_t) jobB.t_start + (int64_t) i * jobB.t_step] : 21u;
+        offA[r] = min(a, 21u) + (uint32_t) ((SWT_MARGIN - lane) * SWT_COL); offB[r] = min(b, 21u) + (uint32_t) ((SWT_MARGIN - lane) * SWT_COL);
+    }
+    pk16 H[R], E[R], best[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) { H[r] = zero2; E[r] = zero2; best[r] = zero2; }
+    pk16 hupPrev = zero2;
+    uint32_t outH = 0, outF = 0;
+    const int steps = (qLen + G - 1 + 15) & ~15;                       // (<= qLen + 30: inside the tail margin)
+#pragma unroll 1
+    for (int s0 = 0; s0 < steps; s0 += UNR) {
+#pragma unroll
+        for (int k = 0; k < UNR; k++) {
+            const pk16 hup = pk_from(shift_up_zero<G>(outH, lane));
+            pk16 F = pk_from(shift_up_zero<G>(outF, lane));
+            pk16 dsave = hupPrev;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                // ds_read_i8, the step as the immediate offset (k columns on)
+                const int sa = (int) smem[offA[r] + (uint32_t) (k * SWT_COL)], sb = (int) smem[offB[r] + (uint32_t) (k * SWT_COL)];
+                const pk16 sc = pk_from(__builtin_amdgcn_perm((uint32_t) sb, (uint32_t) sa, 0x05040100u));
+                const pk16 d = dsave + sc;
+                dsave = H[r];
+                const pk16 h = pk_max(pk_max(d, E[r]), F);
+                best[r] = pk_max(best[r], h);
+                const pk16 ho = pk_subs0(h, go2);
+                E[r] = pk_max(pk_subs0(E[r], ge2), ho);
+                F = pk_max(pk_subs0(F, ge2), ho);
+                H[r] = h;
+            }
+            hupPrev = hup;
+            outH = pk_bits(H[R - 1]);
+            outF = pk_bits(F);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) { offA[r] += (uint32_t) (UNR * SWT_COL); offB[r] += (uint32_t) (UNR * SWT_COL); }
+    }
+    // the two maxima of the group, and the first ROW (fragment position) that reaches each
+    pk16 bAll = zero2;
+#pragma unroll
+    for (int r = 0; r < R; r++) bAll = pk_max(bAll, best[r]);
+    uint32_t b = pk_bits(bAll);
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) b = pk_bits(pk_max(pk_from(b), pk_from((uint32_t) __shfl_xor((int) b, m, G))));
+    uint32_t cA = 0x7FFFFFFFu, cB = 0x7FFFFFFFu;
+#pragma unroll
+    for (int r = R - 1; r >= 0; r--) {
+        if ((pk_bits(best[r]) & 0xFFFFu) == (b & 0xFFFFu)) cA = (uint32_t) (lane * R + r);
+        if ((pk_bits(best[r]) >> 16) == (b >> 16)) cB = (uint32_t) (lane * R + r);
+    }
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) {
+        cA = min(cA, (uint32_t) __shfl_xor((int) cA, m, G));
+        cB = min(cB, (uint32_t) __shfl_xor((int) cB, m, G));
+    }
+    if (lane == 0) {
+        SwOut o;
+        o.end_row = -1; o.pad = 0;                                  // end_col: the first target column that reaches the maximum (the position pass stops there)
+        if (haveA) { o.score = (int32_t) (int16_t) (b & 0xFFFFu); o.end_col = (int32_t) min(cA, (uint32_t) max(tLenA - 1, 0)); L.out[jobA.slot] = o; }
+        if (haveB) { o.score = (int32_t) (int16_t) (b >> 16); o.end_col = (int32_t) min(cB, (uint32_t) max(tLenB - 1, 0)); L.out[jobB.slot] = o; }
+    }
+}
+
+// the longest fragment among the jobs of a wave: up to 256 residues the transposed kernel takes the wave, beyond the classic one
+__device__ __forceinline__ uint32_t swt_longest(const SwLaunch &L, const uint32_t w0, const uint32_t count) {
+    uint32_t tl = 0;
+    if (threadIdx.x < count) tl = L.jobs[L.order[(uint64_t) w0 + threadIdx.x]].t_len;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) tl = max(tl, (uint32_t) __shfl_xor((int) tl, m, 64));
+    return tl;
+}
+constexpr uint32_t SWT_MAX_ROWS = 256;
+
+// the profile of the wave's query as the LDS image swt_unit reads -- [SWT_MARGIN + column][36 bytes: the 21 scores, entry 21 = 0], zero columns around
+// it: the query's own 32-byte lines copied dword by dword --, then the unit in the shape the longest fragment of the wave needs
+template <int CLS>
+__device__ __forceinline__ void swt_wave(const SwLaunch &L, const uint32_t w0, const uint32_t count, const uint32_t tl, int8_t *smem) {
+    const SwJob j0 = L.jobs[L.order[w0]];
+    const int qLen = (int) j0.q_len;
+    uint32_t *img32 = reinterpret_cast<uint32_t *>(smem);
+    constexpr int CW = SWT_COL / 4;
+    for (int i = (int) threadIdx.x; i < SWT_MARGIN * CW; i += 64) img32[i] = 0u;
+    for (int i = (int) threadIdx.x; i < SWT_TAIL * CW; i += 64) img32[(SWT_MARGIN + qLen) * CW + i] = 0u;
+    for (int i = (int) threadIdx.x; i < qLen * 6; i += 64) {
+        const int c = i / 6, w = i - c * 6;
+        uint32_t v = *reinterpret_cast<const uint32_t *>(L.q_prof + ((int64_t) j0.q_start + (int64_t) c * j0.q_step) * 32 + w * 4);
+        if (w == 5) v &= 0xFFu;                                      // (letters 20 | 21 22 23: entry 21 is the "no row" zero)
+        img32[(SWT_MARGIN + c) * CW + w] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if constexpr (CLS == 0) {
+        if (tl <= 32u) swt_unit<2>(L, w0, count, qLen);
+        else if (tl <= 48u) swt_unit<3>(L, w0, count, qLen);
+        else swt_unit<4>(L, w0, count, qLen);
+    } else if constexpr (CLS == 1) {
+        if (tl <= 96u) swt_unit<6>(L, w0, count, qLen);
+        else swt_unit<8>(L, w0, count, qLen);
+    } else {
+        if (tl <= 192u) swt_unit<12>(L, w0, count, qLen);
+        else swt_unit<16>(L, w0, count, qLen);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// persistent one-wave workgroups over the waves of ONE tile configuration of a profile-query batch (the same wave list swp_kernel walks, a counter of
+// its own): the waves whose fragments all fit 256 rows; swp_kernel skips exactly those
+// (three register classes, like the position / reverse passes: fragments of up to 64 / 128 / 256 rows -- 2-4 / 6-8 / 12-16 rows per lane)
+template <int CLS>
+__global__ __launch_bounds__(64) void swt_kernel(SwLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    constexpr uint32_t LO = CLS == 0 ? 0u : (CLS == 1 ? 64u : 128u), HI = CLS == 0 ? 64u : (CLS == 1 ? 128u : SWT_MAX_ROWS);
+    for (uint32_t done = 0; L.units_per_block == 0 || done < L.units_per_block; done++) {
+        uint32_t u = 0;
+        if (threadIdx.x == 0) u = atomicAdd(L.work_counter_t + 16 * CLS, 1u);
+        u = (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
+        if ((uint64_t) u >= L.n_waves) break;
+        const uint32_t w0 = L.wave_start[u], count = min(8u, L.wave_start[u + 1] - w0);
+        const uint32_t tl = swt_longest(L, w0, count);
+        if (tl > HI || (CLS > 0 && tl <= LO)) continue;
+        swt_wave<CLS>(L, w0, count, tl, smem);
+    }
+}
+
 // R rows per lane; the LDS profile keeps RP >= R (even) int16 slots per lane so that a lane's scores are whole dwords.
 // G = 16 lanes per pair of DPs for tiles of at most 256 rows; G = 32 for 384 / 512 rows, where diag + score can pass 32767
 // and the add saturates like the reference's word pass (simdi16_adds, StripedSmithWaterman.cpp:1059).
@@ -380,7 +538,11 @@ __global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
         if (threadIdx.x == 0) u = atomicAdd(L.work_counter, 1u);
         u = (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
         if ((uint64_t) u >= L.n_waves) break;
-        const uint32_t w0 = L.wave_start[u], w1 = L.wave_start[u + 1];
+        const uint32_t wFirst = L.wave_start[u], wEnd = L.wave_start[u + 1];
+        // profile queries (L.narrow: their waves hold up to 8 jobs whatever the tile): the transposed unit takes the wave unless a fragment is long
+        if (L.q_prof && L.narrow && swt_longest(L, wFirst, min(8u, wEnd - wFirst)) <= SWT_MAX_ROWS) continue;       // swt_kernel's
+        for (uint32_t w0 = wFirst; w0 < wEnd; w0 += (uint32_t) (2 * GPB)) {          // (a wave of 8 jobs on a 32-lane tile: two rounds of 4)
+        const uint32_t w1 = wEnd;
         const uint32_t count = min((uint32_t) (2 * GPB), w1 - w0);
         const bool haveA = (uint32_t) (2 * grp) < count, haveB = (uint32_t) (2 * grp + 1) < count;
         const SwJob jobA = L.jobs[L.order[(uint64_t) w0 + (haveA ? 2 * grp : 0)]];
@@ -515,6 +677,7 @@ __global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        }   // rounds of the wave
     }
 }
 
@@ -698,6 +861,13 @@ hipError_t launch_sw_score(const SwLaunch &L, int cfg, hipStream_t stream) {
     const int rows = sw_cfg_rows(cfg);
     const size_t prows = rows == 48 ? 64 : rows;
     const size_t lds = (size_t) 22 * prows * sizeof(int16_t) + 448 + 2 * prows;     // profile + matrix + query residues / bias
+    if (L.q_prof && L.narrow) {
+        // profile queries: the waves whose fragments fit 256 rows go through the transposed kernel (its own counter), the rest through the classic one below
+        if (!L.work_counter_t) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(swt_kernel<0>, dim3((unsigned) grid), dim3(64), swt_image_bytes(rows), stream, L);
+        hipLaunchKernelGGL(swt_kernel<1>, dim3((unsigned) grid), dim3(64), swt_image_bytes(rows), stream, L);
+        hipLaunchKernelGGL(swt_kernel<2>, dim3((unsigned) grid), dim3(64), swt_image_bytes(rows), stream, L);
+    }
     switch (rows) {
         case 32: hipLaunchKernelGGL((swp_kernel<2>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
         case 48: hipLaunchKernelGGL((swp_kernel<3, 4>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;

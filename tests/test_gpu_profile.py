@@ -157,6 +157,13 @@ def test_profile_search_synthetic_vs_oracle(gpu_api, tmp_path, monkeypatch, fron
             frags.append(_rand(rng, rng.randint(0, 20)) + s + _rand(rng, rng.randint(0, 20)))
     frags += [_rand(rng, rng.randint(15, 120)) for _ in range(600)]
     frags += ["A" * 40, "XXXXXXXXXXXXXXXXXXXX", cons[5][:50] + "X" * 5 + cons[5][55:100]]
+    # round 6: fragments around and beyond the 256 rows of the transposed score pass (mk_sw.hip: swt_kernel) -- 250 ... 420 residues of the long
+    # profiles' consensus: waves whose longest fragment does not fit take the classic kernel, 8 jobs in two rounds on the 32-lane tiles
+    for c in cons:
+        if len(c) >= 500:
+            for n in (250, 256, 257, 300, 420):
+                a = rng.randrange(0, len(c) - n)
+                frags.append("".join(rng.choice(AA) if rng.random() < 0.2 else ch for ch in c[a:a + n]))
     rng.shuffle(frags)
     keys = list(range(len(entries)))
     data = b"".join(entries)
@@ -177,6 +184,13 @@ def test_profile_search_synthetic_vs_oracle(gpu_api, tmp_path, monkeypatch, fron
     assert pref == open(tmp_path / "out" / "pref.txt").read()
     aln = _blocks(keys, [api.format_alignments(alns, int(aoff[i]), int(aoff[i + 1])) for i in range(q.n)])
     assert aln == open(tmp_path / "out" / "aln.txt").read()
+    if front == "wide":
+        # the score pass the other way round (MK_SW_NARROW=0: the profile in the lanes' rows for every wave, waves of 4 jobs on the 32-lane tiles): same bytes
+        monkeypatch.setenv("MK_SW_NARROW", "0")
+        q2 = api.Profiles(entries, params)
+        (h2, ho2), (a2, ao2) = api.search(db, q2, params)
+        assert _blocks(keys, [api.format_alignments(a2, int(ao2[i]), int(ao2[i + 1])) for i in range(q2.n)]) == aln
+        monkeypatch.delenv("MK_SW_NARROW")
     residues = sum(len(e) for e in entries) // 25 - len(entries)
     swap_params = api.default_params()
     swap_params.evalue_thr = 1.7976931348623157e308
