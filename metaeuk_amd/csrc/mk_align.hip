@@ -727,6 +727,12 @@ static int run_shared_fwd(const AlignView &V, const mk_params &P, const uint64_t
         L.work_counter = dWork + c; L.work_counter_t = dWork + 16 + c; L.persistent_blocks = S.persistentBlocks[c]; L.units_per_block = S.unitsPerBlock;
         L.gap_open = P.gap_open; L.gap_extend = P.gap_extend;
         L.narrow = narrow;
+        // the transposed score pass: profile queries, the 32-lane tiles (512 / 768 rows; on the 16-lane tiles the classic layout already ramps over 15
+        // steps only and wins: 5 -> 10, 12 -> 17, 54 -> 58 ms at 192 / 256 / 384 rows, profiles/r06_transposed_score_pass.txt)
+        {
+            static const long tMax = knob_long("MK_SW_T_MAXROWS", 256), tMinCfg = knob_long("MK_SW_T_MINCFG", 512);
+            L.t_max_rows = (narrow && V.q_prof && sw_cfg_packed(c) && sw_cfg_rows(c) >= (int) tMinCfg) ? (uint32_t) std::max(0L, std::min(256L, tMax)) : 0u;
+        }
         L.known_score = nullptr;
         if (c == SW_NCFG - 1 && V.max_q_len > (uint32_t) sw_cfg_rows(c)) {
             // queries beyond the largest tile run in row tiles with an HBM border per job; the border is as long as the

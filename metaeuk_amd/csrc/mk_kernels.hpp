@@ -36,7 +36,8 @@ struct SwLaunch {
     // null: every job builds its own profile (test path, reverse pass).
     const uint32_t *wave_start; uint64_t n_waves;
     uint32_t *work_counter;     // shared-query mode: zeroed device counter the persistent workgroups pull wave numbers from
-    uint32_t *work_counter_t = nullptr;   // ... and the transposed score kernel's (profile queries: launch_sw_score runs it over the same waves)
+    uint32_t *work_counter_t = nullptr;   // ... and the transposed score kernels' (profile queries: launch_sw_score runs them over the same waves)
+    uint32_t t_max_rows = 0;    // > 0: waves whose longest target has at most this many residues take the transposed score kernels (mk_sw.hip: swt_kernel)
     uint32_t persistent_blocks; // ... and how many workgroups to launch (0: one per wave)
     uint32_t units_per_block;   // a workgroup retires after this many waves of jobs (0: runs until the counter is exhausted)
     uint64_t boundary_job0;     // job index that owns the first boundary_stride entries of `boundary`

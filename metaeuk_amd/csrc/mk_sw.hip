@@ -509,7 +509,7 @@ __global__ __launch_bounds__(64) void swt_kernel(SwLaunch L) {
         if ((uint64_t) u >= L.n_waves) break;
         const uint32_t w0 = L.wave_start[u], count = min(8u, L.wave_start[u + 1] - w0);
         const uint32_t tl = swt_longest(L, w0, count);
-        if (tl > HI || (CLS > 0 && tl <= LO)) continue;
+        if (tl > HI || (CLS > 0 && tl <= LO) || tl > L.t_max_rows) continue;
         swt_wave<CLS>(L, w0, count, tl, smem);
     }
 }
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(64) void swp_kernel(SwLaunch L) {
         if ((uint64_t) u >= L.n_waves) break;
         const uint32_t wFirst = L.wave_start[u], wEnd = L.wave_start[u + 1];
         // profile queries (L.narrow: their waves hold up to 8 jobs whatever the tile): the transposed unit takes the wave unless a fragment is long
-        if (L.q_prof && L.narrow && swt_longest(L, wFirst, min(8u, wEnd - wFirst)) <= SWT_MAX_ROWS) continue;       // swt_kernel's
+        if (L.t_max_rows && swt_longest(L, wFirst, min(8u, wEnd - wFirst)) <= L.t_max_rows) continue;       // swt_kernel's
         for (uint32_t w0 = wFirst; w0 < wEnd; w0 += (uint32_t) (2 * GPB)) {          // (a wave of 8 jobs on a 32-lane tile: two rounds of 4)
         const uint32_t w1 = wEnd;
         const uint32_t count = min((uint32_t) (2 * GPB), w1 - w0);
@@ -861,12 +861,13 @@ hipError_t launch_sw_score(const SwLaunch &L, int cfg, hipStream_t stream) {
     const int rows = sw_cfg_rows(cfg);
     const size_t prows = rows == 48 ? 64 : rows;
     const size_t lds = (size_t) 22 * prows * sizeof(int16_t) + 448 + 2 * prows;     // profile + matrix + query residues / bias
-    if (L.q_prof && L.narrow) {
-        // profile queries: the waves whose fragments fit 256 rows go through the transposed kernel (its own counter), the rest through the classic one below
-        if (!L.work_counter_t) return hipErrorInvalidValue;
+    if (L.t_max_rows) {
+        // profile queries on the large tiles: the waves whose fragments fit t_max_rows rows go through the transposed kernels (counters of their own), the
+        // rest through the classic one below
+        if (!L.work_counter_t || !L.q_prof || !L.narrow || L.t_max_rows > SWT_MAX_ROWS) return hipErrorInvalidValue;
         hipLaunchKernelGGL(swt_kernel<0>, dim3((unsigned) grid), dim3(64), swt_image_bytes(rows), stream, L);
-        hipLaunchKernelGGL(swt_kernel<1>, dim3((unsigned) grid), dim3(64), swt_image_bytes(rows), stream, L);
-        hipLaunchKernelGGL(swt_kernel<2>, dim3((unsigned) grid), dim3(64), swt_image_bytes(rows), stream, L);
+        if (L.t_max_rows > 64u) hipLaunchKernelGGL(swt_kernel<1>, dim3((unsigned) grid), dim3(64), swt_image_bytes(rows), stream, L);
+        if (L.t_max_rows > 128u) hipLaunchKernelGGL(swt_kernel<2>, dim3((unsigned) grid), dim3(64), swt_image_bytes(rows), stream, L);
     }
     switch (rows) {
         case 32: hipLaunchKernelGGL((swp_kernel<2>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;
