@@ -33,7 +33,10 @@ namespace mk {
 namespace {
 
 constexpr uint32_t KEY_CLS = 4096;                    // target-length classes (16 residues each), falling length = ascending class
-constexpr uint32_t N_BINS = (uint32_t) SW_NCFG * KEY_CLS;
+// (two more "configurations" behind the tile configurations: the position jobs of profile queries that the transposed kernel takes -- 512- and 768-row
+//  profiles, targets of at most 256 residues --, binned by query instead of by target length so that a query's jobs are neighbours in the order)
+constexpr int SW_NBINCFG = SW_NCFG + 2;
+constexpr uint32_t N_BINS = (uint32_t) SW_NBINCFG * KEY_CLS;
 static_assert(SW_NCFG <= 16, "the bounds arrays keep 16 slots per kind");
 
 __device__ __forceinline__ uint32_t len_class(uint32_t tLen) { return KEY_CLS - 1 - min(tLen >> 4, KEY_CLS - 1); }
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256) void gate_count_kernel(const SwJob *fwdJobs, c
 __global__ __launch_bounds__(256) void gate_emit_kernel(const SwJob *fwdJobs, const SwOut *fwdOut, uint64_t n, const GateEntry *gate, const uint32_t *blockStart,
                                                         uint32_t *posPair, SwJob *posJobs, uint32_t *posKeys, int32_t *posScore, uint32_t *hist,
                                                         unsigned long long *work /* [2 * cfg]: bytes, [2 * cfg + 1]: cells of the position pass (statistics) */,
-                                                        bool useBound) {
+                                                        bool useBound, int tposFirstCfg /* >= 0: jobs of this tile configuration and the next go to the transposed kernel */) {
     helper_prio();
     __shared__ unsigned long long sWork[2 * SW_NCFG];
     __shared__ uint32_t sWave[4];
@@ -269,7 +272,9 @@ __global__ __launch_bounds__(256) void gate_emit_kernel(const SwJob *fwdJobs, co
         posScore[r] = fwdOut[p].score;
         j.slot = r;
         posJobs[r] = j;
-        const uint32_t key = sort_key(j.q_len, j.t_len);
+        uint32_t key = sort_key(j.q_len, j.t_len);
+        if (tposFirstCfg >= 0 && (c == tposFirstCfg || c == tposFirstCfg + 1) && j.t_len <= SW_TPOS_MAX_ROWS)
+            key = (uint32_t) (SW_NCFG + c - tposFirstCfg) * KEY_CLS + ((j.q_start >> 7) & (KEY_CLS - 1u));      // (by query: its first column, 128 columns per bin)
         posKeys[r] = key;
         atomicAdd(&hist[key], 1u);
     }
@@ -306,8 +311,8 @@ static_assert(N_BINS % BIN_THREADS == 0, "bins per thread");
 __global__ __launch_bounds__(BIN_THREADS) void bin_scan_kernel(uint32_t *hist, uint32_t *cursor, uint32_t *bounds) {
     helper_prio();
     __shared__ uint32_t sm[16];
-    __shared__ uint32_t sFirst[SW_NCFG];
-    if (threadIdx.x < SW_NCFG) sFirst[threadIdx.x] = 0xFFFFFFFFu;
+    __shared__ uint32_t sFirst[SW_NBINCFG];
+    if (threadIdx.x < SW_NBINCFG) sFirst[threadIdx.x] = 0xFFFFFFFFu;
     __syncthreads();
     const uint32_t k0 = threadIdx.x * BINS_PER_THREAD;
     uint32_t v[1] = {0}, excl[1], total[1];
@@ -325,9 +330,9 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scan_kernel(uint32_t *hist, u
         run += h;
         hist[k0 + k] = 0;
     }
-    if (threadIdx.x == 0) bounds[SW_NCFG] = total[0];
+    if (threadIdx.x == 0) bounds[SW_NBINCFG] = total[0];
     __syncthreads();
-    if (threadIdx.x < SW_NCFG) bounds[32 + threadIdx.x] = sFirst[threadIdx.x] == 0xFFFFFFFFu ? 0u : sFirst[threadIdx.x];
+    if (threadIdx.x < SW_NBINCFG) bounds[32 + threadIdx.x] = sFirst[threadIdx.x] == 0xFFFFFFFFu ? 0u : sFirst[threadIdx.x];
 }
 __global__ __launch_bounds__(256) void bin_scatter_kernel(const uint32_t *keys, uint32_t n, uint32_t *cursor, uint32_t *order) {
     helper_prio();
@@ -574,6 +579,14 @@ static const AlignShapes &align_shapes() {
     return S;
 }
 
+// the transposed position pass (mk_sw.hip: swtp_kernel): profile queries, the 32-lane tiles (512 and 768 rows: configurations 8 and 9), not with the
+// one-launch-per-register-class form (its bounds end at the tile configurations).  MK_SW_TPOS=0 switches it off (read per call)
+static int tpos_first_cfg(const AlignView &V) {
+    static_assert(SW_NCFG == 11, "configurations 8 / 9 = 512 / 768 rows");
+    if (!V.q_prof || knob_long("MK_SW_TPOS", 1) == 0 || knob_long("MK_SW_MULTI", 0) != 0 || knob_long("MK_SW_NARROW", -1) == 0) return -1;
+    return 8;
+}
+
 // position / reverse pass: the jobs (their keys and the key histogram are filled by the producing kernel) ordered by
 // (tile configuration, target length class) with a counting sort, one launch per tile configuration
 static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jobs, SwOut *out, const uint32_t *keys, uint32_t *hist, uint32_t *order,
@@ -665,6 +678,24 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
             if (sw_early_exit()) L.known_score = knownScore;           // sw_unit stops a DP once its known maximum has been seen in a finished column
             ACHK(launch_sw(L, c, stream));
         }
+        te(th);
+    }
+    // the jobs binned for the transposed position kernel (gate_emit_kernel, tposFirstCfg): behind the tile configurations in the order
+    for (int pc = 0; pc < SW_NBINCFG - SW_NCFG; pc++) {
+        const uint32_t lo = hb[SW_NCFG + pc], hi = hb[SW_NCFG + pc + 1];
+        if (hi <= lo) continue;
+        if (!knownScore || !V.q_prof) { err = "transposed position jobs without a known score"; return MK_ERR_DEVICE; }
+        SwLaunch L;
+        L.q_res = V.q_res; L.q_bias8 = V.q_bias8; L.q_prof = V.q_prof; L.t_res = V.t_res; L.mat = V.mat_aln;
+        L.jobs = jobs; L.out = out; L.n_jobs = hi - lo; L.order = order + lo;
+        L.boundary = nullptr; L.boundary_stride = 0; L.boundary_job0 = 0;
+        L.wave_start = nullptr; L.n_waves = 0; L.work_counter = nullptr; L.persistent_blocks = 0; L.units_per_block = 0; L.known_score = knownScore;
+        L.gap_open = P.gap_open; L.gap_extend = P.gap_extend;
+        const int rows = sw_cfg_rows(8 + pc);
+        char nm[64];
+        snprintf(nm, sizeof(nm), "%s_rows%dt", tag, rows);
+        th = tb(nm, 0, 0);
+        ACHK(launch_sw_tpos(L, rows, (uint32_t) S.cus * 8u, stream));
         te(th);
     }
     return MK_OK;
@@ -829,7 +860,7 @@ int run_align_device(const AlignView &V, const uint64_t *hitOffHost, const mk_hi
     SwJob *dRevJobs = (SwJob *) dev_scratch("align_revjobs", (size_t) nRev * sizeof(SwJob));
     ANULL(dRevPair); ANULL(dPosJobs); ANULL(dPosScore); ANULL(dKeys); ANULL(dOrder); ANULL(dPosOut); ANULL(dRevOut); ANULL(dRevJobs);
     hipLaunchKernelGGL(gate_emit_kernel, dim3(nGateBlocks), dim3(256), 0, stream, dJobs, dOut, (uint64_t) n, dGate, (const uint32_t *) dGateBlk,
-                       dRevPair, dPosJobs, dKeys, dPosScore, dHist, dPosWork, sw_early_exit());
+                       dRevPair, dPosJobs, dKeys, dPosScore, dHist, dPosWork, sw_early_exit(), tpos_first_cfg(V));
     te(th);
     ACHK(hipGetLastError());
     ACHK(hipMemcpyAsync(hPosWork, dPosWork, 2 * SW_NCFG * 8, hipMemcpyDeviceToHost, stream));

@@ -77,6 +77,10 @@ hipError_t launch_sw_score(const SwLaunch &L, int cfg, hipStream_t stream);
 // for the tiles sw_cfg_known() names; L.order / L.n_jobs / L.work_counter / L.persistent_blocks as in the persistent launches
 __host__ __device__ inline bool sw_cfg_known(int c) { return sw_cfg_rows(c) <= 64; }
 hipError_t launch_sw_known(const SwLaunch &L, int cfg, hipStream_t stream);
+// round 6: the position pass of profile queries, transposed (the fragment in the lanes' rows, every profile column walked, packed int16, the known score
+// located by the tie rule row first); for forward jobs of at most SW_TPOS_MAX_ROWS target residues whose query is a profile of a 32-lane tile
+constexpr uint32_t SW_TPOS_MAX_ROWS = 256;
+hipError_t launch_sw_tpos(const SwLaunch &L, int rows, uint32_t blocksPerClass, hipStream_t stream);
 // position / reverse pass over ALL tile configurations of a register class in one persistent launch, the bounds of the tile configurations
 // read on the device (mk_sw.hip: sw_multi_kernel)
 hipError_t launch_sw_multi(const SwLaunch &L, const uint32_t *bounds, uint32_t *counter, int cls, uint32_t blocks, hipStream_t stream, bool prio = true);

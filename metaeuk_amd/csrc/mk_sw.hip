@@ -367,6 +367,7 @@ __device__ __forceinline__ pk16 pk_subs0(pk16 a, pk16 b) {
 // unrolled block as the instruction's immediate offset -- no address arithmetic per cell.  H, E, F and the lane hand-over are swp_kernel's; what
 // crosses the lanes is H of a lane's last row and F (two DPP moves), no residues.  The maximum is kept per ROW, so the bound handed to the position pass
 // is exact: the first fragment position that reaches the maximum.  Fragments of at most 256 rows: 256 x 127 < 32 767, no saturation.
+constexpr uint32_t SWT_MAX_ROWS = 256;                            // the longest fragment the transposed kernels take (16 lanes x 16 rows)
 constexpr int SWT_MARGIN = 16, SWT_TAIL = 32, SWT_COL = 36;       // zero columns in front of / behind the profile; bytes per column of the LDS image
 __host__ __device__ inline size_t swt_image_bytes(int qLen) { return (size_t) (SWT_MARGIN + qLen + SWT_TAIL) * SWT_COL; }
 
@@ -452,6 +453,177 @@ __device__ __forceinline__ void swt_unit(const SwLaunch &L, const uint32_t w0, c
     }
 }
 
+// The POSITION pass of the same jobs, transposed (round 6): the maximum S of a job is known from the score pass; asked for is the first target column
+// that reaches it and the smallest query row in that column (StripedSmithWaterman.cpp:820-850) -- here: the smallest fragment ROW with a cell equal to S and the
+// first profile COLUMN in that row.  Per row and step five instructions beside the recurrence (no running maximum is kept): x = h ^ S, e = 1 -sat x (1 where
+// the half is zero), the inverted mask e + 0xFFFF, the candidate column | mask, an unsigned minimum into the row's first column.  Every profile column is
+// walked (the rule's first key is the row: no early exit), the rows are the target cut at the score pass's bound.  A padding row or a column behind the
+// profile can only repeat S one row further down / in a later column than a real cell that holds it, so the smallest (row, column) is a real cell.
+template <int R>
+__device__ __forceinline__ void swtp_unit(const SwLaunch &L, const uint32_t (&jobIdx)[8], const uint32_t count, const int qLen) {
+    constexpr int G = 16;
+    constexpr int UNR = R <= 2 ? 16 : (R <= 4 ? 8 : (R <= 8 ? 4 : 2));
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    const int lane = threadIdx.x % G, grp = threadIdx.x / G;
+    const pk16 go2 = pk_splat(L.gap_open), ge2 = pk_splat(L.gap_extend), zero2 = pk_splat(0);
+    const bool haveA = (uint32_t) (2 * grp) < count, haveB = (uint32_t) (2 * grp + 1) < count;
+    uint32_t ia = jobIdx[0], ib = jobIdx[0];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { if (k == 2 * grp && haveA) ia = jobIdx[k]; if (k == 2 * grp + 1 && haveB) ib = jobIdx[k]; }
+    const SwJob jobA = L.jobs[ia], jobB = L.jobs[ib];
+    const int tLenA = haveA ? (int) jobA.t_len : 0, tLenB = haveB ? (int) jobB.t_len : 0;
+    const uint32_t SA = haveA ? (uint32_t) L.known_score[jobA.slot] & 0xFFFFu : 0x7FFFu, SB = haveB ? (uint32_t) L.known_score[jobB.slot] & 0xFFFFu : 0x7FFFu;
+    const uint32_t S2 = SA | (SB << 16);
+    uint32_t offA[R], offB[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = lane * R + r;
+        const uint32_t a = i < tLenA ? (uint32_t) L.t_res[(int64_t) jobA.t_start + (int64_t) i * jobA.t_step] : 21u;
+        const uint32_t b = i < tLenB ? (uint32_t) L.t_res[(int64_t) jobB.t_start + (int64_t) i * jobB.t_step] : 21u;
+        offA[r] = min(a, 21u) + (uint32_t) ((SWT_MARGIN - lane) * SWT_COL); offB[r] = min(b, 21u) + (uint32_t) ((SWT_MARGIN - lane) * SWT_COL);
+    }
+    pk16 H[R], E[R];
+    uint32_t first[R];                                              // per half: the first column of this row with H == S (0xFFFF: none yet)
+#pragma unroll
+    for (int r = 0; r < R; r++) { H[r] = zero2; E[r] = zero2; first[r] = 0xFFFFFFFFu; }
+    pk16 hupPrev = zero2;
+    uint32_t outH = 0, outF = 0;
+    const uint32_t c0 = (uint32_t) (-lane) & 0xFFFFu;
+    uint32_t cvec = c0 | (c0 << 16);                                // this lane's column, in both halves (negative columns: 0xFFF1 ..: never a minimum)
+    const int steps = (qLen + G - 1 + 15) & ~15;
+#pragma unroll 1
+    for (int s0 = 0; s0 < steps; s0 += UNR) {
+#pragma unroll
+        for (int k = 0; k < UNR; k++) {
+            const pk16 hup = pk_from(shift_up_zero<G>(outH, lane));
+            pk16 F = pk_from(shift_up_zero<G>(outF, lane));
+            pk16 dsave = hupPrev;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int sa = (int) smem[offA[r] + (uint32_t) (k * SWT_COL)], sb = (int) smem[offB[r] + (uint32_t) (k * SWT_COL)];
+                const pk16 sc = pk_from(__builtin_amdgcn_perm((uint32_t) sb, (uint32_t) sa, 0x05040100u));
+                const pk16 d = dsave + sc;
+                dsave = H[r];
+                const pk16 h = pk_max(pk_max(d, E[r]), F);
+                // first column with h == S, per half
+                const pku16 x = __builtin_bit_cast(pku16, pk_bits(h) ^ S2);
+                const pku16 one = {1, 1}, ffff = {0xFFFF, 0xFFFF};
+                const pku16 e = __builtin_elementwise_sub_sat(one, x);                       // 1 where the half is zero
+                const uint32_t inv = __builtin_bit_cast(uint32_t, (pku16) (e + ffff));       // 0x0000 there, 0xFFFF elsewhere
+                first[r] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(pku16, first[r]), __builtin_bit_cast(pku16, cvec | inv)));
+                const pk16 ho = pk_subs0(h, go2);
+                E[r] = pk_max(pk_subs0(E[r], ge2), ho);
+                F = pk_max(pk_subs0(F, ge2), ho);
+                H[r] = h;
+            }
+            hupPrev = hup;
+            outH = pk_bits(H[R - 1]);
+            outF = pk_bits(F);
+            cvec = __builtin_bit_cast(uint32_t, (pku16) (__builtin_bit_cast(pku16, cvec) + (pku16) {1, 1}));
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) { offA[r] += (uint32_t) (UNR * SWT_COL); offB[r] += (uint32_t) (UNR * SWT_COL); }
+    }
+    // smallest row with a hit, and its first column: key = row << 16 | column, minimum over the lanes of the group
+    uint32_t kA = 0xFFFFFFFFu, kB = 0xFFFFFFFFu;
+#pragma unroll
+    for (int r = R - 1; r >= 0; r--) {
+        if ((first[r] & 0xFFFFu) < (uint32_t) qLen) kA = ((uint32_t) (lane * R + r) << 16) | (first[r] & 0xFFFFu);
+        if ((first[r] >> 16) < (uint32_t) qLen) kB = ((uint32_t) (lane * R + r) << 16) | (first[r] >> 16);
+    }
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) {
+        kA = min(kA, (uint32_t) __shfl_xor((int) kA, m, G));
+        kB = min(kB, (uint32_t) __shfl_xor((int) kB, m, G));
+    }
+    if (lane == 0) {
+        SwOut o;
+        o.pad = 0;
+        if (haveA) {
+            const bool ok = kA != 0xFFFFFFFFu && (int) (kA >> 16) < tLenA;
+            o.score = ok ? (int32_t) SA : 0; o.end_col = ok ? (int32_t) (kA >> 16) : -1; o.end_row = ok ? (int32_t) (kA & 0xFFFFu) : -1;
+            L.out[jobA.slot] = o;
+        }
+        if (haveB) {
+            const bool ok = kB != 0xFFFFFFFFu && (int) (kB >> 16) < tLenB;
+            o.score = ok ? (int32_t) SB : 0; o.end_col = ok ? (int32_t) (kB >> 16) : -1; o.end_row = ok ? (int32_t) (kB & 0xFFFFu) : -1;
+            L.out[jobB.slot] = o;
+        }
+    }
+}
+
+// the profile image of swt_unit / swtp_unit for the query that starts at column qStart
+__device__ __forceinline__ void swt_image(const SwLaunch &L, const uint32_t qStart, const int qStep, const int qLen, int8_t *smem) {
+    uint32_t *img32 = reinterpret_cast<uint32_t *>(smem);
+    constexpr int CW = SWT_COL / 4;
+    for (int i = (int) threadIdx.x; i < SWT_MARGIN * CW; i += 64) img32[i] = 0u;
+    for (int i = (int) threadIdx.x; i < SWT_TAIL * CW; i += 64) img32[(SWT_MARGIN + qLen) * CW + i] = 0u;
+    for (int i = (int) threadIdx.x; i < qLen * 6; i += 64) {
+        const int c = i / 6, w = i - c * 6;
+        uint32_t v = *reinterpret_cast<const uint32_t *>(L.q_prof + ((int64_t) qStart + (int64_t) c * qStep) * 32 + w * 4);
+        if (w == 5) v &= 0xFFu;                                      // (letters 20 | 21 22 23: entry 21 is the "no row" zero)
+        img32[(SWT_MARGIN + c) * CW + w] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// position jobs of profile queries in units of 8 consecutive entries of L.order (sorted so that a query's jobs are neighbours: mk_align.hip gate_emit_kernel);
+// inside a unit the jobs are taken query by query (one LDS image each); CLS as in swt_kernel, per run of a query
+template <int CLS>
+__global__ __launch_bounds__(64) void swtp_kernel(SwLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    if (MK_HELPER_PRIO) __builtin_amdgcn_s_setprio(MK_HELPER_PRIO);
+    constexpr uint32_t LO = CLS == 0 ? 0u : (CLS == 1 ? 64u : 128u), HI = CLS == 0 ? 64u : (CLS == 1 ? 128u : SWT_MAX_ROWS);
+    const uint64_t nUnits = (L.n_jobs + 7) / 8;
+    for (uint64_t u = blockIdx.x; u < nUnits; u += gridDim.x) {
+        const uint64_t j0 = u * 8;
+        const uint32_t cnt = (uint32_t) min((uint64_t) 8, L.n_jobs - j0);
+        // lanes 0 .. 7 look at one job each
+        uint32_t myJob = 0, myQ = 0xFFFFFFFFu, myT = 0, myL = 0;
+        if (threadIdx.x < cnt) { myJob = L.order[j0 + threadIdx.x]; const SwJob j = L.jobs[myJob]; myQ = j.q_start; myT = j.t_len; myL = j.q_len; }
+        uint32_t todo = (uint32_t) (__ballot(threadIdx.x < cnt) & 0xFFull);
+        while (todo) {
+            const int lead = __ffs((int) todo) - 1;
+            const uint32_t q = (uint32_t) __shfl((int) myQ, lead, 64), qLen = (uint32_t) __shfl((int) myL, lead, 64);
+            const uint32_t run = (uint32_t) (__ballot(threadIdx.x < 8 && ((todo >> threadIdx.x) & 1u) && myQ == q && myL == qLen) & 0xFFull);
+            todo &= ~run;
+            uint32_t tl = ((run >> (threadIdx.x & 7)) & 1u) && threadIdx.x < 8 ? myT : 0u;
+#pragma unroll
+            for (int m = 4; m >= 1; m >>= 1) tl = max(tl, (uint32_t) __shfl_xor((int) tl, m, 64));
+            tl = (uint32_t) __shfl((int) tl, 0, 64);
+            if (tl > HI || (CLS > 0 && tl <= LO)) continue;
+            uint32_t jobIdx[8];
+            uint32_t n = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t jk = (uint32_t) __shfl((int) myJob, k, 64);
+                if ((run >> k) & 1u) {
+#pragma unroll
+                    for (int s = 0; s < 8; s++) if ((uint32_t) s == n) jobIdx[s] = jk;
+                    n++;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 8; s++) if ((uint32_t) s >= n) jobIdx[s] = jobIdx[0];
+            swt_image(L, q, 1, (int) qLen, smem);
+            if constexpr (CLS == 0) {
+                if (tl <= 32u) swtp_unit<2>(L, jobIdx, n, (int) qLen);
+                else if (tl <= 48u) swtp_unit<3>(L, jobIdx, n, (int) qLen);
+                else swtp_unit<4>(L, jobIdx, n, (int) qLen);
+            } else if constexpr (CLS == 1) {
+                if (tl <= 96u) swtp_unit<6>(L, jobIdx, n, (int) qLen);
+                else swtp_unit<8>(L, jobIdx, n, (int) qLen);
+            } else {
+                if (tl <= 192u) swtp_unit<12>(L, jobIdx, n, (int) qLen);
+                else swtp_unit<16>(L, jobIdx, n, (int) qLen);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // the longest fragment among the jobs of a wave: up to 256 residues the transposed kernel takes the wave, beyond the classic one
 __device__ __forceinline__ uint32_t swt_longest(const SwLaunch &L, const uint32_t w0, const uint32_t count) {
     uint32_t tl = 0;
@@ -460,7 +632,6 @@ __device__ __forceinline__ uint32_t swt_longest(const SwLaunch &L, const uint32_
     for (int m = 32; m >= 1; m >>= 1) tl = max(tl, (uint32_t) __shfl_xor((int) tl, m, 64));
     return tl;
 }
-constexpr uint32_t SWT_MAX_ROWS = 256;
 
 // the profile of the wave's query as the LDS image swt_unit reads -- [SWT_MARGIN + column][36 bytes: the 21 scores, entry 21 = 0], zero columns around
 // it: the query's own 32-byte lines copied dword by dword --, then the unit in the shape the longest fragment of the wave needs
@@ -468,18 +639,7 @@ template <int CLS>
 __device__ __forceinline__ void swt_wave(const SwLaunch &L, const uint32_t w0, const uint32_t count, const uint32_t tl, int8_t *smem) {
     const SwJob j0 = L.jobs[L.order[w0]];
     const int qLen = (int) j0.q_len;
-    uint32_t *img32 = reinterpret_cast<uint32_t *>(smem);
-    constexpr int CW = SWT_COL / 4;
-    for (int i = (int) threadIdx.x; i < SWT_MARGIN * CW; i += 64) img32[i] = 0u;
-    for (int i = (int) threadIdx.x; i < SWT_TAIL * CW; i += 64) img32[(SWT_MARGIN + qLen) * CW + i] = 0u;
-    for (int i = (int) threadIdx.x; i < qLen * 6; i += 64) {
-        const int c = i / 6, w = i - c * 6;
-        uint32_t v = *reinterpret_cast<const uint32_t *>(L.q_prof + ((int64_t) j0.q_start + (int64_t) c * j0.q_step) * 32 + w * 4);
-        if (w == 5) v &= 0xFFu;                                      // (letters 20 | 21 22 23: entry 21 is the "no row" zero)
-        img32[(SWT_MARGIN + c) * CW + w] = v;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    swt_image(L, j0.q_start, j0.q_step, qLen, smem);
     if constexpr (CLS == 0) {
         if (tl <= 32u) swt_unit<2>(L, w0, count, qLen);
         else if (tl <= 48u) swt_unit<3>(L, w0, count, qLen);
@@ -884,6 +1044,18 @@ hipError_t launch_sw_score(const SwLaunch &L, int cfg, hipStream_t stream) {
         case 768: hipLaunchKernelGGL((swp_kernel<24, 24, 32>), dim3((unsigned) grid), dim3(64), lds, stream, L); break;   // (profile queries: 513 .. 768 columns)
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+// transposed position pass (profile queries, forward jobs whose score is known and whose target is at most 256 residues; rows = the tile of the query's
+// length: sizes the LDS image): L.order / L.n_jobs = the jobs, a query's jobs next to each other
+hipError_t launch_sw_tpos(const SwLaunch &L, int rows, uint32_t blocksPerClass, hipStream_t stream) {
+    if (!L.q_prof || !L.order || !L.known_score || rows <= 0) return hipErrorInvalidValue;
+    if (L.n_jobs == 0) return hipSuccess;
+    const unsigned grid = (unsigned) std::min<uint64_t>((L.n_jobs + 7) / 8, std::max<uint32_t>(1u, blocksPerClass));
+    hipLaunchKernelGGL(swtp_kernel<0>, dim3(grid), dim3(64), swt_image_bytes(rows), stream, L);
+    hipLaunchKernelGGL(swtp_kernel<1>, dim3(grid), dim3(64), swt_image_bytes(rows), stream, L);
+    hipLaunchKernelGGL(swtp_kernel<2>, dim3(grid), dim3(64), swt_image_bytes(rows), stream, L);
     return hipGetLastError();
 }
 

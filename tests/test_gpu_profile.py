@@ -191,6 +191,18 @@ def test_profile_search_synthetic_vs_oracle(gpu_api, tmp_path, monkeypatch, fron
         (h2, ho2), (a2, ao2) = api.search(db, q2, params)
         assert _blocks(keys, [api.format_alignments(a2, int(ao2[i]), int(ao2[i + 1])) for i in range(q2.n)]) == aln
         monkeypatch.delenv("MK_SW_NARROW")
+        # ... and the transposed POSITION pass off (MK_SW_TPOS=0: the int32 wavefront with the profile in the rows for every job): same bytes
+        monkeypatch.setenv("MK_SW_TPOS", "0")
+        api.kernel_stats(reset=True)
+        q3 = api.Profiles(entries, params)
+        (h3, ho3), (a3, ao3) = api.search(db, q3, params)
+        assert _blocks(keys, [api.format_alignments(a3, int(ao3[i]), int(ao3[i + 1])) for i in range(q3.n)]) == aln
+        assert not any(k.endswith("t") and k.startswith("sw_pos_rows") for k in api.kernel_stats())
+        monkeypatch.delenv("MK_SW_TPOS")
+        api.kernel_stats(reset=True)
+        q4 = api.Profiles(entries, params)
+        api.search(db, q4, params)
+        assert any(k.endswith("t") and k.startswith("sw_pos_rows") for k in api.kernel_stats()), sorted(api.kernel_stats())
     residues = sum(len(e) for e in entries) // 25 - len(entries)
     swap_params = api.default_params()
     swap_params.evalue_thr = 1.7976931348623157e308
