@@ -695,7 +695,7 @@ static int run_sorted_sw(const AlignView &V, const mk_params &P, const SwJob *jo
         char nm[64];
         snprintf(nm, sizeof(nm), "%s_rows%dt", tag, rows);
         th = tb(nm, 0, 0);
-        ACHK(launch_sw_tpos(L, rows, (uint32_t) S.cus * 8u, stream));
+        ACHK(launch_sw_tpos(L, rows, (uint32_t) S.cus * (uint32_t) std::max(1L, knob_long("MK_SW_TPOS_WAVES", 32)), stream));
         te(th);
     }
     return MK_OK;

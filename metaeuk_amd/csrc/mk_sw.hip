@@ -368,7 +368,7 @@ __device__ __forceinline__ pk16 pk_subs0(pk16 a, pk16 b) {
 // crosses the lanes is H of a lane's last row and F (two DPP moves), no residues.  The maximum is kept per ROW, so the bound handed to the position pass
 // is exact: the first fragment position that reaches the maximum.  Fragments of at most 256 rows: 256 x 127 < 32 767, no saturation.
 constexpr uint32_t SWT_MAX_ROWS = 256;                            // the longest fragment the transposed kernels take (16 lanes x 16 rows)
-constexpr int SWT_MARGIN = 16, SWT_TAIL = 32, SWT_COL = 36;       // zero columns in front of / behind the profile; bytes per column of the LDS image
+constexpr int SWT_MARGIN = 16, SWT_TAIL = 32, SWT_COL = 24;       // zero columns in front of / behind the profile; bytes per column of the LDS image
 __host__ __device__ inline size_t swt_image_bytes(int qLen) { return (size_t) (SWT_MARGIN + qLen + SWT_TAIL) * SWT_COL; }
 
 template <int R>
@@ -575,48 +575,49 @@ __global__ __launch_bounds__(64) void swtp_kernel(SwLaunch L) {
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     if (MK_HELPER_PRIO) __builtin_amdgcn_s_setprio(MK_HELPER_PRIO);
     constexpr uint32_t LO = CLS == 0 ? 0u : (CLS == 1 ? 64u : 128u), HI = CLS == 0 ? 64u : (CLS == 1 ? 128u : SWT_MAX_ROWS);
-    const uint64_t nUnits = (L.n_jobs + 7) / 8;
+    constexpr uint32_t UNIT = 8;                                    // jobs looked at together (32: 41 -> 50 / 62 -> 76 ms, the runs mix target lengths): a query's run inside them is taken 8 jobs at a time
+    const uint64_t nUnits = (L.n_jobs + UNIT - 1) / UNIT;
     for (uint64_t u = blockIdx.x; u < nUnits; u += gridDim.x) {
-        const uint64_t j0 = u * 8;
-        const uint32_t cnt = (uint32_t) min((uint64_t) 8, L.n_jobs - j0);
-        // lanes 0 .. 7 look at one job each
+        const uint64_t j0 = u * UNIT;
+        const uint32_t cnt = (uint32_t) min((uint64_t) UNIT, L.n_jobs - j0);
+        // lanes 0 .. UNIT - 1 look at one job each
         uint32_t myJob = 0, myQ = 0xFFFFFFFFu, myT = 0, myL = 0;
         if (threadIdx.x < cnt) { myJob = L.order[j0 + threadIdx.x]; const SwJob j = L.jobs[myJob]; myQ = j.q_start; myT = j.t_len; myL = j.q_len; }
-        uint32_t todo = (uint32_t) (__ballot(threadIdx.x < cnt) & 0xFFull);
+        uint32_t todo = (uint32_t) (__ballot(threadIdx.x < cnt) & 0xFFFFFFFFull);
         while (todo) {
             const int lead = __ffs((int) todo) - 1;
             const uint32_t q = (uint32_t) __shfl((int) myQ, lead, 64), qLen = (uint32_t) __shfl((int) myL, lead, 64);
-            const uint32_t run = (uint32_t) (__ballot(threadIdx.x < 8 && ((todo >> threadIdx.x) & 1u) && myQ == q && myL == qLen) & 0xFFull);
+            uint32_t run = (uint32_t) (__ballot(threadIdx.x < UNIT && ((todo >> (threadIdx.x & 31u)) & 1u) && myQ == q && myL == qLen) & 0xFFFFFFFFull);
             todo &= ~run;
-            uint32_t tl = ((run >> (threadIdx.x & 7)) & 1u) && threadIdx.x < 8 ? myT : 0u;
+            // the longest target of the run decides the class (a class's kernel takes whole runs)
+            uint32_t tl = (threadIdx.x < UNIT && ((run >> (threadIdx.x & 31u)) & 1u)) ? myT : 0u;
 #pragma unroll
-            for (int m = 4; m >= 1; m >>= 1) tl = max(tl, (uint32_t) __shfl_xor((int) tl, m, 64));
-            tl = (uint32_t) __shfl((int) tl, 0, 64);
+            for (int m = 32; m >= 1; m >>= 1) tl = max(tl, (uint32_t) __shfl_xor((int) tl, m, 64));
             if (tl > HI || (CLS > 0 && tl <= LO)) continue;
-            uint32_t jobIdx[8];
-            uint32_t n = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const uint32_t jk = (uint32_t) __shfl((int) myJob, k, 64);
-                if ((run >> k) & 1u) {
-#pragma unroll
-                    for (int s = 0; s < 8; s++) if ((uint32_t) s == n) jobIdx[s] = jk;
-                    n++;
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 8; s++) if ((uint32_t) s >= n) jobIdx[s] = jobIdx[0];
             swt_image(L, q, 1, (int) qLen, smem);
-            if constexpr (CLS == 0) {
-                if (tl <= 32u) swtp_unit<2>(L, jobIdx, n, (int) qLen);
-                else if (tl <= 48u) swtp_unit<3>(L, jobIdx, n, (int) qLen);
-                else swtp_unit<4>(L, jobIdx, n, (int) qLen);
-            } else if constexpr (CLS == 1) {
-                if (tl <= 96u) swtp_unit<6>(L, jobIdx, n, (int) qLen);
-                else swtp_unit<8>(L, jobIdx, n, (int) qLen);
-            } else {
-                if (tl <= 192u) swtp_unit<12>(L, jobIdx, n, (int) qLen);
-                else swtp_unit<16>(L, jobIdx, n, (int) qLen);
+            while (run) {
+                uint32_t jobIdx[8];
+                uint32_t n = 0;
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    if (run) {
+                        const int k = __ffs((int) run) - 1;
+                        run &= run - 1u;
+                        jobIdx[s] = (uint32_t) __shfl((int) myJob, k, 64);
+                        n++;
+                    } else jobIdx[s] = jobIdx[0];
+                }
+                if constexpr (CLS == 0) {
+                    if (tl <= 32u) swtp_unit<2>(L, jobIdx, n, (int) qLen);
+                    else if (tl <= 48u) swtp_unit<3>(L, jobIdx, n, (int) qLen);
+                    else swtp_unit<4>(L, jobIdx, n, (int) qLen);
+                } else if constexpr (CLS == 1) {
+                    if (tl <= 96u) swtp_unit<6>(L, jobIdx, n, (int) qLen);
+                    else swtp_unit<8>(L, jobIdx, n, (int) qLen);
+                } else {
+                    if (tl <= 192u) swtp_unit<12>(L, jobIdx, n, (int) qLen);
+                    else swtp_unit<16>(L, jobIdx, n, (int) qLen);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -633,7 +634,7 @@ __device__ __forceinline__ uint32_t swt_longest(const SwLaunch &L, const uint32_
     return tl;
 }
 
-// the profile of the wave's query as the LDS image swt_unit reads -- [SWT_MARGIN + column][36 bytes: the 21 scores, entry 21 = 0], zero columns around
+// the profile of the wave's query as the LDS image swt_unit reads -- [SWT_MARGIN + column][24 bytes: the 21 scores, entry 21 = 0], zero columns around
 // it: the query's own 32-byte lines copied dword by dword --, then the unit in the shape the longest fragment of the wave needs
 template <int CLS>
 __device__ __forceinline__ void swt_wave(const SwLaunch &L, const uint32_t w0, const uint32_t count, const uint32_t tl, int8_t *smem) {
