@@ -36,5 +36,5 @@ bash tools/sq_profile.sh > /dev/null 2>&1; cp gpurun_out/sq/sq_summary.txt $OUT/
 bash tools/overlap_trace.sh 2>&1 | tail -22 > $OUT/${TAG}_stage_timeline.txt
 bash tools/mem_profile.sh > /dev/null 2>&1; cp gpurun_out/mem/mem_summary.txt $OUT/${TAG}_mem_counters.txt 2>/dev/null
 fi
-rm -rf $OUT/prof_stats gpurun_out/pmc/rd gpurun_out/pmc/wr gpurun_out/sq/pmc gpurun_out/trace/kt gpurun_out/mem/p1 gpurun_out/mem/p2 gpurun_out/mem/p3
+rm -rf $OUT/prof_stats gpurun_out/pmc/rd gpurun_out/pmc/wr gpurun_out/pmc/dram gpurun_out/sq/pmc gpurun_out/trace/kt gpurun_out/mem/p1 gpurun_out/mem/p2 gpurun_out/mem/p3
 head -12 $OUT/${TAG}_bench_kernel_stats.txt; cat $OUT/${TAG}_bench_host_threads.txt 2>/dev/null; tail -14 $OUT/pmc_traffic.log; python -c "import json;d=json.load(open('$OUT/${TAG}_bench_n1.json'));print(d['ms_per_step'], d['value'], d['roofline'], d['valu_roofline'], d['cpu_baseline'], d['result_digest'])"
