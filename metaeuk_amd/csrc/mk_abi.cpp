@@ -14,6 +14,7 @@
 #include "mk_profile.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <cstdarg>
@@ -49,6 +50,7 @@ int fail(int code, const char *fmt, ...) {
 // Sequences of 32768 residues and more take the reference's wrapped-diagonal path in the prefilter (16-bit index positions and
 // diagonals, UngappedAlignment::computeLongScore); the alignment kernels number target columns in 17 bits.
 constexpr uint32_t MK_MAX_SEQ_LEN = 1u << 17;
+std::atomic<double> g_hitsPerQuery{0.0}, g_alnsPerQuery{0.0};   // results per query of the last finished search (sequence queries): sizes the next batch's result blocks
 
 bool g_ready = false;
 int g_device = -1;
@@ -927,6 +929,17 @@ static int queries_create(const uint8_t *residues, const uint8_t *devResidues, c
     t_stream = callerStream;
     mk::set_scratch_lane(callerLane);
     if (e != hipSuccess) { delete q; return fail(MK_ERR_DEVICE, "query upload failed: %s", hipGetErrorString(e)); }
+    // (round 6) the pinned blocks the results will land in are taken NOW, on the caller's thread: pinning is 0.3 ms per MB, and the search threads needed
+    // the blocks in the middle of a batch's first chunk -- 0.1 s of the first two batches of a command (`metaeuk-amd predictexons` prepares a batch while
+    // the previous one is searched, the first one beside the target index).  A guess -- 48 prefilter hits and 6 accepted alignments per query, 256 MB
+    // each at most -- that the stages enlarge when it is too small; the blocks come from and go back to the pool of result blocks
+    {
+        const double hpq = g_hitsPerQuery.load(), apq = g_alnsPerQuery.load();     // what the last finished search of this process returned per query
+        const size_t hb = hpq > 0 ? (size_t) ((double) n * hpq * 1.08) * sizeof(mk_hit) : std::min<size_t>((size_t) n * 48 * sizeof(mk_hit), (size_t) 256 << 20);
+        const size_t ab = apq > 0 ? (size_t) ((double) n * apq * 1.08) * sizeof(mk_alignment) : std::min<size_t>((size_t) n * 6 * sizeof(mk_alignment), (size_t) 256 << 20);
+        (void) q->hits.reserve(hb + 4096, 0);
+        (void) q->alns.reserve(ab + 4096, 0);
+    }
     *out = q;
     return MK_OK;
 }
@@ -1829,7 +1842,10 @@ int mk_search_wait(mk_queries *q) {
     }
     const int rc = job->rc;
     if (rc != MK_OK) g_err = job->err;
-    else { q->havePref = true; q->haveAln = true; }
+    else {
+        q->havePref = true; q->haveAln = true;
+        if (q->n > 0 && !q->isProfile) { g_hitsPerQuery.store((double) q->nHits / (double) q->n); g_alnsPerQuery.store((double) q->alnOff[q->n] / (double) q->n); }
+    }
     q->job = nullptr;
     delete job;
     return rc;

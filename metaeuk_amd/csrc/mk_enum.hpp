@@ -74,6 +74,44 @@ __device__ __forceinline__ void wave_deal_tail(uint32_t rem, int lane, uint8_t *
     }
 }
 
+// The same deal for the tails of U lists per lane at once (items in the order list group u, lane, entry -- the order the hits of a batch are numbered
+// in): one scan chain and one round of windows for the whole batch instead of one per group, and -- what matters to a kernel that lives on requests in
+// flight -- the caller gets the owner of a window's items BEFORE it touches memory, so it can issue the window's entry loads beside the first entries'.
+// An owner is named by id = u * 64 + lane.
+template <int U>
+struct TailDeal {
+    static_assert(U * WAVE <= 256, "owner ids are marked in bytes");
+    uint32_t excl[U], incl[U], total;
+    __device__ __forceinline__ void init(const uint32_t (&rem)[U]) {
+        uint32_t off = 0;
+#pragma unroll
+        for (int u = 0; u < U; u++) { const uint32_t sc = wave_incl_scan(rem[u]); incl[u] = off + sc; excl[u] = incl[u] - rem[u]; off += wave_last(sc); }
+        total = off;
+    }
+    // window [base, base + 64): the lane learns whose item it got (id), which entry of that list (e >= 1), and whether there is an item at all
+    __device__ __forceinline__ void window(uint32_t base, const uint32_t (&rem)[U], int lane, uint8_t *mark /* [64] per wave */, uint32_t &id, uint32_t &e, bool &valid) const {
+        mark[lane] = 0;
+        wave_sync_lds();
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (rem[u] && excl[u] < base + WAVE && incl[u] > base) mark[max(excl[u], base) - base] = (uint8_t) (u * WAVE + lane);
+        wave_sync_lds();
+        // the ranges ascend with the id, so the prefix maximum spreads an owner over its range; id 0 needs no mark of its own (an item of the window always
+        // has an owner at or before it, and the only owner "no mark" can stand for is the smallest)
+        id = wave_incl_max_scan(mark[lane]);
+        e = 1u + (base + (uint32_t) lane - pick(excl, id));
+        valid = base + (uint32_t) lane < total;
+        wave_sync_lds();
+    }
+    // v[u] of lane l for id = u * 64 + l
+    __device__ __forceinline__ static uint32_t pick(const uint32_t (&v)[U], uint32_t id) {
+        uint32_t r = wave_read_lane(v[0], id & 63u);
+#pragma unroll
+        for (int u = 1; u < U; u++) { const uint32_t x = wave_read_lane(v[u], id & 63u); if ((id >> 6) == (uint32_t) u) r = x; }
+        return r;
+    }
+};
+
 constexpr int AJ = 2;                    // first-half candidates per lane and step
 constexpr int ABLOCK = AJ * WAVE;        // ... per step (one step covers almost every position: the dependent-load chain
                                          // of a position is rows -> cumulative counts -> second-half indices -> index probes)

@@ -179,6 +179,52 @@ __device__ __forceinline__ uint64_t wave_read_lane64(uint64_t v, uint32_t srcLan
 }
 __device__ __forceinline__ bool kmer_present(const uint32_t *bits, uint32_t kmer) { return (bits[kmer >> 5] >> (kmer & 31u)) & 1u; }
 
+// The index probes of a batch of U * 64 k-mers, STAGE BY STAGE: the U presence words, then the U slots, then the U first entries of the longer lists are
+// issued together and waited for once.  (Rounds 2-5 wrote `if (has && present(kmer)) slot = load` inside the loop over u: the compiler turns that into
+// nested divergent regions with a `s_waitcnt vmcnt(0)` inside each, so the chains bitmap -> slot -> entry of the U groups ran one AFTER the other -- the
+// "probe groups" never were in flight together, which is also why U = 4 only made the kernel slower: profiles/r06_prefilter_probe_groups.txt.)
+// kmer[u] is 0 where has[u] is false (every enumerator's contract): the presence word is read without a branch.
+// what a lane without a probe reads: cell 0 of the slot table (the entry array of a small database may be empty)
+// (as an index into the entry array, so that the load stays a global one)
+__device__ __forceinline__ uint64_t idle_entry(const PrefilterDeviceView &V) { return (uint64_t) (V.kmer_slot - V.entries); }
+template <int U>
+__device__ __forceinline__ void probe_lists(const PrefilterDeviceView &V, const uint32_t (&kmer)[U], const bool (&has)[U], uint32_t (&size)[U], uint64_t (&o0)[U],
+                                            uint64_t (&ent0)[U], bool FIRST_ENTRIES = true) {
+    // No branch around a load: a lane without a probe reads cell 0 of the table (one more request per wave instruction, a line every wave shares) and drops
+    // the value.  Inside divergent regions the compiler cannot count the loads in flight at the join and waits for ALL of them before the next group's load.
+    uint32_t word[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) word[u] = V.kmer_bits[kmer[u] >> 5];
+    uint64_t s[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const bool present = ((word[u] >> (kmer[u] & 31u)) & (has[u] ? 1u : 0u)) != 0u;
+        const uint64_t v = ld_probe(V.kmer_slot + (present ? kmer[u] : 0u));
+        s[u] = present ? v : 0ull;
+    }
+    bool far[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {                       // (a slot is never 0: bit 63 marks the inline entry, a longer list has a length)
+        const bool isInline = (s[u] >> 63) != 0;
+        size[u] = isInline ? 1u : (uint32_t) (s[u] >> 40) & 0x7FFFFFu;
+        o0[u] = s[u] & 0xFFFFFFFFFFull;
+        ent0[u] = s[u] & 0x0000FFFFFFFFFFFFull;
+        far[u] = !isInline && s[u] != 0;
+    }
+    if (FIRST_ENTRIES) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            // (the lane mask passes through an empty asm: as a select on far[u] the compiler puts the load back under a branch)
+            uint32_t m = far[u] ? 0xFFFFFFFFu : 0u;
+            asm volatile("" : "+v"(m));
+            const uint64_t mm = ((uint64_t) m << 32) | m;
+            const uint64_t idle = idle_entry(V);
+            const uint64_t v = ld_probe(V.entries + (idle ^ ((o0[u] ^ idle) & mm)));
+            ent0[u] = (v & mm) | (ent0[u] & ~mm);
+        }
+    }
+}
+
 #ifndef MK_PROBE_U
 #define MK_PROBE_U 4
 #endif
@@ -231,18 +277,11 @@ __global__ __launch_bounds__(256) void probe_kernel(ProbeArgs A) {
             uint32_t size[PROBE_U];
             uint64_t o0[PROBE_U];
             uint64_t ent0[PROBE_U];
-            bool inl[PROBE_U];
-#pragma unroll
-            for (int u = 0; u < PROBE_U; u++) {
-                size[u] = 0; o0[u] = 0; ent0[u] = 0; inl[u] = true;
-                if (has[u] && kmer_present(A.V.kmer_bits, kmer[u])) { const KmerList l = load_kmer_list(A.V.kmer_slot, kmer[u]); o0[u] = l.first; size[u] = l.size; ent0[u] = l.ent0; inl[u] = l.isInline; }
-            }
+            probe_lists<PROBE_U>(A.V, kmer, has, size, o0, ent0, GATHER);
             if (!GATHER) {
 #pragma unroll
                 for (int u = 0; u < PROBE_U; u++) hits += size[u];
             } else {
-#pragma unroll
-                for (int u = 0; u < PROBE_U; u++) if (!inl[u]) ent0[u] = A.V.entries[o0[u]];
                 const auto put = [&](uint64_t ent, uint64_t at) {
                     const uint32_t seq = (uint32_t) ent;
                     const uint32_t posj = (uint32_t) (ent >> 32) & 0xFFFFu;
@@ -485,6 +524,31 @@ __global__ __launch_bounds__(256) void kmer_count_kernel(PrefilterDeviceView V, 
 
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 
+// Bitonic network over P keys in LDS (P a power of two) by the BLOCK threads of a workgroup.  Pair i of a stage belongs to thread i mod BLOCK, so a wave
+// owns the same 64 pairs in every stage -- and while the partners are at most 64 apart those pairs lie inside ONE 128-key block: the stages j = 64 .. 1 of
+// every merge need no workgroup barrier, only the wave's own LDS order (rounds 2-5 had a __syncthreads after each of the log P (log P + 1) / 2 stages: 21 for
+// the 64 k-mer starts of a short fragment, 66 for 2 048 survivors -- now 0 and 10).  The caller's writes are covered by the barrier of the first stage; the
+// network ends with a barrier.
+template <int BLOCK, bool DESCENDING, typename T>
+__device__ __forceinline__ void lds_bitonic_sort(T *key, uint32_t P, int tid) {
+    bool prevCross = true;
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            const bool cross = j > (uint32_t) WAVE;
+            if (cross || prevCross) __syncthreads(); else wave_sync_lds();
+            prevCross = cross;
+            for (uint32_t i = (uint32_t) tid; i < (P >> 1); i += BLOCK) {
+                const uint32_t l = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
+                const uint32_t r2 = l | j;
+                const T x = key[l], y = key[r2];
+                const bool up = (l & k) == 0;
+                if ((DESCENDING ? x < y : x > y) == up) { key[l] = y; key[r2] = x; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
 // =====================================================================================================
 //  A. per-query path: the index hits of a query pass through a workgroup-private region in HBM
 // =====================================================================================================
@@ -622,18 +686,7 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
         if (tid == 0) sNumOrder = 0;
         __syncthreads();
         // descending bitonic sort of the k-mer starts by cost (starts without k-mers, cost 0, come last)
-        for (uint32_t k = 2; k <= PO; k <<= 1) {
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t i = (uint32_t) tid; i < (PO >> 1); i += BLOCK) {
-                    const uint32_t l = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
-                    const uint32_t r2 = l | j;
-                    const uint32_t x = sOrdKey[l], y = sOrdKey[r2];
-                    const bool up = (l & k) == 0;
-                    if ((x < y) == up) { sOrdKey[l] = y; sOrdKey[r2] = x; }
-                }
-                __syncthreads();
-            }
-        }
+        lds_bitonic_sort<BLOCK, true>(sOrdKey, PO, tid);
         for (int k = tid; k < nOrd; k += BLOCK) {
             const uint32_t key = sOrdKey[k];
             sOrder[k] = (uint16_t) (key & 0xFFFu);
@@ -663,14 +716,7 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
                     uint32_t size[U], ex[U];
                     uint64_t o0[U];
                     uint64_t ent0[U];
-                    bool inl[U];
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        size[u] = 0; o0[u] = 0; ent0[u] = 0; inl[u] = true;
-                        if (has[u] && kmer_present(A.V.kmer_bits, kmer[u])) { const KmerList l = load_kmer_list(A.V.kmer_slot, kmer[u]); o0[u] = l.first; size[u] = l.size; ent0[u] = l.ent0; inl[u] = l.isInline; }
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; u++) if (!inl[u]) ent0[u] = ld_probe(A.V.entries + o0[u]);
+                    probe_lists<U>(A.V, kmer, has, size, o0, ent0);          // (the first entries of the longer lists are still in flight below)
                     uint32_t totAll = 0;
 #pragma unroll
                     for (int u = 0; u < U; u++) { const uint32_t incl = enumk::wave_incl_scan(size[u]); ex[u] = incl - size[u] + totAll; totAll += enumk::wave_last(incl); }
@@ -688,16 +734,29 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
                         const uint32_t bit = 1u << (hb & 31u);
                         if (atomicOr(&sBm1[hb >> 5], bit) & bit) atomicOr(&sBm2[hb >> 5], bit);
                     };
+                    // the further entries of the longer lists, one per lane: the first window's loads go out before the first entries are stored
+                    uint32_t rem[U], oLo[U], oHi[U];
 #pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        const uint32_t r0 = ex[u];
-                        if (size[u]) put(ent0[u], r0);
-                        enumk::wave_deal_tail(size[u] > 1 ? size[u] - 1 : 0u, lane, P1.mark[w], [&](uint32_t owner, uint32_t e, bool valid) {
-                            const uint64_t oFirst = wave_read_lane64(o0[u], owner);
-                            const uint32_t oR0 = enumk::wave_read_lane(r0, owner);
-                            if (valid) put(ld_probe(A.V.entries + oFirst + e), oR0 + e);
-                        });
-                    }
+                    for (int u = 0; u < U; u++) { rem[u] = size[u] > 1 ? size[u] - 1 : 0u; oLo[u] = (uint32_t) o0[u]; oHi[u] = (uint32_t) (o0[u] >> 32); }
+                    enumk::TailDeal<U> D;
+                    D.init(rem);
+                    const auto tail_of = [&](uint32_t tbase, uint64_t &ent, uint32_t &rel) -> bool {
+                        uint32_t id, e;
+                        bool valid;
+                        D.window(tbase, rem, lane, P1.mark[w], id, e, valid);
+                        const uint64_t oFirst = (uint64_t) enumk::TailDeal<U>::pick(oLo, id) | ((uint64_t) enumk::TailDeal<U>::pick(oHi, id) << 32);
+                        rel = enumk::TailDeal<U>::pick(ex, id) + e;
+                        ent = ld_probe(A.V.entries + (valid ? oFirst + e : idle_entry(A.V)));      // (no branch around the load: see probe_lists)
+                        return valid;
+                    };
+                    uint64_t tEnt = 0;
+                    uint32_t tRel = 0;
+                    bool tValid = false;
+                    if (D.total) tValid = tail_of(0, tEnt, tRel);
+#pragma unroll
+                    for (int u = 0; u < U; u++) if (size[u]) put(ent0[u], ex[u]);
+                    if (tValid) put(tEnt, tRel);
+                    for (uint32_t tbase = WAVE; tbase < D.total; tbase += WAVE) if (tail_of(tbase, tEnt, tRel)) put(tEnt, tRel);
                     wcount += totAll;
                     return true;
                 });
@@ -799,18 +858,7 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
             for (uint32_t s = nSurv + (uint32_t) tid; s < P; s += BLOCK) sKey[s] = ~0ull;
             __syncthreads();
             // ---- bitonic sort (keys are distinct: (target, rank) is unique)
-            for (uint32_t k = 2; k <= P; k <<= 1) {
-                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                    for (uint32_t i = (uint32_t) tid; i < (P >> 1); i += BLOCK) {
-                        const uint32_t l = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
-                        const uint32_t r2 = l | j;
-                        const uint64_t x = sKey[l], y = sKey[r2];
-                        const bool up = (l & k) == 0;
-                        if ((x > y) == up) { sKey[l] = y; sKey[r2] = x; }
-                    }
-                    __syncthreads();
-                }
-            }
+            lds_bitonic_sort<BLOCK, false>(sKey, P, tid);
             const unsigned long long tc1 = wall_clock64();
             // ---- the double-diagonal rule on the target runs -> flag bits
             for (uint32_t t0 = 0; t0 < P; t0 += BLOCK) {
@@ -1147,18 +1195,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
         if (tid == 0) sNumOrder = 0;
         __syncthreads();
         // descending bitonic sort of the k-mer starts by cost (starts without k-mers, cost 0, come last)
-        for (uint32_t k = 2; k <= PO; k <<= 1) {
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t i = (uint32_t) tid; i < (PO >> 1); i += BLOCK) {
-                    const uint32_t l = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
-                    const uint32_t r2 = l | j;
-                    const uint32_t x = sOrdKey[l], y = sOrdKey[r2];
-                    const bool up = (l & k) == 0;
-                    if ((x < y) == up) { sOrdKey[l] = y; sOrdKey[r2] = x; }
-                }
-                __syncthreads();
-            }
-        }
+        lds_bitonic_sort<BLOCK, true>(sOrdKey, PO, tid);
         for (int k = tid; k < nOrd; k += BLOCK) {
             const uint32_t key = sOrdKey[k];
             sOrder[k] = (uint16_t) (key & 0xFFFu);
@@ -1187,14 +1224,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
                     uint32_t size[U], ex[U];
                     uint64_t o0[U];
                     uint64_t ent0[U];
-                    bool inl[U];
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        size[u] = 0; o0[u] = 0; ent0[u] = 0; inl[u] = true;
-                        if (has[u] && kmer_present(A.V.kmer_bits, kmer[u])) { const KmerList l = load_kmer_list(A.V.kmer_slot, kmer[u]); o0[u] = l.first; size[u] = l.size; ent0[u] = l.ent0; inl[u] = l.isInline; }
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; u++) if (!inl[u]) ent0[u] = ld_probe(A.V.entries + o0[u]);
+                    probe_lists<U>(A.V, kmer, has, size, o0, ent0);          // (the first entries of the longer lists are still in flight below)
                     uint32_t totAll = 0;
 #pragma unroll
                     for (int u = 0; u < U; u++) { const uint32_t incl = enumk::wave_incl_scan(size[u]); ex[u] = incl - size[u] + totAll; totAll += enumk::wave_last(incl); }
@@ -1213,16 +1243,28 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
                             region[at] = Rec12{(uint32_t) rec, (uint32_t) (rec >> 32), wcount + rel};
                         } else over = true;
                     };
+                    uint32_t rem[U], oLo[U], oHi[U];
 #pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        const uint32_t r0 = ex[u];
-                        if (size[u]) put(ent0[u], r0);
-                        enumk::wave_deal_tail(size[u] > 1 ? size[u] - 1 : 0u, lane, P1.mark[w], [&](uint32_t owner, uint32_t e, bool valid) {
-                            const uint64_t oFirst = wave_read_lane64(o0[u], owner);
-                            const uint32_t oR0 = enumk::wave_read_lane(r0, owner);
-                            if (valid) put(ld_probe(A.V.entries + oFirst + e), oR0 + e);
-                        });
-                    }
+                    for (int u = 0; u < U; u++) { rem[u] = size[u] > 1 ? size[u] - 1 : 0u; oLo[u] = (uint32_t) o0[u]; oHi[u] = (uint32_t) (o0[u] >> 32); }
+                    enumk::TailDeal<U> D;
+                    D.init(rem);
+                    const auto tail_of = [&](uint32_t tbase, uint64_t &ent, uint32_t &rel) -> bool {
+                        uint32_t id, e;
+                        bool valid;
+                        D.window(tbase, rem, lane, P1.mark[w], id, e, valid);
+                        const uint64_t oFirst = (uint64_t) enumk::TailDeal<U>::pick(oLo, id) | ((uint64_t) enumk::TailDeal<U>::pick(oHi, id) << 32);
+                        rel = enumk::TailDeal<U>::pick(ex, id) + e;
+                        ent = ld_probe(A.V.entries + (valid ? oFirst + e : idle_entry(A.V)));      // (no branch around the load: see probe_lists)
+                        return valid;
+                    };
+                    uint64_t tEnt = 0;
+                    uint32_t tRel = 0;
+                    bool tValid = false;
+                    if (D.total) tValid = tail_of(0, tEnt, tRel);              // the first window's loads go out before the first entries are stored
+#pragma unroll
+                    for (int u = 0; u < U; u++) if (size[u]) put(ent0[u], ex[u]);
+                    if (tValid) put(tEnt, tRel);
+                    for (uint32_t tbase = WAVE; tbase < D.total; tbase += WAVE) if (tail_of(tbase, tEnt, tRel)) put(tEnt, tRel);
                     wcount += totAll;
                     if (__ballot(over) != 0ull) { dead = true; if (lane == 0) sOverflow = 1; return false; }   // a class is full: the global path takes the query
                     return true;
@@ -1456,18 +1498,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
                 for (uint32_t s = nSurv + (uint32_t) tid; s < P; s += BLOCK) sKey[s] = ~0ull;
                 __syncthreads();
                 // ---- bitonic sort (keys are distinct: (target, rank) is unique)
-                for (uint32_t k = 2; k <= P; k <<= 1) {
-                    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                        for (uint32_t i = (uint32_t) tid; i < (P >> 1); i += BLOCK) {
-                            const uint32_t l = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
-                            const uint32_t r2 = l | j;
-                            const uint64_t x = sKey[l], y = sKey[r2];
-                            const bool up = (l & k) == 0;
-                            if ((x > y) == up) { sKey[l] = y; sKey[r2] = x; }
-                        }
-                        __syncthreads();
-                    }
-                }
+                lds_bitonic_sort<BLOCK, false>(sKey, P, tid);
                 const unsigned long long ts1 = wall_clock64();
                 // ---- the double-diagonal rule on the target runs -> flag bits
                 for (uint32_t t0 = 0; t0 < P; t0 += BLOCK) {

@@ -7,7 +7,7 @@ NAME=$1; shift
 O=$R/tools/_variants
 mkdir -p $O
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fopenmp -ffp-contract=off -Wno-unused-value -Wno-unused-result"
-/opt/rocm/bin/hipcc $FLAGS "$@" -c $R/metaeuk_amd/csrc/mk_prefilter.hip -o $O/mk_prefilter_$NAME.o
+/opt/rocm/bin/hipcc $FLAGS "$@" -c $R/metaeuk_amd/csrc/${SRC:-mk_prefilter.hip} -o $O/mk_prefilter_$NAME.o
 OBJS=$(ls $R/metaeuk_amd/lib/obj/*.o | grep -v mk_prefilter.hip.o)
 /opt/rocm/bin/hipcc $FLAGS -shared $OBJS $O/mk_prefilter_$NAME.o -o $O/libmetaeuk_amd_$NAME.so
 rm -f $O/mk_prefilter_$NAME.o
