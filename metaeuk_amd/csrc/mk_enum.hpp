@@ -82,11 +82,18 @@ template <int U>
 struct TailDeal {
     static_assert(U * WAVE <= 256, "owner ids are marked in bytes");
     uint32_t excl[U], incl[U], total;
-    __device__ __forceinline__ void init(const uint32_t (&rem)[U]) {
-        uint32_t off = 0;
+    // rem = size - 1 of the non-empty lists; ex = the exclusive prefix of the sizes over (u, lane), totAll their sum: the prefix of rem is that of size less
+    // the number of non-empty lists before this one -- a ballot and a bit count, no second scan
+    __device__ __forceinline__ void init(const uint32_t (&size)[U], const uint32_t (&rem)[U], const uint32_t (&ex)[U], uint32_t totAll) {
+        uint32_t lists = 0;
 #pragma unroll
-        for (int u = 0; u < U; u++) { const uint32_t sc = wave_incl_scan(rem[u]); incl[u] = off + sc; excl[u] = incl[u] - rem[u]; off += wave_last(sc); }
-        total = off;
+        for (int u = 0; u < U; u++) {
+            const unsigned long long nz = __ballot(size[u] != 0u);
+            excl[u] = ex[u] - lists - __builtin_amdgcn_mbcnt_hi((uint32_t) (nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) nz, 0u));
+            incl[u] = excl[u] + rem[u];
+            lists += (uint32_t) __popcll(nz);
+        }
+        total = totAll - lists;
     }
     // window [base, base + 64): the lane learns whose item it got (id), which entry of that list (e >= 1), and whether there is an item at all
     __device__ __forceinline__ void window(uint32_t base, const uint32_t (&rem)[U], int lane, uint8_t *mark /* [64] per wave */, uint32_t &id, uint32_t &e, bool &valid) const {
@@ -125,6 +132,21 @@ struct EnumLds {
     uint32_t sec[WAVE];          // the 64 best second halves (cell_second of their address codes): fetched with the row heads, one dependent
                                  // load less for nearly every product (a first half rarely pairs with more than a few second halves)
 };
+
+// owner(x) of the U * 64 products of a window from the histogram of the inclusive prefixes: carry + inclusive prefix sum of cnt over the window.  A step has
+// at most ABLOCK candidates, so the counts of two 64-product groups are scanned as the halves of ONE register (a scan is 6 DPP adds).
+template <int U>
+__device__ __forceinline__ void window_owners(const uint32_t *cnt, int lane, uint32_t carry, uint32_t (&owner)[U]) {
+#pragma unroll
+    for (int u = 0; u + 1 < U; u += 2) {
+        const uint32_t sc = wave_incl_scan(cnt[u * WAVE + lane] | (cnt[(u + 1) * WAVE + lane] << 16));
+        const uint32_t tot = wave_last(sc);
+        owner[u] = carry + (sc & 0xFFFFu);
+        owner[u + 1] = carry + (tot & 0xFFFFu) + (sc >> 16);
+        carry += (tot & 0xFFFFu) + (tot >> 16);
+    }
+    if constexpr (U % 2 == 1) owner[U - 1] = carry + wave_incl_scan(cnt[(U - 1) * WAVE + lane]);
+}
 
 // Table cell of a k-mer = cell_first(address code of its first 3-mer) + cell_second(code of its second 3-mer); a code is tile << 6 | w
 // (mk_host.cpp: the tiled address order -- k-mers that differ by substitutions inside the residue quads share 128-byte lines)
@@ -187,19 +209,17 @@ __device__ __forceinline__ uint32_t enumerate_position(const PrefilterDeviceView
                 carry += (uint32_t) __popcll(__ballot(incl[j] < base));
             }
             wave_sync_lds();
-            uint32_t kmer[U];
+            uint32_t kmer[U], owner[U];
             bool has[U];
+            window_owners<U>(S.cnt, lane, carry, owner);
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const uint32_t x = base + (uint32_t) (u * WAVE + lane);
-                const uint32_t sc = wave_incl_scan(S.cnt[u * WAVE + lane]);
-                const uint32_t owner = carry + sc;
-                carry += wave_last(sc);
                 has[u] = x < total;
                 kmer[u] = 0;
                 if (has[u]) {
-                    const uint32_t b = x - S.start[owner];
-                    kmer[u] = S.idx0[owner] + (b < (uint32_t) WAVE ? S.sec[b] : cell_second(i1[b]));
+                    const uint32_t b = x - S.start[owner[u]];
+                    kmer[u] = S.idx0[owner[u]] + (b < (uint32_t) WAVE ? S.sec[b] : cell_second(i1[b]));
                 }
             }
             if (!onBatch(kmer, has)) return kmers;
@@ -278,19 +298,17 @@ __device__ __forceinline__ uint32_t enumerate7_position(const PrefilterDeviceVie
                 if (incl >= base && rel < (uint32_t) (U * WAVE)) atomicAdd(&S.cnt[rel], 1u);
                 uint32_t carry = (uint32_t) __popcll(__ballot(incl < base));
                 wave_sync_lds();
-                uint32_t kmer[U];
+                uint32_t kmer[U], owner[U];
                 bool has[U];
+                window_owners<U>(S.cnt, lane, carry, owner);
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     const uint32_t x = base + (uint32_t) (u * WAVE + lane);
-                    const uint32_t sc = wave_incl_scan(S.cnt[u * WAVE + lane]);
-                    const uint32_t owner = carry + sc;
-                    carry += wave_last(sc);
                     has[u] = x < total;
                     kmer[u] = 0;
                     if (has[u]) {
-                        const uint32_t c = x - S.start[owner];
-                        kmer[u] = S.idx0[owner] + (c < (uint32_t) WAVE ? S.sec[c] : 160000u * (uint32_t) V.num3[i2[c]]);
+                        const uint32_t c = x - S.start[owner[u]];
+                        kmer[u] = S.idx0[owner[u]] + (c < (uint32_t) WAVE ? S.sec[c] : 160000u * (uint32_t) V.num3[i2[c]]);
                     }
                 }
                 if (!onBatch(kmer, has)) return kmers;

@@ -739,7 +739,7 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
 #pragma unroll
                     for (int u = 0; u < U; u++) { rem[u] = size[u] > 1 ? size[u] - 1 : 0u; oLo[u] = (uint32_t) o0[u]; oHi[u] = (uint32_t) (o0[u] >> 32); }
                     enumk::TailDeal<U> D;
-                    D.init(rem);
+                    D.init(size, rem, ex, totAll);
                     const auto tail_of = [&](uint32_t tbase, uint64_t &ent, uint32_t &rel) -> bool {
                         uint32_t id, e;
                         bool valid;
@@ -1247,7 +1247,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
 #pragma unroll
                     for (int u = 0; u < U; u++) { rem[u] = size[u] > 1 ? size[u] - 1 : 0u; oLo[u] = (uint32_t) o0[u]; oHi[u] = (uint32_t) (o0[u] >> 32); }
                     enumk::TailDeal<U> D;
-                    D.init(rem);
+                    D.init(size, rem, ex, totAll);
                     const auto tail_of = [&](uint32_t tbase, uint64_t &ent, uint32_t &rel) -> bool {
                         uint32_t id, e;
                         bool valid;
