@@ -590,6 +590,7 @@ def main():
         if args.two_calls or args.blocking:
             for k in range(n):
                 res = step(keep=(keep_last and k == n - 1))
+                step_counts.append(res)
             return res
         pending = []
         for k in range(n):
@@ -597,12 +598,14 @@ def main():
             api.search_begin(db, q)
             pending.append(q)
             if len(pending) >= max(1, args.queue_depth):
-                collect(pending.pop(0))
+                step_counts.append(collect(pending.pop(0)))
         while pending:
             q = pending.pop(0)
             res = collect(q, keep=keep_last and not pending)
+            step_counts.append(res)
         return res
 
+    step_counts = []           # (hits, alignments) of every step, warm-up included: the same input every step, so the counts must not move
     run_steps(args.warmup, False)
     api.kernel_stats(reset=True)
     barrier()
@@ -675,6 +678,7 @@ def main():
         "gcups_sw": gcups_total,
         "gcups_sw_kernel_only": (cells_sw / max(sw_ms * 1e-3, 1e-12) / 1e9) if sw_ms else None,      # (kernel durations summed: overlapping launches count twice)
         "prefilter_hits": nhits, "alignments_passed": npass,
+        "steps_with_other_counts": sum(1 for c in step_counts if c != (nhits, npass)),      # every step searches the same batch: 0, or a race
         "setup_s": {"generate": round(t_gen, 2), "target_index_build_upload": round(t_index, 2), "target_from_index_db": bool(args.target_index)},
         "host": {"threads": int(api.lib().mk_host_threads()) if not os.environ.get("OMP_NUM_THREADS") else int(os.environ["OMP_NUM_THREADS"]),
                  "max_rss_mb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1024.0, 1)},

@@ -190,6 +190,16 @@ __device__ __forceinline__ uint64_t idle_entry(const PrefilterDeviceView &V) { r
 template <int U>
 __device__ __forceinline__ void probe_lists(const PrefilterDeviceView &V, const uint32_t (&kmer)[U], const bool (&has)[U], uint32_t (&size)[U], uint64_t (&o0)[U],
                                             uint64_t (&ent0)[U], bool FIRST_ENTRIES = true) {
+#if MK_BISECT_OLD_PROBES
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        size[u] = 0; o0[u] = 0; ent0[u] = 0;
+        bool inl = true;
+        if (has[u] && kmer_present(V.kmer_bits, kmer[u])) { const KmerList l = load_kmer_list(V.kmer_slot, kmer[u]); o0[u] = l.first; size[u] = l.size; ent0[u] = l.ent0; inl = l.isInline; }
+        if (FIRST_ENTRIES && !inl) ent0[u] = ld_probe(V.entries + o0[u]);
+    }
+    return;
+#endif
     // No branch around a load: a lane without a probe reads cell 0 of the table (one more request per wave instruction, a line every wave shares) and drops
     // the value.  Inside divergent regions the compiler cannot count the loads in flight at the join and waits for ALL of them before the next group's load.
     uint32_t word[U];
@@ -225,6 +235,15 @@ __device__ __forceinline__ void probe_lists(const PrefilterDeviceView &V, const 
     }
 }
 
+#ifndef MK_BISECT_OLD_PROBES
+#define MK_BISECT_OLD_PROBES 0
+#endif
+#ifndef MK_BISECT_INLINE_SORT
+#define MK_BISECT_INLINE_SORT 0
+#endif
+#ifndef MK_BISECT_OLD_TAILS
+#define MK_BISECT_OLD_TAILS 0
+#endif
 #ifndef MK_PROBE_U
 #define MK_PROBE_U 4
 #endif
@@ -525,18 +544,24 @@ __global__ __launch_bounds__(256) void kmer_count_kernel(PrefilterDeviceView V, 
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 
 // Bitonic network over P keys in LDS (P a power of two) by the BLOCK threads of a workgroup.  Pair i of a stage belongs to thread i mod BLOCK, so a wave
-// owns the same 64 pairs in every stage -- and while the partners are at most 64 apart those pairs lie inside ONE 128-key block: the stages j = 64 .. 1 of
-// every merge need no workgroup barrier, only the wave's own LDS order (rounds 2-5 had a __syncthreads after each of the log P (log P + 1) / 2 stages: 21 for
-// the 64 k-mer starts of a short fragment, 66 for 2 048 survivors -- now 0 and 10).  The caller's writes are covered by the barrier of the first stage; the
-// network ends with a barrier.
+// owns the same 64 pairs in every stage -- and while the partners are at most 64 apart those pairs lie inside ONE 128-key block: between two such stages
+// the wave's own LDS order is enough; a workgroup barrier follows a stage only when it or the next one crosses the blocks (rounds 2-5 had a __syncthreads
+// after each of the log P (log P + 1) / 2 stages: 21 for the 64 k-mer starts of a short fragment, 66 for 2 048 survivors -- now 1 and 11).
+// The barrier stands BEHIND the stage's loop and is preceded by an explicit s_waitcnt: with __syncthreads() at the HEAD of the stage loop this compiler
+// (ROCm 7.2) drops the wait for the ds_writes that reach the barrier over the back edge -- `s_barrier` with LDS writes of the previous stage still in
+// flight, a few wrong candidates per 2 * 10^6 queries, different ones every run (profiles/r06_barrier_at_loop_head.txt).
+__device__ __forceinline__ void workgroup_sync_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+#ifndef MK_SORT_ALWAYS_BARRIER
+#define MK_SORT_ALWAYS_BARRIER 0     // 1: a workgroup barrier after every stage (the form of rounds 2-5; experiments)
+#endif
 template <int BLOCK, bool DESCENDING, typename T>
 __device__ __forceinline__ void lds_bitonic_sort(T *key, uint32_t P, int tid) {
-    bool prevCross = true;
+    workgroup_sync_lds();                                        // the caller's keys
     for (uint32_t k = 2; k <= P; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            const bool cross = j > (uint32_t) WAVE;
-            if (cross || prevCross) __syncthreads(); else wave_sync_lds();
-            prevCross = cross;
             for (uint32_t i = (uint32_t) tid; i < (P >> 1); i += BLOCK) {
                 const uint32_t l = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
                 const uint32_t r2 = l | j;
@@ -544,9 +569,11 @@ __device__ __forceinline__ void lds_bitonic_sort(T *key, uint32_t P, int tid) {
                 const bool up = (l & k) == 0;
                 if ((DESCENDING ? x < y : x > y) == up) { key[l] = y; key[r2] = x; }
             }
+            const uint32_t jNext = j > 1u ? j >> 1 : k;           // partner distance of the next stage (the first one of the merge of 2 k keys: k)
+            const bool last = j == 1u && k == P;
+            if (MK_SORT_ALWAYS_BARRIER || last || j > (uint32_t) WAVE || jNext > (uint32_t) WAVE) workgroup_sync_lds(); else wave_sync_lds();
         }
     }
-    __syncthreads();
 }
 
 // =====================================================================================================
@@ -686,7 +713,22 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
         if (tid == 0) sNumOrder = 0;
         __syncthreads();
         // descending bitonic sort of the k-mer starts by cost (starts without k-mers, cost 0, come last)
+#if MK_BISECT_INLINE_SORT
+        for (uint32_t k = 2; k <= PO; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = (uint32_t) tid; i < (PO >> 1); i += BLOCK) {
+                    const uint32_t l = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
+                    const uint32_t r2 = l | j;
+                    const uint32_t x = sOrdKey[l], y = sOrdKey[r2];
+                    const bool up = (l & k) == 0;
+                    if ((x < y) == up) { sOrdKey[l] = y; sOrdKey[r2] = x; }
+                }
+                __syncthreads();
+            }
+        }
+#else
         lds_bitonic_sort<BLOCK, true>(sOrdKey, PO, tid);
+#endif
         for (int k = tid; k < nOrd; k += BLOCK) {
             const uint32_t key = sOrdKey[k];
             sOrder[k] = (uint16_t) (key & 0xFFFu);
@@ -735,6 +777,20 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
                         if (atomicOr(&sBm1[hb >> 5], bit) & bit) atomicOr(&sBm2[hb >> 5], bit);
                     };
                     // the further entries of the longer lists, one per lane: the first window's loads go out before the first entries are stored
+#if MK_BISECT_OLD_TAILS
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const uint32_t r0 = ex[u];
+                        if (size[u]) put(ent0[u], r0);
+                        enumk::wave_deal_tail(size[u] > 1 ? size[u] - 1 : 0u, lane, P1.mark[w], [&](uint32_t owner, uint32_t e, bool valid) {
+                            const uint64_t oFirst = wave_read_lane64(o0[u], owner);
+                            const uint32_t oR0 = enumk::wave_read_lane(r0, owner);
+                            if (valid) put(ld_probe(A.V.entries + oFirst + e), oR0 + e);
+                        });
+                    }
+                    wcount += totAll;
+                    return true;
+#endif
                     uint32_t rem[U], oLo[U], oHi[U];
 #pragma unroll
                     for (int u = 0; u < U; u++) { rem[u] = size[u] > 1 ? size[u] - 1 : 0u; oLo[u] = (uint32_t) o0[u]; oHi[u] = (uint32_t) (o0[u] >> 32); }
@@ -858,7 +914,22 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
             for (uint32_t s = nSurv + (uint32_t) tid; s < P; s += BLOCK) sKey[s] = ~0ull;
             __syncthreads();
             // ---- bitonic sort (keys are distinct: (target, rank) is unique)
+#if MK_BISECT_INLINE_SORT
+            for (uint32_t k = 2; k <= P; k <<= 1) {
+                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                    for (uint32_t i = (uint32_t) tid; i < (P >> 1); i += BLOCK) {
+                        const uint32_t l = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
+                        const uint32_t r2 = l | j;
+                        const uint64_t x = sKey[l], y = sKey[r2];
+                        const bool up = (l & k) == 0;
+                        if ((x > y) == up) { sKey[l] = y; sKey[r2] = x; }
+                    }
+                    __syncthreads();
+                }
+            }
+#else
             lds_bitonic_sort<BLOCK, false>(sKey, P, tid);
+#endif
             const unsigned long long tc1 = wall_clock64();
             // ---- the double-diagonal rule on the target runs -> flag bits
             for (uint32_t t0 = 0; t0 < P; t0 += BLOCK) {

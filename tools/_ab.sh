@@ -4,8 +4,12 @@ O=gpurun_out/$1; shift
 mkdir -p $O
 ARGS=${AB_ARGS:---steps 8 --warmup 3 --cpu-sample 0 --config4-profiles 0 --e2e-sample -1 --config5-targets 0 --blocking-steps 0}
 for v in "$@"; do
-  if [ $v = product ]; then unset METAEUK_AMD_LIB; else export METAEUK_AMD_LIB=$PWD/tools/_variants/libmetaeuk_amd_${v%%.*}.so; fi
-  python bench.py $ARGS > $O/bench_$v.json 2> $O/bench_$v.err
+  # name[.tag][@VAR=value[,VAR=value]]: environment of the run after the @
+  envs=""; case $v in *@*) envs=${v#*@}; v=${v%%@*};; esac
+  lib=${v%%.*}
+  if [ $lib = product ]; then unset METAEUK_AMD_LIB; else export METAEUK_AMD_LIB=$PWD/tools/_variants/libmetaeuk_amd_$lib.so; fi
+  v=$v${envs:+@$envs}
+  env $(echo $envs | tr "," " ") python bench.py $ARGS > $O/bench_$v.json 2> $O/bench_$v.err
   python - $O/bench_$v.json $v <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
