@@ -184,13 +184,29 @@ __device__ __forceinline__ bool kmer_present(const uint32_t *bits, uint32_t kmer
 // nested divergent regions with a `s_waitcnt vmcnt(0)` inside each, so the chains bitmap -> slot -> entry of the U groups ran one AFTER the other -- the
 // "probe groups" never were in flight together, which is also why U = 4 only made the kernel slower: profiles/r06_prefilter_probe_groups.txt.)
 // kmer[u] is 0 where has[u] is false (every enumerator's contract): the presence word is read without a branch.
+// the wide kernel (16 waves of 64 registers, 35-47 spills already) keeps the probe and tail code of rounds 2-5 unless these are set: measured below
+#ifndef MK_BISECT_OLD_PROBES
+#define MK_BISECT_OLD_PROBES 0
+#endif
+#ifndef MK_WIDE_STAGED_PROBES
+#define MK_WIDE_STAGED_PROBES 0
+#endif
+#ifndef MK_WIDE_MERGED_TAILS
+#define MK_WIDE_MERGED_TAILS 0
+#endif
+#ifndef MK_BISECT_INLINE_SORT
+#define MK_BISECT_INLINE_SORT 0
+#endif
+#ifndef MK_BISECT_OLD_TAILS
+#define MK_BISECT_OLD_TAILS 0
+#endif
 // what a lane without a probe reads: cell 0 of the slot table (the entry array of a small database may be empty)
 // (as an index into the entry array, so that the load stays a global one)
 __device__ __forceinline__ uint64_t idle_entry(const PrefilterDeviceView &V) { return (uint64_t) (V.kmer_slot - V.entries); }
-template <int U>
+template <int U, bool STAGED = true>
 __device__ __forceinline__ void probe_lists(const PrefilterDeviceView &V, const uint32_t (&kmer)[U], const bool (&has)[U], uint32_t (&size)[U], uint64_t (&o0)[U],
                                             uint64_t (&ent0)[U], bool FIRST_ENTRIES = true) {
-#if MK_BISECT_OLD_PROBES
+    if constexpr (!STAGED || MK_BISECT_OLD_PROBES) {           // the form of rounds 2-5 (the wide kernel keeps it: see MK_WIDE_STAGED_PROBES)
 #pragma unroll
     for (int u = 0; u < U; u++) {
         size[u] = 0; o0[u] = 0; ent0[u] = 0;
@@ -199,7 +215,7 @@ __device__ __forceinline__ void probe_lists(const PrefilterDeviceView &V, const 
         if (FIRST_ENTRIES && !inl) ent0[u] = ld_probe(V.entries + o0[u]);
     }
     return;
-#endif
+    }
     // No branch around a load: a lane without a probe reads cell 0 of the table (one more request per wave instruction, a line every wave shares) and drops
     // the value.  Inside divergent regions the compiler cannot count the loads in flight at the join and waits for ALL of them before the next group's load.
     uint32_t word[U];
@@ -235,15 +251,6 @@ __device__ __forceinline__ void probe_lists(const PrefilterDeviceView &V, const 
     }
 }
 
-#ifndef MK_BISECT_OLD_PROBES
-#define MK_BISECT_OLD_PROBES 0
-#endif
-#ifndef MK_BISECT_INLINE_SORT
-#define MK_BISECT_INLINE_SORT 0
-#endif
-#ifndef MK_BISECT_OLD_TAILS
-#define MK_BISECT_OLD_TAILS 0
-#endif
 #ifndef MK_PROBE_U
 #define MK_PROBE_U 4
 #endif
@@ -1295,7 +1302,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
                     uint32_t size[U], ex[U];
                     uint64_t o0[U];
                     uint64_t ent0[U];
-                    probe_lists<U>(A.V, kmer, has, size, o0, ent0);          // (the first entries of the longer lists are still in flight below)
+                    probe_lists<U, MK_WIDE_STAGED_PROBES != 0>(A.V, kmer, has, size, o0, ent0);
                     uint32_t totAll = 0;
 #pragma unroll
                     for (int u = 0; u < U; u++) { const uint32_t incl = enumk::wave_incl_scan(size[u]); ex[u] = incl - size[u] + totAll; totAll += enumk::wave_last(incl); }
@@ -1314,6 +1321,18 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
                             region[at] = Rec12{(uint32_t) rec, (uint32_t) (rec >> 32), wcount + rel};
                         } else over = true;
                     };
+#if !MK_WIDE_MERGED_TAILS
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const uint32_t r0 = ex[u];
+                        if (size[u]) put(ent0[u], r0);
+                        enumk::wave_deal_tail(size[u] > 1 ? size[u] - 1 : 0u, lane, P1.mark[w], [&](uint32_t owner, uint32_t e, bool valid) {
+                            const uint64_t oFirst = wave_read_lane64(o0[u], owner);
+                            const uint32_t oR0 = enumk::wave_read_lane(r0, owner);
+                            if (valid) put(ld_probe(A.V.entries + oFirst + e), oR0 + e);
+                        });
+                    }
+#else
                     uint32_t rem[U], oLo[U], oHi[U];
 #pragma unroll
                     for (int u = 0; u < U; u++) { rem[u] = size[u] > 1 ? size[u] - 1 : 0u; oLo[u] = (uint32_t) o0[u]; oHi[u] = (uint32_t) (o0[u] >> 32); }
@@ -1336,6 +1355,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
                     for (int u = 0; u < U; u++) if (size[u]) put(ent0[u], ex[u]);
                     if (tValid) put(tEnt, tRel);
                     for (uint32_t tbase = WAVE; tbase < D.total; tbase += WAVE) if (tail_of(tbase, tEnt, tRel)) put(tEnt, tRel);
+#endif
                     wcount += totAll;
                     if (__ballot(over) != 0ull) { dead = true; if (lane == 0) sOverflow = 1; return false; }   // a class is full: the global path takes the query
                     return true;
