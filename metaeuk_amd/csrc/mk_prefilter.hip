@@ -690,9 +690,24 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
     const uint32_t nOwn = A.own_count[0], ownFirst = A.own_first[0];
     const uint32_t nItems = nOwn + A.prev_count[0];
     constexpr uint64_t TMASK = (1ull << REC_T_BITS) - 1ull;
-    const auto survives = [&](uint64_t rec) -> bool {
+    // A record can take part in the double-diagonal rule when its target was hit twice (or its diagonal's low byte is 0: the first hit of a target is compared
+    // with 0).  Pass 1 knows "the target's BUCKET was hit twice" (sBm2): with 1 000 ... 10 000 hits in 8 192 ... 65 536 buckets 95 % of the records that pass are
+    // two targets sharing a bucket (round 6, MK_PREFILTER_DEBUG: 1.63e8 such records for 8.2e6 candidates in a chunk of the third tier) -- and they were
+    // SORTED, in several class passes once they exceeded the LDS sort.  Second round, over those records only and with an independent hash: the memory of the
+    // first bitmap (not needed after pass 1) becomes a once / twice pair of half the size; two hits of one target land in one bucket of both rounds, so no
+    // record the rule needs is lost, and of the chance pairs of round one 2-12 % survive round two.
+    constexpr int H2_BITS = LOG_MBITS - 1;
+    uint32_t *sBm3 = sBm1, *sBm4 = sBm1 + MBITS / 64;
+    const auto hit_twice = [&](uint64_t rec) -> bool {
         const uint32_t hb = ((uint32_t) (rec & TMASK) * 2654435761u) >> (32 - LOG_MBITS);
-        return ((sBm2[hb >> 5] >> (hb & 31u)) & 1u) || ((uint32_t) (rec >> REC_T_BITS) & 0xFFu) == 0u;
+        return ((sBm2[hb >> 5] >> (hb & 31u)) & 1u) != 0u;
+    };
+    const auto bucket2 = [&](uint64_t rec) -> uint32_t { return mix32((uint32_t) (rec & TMASK) ^ 0x9E3779B9u) >> (32 - H2_BITS); };
+    const auto survives = [&](uint64_t rec) -> bool {
+        if (((uint32_t) (rec >> REC_T_BITS) & 0xFFu) == 0u) return true;
+        if (!hit_twice(rec)) return false;
+        const uint32_t h2 = bucket2(rec);
+        return ((sBm4[h2 >> 5] >> (h2 & 31u)) & 1u) != 0u;
     };
     // target class of a record: a 24-bit hash scaled to the range (multiply and shift).  NOT `hash % n`: for operands the compiler can bound below 2^24
     // it emits a float-reciprocal division that returns remainder 0xFFFFFF where the true one is n - 1 (large numerators; n = 11, 44, 46, 57 ... on this
@@ -842,6 +857,18 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
         }
         const uint32_t used = sUsed;
         if (used == 0) continue;
+        // ---- second round of the target filter (see `survives`): the first bitmap's memory, cleared, takes the bucket pairs of the records that passed round one
+        for (int k = tid; k < MBITS / 32; k += BLOCK) sBm1[k] = 0;
+        __syncthreads();
+        for (uint32_t s = (uint32_t) tid; s < used; s += BLOCK) {
+            const uint64_t rec = region[s];
+            if (hit_twice(rec)) {
+                const uint32_t h2 = bucket2(rec);
+                const uint32_t bit = 1u << (h2 & 31u);
+                if (atomicOr(&sBm3[h2 >> 5], bit) & bit) atomicOr(&sBm4[h2 >> 5], bit);
+            }
+        }
+        __syncthreads();
         // arrival rank of a hit = hits of the earlier k-mer starts + its ordinal
         if (w == 0) {
             const uint32_t perLane = ((uint32_t) nStart + WAVE - 1) / WAVE;
@@ -861,6 +888,7 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
         __syncthreads();
         const uint32_t nSurvAll = sSurv;
         if (nSurvAll == 0) continue;
+        if (tid == 0) atomicAdd(&A.totals[10], (unsigned long long) nSurvAll);     // (statistics: survivors of the bucket filter; [11]: candidates)
         uint32_t nClasses = 1;
         if (nSurvAll > (uint32_t) SURV) {
             nClasses = (nSurvAll + (uint32_t) (SURV * 3 / 4) - 1) / (uint32_t) (SURV * 3 / 4);
@@ -976,7 +1004,7 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
                 uint32_t total;
                 uint32_t run = wave_excl_scan(sum, total);
                 for (uint32_t k = b; k < e; k++) { sWordPrefix[k] = run; run += (uint32_t) __popc(sFlagBits[k]); }
-                if (lane == 0) { sEmitBase = total ? atomicAdd(&A.counters[0], total) : 0u; sEmitCount = total; }
+                if (lane == 0) { sEmitBase = total ? atomicAdd(&A.counters[0], total) : 0u; sEmitCount = total; if (total) atomicAdd(&A.totals[11], (unsigned long long) total); }
             }
             __syncthreads();
             const uint32_t nEmit = sEmitCount, ebase = sEmitBase;
@@ -2889,8 +2917,8 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             if (knob("MK_PREFILTER_DEBUG"))
                 for (int t = 0; t < N_TIERS; t++) {
                     const unsigned long long *T = hFTotals + 16 * (t + 1);
-                    fprintf(stderr, "[prefilter]   tier %d (%s %d): queries %zu overflowed %llu | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g sort %.3g emit %.3g overflowed %.3g | extra class passes %llu\n",
-                            t, "region", tiers[t].cap, listed[t], T[8], (double) T[0], (double) T[1], (double) T[2], (double) T[3], (double) T[4], (double) T[5], (double) T[6], T[9]);
+                    fprintf(stderr, "[prefilter]   tier %d (%s %d): queries %zu overflowed %llu | kmers %.3g hits %.3g pos %.3g | wg-ticks gather %.3g sort %.3g emit %.3g overflowed %.3g | extra class passes %llu | survivors %.3g candidates %.3g\n",
+                            t, "region", tiers[t].cap, listed[t], T[8], (double) T[0], (double) T[1], (double) T[2], (double) T[3], (double) T[4], (double) T[5], (double) T[6], T[9], (double) T[10], (double) T[11]);
                 }
             const uint32_t nOvf = hCounters[4 + nTiersUsed - 1];               // what even the largest tier in use could not hold
             if (hCounters[0] > CAND_CAP) rc = RC_CAND_OVERFLOW;
