@@ -135,16 +135,8 @@ struct EnumLds {
 
 // owner(x) of the U * 64 products of a window from the histogram of the inclusive prefixes: carry + inclusive prefix sum of cnt over the window.  A step has
 // at most ABLOCK candidates, so the counts of two 64-product groups are scanned as the halves of ONE register (a scan is 6 DPP adds).
-#ifndef MK_BISECT_OLD_OWNERS
-#define MK_BISECT_OLD_OWNERS 0
-#endif
 template <int U>
 __device__ __forceinline__ void window_owners(const uint32_t *cnt, int lane, uint32_t carry, uint32_t (&owner)[U]) {
-#if MK_BISECT_OLD_OWNERS
-#pragma unroll
-    for (int u = 0; u < U; u++) { const uint32_t sc = wave_incl_scan(cnt[u * WAVE + lane]); owner[u] = carry + sc; carry += wave_last(sc); }
-    return;
-#endif
 #pragma unroll
     for (int u = 0; u + 1 < U; u += 2) {
         const uint32_t sc = wave_incl_scan(cnt[u * WAVE + lane] | (cnt[(u + 1) * WAVE + lane] << 16));

@@ -184,21 +184,15 @@ __device__ __forceinline__ bool kmer_present(const uint32_t *bits, uint32_t kmer
 // nested divergent regions with a `s_waitcnt vmcnt(0)` inside each, so the chains bitmap -> slot -> entry of the U groups ran one AFTER the other -- the
 // "probe groups" never were in flight together, which is also why U = 4 only made the kernel slower: profiles/r06_prefilter_probe_groups.txt.)
 // kmer[u] is 0 where has[u] is false (every enumerator's contract): the presence word is read without a branch.
-// the wide kernel (16 waves of 64 registers, 35-47 spills already) keeps the probe and tail code of rounds 2-5 unless these are set: measured below
-#ifndef MK_BISECT_OLD_PROBES
-#define MK_BISECT_OLD_PROBES 0
-#endif
+// Measured (one MI355X per call, base = the code of round 5 on the same box): third tier alone 274 -> 265 ms per step, beside the alignment stage 439 -> 420,
+// config-2 step 834 -> 822 ms; with U = 4 the kernel stays slower (559 ms): the fabric's request rate, not the requests in flight per wave, bounds it.
+// The wide kernel (16 waves of 64 registers, 35-47 spills already) keeps the probe and tail code of rounds 2-5 unless the two switches below are set: at
+// 60 M proteins the staged probes change nothing (2 049 against 2 043 ms per pass of 20 000 fragments) and the merged tails cost 7 % (2 180 ms, 45 spills).
 #ifndef MK_WIDE_STAGED_PROBES
 #define MK_WIDE_STAGED_PROBES 0
 #endif
 #ifndef MK_WIDE_MERGED_TAILS
 #define MK_WIDE_MERGED_TAILS 0
-#endif
-#ifndef MK_BISECT_INLINE_SORT
-#define MK_BISECT_INLINE_SORT 0
-#endif
-#ifndef MK_BISECT_OLD_TAILS
-#define MK_BISECT_OLD_TAILS 0
 #endif
 // what a lane without a probe reads: cell 0 of the slot table (the entry array of a small database may be empty)
 // (as an index into the entry array, so that the load stays a global one)
@@ -206,7 +200,7 @@ __device__ __forceinline__ uint64_t idle_entry(const PrefilterDeviceView &V) { r
 template <int U, bool STAGED = true>
 __device__ __forceinline__ void probe_lists(const PrefilterDeviceView &V, const uint32_t (&kmer)[U], const bool (&has)[U], uint32_t (&size)[U], uint64_t (&o0)[U],
                                             uint64_t (&ent0)[U], bool FIRST_ENTRIES = true) {
-    if constexpr (!STAGED || MK_BISECT_OLD_PROBES) {           // the form of rounds 2-5 (the wide kernel keeps it: see MK_WIDE_STAGED_PROBES)
+    if constexpr (!STAGED) {                                   // the form of rounds 2-5 (the wide kernel keeps it: see MK_WIDE_STAGED_PROBES)
 #pragma unroll
     for (int u = 0; u < U; u++) {
         size[u] = 0; o0[u] = 0; ent0[u] = 0;
@@ -735,22 +729,7 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
         if (tid == 0) sNumOrder = 0;
         __syncthreads();
         // descending bitonic sort of the k-mer starts by cost (starts without k-mers, cost 0, come last)
-#if MK_BISECT_INLINE_SORT
-        for (uint32_t k = 2; k <= PO; k <<= 1) {
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t i = (uint32_t) tid; i < (PO >> 1); i += BLOCK) {
-                    const uint32_t l = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
-                    const uint32_t r2 = l | j;
-                    const uint32_t x = sOrdKey[l], y = sOrdKey[r2];
-                    const bool up = (l & k) == 0;
-                    if ((x < y) == up) { sOrdKey[l] = y; sOrdKey[r2] = x; }
-                }
-                __syncthreads();
-            }
-        }
-#else
         lds_bitonic_sort<BLOCK, true>(sOrdKey, PO, tid);
-#endif
         for (int k = tid; k < nOrd; k += BLOCK) {
             const uint32_t key = sOrdKey[k];
             sOrder[k] = (uint16_t) (key & 0xFFFu);
@@ -799,20 +778,6 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
                         if (atomicOr(&sBm1[hb >> 5], bit) & bit) atomicOr(&sBm2[hb >> 5], bit);
                     };
                     // the further entries of the longer lists, one per lane: the first window's loads go out before the first entries are stored
-#if MK_BISECT_OLD_TAILS
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        const uint32_t r0 = ex[u];
-                        if (size[u]) put(ent0[u], r0);
-                        enumk::wave_deal_tail(size[u] > 1 ? size[u] - 1 : 0u, lane, P1.mark[w], [&](uint32_t owner, uint32_t e, bool valid) {
-                            const uint64_t oFirst = wave_read_lane64(o0[u], owner);
-                            const uint32_t oR0 = enumk::wave_read_lane(r0, owner);
-                            if (valid) put(ld_probe(A.V.entries + oFirst + e), oR0 + e);
-                        });
-                    }
-                    wcount += totAll;
-                    return true;
-#endif
                     uint32_t rem[U], oLo[U], oHi[U];
 #pragma unroll
                     for (int u = 0; u < U; u++) { rem[u] = size[u] > 1 ? size[u] - 1 : 0u; oLo[u] = (uint32_t) o0[u]; oHi[u] = (uint32_t) (o0[u] >> 32); }
@@ -949,22 +914,7 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
             for (uint32_t s = nSurv + (uint32_t) tid; s < P; s += BLOCK) sKey[s] = ~0ull;
             __syncthreads();
             // ---- bitonic sort (keys are distinct: (target, rank) is unique)
-#if MK_BISECT_INLINE_SORT
-            for (uint32_t k = 2; k <= P; k <<= 1) {
-                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                    for (uint32_t i = (uint32_t) tid; i < (P >> 1); i += BLOCK) {
-                        const uint32_t l = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
-                        const uint32_t r2 = l | j;
-                        const uint64_t x = sKey[l], y = sKey[r2];
-                        const bool up = (l & k) == 0;
-                        if ((x > y) == up) { sKey[l] = y; sKey[r2] = x; }
-                    }
-                    __syncthreads();
-                }
-            }
-#else
             lds_bitonic_sort<BLOCK, false>(sKey, P, tid);
-#endif
             const unsigned long long tc1 = wall_clock64();
             // ---- the double-diagonal rule on the target runs -> flag bits
             for (uint32_t t0 = 0; t0 < P; t0 += BLOCK) {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# config-4 and config-5 legs of bench.py for library variants on one box: tools/_ab45.sh <out dir> <variants...>
+# config-4 and config-5 legs of bench.py for library variants on one box: tools/ab_config45.sh <out dir> <variants...>
 O=gpurun_out/$1; shift; mkdir -p $O
 for v in "$@"; do
   if [ $v = product ]; then unset METAEUK_AMD_LIB; else export METAEUK_AMD_LIB=$PWD/tools/_variants/libmetaeuk_amd_$v.so; fi

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library variants on ONE box: tools/_ab.sh <out dir under gpurun_out> <variant names ...>   ("product" = the in-tree library)
+# A/B of library variants on ONE box: tools/ab_variants.sh <out dir under gpurun_out> <variant names ...>   ("product" = the in-tree library)
 O=gpurun_out/$1; shift
 mkdir -p $O
 ARGS=${AB_ARGS:---steps 8 --warmup 3 --cpu-sample 0 --config4-profiles 0 --e2e-sample -1 --config5-targets 0 --blocking-steps 0}

@@ -1,5 +1,5 @@
 """Run the prefilter (and the pipelined search) of the headline workload repeatedly and compare every run's hit list with the first run's.
-   python tools/_determinism.py [--runs N] [--search M]     (METAEUK_AMD_LIB selects a library variant)"""
+   python tools/determinism.py [--runs N] [--search M]     (METAEUK_AMD_LIB selects a library variant)"""
 import argparse, os, sys, hashlib
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
