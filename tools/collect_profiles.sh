@@ -11,7 +11,7 @@ mkdir -p $OUT
 cd $R
 # the HBM traffic of THIS build first: bench.py reads profiles/<tag>_pmc_hbm_traffic.json for roofline.traffic
 bash tools/pmc_traffic.sh $TAG > $OUT/pmc_traffic.log 2>&1; cp gpurun_out/pmc/${TAG}_pmc_hbm_traffic.json $OUT/ 2>/dev/null; cp gpurun_out/pmc/${TAG}_pmc_hbm_traffic.json profiles/ 2>/dev/null
-python bench.py --steps 5 --warmup 2 > $OUT/${TAG}_bench_n1.json 2> $OUT/bench.err
+python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench_n1.json 2> $OUT/bench.err
 X="--config4-profiles 0 --config5-targets 0 --alone-steps 0 --e2e-sample -1 --blocking-steps 0"
 [ -n "${QUICK:-}" ] || for th in 16 2; do MK_HOST_THREADS=$th python bench.py --steps 2 --warmup 1 --cpu-sample 0 $X 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.read());print('MK_HOST_THREADS=$th  ms_per_step %.1f  fragments/s %.0f  host phases (ms/step): %s' % (d['ms_per_step'], d['value'], {k: round(v / d['steps'], 1) for k, v in d['kernels_ms'].items() if k.startswith('host_')}))"; done > $OUT/${TAG}_bench_host_threads.txt
 python bench.py --steps 2 --warmup 1 --cpu-sample 0 --two-calls $X > $OUT/${TAG}_bench_two_calls.json 2>/dev/null
