@@ -251,6 +251,7 @@ __device__ __forceinline__ void count_round(const CountArgs &A, uint32_t s, uint
     bool dup = false;
     if (nStart <= 65536) {
         for (int j0 = 0; j0 < i0 + CT && j0 < nStart; j0 += TJ) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (a barrier at a loop head gets its wait spelled out: profiles/r06_barrier_at_loop_head.txt)
             __syncthreads();
             for (int t = tid; t < TJ; t += CT) { const int j = j0 + t; sCell[t] = j < nStart ? cell_of<K>(seq + j, A.G) : INVALID_CELL; }
             __syncthreads();
@@ -266,6 +267,7 @@ __device__ __forceinline__ void count_round(const CountArgs &A, uint32_t s, uint
         // stored) and keeps the first, so beyond 65536 residues "first" means the smallest WRAPPED position -- every start is compared
         const uint32_t key = (((uint32_t) i & 0xFFFFu) << 16) | ((uint32_t) i >> 16);
         for (int j0 = 0; j0 < nStart; j0 += TJ) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (a barrier at a loop head gets its wait spelled out: profiles/r06_barrier_at_loop_head.txt)
             __syncthreads();
             for (int t = tid; t < TJ; t += CT) { const int j = j0 + t; sCell[t] = j < nStart ? cell_of<K>(seq + j, A.G) : INVALID_CELL; }
             __syncthreads();

@@ -709,7 +709,7 @@ __global__ __launch_bounds__(NW * 64, 8) void stream_kernel(StreamArgs A) {     
     // host model: tools/micro/urem24.hip, profiles/r05_lost_subset_root_cause.txt; tests/test_div24.py scans every kernel for the sequence)
     const auto class_of = [&](uint64_t rec, uint32_t n) -> uint32_t { return ((mix32((uint32_t) (rec & TMASK) ^ 0x85EBCA6Bu) >> 8) * n) >> 24; };
     for (;;) {
-        __syncthreads();                                  // the previous query's LDS is no longer read
+        workgroup_sync_lds();                             // the previous query's LDS is no longer read (a barrier at a loop head: with its own wait)
         if (tid == 0) sItem = atomicAdd(A.work_counter, 1u);
         __syncthreads();
         const uint32_t item = sItem;
@@ -1197,7 +1197,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
     // (subset / sub-class of a target = hash bits scaled to the range: multiply and shift, no division)
     const auto sub_of = [&](uint64_t rec, uint32_t nSub) -> uint32_t { return ((mix32((uint32_t) (rec & TMASK) + 0x9E3779B9u) >> 8) * nSub) >> 24; };
     for (;;) {
-        __syncthreads();                                  // the previous query's LDS is no longer read
+        workgroup_sync_lds();                             // the previous query's LDS is no longer read (a barrier at a loop head: with its own wait)
         if (tid == 0) {
             if (sRedoN > 0) { sCurPart = sRedo[--sRedoN]; sItem = 1; }     // a half of the part that has just filled a class (the query stays: sCurQ)
             else {
