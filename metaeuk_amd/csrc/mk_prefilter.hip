@@ -354,6 +354,11 @@ __global__ __launch_bounds__(256) void chunk_totals_kernel(const uint64_t *qOff,
     atomicMax(&totals[3], (unsigned long long) (endv - scan[b]));
 }
 
+// The "k-mers per position" statistic is a sum of per-query quotients: accumulated in units of 2^-24 with INTEGER atomics, so that the sum does not depend on
+// the order in which the waves arrive (a double atomicAdd made the printed statistic differ in its last digits from run to run)
+constexpr double KPP_UNIT = 16777216.0;
+__device__ __forceinline__ void kpp_add(double *cell, double v) { atomicAdd(reinterpret_cast<unsigned long long *>(cell), (unsigned long long) __double2ll_rn(v * KPP_UNIT)); }
+static inline double kpp_value(const void *cell) { unsigned long long u; std::memcpy(&u, cell, 8); return (double) u / KPP_UNIT; }
 // statistics: sum over the queries of a piece of (similar k-mers of the query) / (its length), in double, one atomic per wave
 __global__ __launch_bounds__(256) void kmers_per_pos_kernel(const uint64_t *qOff, uint32_t qFirst, uint32_t nq, uint64_t posBegin, const uint32_t *kmerCount, double *out) {
     const uint32_t ql = blockIdx.x * blockDim.x + threadIdx.x;
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(256) void kmers_per_pos_kernel(const uint64_t *qOff
         const uint32_t lo = (uint32_t) __shfl_xor((int) (uint32_t) __double_as_longlong(v), d, WAVE), hi = (uint32_t) __shfl_xor((int) (uint32_t) (__double_as_longlong(v) >> 32), d, WAVE);
         v += __longlong_as_double((long long) (((uint64_t) hi << 32) | lo));
     }
-    if ((threadIdx.x & (WAVE - 1)) == 0 && v != 0.0) atomicAdd(out, v);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && v != 0.0) kpp_add(out, v);
 }
 
 // first record of every query of a piece (+ the end): the exclusive hit scan at the query's first position
@@ -1030,7 +1035,7 @@ __global__ __launch_bounds__(256) void tier_classify_kernel(TierPlan T) {
             const uint32_t lo = (uint32_t) __shfl_xor((int) (uint32_t) __double_as_longlong(v), d, WAVE), hi = (uint32_t) __shfl_xor((int) (uint32_t) (__double_as_longlong(v) >> 32), d, WAVE);
             v += __longlong_as_double((long long) (((uint64_t) hi << 32) | lo));
         }
-        if ((threadIdx.x & (WAVE - 1)) == 0 && v != 0.0) atomicAdd(T.kpp, v);
+        if ((threadIdx.x & (WAVE - 1)) == 0 && v != 0.0) kpp_add(T.kpp, v);
     }
     __syncthreads();
     for (int k = threadIdx.x; k < TIER_BINS; k += 256) if (sHist[k]) atomicAdd(&T.hist[k], sHist[k]);
@@ -1387,7 +1392,7 @@ __global__ __launch_bounds__(NW * 64, 8) void wide_kernel(WideArgs A) {        /
             atomicAdd(&A.totals[0], (unsigned long long) km);
             atomicAdd(&A.totals[1], (unsigned long long) hitsAll);
             atomicAdd(&A.totals[2], (unsigned long long) np);
-            if (MODE == W_MODE_ENUM7 && km != 0 && L > 0) atomicAdd(reinterpret_cast<double *>(&A.totals[11]), (double) km / (double) L);
+            if (MODE == W_MODE_ENUM7 && km != 0 && L > 0) kpp_add(reinterpret_cast<double *>(&A.totals[11]), (double) km / (double) L);
         }
         if (hitsAll == 0) continue;
         // arrival rank of a hit = hits of the earlier k-mer starts + its ordinal
@@ -2188,7 +2193,7 @@ int global_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hO
                 hipLaunchKernelGGL(kmers_per_pos_kernel, dim3((q1 - q0 + 255) / 256), dim3(256), 0, stream, V.q_off, q0, q1 - q0, hOff[q0], dKmer, dSum);
                 PCHK(hipMemcpyAsync(&hSum, dSum, 8, hipMemcpyDeviceToHost, stream));
                 PCHK(sync_wait(stream, "wait_prefilter"));
-                X.stats->kmers_per_pos += hSum;
+                X.stats->kmers_per_pos += kpp_value(&hSum);
             }
         }
         if (nPos > 0 && totalHits > 0) {
@@ -2605,7 +2610,7 @@ int wide_candidates(Ctx &X, const PrefilterDeviceView &Vin, const uint64_t *hOff
                 X.ts(th, 16.0 * (double) hTot[0] + 6.0 * (double) hTot[1], (double) hTot[0]);
                 nCand = hCtr[0];
                 dbMatchesDone += hTot[1];
-                if (k7enum) { double sumK; std::memcpy(&sumK, &hTot[11], 8); kmersPerPosDone += sumK; }
+                if (k7enum) kmersPerPosDone += kpp_value(&hTot[11]);
                 unitsDone += (double) (k7enum ? hTot[2] : hTot[0]); hitsDone += (double) hTot[1];
                 const uint32_t nOvf = hCtr[4];
                 itemQ.clear(); itemPart.clear();
@@ -2861,7 +2866,7 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
             size_t listed[N_TIERS];
             for (int t = 0; t < N_TIERS; t++) listed[t] = hInfo[4 + t];
             const uint32_t nFallback = hInfo[8];
-            if (hooks.stats) { double sum; std::memcpy(&sum, hTier + 16, 8); cs.kmers_per_pos += sum; }
+            if (hooks.stats) cs.kmers_per_pos += kpp_value(hTier + 16);
             for (int k = 0; k < 16; k++) { hFTotals[k] = 0; for (int t = 0; t < N_TIERS; t++) hFTotals[k] += hFTotals[16 * (t + 1) + k]; }
             cs.db_matches += hFTotals[1];
             if (knob("MK_PREFILTER_DEBUG"))
