@@ -11,9 +11,12 @@ ap.add_argument("--runs", type=int, default=12)
 ap.add_argument("--search", type=int, default=4)
 ap.add_argument("--contigs", type=int, default=10000)
 ap.add_argument("--targets", type=int, default=100000)
+ap.add_argument("--k7", action="store_true", help="k = 7 forced: every query through the wide per-query kernel (what a 60 M-protein database takes)")
 a = ap.parse_args()
 api.init(0)
 params = api.default_params()
+if a.k7:
+    params.kmer_size = 7
 targets, queries, _ = bench.make_inputs(a.contigs, a.targets, 11, 0)
 t_res, t_off = bench.pack(targets)
 q_res, q_off = bench.pack(queries)
