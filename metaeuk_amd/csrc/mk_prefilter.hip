@@ -2832,6 +2832,10 @@ int run_prefilter(const PrefilterDeviceView &V, const std::vector<uint64_t> &qOf
                     if (!cus) { int dev = 0; (void) hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
                     int perCu = tiers[t].wgPerCu;
                     if (hooks.co_resident) perCu = std::max(1, tiers[t].waves * perCu > 16 ? 16 / tiers[t].waves : perCu);   // at most 16 waves per CU
+                    // ... and 8 for the one-wave tiers (round 6, profiles/r06_small_tier_occupancy.txt): their ~50 ms per step hardly depend on the number of
+                    // workgroups (56 / 50 / 48 ms with 4 / 8 / 16 per CU: each wave walks its queries through chains of dependent loads), but what they occupy is
+                    // taken from the alignment stage, whose backlog then meets the third tier: step 819 -> 792 ms with 8 instead of 16
+                    if (hooks.co_resident && tiers[t].waves == 1) perCu = std::min(perCu, 8);
                     if (const char *e = knob(t == 2 ? "MK_PREFILTER_WG_PER_CU_A" : (t == 3 ? "MK_PREFILTER_WG_PER_CU_B" : "MK_PREFILTER_WG_PER_CU_S"))) perCu = std::max(1, atoi(e));
                     const unsigned launch = (unsigned) std::min<size_t>((size_t) nqc, (size_t) cus * perCu);     // (a chunk has at most nqc queries for any tier)
                     char pn[32];
