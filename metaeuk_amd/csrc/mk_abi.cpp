@@ -307,7 +307,8 @@ struct mk_queries {
     mk::PrefilterStats pfStats;      // run statistics of the prefilter over this batch (Prefiltering.cpp:889-904)
     mk::HostBlock alns; std::vector<uint64_t> alnOff; bool haveAln = false;
     struct SearchJob *job = nullptr; // mk_search_begin: the search in flight over this batch (mk_search_wait clears it)
-    mk_queries() { dRes.pooled = dOff.pooled = dKmerThr.pooled = dCorr.pooled = dBias8.pooled = true; }
+    // (the profile images too -- ADVICE round 5: a hipFree of theirs in mk_queries_destroy synchronised the device under the batch in flight)
+    mk_queries() { dRes.pooled = dOff.pooled = dKmerThr.pooled = dCorr.pooled = dBias8.pooled = dProfSorted.pooled = dProfAln.pooled = true; }
 };
 
 // the alignment stage's score tables for batch q (e-value per query length and score, the gate), from the database's cache.  A snapshot
